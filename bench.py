@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""
+bench.py -- BASELINE.json's metric: megapixels/s decoded (dequantize+IDCT -> h2v2 up-sample -> RGB)
+on synthetic 4096x4096 4:2:0 baseline frames, coefficient planes resident in HBM, plus the achieved
+HBM GB/s of the fused kernel against the MI355X roofline and the CPU baseline timed beside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path (one launch of the fused kernel) over a batch of B frames per GPU.
+B defaults to 16 so one step moves 1.6 GB, far more than the 256 MiB Infinity Cache.  Frames are
+image-sharded across ranks with no data-path collective (weak scaling); RCCL is used only for the
+barrier, the MAX over ranks and the trivial gather of per-rank checksums after the timed region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+W = H = 4096
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_PX = 6.0               # 3 B coefficients read + 3 B RGB written per pixel
+
+
+def cpu_baseline(planes, qts, budget_s=12.0):
+    """The oracle (kind "port": scalar C restatement of the reference's scalar arms), one thread, on
+    whole 4096x4096 4:2:0 frames until ~budget_s of CPU work.  Checker/baseline only -- never on
+    the product path."""
+    import oracle_c as oc
+    f = oc.make_frame(W, H, 2, 2, 3, oc.RGB, qts)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        rc, _ = oc.decode_planes(f, planes)
+        assert rc == 0
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 64:
+            break
+    return {"value": round(n * W * H / 1e6 / dt, 2), "unit": "megapixels/s", "cores": 1, "kind": "port",
+            "sample": f"{n} x 4096x4096 4:2:0 frame(s), scalar C restatement (oracle/zj_oracle.c), 1 thread, {dt:.1f} s"}
+
+
+def load_traffic():
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary (tools/pmc_summary.py), or None."""
+    p = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        return json.load(open(p))
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=16, help="4096x4096 frames per GPU per step")
+    ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic frames generated (tiled to --frames)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch  # before libzjhip: both bind the same libamdhip64.so.7
+    zj = importlib.import_module("zune-jpeg_amd")
+    synth = importlib.import_module("zune-jpeg_amd.synth")
+    shard = importlib.import_module("zune-jpeg_amd.shard")
+
+    rank, local_rank, world = shard.env_world()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    shard.init_process_group("nccl", rank, world)
+
+    B = args.frames
+    ctx = zj.Context(zj.BACKEND_HIP, local_rank)
+    # synthetic data, SURVEY.md 8d generator; every rank decodes its own shard of the global batch
+    lo, _ = shard.shard_range(B * world, rank, world)
+    frames = [synth.make_frame(W, H, 2, 2, 3, seed=1234, frame_index=(lo + i) % max(args.distinct, 1))
+              for i in range(min(args.distinct, B))]
+    qts = frames[0][1]
+    desc = zj.FrameDesc.make(W, H, 2, 2, 3, zj.ColorSpace.RGB, qts)
+    host = [np.concatenate([frames[i % len(frames)][0][c] for i in range(B)]) for c in range(3)]
+    d_planes = [torch.from_numpy(h).to(dev) for h in host]
+    d_out = torch.empty(B * W * H * 3, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    ptrs = [t.data_ptr() for t in d_planes] + [d_out.data_ptr()]
+
+    def step():
+        ctx.decode_planes_device(desc, B, ptrs[0], ptrs[1], ptrs[2], ptrs[3], stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    shard.barrier(world)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    shard.barrier(world)
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, world, dev)
+
+    # dominant-kernel duration, HIP events recorded on the launch stream (outside the timed region)
+    kiters = max(10, min(args.steps, 50))
+    kms, kname = ctx.time_decode_device(desc, B, ptrs[0], ptrs[1], ptrs[2], ptrs[3], kiters, stream)
+    kernel_ms = kms / kiters
+    # trivial gather: per-rank checksum of frame 0 (all ranks decode the same synthetic seeds modulo shard)
+    torch.cuda.synchronize()
+    first = d_out[: W * H * 3].cpu().numpy()
+    sums = shard.gather_checksums([shard.frame_checksum(first)], world, dev)
+
+    if rank == 0:
+        mp_total = world * B * args.steps * W * H / 1e6
+        algo_bytes = B * W * H * BYTES_PER_PX
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        tr = load_traffic()
+        res = {
+            "metric": "megapixels/sec decoded (IDCT->RGB), 4K 4:2:0 baseline",
+            "value": round(mp_total / elapsed, 1),
+            "unit": "megapixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "i16 coefficients -> i32 fixed-point IDCT -> packed-i16 colour -> u8",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: 4096x4096 baseline 4:2:0, dequant+IDCT+h2v2+YCbCr->RGB, planes resident in HBM",
+                       "frames_per_gpu_per_step": B, "sharding": f"image-level x{world}, no data-path collective",
+                       "distinct_frames": len(frames)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": (tr or {}).get("hbm_bytes_per_launch"),
+                         "kernel": kname, "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": int(algo_bytes),
+                         "traffic_source": (tr or {}).get("source")},
+            # every rank's first frame is synthetic frame (rank*B) % distinct: identical data when B % distinct == 0
+            "checksums_equal_across_ranks": (len({tuple(s) for s in sums}) == 1) if (world > 1 and B % max(args.distinct, 1) == 0) else None,
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(frames[0][0], qts)
+        print(json.dumps(res), flush=True)
+    shard.barrier(world)
+    ctx.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,163 @@
+/*
+ * zjhip.h -- C ABI of libzjhip.so: zune-jpeg's post-entropy pixel path on MI355X (gfx950).
+ *
+ * The library replaces, for the `hip` arm of the reference's function-pointer dispatch, exactly
+ * the functions that sit behind these reference interfaces (paths relative to the zune-jpeg tree):
+ *
+ *   IDCTPtr            = fn(&[i16], &Aligned32<[i32;64]>, usize, usize, usize) -> Vec<i16>
+ *                        src/decoder.rs:56, chosen by choose_idct_func          src/idct.rs:40
+ *   UpSampler          = fn(&[i16], usize) -> Vec<i16>
+ *                        src/components.rs:14, chosen in Decoder::set_upsampling src/decoder.rs:468
+ *   ColorConvert16Ptr  = fn(&[i16;16], &[i16;16], &[i16;16], &mut [u8], &mut usize)
+ *                        src/decoder.rs:47, chosen by choose_ycbcr_to_rgb_convert_func
+ *                                                                         src/color_convert.rs:61
+ *   post_process(coeff, component_data, idct_func, color_convert_16, in_cs, out_cs, output, width)
+ *                        src/worker.rs:32, called per strip from src/mcu.rs:364 and
+ *                        src/mcu_prog.rs:214,228
+ *
+ * plus the frame/batch-level entry points the GPU actually wants (whole-image coefficient planes,
+ * the layout src/mcu_prog.rs:73-79 allocates; baseline strips concatenate to the same planes).
+ *
+ * Conventions: plain C types, caller-owned buffers, int status (0 = ZJ_OK, negative = error), no
+ * exceptions or aborts across the boundary.  Where the reference would panic (slice bounds,
+ * unwrap, assert!) the call returns ZJ_ERR_PANIC and leaves the output unspecified.  Results are
+ * bit-exact with the reference's SCALAR arms (ZuneJpegOptions::set_use_unsafe(false)).
+ * Everything runs on the GPU: there is no CPU fallback; without a usable HIP device every
+ * entry point that computes returns ZJ_ERR_NO_DEVICE.
+ *
+ * Thread safety: a zj_ctx owns one HIP stream and scratch buffers; use one ctx per (thread, device).
+ */
+#ifndef ZJHIP_H
+#define ZJHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZJ_ABI_VERSION 1
+
+/* ColorSpace, same order as src/misc.rs:88-106 */
+typedef enum zj_colorspace {
+    ZJ_CS_RGB = 0,
+    ZJ_CS_GRAYSCALE = 1,
+    ZJ_CS_YCBCR = 2,
+    ZJ_CS_CMYK = 3,
+    ZJ_CS_YCCK = 4,
+    ZJ_CS_RGBA = 5,
+    ZJ_CS_RGBX = 6
+} zj_colorspace;
+
+/* Arms of the reference's dispatch (src/idct.rs:40-61, src/upsampler.rs:82-112,
+ * src/color_convert.rs:61-107).  SCALAR and AVX2 stay in the host application (the Rust crate);
+ * this library implements only the HIP arm and reports ZJ_ERR_BACKEND for the others. */
+typedef enum zj_backend { ZJ_BACKEND_SCALAR = 0, ZJ_BACKEND_AVX2 = 1, ZJ_BACKEND_HIP = 2 } zj_backend;
+
+typedef enum zj_status {
+    ZJ_OK = 0,
+    ZJ_ERR_ARG = -1,         /* null pointer / inconsistent sizes */
+    ZJ_ERR_UNSUPPORTED = -2, /* valid for the reference, not implemented by this library */
+    ZJ_ERR_HIP = -3,         /* a HIP runtime call failed; see zj_last_error() */
+    ZJ_ERR_NOMEM = -4,
+    ZJ_ERR_PANIC = -5,       /* the reference would panic on these arguments */
+    ZJ_ERR_NO_DEVICE = -6,   /* no usable HIP device / kernels could not be loaded */
+    ZJ_ERR_BACKEND = -7      /* backend other than ZJ_BACKEND_HIP requested */
+} zj_status;
+
+/* The fields of `Components` (src/components.rs:18-43) the pixel path reads. */
+typedef struct zj_component {
+    size_t horizontal_sample;       /* components.rs:25 */
+    size_t vertical_sample;         /* components.rs:23 */
+    size_t width_stride;            /* components.rs:40; headers.rs:338 = h_samp * mcu_x * 8 */
+    int32_t quantization_table[64]; /* components.rs:33, natural order, values 0..255 */
+} zj_component;
+
+/* One frame of whole-image coefficient planes (src/mcu_prog.rs:62-79). */
+typedef struct zj_frame_desc {
+    uint32_t width, height;  /* pixels */
+    uint32_t h_max, v_max;   /* luma sampling factors: (1,1) (2,1) (1,2) (2,2); chroma is (1,1) */
+    uint32_t in_components;  /* 1 (grayscale JPEG) or 3 (YCbCr) */
+    int32_t out_colorspace;  /* ZJ_CS_RGB, ZJ_CS_GRAYSCALE or ZJ_CS_YCBCR */
+    int32_t qt[3][64];       /* per component, natural order, values 0..255 (8-bit DQT only,
+                                src/headers.rs:154-174) */
+} zj_frame_desc;
+
+typedef struct zj_ctx zj_ctx;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+int zj_abi_version(void);
+int zj_device_count(void);                              /* <0: zj_status */
+zj_ctx *zj_ctx_create(int backend, int device, int *status);
+void zj_ctx_destroy(zj_ctx *ctx);
+zj_ctx *zj_default_ctx(void);        /* lazily created ctx on device 0 (for fn-pointer shims) */
+const char *zj_strerror(int status);
+const char *zj_last_error(const zj_ctx *ctx);           /* detail of the last ZJ_ERR_HIP */
+
+/* ---- strip level: pointer-compatible with the reference's fn types (host buffers) ----------- */
+/* IDCTPtr, src/idct/scalar.rs:19 dequantize_and_idct_int(vector, qt_table, stride, samp_factors, v_samp) */
+int zj_idct_strip(zj_ctx *ctx, const int16_t *coeff, size_t n, const int32_t qt[64], size_t stride,
+                  size_t samp_factors, size_t v_samp, int16_t *out /* n */);
+/* UpSampler, src/upsampler/scalar.rs:5 / :64 / :148 (input, output_len) */
+int zj_upsample_h(zj_ctx *ctx, const int16_t *in, size_t n, int16_t *out, size_t out_len);
+int zj_upsample_v(zj_ctx *ctx, const int16_t *in, size_t n, int16_t *out, size_t out_len);
+int zj_upsample_hv(zj_ctx *ctx, const int16_t *in, size_t n, int16_t *out, size_t out_len);
+/* ColorConvert16Ptr, src/color_convert/scalar.rs:52 ycbcr_to_rgb_16_scalar(y, cb, cr, output, pos) */
+int zj_ycbcr_to_rgb16(zj_ctx *ctx, const int16_t y[16], const int16_t cb[16], const int16_t cr[16],
+                      uint8_t *out, size_t out_len, size_t *pos);
+/* post_process, src/worker.rs:32.  `out` must be zero-filled by the caller exactly as the
+ * reference's callers do (src/mcu.rs:222, src/mcu_prog.rs:176): bytes the reference never writes
+ * are left untouched. */
+int zj_post_process_strip(zj_ctx *ctx, const int16_t *const coeff[3], const size_t len[3],
+                          const zj_component comps[3], int in_cs, int out_cs, uint8_t *out,
+                          size_t out_len, size_t width);
+
+/* Function-pointer dispatch mirror of choose_idct_func & friends: returns the HIP arm. */
+typedef int (*zj_idct_fn)(zj_ctx *, const int16_t *, size_t, const int32_t *, size_t, size_t, size_t,
+                          int16_t *);
+typedef int (*zj_upsample_fn)(zj_ctx *, const int16_t *, size_t, int16_t *, size_t);
+typedef int (*zj_color_convert16_fn)(zj_ctx *, const int16_t *, const int16_t *, const int16_t *,
+                                     uint8_t *, size_t, size_t *);
+zj_idct_fn zj_choose_idct_func(int backend);                        /* src/idct.rs:40 */
+zj_upsample_fn zj_choose_upsample_func(int backend, int h_max, int v_max); /* decoder.rs:468 */
+zj_color_convert16_fn zj_choose_ycbcr_to_rgb_convert_func(int backend, int out_cs); /* color_convert.rs:61 */
+
+/* ---- frame / batch level -------------------------------------------------------------------- */
+size_t zj_plane_len(const zj_frame_desc *d, int comp); /* int16 elements; mcu_prog.rs:76 */
+size_t zj_out_len(const zj_frame_desc *d);             /* bytes = width*height*ncomp */
+int zj_num_components(int colorspace);                 /* misc.rs:113 */
+
+/* Host buffers; H2D copy, fused kernel(s), D2H copy, synchronous.  Output is fully written
+ * (including the bytes the reference leaves at their initial 0). */
+int zj_decode_planes(zj_ctx *ctx, const zj_frame_desc *d, const int16_t *y, const int16_t *cb,
+                     const int16_t *cr, uint8_t *out);
+/* nframes frames of identical geometry, planes and outputs contiguous frame after frame. */
+int zj_decode_planes_batch(zj_ctx *ctx, const zj_frame_desc *d, size_t nframes, const int16_t *y,
+                           const int16_t *cb, const int16_t *cr, uint8_t *out);
+/* Device-resident variant (kernel-only path used by bench.py): all pointers are device pointers
+ * on ctx's device, 16-byte aligned; frames contiguous.  Asynchronous on `stream` (a hipStream_t;
+ * NULL = the ctx stream).  The frame's quantisation tables are uploaded on first use per ctx and
+ * cached by value. */
+int zj_decode_planes_device(zj_ctx *ctx, const zj_frame_desc *d, size_t nframes,
+                            const int16_t *d_y, const int16_t *d_cb, const int16_t *d_cr,
+                            uint8_t *d_out, void *stream);
+/* Times `iters` back-to-back zj_decode_planes_device calls with HIP events recorded on the
+ * launch stream; returns total milliseconds and the name of the dominant kernel. */
+int zj_time_decode_device(zj_ctx *ctx, const zj_frame_desc *d, size_t nframes, const int16_t *d_y,
+                          const int16_t *d_cb, const int16_t *d_cr, uint8_t *d_out, void *stream,
+                          int iters, float *ms_total, const char **kernel_name);
+
+/* ---- memory helpers ------------------------------------------------------------------------- */
+void *zj_alloc_pinned(size_t bytes); /* hipHostMalloc; NULL on failure */
+void zj_free_pinned(void *p);
+void *zj_device_alloc(zj_ctx *ctx, size_t bytes);
+void zj_device_free(zj_ctx *ctx, void *p);
+int zj_memcpy_h2d(zj_ctx *ctx, void *dst, const void *src, size_t bytes);
+int zj_memcpy_d2h(zj_ctx *ctx, void *dst, const void *src, size_t bytes);
+int zj_sync(zj_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

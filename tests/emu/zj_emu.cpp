@@ -1,0 +1,60 @@
+// zj_emu.cpp -- CPU EMULATION of the HIP workgroup phases in zune-jpeg_amd/csrc/zj_device.h.
+//
+// TEST INFRASTRUCTURE ONLY: it lets the CPU test-suite (-m "not gpu") check the kernel's tile /
+// halo / tail indexing against the oracle without a GPU, by running phase_idct and phase_color for
+// every (workgroup, thread) sequentially with the barrier between them.  It is never linked into
+// libzjhip.so and nothing in the product path can reach it.
+#define ZJ_EMU 1
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../zune-jpeg_amd/csrc/zj_plan.h"
+
+using namespace zj;
+
+template <int HS, int VS, int OUT>
+static void run(const Params& p)
+{
+    using C = Cfg<HS, VS, OUT>;
+    std::vector<int16_t> lds_store(C::LDS_I16 + 8);
+    // 16-byte aligned like a real LDS allocation
+    int16_t* lds = (int16_t*)(((uintptr_t)lds_store.data() + 15) & ~(uintptr_t)15);
+    for (int bid = 0; bid < p.total_tiles; bid++) {
+        for (int i = 0; i < C::LDS_I16; i++) lds[i] = 0x7B7B; // poison: unwritten LDS must not matter
+        const TileId t = decode_tile(p, bid);
+        for (int tid = 0; tid < C::NT; tid++) phase_idct<C>(p, t, tid, lds);
+        /* __syncthreads() */
+        for (int tid = 0; tid < C::NT; tid++) phase_color<C, HS, VS, OUT>(p, t, tid, lds);
+    }
+}
+
+extern "C" int zje_threads_per_group(const zj_frame_desc* d)
+{
+    Plan pl;
+    int rc = make_plan(d, pl);
+    return rc ? rc : pl.nt;
+}
+
+extern "C" int zje_decode_planes(const zj_frame_desc* d, size_t nframes, const int16_t* y,
+                                 const int16_t* cb, const int16_t* cr, uint8_t* out, int zero_fill)
+{
+    Plan pl;
+    int rc = make_plan(d, pl);
+    if (rc) return rc;
+    if (!pl.fast) return ZJ_ERR_UNSUPPORTED;
+    Params p;
+    fill_params(d, pl, nframes, y, cb, cr, out, &d->qt[0][0], zero_fill, p);
+    if (zero_fill && pl.rows_covered < (int)d->height) // same remainder memset as zj_api.cpp
+        for (size_t f = 0; f < nframes; f++)
+            memset(out + f * pl.out_len + (size_t)pl.rows_covered * d->width * pl.ncomp_out, 0,
+                   (size_t)(d->height - pl.rows_covered) * d->width * pl.ncomp_out);
+#define ZJ_CASE(H, V, O) if (pl.hs == H && pl.vs == V && pl.out == O) { run<H, V, O>(p); return ZJ_OK; }
+    ZJ_CASE(1, 1, OUT_RGB) ZJ_CASE(1, 1, OUT_GRAY) ZJ_CASE(1, 1, OUT_YCBCR)
+    ZJ_CASE(2, 1, OUT_RGB) ZJ_CASE(2, 1, OUT_GRAY) ZJ_CASE(2, 1, OUT_YCBCR)
+    ZJ_CASE(1, 2, OUT_RGB) ZJ_CASE(1, 2, OUT_GRAY) ZJ_CASE(1, 2, OUT_YCBCR)
+    ZJ_CASE(2, 2, OUT_RGB) ZJ_CASE(2, 2, OUT_GRAY) ZJ_CASE(2, 2, OUT_YCBCR)
+#undef ZJ_CASE
+    return ZJ_ERR_UNSUPPORTED;
+}

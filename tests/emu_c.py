@@ -1,0 +1,38 @@
+"""ctypes binding of the CPU emulation of the HIP workgroup phases (tests/emu).  TEST ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(HERE, "emu", "libzjemu.so")
+        srcs = [os.path.join(HERE, "emu", "zj_emu.cpp"),
+                os.path.join(ROOT, "zune-jpeg_amd", "csrc", "zj_device.h"),
+                os.path.join(ROOT, "zune-jpeg_amd", "csrc", "zj_plan.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fno-strict-aliasing",
+                                   "-Wall", "-Wno-unknown-pragmas", "-o", so, srcs[0]])
+        _LIB = C.CDLL(so)
+    return _LIB
+
+
+def decode_planes(frame, planes, nframes=1, zero_fill=1, poison=0xAA):
+    """frame: any ctypes struct laid out like zj_frame_desc."""
+    arrs = [np.ascontiguousarray(p, np.int16) for p in planes]
+    while len(arrs) < 3:
+        arrs.append(np.zeros(8, np.int16))
+    w, h = frame.width, frame.height
+    ncomp = {0: 3, 1: 1, 2: 3}[frame.out_colorspace]
+    out = np.full(nframes * w * h * ncomp, poison, np.uint8)
+    rc = lib().zje_decode_planes(C.byref(frame), C.c_size_t(nframes), C.c_void_p(arrs[0].ctypes.data),
+                                 C.c_void_p(arrs[1].ctypes.data), C.c_void_p(arrs[2].ctypes.data),
+                                 C.c_void_p(out.ctypes.data), C.c_int(zero_fill))
+    return rc, out

@@ -1,0 +1,72 @@
+"""CPU, world_size 2 over gloo: the N>1 plumbing of bench.py (shard, barrier, MAX over ranks, trivial
+gather of checksums).  The per-rank 'decode' is the oracle here; on the GPU box it is libzjhip."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, nframes, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests"), os.path.join(root, "oracle")):
+        sys.path.insert(0, p)
+    import oracle_c as oc
+    shard = importlib.import_module("zune-jpeg_amd.shard")
+    synth = importlib.import_module("zune-jpeg_amd.synth")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    shard.init_process_group("gloo", rank, world)
+    lo, hi = shard.shard_range(nframes, rank, world)
+    sums = []
+    for i in range(lo, hi):
+        planes, qts = synth.make_frame(64, 32, 2, 2, 3, seed=500, frame_index=i)
+        rc, out = oc.decode_planes(oc.make_frame(64, 32, 2, 2, 3, oc.RGB, qts), planes)
+        assert rc == 0
+        sums.append(shard.frame_checksum(out))
+    shard.barrier(world)
+    elapsed = shard.max_over_ranks(1.0 + rank, world)
+    total = shard.sum_over_ranks(hi - lo, world)
+    pad = sums + [0] * (3 - len(sums))
+    allsums = shard.gather_checksums(pad, world)
+    q.put((rank, lo, hi, elapsed, total, allsums))
+
+
+def test_two_rank_shard_and_gather():
+    shard = importlib.import_module("zune-jpeg_amd.shard")
+    synth = importlib.import_module("zune-jpeg_amd.synth")
+    import oracle_c as oc
+    assert [shard.shard_range(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]
+    assert [shard.shard_range(1024, r, 8) for r in (0, 7)] == [(0, 128), (896, 1024)]
+    nframes, world = 5, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nframes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    expect = []
+    for i in range(nframes):
+        planes, qts = synth.make_frame(64, 32, 2, 2, 3, seed=500, frame_index=i)
+        rc, out = oc.decode_planes(oc.make_frame(64, 32, 2, 2, 3, oc.RGB, qts), planes)
+        expect.append(shard.frame_checksum(out))
+    for rank, lo, hi, elapsed, total, allsums in res:
+        assert elapsed == 2.0            # MAX over ranks
+        assert total == nframes          # every frame decoded exactly once
+        flat = allsums[0][:3] + allsums[1][:2]
+        assert flat == expect            # gathered checksums == single-process decode
+    assert len(set(expect)) == nframes

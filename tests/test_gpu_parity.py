@@ -1,0 +1,308 @@
+"""GPU parity tests: every call goes through the C ABI of libzjhip.so (include/zjhip.h) and is compared
+bit for bit with the oracle on the same seeded inputs.  Mirrors the reference's own unit tests
+(src/idct.rs:66-127 KATs, src/upsampler.rs:123-151 ramps) and integration sizes
+(tests/large_images.rs, tests/medium_images.rs)."""
+import glob
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_c as oc
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+MODES = {"none": (1, 1), "h": (2, 1), "v": (1, 2), "hv": (2, 2)}
+
+
+@pytest.fixture(scope="module")
+def zj():
+    return importlib.import_module("zune-jpeg_amd")
+
+
+@pytest.fixture(scope="module")
+def ctx(zj):
+    c = zj.Context(zj.BACKEND_HIP, 0)  # no GPU -> raises; nothing falls back to the CPU
+    yield c
+    c.close()
+
+
+def assert_same(out, exp, what):
+    if not np.array_equal(out, exp):
+        bad = np.nonzero(np.asarray(out).reshape(-1) != np.asarray(exp).reshape(-1))[0]
+        raise AssertionError(f"{what}: {bad.size} of {exp.size} values differ, first at {bad[:10]}")
+
+
+# ---- strip level: IDCTPtr ---------------------------------------------------------------------
+KAT = json.load(open(os.path.join(HERE, "golden", "idct_kat.json")))
+
+
+@pytest.mark.parametrize("name", ["zeroes", "max", "min"])
+def test_idct_reference_kat(ctx, name):
+    """src/idct.rs:66-127: test_zeroes / test_max / test_min"""
+    coeff = np.full(64, KAT[name]["coeff"], np.int16)
+    out = ctx.idct_strip(coeff, np.ones(64, np.int32), 8, 1, 1)
+    assert_same(out, np.array(KAT[name]["expected"], np.int16), name)
+
+
+def test_idct_golden_blocks(ctx):
+    z = np.load(os.path.join(HERE, "golden", "idct_blocks.npz"))
+    n = z["blocks"].shape[0]
+    out = ctx.idct_strip(z["blocks"].reshape(-1), z["qt"], 8 * n, 1, 1)
+    assert_same(out.reshape(8, n, 8).transpose(1, 0, 2), z["expected"], "idct_blocks")
+
+
+@pytest.mark.parametrize("kind", ["full", "sparse", "dc"])
+def test_idct_random_blocks_vs_oracle(ctx, kind):
+    rng = np.random.default_rng(17)
+    n = 100_000
+    if kind == "full":
+        b = rng.integers(-32768, 32768, size=(n, 64))
+    elif kind == "sparse":
+        b = rng.integers(-300, 301, size=(n, 64))
+        b[rng.random((n, 64)) < 0.8] = 0
+    else:
+        b = np.zeros((n, 64), np.int64)
+        b[:, 0] = rng.integers(-32768, 32768, size=n)
+    b = b.astype(np.int16).reshape(-1)
+    qt = rng.integers(1, 256, size=64).astype(np.int32)
+    rc, exp = oc.idct_strip(b, qt, 8 * n, 1, 1)
+    assert rc == 0
+    assert_same(ctx.idct_strip(b, qt, 8 * n, 1, 1), exp, kind)
+
+
+def test_idct_strip_geometry_and_panics(ctx, zj):
+    rng = np.random.default_rng(3)
+    qt = rng.integers(1, 64, size=64).astype(np.int32)
+    # 4:2:0 luma strip (stride 16*mcu_x, samp 4, v 1) and chroma strip (stride 8*mcu_x, samp 4, v 2)
+    for n, stride, samp, vs in ((4 * 2 * 24 * 64, 16 * 24, 4, 1), (2 * 24 * 64, 8 * 24, 4, 2), (40 * 64, 8 * 40 + 5, 1, 1)):
+        c = rng.integers(-200, 200, size=n).astype(np.int16)
+        rc, exp = oc.idct_strip(c, qt, stride, samp, vs)
+        if rc == 0:
+            assert_same(ctx.idct_strip(c, qt, stride, samp, vs), exp, (n, stride))
+        else:
+            with pytest.raises(zj.ZjError) as e:
+                ctx.idct_strip(c, qt, stride, samp, vs)
+            assert e.value.status == -5
+    with pytest.raises(zj.ZjError) as e:  # stride too small: reference panics on get_mut().unwrap()
+        ctx.idct_strip(np.zeros(128, np.int16), qt, 4096, 1, 1)
+    assert e.value.status == -5
+    assert ctx.idct_strip(np.zeros(0, np.int16), qt, 8, 1, 1).size == 0  # empty input
+
+
+# ---- strip level: UpSampler ---------------------------------------------------------------------
+def test_upsample_ramps_like_reference_tests(ctx):
+    """src/upsampler.rs:123-151 use ramps 0..128 and (0..1280).rev()"""
+    for inp in (np.arange(128), np.arange(1280)[::-1]):
+        inp = inp.astype(np.int16)
+        rc, exp = oc.upsample_h(inp, 2 * inp.size)
+        assert rc == 0
+        assert_same(ctx.upsample_horizontal(inp, 2 * inp.size), exp, "ramp")
+
+
+@pytest.mark.parametrize("n", [8, 24, 16 * 40, 32768, 65536 + 8])
+def test_upsamplers_vs_oracle(ctx, n):
+    rng = np.random.default_rng(n)
+    inp = rng.integers(-3968, 4224, size=n).astype(np.int16)
+    for name, fn, ofn, olen in (("h", ctx.upsample_horizontal, oc.upsample_h, 2 * n),
+                                ("v", ctx.upsample_vertical, oc.upsample_v, 2 * n),
+                                ("hv", ctx.upsample_hv, oc.upsample_hv, 4 * n)):
+        rc, exp = ofn(inp, olen)
+        assert rc == 0
+        assert_same(fn(inp, olen), exp, (name, n))
+
+
+def test_upsample_panics_and_odd_lengths(ctx, zj):
+    with pytest.raises(zj.ZjError) as e:
+        ctx.upsample_horizontal(np.zeros(2, np.int16), 16)  # "Too Short of a vector"
+    assert e.value.status == -5
+    with pytest.raises(zj.ZjError):
+        ctx.upsample_vertical(np.zeros(4, np.int16), 8)     # stride 0
+    rng = np.random.default_rng(9)
+    inp = rng.integers(-100, 100, size=50).astype(np.int16)
+    for olen in (100, 90, 60):  # output shorter than 2n: zip stops early, tail still written
+        rc, exp = oc.upsample_h(inp, olen)
+        assert rc == 0
+        assert_same(ctx.upsample_horizontal(inp, olen), exp, olen)
+
+
+# ---- strip level: ColorConvert16Ptr -------------------------------------------------------------
+def test_rgb16_vs_oracle(ctx, zj):
+    rng = np.random.default_rng(23)
+    for _ in range(20):
+        y, cb, cr = (rng.integers(-4100, 4400, size=16).astype(np.int16) for _ in range(3))
+        out = np.zeros(112, np.uint8)
+        exp = np.zeros(112, np.uint8)
+        pos = ctx.ycbcr_to_rgb_16(y, cb, cr, out, 16)
+        rc, epos = oc.ycbcr_to_rgb16(y, cb, cr, exp, 16)
+        assert rc == 0 and pos == epos == 64
+        assert_same(out, exp, "rgb16")
+    with pytest.raises(zj.ZjError) as e:
+        ctx.ycbcr_to_rgb_16(y, cb, cr, np.zeros(60, np.uint8), 13)  # "Slice to small cannot write"
+    assert e.value.status == -5
+
+
+# ---- post_process (one strip) -------------------------------------------------------------------
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("out_cs", [oc.RGB, oc.GRAYSCALE, oc.YCBCR])
+def test_post_process_strip_vs_oracle(ctx, zj, synth, mode, out_cs):
+    hs, vs = MODES[mode]
+    rows = 32 if (hs, vs) == (2, 2) else (16 if hs == 2 or vs == 2 else 8)
+    w = 320
+    mcu_x = w // (8 * hs)
+    for adversarial in (False, True):
+        mk = synth.make_adversarial_frame if adversarial else synth.make_frame
+        planes, qts = mk(w, rows, hs, vs, 3, seed=41)
+        ncomp = {oc.RGB: 3, oc.GRAYSCALE: 1, oc.YCBCR: 3}[out_cs]
+        exp = np.zeros(rows * w * ncomp, np.uint8)   # callers hand over zeroed chunks (mcu.rs:222)
+        assert oc.post_process(planes, oc.make_components(hs, vs, mcu_x, qts), oc.YCBCR, out_cs, exp, w) == 0
+        out = np.zeros(rows * w * ncomp, np.uint8)
+        comps = (zj.Component * 3)()
+        for c in range(3):
+            comps[c].horizontal_sample = hs if c == 0 else 1
+            comps[c].vertical_sample = vs if c == 0 else 1
+            comps[c].width_stride = (hs if c == 0 else 1) * mcu_x * 8
+            for k in range(64):
+                comps[c].quantization_table[k] = int(qts[c][k])
+        ctx.post_process(planes, comps, oc.YCBCR, out_cs, out, w)
+        assert_same(out, exp, (mode, out_cs, adversarial))
+
+
+def test_post_process_leaves_unwritten_bytes_untouched(ctx, zj, synth):
+    w, rows, hs, vs = 64, 32, 2, 2
+    planes, qts = synth.make_frame(w, rows, hs, vs, 3, seed=2)
+    comps = (zj.Component * 3)()
+    for c in range(3):
+        comps[c].horizontal_sample = hs if c == 0 else 1
+        comps[c].vertical_sample = vs if c == 0 else 1
+        comps[c].width_stride = (hs if c == 0 else 1) * 4 * 8
+        for k in range(64):
+            comps[c].quantization_table[k] = int(qts[c][k])
+    out = np.full(rows * w * 3, 0x77, np.uint8)
+    ctx.post_process(planes, comps, oc.YCBCR, oc.RGB, out, w)
+    assert (out.reshape(rows, 3 * w)[:, -16:] == 0x77).all()  # Q5/Q6: never written by the reference
+
+
+# ---- frame level --------------------------------------------------------------------------------
+GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "strip_*.npz")) +
+                glob.glob(os.path.join(HERE, "golden", "frame_*.npz")) +
+                glob.glob(os.path.join(HERE, "golden", "adversarial_*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_golden_fixtures(ctx, zj, path):
+    z = np.load(path)
+    d = zj.FrameDesc.make(int(z["width"]), int(z["height"]), int(z["h_max"]), int(z["v_max"]), 3,
+                          int(z["out_cs"]), list(z["qt"]))
+    assert_same(ctx.decode_planes(d, [z["y"], z["cb"], z["cr"]]), z["expected"], os.path.basename(path))
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("out_cs", [oc.RGB, oc.GRAYSCALE, oc.YCBCR])
+@pytest.mark.parametrize("wh", [(64, 64), (528, 40), (32, 8), (1040, 33), (1920, 1080)])
+def test_decode_planes_vs_oracle(ctx, zj, synth, mode, out_cs, wh):
+    hs, vs = MODES[mode]
+    w, h = wh
+    for adversarial in (False, True):
+        if adversarial and w * h > 600_000:
+            continue
+        mk = synth.make_adversarial_frame if adversarial else synth.make_frame
+        planes, qts = mk(w, h, hs, vs, 3, seed=61)
+        rc, exp = oc.decode_planes(oc.make_frame(w, h, hs, vs, 3, out_cs, qts), planes)
+        assert rc == 0
+        d = zj.FrameDesc.make(w, h, hs, vs, 3, out_cs, qts)
+        assert_same(ctx.decode_planes(d, planes), exp, (mode, out_cs, wh, adversarial))
+
+
+def test_decode_grayscale_jpeg(ctx, zj, synth):
+    """1-component input -> GRAYSCALE (benches/decode_grayscale.rs path)"""
+    planes, qts = synth.make_frame(640, 200, 1, 1, 1, seed=4)
+    rc, exp = oc.decode_planes(oc.make_frame(640, 200, 1, 1, 1, oc.GRAYSCALE, qts), planes)
+    assert rc == 0
+    d = zj.FrameDesc.make(640, 200, 1, 1, 1, zj.ColorSpace.GRAYSCALE, qts)
+    assert_same(ctx.decode_planes(d, planes), exp, "gray-in")
+
+
+def test_decode_batch_and_device_api(ctx, zj, synth):
+    """Batch of frames through the device-pointer API used by bench.py (different tables per call)."""
+    import ctypes as C
+    w, h, n = 256, 64, 5
+    frames = [synth.make_frame(w, h, 2, 2, 3, seed=70, frame_index=i) for i in range(n)]
+    qts = frames[0][1]
+    planes = [np.concatenate([f[0][c] for f in frames]) for c in range(3)]
+    d = zj.FrameDesc.make(w, h, 2, 2, 3, zj.ColorSpace.RGB, qts)
+    out_len = zj.lib().zj_out_len(C.byref(d))
+    bufs = [ctx.device_alloc(p.nbytes) for p in planes] + [ctx.device_alloc(n * out_len)]
+    try:
+        for p, b in zip(planes, bufs):
+            ctx.h2d(b, p)
+        ctx.decode_planes_device(d, n, bufs[0], bufs[1], bufs[2], bufs[3])
+        out = np.empty(n * out_len, np.uint8)
+        ctx.d2h(out, bufs[3])
+        for i, f in enumerate(frames):
+            rc, exp = oc.decode_planes(oc.make_frame(w, h, 2, 2, 3, oc.RGB, qts), f[0])
+            assert rc == 0
+            assert_same(out[i * out_len:(i + 1) * out_len], exp, f"frame {i}")
+        ms, name = ctx.time_decode_device(d, n, bufs[0], bufs[1], bufs[2], bufs[3], 3)
+        assert ms > 0 and "zj_fused_kernel<2,2,0>" == name
+    finally:
+        for b in bufs:
+            ctx.device_free(b)
+
+
+def test_unsupported_and_invalid_arguments(ctx, zj, synth):
+    planes, qts = synth.make_frame(64, 64, 2, 2, 3, seed=1)
+    with pytest.raises(zj.ZjError) as e:  # 16-bit quantisation tables are rejected (headers.rs:154-174)
+        ctx.decode_planes(zj.FrameDesc.make(64, 64, 2, 2, 3, 0, [np.full(64, 300, np.int32)] * 3), planes)
+    assert e.value.status == -2
+    with pytest.raises(zj.ZjError) as e:  # sampling factor 4 is not a mode the reference knows
+        ctx.decode_planes(zj.FrameDesc.make(64, 64, 4, 1, 3, 0, qts), planes)
+    assert e.value.status == -1
+    with pytest.raises(zj.ZjError):       # RGBA output is malformed in the reference
+        ctx.decode_planes(zj.FrameDesc.make(64, 64, 2, 2, 3, int(zj.ColorSpace.RGBA), qts), planes)
+
+
+# ---- BASELINE.json full size: 4096x4096, properties that do not need the (slow) oracle everywhere ----
+def _crc_rows(a, w3):
+    return np.add.reduce(a.reshape(-1, w3).astype(np.uint64) * (np.arange(w3, dtype=np.uint64) % 251 + 1), axis=1)
+
+
+@pytest.mark.parametrize("mode,out_cs", [("hv", oc.RGB), ("none", oc.RGB), ("none", oc.GRAYSCALE)])
+def test_full_size_4096(ctx, zj, synth, mode, out_cs):
+    """configs[1] / configs[2]: 4096x4096.  (a) strips are independent: decoding the frame equals
+    decoding each strip as its own frame (checked on a sample of strips against the oracle);
+    (b) the Q5/Q6 byte pattern holds on every row; (c) decoding twice is idempotent."""
+    hs, vs = MODES[mode]
+    w = h = 4096
+    planes, qts = synth.make_frame(w, h, hs, vs, 3, seed=1234)
+    d = zj.FrameDesc.make(w, h, hs, vs, 3, out_cs, qts)
+    out = ctx.decode_planes(d, planes)
+    ncomp = 3 if out_cs == oc.RGB else 1
+    rows = out.reshape(h, w * ncomp)
+    if out_cs == oc.RGB:
+        assert not rows[:, -16:].any()
+        assert rows[:, :-16].any(axis=1).all()
+    strip_rows = 32 if mode == "hv" else 8
+    ybr = strip_rows // 8
+    ypl = planes[0].reshape(h // 8, -1)
+    cpl = [p.reshape(h // (8 * vs), -1) for p in planes[1:]]
+    cbr = 2 if mode == "hv" else 1
+    for s in (0, 1, h // strip_rows // 2, h // strip_rows - 1):
+        sp = [ypl[s * ybr:(s + 1) * ybr].reshape(-1)] + [c[s * cbr:(s + 1) * cbr].reshape(-1) for c in cpl]
+        rc, exp = oc.decode_planes(oc.make_frame(w, strip_rows, hs, vs, 3, out_cs, qts), sp)
+        assert rc == 0
+        assert_same(rows[s * strip_rows:(s + 1) * strip_rows].reshape(-1), exp, (mode, "strip", s))
+    out2 = ctx.decode_planes(d, planes)
+    assert np.array_equal(_crc_rows(out, w * ncomp), _crc_rows(out2, w * ncomp))
+
+
+def test_full_size_4096_hv_whole_frame_vs_oracle(ctx, zj, synth):
+    """One complete 4096x4096 4:2:0 frame against the oracle (the oracle needs a few seconds)."""
+    w = h = 4096
+    planes, qts = synth.make_frame(w, h, 2, 2, 3, seed=99)
+    rc, exp = oc.decode_planes(oc.make_frame(w, h, 2, 2, 3, oc.RGB, qts), planes)
+    assert rc == 0
+    d = zj.FrameDesc.make(w, h, 2, 2, 3, zj.ColorSpace.RGB, qts)
+    assert_same(ctx.decode_planes(d, planes), exp, "4096 hv")

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""
+Generates the committed golden fixtures under tests/golden/ with the numpy restatement
+(oracle/oracle_np.py).  The reference is Rust and cannot be run in this image, so these vectors
+are restatement-generated: small inputs + expected outputs, data only.
+
+    python tools/make_golden.py
+
+Fixtures (all tiny):
+  strip_<mode>_<out>.npz   one strip (frame one strip tall) per sampling mode / output colour space:
+                           planes y/cb/cr (int16), qt (3x64 int32), width, height, expected (uint8)
+  frame_hv_rgb_96x80.npz   a 3-strip 4:2:0 frame whose height is not a multiple of the strip
+  adversarial_hv_rgb.npz   full-range coefficients / tables (wrap-around paths, Q1/Q7)
+  idct_blocks.npz          256 random blocks + expected pixel blocks (incl. DC-only, wrap)
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+import oracle_np as onp  # noqa: E402
+
+synth = importlib.import_module("zune-jpeg_amd.synth")
+OUT = os.path.join(ROOT, "tests", "golden")
+MODES = {"none": (1, 1), "h": (2, 1), "v": (1, 2), "hv": (2, 2)}
+CS = {"rgb": onp.RGB, "gray": onp.GRAYSCALE, "ycbcr": onp.YCBCR}
+
+
+def save_frame(name, w, h, hs, vs, out_cs, planes, qts):
+    exp = onp.decode_planes(w, h, hs, vs, 3, out_cs, qts, planes)
+    np.savez_compressed(os.path.join(OUT, name), y=planes[0], cb=planes[1], cr=planes[2],
+                        qt=np.stack(qts).astype(np.int32), width=w, height=h, h_max=hs, v_max=vs,
+                        out_cs=out_cs, expected=exp)
+    return exp.size
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    total = 0
+    for mode, (hs, vs) in MODES.items():
+        strip_rows = 32 if (hs, vs) == (2, 2) else (16 if hs == 2 or vs == 2 else 8)
+        for cname, cs in CS.items():
+            w = 64
+            planes, qts = synth.make_frame(w, strip_rows, hs, vs, 3, seed=100 + 7 * hs + vs)
+            total += save_frame(f"strip_{mode}_{cname}.npz", w, strip_rows, hs, vs, cs, planes, qts)
+    planes, qts = synth.make_frame(96, 80, 2, 2, 3, seed=321)
+    total += save_frame("frame_hv_rgb_96x80.npz", 96, 80, 2, 2, onp.RGB, planes, qts)
+    planes, qts = synth.make_adversarial_frame(64, 32, 2, 2, 3, seed=77)
+    total += save_frame("adversarial_hv_rgb.npz", 64, 32, 2, 2, onp.RGB, planes, qts)
+    rng = np.random.default_rng(2024)
+    blocks = rng.integers(-32768, 32768, size=(256, 64)).astype(np.int16)
+    blocks[64:128] = rng.integers(-40, 41, size=(64, 64))
+    blocks[128:192, 1:] = 0
+    blocks[192:224] = 0
+    qt = rng.integers(1, 256, size=64).astype(np.int32)
+    np.savez_compressed(os.path.join(OUT, "idct_blocks.npz"), blocks=blocks, qt=qt,
+                        expected=onp.idct_blocks(blocks, qt))
+    print("wrote fixtures to", OUT, "expected bytes:", total)
+
+
+if __name__ == "__main__":
+    main()

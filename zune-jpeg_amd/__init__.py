@@ -1,0 +1,14 @@
+"""
+zune-jpeg_amd -- MI355X-native implementation of zune-jpeg's post-entropy pixel path
+(dequantize + 8x8 integer IDCT, chroma up-sampling, YCbCr->RGB), behind the C ABI of
+include/zjhip.h.  This Python package is only the thin ctypes binding used by tests/ and bench.py;
+the product is libzjhip.so (zune-jpeg_amd/csrc).
+
+There is NO CPU fallback: if libzjhip.so is missing, or no HIP device is usable, the calls raise.
+Import with importlib.import_module("zune-jpeg_amd") (the directory name carries a hyphen).
+"""
+from .host import (  # noqa: F401
+    BACKEND_AVX2, BACKEND_HIP, BACKEND_SCALAR, ColorSpace, Component, Context, FrameDesc, ZjError,
+    ZuneJpegOptions, abi_symbols, choose_idct_func, choose_upsample_func,
+    choose_ycbcr_to_rgb_convert_func, device_count, lib, lib_path, num_components,
+)

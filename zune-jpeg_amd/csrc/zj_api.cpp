@@ -1,0 +1,484 @@
+// zj_api.cpp -- C ABI of libzjhip.so (see include/zjhip.h).  Host side of the HIP arm: argument
+// validation that mirrors the reference's panics, geometry (zj_plan.h), buffer management and
+// kernel launches.  There is no CPU compute path in this library.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <new>
+#include <string>
+
+#include "../../include/zjhip.h"
+#include "zj_launch.h"
+#include "zj_plan.h"
+
+using namespace zj;
+
+namespace {
+constexpr int QT_SLOTS = 8;
+constexpr int N_SCRATCH = 4;
+}
+
+struct zj_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int32_t* d_qt = nullptr;      // QT_SLOTS x [3][64]
+    int32_t* h_qt = nullptr;      // pinned mirror
+    int qt_slot = -1;             // slot holding the tables of the last frame desc
+    int qt_used = 0;
+    void* scratch[N_SCRATCH] = {nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_cap[N_SCRATCH] = {0, 0, 0, 0};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string last_error;
+};
+
+#define ZJ_HIP(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e_);                 \
+            return ZJ_ERR_HIP;                                                                     \
+        }                                                                                          \
+    } while (0)
+
+static int ensure_scratch(zj_ctx* c, int i, size_t bytes)
+{
+    if (bytes <= c->scratch_cap[i]) return ZJ_OK;
+    if (c->scratch[i]) { ZJ_HIP(c, hipStreamSynchronize(c->stream)); ZJ_HIP(c, hipFree(c->scratch[i])); c->scratch[i] = nullptr; c->scratch_cap[i] = 0; }
+    size_t cap = bytes + bytes / 4 + 4096;
+    ZJ_HIP(c, hipMalloc(&c->scratch[i], cap));
+    c->scratch_cap[i] = cap;
+    return ZJ_OK;
+}
+
+// uploads (or finds) the 3x64 quantisation tables; returns the device pointer in *out
+static int stage_qt(zj_ctx* c, const int32_t qt[3][64], hipStream_t s, const int32_t** out)
+{
+    if (c->qt_slot >= 0 && memcmp(c->h_qt + 192 * c->qt_slot, qt, 192 * sizeof(int32_t)) == 0) {
+        *out = c->d_qt + 192 * c->qt_slot;
+        return ZJ_OK;
+    }
+    int slot = c->qt_used % QT_SLOTS;
+    if (c->qt_used >= QT_SLOTS) ZJ_HIP(c, hipStreamSynchronize(s)); // slot may still be read by an old launch
+    c->qt_used++;
+    memcpy(c->h_qt + 192 * slot, qt, 192 * sizeof(int32_t));
+    ZJ_HIP(c, hipMemcpyAsync(c->d_qt + 192 * slot, c->h_qt + 192 * slot, 192 * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    c->qt_slot = slot;
+    *out = c->d_qt + 192 * slot;
+    return ZJ_OK;
+}
+
+extern "C" {
+
+int zj_abi_version(void) { return ZJ_ABI_VERSION; }
+
+int zj_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return ZJ_ERR_NO_DEVICE;
+    return n;
+}
+
+const char* zj_strerror(int status)
+{
+    switch (status) {
+    case ZJ_OK: return "ok";
+    case ZJ_ERR_ARG: return "invalid argument";
+    case ZJ_ERR_UNSUPPORTED: return "valid for the reference but not supported by the HIP arm";
+    case ZJ_ERR_HIP: return "HIP runtime error (see zj_last_error)";
+    case ZJ_ERR_NOMEM: return "out of memory";
+    case ZJ_ERR_PANIC: return "the reference would panic on these arguments";
+    case ZJ_ERR_NO_DEVICE: return "no usable HIP device";
+    case ZJ_ERR_BACKEND: return "only ZJ_BACKEND_HIP is implemented by this library";
+    default: return "unknown status";
+    }
+}
+
+const char* zj_last_error(const zj_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+zj_ctx* zj_ctx_create(int backend, int device, int* status)
+{
+    int dummy;
+    if (!status) status = &dummy;
+    if (backend != ZJ_BACKEND_HIP) { *status = ZJ_ERR_BACKEND; return nullptr; }
+    int n = zj_device_count();
+    if (n <= 0 || device < 0 || device >= n) { *status = ZJ_ERR_NO_DEVICE; return nullptr; }
+    zj_ctx* c = new (std::nothrow) zj_ctx();
+    if (!c) { *status = ZJ_ERR_NOMEM; return nullptr; }
+    c->device = device;
+    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc((void**)&c->d_qt, QT_SLOTS * 192 * sizeof(int32_t)) == hipSuccess &&
+              hipHostMalloc((void**)&c->h_qt, QT_SLOTS * 192 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess &&
+              hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
+    if (!ok) { zj_ctx_destroy(c); *status = ZJ_ERR_NO_DEVICE; return nullptr; }
+    *status = ZJ_OK;
+    return c;
+}
+
+void zj_ctx_destroy(zj_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < N_SCRATCH; i++)
+        if (c->scratch[i]) (void)hipFree(c->scratch[i]);
+    if (c->d_qt) (void)hipFree(c->d_qt);
+    if (c->h_qt) (void)hipHostFree(c->h_qt);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+zj_ctx* zj_default_ctx(void)
+{
+    static std::mutex mu;
+    static zj_ctx* def = nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!def) { int st; def = zj_ctx_create(ZJ_BACKEND_HIP, 0, &st); }
+    return def;
+}
+
+int zj_num_components(int cs) { return ncomp_of(cs); }
+
+size_t zj_plane_len(const zj_frame_desc* d, int comp)
+{
+    if (!d || d->width == 0 || d->height == 0) return 0;
+    if (!((d->h_max == 1 || d->h_max == 2) && (d->v_max == 1 || d->v_max == 2))) return 0;
+    if (comp < 0 || comp >= (int)d->in_components || d->in_components > 3) return 0;
+    const size_t mcu_x = (d->width + 8 * d->h_max - 1) / (8 * d->h_max);  // headers.rs:317
+    const size_t mcu_y = (d->height + 8 * d->v_max - 1) / (8 * d->v_max); // headers.rs:319
+    const size_t hs = comp == 0 ? d->h_max : 1, vs = comp == 0 ? d->v_max : 1;
+    return mcu_x * 64 * vs * hs * mcu_y; // mcu_prog.rs:76
+}
+
+size_t zj_out_len(const zj_frame_desc* d)
+{
+    if (!d) return 0;
+    return (size_t)d->width * d->height * (size_t)ncomp_of(d->out_colorspace);
+}
+
+/* ---- memory helpers ------------------------------------------------------------------------- */
+void* zj_alloc_pinned(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void zj_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
+void* zj_device_alloc(zj_ctx* c, size_t bytes)
+{
+    if (!c || hipSetDevice(c->device) != hipSuccess) return nullptr;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr;
+    return p;
+}
+void zj_device_free(zj_ctx* c, void* p) { if (c && p) { (void)hipSetDevice(c->device); (void)hipFree(p); } }
+int zj_memcpy_h2d(zj_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!c) return ZJ_ERR_ARG;
+    ZJ_HIP(c, hipSetDevice(c->device));
+    ZJ_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    ZJ_HIP(c, hipStreamSynchronize(c->stream));
+    return ZJ_OK;
+}
+int zj_memcpy_d2h(zj_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!c) return ZJ_ERR_ARG;
+    ZJ_HIP(c, hipSetDevice(c->device));
+    ZJ_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    ZJ_HIP(c, hipStreamSynchronize(c->stream));
+    return ZJ_OK;
+}
+int zj_sync(zj_ctx* c)
+{
+    if (!c) return ZJ_ERR_ARG;
+    ZJ_HIP(c, hipSetDevice(c->device));
+    ZJ_HIP(c, hipStreamSynchronize(c->stream));
+    return ZJ_OK;
+}
+
+/* ---- frame / batch level -------------------------------------------------------------------- */
+static int decode_device_impl(zj_ctx* c, const zj_frame_desc* d, const Plan& pl, size_t nframes,
+                              const int16_t* d_y, const int16_t* d_cb, const int16_t* d_cr,
+                              uint8_t* d_out, hipStream_t s, int zero_fill)
+{
+    const int32_t* d_qt = nullptr;
+    int rc = stage_qt(c, d->qt, s, &d_qt);
+    if (rc) return rc;
+    Params p;
+    fill_params(d, pl, nframes, d_y, d_cb, d_cr, d_out, d_qt, zero_fill, p);
+    if (zero_fill && pl.rows_covered < (int)d->height) {
+        // rows below the last complete strip are never written by the reference (Q6): zeros
+        const size_t off = (size_t)pl.rows_covered * d->width * pl.ncomp_out;
+        for (size_t f = 0; f < nframes; f++)
+            ZJ_HIP(c, hipMemsetAsync(d_out + f * pl.out_len + off, 0, pl.out_len - off, s));
+    }
+    ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, p, s));
+    return ZJ_OK;
+}
+
+static int check_frame_args(zj_ctx* c, const zj_frame_desc* d, size_t nframes, const void* y,
+                            const void* cb, const void* cr, const void* out, Plan& pl)
+{
+    if (!c) return ZJ_ERR_ARG;
+    int rc = make_plan(d, pl);
+    if (rc) return rc;
+    if (nframes == 0 || nframes > (size_t)1 << 20) return ZJ_ERR_ARG;
+    if (!y || !out) return ZJ_ERR_ARG;
+    if (pl.out != OUT_GRAY && (!cb || !cr)) return ZJ_ERR_ARG;
+    if (!pl.fast) return ZJ_ERR_UNSUPPORTED; // ragged widths: not implemented yet
+    if ((long long)nframes * pl.n_strips * pl.tiles_per_row > 0x7fffffffLL) return ZJ_ERR_ARG;
+    return ZJ_OK;
+}
+
+int zj_decode_planes_device(zj_ctx* c, const zj_frame_desc* d, size_t nframes, const int16_t* d_y,
+                            const int16_t* d_cb, const int16_t* d_cr, uint8_t* d_out, void* stream)
+{
+    Plan pl;
+    int rc = check_frame_args(c, d, nframes, d_y, d_cb, d_cr, d_out, pl);
+    if (rc) return rc;
+    if (((uintptr_t)d_y | (uintptr_t)d_cb | (uintptr_t)d_cr | (uintptr_t)d_out) & 15) return ZJ_ERR_ARG;
+    ZJ_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return decode_device_impl(c, d, pl, nframes, d_y, d_cb, d_cr, d_out, s, 1);
+}
+
+int zj_time_decode_device(zj_ctx* c, const zj_frame_desc* d, size_t nframes, const int16_t* d_y,
+                          const int16_t* d_cb, const int16_t* d_cr, uint8_t* d_out, void* stream,
+                          int iters, float* ms_total, const char** kernel_name)
+{
+    Plan pl;
+    int rc = check_frame_args(c, d, nframes, d_y, d_cb, d_cr, d_out, pl);
+    if (rc) return rc;
+    if (iters <= 0 || !ms_total) return ZJ_ERR_ARG;
+    ZJ_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (kernel_name) *kernel_name = fused_kernel_name(pl.hs, pl.vs, pl.out);
+    ZJ_HIP(c, hipEventRecord(c->ev0, s));
+    for (int i = 0; i < iters; i++) {
+        rc = decode_device_impl(c, d, pl, nframes, d_y, d_cb, d_cr, d_out, s, 1);
+        if (rc) return rc;
+    }
+    ZJ_HIP(c, hipEventRecord(c->ev1, s));
+    ZJ_HIP(c, hipEventSynchronize(c->ev1));
+    ZJ_HIP(c, hipEventElapsedTime(ms_total, c->ev0, c->ev1));
+    return ZJ_OK;
+}
+
+int zj_decode_planes_batch(zj_ctx* c, const zj_frame_desc* d, size_t nframes, const int16_t* y,
+                           const int16_t* cb, const int16_t* cr, uint8_t* out)
+{
+    Plan pl;
+    int rc = check_frame_args(c, d, nframes, y, cb, cr, out, pl);
+    if (rc) return rc;
+    ZJ_HIP(c, hipSetDevice(c->device));
+    const bool chroma = pl.out != OUT_GRAY;
+    const size_t yb = nframes * pl.y_len * 2, cbytes = chroma ? nframes * pl.c_len * 2 : 0, ob = nframes * pl.out_len;
+    if ((rc = ensure_scratch(c, 0, yb))) return rc;
+    if (chroma && ((rc = ensure_scratch(c, 1, cbytes)) || (rc = ensure_scratch(c, 2, cbytes)))) return rc;
+    if ((rc = ensure_scratch(c, 3, ob))) return rc;
+    hipStream_t s = c->stream;
+    ZJ_HIP(c, hipMemcpyAsync(c->scratch[0], y, yb, hipMemcpyHostToDevice, s));
+    if (chroma) {
+        ZJ_HIP(c, hipMemcpyAsync(c->scratch[1], cb, cbytes, hipMemcpyHostToDevice, s));
+        ZJ_HIP(c, hipMemcpyAsync(c->scratch[2], cr, cbytes, hipMemcpyHostToDevice, s));
+    }
+    rc = decode_device_impl(c, d, pl, nframes, (const int16_t*)c->scratch[0], (const int16_t*)c->scratch[1],
+                            (const int16_t*)c->scratch[2], (uint8_t*)c->scratch[3], s, 1);
+    if (rc) return rc;
+    ZJ_HIP(c, hipMemcpyAsync(out, c->scratch[3], ob, hipMemcpyDeviceToHost, s));
+    ZJ_HIP(c, hipStreamSynchronize(s));
+    return ZJ_OK;
+}
+
+int zj_decode_planes(zj_ctx* c, const zj_frame_desc* d, const int16_t* y, const int16_t* cb,
+                     const int16_t* cr, uint8_t* out)
+{
+    return zj_decode_planes_batch(c, d, 1, y, cb, cr, out);
+}
+
+/* ---- strip level ---------------------------------------------------------------------------- */
+int zj_idct_strip(zj_ctx* c, const int16_t* coeff, size_t n, const int32_t qt[64], size_t stride,
+                  size_t samp_factors, size_t v_samp, int16_t* out)
+{
+    if (!c || !qt || (n && (!coeff || !out))) return ZJ_ERR_ARG;
+    if (samp_factors == 0) return ZJ_ERR_PANIC;          // division by zero, scalar.rs:30
+    if (n == 0) return ZJ_OK;
+    for (int k = 0; k < 64; k++)
+        if (qt[k] < 0 || qt[k] > 255) return ZJ_ERR_UNSUPPORTED;
+    const size_t chunks = n * v_samp / samp_factors;     // scalar.rs:30
+    if (chunks == 0) return ZJ_ERR_PANIC;                // chunks_exact(0)
+    const size_t nchunks = n / chunks, bpc = chunks / 64;
+    // get_mut(pos..pos+8).unwrap() (scalar.rs:52,249): the last block's last row must fit the chunk
+    if (bpc > 0 && (bpc - 1) * 8 + 7 * stride + 8 > chunks) return ZJ_ERR_PANIC;
+    ZJ_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure_scratch(c, 0, n * 2)) || (rc = ensure_scratch(c, 1, n * 2))) return rc;
+    hipStream_t s = c->stream;
+    int32_t qt3[3][64];
+    memcpy(qt3[0], qt, 256); memcpy(qt3[1], qt, 256); memcpy(qt3[2], qt, 256);
+    const int32_t* d_qt = nullptr;
+    if ((rc = stage_qt(c, qt3, s, &d_qt))) return rc;
+    ZJ_HIP(c, hipMemcpyAsync(c->scratch[0], coeff, n * 2, hipMemcpyHostToDevice, s));
+    ZJ_HIP(c, hipMemsetAsync(c->scratch[1], 0, n * 2, s)); // vec![0; len], scalar.rs:26
+    ZJ_HIP(c, launch_idct_strip((const int16_t*)c->scratch[0], d_qt, (int16_t*)c->scratch[1],
+                                (long long)(nchunks * bpc), (long long)chunks, (long long)bpc, (long long)stride, s));
+    ZJ_HIP(c, hipMemcpyAsync(out, c->scratch[1], n * 2, hipMemcpyDeviceToHost, s));
+    ZJ_HIP(c, hipStreamSynchronize(s));
+    return ZJ_OK;
+}
+
+// runs one flat filter on device buffers (scratch[si] -> scratch[so]); no sync
+static int upsample_h_dev(zj_ctx* c, int si, size_t n, int so, size_t out_len)
+{
+    if (!(out_len > 4 && n > 2)) return ZJ_ERR_PANIC; // assert!, upsampler/scalar.rs:9-12
+    const size_t m = ((out_len - 2) / 2 < n - 2) ? (out_len - 2) / 2 : n - 2; // zip(chunks_exact_mut(2), windows(3))
+    ZJ_HIP(c, hipMemsetAsync(c->scratch[so], 0, out_len * 2, c->stream));
+    ZJ_HIP(c, launch_upsample_h((const int16_t*)c->scratch[si], (long long)n, (int16_t*)c->scratch[so],
+                                (long long)out_len, (long long)m, c->stream));
+    return ZJ_OK;
+}
+static int upsample_v_dev(zj_ctx* c, int si, size_t n, int so, size_t out_len)
+{
+    const size_t stride = n >> 3; // upsampler/scalar.rs:73
+    if (stride == 0) return ZJ_ERR_PANIC;
+    // out[i..].split_at_mut(stride) for i = 0, 2*stride, ... 14*stride (scalar.rs:95-110)
+    if (14 * stride + stride > out_len) return ZJ_ERR_PANIC;
+    ZJ_HIP(c, hipMemsetAsync(c->scratch[so], 0, out_len * 2, c->stream));
+    ZJ_HIP(c, launch_upsample_v((const int16_t*)c->scratch[si], (long long)stride, (int16_t*)c->scratch[so],
+                                (long long)out_len, c->stream));
+    return ZJ_OK;
+}
+
+static int upsample_common(zj_ctx* c, int kind, const int16_t* in, size_t n, int16_t* out, size_t out_len)
+{
+    if (!c || !in || !out) return ZJ_ERR_ARG;
+    ZJ_HIP(c, hipSetDevice(c->device));
+    int rc;
+    const size_t mid = n * 2;
+    if ((rc = ensure_scratch(c, 0, (n ? n : 1) * 2)) || (rc = ensure_scratch(c, 1, (out_len ? out_len : 1) * 2)) ||
+        (rc = ensure_scratch(c, 2, (mid ? mid : 1) * 2))) return rc;
+    ZJ_HIP(c, hipMemcpyAsync(c->scratch[0], in, n * 2, hipMemcpyHostToDevice, c->stream));
+    if (kind == 0) rc = upsample_h_dev(c, 0, n, 1, out_len);
+    else if (kind == 1) rc = upsample_v_dev(c, 0, n, 1, out_len);
+    else { // upsample_hv = horizontal(vertical(input, 2*len), output_len), scalar.rs:148-166
+        rc = upsample_v_dev(c, 0, n, 2, mid);
+        if (!rc) rc = upsample_h_dev(c, 2, mid, 1, out_len);
+    }
+    if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+    ZJ_HIP(c, hipMemcpyAsync(out, c->scratch[1], out_len * 2, hipMemcpyDeviceToHost, c->stream));
+    ZJ_HIP(c, hipStreamSynchronize(c->stream));
+    return ZJ_OK;
+}
+
+int zj_upsample_h(zj_ctx* c, const int16_t* in, size_t n, int16_t* out, size_t out_len) { return upsample_common(c, 0, in, n, out, out_len); }
+int zj_upsample_v(zj_ctx* c, const int16_t* in, size_t n, int16_t* out, size_t out_len) { return upsample_common(c, 1, in, n, out, out_len); }
+int zj_upsample_hv(zj_ctx* c, const int16_t* in, size_t n, int16_t* out, size_t out_len) { return upsample_common(c, 2, in, n, out, out_len); }
+
+int zj_ycbcr_to_rgb16(zj_ctx* c, const int16_t y[16], const int16_t cb[16], const int16_t cr[16],
+                      uint8_t* out, size_t out_len, size_t* pos)
+{
+    if (!c || !y || !cb || !cr || !out || !pos) return ZJ_ERR_ARG;
+    if (*pos > out_len || out_len - *pos < 48) return ZJ_ERR_PANIC; // "Slice to small cannot write", scalar.rs:57-64
+    ZJ_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure_scratch(c, 0, 96)) || (rc = ensure_scratch(c, 1, 48))) return rc;
+    int16_t h[48];
+    memcpy(h, y, 32); memcpy(h + 16, cb, 32); memcpy(h + 32, cr, 32);
+    ZJ_HIP(c, hipMemcpyAsync(c->scratch[0], h, 96, hipMemcpyHostToDevice, c->stream));
+    ZJ_HIP(c, hipStreamSynchronize(c->stream)); // `h` is pageable stack memory
+    ZJ_HIP(c, launch_rgb16((const int16_t*)c->scratch[0], (uint8_t*)c->scratch[1], c->stream));
+    ZJ_HIP(c, hipMemcpyAsync(out + *pos, c->scratch[1], 48, hipMemcpyDeviceToHost, c->stream));
+    ZJ_HIP(c, hipStreamSynchronize(c->stream));
+    *pos += 48;
+    return ZJ_OK;
+}
+
+int zj_post_process_strip(zj_ctx* c, const int16_t* const coeff[3], const size_t len[3],
+                          const zj_component comps[3], int in_cs, int out_cs, uint8_t* out,
+                          size_t out_len, size_t width)
+{
+    if (!c || !coeff || !len || !comps || !out) return ZJ_ERR_ARG;
+    const size_t hs = comps[0].horizontal_sample, vs = comps[0].vertical_sample; // worker.rs:43-45
+    if (!((hs == 1 || hs == 2) && (vs == 1 || vs == 2))) return ZJ_ERR_UNSUPPORTED;
+    if (in_cs != ZJ_CS_YCBCR && in_cs != ZJ_CS_GRAYSCALE) return ZJ_ERR_UNSUPPORTED;
+    if (width == 0 || width > 65535) return ZJ_ERR_ARG;
+    // One strip == a frame that is exactly one strip tall (mcu.rs:225-226).
+    zj_frame_desc d;
+    memset(&d, 0, sizeof d);
+    d.width = (uint32_t)width;
+    d.h_max = (uint32_t)hs; d.v_max = (uint32_t)vs;
+    d.in_components = in_cs == ZJ_CS_YCBCR ? 3 : 1;
+    d.out_colorspace = out_cs;
+    const uint32_t strip_rows = (hs == 2 && vs == 2) ? 32 : ((hs == 2 || vs == 2) ? 16 : 8);
+    d.height = strip_rows;
+    for (int k = 0; k < 3; k++) memcpy(d.qt[k], comps[k < (int)d.in_components ? k : 0].quantization_table, 256);
+    Plan pl;
+    int rc = make_plan(&d, pl);
+    if (rc) return rc;
+    // the strip must have the geometry the reference's callers produce (headers.rs:338, mcu.rs:238-250)
+    if (comps[0].width_stride != (size_t)pl.mcu_x * 8 * hs || len[0] != pl.y_len) return ZJ_ERR_UNSUPPORTED;
+    const bool chroma = pl.out != OUT_GRAY;
+    if (chroma && (len[1] != pl.c_len || len[2] != pl.c_len || comps[1].width_stride != (size_t)pl.mcu_x * 8 ||
+                   comps[2].width_stride != (size_t)pl.mcu_x * 8)) return ZJ_ERR_UNSUPPORTED;
+    if (!coeff[0] || (chroma && (!coeff[1] || !coeff[2]))) return ZJ_ERR_ARG;
+    if (out_len < pl.out_len) return ZJ_ERR_PANIC; // &mut output[start..end], worker.rs:174
+    if (!pl.fast) return ZJ_ERR_UNSUPPORTED;
+    ZJ_HIP(c, hipSetDevice(c->device));
+    const size_t yb = pl.y_len * 2, cbytes = chroma ? pl.c_len * 2 : 0;
+    if ((rc = ensure_scratch(c, 0, yb))) return rc;
+    if (chroma && ((rc = ensure_scratch(c, 1, cbytes)) || (rc = ensure_scratch(c, 2, cbytes)))) return rc;
+    if ((rc = ensure_scratch(c, 3, pl.out_len))) return rc;
+    hipStream_t s = c->stream;
+    ZJ_HIP(c, hipMemcpyAsync(c->scratch[0], coeff[0], yb, hipMemcpyHostToDevice, s));
+    if (chroma) {
+        ZJ_HIP(c, hipMemcpyAsync(c->scratch[1], coeff[1], cbytes, hipMemcpyHostToDevice, s));
+        ZJ_HIP(c, hipMemcpyAsync(c->scratch[2], coeff[2], cbytes, hipMemcpyHostToDevice, s));
+    }
+    // bytes the reference never writes keep the caller's content: round-trip the caller's buffer
+    ZJ_HIP(c, hipMemcpyAsync(c->scratch[3], out, pl.out_len, hipMemcpyHostToDevice, s));
+    rc = decode_device_impl(c, &d, pl, 1, (const int16_t*)c->scratch[0], (const int16_t*)c->scratch[1],
+                            (const int16_t*)c->scratch[2], (uint8_t*)c->scratch[3], s, 0);
+    if (rc) return rc;
+    ZJ_HIP(c, hipMemcpyAsync(out, c->scratch[3], pl.out_len, hipMemcpyDeviceToHost, s));
+    ZJ_HIP(c, hipStreamSynchronize(s));
+    return ZJ_OK;
+}
+
+/* ---- dispatch mirror ------------------------------------------------------------------------ */
+zj_idct_fn zj_choose_idct_func(int backend) { return backend == ZJ_BACKEND_HIP ? zj_idct_strip : nullptr; }
+zj_upsample_fn zj_choose_upsample_func(int backend, int h_max, int v_max)
+{
+    if (backend != ZJ_BACKEND_HIP) return nullptr;
+    if (h_max == 2 && v_max == 1) return zj_upsample_h;  // decoder.rs:480-491
+    if (h_max == 1 && v_max == 2) return zj_upsample_v;  // decoder.rs:492-501
+    if (h_max == 2 && v_max == 2) return zj_upsample_hv; // decoder.rs:502-511
+    return nullptr;                                      // (1,1): upsample_no_op / unknown ratio
+}
+zj_color_convert16_fn zj_choose_ycbcr_to_rgb_convert_func(int backend, int out_cs)
+{
+    // the reference only ever asks for ColorSpace::RGB (decoder.rs:127-128)
+    if (backend != ZJ_BACKEND_HIP || out_cs != ZJ_CS_RGB) return nullptr;
+    return zj_ycbcr_to_rgb16;
+}
+
+/* micro-benchmark hook used by tools/ubench.py (not part of the decode path) */
+int zj_ubench(zj_ctx* c, int op, int blocks, int iters, int reps, float* ms)
+{
+    if (!c || !ms) return ZJ_ERR_ARG;
+    ZJ_HIP(c, hipSetDevice(c->device));
+    int rc = ensure_scratch(c, 0, (size_t)blocks * 256 * 4);
+    if (rc) return rc;
+    ZJ_HIP(c, launch_ubench(op, (int*)c->scratch[0], blocks, iters, 12345, c->stream)); // warm-up
+    ZJ_HIP(c, hipEventRecord(c->ev0, c->stream));
+    for (int r = 0; r < reps; r++) ZJ_HIP(c, launch_ubench(op, (int*)c->scratch[0], blocks, iters, 12345 + r, c->stream));
+    ZJ_HIP(c, hipEventRecord(c->ev1, c->stream));
+    ZJ_HIP(c, hipEventSynchronize(c->ev1));
+    ZJ_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return ZJ_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,578 @@
+// zj_device.h -- device-side code of the MI355X pixel path (dequantize + 8x8 integer IDCT, chroma
+// up-sampling, YCbCr->RGB/gray/YCbCr), written for gfx950 (wave64, LDS, packed-i16 VALU).
+//
+// The arithmetic restates zune-jpeg's SCALAR arms bit-exactly (paths relative to the reference):
+//   src/idct/scalar.rs:19-282, src/upsampler/scalar.rs:5-166, src/color_convert/scalar.rs:52-169,
+//   src/worker.rs:32-251.  Quirk numbers (Q1..Q8) refer to SURVEY.md section 8a.
+//
+// The same header is compiled (a) by hipcc into libzjhip.so and (b) by g++ into the CPU
+// *emulation* harness under tests/emu/, which runs every workgroup phase thread by thread so the
+// indexing can be checked against the oracle without a GPU.  (b) is test infrastructure only: the
+// product library contains no CPU path.  ZJ_EMU selects (b).
+#pragma once
+
+#include <stdint.h>
+
+#if defined(ZJ_EMU)
+#define ZJ_DEV inline
+#define ZJ_HD inline
+#else
+#include <hip/hip_runtime.h>
+#define ZJ_DEV __device__ __forceinline__
+#define ZJ_HD __host__ __device__ __forceinline__
+#endif
+
+namespace zj {
+
+// ------------------------------------------------------------------------------------------------
+// small portable vector / intrinsic layer
+// ------------------------------------------------------------------------------------------------
+typedef uint16_t u16x2 __attribute__((vector_size(4)));  // packed pair, wrap-around + - *
+typedef int16_t s16x2 __attribute__((vector_size(4)));   // packed pair, arithmetic >>, min/max
+
+struct alignas(16) U4 { uint32_t x, y, z, w; };
+
+ZJ_DEV uint32_t as_u32(u16x2 v) { uint32_t r; __builtin_memcpy(&r, &v, 4); return r; }
+ZJ_DEV uint32_t as_u32(s16x2 v) { uint32_t r; __builtin_memcpy(&r, &v, 4); return r; }
+ZJ_DEV u16x2 as_u16x2(uint32_t v) { u16x2 r; __builtin_memcpy(&r, &v, 4); return r; }
+ZJ_DEV s16x2 as_s16x2(uint32_t v) { s16x2 r; __builtin_memcpy(&r, &v, 4); return r; }
+
+// 24-bit multiply: exact (== wrapping 32-bit product) iff both operands fit in signed 24 bits.
+// The emulation build implements the hardware semantics literally so range violations show up.
+#if !defined(ZJ_EMU)
+// the LLVM intrinsic itself (no clang builtin exists); selects v_mul_i32_i24 / v_mad_i32_i24 / SDWA forms
+extern "C" __device__ __attribute__((const)) int zj_llvm_mul_i24(int, int) __asm("llvm.amdgcn.mul.i24");
+#endif
+ZJ_DEV int32_t mul24(int32_t a, int32_t b)
+{
+#if defined(ZJ_EMU)
+    int32_t a24 = (int32_t)((uint32_t)a << 8) >> 8, b24 = (int32_t)((uint32_t)b << 8) >> 8;
+    return (int32_t)((uint32_t)a24 * (uint32_t)b24);
+#else
+    return zj_llvm_mul_i24(a, b);
+#endif
+}
+ZJ_DEV int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+ZJ_DEV int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+ZJ_DEV int32_t mad24(int32_t a, int32_t b, int32_t c) { return wadd(mul24(a, b), c); }
+ZJ_DEV int32_t wshl(int32_t a, int s) { return (int32_t)((uint32_t)a << s); }
+
+// v_perm_b32: bytes {s0[3..0] -> 7..4, s1[3..0] -> 3..0}; selector byte i picks result byte i.
+ZJ_DEV uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel)
+{
+#if defined(ZJ_EMU)
+    uint64_t src = ((uint64_t)s0 << 32) | s1;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; i++) {
+        uint32_t s = (sel >> (8 * i)) & 0xff;
+        uint32_t b = s < 8 ? (uint32_t)((src >> (8 * s)) & 0xff) : (s == 12 ? 0u : 0xffu);
+        r |= b << (8 * i);
+    }
+    return r;
+#else
+    return __builtin_amdgcn_perm(s0, s1, sel);
+#endif
+}
+// (hi:lo) >> 16, i.e. {lo.hi16, hi.lo16}
+ZJ_DEV uint32_t align16(uint32_t hi, uint32_t lo) { return (lo >> 16) | (hi << 16); }
+
+ZJ_DEV s16x2 pk_max(s16x2 a, s16x2 b)
+{
+#if defined(ZJ_EMU)
+    s16x2 r; for (int i = 0; i < 2; i++) r[i] = a[i] > b[i] ? a[i] : b[i]; return r;
+#else
+    return __builtin_elementwise_max(a, b);
+#endif
+}
+ZJ_DEV s16x2 pk_min(s16x2 a, s16x2 b)
+{
+#if defined(ZJ_EMU)
+    s16x2 r; for (int i = 0; i < 2; i++) r[i] = a[i] < b[i] ? a[i] : b[i]; return r;
+#else
+    return __builtin_elementwise_min(a, b);
+#endif
+}
+ZJ_DEV u16x2 splat(int v) { u16x2 r = {(uint16_t)v, (uint16_t)v}; return r; }
+ZJ_DEV s16x2 sar(u16x2 a, int s) { s16x2 t = (s16x2)a; s16x2 sh = {(int16_t)s, (int16_t)s}; return t >> sh; }
+
+ZJ_DEV int uniform(int v)
+{
+#if defined(ZJ_EMU)
+    return v;
+#else
+    return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// 8x8 dequantize + IDCT of ONE block held by ONE lane (64 coefficients in 8 x 16-byte registers).
+//
+// Algebra: every step of the reference butterfly (scalar.rs:79-274) is +,-,* by constants and <<
+// in wrapping i32, i.e. ring operations mod 2^32, so any re-association is bit-exact.  The odd
+// part is expanded into its 4x4 integer matrix so that the only multiplicands are the pass inputs
+// themselves: dequantized coefficients |c*q| <= 32768*255 < 2^23 in pass 1 and (x >> 10) in
+// [-2^21, 2^21) in pass 2.  Both always fit the signed 24-bit operand of v_mul_i32_i24 /
+// v_mad_i32_i24, which makes the full-rate 24-bit multiplier exact for EVERY input (including the
+// wrap-around adversarial ones) without any range check.  Requires 0 <= q <= 255 (8-bit DQT,
+// headers.rs:154-174), enforced by the host side.
+// ------------------------------------------------------------------------------------------------
+ZJ_DEV void idct_1d(const int32_t s[8], const int32_t bias, int32_t o[8])
+{
+    // even part: t3 = (s2+s6)*2217 + s2*3135, t2 = (s2+s6)*2217 - s6*7567      (scalar.rs:81-87)
+    const int32_t t3 = mad24(s[6], 2217, mul24(s[2], 2217 + 3135));
+    const int32_t t2 = mad24(s[6], 2217 - 7567, mul24(s[2], 2217));
+    const int32_t t0 = wadd(wshl(wadd(s[0], s[4]), 12), bias); // fsh(p2+p3) + bias   (:93,:99)
+    const int32_t t1 = wadd(wshl(wsub(s[0], s[4]), 12), bias);
+    const int32_t x0 = wadd(t0, t3), x3 = wsub(t0, t3), x1 = wadd(t1, t2), x2 = wsub(t1, t2);
+    // odd part (scalar.rs:109-148) as the integer matrix it is; a=s7 b=s5 c=s3 d=s1
+    const int32_t a = s[7], b = s[5], c = s[3], d = s[1];
+    const int32_t u3 = mad24(c, 4816, mad24(b, 4816 - 1597, mad24(a, 4816 - 3685, mul24(d, 6149 + 4816 - 3685 - 1597))));
+    const int32_t u2 = mad24(d, 4816, mad24(a, 4816 - 8034, mad24(b, 4816 - 10497, mul24(c, 12586 + 4816 - 10497 - 8034))));
+    const int32_t u1 = mad24(a, 4816, mad24(d, 4816 - 1597, mad24(c, 4816 - 10497, mul24(b, 8410 + 4816 - 10497 - 1597))));
+    const int32_t u0 = mad24(b, 4816, mad24(c, 4816 - 8034, mad24(d, 4816 - 3685, mul24(a, 1223 + 4816 - 3685 - 8034))));
+    o[0] = wadd(x0, u3); o[7] = wsub(x0, u3);
+    o[1] = wadd(x1, u2); o[6] = wsub(x1, u2);
+    o[2] = wadd(x2, u1); o[5] = wsub(x2, u1);
+    o[3] = wadd(x3, u0); o[4] = wsub(x3, u0);
+}
+
+ZJ_DEV int32_t lo16s(uint32_t v) { return (int32_t)(int16_t)(v & 0xffff); }
+ZJ_DEV int32_t hi16s(uint32_t v) { return (int32_t)v >> 16; }
+
+// raw[r] = coefficient row r (8 x i16, natural order).  qt: 64 x int32 (wave-uniform pointer).
+// CENTER (chroma): 128 is subtracted from every finished sample (packed, after the clamp), because
+// the `- 128` of color_convert/scalar.rs:68-70 commutes exactly with both triangle filters
+// ((3(a-128)+(b-128)+2)>>2 == ((3a+b+2)>>2)-128).  It must NOT be folded into the pass-2 bias: the
+// i32 sums may wrap (idct.rs:86) and the arithmetic >> 17 would then see a different sign.
+// out[r] = pixel row r as 8 packed i16 (4 dwords).
+template <bool CENTER>
+ZJ_DEV void idct_block(const U4 raw[8], const int32_t* __restrict__ qt, U4 out[8])
+{
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(raw);
+    // DC-only test (scalar.rs:45): every coefficient except [0] is zero
+    uint32_t any = w[0] & 0xffff0000u;
+#pragma unroll
+    for (int i = 1; i < 32; i++) any |= w[i];
+
+    int32_t tmp[64];
+    // pass 1: columns (scalar.rs:79-167), bias 512, >> 10
+#pragma unroll
+    for (int col = 0; col < 8; col++) {
+        int32_t s[8], o[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t pair = w[k * 4 + (col >> 1)];
+            const int32_t cf = (col & 1) ? hi16s(pair) : lo16s(pair);
+            s[k] = mul24(cf, qt[k * 8 + col]); // dequantize (scalar.rs:308); q is 0..255
+        }
+        idct_1d(s, 512, o);
+#pragma unroll
+        for (int k = 0; k < 8; k++) tmp[k * 8 + col] = o[k] >> 10;
+    }
+    // pass 2: rows (scalar.rs:170-274), bias SCALE_BITS, >> 17, clamp
+    constexpr int32_t bias2 = 512 + 65536 + (128 << 17); // SCALE_BITS, scalar.rs:6
+    constexpr int32_t lo = 0, hi = 255;                  // clamp, scalar.rs:302-305
+    uint32_t* ow = reinterpret_cast<uint32_t*>(out);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        int32_t o[8];
+        idct_1d(&tmp[r * 8], bias2, o);
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+            int32_t p0 = o[k] >> 17, p1 = o[k + 1] >> 17;
+            p0 = p0 < lo ? lo : (p0 > hi ? hi : p0);
+            p1 = p1 < lo ? lo : (p1 > hi ? hi : p1);
+            const uint32_t pk = (uint32_t)p0 | ((uint32_t)p1 << 16);
+            ow[r * 4 + (k >> 1)] = CENTER ? as_u32(as_u16x2(pk) - splat(128)) : pk;
+        }
+    }
+    // Q1: DC-only blocks take the shortcut value, i16 wrapping, floor >> 3, NOT clamped (scalar.rs:48)
+    if (any == 0) {
+        const int16_t dc = (int16_t)(uint16_t)((uint32_t)lo16s(w[0]) * (uint32_t)(int32_t)(int16_t)qt[0]);
+        const int32_t v = ((int32_t)dc >> 3) + (CENTER ? 0 : 128);
+        const uint32_t pv = ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16);
+#pragma unroll
+        for (int i = 0; i < 32; i++) ow[i] = pv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// colour conversion of a packed pixel pair (color_convert/scalar.rs:66-85); cb, cr already centred
+// (value - 128).  All products/sums wrap in i16 exactly like the reference (Q7).  Returns
+// R, G, B clamped to 0..255 in the two 16-bit lanes.
+// ------------------------------------------------------------------------------------------------
+struct RGB2 { uint32_t r, g, b; };
+ZJ_DEV RGB2 ycc_to_rgb_pair(uint32_t y_, uint32_t cb_, uint32_t cr_)
+{
+    const u16x2 y = as_u16x2(y_), cb = as_u16x2(cb_), cr = as_u16x2(cr_);
+    const u16x2 r = y + (u16x2)sar(splat(45) * cr, 5);
+    const u16x2 g = y - (u16x2)sar(splat(11) * cb + splat(23) * cr, 5);
+    const u16x2 b = y + (u16x2)sar(splat(113) * cb, 6);
+    const s16x2 z = {0, 0}, m = {255, 255};
+    RGB2 o;
+    o.r = as_u32(pk_min(pk_max((s16x2)r, z), m));
+    o.g = as_u32(pk_min(pk_max((s16x2)g, z), m));
+    o.b = as_u32(pk_min(pk_max((s16x2)b, z), m));
+    return o;
+}
+
+// triangle filter on packed pairs: (3*near + far + 2) >> 2   (upsampler/scalar.rs:35-41,124-126)
+ZJ_DEV uint32_t tri(uint32_t near_, uint32_t far_)
+{
+    return as_u32(sar(splat(3) * as_u16x2(near_) + as_u16x2(far_) + splat(2), 2));
+}
+ZJ_DEV int tri1(int near_, int far_) { return (int)(int16_t)(uint16_t)(3 * near_ + far_ + 2) >> 2; }
+
+// ------------------------------------------------------------------------------------------------
+// Tile geometry per sampling mode.  A workgroup owns one "tile": the full height of one strip
+// (the reference's unit of work, src/mcu.rs:225-226 / src/mcu_prog.rs:188-203) x TWY luma columns.
+//   mode      strip = Y block rows x chroma block rows   (mcu.rs:139-218, mcu_prog.rs:138-144)
+//   (1,1)     1 x 1      (2,1) 2 x 2 (two MCU rows)     (1,2) 2 x 1      (2,2) 4 x 2
+// Horizontal modes need one extra chroma block column on each side (the triangle filter's taps);
+// because the reference filters the strip as ONE flat array (Q4) the neighbour of the first/last
+// column is the other end of the previous/next row, so the halo wraps around with a row shift.
+// IDCT lanes are laid out so that every wave works on ONE component (quantisation table in SGPRs).
+// ------------------------------------------------------------------------------------------------
+template <int HS, int VS>
+struct Geo {
+    static constexpr int YBR = (HS == 2 && VS == 2) ? 4 : ((HS == 2 || VS == 2) ? 2 : 1);
+    static constexpr int CBR = (HS == 2) ? 2 : 1;
+    static constexpr int SH = YBR * 8;                 // luma rows per strip
+    static constexpr int CROWS = CBR * 8;              // chroma rows per strip
+    static constexpr int TWC = (HS == 2) ? 16 : 64;    // chroma block columns per tile
+    static constexpr int HALO = (HS == 2) ? 1 : 0;
+    static constexpr int TWYB = TWC * HS;              // luma block columns per tile
+    static constexpr int TWY = TWYB * 8;               // luma pixels per tile row
+    static constexpr int NYB = YBR * TWYB;             // luma blocks per tile
+    static constexpr int CCOLS = TWC + 2 * HALO;       // chroma block columns incl. halo
+    static constexpr int NCB = CBR * CCOLS;            // chroma blocks per tile and component
+    static constexpr int NYB64 = (NYB + 63) / 64 * 64;
+    static constexpr int NCB64 = (NCB + 63) / 64 * 64;
+    static constexpr int CPITCH = TWC * 8 + (HALO ? 16 : 0); // i16 per chroma LDS row
+    static constexpr int COFF = HALO ? 8 : 0;          // LDS column of chroma column 0
+    static constexpr int YSZ = SH * TWY;               // i16 elements
+    static constexpr int CSZ = CROWS * CPITCH;
+    static constexpr int NGRP = TWY / 16;              // 16-pixel groups per tile row
+    static constexpr int NITEMS = SH * NGRP;
+};
+
+enum { OUT_RGB = 0, OUT_GRAY = 1, OUT_YCBCR = 2 };
+
+template <int HS, int VS, int OUT>
+struct Cfg : Geo<HS, VS> {
+    using G = Geo<HS, VS>;
+    static constexpr bool CHROMA = OUT != OUT_GRAY;
+    static constexpr int NT = G::NYB64 + (CHROMA ? 2 * G::NCB64 : 0); // threads per workgroup
+    static constexpr int LDS_I16 = G::YSZ + (CHROMA ? 2 * G::CSZ : 0);
+};
+
+struct Params {
+    const int16_t* y;
+    const int16_t* cb;
+    const int16_t* cr;
+    uint8_t* out;
+    const int32_t* qt;            // [3][64]
+    long long y_frame_stride;     // i16 elements between frames
+    long long c_frame_stride;
+    long long out_frame_stride;   // bytes between frames
+    int width, height;            // pixels
+    int mcu_x;                    // MCUs per row (headers.rs:317)
+    int n_strips;
+    int tiles_per_row;
+    int nframes;
+    int zero_fill;                // 1: also write the bytes the reference leaves 0 (Q5/Q6)
+    int total_tiles;
+};
+
+// vertical schedule of upsample_vertical (upsampler/scalar.rs:84-144): pair k -> (near, far)
+ZJ_DEV void vsched(int k, int& n, int& f) { n = k; f = (k == 0) ? 0 : (k < 7 ? k + 1 : 7); }
+
+// chroma source rows (A weighted 3, B weighted 1) of up-sampled row m of a strip  (Q3)
+template <int HS, int VS>
+ZJ_DEV void vrows(int m, int& ra, int& rb)
+{
+    if (VS == 1) { ra = rb = m; return; }
+    int n, f;
+    if (HS == 1) { // (1,2): 8 real rows -> 16
+        vsched(m >> 1, n, f);
+        ra = (m & 1) ? f : n;
+        rb = (m & 1) ? n : f;
+    } else {       // (2,2): upsample_vertical sees 8 "rows" made of 2 real rows each
+        vsched(m >> 2, n, f);
+        const int half = m & 1, farw = (m >> 1) & 1;
+        ra = 2 * (farw ? f : n) + half;
+        rb = 2 * (farw ? n : f) + half;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Phase 1: every lane IDCTs one block of the tile into the LDS planar staging area.
+//   lds layout: Yp[SH][TWY] | Cb[CROWS][CPITCH] | Cr[CROWS][CPITCH]   (i16)
+// ------------------------------------------------------------------------------------------------
+struct TileId { int frame, strip, tile; };
+
+ZJ_DEV TileId decode_tile(const Params& p, int bid)
+{
+    // XCD-aware order: hardware sends workgroup b to XCD b % 8; give each XCD a contiguous run of
+    // tiles so neighbouring tiles (which share halo blocks) meet in the same L2.
+    int id = bid;
+    if ((p.total_tiles & 7) == 0) id = (bid & 7) * (p.total_tiles >> 3) + (bid >> 3);
+    TileId t;
+    t.tile = id % p.tiles_per_row;
+    const int r = id / p.tiles_per_row;
+    t.strip = r % p.n_strips;
+    t.frame = r / p.n_strips;
+    return t;
+}
+
+template <class C>
+ZJ_DEV void phase_idct(const Params& p, const TileId t, const int tid, int16_t* lds)
+{
+    const int ybw = p.mcu_x * (C::TWYB / C::TWC); // luma blocks per plane row   (= mcu_x * HS)
+    const int cbw = p.mcu_x;                      // chroma blocks per plane row
+    const int seg = uniform(tid < C::NYB64 ? 0 : (tid < C::NYB64 + C::NCB64 ? 1 : 2));
+    U4 raw[8], px[8];
+    if (seg == 0) {
+        const int b = tid;
+        if (b >= C::NYB) return;
+        const int brow = b / C::TWYB, bcol = b % C::TWYB;
+        const int gcol = t.tile * C::TWYB + bcol;
+        if (gcol >= ybw) return;
+        const long long blk = (long long)(t.strip * C::YBR + brow) * ybw + gcol;
+        const U4* src = reinterpret_cast<const U4*>(p.y + (long long)t.frame * p.y_frame_stride + blk * 64);
+#pragma unroll
+        for (int i = 0; i < 8; i++) raw[i] = src[i];
+        idct_block<false>(raw, p.qt, px);
+        int16_t* dst = lds + (brow * 8) * C::TWY + bcol * 8;
+#pragma unroll
+        for (int r = 0; r < 8; r++) *reinterpret_cast<U4*>(dst + r * C::TWY) = px[r];
+    } else if (C::CHROMA) {
+        const int b = tid - (seg == 1 ? C::NYB64 : C::NYB64 + C::NCB64);
+        if (b >= C::NCB) return;
+        const int brow = b / C::CCOLS, j = b % C::CCOLS;
+        const int cb0 = t.tile * C::TWC;
+        const int nvalid = (cbw - cb0) < C::TWC ? (cbw - cb0) : C::TWC;
+        int gcol, lcol; // plane block column, LDS column of the block's first pixel
+        bool halo = false, left = false;
+        if (C::HALO) {
+            if (j == 0) { gcol = cb0 > 0 ? cb0 - 1 : cbw - 1; lcol = 0; halo = left = true; }
+            else if (j == C::CCOLS - 1) { gcol = cb0 + nvalid < cbw ? cb0 + nvalid : 0; lcol = C::COFF + 8 * nvalid; halo = true; }
+            else { gcol = cb0 + j - 1; lcol = C::COFF + 8 * (j - 1); if (j - 1 >= nvalid) return; }
+        } else {
+            gcol = cb0 + j; lcol = 8 * j;
+            if (j >= nvalid) return;
+        }
+        const long long blk = (long long)(t.strip * C::CBR + brow) * cbw + gcol;
+        const int16_t* plane = (seg == 1 ? p.cb : p.cr) + (long long)t.frame * p.c_frame_stride;
+        const U4* src = reinterpret_cast<const U4*>(plane + blk * 64);
+#pragma unroll
+        for (int i = 0; i < 8; i++) raw[i] = src[i];
+        idct_block<true>(raw, p.qt + 64 * seg, px);
+        int16_t* dst = lds + C::YSZ + (seg - 1) * C::CSZ + (brow * 8) * C::CPITCH;
+        if (!halo) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) *reinterpret_cast<U4*>(dst + r * C::CPITCH + lcol) = px[r];
+        } else {
+            // only one pixel column of a halo block is ever read: its last (left) / first (right)
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t v = left ? (px[r].w >> 16) : (px[r].x & 0xffffu);
+                dst[r * C::CPITCH + (left ? C::COFF - 1 : lcol)] = (int16_t)v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Phase 2: up-sample + colour-convert + store.  One item = 16 consecutive pixels of one row.
+// ------------------------------------------------------------------------------------------------
+ZJ_DEV void store16(uint8_t* p, const U4& v) { *reinterpret_cast<U4*>(p) = v; }
+
+// 4 pixels -> 12 bytes.  EO arrangement: (e) holds px 0,2  (o) holds px 1,3.
+ZJ_DEV void pack_rgb4_eo(const RGB2& e, const RGB2& o, uint32_t& d0, uint32_t& d1, uint32_t& d2)
+{
+    const uint32_t rg_e = e.r | (e.g << 8); // R0 G0 R2 G2
+    const uint32_t gb_o = o.g | (o.b << 8); // G1 B1 G3 B3
+    const uint32_t br = e.b | (o.r << 8);   // B0 R1 B2 R3
+    d0 = perm(br, rg_e, 0x05040100u);       // R0 G0 B0 R1
+    d1 = perm(rg_e, gb_o, 0x07060100u);     // G1 B1 R2 G2
+    d2 = perm(gb_o, br, 0x07060302u);       // B2 R3 G3 B3
+}
+// natural arrangement: (a) holds px 0,1  (b) holds px 2,3
+ZJ_DEV void pack_rgb4_nat(const RGB2& a, const RGB2& b, uint32_t& d0, uint32_t& d1, uint32_t& d2)
+{
+    const uint32_t rg_a = a.r | (a.g << 8); // R0 G0 R1 G1
+    const uint32_t gb_a = a.g | (a.b << 8); // G0 B0 G1 B1
+    const uint32_t rg_b = b.r | (b.g << 8); // R2 G2 R3 G3
+    const uint32_t gb_b = b.g | (b.b << 8); // G2 B2 G3 B3
+    d0 = perm(a.b, rg_a, 0x02040100u);      // R0 G0 B0 R1
+    d1 = perm(rg_b, gb_a, 0x05040302u);     // G1 B1 R2 G2
+    const uint32_t x = perm(b.r, b.b, 0x00000600u); // B2 R3 . .
+    d2 = perm(gb_b, x, 0x07060100u);        // B2 R3 G3 B3
+}
+
+template <class C, int HS, int VS, int OUT>
+ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const int16_t* lds)
+{
+    const int P = p.mcu_x * 8 * HS;       // padded row length == luma width_stride (headers.rs:338)
+    const int W = p.width;
+    const int cbw = p.mcu_x;
+    const int cb0 = t.tile * C::TWC;
+    const int nvalid = (cbw - cb0) < C::TWC ? (cbw - cb0) : C::TWC;
+    const bool left_wrap = cb0 == 0, right_wrap = cb0 + C::TWC >= cbw;
+    const int x0 = t.tile * C::TWY;
+    const int ncomp = OUT == OUT_GRAY ? 1 : 3;
+    const long long row_bytes = (long long)W * ncomp;
+    uint8_t* const frame_out = p.out + (long long)t.frame * p.out_frame_stride;
+    const int elements = P / 16 - 1; // worker.rs:171 (P >= 32 on this path)
+
+    for (int item = tid; item < C::NITEMS; item += C::NT) {
+        const int m = item / C::NGRP, g = item % C::NGRP;
+        const int px0 = x0 + 16 * g;      // first pixel of the group in the padded row
+        const int row = t.strip * C::SH + m;
+        if (px0 >= P || row >= p.height) continue;
+        const U4* yrow = reinterpret_cast<const U4*>(lds + m * C::TWY + 16 * g);
+        const U4 ya = yrow[0], yb = yrow[1];
+        const uint32_t yw[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+        uint8_t* const orow = frame_out + (long long)row * row_bytes;
+
+        if (OUT == OUT_GRAY) {
+            // ycbcr_to_grayscale (color_convert/scalar.rs:91-114): `as u8` truncation (Q7)
+            U4 o;
+            o.x = perm(yw[1], yw[0], 0x06040200u); o.y = perm(yw[3], yw[2], 0x06040200u);
+            o.z = perm(yw[5], yw[4], 0x06040200u); o.w = perm(yw[7], yw[6], 0x06040200u);
+            store16(orow + px0, o); // fast path: W % 16 == 0
+            continue;
+        }
+
+        // ---- chroma for the 16 pixels, centred (value-128), packed pairs ------------------------
+        uint32_t cbp[8], crp[8]; // HS==2: [0..3] = E_k (px 4k, 4k+2), [4..7] = O_k (px 4k+1, 4k+3)
+                                 // HS==1: natural pairs (px 2k, 2k+1)
+        int ra, rb;
+        vrows<HS, VS>(m, ra, rb);
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+            const int16_t* cp = lds + C::YSZ + ch * C::CSZ;
+            uint32_t* dst = ch ? crp : cbp;
+            if (HS == 1) {
+                const U4* A = reinterpret_cast<const U4*>(cp + ra * C::CPITCH + 16 * g);
+                const U4 a0 = A[0], a1 = A[1];
+                uint32_t v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                if (VS == 2) {
+                    const U4* B = reinterpret_cast<const U4*>(cp + rb * C::CPITCH + 16 * g);
+                    const U4 b0 = B[0], b1 = B[1];
+                    const uint32_t f[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                    for (int k = 0; k < 8; k++) v[k] = tri(v[k], f[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) dst[k] = v[k];
+            } else {
+                const int lc = C::COFF + 8 * g; // LDS column of this group's first chroma sample
+                const U4 a = *reinterpret_cast<const U4*>(cp + ra * C::CPITCH + lc);
+                uint32_t vm[4] = {a.x, a.y, a.z, a.w}; // (v1,v2) (v3,v4) (v5,v6) (v7,v8)
+                if (VS == 2) {
+                    const U4 b = *reinterpret_cast<const U4*>(cp + rb * C::CPITCH + lc);
+                    vm[0] = tri(vm[0], b.x); vm[1] = tri(vm[1], b.y);
+                    vm[2] = tri(vm[2], b.z); vm[3] = tri(vm[3], b.w);
+                }
+                // flat-array neighbours (Q4): rows shift by one where the halo wrapped around
+                const bool first = (g == 0) && left_wrap;              // chroma column 0 of the strip
+                const bool last = (8 * g + 8 == 8 * nvalid) && right_wrap; // last chroma column
+                int v0 = 0, v9 = 0;
+                const bool no_left = first && m == 0, no_right = last && m == C::SH - 1;
+                if (!no_left) {
+                    int la, lb;
+                    vrows<HS, VS>(first ? m - 1 : m, la, lb);
+                    const int na = cp[la * C::CPITCH + lc - 1];
+                    v0 = VS == 2 ? tri1(na, cp[lb * C::CPITCH + lc - 1]) : na;
+                }
+                if (!no_right) {
+                    int la, lb;
+                    vrows<HS, VS>(last ? m + 1 : m, la, lb);
+                    const int na = cp[la * C::CPITCH + lc + 8];
+                    v9 = VS == 2 ? tri1(na, cp[lb * C::CPITCH + lc + 8]) : na;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t prev = k == 0 ? ((uint32_t)v0 << 16) : vm[k - 1];
+                    const uint32_t next = k == 3 ? ((uint32_t)v9 & 0xffffu) : vm[k + 1];
+                    const uint32_t L = align16(vm[k], prev); // (v_{2k},   v_{2k+1})
+                    const uint32_t R = align16(next, vm[k]); // (v_{2k+2}, v_{2k+3})
+                    dst[k] = tri(vm[k], L);                  // even outputs: px 4k, 4k+2
+                    dst[4 + k] = tri(vm[k], R);              // odd outputs:  px 4k+1, 4k+3
+                }
+                // the three unfiltered / mis-weighted samples of a strip (upsampler/scalar.rs:13,55,57)
+                if (no_left) dst[0] = (dst[0] & 0xffff0000u) | (vm[0] & 0xffffu);       // out[0] = in[0]
+                if (no_right) {
+                    const uint32_t o7 = dst[7];
+                    // out[2n-2] = (3*in[n-2] + in[n-1] + 2) >> 2  == the odd output of column n-2
+                    dst[3] = (dst[3] & 0x0000ffffu) | (o7 << 16);                        // px 14 <- O(px 13)
+                    dst[7] = (o7 & 0x0000ffffu) | (vm[3] & 0xffff0000u);                 // px 15 = in[n-1]
+                }
+            }
+        }
+
+        // ---- luma pairing to match the chroma arrangement ---------------------------------------
+        uint32_t yp[8];
+        if (HS == 2) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                yp[k] = perm(yw[2 * k + 1], yw[2 * k], 0x05040100u);     // (Y[4k],   Y[4k+2])
+                yp[4 + k] = perm(yw[2 * k + 1], yw[2 * k], 0x07060302u); // (Y[4k+1], Y[4k+3])
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) yp[k] = yw[k];
+        }
+
+        uint32_t d[12];
+        if (OUT == OUT_RGB) {
+            RGB2 c[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) c[k] = ycc_to_rgb_pair(yp[k], cbp[k], crp[k]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (HS == 2) pack_rgb4_eo(c[k], c[4 + k], d[3 * k], d[3 * k + 1], d[3 * k + 2]);
+                else pack_rgb4_nat(c[2 * k], c[2 * k + 1], d[3 * k], d[3 * k + 1], d[3 * k + 2]);
+            }
+        } else { // OUT_YCBCR: ycbcr_to_ycbcr (color_convert/scalar.rs:119-169), `as u8` truncation
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                cbp[k] = as_u32(as_u16x2(cbp[k]) + splat(128));
+                crp[k] = as_u32(as_u16x2(crp[k]) + splat(128));
+            }
+            RGB2 c[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { c[k].r = yp[k] & 0x00ff00ffu; c[k].g = cbp[k] & 0x00ff00ffu; c[k].b = crp[k] & 0x00ff00ffu; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (HS == 2) pack_rgb4_eo(c[k], c[4 + k], d[3 * k], d[3 * k + 1], d[3 * k + 2]);
+                else pack_rgb4_nat(c[2 * k], c[2 * k + 1], d[3 * k], d[3 * k + 1], d[3 * k + 2]);
+            }
+        }
+        const U4 s0 = {d[0], d[1], d[2], d[3]}, s1 = {d[4], d[5], d[6], d[7]}, s2 = {d[8], d[9], d[10], d[11]};
+        const int G = px0 >> 4; // 16-pixel group index in the row
+        if (OUT == OUT_YCBCR) {
+            uint8_t* o = orow + 48ll * G;
+            store16(o, s0); store16(o + 16, s1); store16(o + 32, s2);
+        } else {
+            // color_convert_ycbcr (worker.rs:166-250), W % 16 == 0, W >= 32:
+            //   groups 0..elements-1 at 48*G; the LAST 16 samples at 3W-64 (16 bytes early, Q5);
+            //   bytes [3W-16, 3W) of every row are never written by the reference (Q6).
+            if (G < elements - 1) {
+                uint8_t* o = orow + 48ll * G;
+                store16(o, s0); store16(o + 16, s1); store16(o + 32, s2);
+            } else if (G == elements - 1) {
+                uint8_t* o = orow + 48ll * G;
+                store16(o, s0); store16(o + 16, s1); // last 16 bytes are overwritten by the tail
+            } else {
+                uint8_t* o = orow + 3ll * W - 64;
+                store16(o, s0); store16(o + 16, s1); store16(o + 32, s2);
+                if (p.zero_fill) { const U4 z = {0, 0, 0, 0}; store16(o + 48, z); }
+            }
+        }
+    }
+}
+
+} // namespace zj

@@ -1,0 +1,203 @@
+// zj_kernels.hip -- gfx950 kernels of the pixel path and their launchers.
+//
+//   zj_fused_kernel<HS,VS,OUT>  whole hot path per tile: dequantize + IDCT -> LDS planar staging ->
+//                               up-sample + colour-convert -> global store.  One HBM read of the
+//                               coefficients, one HBM write of the pixels (6 B/px for 4:2:0->RGB).
+//   zj_idct_strip_kernel        IDCTPtr-compatible strip IDCT  (src/idct/scalar.rs:19)
+//   zj_upsample_{h,v}_kernel    UpSampler-compatible flat-array filters (src/upsampler/scalar.rs)
+//   zj_rgb16_kernel             ColorConvert16Ptr (src/color_convert/scalar.rs:52)
+#include <hip/hip_runtime.h>
+
+#include "zj_device.h"
+#include "zj_launch.h"
+
+namespace zj {
+
+// ------------------------------------------------------------------------------------------------
+// fused tile kernel
+// ------------------------------------------------------------------------------------------------
+template <int HS, int VS, int OUT>
+__global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT)) void zj_fused_kernel(const Params p)
+{
+    using C = Cfg<HS, VS, OUT>;
+    __shared__ __attribute__((aligned(16))) int16_t lds[C::LDS_I16];
+    const TileId t = decode_tile(p, (int)blockIdx.x);
+    phase_idct<C>(p, t, (int)threadIdx.x, lds);
+    __syncthreads();
+    phase_color<C, HS, VS, OUT>(p, t, (int)threadIdx.x, lds);
+}
+
+template <int HS, int VS, int OUT>
+static hipError_t launch_fused_t(const Params& p, hipStream_t s)
+{
+    using C = Cfg<HS, VS, OUT>;
+    if (p.total_tiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT>), dim3((unsigned)p.total_tiles), dim3(C::NT), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_fused(int hs, int vs, int out, const Params& p, hipStream_t s)
+{
+#define ZJ_CASE(H, V, O) if (hs == H && vs == V && out == O) return launch_fused_t<H, V, O>(p, s);
+    ZJ_CASE(1, 1, OUT_RGB) ZJ_CASE(1, 1, OUT_GRAY) ZJ_CASE(1, 1, OUT_YCBCR)
+    ZJ_CASE(2, 1, OUT_RGB) ZJ_CASE(2, 1, OUT_GRAY) ZJ_CASE(2, 1, OUT_YCBCR)
+    ZJ_CASE(1, 2, OUT_RGB) ZJ_CASE(1, 2, OUT_GRAY) ZJ_CASE(1, 2, OUT_YCBCR)
+    ZJ_CASE(2, 2, OUT_RGB) ZJ_CASE(2, 2, OUT_GRAY) ZJ_CASE(2, 2, OUT_YCBCR)
+#undef ZJ_CASE
+    return hipErrorInvalidValue;
+}
+
+const char* fused_kernel_name(int hs, int vs, int out)
+{
+    static const char* names[2][2][3] = {
+        {{"zj_fused_kernel<1,1,0>", "zj_fused_kernel<1,1,1>", "zj_fused_kernel<1,1,2>"},
+         {"zj_fused_kernel<1,2,0>", "zj_fused_kernel<1,2,1>", "zj_fused_kernel<1,2,2>"}},
+        {{"zj_fused_kernel<2,1,0>", "zj_fused_kernel<2,1,1>", "zj_fused_kernel<2,1,2>"},
+         {"zj_fused_kernel<2,2,0>", "zj_fused_kernel<2,2,1>", "zj_fused_kernel<2,2,2>"}}};
+    return names[hs - 1][vs - 1][out];
+}
+
+// ------------------------------------------------------------------------------------------------
+// strip-level kernels (fn-pointer compatible API; not the hot path)
+// ------------------------------------------------------------------------------------------------
+// dequantize_and_idct_int (src/idct/scalar.rs:19-282): one lane per block.  `out` pre-zeroed.
+__global__ __launch_bounds__(64) void zj_idct_strip_kernel(const int16_t* __restrict__ coeff,
+                                                           const int32_t* __restrict__ qt,
+                                                           int16_t* __restrict__ out, long long nblocks,
+                                                           long long chunks, long long bpc, long long stride)
+{
+    const long long j = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (j >= nblocks) return;
+    const long long c = j / bpc, k = j % bpc; // chunk, block within chunk (scalar.rs:32-40)
+    const U4* src = reinterpret_cast<const U4*>(coeff + c * chunks + k * 64);
+    U4 raw[8], px[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) raw[i] = src[i];
+    idct_block<false>(raw, qt, px);
+    int16_t* dst = out + c * chunks + k * 8; // pos = x = 8k (scalar.rs:277-278)
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(&px[r]);
+        int16_t* d = dst + r * stride; // arbitrary stride: 2-byte stores
+#pragma unroll
+        for (int i = 0; i < 4; i++) { d[2 * i] = (int16_t)(w[i] & 0xffff); d[2 * i + 1] = (int16_t)(w[i] >> 16); }
+    }
+}
+
+// upsample_horizontal (src/upsampler/scalar.rs:5-60), flat array; `out` pre-zeroed.
+__global__ void zj_upsample_h_kernel(const int16_t* __restrict__ in, long long n, int16_t* __restrict__ out,
+                                     long long out_len, long long m /* windows */)
+{
+    const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < m) {
+        const int s = (int16_t)(uint16_t)(3 * in[w + 1] + 2);
+        const long long o = 2 + 2 * w;
+        // the last two outputs are owned by the epilogue below (scalar.rs:46-57 runs after the loop)
+        if (o < out_len - 2) out[o] = (int16_t)((int16_t)(uint16_t)(s + in[w]) >> 2);
+        if (o + 1 < out_len - 2) out[o + 1] = (int16_t)((int16_t)(uint16_t)(s + in[w + 2]) >> 2);
+    }
+    if (w == 0) {
+        out[0] = in[0];
+        out[1] = (int16_t)tri1(in[0], in[1]);
+        out[out_len - 2] = (int16_t)tri1(in[n - 2], in[n - 1]);
+        out[out_len - 1] = in[n - 1];
+    }
+}
+
+// upsample_vertical (src/upsampler/scalar.rs:64-147): 8 input rows of `stride`; `out` pre-zeroed.
+__global__ void zj_upsample_v_kernel(const int16_t* __restrict__ in, long long stride,
+                                     int16_t* __restrict__ out, long long out_len)
+{
+    const long long x = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y; // pair 0..7
+    int n, f;
+    vsched(k, n, f);
+    const long long i = 2ll * k * stride;
+    const long long rem = out_len - i - stride;
+    const long long cnt = stride < rem ? stride : rem; // zip stops at the shortest (scalar.rs:110-127)
+    if (x >= cnt) return;
+    const int a = in[n * stride + x], b = in[f * stride + x];
+    out[i + x] = (int16_t)tri1(a, b);
+    out[i + stride + x] = (int16_t)tri1(b, a);
+}
+
+// ycbcr_to_rgb_16_scalar (src/color_convert/scalar.rs:52-89): 16 pixels -> 48 bytes
+__global__ void zj_rgb16_kernel(const int16_t* __restrict__ ycc /* y[16] cb[16] cr[16] */, uint8_t* __restrict__ out)
+{
+    const int i = threadIdx.x;
+    if (i >= 16) return;
+    const uint32_t y = (uint16_t)ycc[i], cb = (uint16_t)(ycc[16 + i] - 128), cr = (uint16_t)(ycc[32 + i] - 128);
+    const RGB2 c = ycc_to_rgb_pair(y, cb, cr);
+    out[3 * i] = (uint8_t)c.r; out[3 * i + 1] = (uint8_t)c.g; out[3 * i + 2] = (uint8_t)c.b;
+}
+
+hipError_t launch_idct_strip(const int16_t* coeff, const int32_t* qt, int16_t* out, long long nblocks,
+                             long long chunks, long long bpc, long long stride, hipStream_t s)
+{
+    if (nblocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(zj_idct_strip_kernel, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, s, coeff, qt,
+                       out, nblocks, chunks, bpc, stride);
+    return hipGetLastError();
+}
+hipError_t launch_upsample_h(const int16_t* in, long long n, int16_t* out, long long out_len, long long m, hipStream_t s)
+{
+    const long long work = m > 1 ? m : 1;
+    hipLaunchKernelGGL(zj_upsample_h_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, in, n, out, out_len, m);
+    return hipGetLastError();
+}
+hipError_t launch_upsample_v(const int16_t* in, long long stride, int16_t* out, long long out_len, hipStream_t s)
+{
+    hipLaunchKernelGGL(zj_upsample_v_kernel, dim3((unsigned)((stride + 255) / 256), 8), dim3(256), 0, s, in, stride, out, out_len);
+    return hipGetLastError();
+}
+hipError_t launch_rgb16(const int16_t* ycc, uint8_t* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(zj_rgb16_kernel, dim3(1), dim3(64), 0, s, ycc, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// integer-VALU micro-benchmark (tools/ubench.py): issue rate of the ops the IDCT design relies on
+// ------------------------------------------------------------------------------------------------
+template <int OP>
+__global__ __launch_bounds__(256) void zj_ubench_kernel(int* out, int iters, int seed)
+{
+    int a[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = seed * (i + 1) + (int)threadIdx.x;
+    const int k = seed | 1;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (OP == 0) a[i] = a[i] + k;                                        // v_add_u32
+                else if (OP == 1) a[i] = (int)((unsigned)a[i] * (unsigned)k);        // v_mul_lo_u32
+                else if (OP == 2) a[i] = __mul24(a[i], k);                           // v_mul_i32_i24
+                else if (OP == 3) a[i] = __mul24(a[i], k) + a[(i + 1) & 7];          // v_mad_i32_i24
+                else if (OP == 4) a[i] = as_u32(as_u16x2((uint32_t)a[i]) * as_u16x2((uint32_t)k)); // v_pk_mul_lo_u16
+                else if (OP == 5) a[i] = as_u32(as_u16x2((uint32_t)a[i]) * as_u16x2((uint32_t)k) + as_u16x2((uint32_t)a[(i + 1) & 7])); // v_pk_mad_u16
+                else if (OP == 6) a[i] = (a[i] >> 3) + k;                            // shift + add
+                else if (OP == 7) a[i] = (int)__builtin_amdgcn_perm((unsigned)a[i], (unsigned)a[(i + 1) & 7], 0x07060100u); // v_perm_b32
+                else if (OP == 8) { int v = a[i] + k; a[i] = v < 0 ? 0 : (v > 255 ? 255 : v) + it; } // add + med3 + add
+            }
+        }
+    }
+    int acc = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc ^= a[i];
+    if (acc == 0x7fffffff) out[blockIdx.x * blockDim.x + threadIdx.x] = acc; // never true in practice; keeps the chain live
+}
+
+hipError_t launch_ubench(int op, int* out, int blocks, int iters, int seed, hipStream_t s)
+{
+#define ZJ_UB(O) case O: hipLaunchKernelGGL((zj_ubench_kernel<O>), dim3(blocks), dim3(256), 0, s, out, iters, seed); break;
+    switch (op) {
+        ZJ_UB(0) ZJ_UB(1) ZJ_UB(2) ZJ_UB(3) ZJ_UB(4) ZJ_UB(5) ZJ_UB(6) ZJ_UB(7) ZJ_UB(8)
+    default: return hipErrorInvalidValue;
+    }
+#undef ZJ_UB
+    return hipGetLastError();
+}
+
+} // namespace zj

@@ -1,0 +1,16 @@
+// zj_launch.h -- launcher prototypes shared by zj_kernels.hip and zj_api.cpp
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "zj_device.h"
+
+namespace zj {
+hipError_t launch_fused(int hs, int vs, int out, const Params& p, hipStream_t s);
+const char* fused_kernel_name(int hs, int vs, int out);
+hipError_t launch_idct_strip(const int16_t* coeff, const int32_t* qt, int16_t* out, long long nblocks,
+                             long long chunks, long long bpc, long long stride, hipStream_t s);
+hipError_t launch_upsample_h(const int16_t* in, long long n, int16_t* out, long long out_len, long long m, hipStream_t s);
+hipError_t launch_upsample_v(const int16_t* in, long long stride, int16_t* out, long long out_len, hipStream_t s);
+hipError_t launch_rgb16(const int16_t* ycc, uint8_t* out, hipStream_t s);
+hipError_t launch_ubench(int op, int* out, int blocks, int iters, int seed, hipStream_t s);
+} // namespace zj

@@ -1,0 +1,110 @@
+// zj_plan.h -- host-side geometry/launch planning shared by the product library (zj_api.cpp) and the
+// CPU emulation harness used by the CPU test-suite (tests/emu).  No device code here.
+//
+// Geometry follows src/headers.rs:306-339 (mcu_x, mcu_y, width_stride) and the strip loop of
+// src/mcu_prog.rs:132-246 / src/mcu.rs:139-230 (paths relative to the reference tree).
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/zjhip.h"
+#include "zj_device.h"
+
+namespace zj {
+
+struct Plan {
+    int hs, vs;          // luma sampling factors
+    int out;             // OUT_RGB / OUT_GRAY / OUT_YCBCR
+    int mcu_x, mcu_y;
+    int n_strips;        // strips the reference's zip() would process
+    int strip_rows;      // luma rows per strip
+    int tiles_per_row;
+    int nt;              // threads per workgroup
+    size_t y_len, c_len; // i16 elements per plane
+    size_t out_len;      // bytes per frame
+    int ncomp_out;
+    bool fast;           // aligned fast path (W % 16 == 0, W >= 32)
+    int rows_covered;    // n_strips * strip_rows; rows below stay 0 in the reference (Q6)
+};
+
+inline int ncomp_of(int cs)
+{
+    switch (cs) {
+    case ZJ_CS_RGB: case ZJ_CS_YCBCR: return 3;
+    case ZJ_CS_GRAYSCALE: return 1;
+    case ZJ_CS_CMYK: case ZJ_CS_YCCK: case ZJ_CS_RGBA: case ZJ_CS_RGBX: return 4;
+    default: return 0;
+    }
+}
+
+template <int HS, int VS>
+inline void plan_geo(Plan& pl, bool chroma)
+{
+    using G = Geo<HS, VS>;
+    pl.strip_rows = G::SH;
+    pl.tiles_per_row = (pl.mcu_x + G::TWC - 1) / G::TWC;
+    pl.nt = G::NYB64 + (chroma ? 2 * G::NCB64 : 0);
+}
+
+// Returns ZJ_OK or an error status.
+inline int make_plan(const zj_frame_desc* d, Plan& pl)
+{
+    if (!d || d->width == 0 || d->height == 0) return ZJ_ERR_ARG;
+    if (!((d->h_max == 1 || d->h_max == 2) && (d->v_max == 1 || d->v_max == 2))) return ZJ_ERR_ARG;
+    if (d->in_components != 1 && d->in_components != 3) return ZJ_ERR_ARG;
+    if (d->width > 65535 || d->height > 65535) return ZJ_ERR_ARG; // u16 in the reference (decoder.rs:652)
+    const int nout = ncomp_of(d->out_colorspace);
+    if (nout == 0) return ZJ_ERR_ARG;
+    // grayscale JPEG with a down-sampled component (mcu.rs:170-196) is reset to (1,1) by the
+    // reference with a warning; callers must pass (1,1) here.
+    if (d->in_components == 1 && (d->h_max != 1 || d->v_max != 1)) return ZJ_ERR_UNSUPPORTED;
+    for (int c = 0; c < 3; c++)
+        for (int k = 0; k < 64; k++)
+            if (d->qt[c][k] < 0 || d->qt[c][k] > 255) return ZJ_ERR_UNSUPPORTED; // 8-bit DQT only
+    pl.hs = (int)d->h_max;
+    pl.vs = (int)d->v_max;
+    if (d->out_colorspace == ZJ_CS_GRAYSCALE) pl.out = OUT_GRAY;
+    else if (d->out_colorspace == ZJ_CS_RGB && d->in_components == 3) pl.out = OUT_RGB;
+    else if (d->out_colorspace == ZJ_CS_YCBCR && d->in_components == 3) pl.out = OUT_YCBCR;
+    else return ZJ_ERR_UNSUPPORTED; // RGBA/RGBX are malformed in the reference, CMYK/YCCK no-ops
+    pl.ncomp_out = nout;
+    pl.mcu_x = (int)((d->width + 8 * d->h_max - 1) / (8 * d->h_max));  // headers.rs:317
+    pl.mcu_y = (int)((d->height + 8 * d->v_max - 1) / (8 * d->v_max)); // headers.rs:319
+    pl.y_len = (size_t)pl.mcu_x * 64 * d->v_max * d->h_max * pl.mcu_y; // mcu_prog.rs:76
+    pl.c_len = d->in_components == 3 ? (size_t)pl.mcu_x * 64 * pl.mcu_y : 0;
+    pl.out_len = (size_t)d->width * d->height * nout;
+    const bool chroma = pl.out != OUT_GRAY;
+    if (pl.hs == 1 && pl.vs == 1) plan_geo<1, 1>(pl, chroma);
+    else if (pl.hs == 2 && pl.vs == 1) plan_geo<2, 1>(pl, chroma);
+    else if (pl.hs == 1 && pl.vs == 2) plan_geo<1, 2>(pl, chroma);
+    else plan_geo<2, 2>(pl, chroma);
+    // strips: (2,1) and (2,2) take two MCU rows per strip, an odd last MCU row is dropped by
+    // chunks_exact (mcu_prog.rs:191-205; mcu.rs:145-156 `mcu_y / 2`)
+    const int mcu_rows_per_strip = (pl.hs == 2) ? 2 : 1;
+    pl.n_strips = pl.mcu_y / mcu_rows_per_strip;
+    // the zip with out_chunks (mcu_prog.rs:188-189) can only cut it shorter on absurd aspect ratios
+    const size_t interleaved = (pl.hs != 1 || pl.vs != 1) ? 1 : 0;
+    const size_t total = ((size_t)d->width + 8) * ((size_t)d->height + 8) * nout + interleaved * 128 * d->height * nout;
+    const size_t chunk = (size_t)d->width * nout * 8 * d->h_max * d->v_max;
+    if (total / chunk < (size_t)pl.n_strips) pl.n_strips = (int)(total / chunk);
+    pl.fast = (d->width % 16 == 0) && d->width >= 32;
+    pl.rows_covered = pl.n_strips * pl.strip_rows;
+    return ZJ_OK;
+}
+
+inline void fill_params(const zj_frame_desc* d, const Plan& pl, size_t nframes, const int16_t* y,
+                        const int16_t* cb, const int16_t* cr, uint8_t* out, const int32_t* d_qt,
+                        int zero_fill, Params& p)
+{
+    p.y = y; p.cb = cb; p.cr = cr; p.out = out; p.qt = d_qt;
+    p.y_frame_stride = (long long)pl.y_len;
+    p.c_frame_stride = (long long)pl.c_len;
+    p.out_frame_stride = (long long)pl.out_len;
+    p.width = (int)d->width; p.height = (int)d->height;
+    p.mcu_x = pl.mcu_x; p.n_strips = pl.n_strips; p.tiles_per_row = pl.tiles_per_row;
+    p.nframes = (int)nframes; p.zero_fill = zero_fill;
+    p.total_tiles = (int)nframes * pl.n_strips * pl.tiles_per_row;
+}
+
+} // namespace zj

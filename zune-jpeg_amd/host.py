@@ -1,0 +1,329 @@
+"""
+host.py -- ctypes binding of libzjhip.so mirroring the reference's interface for the pixel path.
+
+Names follow the reference (paths relative to the zune-jpeg tree):
+  ColorSpace                         src/misc.rs:88-121
+  ZuneJpegOptions                    src/options.rs:6-160 (+ a `backend` knob: scalar / avx2 / hip)
+  choose_idct_func                   src/idct.rs:40
+  choose_upsample_func               Decoder::set_upsampling, src/decoder.rs:468-523
+  choose_ycbcr_to_rgb_convert_func   src/color_convert.rs:61
+  Context.post_process               src/worker.rs:32
+  Context.decode_planes              strip loop of src/mcu_prog.rs:132-246 over whole-image planes
+
+Only the HIP arm exists here; asking for scalar/avx2 raises ZjError(ZJ_ERR_BACKEND) because those
+arms live in the host application (the Rust crate), not in this library.
+"""
+import ctypes as C
+import enum
+import os
+
+import numpy as np
+
+BACKEND_SCALAR, BACKEND_AVX2, BACKEND_HIP = 0, 1, 2
+
+OK, ERR_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM, ERR_PANIC, ERR_NO_DEVICE, ERR_BACKEND = 0, -1, -2, -3, -4, -5, -6, -7
+
+
+class ColorSpace(enum.IntEnum):  # src/misc.rs:88-106
+    RGB = 0
+    GRAYSCALE = 1
+    YCbCr = 2
+    CMYK = 3
+    YCCK = 4
+    RGBA = 5
+    RGBX = 6
+
+    def num_components(self):  # src/misc.rs:113-121
+        return {0: 3, 2: 3, 1: 1}.get(int(self), 4)
+
+
+def num_components(cs):
+    return ColorSpace(cs).num_components()
+
+
+class ZjError(RuntimeError):
+    def __init__(self, status, what=""):
+        self.status = status
+        msg = what
+        try:
+            msg = f"{what}: {lib().zj_strerror(status).decode()}"
+        except Exception:
+            pass
+        super().__init__(f"[zj status {status}] {msg}")
+
+
+class Component(C.Structure):  # zj_component  <->  Components, src/components.rs:18-43
+    _fields_ = [("horizontal_sample", C.c_size_t), ("vertical_sample", C.c_size_t),
+                ("width_stride", C.c_size_t), ("quantization_table", C.c_int32 * 64)]
+
+
+class FrameDesc(C.Structure):  # zj_frame_desc
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("h_max", C.c_uint32),
+                ("v_max", C.c_uint32), ("in_components", C.c_uint32), ("out_colorspace", C.c_int32),
+                ("qt", (C.c_int32 * 64) * 3)]
+
+    @classmethod
+    def make(cls, width, height, h_max, v_max, in_components, out_colorspace, qts):
+        d = cls()
+        d.width, d.height, d.h_max, d.v_max = width, height, h_max, v_max
+        d.in_components, d.out_colorspace = in_components, int(out_colorspace)
+        for c in range(3):
+            q = np.asarray(qts[min(c, len(qts) - 1)], np.int32).reshape(64)
+            C.memmove(d.qt[c], q.ctypes.data, 256)
+        return d
+
+
+class ZuneJpegOptions:
+    """Mirror of src/options.rs:6-40 (defaults :26-40) plus the dispatch knob."""
+
+    def __init__(self):
+        self.use_unsafe = True
+        self.out_colorspace = ColorSpace.RGB
+        self.num_threads = 4
+        self.max_width = 16384
+        self.max_height = 16384
+        self.max_scans = 64
+        self.strict_mode = False
+        self.backend = BACKEND_HIP
+        self.device = 0
+
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+ABI = [  # every symbol include/zjhip.h declares
+    "zj_abi_version", "zj_device_count", "zj_ctx_create", "zj_ctx_destroy", "zj_default_ctx",
+    "zj_strerror", "zj_last_error", "zj_idct_strip", "zj_upsample_h", "zj_upsample_v",
+    "zj_upsample_hv", "zj_ycbcr_to_rgb16", "zj_post_process_strip", "zj_choose_idct_func",
+    "zj_choose_upsample_func", "zj_choose_ycbcr_to_rgb_convert_func", "zj_plane_len", "zj_out_len",
+    "zj_num_components", "zj_decode_planes", "zj_decode_planes_batch", "zj_decode_planes_device",
+    "zj_time_decode_device", "zj_alloc_pinned", "zj_free_pinned", "zj_device_alloc",
+    "zj_device_free", "zj_memcpy_h2d", "zj_memcpy_d2h", "zj_sync",
+]
+
+
+def abi_symbols():
+    return list(ABI)
+
+
+def lib_path():
+    return os.path.join(_HERE, "libzjhip.so")
+
+
+def lib():
+    """Loads libzjhip.so; raises (never falls back) when it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not os.path.exists(p):
+        raise ImportError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C zune-jpeg_amd/csrc` (there is no CPU fallback)")
+    L = C.CDLL(p)
+    vp, sz, i16p, i32p, u8p = C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p
+    L.zj_strerror.restype = C.c_char_p
+    L.zj_strerror.argtypes = [C.c_int]
+    L.zj_last_error.restype = C.c_char_p
+    L.zj_last_error.argtypes = [vp]
+    L.zj_ctx_create.restype = vp
+    L.zj_ctx_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.zj_ctx_destroy.argtypes = [vp]
+    L.zj_default_ctx.restype = vp
+    L.zj_plane_len.restype = sz
+    L.zj_plane_len.argtypes = [C.POINTER(FrameDesc), C.c_int]
+    L.zj_out_len.restype = sz
+    L.zj_out_len.argtypes = [C.POINTER(FrameDesc)]
+    L.zj_idct_strip.argtypes = [vp, i16p, sz, i32p, sz, sz, sz, i16p]
+    for f in (L.zj_upsample_h, L.zj_upsample_v, L.zj_upsample_hv):
+        f.argtypes = [vp, i16p, sz, i16p, sz]
+    L.zj_ycbcr_to_rgb16.argtypes = [vp, i16p, i16p, i16p, u8p, sz, C.POINTER(sz)]
+    L.zj_post_process_strip.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(sz), C.POINTER(Component),
+                                        C.c_int, C.c_int, u8p, sz, sz]
+    L.zj_decode_planes.argtypes = [vp, C.POINTER(FrameDesc), i16p, i16p, i16p, u8p]
+    L.zj_decode_planes_batch.argtypes = [vp, C.POINTER(FrameDesc), sz, i16p, i16p, i16p, u8p]
+    L.zj_decode_planes_device.argtypes = [vp, C.POINTER(FrameDesc), sz, vp, vp, vp, vp, vp]
+    L.zj_time_decode_device.argtypes = [vp, C.POINTER(FrameDesc), sz, vp, vp, vp, vp, vp, C.c_int,
+                                        C.POINTER(C.c_float), C.POINTER(C.c_char_p)]
+    L.zj_alloc_pinned.restype = vp
+    L.zj_alloc_pinned.argtypes = [sz]
+    L.zj_free_pinned.argtypes = [vp]
+    L.zj_device_alloc.restype = vp
+    L.zj_device_alloc.argtypes = [vp, sz]
+    L.zj_device_free.argtypes = [vp, vp]
+    L.zj_memcpy_h2d.argtypes = [vp, vp, vp, sz]
+    L.zj_memcpy_d2h.argtypes = [vp, vp, vp, sz]
+    L.zj_sync.argtypes = [vp]
+    L.zj_choose_idct_func.restype = vp
+    L.zj_choose_idct_func.argtypes = [C.c_int]
+    L.zj_choose_upsample_func.restype = vp
+    L.zj_choose_upsample_func.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.zj_choose_ycbcr_to_rgb_convert_func.restype = vp
+    L.zj_choose_ycbcr_to_rgb_convert_func.argtypes = [C.c_int, C.c_int]
+    L.zj_ubench.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    _LIB = L
+    return L
+
+
+def device_count():
+    return lib().zj_device_count()
+
+
+def _check(rc, what, ctx=None):
+    if rc != OK:
+        detail = what
+        if rc == ERR_HIP and ctx is not None:
+            detail = f"{what} ({lib().zj_last_error(ctx).decode()})"
+        raise ZjError(rc, detail)
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def _i16(a):
+    return np.ascontiguousarray(a, dtype=np.int16)
+
+
+IDCT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
+                      C.c_size_t, C.c_void_p)
+UPSAMPLE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t)
+CC16_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                      C.POINTER(C.c_size_t))
+
+
+def _fn_or_raise(addr, proto, what):
+    if not addr:
+        raise ZjError(ERR_BACKEND, what)
+    return proto(addr)
+
+
+def choose_idct_func(backend=BACKEND_HIP):
+    """src/idct.rs:40 -- returns the C function pointer of the chosen arm (HIP only)."""
+    return _fn_or_raise(lib().zj_choose_idct_func(backend), IDCT_FN, "choose_idct_func")
+
+
+def choose_upsample_func(backend, h_max, v_max):
+    """Decoder::set_upsampling, src/decoder.rs:468-523."""
+    return _fn_or_raise(lib().zj_choose_upsample_func(backend, h_max, v_max), UPSAMPLE_FN, "choose_upsample_func")
+
+
+def choose_ycbcr_to_rgb_convert_func(backend, out_cs=ColorSpace.RGB):
+    """src/color_convert.rs:61"""
+    return _fn_or_raise(lib().zj_choose_ycbcr_to_rgb_convert_func(backend, int(out_cs)), CC16_FN,
+                        "choose_ycbcr_to_rgb_convert_func")
+
+
+class Context:
+    """zj_ctx: one HIP stream + scratch buffers on one device."""
+
+    def __init__(self, backend=BACKEND_HIP, device=0):
+        st = C.c_int(0)
+        self._h = lib().zj_ctx_create(backend, device, C.byref(st))
+        if not self._h:
+            raise ZjError(st.value, "zj_ctx_create")
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().zj_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    # ---- strip level (fn-pointer compatible) -------------------------------------------------
+    def idct_strip(self, coeff, qt, stride, samp_factors, v_samp):
+        """IDCTPtr: dequantize_and_idct_int(vector, qt_table, stride, samp_factors, v_samp)."""
+        coeff = _i16(coeff)
+        qt = np.ascontiguousarray(qt, dtype=np.int32)
+        out = np.empty(coeff.size, np.int16)
+        _check(lib().zj_idct_strip(self._h, _ptr(coeff), coeff.size, _ptr(qt), stride, samp_factors, v_samp,
+                                   _ptr(out)), "zj_idct_strip", self._h)
+        return out
+
+    def _ups(self, fn, inp, out_len, what):
+        inp = _i16(inp)
+        out = np.empty(out_len, np.int16)
+        _check(fn(self._h, _ptr(inp), inp.size, _ptr(out), out_len), what, self._h)
+        return out
+
+    def upsample_horizontal(self, inp, output_len):
+        return self._ups(lib().zj_upsample_h, inp, output_len, "zj_upsample_h")
+
+    def upsample_vertical(self, inp, output_len):
+        return self._ups(lib().zj_upsample_v, inp, output_len, "zj_upsample_v")
+
+    def upsample_hv(self, inp, output_len):
+        return self._ups(lib().zj_upsample_hv, inp, output_len, "zj_upsample_hv")
+
+    def ycbcr_to_rgb_16(self, y, cb, cr, output, pos):
+        """ColorConvert16Ptr; returns the new pos."""
+        y, cb, cr = _i16(y), _i16(cb), _i16(cr)
+        p = C.c_size_t(pos)
+        _check(lib().zj_ycbcr_to_rgb16(self._h, _ptr(y), _ptr(cb), _ptr(cr), _ptr(output), output.size,
+                                       C.byref(p)), "zj_ycbcr_to_rgb16", self._h)
+        return p.value
+
+    def post_process(self, coeff, comps, in_cs, out_cs, output, width):
+        """post_process(coeff, component_data, .., input_colorspace, output_colorspace, output, width)"""
+        arrs = [_i16(c) for c in coeff]
+        while len(arrs) < 3:
+            arrs.append(np.zeros(0, np.int16))
+        ptrs = (C.c_void_p * 3)(*[a.ctypes.data if a.size else None for a in arrs])
+        lens = (C.c_size_t * 3)(*[a.size for a in arrs])
+        _check(lib().zj_post_process_strip(self._h, ptrs, lens, comps, int(in_cs), int(out_cs), _ptr(output),
+                                           output.size, width), "zj_post_process_strip", self._h)
+
+    # ---- frame level ---------------------------------------------------------------------------
+    def decode_planes(self, desc, planes, nframes=1):
+        arrs = [_i16(p) for p in planes]
+        while len(arrs) < 3:
+            arrs.append(np.zeros(8, np.int16))
+        out = np.empty(nframes * lib().zj_out_len(C.byref(desc)), np.uint8)
+        _check(lib().zj_decode_planes_batch(self._h, C.byref(desc), nframes, _ptr(arrs[0]), _ptr(arrs[1]),
+                                            _ptr(arrs[2]), _ptr(out)), "zj_decode_planes_batch", self._h)
+        return out
+
+    def decode_planes_device(self, desc, nframes, d_y, d_cb, d_cr, d_out, stream=None):
+        """Device pointers (ints), asynchronous on `stream` (int handle or None = ctx stream)."""
+        _check(lib().zj_decode_planes_device(self._h, C.byref(desc), nframes, d_y, d_cb, d_cr, d_out, stream),
+               "zj_decode_planes_device", self._h)
+
+    def time_decode_device(self, desc, nframes, d_y, d_cb, d_cr, d_out, iters, stream=None):
+        """HIP-event time (ms) of `iters` launches on the launch stream; returns (ms, kernel name)."""
+        ms = C.c_float(0)
+        name = C.c_char_p()
+        _check(lib().zj_time_decode_device(self._h, C.byref(desc), nframes, d_y, d_cb, d_cr, d_out, stream,
+                                           iters, C.byref(ms), C.byref(name)), "zj_time_decode_device", self._h)
+        return ms.value, (name.value or b"").decode()
+
+    def device_alloc(self, nbytes):
+        p = lib().zj_device_alloc(self._h, nbytes)
+        if not p:
+            raise ZjError(ERR_NOMEM, "zj_device_alloc")
+        return p
+
+    def device_free(self, p):
+        lib().zj_device_free(self._h, p)
+
+    def h2d(self, dst, arr):
+        arr = np.ascontiguousarray(arr)
+        _check(lib().zj_memcpy_h2d(self._h, dst, _ptr(arr), arr.nbytes), "zj_memcpy_h2d", self._h)
+
+    def d2h(self, arr, src):
+        _check(lib().zj_memcpy_d2h(self._h, _ptr(arr), src, arr.nbytes), "zj_memcpy_d2h", self._h)
+
+    def sync(self):
+        _check(lib().zj_sync(self._h), "zj_sync", self._h)
+
+    def ubench(self, op, blocks=2048, iters=200, reps=5):
+        ms = C.c_float(0)
+        _check(lib().zj_ubench(self._h, op, blocks, iters, reps, C.byref(ms)), "zj_ubench", self._h)
+        return ms.value / reps
