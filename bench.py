@@ -116,8 +116,7 @@ def main():
 
     # dominant-kernel duration, HIP events recorded on the launch stream (outside the timed region)
     kiters = max(10, min(args.steps, 50))
-    kms, kname = ctx.time_decode_device(desc, B, ptrs[0], ptrs[1], ptrs[2], ptrs[3], kiters, stream)
-    kernel_ms = kms / kiters
+    kernel_ms, kernel_ms_each, kname = ctx.time_decode_device(desc, B, ptrs[0], ptrs[1], ptrs[2], ptrs[3], kiters, stream)
     # trivial gather: per-rank checksum of frame 0 (all ranks decode the same synthetic seeds modulo shard)
     torch.cuda.synchronize()
     first = d_out[: W * H * 3].cpu().numpy()
@@ -143,7 +142,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": (tr or {}).get("hbm_bytes_per_launch"),
-                         "kernel": kname, "kernel_ms": round(kernel_ms, 4),
+                         "kernel": kname, "kernel_ms": round(kernel_ms, 4), "kernel_ms_single_launch": round(kernel_ms_each, 4),
                          "algorithmic_bytes_per_launch": int(algo_bytes),
                          "traffic_source": (tr or {}).get("source")},
             # every rank's first frame is synthetic frame (rank*B) % distinct: identical data when B % distinct == 0

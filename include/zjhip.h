@@ -142,11 +142,12 @@ int zj_decode_planes_batch(zj_ctx *ctx, const zj_frame_desc *d, size_t nframes, 
 int zj_decode_planes_device(zj_ctx *ctx, const zj_frame_desc *d, size_t nframes,
                             const int16_t *d_y, const int16_t *d_cb, const int16_t *d_cr,
                             uint8_t *d_out, void *stream);
-/* Times `iters` back-to-back zj_decode_planes_device calls with HIP events recorded on the
- * launch stream; returns total milliseconds and the name of the dominant kernel. */
+/* Times zj_decode_planes_device with HIP events recorded on the launch stream: *ms_total = `iters`
+ * back-to-back launches between one event pair; *ms_each (optional) = mean over `iters` launches
+ * each bracketed by its own event pair; *kernel_name = the dominant kernel. */
 int zj_time_decode_device(zj_ctx *ctx, const zj_frame_desc *d, size_t nframes, const int16_t *d_y,
                           const int16_t *d_cb, const int16_t *d_cr, uint8_t *d_out, void *stream,
-                          int iters, float *ms_total, const char **kernel_name);
+                          int iters, float *ms_total, float *ms_each, const char **kernel_name);
 
 /* ---- memory helpers ------------------------------------------------------------------------- */
 void *zj_alloc_pinned(size_t bytes); /* hipHostMalloc; NULL on failure */

@@ -31,6 +31,17 @@ def main():
                 if name is None or v is None:
                     continue
                 vals.setdefault(name, []).append(float(v))
+    dbs = glob.glob(os.path.join(a.dir, "**", "*.db"), recursive=True)  # rocpd (sqlite) output format
+    for f in dbs:
+        import sqlite3
+        try:
+            cur = sqlite3.connect(f).cursor()
+            for kname, cname, v in cur.execute("select kernel_name, counter_name, value from counters_collection"):
+                if a.kernel in (kname or ""):
+                    vals.setdefault(cname, []).append(float(v))
+        except Exception as e:  # noqa: BLE001
+            print("skip", f, e)
+    files += dbs
     out = {"source": f"rocprofv3 --pmc, {len(files)} csv file(s) {a.tag}".strip(), "kernel": a.kernel, "counters": {}}
     for k, v in vals.items():
         out["counters"][k] = {"launches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}

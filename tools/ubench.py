@@ -1,30 +1,29 @@
 #!/usr/bin/env python3
-"""Integer-VALU issue-rate micro-benchmark on the GPU (needs libzjhip.so and a device).
-Reports lane-ops/s per op kind relative to v_add_u32; decides e.g. whether v_mul_lo_u32 is
-quarter-rate on gfx950 (it is why the IDCT uses v_mul_i32_i24 / v_mad_i32_i24)."""
+"""Issue cost of gfx950 integer VALU instructions (inline-asm kernels in csrc/zj_ubench.hip), in
+cycles per wave64 instruction per SIMD.  Needs libzjhip.so and a GPU.  The result table drives the
+instruction selection of the IDCT / colour code (DESIGN.md "VALU cost model")."""
 import importlib
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-OPS = ["v_add_u32", "v_mul_lo_u32", "v_mul_i32_i24", "v_mad_i32_i24 (mul24+add)", "v_pk_mul_lo_u16",
-       "v_pk_mad_u16 (pk mul+add)", "v_ashrrev+v_add (2 ops)", "v_perm_b32", "add+med3+add (3 ops)"]
-NOPS = [1, 1, 1, 1, 1, 1, 2, 1, 3]
 
 
 def main():
     zj = importlib.import_module("zune-jpeg_amd")
+    L = zj.lib()
     ctx = zj.Context()
-    blocks, iters = 4096, 400
-    per_launch = blocks * 256 * iters * 64  # statements executed per launch
-    base = None
-    print(f"{'op':32s} {'ms':>9s} {'G stmts/s':>12s} {'rel. to add':>12s}")
-    for op, name in enumerate(OPS):
+    mhz = ctx.ubench_clock_mhz()
+    blocks, iters = 4096, 200            # 16 blocks per CU -> 8 waves per SIMD resident
+    n_simd = 256 * 4
+    wave_instr = blocks * 4 * iters * 64  # wave-instructions per launch
+    print(f"shader clock during a 1-wave spin: {mhz:.0f} MHz (s_memtime / event time)")
+    print(f"{'instruction':40s} {'ms':>8s} {'cyc/wave-instr/SIMD @clk':>26s}")
+    for op in range(L.zj_ubench_count()):
         ms = ctx.ubench(op, blocks, iters, 5)
-        rate = per_launch / (ms * 1e-3) / 1e9
-        base = base or rate
-        print(f"{name:32s} {ms:9.3f} {rate:12.1f} {rate / base:12.3f}   ({NOPS[op]} VALU op(s) per statement)")
+        cyc = ms * 1e-3 * mhz * 1e6 / (wave_instr / n_simd)
+        print(f"{L.zj_ubench_name(op).decode():40s} {ms:8.3f} {cyc:26.2f}")
     ctx.close()
 
 

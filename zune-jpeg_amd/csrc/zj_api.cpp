@@ -248,7 +248,7 @@ int zj_decode_planes_device(zj_ctx* c, const zj_frame_desc* d, size_t nframes, c
 
 int zj_time_decode_device(zj_ctx* c, const zj_frame_desc* d, size_t nframes, const int16_t* d_y,
                           const int16_t* d_cb, const int16_t* d_cr, uint8_t* d_out, void* stream,
-                          int iters, float* ms_total, const char** kernel_name)
+                          int iters, float* ms_total, float* ms_each, const char** kernel_name)
 {
     Plan pl;
     int rc = check_frame_args(c, d, nframes, d_y, d_cb, d_cr, d_out, pl);
@@ -257,6 +257,7 @@ int zj_time_decode_device(zj_ctx* c, const zj_frame_desc* d, size_t nframes, con
     ZJ_HIP(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     if (kernel_name) *kernel_name = fused_kernel_name(pl.hs, pl.vs, pl.out);
+    // (1) `iters` back-to-back launches between one event pair
     ZJ_HIP(c, hipEventRecord(c->ev0, s));
     for (int i = 0; i < iters; i++) {
         rc = decode_device_impl(c, d, pl, nframes, d_y, d_cb, d_cr, d_out, s, 1);
@@ -265,6 +266,21 @@ int zj_time_decode_device(zj_ctx* c, const zj_frame_desc* d, size_t nframes, con
     ZJ_HIP(c, hipEventRecord(c->ev1, s));
     ZJ_HIP(c, hipEventSynchronize(c->ev1));
     ZJ_HIP(c, hipEventElapsedTime(ms_total, c->ev0, c->ev1));
+    // (2) every launch bracketed by its own event pair: the per-dispatch duration a profiler reports
+    if (ms_each) {
+        double sum = 0;
+        for (int i = 0; i < iters; i++) {
+            ZJ_HIP(c, hipEventRecord(c->ev0, s));
+            rc = decode_device_impl(c, d, pl, nframes, d_y, d_cb, d_cr, d_out, s, 1);
+            if (rc) return rc;
+            ZJ_HIP(c, hipEventRecord(c->ev1, s));
+            ZJ_HIP(c, hipEventSynchronize(c->ev1));
+            float t = 0;
+            ZJ_HIP(c, hipEventElapsedTime(&t, c->ev0, c->ev1));
+            sum += t;
+        }
+        *ms_each = (float)(sum / iters);
+    }
     return ZJ_OK;
 }
 
@@ -465,19 +481,39 @@ zj_color_convert16_fn zj_choose_ycbcr_to_rgb_convert_func(int backend, int out_c
     return zj_ycbcr_to_rgb16;
 }
 
-/* micro-benchmark hook used by tools/ubench.py (not part of the decode path) */
+/* micro-benchmark hooks used by tools/ubench.py (not part of the decode path) */
+int zj_ubench_count(void) { return ubench2_count(); }
+const char* zj_ubench_name(int op) { return ubench2_name(op); }
 int zj_ubench(zj_ctx* c, int op, int blocks, int iters, int reps, float* ms)
 {
     if (!c || !ms) return ZJ_ERR_ARG;
     ZJ_HIP(c, hipSetDevice(c->device));
     int rc = ensure_scratch(c, 0, (size_t)blocks * 256 * 4);
     if (rc) return rc;
-    ZJ_HIP(c, launch_ubench(op, (int*)c->scratch[0], blocks, iters, 12345, c->stream)); // warm-up
+    ZJ_HIP(c, launch_ubench2(op, (int*)c->scratch[0], blocks, iters, 12345, c->stream)); // warm-up
     ZJ_HIP(c, hipEventRecord(c->ev0, c->stream));
-    for (int r = 0; r < reps; r++) ZJ_HIP(c, launch_ubench(op, (int*)c->scratch[0], blocks, iters, 12345 + r, c->stream));
+    for (int r = 0; r < reps; r++) ZJ_HIP(c, launch_ubench2(op, (int*)c->scratch[0], blocks, iters, 12345 + r, c->stream));
     ZJ_HIP(c, hipEventRecord(c->ev1, c->stream));
     ZJ_HIP(c, hipEventSynchronize(c->ev1));
     ZJ_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return ZJ_OK;
+}
+/* shader clock: cycles counted by s_memtime in one wave over a fixed spin, and the wall ms of it */
+int zj_ubench_clock(zj_ctx* c, int iters, double* cycles, float* ms)
+{
+    if (!c || !cycles || !ms) return ZJ_ERR_ARG;
+    ZJ_HIP(c, hipSetDevice(c->device));
+    int rc = ensure_scratch(c, 0, 4096);
+    if (rc) return rc;
+    ZJ_HIP(c, launch_ub_clock((unsigned long long*)c->scratch[0], 1, iters, c->stream));
+    ZJ_HIP(c, hipEventRecord(c->ev0, c->stream));
+    ZJ_HIP(c, launch_ub_clock((unsigned long long*)c->scratch[0], 1, iters, c->stream));
+    ZJ_HIP(c, hipEventRecord(c->ev1, c->stream));
+    ZJ_HIP(c, hipEventSynchronize(c->ev1));
+    ZJ_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    unsigned long long v = 0;
+    ZJ_HIP(c, hipMemcpy(&v, c->scratch[0], 8, hipMemcpyDeviceToHost));
+    *cycles = (double)v;
     return ZJ_OK;
 }
 

@@ -156,48 +156,4 @@ hipError_t launch_rgb16(const int16_t* ycc, uint8_t* out, hipStream_t s)
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------------
-// integer-VALU micro-benchmark (tools/ubench.py): issue rate of the ops the IDCT design relies on
-// ------------------------------------------------------------------------------------------------
-template <int OP>
-__global__ __launch_bounds__(256) void zj_ubench_kernel(int* out, int iters, int seed)
-{
-    int a[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) a[i] = seed * (i + 1) + (int)threadIdx.x;
-    const int k = seed | 1;
-    for (int it = 0; it < iters; it++) {
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                if (OP == 0) a[i] = a[i] + k;                                        // v_add_u32
-                else if (OP == 1) a[i] = (int)((unsigned)a[i] * (unsigned)k);        // v_mul_lo_u32
-                else if (OP == 2) a[i] = __mul24(a[i], k);                           // v_mul_i32_i24
-                else if (OP == 3) a[i] = __mul24(a[i], k) + a[(i + 1) & 7];          // v_mad_i32_i24
-                else if (OP == 4) a[i] = as_u32(as_u16x2((uint32_t)a[i]) * as_u16x2((uint32_t)k)); // v_pk_mul_lo_u16
-                else if (OP == 5) a[i] = as_u32(as_u16x2((uint32_t)a[i]) * as_u16x2((uint32_t)k) + as_u16x2((uint32_t)a[(i + 1) & 7])); // v_pk_mad_u16
-                else if (OP == 6) a[i] = (a[i] >> 3) + k;                            // shift + add
-                else if (OP == 7) a[i] = (int)__builtin_amdgcn_perm((unsigned)a[i], (unsigned)a[(i + 1) & 7], 0x07060100u); // v_perm_b32
-                else if (OP == 8) { int v = a[i] + k; a[i] = v < 0 ? 0 : (v > 255 ? 255 : v) + it; } // add + med3 + add
-            }
-        }
-    }
-    int acc = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) acc ^= a[i];
-    if (acc == 0x7fffffff) out[blockIdx.x * blockDim.x + threadIdx.x] = acc; // never true in practice; keeps the chain live
-}
-
-hipError_t launch_ubench(int op, int* out, int blocks, int iters, int seed, hipStream_t s)
-{
-#define ZJ_UB(O) case O: hipLaunchKernelGGL((zj_ubench_kernel<O>), dim3(blocks), dim3(256), 0, s, out, iters, seed); break;
-    switch (op) {
-        ZJ_UB(0) ZJ_UB(1) ZJ_UB(2) ZJ_UB(3) ZJ_UB(4) ZJ_UB(5) ZJ_UB(6) ZJ_UB(7) ZJ_UB(8)
-    default: return hipErrorInvalidValue;
-    }
-#undef ZJ_UB
-    return hipGetLastError();
-}
-
 } // namespace zj

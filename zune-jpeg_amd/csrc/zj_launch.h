@@ -12,5 +12,8 @@ hipError_t launch_idct_strip(const int16_t* coeff, const int32_t* qt, int16_t* o
 hipError_t launch_upsample_h(const int16_t* in, long long n, int16_t* out, long long out_len, long long m, hipStream_t s);
 hipError_t launch_upsample_v(const int16_t* in, long long stride, int16_t* out, long long out_len, hipStream_t s);
 hipError_t launch_rgb16(const int16_t* ycc, uint8_t* out, hipStream_t s);
-hipError_t launch_ubench(int op, int* out, int blocks, int iters, int seed, hipStream_t s);
+int ubench2_count();
+const char* ubench2_name(int op);
+hipError_t launch_ubench2(int op, int* out, int blocks, int iters, int seed, hipStream_t s);
+hipError_t launch_ub_clock(unsigned long long* out, int blocks, int iters, hipStream_t s);
 } // namespace zj

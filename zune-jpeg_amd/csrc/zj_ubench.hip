@@ -1,0 +1,140 @@
+// zj_ubench.hip -- instruction-issue micro-benchmarks for gfx950 integer VALU ops (tools/ubench.py).
+// Every variant executes, per loop iteration, 8 asm statements of 8 independent instructions each
+// (64 instructions on 8 registers), written in inline asm so the compiler can neither fold nor
+// re-select them.  Not part of the decode path.
+#include <hip/hip_runtime.h>
+
+#include "zj_launch.h"
+
+namespace zj {
+
+#define R8(x) x x x x x x x x
+
+#define UB_KERNEL(NAME, INSTR)                                                                         \
+    __global__ __launch_bounds__(256) void NAME(int* out, int iters, int seed)                         \
+    {                                                                                                  \
+        int a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, \
+            a6 = a0 * 17, a7 = a0 * 19;                                                                \
+        int k = __builtin_amdgcn_readfirstlane(seed | 3);                                              \
+        int b = a0 ^ 0x55aa;                                                                           \
+        for (int it = 0; it < iters; it++) {                                                           \
+            R8(asm volatile(INSTR(%0) INSTR(%1) INSTR(%2) INSTR(%3) INSTR(%4) INSTR(%5) INSTR(%6) INSTR(%7) \
+                            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) \
+                            : "s"(k), "v"(b));)                                                        \
+        }                                                                                              \
+        int acc = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;                                               \
+        if (acc == 0x7fffffff) out[blockIdx.x * blockDim.x + threadIdx.x] = acc;                       \
+    }
+
+// %8 = SGPR k, %9 = VGPR b
+#define I_ADD(r) "v_add_u32_e32 " #r ", %9, " #r "\n"
+#define I_ADD64(r) "v_add_u32_e64 " #r ", %9, " #r "\n"
+#define I_ADDS(r) "v_add_u32_e32 " #r ", %8, " #r "\n"
+#define I_MULLO(r) "v_mul_lo_u32 " #r ", " #r ", %8\n"
+#define I_MUL24(r) "v_mul_i32_i24_e32 " #r ", %8, " #r "\n"
+#define I_MUL24L(r) "v_mul_i32_i24_e32 " #r ", 0x14e8, " #r "\n"
+#define I_MAD24S(r) "v_mad_i32_i24 " #r ", " #r ", %8, %9\n"
+#define I_MAD24V(r) "v_mad_i32_i24 " #r ", " #r ", %9, %9\n"
+#define I_MAD24VV(r) "v_mad_i32_i24 " #r ", " #r ", %9, " #r "\n"
+#define I_ASHR(r) "v_ashrrev_i32_e32 " #r ", 3, " #r "\n"
+#define I_LSHLADD(r) "v_lshl_add_u32 " #r ", " #r ", 3, %9\n"
+#define I_ADD3(r) "v_add3_u32 " #r ", " #r ", %9, %8\n"
+#define I_MED3(r) "v_med3_i32 " #r ", " #r ", 0, %8\n"
+#define I_PERM(r) "v_perm_b32 " #r ", " #r ", %9, %8\n"
+#define I_PKADD(r) "v_pk_add_u16 " #r ", " #r ", %9\n"
+#define I_PKMUL(r) "v_pk_mul_lo_u16 " #r ", " #r ", %9\n"
+#define I_PKMAD(r) "v_pk_mad_u16 " #r ", " #r ", %9, %9\n"
+#define I_PKASHR(r) "v_pk_ashrrev_i16 " #r ", 2, " #r "\n"
+#define I_PKMAX(r) "v_pk_max_i16 " #r ", " #r ", %9\n"
+#define I_SDWA(r) "v_mul_i32_i24_sdwa " #r ", %8, sext(" #r ") dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+#define I_LSHLOR(r) "v_lshl_or_b32 " #r ", " #r ", 8, %9\n"
+#define I_ANDOR(r) "v_and_or_b32 " #r ", " #r ", %8, %9\n"
+#define I_ALIGN(r) "v_alignbit_b32 " #r ", " #r ", %9, 16\n"
+#define I_BFE(r) "v_bfe_i32 " #r ", " #r ", 0, 16\n"
+#define I_MOV(r) "v_mov_b32_e32 " #r ", %9\n"
+#define I_CNDMASK(r) "v_cndmask_b32_e32 " #r ", " #r ", %9, vcc\n"
+#define I_OR(r) "v_or_b32_e32 " #r ", %9, " #r "\n"
+#define I_SUB(r) "v_sub_u32_e32 " #r ", " #r ", %9\n"
+#define I_MADU16(r) "v_mad_i32_i16 " #r ", " #r ", %9, %9\n"
+#define I_SATPK(r) "v_sat_pk_u8_i16_e32 " #r ", " #r "\n"
+#define I_MAD_U32_U24(r) "v_mad_u32_u24 " #r ", " #r ", %8, %9\n"
+#define I_PKSUB(r) "v_pk_sub_i16 " #r ", " #r ", %9\n"
+#define I_PKMIN(r) "v_pk_min_i16 " #r ", " #r ", %9\n"
+#define I_OR3(r) "v_or3_b32 " #r ", " #r ", %9, %8\n"
+
+UB_KERNEL(ub_add, I_ADD)
+UB_KERNEL(ub_add64, I_ADD64)
+UB_KERNEL(ub_adds, I_ADDS)
+UB_KERNEL(ub_mullo, I_MULLO)
+UB_KERNEL(ub_mul24, I_MUL24)
+UB_KERNEL(ub_mul24l, I_MUL24L)
+UB_KERNEL(ub_mad24s, I_MAD24S)
+UB_KERNEL(ub_mad24v, I_MAD24V)
+UB_KERNEL(ub_mad24vv, I_MAD24VV)
+UB_KERNEL(ub_ashr, I_ASHR)
+UB_KERNEL(ub_lshladd, I_LSHLADD)
+UB_KERNEL(ub_add3, I_ADD3)
+UB_KERNEL(ub_med3, I_MED3)
+UB_KERNEL(ub_perm, I_PERM)
+UB_KERNEL(ub_pkadd, I_PKADD)
+UB_KERNEL(ub_pkmul, I_PKMUL)
+UB_KERNEL(ub_pkmad, I_PKMAD)
+UB_KERNEL(ub_pkashr, I_PKASHR)
+UB_KERNEL(ub_pkmax, I_PKMAX)
+UB_KERNEL(ub_sdwa, I_SDWA)
+UB_KERNEL(ub_lshlor, I_LSHLOR)
+UB_KERNEL(ub_andor, I_ANDOR)
+UB_KERNEL(ub_align, I_ALIGN)
+UB_KERNEL(ub_bfe, I_BFE)
+UB_KERNEL(ub_mov, I_MOV)
+UB_KERNEL(ub_cndmask, I_CNDMASK)
+UB_KERNEL(ub_or, I_OR)
+UB_KERNEL(ub_sub, I_SUB)
+UB_KERNEL(ub_madi16, I_MADU16)
+UB_KERNEL(ub_satpk, I_SATPK)
+UB_KERNEL(ub_madu24, I_MAD_U32_U24)
+UB_KERNEL(ub_pksub, I_PKSUB)
+UB_KERNEL(ub_pkmin, I_PKMIN)
+UB_KERNEL(ub_or3, I_OR3)
+
+// shader-clock probe: cycles (s_memtime) spent by one wave in a fixed spin, to convert ms -> MHz
+__global__ void ub_clock(unsigned long long* out, int iters)
+{
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    int a = threadIdx.x;
+    for (int i = 0; i < iters; i++) asm volatile(R8("v_add_u32_e32 %0, 1, %0\n") : "+v"(a));
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0 + (a == 0x7fffffff);
+}
+
+typedef void (*ub_fn)(int*, int, int);
+static const struct { const char* name; ub_fn fn; } UB[] = {
+    {"v_add_u32_e32 v,v,v", ub_add}, {"v_add_u32_e64 v,v,v", ub_add64}, {"v_add_u32_e32 v,s,v", ub_adds},
+    {"v_sub_u32_e32", ub_sub}, {"v_or_b32_e32", ub_or}, {"v_mov_b32_e32", ub_mov}, {"v_ashrrev_i32_e32", ub_ashr},
+    {"v_cndmask_b32_e32", ub_cndmask},
+    {"v_mul_lo_u32 v,v,s", ub_mullo}, {"v_mul_i32_i24_e32 v,s,v", ub_mul24}, {"v_mul_i32_i24_e32 v,lit,v", ub_mul24l},
+    {"v_mul_i32_i24_sdwa v,s,sext(v.w1)", ub_sdwa},
+    {"v_mad_i32_i24 v,v,s,v", ub_mad24s}, {"v_mad_i32_i24 v,v,v,v(2 regs)", ub_mad24v}, {"v_mad_i32_i24 v,v,v,v(self)", ub_mad24vv},
+    {"v_mad_u32_u24 v,v,s,v", ub_madu24}, {"v_mad_i32_i16 v,v,v,v", ub_madi16},
+    {"v_lshl_add_u32", ub_lshladd}, {"v_add3_u32", ub_add3}, {"v_or3_b32", ub_or3}, {"v_med3_i32", ub_med3},
+    {"v_perm_b32", ub_perm}, {"v_lshl_or_b32", ub_lshlor}, {"v_and_or_b32", ub_andor}, {"v_alignbit_b32", ub_align},
+    {"v_bfe_i32", ub_bfe}, {"v_sat_pk_u8_i16", ub_satpk},
+    {"v_pk_add_u16", ub_pkadd}, {"v_pk_sub_i16", ub_pksub}, {"v_pk_mul_lo_u16", ub_pkmul}, {"v_pk_mad_u16", ub_pkmad},
+    {"v_pk_ashrrev_i16", ub_pkashr}, {"v_pk_max_i16", ub_pkmax}, {"v_pk_min_i16", ub_pkmin},
+};
+
+int ubench2_count() { return (int)(sizeof(UB) / sizeof(UB[0])); }
+const char* ubench2_name(int op) { return (op >= 0 && op < ubench2_count()) ? UB[op].name : ""; }
+hipError_t launch_ubench2(int op, int* out, int blocks, int iters, int seed, hipStream_t s)
+{
+    if (op < 0 || op >= ubench2_count()) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(UB[op].fn, dim3(blocks), dim3(256), 0, s, out, iters, seed);
+    return hipGetLastError();
+}
+hipError_t launch_ub_clock(unsigned long long* out, int blocks, int iters, hipStream_t s)
+{
+    hipLaunchKernelGGL(ub_clock, dim3(blocks), dim3(64), 0, s, out, iters);
+    return hipGetLastError();
+}
+
+} // namespace zj

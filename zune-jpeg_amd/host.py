@@ -143,7 +143,7 @@ def lib():
     L.zj_decode_planes_batch.argtypes = [vp, C.POINTER(FrameDesc), sz, i16p, i16p, i16p, u8p]
     L.zj_decode_planes_device.argtypes = [vp, C.POINTER(FrameDesc), sz, vp, vp, vp, vp, vp]
     L.zj_time_decode_device.argtypes = [vp, C.POINTER(FrameDesc), sz, vp, vp, vp, vp, vp, C.c_int,
-                                        C.POINTER(C.c_float), C.POINTER(C.c_char_p)]
+                                        C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_char_p)]
     L.zj_alloc_pinned.restype = vp
     L.zj_alloc_pinned.argtypes = [sz]
     L.zj_free_pinned.argtypes = [vp]
@@ -160,6 +160,9 @@ def lib():
     L.zj_choose_ycbcr_to_rgb_convert_func.restype = vp
     L.zj_choose_ycbcr_to_rgb_convert_func.argtypes = [C.c_int, C.c_int]
     L.zj_ubench.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.zj_ubench_name.restype = C.c_char_p
+    L.zj_ubench_name.argtypes = [C.c_int]
+    L.zj_ubench_clock.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float)]
     _LIB = L
     return L
 
@@ -297,12 +300,14 @@ class Context:
                "zj_decode_planes_device", self._h)
 
     def time_decode_device(self, desc, nframes, d_y, d_cb, d_cr, d_out, iters, stream=None):
-        """HIP-event time (ms) of `iters` launches on the launch stream; returns (ms, kernel name)."""
-        ms = C.c_float(0)
+        """HIP-event timing on the launch stream.  Returns (ms per launch from `iters` back-to-back
+        launches, mean ms of individually bracketed launches, kernel name)."""
+        ms, each = C.c_float(0), C.c_float(0)
         name = C.c_char_p()
         _check(lib().zj_time_decode_device(self._h, C.byref(desc), nframes, d_y, d_cb, d_cr, d_out, stream,
-                                           iters, C.byref(ms), C.byref(name)), "zj_time_decode_device", self._h)
-        return ms.value, (name.value or b"").decode()
+                                           iters, C.byref(ms), C.byref(each), C.byref(name)),
+               "zj_time_decode_device", self._h)
+        return ms.value / iters, each.value, (name.value or b"").decode()
 
     def device_alloc(self, nbytes):
         p = lib().zj_device_alloc(self._h, nbytes)
@@ -327,3 +332,8 @@ class Context:
         ms = C.c_float(0)
         _check(lib().zj_ubench(self._h, op, blocks, iters, reps, C.byref(ms)), "zj_ubench", self._h)
         return ms.value / reps
+
+    def ubench_clock_mhz(self, iters=200000):
+        cyc, ms = C.c_double(0), C.c_float(0)
+        _check(lib().zj_ubench_clock(self._h, iters, C.byref(cyc), C.byref(ms)), "zj_ubench_clock", self._h)
+        return cyc.value / (ms.value * 1e3)
