@@ -18,13 +18,20 @@ template <int HS, int VS, int OUT>
 static void run(const Params& p)
 {
     using C = Cfg<HS, VS, OUT>;
-    std::vector<int16_t> lds_store(C::LDS_I16 + 8);
+    std::vector<char> lds_store(C::LDS_BYTES + 32);
     // 16-byte aligned like a real LDS allocation
     int16_t* lds = (int16_t*)(((uintptr_t)lds_store.data() + 15) & ~(uintptr_t)15);
     for (int bid = 0; bid < p.total_tiles; bid++) {
-        for (int i = 0; i < C::LDS_I16; i++) lds[i] = 0x7B7B; // poison: unwritten LDS must not matter
+        memset(lds, 0x7B, C::LDS_BYTES); // poison: unwritten LDS must not matter
         const TileId t = decode_tile(p, bid);
-        for (int tid = 0; tid < C::NT; tid++) phase_idct<C>(p, t, tid, lds);
+        for (int tid = 0; tid < C::NT; tid++) phase_setup<C>(p, tid, lds);
+        /* __syncthreads() */
+        for (int tid = 0; tid < C::NT; tid++) {
+            const BlockLoc L = locate<C>(p, t, tid, lds);
+            U4 raw[8];
+            load_block(L, raw);
+            finish_block<C>(L, raw, lds);
+        }
         /* __syncthreads() */
         for (int tid = 0; tid < C::NT; tid++) phase_color<C, HS, VS, OUT>(p, t, tid, lds);
     }

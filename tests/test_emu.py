@@ -12,7 +12,7 @@ MODES = {"none": (1, 1), "h": (2, 1), "v": (1, 2), "hv": (2, 2)}
 
 @pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("out_cs", [oc.RGB, oc.GRAYSCALE, oc.YCBCR])
-@pytest.mark.parametrize("wh", [(64, 64), (528, 40), (32, 8), (272, 100), (1040, 33)])
+@pytest.mark.parametrize("wh", [(64, 64), (528, 40), (32, 8), (272, 100), (1040, 33), (2080, 16)])
 def test_emulated_kernel_matches_oracle(mode, out_cs, wh, synth):
     hs, vs = MODES[mode]
     w, h = wh

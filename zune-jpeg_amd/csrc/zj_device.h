@@ -139,21 +139,28 @@ ZJ_DEV void idct_1d(const int32_t s[8], const int32_t bias, int32_t o[8])
 ZJ_DEV int32_t lo16s(uint32_t v) { return (int32_t)(int16_t)(v & 0xffff); }
 ZJ_DEV int32_t hi16s(uint32_t v) { return (int32_t)v >> 16; }
 
-// raw[r] = coefficient row r (8 x i16, natural order).  qt: 64 x int32 (wave-uniform pointer).
-// CENTER (chroma): 128 is subtracted from every finished sample (packed, after the clamp), because
-// the `- 128` of color_convert/scalar.rs:68-70 commutes exactly with both triangle filters
-// ((3(a-128)+(b-128)+2)>>2 == ((3a+b+2)>>2)-128).  It must NOT be folded into the pass-2 bias: the
-// i32 sums may wrap (idct.rs:86) and the arithmetic >> 17 would then see a different sign.
-// out[r] = pixel row r as 8 packed i16 (4 dwords).
-template <bool CENTER>
-ZJ_DEV void idct_block(const U4 raw[8], const int32_t* __restrict__ qt, U4 out[8])
+// v_sat_pk_u8_i16: {0, 0, sat_u8(hi16), sat_u8(lo16)} -- the two 16-bit lanes clamped to 0..255 and
+// packed into bytes 0 and 1 (replaces v_pk_max_i16 + v_pk_min_i16 and half of the byte packing)
+ZJ_DEV uint32_t sat_pk_u8(uint32_t v)
+{
+#if defined(ZJ_EMU)
+    int lo = (int16_t)(v & 0xffff), hi = (int16_t)(v >> 16);
+    lo = lo < 0 ? 0 : (lo > 255 ? 255 : lo);
+    hi = hi < 0 ? 0 : (hi > 255 ? 255 : hi);
+    return (uint32_t)lo | ((uint32_t)hi << 8);
+#else
+    uint32_t r;
+    asm("v_sat_pk_u8_i16_e32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+#endif
+}
+
+// raw[r] = coefficient row r (8 x i16, natural order).  qt: this lane's 64 x int32 table (LDS).
+// out[r] = pixel row r as 8 packed i16 (4 dwords): level-shifted (+128) and clamped to 0..255
+// (SCALE_BITS scalar.rs:6, clamp :302-305).  The caller handles DC-only blocks (scalar.rs:45-74).
+ZJ_DEV void idct_block(const U4 raw[8], const int32_t* qt, U4 out[8])
 {
     const uint32_t* w = reinterpret_cast<const uint32_t*>(raw);
-    // DC-only test (scalar.rs:45): every coefficient except [0] is zero
-    uint32_t any = w[0] & 0xffff0000u;
-#pragma unroll
-    for (int i = 1; i < 32; i++) any |= w[i];
-
     int32_t tmp[64];
     // pass 1: columns (scalar.rs:79-167), bias 512, >> 10
 #pragma unroll
@@ -170,8 +177,7 @@ ZJ_DEV void idct_block(const U4 raw[8], const int32_t* __restrict__ qt, U4 out[8
         for (int k = 0; k < 8; k++) tmp[k * 8 + col] = o[k] >> 10;
     }
     // pass 2: rows (scalar.rs:170-274), bias SCALE_BITS, >> 17, clamp
-    constexpr int32_t bias2 = 512 + 65536 + (128 << 17); // SCALE_BITS, scalar.rs:6
-    constexpr int32_t lo = 0, hi = 255;                  // clamp, scalar.rs:302-305
+    constexpr int32_t bias2 = 512 + 65536 + (128 << 17);
     uint32_t* ow = reinterpret_cast<uint32_t*>(out);
 #pragma unroll
     for (int r = 0; r < 8; r++) {
@@ -180,39 +186,38 @@ ZJ_DEV void idct_block(const U4 raw[8], const int32_t* __restrict__ qt, U4 out[8
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
             int32_t p0 = o[k] >> 17, p1 = o[k + 1] >> 17;
-            p0 = p0 < lo ? lo : (p0 > hi ? hi : p0);
-            p1 = p1 < lo ? lo : (p1 > hi ? hi : p1);
-            const uint32_t pk = (uint32_t)p0 | ((uint32_t)p1 << 16);
-            ow[r * 4 + (k >> 1)] = CENTER ? as_u32(as_u16x2(pk) - splat(128)) : pk;
+            p0 = p0 < 0 ? 0 : (p0 > 255 ? 255 : p0);
+            p1 = p1 < 0 ? 0 : (p1 > 255 ? 255 : p1);
+            ow[r * 4 + (k >> 1)] = (uint32_t)p0 | ((uint32_t)p1 << 16);
         }
-    }
-    // Q1: DC-only blocks take the shortcut value, i16 wrapping, floor >> 3, NOT clamped (scalar.rs:48)
-    if (any == 0) {
-        const int16_t dc = (int16_t)(uint16_t)((uint32_t)lo16s(w[0]) * (uint32_t)(int32_t)(int16_t)qt[0]);
-        const int32_t v = ((int32_t)dc >> 3) + (CENTER ? 0 : 128);
-        const uint32_t pv = ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16);
-#pragma unroll
-        for (int i = 0; i < 32; i++) ow[i] = pv;
     }
 }
 
+// Q1: DC-only blocks take the shortcut value: i16 wrapping product, floor >> 3, + 128, NOT clamped
+// (scalar.rs:48).  Returns the value replicated in both 16-bit lanes.
+ZJ_DEV uint32_t dc_only_value(uint32_t w0, int32_t q0)
+{
+    const int16_t dc = (int16_t)(uint16_t)((uint32_t)lo16s(w0) * (uint32_t)(int32_t)(int16_t)q0);
+    const int32_t v = ((int32_t)dc >> 3) + 128;
+    return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16);
+}
+
 // ------------------------------------------------------------------------------------------------
-// colour conversion of a packed pixel pair (color_convert/scalar.rs:66-85); cb, cr already centred
-// (value - 128).  All products/sums wrap in i16 exactly like the reference (Q7).  Returns
-// R, G, B clamped to 0..255 in the two 16-bit lanes.
+// colour conversion of a packed pixel pair (color_convert/scalar.rs:66-85).  cb, cr are the RAW
+// samples; the reference's `cb - 128`, `cr - 128` are folded into the multiply-adds, which is exact
+// because every product/sum wraps mod 2^16 in the reference too (Q7):
+//   45*(cr-128) == 45*cr - 5760,  11*(cb-128) + 23*(cr-128) == 11*cb + 23*cr - 4352,
+//   113*(cb-128) == 113*cb - 14464                                   (mod 2^16)
+// Returns R, G, B as UNCLAMPED i16 pairs.
 // ------------------------------------------------------------------------------------------------
 struct RGB2 { uint32_t r, g, b; };
 ZJ_DEV RGB2 ycc_to_rgb_pair(uint32_t y_, uint32_t cb_, uint32_t cr_)
 {
     const u16x2 y = as_u16x2(y_), cb = as_u16x2(cb_), cr = as_u16x2(cr_);
-    const u16x2 r = y + (u16x2)sar(splat(45) * cr, 5);
-    const u16x2 g = y - (u16x2)sar(splat(11) * cb + splat(23) * cr, 5);
-    const u16x2 b = y + (u16x2)sar(splat(113) * cb, 6);
-    const s16x2 z = {0, 0}, m = {255, 255};
     RGB2 o;
-    o.r = as_u32(pk_min(pk_max((s16x2)r, z), m));
-    o.g = as_u32(pk_min(pk_max((s16x2)g, z), m));
-    o.b = as_u32(pk_min(pk_max((s16x2)b, z), m));
+    o.r = as_u32(y + (u16x2)sar(splat(45) * cr + splat(-5760), 5));
+    o.g = as_u32(y - (u16x2)sar(splat(11) * cb + (splat(23) * cr + splat(-4352)), 5));
+    o.b = as_u32(y + (u16x2)sar(splat(113) * cb + splat(-14464), 6));
     return o;
 }
 
@@ -231,39 +236,49 @@ ZJ_DEV int tri1(int near_, int far_) { return (int)(int16_t)(uint16_t)(3 * near_
 // Horizontal modes need one extra chroma block column on each side (the triangle filter's taps);
 // because the reference filters the strip as ONE flat array (Q4) the neighbour of the first/last
 // column is the other end of the previous/next row, so the halo wraps around with a row shift.
-// IDCT lanes are laid out so that every wave works on ONE component (quantisation table in SGPRs).
-// ------------------------------------------------------------------------------------------------
-template <int HS, int VS>
-struct Geo {
+// Tile width (TWC chroma block columns) is chosen so that the tile's blocks fill the workgroup's
+// waves: with one lane per block and 256 lanes, 4:2:0->RGB has 12*TWC + 8 blocks -> TWC = 20 (248).
+template <int HS, int VS, bool CHROMA> struct TileWidth;
+template <> struct TileWidth<2, 2, true> { static constexpr int TWC = 20; };   // 248 blocks, 320 px
+template <> struct TileWidth<2, 1, true> { static constexpr int TWC = 31; };   // 8*TWC+8 = 256, 496 px
+template <> struct TileWidth<1, 2, true> { static constexpr int TWC = 64; };   // 4*TWC = 256, 512 px
+template <> struct TileWidth<1, 1, true> { static constexpr int TWC = 84; };   // 3*TWC = 252, 672 px
+template <> struct TileWidth<2, 2, false> { static constexpr int TWC = 32; };  // 8*TWC = 256 luma blocks
+template <> struct TileWidth<2, 1, false> { static constexpr int TWC = 64; };
+template <> struct TileWidth<1, 2, false> { static constexpr int TWC = 128; };
+template <> struct TileWidth<1, 1, false> { static constexpr int TWC = 128; }; // 128 blocks, 2 waves
+
+enum { OUT_RGB = 0, OUT_GRAY = 1, OUT_YCBCR = 2 };
+
+// LDS layout (bytes): planar staging Yp[SH][TWY] | Cb[CROWS][CPITCH] | Cr[..] (i16), then the three
+// quantisation tables (int32) every lane indexes by its block's component.
+template <int HS, int VS, int OUT>
+struct Cfg {
+    static constexpr bool CHROMA = OUT != OUT_GRAY;
     static constexpr int YBR = (HS == 2 && VS == 2) ? 4 : ((HS == 2 || VS == 2) ? 2 : 1);
     static constexpr int CBR = (HS == 2) ? 2 : 1;
     static constexpr int SH = YBR * 8;                 // luma rows per strip
     static constexpr int CROWS = CBR * 8;              // chroma rows per strip
-    static constexpr int TWC = (HS == 2) ? 16 : 64;    // chroma block columns per tile
+    static constexpr int TWC = TileWidth<HS, VS, CHROMA>::TWC; // chroma block columns per tile
     static constexpr int HALO = (HS == 2) ? 1 : 0;
     static constexpr int TWYB = TWC * HS;              // luma block columns per tile
     static constexpr int TWY = TWYB * 8;               // luma pixels per tile row
     static constexpr int NYB = YBR * TWYB;             // luma blocks per tile
     static constexpr int CCOLS = TWC + 2 * HALO;       // chroma block columns incl. halo
     static constexpr int NCB = CBR * CCOLS;            // chroma blocks per tile and component
-    static constexpr int NYB64 = (NYB + 63) / 64 * 64;
-    static constexpr int NCB64 = (NCB + 63) / 64 * 64;
     static constexpr int CPITCH = TWC * 8 + (HALO ? 16 : 0); // i16 per chroma LDS row
     static constexpr int COFF = HALO ? 8 : 0;          // LDS column of chroma column 0
     static constexpr int YSZ = SH * TWY;               // i16 elements
     static constexpr int CSZ = CROWS * CPITCH;
     static constexpr int NGRP = TWY / 16;              // 16-pixel groups per tile row
     static constexpr int NITEMS = SH * NGRP;
-};
-
-enum { OUT_RGB = 0, OUT_GRAY = 1, OUT_YCBCR = 2 };
-
-template <int HS, int VS, int OUT>
-struct Cfg : Geo<HS, VS> {
-    using G = Geo<HS, VS>;
-    static constexpr bool CHROMA = OUT != OUT_GRAY;
-    static constexpr int NT = G::NYB64 + (CHROMA ? 2 * G::NCB64 : 0); // threads per workgroup
-    static constexpr int LDS_I16 = G::YSZ + (CHROMA ? 2 * G::CSZ : 0);
+    static constexpr int NBLK = NYB + (CHROMA ? 2 * NCB : 0);        // blocks per tile
+    static constexpr int NT = (NBLK + 63) / 64 * 64;                 // threads per workgroup
+    static constexpr int PLANAR_I16 = YSZ + (CHROMA ? 2 * CSZ : 0);
+    static constexpr int QT_OFF = PLANAR_I16 * 2;                    // byte offset, 16-aligned
+    static constexpr int LDS_BYTES = QT_OFF + 3 * 64 * 4;
+    static_assert(PLANAR_I16 % 8 == 0, "planar area must keep 16-byte alignment");
+    static_assert(NT <= 256 && NBLK <= NT, "one lane per block, at most 4 waves");
 };
 
 struct Params {
@@ -305,10 +320,6 @@ ZJ_DEV void vrows(int m, int& ra, int& rb)
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Phase 1: every lane IDCTs one block of the tile into the LDS planar staging area.
-//   lds layout: Yp[SH][TWY] | Cb[CROWS][CPITCH] | Cr[CROWS][CPITCH]   (i16)
-// ------------------------------------------------------------------------------------------------
 struct TileId { int frame, strip, tile; };
 
 ZJ_DEV TileId decode_tile(const Params& p, int bid)
@@ -325,62 +336,114 @@ ZJ_DEV TileId decode_tile(const Params& p, int bid)
     return t;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Block b of a tile: where its 64 coefficients live in HBM and where its pixels go in LDS.
+//   b in [0, NYB): luma; then NCB Cb blocks; then NCB Cr blocks (halo columns first/last per row)
+// ------------------------------------------------------------------------------------------------
+struct BlockLoc {
+    const U4* src;   // 8 x 16 bytes of coefficients
+    int16_t* dst;    // LDS address of the block's pixel (0,0) -- or of the single halo column
+    int pitch;       // LDS row pitch in i16
+    int comp;        // 0 Y, 1 Cb, 2 Cr
+    int halo;        // 0: full block, 1: left halo (keep pixel column 7), 2: right halo (column 0)
+    bool valid;
+};
+
 template <class C>
-ZJ_DEV void phase_idct(const Params& p, const TileId t, const int tid, int16_t* lds)
+ZJ_DEV BlockLoc locate(const Params& p, const TileId t, const int b, int16_t* lds)
 {
-    const int ybw = p.mcu_x * (C::TWYB / C::TWC); // luma blocks per plane row   (= mcu_x * HS)
+    BlockLoc L;
+    L.valid = false; L.halo = 0; L.comp = 0; L.src = nullptr; L.dst = lds; L.pitch = C::TWY;
+    const int ybw = p.mcu_x * (C::TWYB / C::TWC); // luma blocks per plane row (= mcu_x * HS)
     const int cbw = p.mcu_x;                      // chroma blocks per plane row
-    const int seg = uniform(tid < C::NYB64 ? 0 : (tid < C::NYB64 + C::NCB64 ? 1 : 2));
-    U4 raw[8], px[8];
-    if (seg == 0) {
-        const int b = tid;
-        if (b >= C::NYB) return;
+    if (b < C::NYB) {
         const int brow = b / C::TWYB, bcol = b % C::TWYB;
         const int gcol = t.tile * C::TWYB + bcol;
-        if (gcol >= ybw) return;
+        if (gcol >= ybw) return L;
         const long long blk = (long long)(t.strip * C::YBR + brow) * ybw + gcol;
-        const U4* src = reinterpret_cast<const U4*>(p.y + (long long)t.frame * p.y_frame_stride + blk * 64);
-#pragma unroll
-        for (int i = 0; i < 8; i++) raw[i] = src[i];
-        idct_block<false>(raw, p.qt, px);
-        int16_t* dst = lds + (brow * 8) * C::TWY + bcol * 8;
-#pragma unroll
-        for (int r = 0; r < 8; r++) *reinterpret_cast<U4*>(dst + r * C::TWY) = px[r];
-    } else if (C::CHROMA) {
-        const int b = tid - (seg == 1 ? C::NYB64 : C::NYB64 + C::NCB64);
-        if (b >= C::NCB) return;
-        const int brow = b / C::CCOLS, j = b % C::CCOLS;
-        const int cb0 = t.tile * C::TWC;
-        const int nvalid = (cbw - cb0) < C::TWC ? (cbw - cb0) : C::TWC;
-        int gcol, lcol; // plane block column, LDS column of the block's first pixel
-        bool halo = false, left = false;
-        if (C::HALO) {
-            if (j == 0) { gcol = cb0 > 0 ? cb0 - 1 : cbw - 1; lcol = 0; halo = left = true; }
-            else if (j == C::CCOLS - 1) { gcol = cb0 + nvalid < cbw ? cb0 + nvalid : 0; lcol = C::COFF + 8 * nvalid; halo = true; }
-            else { gcol = cb0 + j - 1; lcol = C::COFF + 8 * (j - 1); if (j - 1 >= nvalid) return; }
-        } else {
-            gcol = cb0 + j; lcol = 8 * j;
-            if (j >= nvalid) return;
-        }
-        const long long blk = (long long)(t.strip * C::CBR + brow) * cbw + gcol;
-        const int16_t* plane = (seg == 1 ? p.cb : p.cr) + (long long)t.frame * p.c_frame_stride;
-        const U4* src = reinterpret_cast<const U4*>(plane + blk * 64);
-#pragma unroll
-        for (int i = 0; i < 8; i++) raw[i] = src[i];
-        idct_block<true>(raw, p.qt + 64 * seg, px);
-        int16_t* dst = lds + C::YSZ + (seg - 1) * C::CSZ + (brow * 8) * C::CPITCH;
-        if (!halo) {
-#pragma unroll
-            for (int r = 0; r < 8; r++) *reinterpret_cast<U4*>(dst + r * C::CPITCH + lcol) = px[r];
-        } else {
-            // only one pixel column of a halo block is ever read: its last (left) / first (right)
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const uint32_t v = left ? (px[r].w >> 16) : (px[r].x & 0xffffu);
-                dst[r * C::CPITCH + (left ? C::COFF - 1 : lcol)] = (int16_t)v;
-            }
-        }
+        L.src = reinterpret_cast<const U4*>(p.y + (long long)t.frame * p.y_frame_stride + blk * 64);
+        L.dst = lds + (brow * 8) * C::TWY + bcol * 8;
+        L.valid = true;
+        return L;
     }
+    if (!C::CHROMA || b >= C::NBLK) return L;
+    const int cb_ = b - C::NYB;
+    const int comp = cb_ < C::NCB ? 1 : 2;
+    const int bb = comp == 1 ? cb_ : cb_ - C::NCB;
+    const int brow = bb / C::CCOLS, j = bb % C::CCOLS;
+    const int cb0 = t.tile * C::TWC;
+    const int nvalid = (cbw - cb0) < C::TWC ? (cbw - cb0) : C::TWC;
+    int gcol, lcol;
+    if (C::HALO) {
+        if (j == 0) { gcol = cb0 > 0 ? cb0 - 1 : cbw - 1; lcol = C::COFF - 1; L.halo = 1; }
+        else if (j == C::CCOLS - 1) { gcol = cb0 + nvalid < cbw ? cb0 + nvalid : 0; lcol = C::COFF + 8 * nvalid; L.halo = 2; }
+        else { if (j - 1 >= nvalid) return L; gcol = cb0 + j - 1; lcol = C::COFF + 8 * (j - 1); }
+    } else {
+        if (j >= nvalid) return L;
+        gcol = cb0 + j; lcol = 8 * j;
+    }
+    const long long blk = (long long)(t.strip * C::CBR + brow) * cbw + gcol;
+    const int16_t* plane = (comp == 1 ? p.cb : p.cr) + (long long)t.frame * p.c_frame_stride;
+    L.src = reinterpret_cast<const U4*>(plane + blk * 64);
+    L.dst = lds + C::YSZ + (comp - 1) * C::CSZ + (brow * 8) * C::CPITCH + lcol;
+    L.pitch = C::CPITCH;
+    L.comp = comp;
+    L.valid = true;
+    return L;
+}
+
+ZJ_DEV void store_block(const BlockLoc& L, const U4 px[8])
+{
+    if (L.halo == 0) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) *reinterpret_cast<U4*>(L.dst + r * L.pitch) = px[r];
+    } else {
+        // only one pixel column of a halo block is ever read: its last (left) / first (right)
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+            L.dst[r * L.pitch] = (int16_t)(L.halo == 1 ? (px[r].w >> 16) : (px[r].x & 0xffffu));
+    }
+}
+
+template <class C> ZJ_DEV int32_t* lds_qt(int16_t* lds) { return reinterpret_cast<int32_t*>(reinterpret_cast<char*>(lds) + C::QT_OFF); }
+
+// ------------------------------------------------------------------------------------------------
+// Phase 1 (one lane per block, every wave full whatever the component mix):
+//   load_block   issues the lane's 8 x 16-byte coefficient loads                 (before the barrier
+//   phase_setup  stages the three quantisation tables in LDS                      that publishes QT)
+//   finish_block dequantize + IDCT (or the DC-only shortcut, Q1) -> LDS planar staging
+// ------------------------------------------------------------------------------------------------
+ZJ_DEV void load_block(const BlockLoc& L, U4 raw[8])
+{
+    if (!L.valid) return;
+#pragma unroll
+    for (int i = 0; i < 8; i++) raw[i] = L.src[i];
+}
+
+template <class C>
+ZJ_DEV void phase_setup(const Params& p, const int tid, int16_t* lds)
+{
+    for (int i = tid; i < 192; i += C::NT) lds_qt<C>(lds)[i] = p.qt[i];
+}
+
+template <class C>
+ZJ_DEV void finish_block(const BlockLoc& L, const U4 raw[8], int16_t* lds)
+{
+    if (!L.valid) return;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(raw);
+    const int32_t* qt = lds_qt<C>(lds) + 64 * L.comp;
+    uint32_t any = w[0] & 0xffff0000u; // DC-only test (scalar.rs:45): all but coefficient 0 are zero
+#pragma unroll
+    for (int i = 1; i < 32; i++) any |= w[i];
+    U4 px[8];
+    if (any != 0) {
+        idct_block(raw, qt, px);
+    } else {
+        const uint32_t v = dc_only_value(w[0], qt[0]);
+#pragma unroll
+        for (int r = 0; r < 8; r++) { px[r].x = v; px[r].y = v; px[r].z = v; px[r].w = v; }
+    }
+    store_block(L, px);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -388,27 +451,31 @@ ZJ_DEV void phase_idct(const Params& p, const TileId t, const int tid, int16_t* 
 // ------------------------------------------------------------------------------------------------
 ZJ_DEV void store16(uint8_t* p, const U4& v) { *reinterpret_cast<U4*>(p) = v; }
 
-// 4 pixels -> 12 bytes.  EO arrangement: (e) holds px 0,2  (o) holds px 1,3.
+// 4 pixels -> 12 bytes from UNCLAMPED i16 pairs.  EO arrangement: (e) holds px 0,2  (o) px 1,3.
 ZJ_DEV void pack_rgb4_eo(const RGB2& e, const RGB2& o, uint32_t& d0, uint32_t& d1, uint32_t& d2)
 {
-    const uint32_t rg_e = e.r | (e.g << 8); // R0 G0 R2 G2
-    const uint32_t gb_o = o.g | (o.b << 8); // G1 B1 G3 B3
-    const uint32_t br = e.b | (o.r << 8);   // B0 R1 B2 R3
-    d0 = perm(br, rg_e, 0x05040100u);       // R0 G0 B0 R1
-    d1 = perm(rg_e, gb_o, 0x07060100u);     // G1 B1 R2 G2
-    d2 = perm(gb_o, br, 0x07060302u);       // B2 R3 G3 B3
+    const uint32_t x = sat_pk_u8(e.r) | (sat_pk_u8(e.g) << 16); // R0 R2 G0 G2
+    const uint32_t y = sat_pk_u8(e.b) | (sat_pk_u8(o.r) << 16); // B0 B2 R1 R3
+    const uint32_t z = sat_pk_u8(o.g) | (sat_pk_u8(o.b) << 16); // G1 G3 B1 B3
+    d0 = perm(y, x, 0x06040200u);                               // R0 G0 B0 R1
+    d1 = perm(x, z, 0x07050200u);                               // G1 B1 R2 G2
+    d2 = perm(z, y, 0x07050301u);                               // B2 R3 G3 B3
 }
 // natural arrangement: (a) holds px 0,1  (b) holds px 2,3
 ZJ_DEV void pack_rgb4_nat(const RGB2& a, const RGB2& b, uint32_t& d0, uint32_t& d1, uint32_t& d2)
 {
-    const uint32_t rg_a = a.r | (a.g << 8); // R0 G0 R1 G1
-    const uint32_t gb_a = a.g | (a.b << 8); // G0 B0 G1 B1
-    const uint32_t rg_b = b.r | (b.g << 8); // R2 G2 R3 G3
-    const uint32_t gb_b = b.g | (b.b << 8); // G2 B2 G3 B3
-    d0 = perm(a.b, rg_a, 0x02040100u);      // R0 G0 B0 R1
-    d1 = perm(rg_b, gb_a, 0x05040302u);     // G1 B1 R2 G2
-    const uint32_t x = perm(b.r, b.b, 0x00000600u); // B2 R3 . .
-    d2 = perm(gb_b, x, 0x07060100u);        // B2 R3 G3 B3
+    const uint32_t x = sat_pk_u8(a.r) | (sat_pk_u8(a.g) << 16); // R0 R1 G0 G1
+    const uint32_t y = sat_pk_u8(a.b) | (sat_pk_u8(b.r) << 16); // B0 B1 R2 R3
+    const uint32_t z = sat_pk_u8(b.g) | (sat_pk_u8(b.b) << 16); // G2 G3 B2 B3
+    d0 = perm(y, x, 0x01040200u);                               // R0 G0 B0 R1
+    const uint32_t m = perm(y, x, 0x00060503u);                 // G1 B1 R2 .
+    d1 = perm(z, m, 0x04020100u);                               // G1 B1 R2 G2
+    d2 = perm(z, y, 0x07050306u);                               // B2 R3 G3 B3
+}
+// truncating variant (`as u8`, ycbcr_to_ycbcr, color_convert/scalar.rs:119-169): low bytes
+ZJ_DEV RGB2 trunc3(uint32_t a, uint32_t b, uint32_t c)
+{
+    RGB2 o; o.r = a & 0x00ff00ffu; o.g = b & 0x00ff00ffu; o.b = c & 0x00ff00ffu; return o;
 }
 
 template <class C, int HS, int VS, int OUT>
@@ -445,7 +512,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const in
             continue;
         }
 
-        // ---- chroma for the 16 pixels, centred (value-128), packed pairs ------------------------
+        // ---- chroma for the 16 pixels (raw samples), packed pairs ---------------------------------
         uint32_t cbp[8], crp[8]; // HS==2: [0..3] = E_k (px 4k, 4k+2), [4..7] = O_k (px 4k+1, 4k+3)
                                  // HS==1: natural pairs (px 2k, 2k+1)
         int ra, rb;
@@ -499,8 +566,9 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const in
                     const uint32_t next = k == 3 ? ((uint32_t)v9 & 0xffffu) : vm[k + 1];
                     const uint32_t L = align16(vm[k], prev); // (v_{2k},   v_{2k+1})
                     const uint32_t R = align16(next, vm[k]); // (v_{2k+2}, v_{2k+3})
-                    dst[k] = tri(vm[k], L);                  // even outputs: px 4k, 4k+2
-                    dst[4 + k] = tri(vm[k], R);              // odd outputs:  px 4k+1, 4k+3
+                    const u16x2 t3 = splat(3) * as_u16x2(vm[k]) + splat(2); // shared 3*near + 2
+                    dst[k] = as_u32(sar(t3 + as_u16x2(L), 2));     // even outputs: px 4k, 4k+2
+                    dst[4 + k] = as_u32(sar(t3 + as_u16x2(R), 2)); // odd outputs:  px 4k+1, 4k+3
                 }
                 // the three unfiltered / mis-weighted samples of a strip (upsampler/scalar.rs:13,55,57)
                 if (no_left) dst[0] = (dst[0] & 0xffff0000u) | (vm[0] & 0xffffu);       // out[0] = in[0]
@@ -527,29 +595,14 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const in
         }
 
         uint32_t d[12];
-        if (OUT == OUT_RGB) {
-            RGB2 c[8];
+        RGB2 c[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) c[k] = ycc_to_rgb_pair(yp[k], cbp[k], crp[k]);
+        for (int k = 0; k < 8; k++)
+            c[k] = OUT == OUT_RGB ? ycc_to_rgb_pair(yp[k], cbp[k], crp[k]) : trunc3(yp[k], cbp[k], crp[k]);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (HS == 2) pack_rgb4_eo(c[k], c[4 + k], d[3 * k], d[3 * k + 1], d[3 * k + 2]);
-                else pack_rgb4_nat(c[2 * k], c[2 * k + 1], d[3 * k], d[3 * k + 1], d[3 * k + 2]);
-            }
-        } else { // OUT_YCBCR: ycbcr_to_ycbcr (color_convert/scalar.rs:119-169), `as u8` truncation
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                cbp[k] = as_u32(as_u16x2(cbp[k]) + splat(128));
-                crp[k] = as_u32(as_u16x2(crp[k]) + splat(128));
-            }
-            RGB2 c[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) { c[k].r = yp[k] & 0x00ff00ffu; c[k].g = cbp[k] & 0x00ff00ffu; c[k].b = crp[k] & 0x00ff00ffu; }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (HS == 2) pack_rgb4_eo(c[k], c[4 + k], d[3 * k], d[3 * k + 1], d[3 * k + 2]);
-                else pack_rgb4_nat(c[2 * k], c[2 * k + 1], d[3 * k], d[3 * k + 1], d[3 * k + 2]);
-            }
+        for (int k = 0; k < 4; k++) {
+            if (HS == 2) pack_rgb4_eo(c[k], c[4 + k], d[3 * k], d[3 * k + 1], d[3 * k + 2]);
+            else pack_rgb4_nat(c[2 * k], c[2 * k + 1], d[3 * k], d[3 * k + 1], d[3 * k + 2]);
         }
         const U4 s0 = {d[0], d[1], d[2], d[3]}, s1 = {d[4], d[5], d[6], d[7]}, s2 = {d[8], d[9], d[10], d[11]};
         const int G = px0 >> 4; // 16-pixel group index in the row

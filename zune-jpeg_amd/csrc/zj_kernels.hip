@@ -20,11 +20,18 @@ template <int HS, int VS, int OUT>
 __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT)) void zj_fused_kernel(const Params p)
 {
     using C = Cfg<HS, VS, OUT>;
-    __shared__ __attribute__((aligned(16))) int16_t lds[C::LDS_I16];
+    __shared__ __attribute__((aligned(16))) char lds_raw[C::LDS_BYTES];
+    int16_t* lds = reinterpret_cast<int16_t*>(lds_raw);
     const TileId t = decode_tile(p, (int)blockIdx.x);
-    phase_idct<C>(p, t, (int)threadIdx.x, lds);
+    const int tid = (int)threadIdx.x;
+    const BlockLoc L = locate<C>(p, t, tid, lds);
+    U4 raw[8];
+    load_block(L, raw);          // HBM loads in flight across the barrier below
+    phase_setup<C>(p, tid, lds);
     __syncthreads();
-    phase_color<C, HS, VS, OUT>(p, t, (int)threadIdx.x, lds);
+    finish_block<C>(L, raw, lds);
+    __syncthreads();
+    phase_color<C, HS, VS, OUT>(p, t, tid, lds);
 }
 
 template <int HS, int VS, int OUT>
@@ -73,7 +80,17 @@ __global__ __launch_bounds__(64) void zj_idct_strip_kernel(const int16_t* __rest
     U4 raw[8], px[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) raw[i] = src[i];
-    idct_block<false>(raw, qt, px);
+    const uint32_t* cw = reinterpret_cast<const uint32_t*>(raw);
+    uint32_t any = cw[0] & 0xffff0000u;
+#pragma unroll
+    for (int i = 1; i < 32; i++) any |= cw[i];
+    if (any == 0) { // DC-only shortcut (scalar.rs:45-74)
+        const uint32_t v = dc_only_value(cw[0], qt[0]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { px[i].x = v; px[i].y = v; px[i].z = v; px[i].w = v; }
+    } else {
+        idct_block(raw, qt, px);
+    }
     int16_t* dst = out + c * chunks + k * 8; // pos = x = 8k (scalar.rs:277-278)
 #pragma unroll
     for (int r = 0; r < 8; r++) {
@@ -126,9 +143,9 @@ __global__ void zj_rgb16_kernel(const int16_t* __restrict__ ycc /* y[16] cb[16] 
 {
     const int i = threadIdx.x;
     if (i >= 16) return;
-    const uint32_t y = (uint16_t)ycc[i], cb = (uint16_t)(ycc[16 + i] - 128), cr = (uint16_t)(ycc[32 + i] - 128);
+    const uint32_t y = (uint16_t)ycc[i], cb = (uint16_t)ycc[16 + i], cr = (uint16_t)ycc[32 + i];
     const RGB2 c = ycc_to_rgb_pair(y, cb, cr);
-    out[3 * i] = (uint8_t)c.r; out[3 * i + 1] = (uint8_t)c.g; out[3 * i + 2] = (uint8_t)c.b;
+    out[3 * i] = (uint8_t)sat_pk_u8(c.r); out[3 * i + 1] = (uint8_t)sat_pk_u8(c.g); out[3 * i + 2] = (uint8_t)sat_pk_u8(c.b);
 }
 
 hipError_t launch_idct_strip(const int16_t* coeff, const int32_t* qt, int16_t* out, long long nblocks,

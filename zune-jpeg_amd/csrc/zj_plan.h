@@ -41,10 +41,13 @@ inline int ncomp_of(int cs)
 template <int HS, int VS>
 inline void plan_geo(Plan& pl, bool chroma)
 {
-    using G = Geo<HS, VS>;
-    pl.strip_rows = G::SH;
-    pl.tiles_per_row = (pl.mcu_x + G::TWC - 1) / G::TWC;
-    pl.nt = G::NYB64 + (chroma ? 2 * G::NCB64 : 0);
+    if (chroma) {
+        using C = Cfg<HS, VS, OUT_RGB>;
+        pl.strip_rows = C::SH; pl.tiles_per_row = (pl.mcu_x + C::TWC - 1) / C::TWC; pl.nt = C::NT;
+    } else {
+        using C = Cfg<HS, VS, OUT_GRAY>;
+        pl.strip_rows = C::SH; pl.tiles_per_row = (pl.mcu_x + C::TWC - 1) / C::TWC; pl.nt = C::NT;
+    }
 }
 
 // Returns ZJ_OK or an error status.
