@@ -61,8 +61,9 @@ def load_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=100,
+                    help="untimed steps; the first ~70 launches after idle run 5-35%% slow while the clocks settle")
     ap.add_argument("--frames", type=int, default=16, help="4096x4096 frames per GPU per step")
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic frames generated (tiled to --frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -96,7 +97,11 @@ def main():
     host = [np.concatenate([frames[i % len(frames)][0][c] for i in range(B)]) for c in range(3)]
     d_planes = [torch.from_numpy(h).to(dev) for h in host]
     d_out = torch.empty(B * W * H * 3, dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    # a dedicated stream: launches on the legacy NULL stream serialise against every blocking stream
+    # and cost ~30 us each (tools/launch_overhead.py); torch.cuda.synchronize() still covers it
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    stream = side.cuda_stream
     ptrs = [t.data_ptr() for t in d_planes] + [d_out.data_ptr()]
 
     def step():

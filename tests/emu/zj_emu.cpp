@@ -24,7 +24,7 @@ static void run(const Params& p)
     for (int bid = 0; bid < p.total_tiles; bid++) {
         memset(lds, 0x7B, C::LDS_BYTES); // poison: unwritten LDS must not matter
         const TileId t = decode_tile(p, bid);
-        for (int tid = 0; tid < C::NT; tid++) phase_setup<C>(p, tid, lds);
+        for (int tid = 0; tid < C::NT; tid++) phase_setup<C, HS, VS>(p, tid, lds);
         /* __syncthreads() */
         for (int tid = 0; tid < C::NT; tid++) {
             const BlockLoc L = locate<C>(p, t, tid, lds);

@@ -25,6 +25,10 @@ if has ubench; then
   echo "== ubench" | tee -a $O/summary.txt
   timeout 300 python tools/ubench.py > $O/ubench.txt 2>&1; cat $O/ubench.txt | tee -a $O/summary.txt
 fi
+if has lab; then
+  echo "== lab" | tee -a $O/summary.txt
+  timeout 300 python tools/lab.py > $O/lab.txt 2>&1; cat $O/lab.txt | tee -a $O/summary.txt
+fi
 if has bench; then
   echo "== bench" | tee -a $O/summary.txt
   timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.json | tee -a $O/summary.txt; tail -3 $O/bench.err

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Times IDCT / colour formulations in isolation (csrc/zj_lab.hip).  cycles = per wave-iteration per
+SIMD, i.e. the VALU time one wave needs for 64 blocks (IDCT) or 64 x 16 pixels (colour)."""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    zj = importlib.import_module("zune-jpeg_amd")
+    L = zj.lib()
+    ctx = zj.Context()
+    mhz = ctx.ubench_clock_mhz()
+    blocks, iters = 4096, 20
+    print(f"clock {mhz:.0f} MHz; {'variant':52s} {'ms':>8s} {'cycles/wave-iter/SIMD':>22s}")
+    for v in range(L.zj_lab_count()):
+        ms = ctx.lab(v, blocks, iters, 3)
+        cyc = ms * 1e-3 * mhz * 1e6 * 1024 / (blocks * 4 * iters)
+        print(f"{'':16s}{L.zj_lab_name(v).decode():52s} {ms:8.3f} {cyc:22.0f}")
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -498,6 +498,26 @@ int zj_ubench(zj_ctx* c, int op, int blocks, int iters, int reps, float* ms)
     ZJ_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
     return ZJ_OK;
 }
+int zj_lab_count(void) { return lab_count(); }
+const char* zj_lab_name(int i) { return lab_name(i); }
+int zj_lab(zj_ctx* c, int variant, int blocks, int iters, int reps, float* ms)
+{
+    if (!c || !ms) return ZJ_ERR_ARG;
+    ZJ_HIP(c, hipSetDevice(c->device));
+    int rc = ensure_scratch(c, 0, (size_t)blocks * 256 * 4);
+    if (rc) return rc;
+    int32_t qt3[3][64];
+    for (int k = 0; k < 3; k++) for (int i = 0; i < 64; i++) qt3[k][i] = 1 + ((i * 7 + k * 3) % 29);
+    const int32_t* d_qt = nullptr;
+    if ((rc = stage_qt(c, qt3, c->stream, &d_qt))) return rc;
+    ZJ_HIP(c, launch_lab(variant, d_qt, (int*)c->scratch[0], blocks, iters, c->stream)); // warm-up
+    ZJ_HIP(c, hipEventRecord(c->ev0, c->stream));
+    for (int r = 0; r < reps; r++) ZJ_HIP(c, launch_lab(variant, d_qt, (int*)c->scratch[0], blocks, iters, c->stream));
+    ZJ_HIP(c, hipEventRecord(c->ev1, c->stream));
+    ZJ_HIP(c, hipEventSynchronize(c->ev1));
+    ZJ_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return ZJ_OK;
+}
 /* shader clock: cycles counted by s_memtime in one wave over a fixed spin, and the wall ms of it */
 int zj_ubench_clock(zj_ctx* c, int iters, double* cycles, float* ms)
 {

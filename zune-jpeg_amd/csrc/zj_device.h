@@ -116,20 +116,30 @@ ZJ_DEV int uniform(int v)
 // wrap-around adversarial ones) without any range check.  Requires 0 <= q <= 255 (8-bit DQT,
 // headers.rs:154-174), enforced by the host side.
 // ------------------------------------------------------------------------------------------------
+// pin(): keeps a partial sum opaque so the compiler cannot re-associate a multiply-add chain into
+// mul + mul + add3 (one instruction more per output); every VALU instruction costs ~4 cycles per
+// wave on gfx950 (profiles/r01_ubench_valu_issue_cost.txt), so instruction count is the metric.
+#if defined(ZJ_EMU)
+#define ZJ_PIN(x) ((void)0)
+#else
+#define ZJ_PIN(x) asm volatile("" : "+v"(x))
+#endif
 ZJ_DEV void idct_1d(const int32_t s[8], const int32_t bias, int32_t o[8])
 {
     // even part: t3 = (s2+s6)*2217 + s2*3135, t2 = (s2+s6)*2217 - s6*7567      (scalar.rs:81-87)
-    const int32_t t3 = mad24(s[6], 2217, mul24(s[2], 2217 + 3135));
-    const int32_t t2 = mad24(s[6], 2217 - 7567, mul24(s[2], 2217));
-    const int32_t t0 = wadd(wshl(wadd(s[0], s[4]), 12), bias); // fsh(p2+p3) + bias   (:93,:99)
-    const int32_t t1 = wadd(wshl(wsub(s[0], s[4]), 12), bias);
+    int32_t t3 = mul24(s[2], 2217 + 3135); ZJ_PIN(t3); t3 = mad24(s[6], 2217, t3);
+    int32_t t2 = mul24(s[2], 2217); ZJ_PIN(t2); t2 = mad24(s[6], 2217 - 7567, t2);
+    // t0 = fsh(s0+s4) + bias, t1 = fsh(s0-s4) + bias                           (:93-99)
+    int32_t A = wadd(wshl(s[0], 12), bias); ZJ_PIN(A);
+    const int32_t t0 = mad24(s[4], 4096, A), t1 = mad24(s[4], -4096, A);
     const int32_t x0 = wadd(t0, t3), x3 = wsub(t0, t3), x1 = wadd(t1, t2), x2 = wsub(t1, t2);
     // odd part (scalar.rs:109-148) as the integer matrix it is; a=s7 b=s5 c=s3 d=s1
+    //   u3 = d*6149 + p1 + p4 ... expanded: e.g. coefficient of d in u3 = 6149 + 4816 - 3685 - 1597
     const int32_t a = s[7], b = s[5], c = s[3], d = s[1];
-    const int32_t u3 = mad24(c, 4816, mad24(b, 4816 - 1597, mad24(a, 4816 - 3685, mul24(d, 6149 + 4816 - 3685 - 1597))));
-    const int32_t u2 = mad24(d, 4816, mad24(a, 4816 - 8034, mad24(b, 4816 - 10497, mul24(c, 12586 + 4816 - 10497 - 8034))));
-    const int32_t u1 = mad24(a, 4816, mad24(d, 4816 - 1597, mad24(c, 4816 - 10497, mul24(b, 8410 + 4816 - 10497 - 1597))));
-    const int32_t u0 = mad24(b, 4816, mad24(c, 4816 - 8034, mad24(d, 4816 - 3685, mul24(a, 1223 + 4816 - 3685 - 8034))));
+    int32_t u3 = mul24(d, 6149 + 4816 - 3685 - 1597); ZJ_PIN(u3); u3 = mad24(a, 4816 - 3685, u3); ZJ_PIN(u3); u3 = mad24(b, 4816 - 1597, u3); ZJ_PIN(u3); u3 = mad24(c, 4816, u3);
+    int32_t u2 = mul24(c, 12586 + 4816 - 10497 - 8034); ZJ_PIN(u2); u2 = mad24(b, 4816 - 10497, u2); ZJ_PIN(u2); u2 = mad24(a, 4816 - 8034, u2); ZJ_PIN(u2); u2 = mad24(d, 4816, u2);
+    int32_t u1 = mul24(b, 8410 + 4816 - 10497 - 1597); ZJ_PIN(u1); u1 = mad24(c, 4816 - 10497, u1); ZJ_PIN(u1); u1 = mad24(d, 4816 - 1597, u1); ZJ_PIN(u1); u1 = mad24(a, 4816, u1);
+    int32_t u0 = mul24(a, 1223 + 4816 - 3685 - 8034); ZJ_PIN(u0); u0 = mad24(d, 4816 - 3685, u0); ZJ_PIN(u0); u0 = mad24(c, 4816 - 8034, u0); ZJ_PIN(u0); u0 = mad24(b, 4816, u0);
     o[0] = wadd(x0, u3); o[7] = wsub(x0, u3);
     o[1] = wadd(x1, u2); o[6] = wsub(x1, u2);
     o[2] = wadd(x2, u1); o[5] = wsub(x2, u1);
@@ -151,6 +161,19 @@ ZJ_DEV uint32_t sat_pk_u8(uint32_t v)
 #else
     uint32_t r;
     asm("v_sat_pk_u8_i16_e32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+#endif
+}
+
+// lo = sat_pk_u8(a) in bits 0..15, sat_pk_u8(b) in bits 16..31 (SDWA write into the high word)
+ZJ_DEV uint32_t sat_pk_u8_2(uint32_t a, uint32_t b)
+{
+#if defined(ZJ_EMU)
+    return sat_pk_u8(a) | (sat_pk_u8(b) << 16);
+#else
+    uint32_t r;
+    asm("v_sat_pk_u8_i16_e32 %0, %1" : "=v"(r) : "v"(a));
+    asm("v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(r) : "v"(b));
     return r;
 #endif
 }
@@ -185,10 +208,10 @@ ZJ_DEV void idct_block(const U4 raw[8], const int32_t* qt, U4 out[8])
         idct_1d(&tmp[r * 8], bias2, o);
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
-            int32_t p0 = o[k] >> 17, p1 = o[k + 1] >> 17;
-            p0 = p0 < 0 ? 0 : (p0 > 255 ? 255 : p0);
-            p1 = p1 < 0 ? 0 : (p1 > 255 ? 255 : p1);
-            ow[r * 4 + (k >> 1)] = (uint32_t)p0 | ((uint32_t)p1 << 16);
+            // (x >> 17) always fits 15 bits: pack the pair first, then clamp both lanes at once
+            const uint32_t pk = ((uint32_t)(o[k] >> 17) & 0xffffu) | ((uint32_t)(o[k + 1] >> 17) << 16);
+            const s16x2 z = {0, 0}, m = {255, 255};
+            ow[r * 4 + (k >> 1)] = as_u32(pk_min(pk_max(as_s16x2(pk), z), m));
         }
     }
 }
@@ -276,7 +299,9 @@ struct Cfg {
     static constexpr int NT = (NBLK + 63) / 64 * 64;                 // threads per workgroup
     static constexpr int PLANAR_I16 = YSZ + (CHROMA ? 2 * CSZ : 0);
     static constexpr int QT_OFF = PLANAR_I16 * 2;                    // byte offset, 16-aligned
-    static constexpr int LDS_BYTES = QT_OFF + 3 * 64 * 4;
+    static constexpr int LUT_OFF = QT_OFF + 3 * 64 * 4;              // row-offset tables, see phase_setup
+    static constexpr int LUT_N = SH + 2;
+    static constexpr int LDS_BYTES = LUT_OFF + ((2 * LUT_N * 2 + 15) / 16) * 16;
     static_assert(PLANAR_I16 % 8 == 0, "planar area must keep 16-byte alignment");
     static_assert(NT <= 256 && NBLK <= NT, "one lane per block, at most 4 waves");
 };
@@ -420,10 +445,23 @@ ZJ_DEV void load_block(const BlockLoc& L, U4 raw[8])
     for (int i = 0; i < 8; i++) raw[i] = L.src[i];
 }
 
-template <class C>
+template <class C> ZJ_DEV int16_t* lds_lut(int16_t* lds) { return reinterpret_cast<int16_t*>(reinterpret_cast<char*>(lds) + C::LUT_OFF); }
+template <class C> ZJ_DEV const int16_t* lds_lut(const int16_t* lds) { return reinterpret_cast<const int16_t*>(reinterpret_cast<const char*>(lds) + C::LUT_OFF); }
+
+// Stages the three quantisation tables and, for vertically sub-sampled modes, the LDS offsets of the
+// two chroma rows (weights 3 and 1) behind every up-sampled row m = -1 .. SH (Q3): lutA[m+1], lutB[m+1].
+template <class C, int HS, int VS>
 ZJ_DEV void phase_setup(const Params& p, const int tid, int16_t* lds)
 {
     for (int i = tid; i < 192; i += C::NT) lds_qt<C>(lds)[i] = p.qt[i];
+    if (C::CHROMA && VS == 2) {
+        for (int i = tid; i < C::LUT_N; i += C::NT) {
+            int ra = 0, rb = 0;
+            if (i >= 1 && i <= C::SH) vrows<HS, VS>(i - 1, ra, rb);
+            lds_lut<C>(lds)[i] = (int16_t)(ra * C::CPITCH);
+            lds_lut<C>(lds)[C::LUT_N + i] = (int16_t)(rb * C::CPITCH);
+        }
+    }
 }
 
 template <class C>
@@ -454,9 +492,9 @@ ZJ_DEV void store16(uint8_t* p, const U4& v) { *reinterpret_cast<U4*>(p) = v; }
 // 4 pixels -> 12 bytes from UNCLAMPED i16 pairs.  EO arrangement: (e) holds px 0,2  (o) px 1,3.
 ZJ_DEV void pack_rgb4_eo(const RGB2& e, const RGB2& o, uint32_t& d0, uint32_t& d1, uint32_t& d2)
 {
-    const uint32_t x = sat_pk_u8(e.r) | (sat_pk_u8(e.g) << 16); // R0 R2 G0 G2
-    const uint32_t y = sat_pk_u8(e.b) | (sat_pk_u8(o.r) << 16); // B0 B2 R1 R3
-    const uint32_t z = sat_pk_u8(o.g) | (sat_pk_u8(o.b) << 16); // G1 G3 B1 B3
+    const uint32_t x = sat_pk_u8_2(e.r, e.g); // R0 R2 G0 G2
+    const uint32_t y = sat_pk_u8_2(e.b, o.r); // B0 B2 R1 R3
+    const uint32_t z = sat_pk_u8_2(o.g, o.b); // G1 G3 B1 B3
     d0 = perm(y, x, 0x06040200u);                               // R0 G0 B0 R1
     d1 = perm(x, z, 0x07050200u);                               // G1 B1 R2 G2
     d2 = perm(z, y, 0x07050301u);                               // B2 R3 G3 B3
@@ -464,9 +502,9 @@ ZJ_DEV void pack_rgb4_eo(const RGB2& e, const RGB2& o, uint32_t& d0, uint32_t& d
 // natural arrangement: (a) holds px 0,1  (b) holds px 2,3
 ZJ_DEV void pack_rgb4_nat(const RGB2& a, const RGB2& b, uint32_t& d0, uint32_t& d1, uint32_t& d2)
 {
-    const uint32_t x = sat_pk_u8(a.r) | (sat_pk_u8(a.g) << 16); // R0 R1 G0 G1
-    const uint32_t y = sat_pk_u8(a.b) | (sat_pk_u8(b.r) << 16); // B0 B1 R2 R3
-    const uint32_t z = sat_pk_u8(b.g) | (sat_pk_u8(b.b) << 16); // G2 G3 B2 B3
+    const uint32_t x = sat_pk_u8_2(a.r, a.g); // R0 R1 G0 G1
+    const uint32_t y = sat_pk_u8_2(a.b, b.r); // B0 B1 R2 R3
+    const uint32_t z = sat_pk_u8_2(b.g, b.b); // G2 G3 B2 B3
     d0 = perm(y, x, 0x01040200u);                               // R0 G0 B0 R1
     const uint32_t m = perm(y, x, 0x00060503u);                 // G1 B1 R2 .
     d1 = perm(z, m, 0x04020100u);                               // G1 B1 R2 G2
@@ -515,18 +553,33 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const in
         // ---- chroma for the 16 pixels (raw samples), packed pairs ---------------------------------
         uint32_t cbp[8], crp[8]; // HS==2: [0..3] = E_k (px 4k, 4k+2), [4..7] = O_k (px 4k+1, 4k+3)
                                  // HS==1: natural pairs (px 2k, 2k+1)
-        int ra, rb;
-        vrows<HS, VS>(m, ra, rb);
+        // LDS offsets (i16 elements) of the chroma rows behind up-sampled row m, and behind rows
+        // m-1 / m+1 where the flat-array neighbour wraps to the other end of the strip (Q4)
+        const bool first = HS == 2 && (g == 0) && left_wrap;                  // chroma column 0 of the strip
+        const bool last = HS == 2 && (8 * g + 8 == 8 * nvalid) && right_wrap; // last chroma column
+        const bool no_left = first && m == 0, no_right = last && m == C::SH - 1;
+        int oa, ob, oal, obl, oar, obr;
+        if (VS == 2) {
+            const int16_t* lut = lds_lut<C>(lds);
+            const int im = m + 1, il = im - (first ? 1 : 0), ir = im + (last ? 1 : 0);
+            oa = lut[im]; ob = lut[C::LUT_N + im];
+            oal = lut[il]; obl = lut[C::LUT_N + il];
+            oar = lut[ir]; obr = lut[C::LUT_N + ir];
+        } else {
+            oa = ob = m * C::CPITCH;
+            oal = obl = (first && m > 0 ? m - 1 : m) * C::CPITCH;
+            oar = obr = (last && m < C::SH - 1 ? m + 1 : m) * C::CPITCH;
+        }
 #pragma unroll
         for (int ch = 0; ch < 2; ch++) {
             const int16_t* cp = lds + C::YSZ + ch * C::CSZ;
             uint32_t* dst = ch ? crp : cbp;
             if (HS == 1) {
-                const U4* A = reinterpret_cast<const U4*>(cp + ra * C::CPITCH + 16 * g);
+                const U4* A = reinterpret_cast<const U4*>(cp + oa + 16 * g);
                 const U4 a0 = A[0], a1 = A[1];
                 uint32_t v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
                 if (VS == 2) {
-                    const U4* B = reinterpret_cast<const U4*>(cp + rb * C::CPITCH + 16 * g);
+                    const U4* B = reinterpret_cast<const U4*>(cp + ob + 16 * g);
                     const U4 b0 = B[0], b1 = B[1];
                     const uint32_t f[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
@@ -536,37 +589,23 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const in
                 for (int k = 0; k < 8; k++) dst[k] = v[k];
             } else {
                 const int lc = C::COFF + 8 * g; // LDS column of this group's first chroma sample
-                const U4 a = *reinterpret_cast<const U4*>(cp + ra * C::CPITCH + lc);
+                const U4 a = *reinterpret_cast<const U4*>(cp + oa + lc);
                 uint32_t vm[4] = {a.x, a.y, a.z, a.w}; // (v1,v2) (v3,v4) (v5,v6) (v7,v8)
+                // the neighbours come as aligned pairs: (x, v0) left of the group, (v9, x) right of it
+                uint32_t prev = *reinterpret_cast<const uint32_t*>(cp + oal + lc - 2);
+                uint32_t next = *reinterpret_cast<const uint32_t*>(cp + oar + lc + 8);
                 if (VS == 2) {
-                    const U4 b = *reinterpret_cast<const U4*>(cp + rb * C::CPITCH + lc);
+                    const U4 b = *reinterpret_cast<const U4*>(cp + ob + lc);
                     vm[0] = tri(vm[0], b.x); vm[1] = tri(vm[1], b.y);
                     vm[2] = tri(vm[2], b.z); vm[3] = tri(vm[3], b.w);
-                }
-                // flat-array neighbours (Q4): rows shift by one where the halo wrapped around
-                const bool first = (g == 0) && left_wrap;              // chroma column 0 of the strip
-                const bool last = (8 * g + 8 == 8 * nvalid) && right_wrap; // last chroma column
-                int v0 = 0, v9 = 0;
-                const bool no_left = first && m == 0, no_right = last && m == C::SH - 1;
-                if (!no_left) {
-                    int la, lb;
-                    vrows<HS, VS>(first ? m - 1 : m, la, lb);
-                    const int na = cp[la * C::CPITCH + lc - 1];
-                    v0 = VS == 2 ? tri1(na, cp[lb * C::CPITCH + lc - 1]) : na;
-                }
-                if (!no_right) {
-                    int la, lb;
-                    vrows<HS, VS>(last ? m + 1 : m, la, lb);
-                    const int na = cp[la * C::CPITCH + lc + 8];
-                    v9 = VS == 2 ? tri1(na, cp[lb * C::CPITCH + lc + 8]) : na;
+                    prev = tri(prev, *reinterpret_cast<const uint32_t*>(cp + obl + lc - 2));
+                    next = tri(next, *reinterpret_cast<const uint32_t*>(cp + obr + lc + 8));
                 }
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const uint32_t prev = k == 0 ? ((uint32_t)v0 << 16) : vm[k - 1];
-                    const uint32_t next = k == 3 ? ((uint32_t)v9 & 0xffffu) : vm[k + 1];
-                    const uint32_t L = align16(vm[k], prev); // (v_{2k},   v_{2k+1})
-                    const uint32_t R = align16(next, vm[k]); // (v_{2k+2}, v_{2k+3})
-                    const u16x2 t3 = splat(3) * as_u16x2(vm[k]) + splat(2); // shared 3*near + 2
+                    const uint32_t L = align16(vm[k], k == 0 ? prev : vm[k - 1]); // (v_{2k},   v_{2k+1})
+                    const uint32_t R = align16(k == 3 ? next : vm[k + 1], vm[k]); // (v_{2k+2}, v_{2k+3})
+                    const u16x2 t3 = splat(3) * as_u16x2(vm[k]) + splat(2);        // shared 3*near + 2
                     dst[k] = as_u32(sar(t3 + as_u16x2(L), 2));     // even outputs: px 4k, 4k+2
                     dst[4 + k] = as_u32(sar(t3 + as_u16x2(R), 2)); // odd outputs:  px 4k+1, 4k+3
                 }

@@ -27,7 +27,7 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT)) void zj_fused_kernel(const 
     const BlockLoc L = locate<C>(p, t, tid, lds);
     U4 raw[8];
     load_block(L, raw);          // HBM loads in flight across the barrier below
-    phase_setup<C>(p, tid, lds);
+    phase_setup<C, HS, VS>(p, tid, lds);
     __syncthreads();
     finish_block<C>(L, raw, lds);
     __syncthreads();

@@ -15,5 +15,8 @@ hipError_t launch_rgb16(const int16_t* ycc, uint8_t* out, hipStream_t s);
 int ubench2_count();
 const char* ubench2_name(int op);
 hipError_t launch_ubench2(int op, int* out, int blocks, int iters, int seed, hipStream_t s);
+int lab_count();
+const char* lab_name(int i);
+hipError_t launch_lab(int i, const int32_t* qt, int* out, int blocks, int iters, hipStream_t s);
 hipError_t launch_ub_clock(unsigned long long* out, int blocks, int iters, hipStream_t s);
 } // namespace zj

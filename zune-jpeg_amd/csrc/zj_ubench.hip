@@ -61,6 +61,12 @@ namespace zj {
 #define I_PKSUB(r) "v_pk_sub_i16 " #r ", " #r ", %9\n"
 #define I_PKMIN(r) "v_pk_min_i16 " #r ", " #r ", %9\n"
 #define I_OR3(r) "v_or3_b32 " #r ", " #r ", %9, %8\n"
+#define I_MIX1(r) "v_mul_i32_i24_e32 " #r ", 0x14e8, " #r "\n v_add_u32_e32 " #r ", %9, " #r "\n"
+#define I_MIX2(r) "v_mad_i32_i24 " #r ", " #r ", %9, %9\n v_add_u32_e32 " #r ", %9, " #r "\n v_ashrrev_i32_e32 " #r ", 3, " #r "\n"
+#define I_MIX3(r) "v_add_u32_e32 " #r ", %9, " #r "\n v_ashrrev_i32_e32 " #r ", 3, " #r "\n"
+#define I_MAX(r) "v_max_i32_e32 " #r ", %9, " #r "\n"
+#define I_LSHL(r) "v_lshlrev_b32_e32 " #r ", 3, " #r "\n"
+#define I_AND(r) "v_and_b32_e32 " #r ", %9, " #r "\n"
 
 UB_KERNEL(ub_add, I_ADD)
 UB_KERNEL(ub_add64, I_ADD64)
@@ -96,6 +102,36 @@ UB_KERNEL(ub_madu24, I_MAD_U32_U24)
 UB_KERNEL(ub_pksub, I_PKSUB)
 UB_KERNEL(ub_pkmin, I_PKMIN)
 UB_KERNEL(ub_or3, I_OR3)
+UB_KERNEL(ub_mix1, I_MIX1)
+UB_KERNEL(ub_mix2, I_MIX2)
+UB_KERNEL(ub_mix3, I_MIX3)
+UB_KERNEL(ub_max, I_MAX)
+UB_KERNEL(ub_lshl, I_LSHL)
+UB_KERNEL(ub_and, I_AND)
+
+#define UB_KERNEL_BODY(NAME, BODY)                                                                     \
+    __global__ __launch_bounds__(256) void NAME(int* out, int iters, int seed)                         \
+    {                                                                                                  \
+        int a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, \
+            a6 = a0 * 17, a7 = a0 * 19;                                                                \
+        int k = __builtin_amdgcn_readfirstlane(seed | 3);                                              \
+        int b = a0 ^ 0x55aa;                                                                           \
+        for (int it = 0; it < iters; it++) {                                                           \
+            R8(asm volatile(BODY                                                                       \
+                            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) \
+                            : "s"(k), "v"(b));)                                                        \
+        }                                                                                              \
+        int acc = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;                                               \
+        if (acc == 0x7fffffff) out[blockIdx.x * blockDim.x + threadIdx.x] = acc;                       \
+    }
+#define ALL8(I) I(%0) I(%1) I(%2) I(%3) I(%4) I(%5) I(%6) I(%7)
+// 24 instructions per statement: 8 mad + 8 add + 8 ashr, grouped by kind vs interleaved per register
+UB_KERNEL_BODY(ub_grp_mad_add_ashr, ALL8(I_MAD24V) ALL8(I_ADD) ALL8(I_ASHR))
+UB_KERNEL_BODY(ub_grp_mad_add2, ALL8(I_MAD24V) ALL8(I_ADD) ALL8(I_SUB) ALL8(I_ASHR) ALL8(I_OR))
+UB_KERNEL_BODY(ub_grp_mad4_add4, I_MAD24V(%0) I_MAD24V(%1) I_MAD24V(%2) I_MAD24V(%3) I_ADD(%4) I_ADD(%5) I_ADD(%6) I_ADD(%7) I_MAD24V(%4) I_MAD24V(%5) I_MAD24V(%6) I_MAD24V(%7) I_ADD(%0) I_ADD(%1) I_ADD(%2) I_ADD(%3))
+UB_KERNEL_BODY(ub_grp_mad2_add2, I_MAD24V(%0) I_MAD24V(%1) I_ADD(%2) I_ADD(%3) I_MAD24V(%4) I_MAD24V(%5) I_ADD(%6) I_ADD(%7) I_MAD24V(%2) I_MAD24V(%3) I_ADD(%0) I_ADD(%1) I_MAD24V(%6) I_MAD24V(%7) I_ADD(%4) I_ADD(%5))
+UB_KERNEL_BODY(ub_grp_mad1_add1_indep, I_MAD24V(%0) I_ADD(%1) I_MAD24V(%2) I_ADD(%3) I_MAD24V(%4) I_ADD(%5) I_MAD24V(%6) I_ADD(%7) I_MAD24V(%1) I_ADD(%0) I_MAD24V(%3) I_ADD(%2) I_MAD24V(%5) I_ADD(%4) I_MAD24V(%7) I_ADD(%6))
+UB_KERNEL_BODY(ub_grp_mad1_add3, I_MAD24V(%0) I_ADD(%1) I_ADD(%2) I_ADD(%3) I_MAD24V(%4) I_ADD(%5) I_ADD(%6) I_ADD(%7) I_MAD24V(%1) I_ADD(%0) I_ADD(%2) I_ADD(%3) I_MAD24V(%5) I_ADD(%4) I_ADD(%6) I_ADD(%7))
 
 // shader-clock probe: cycles (s_memtime) spent by one wave in a fixed spin, to convert ms -> MHz
 __global__ void ub_clock(unsigned long long* out, int iters)
@@ -121,6 +157,14 @@ static const struct { const char* name; ub_fn fn; } UB[] = {
     {"v_bfe_i32", ub_bfe}, {"v_sat_pk_u8_i16", ub_satpk},
     {"v_pk_add_u16", ub_pkadd}, {"v_pk_sub_i16", ub_pksub}, {"v_pk_mul_lo_u16", ub_pkmul}, {"v_pk_mad_u16", ub_pkmad},
     {"v_pk_ashrrev_i16", ub_pkashr}, {"v_pk_max_i16", ub_pkmax}, {"v_pk_min_i16", ub_pkmin},
+    {"v_max_i32_e32", ub_max}, {"v_lshlrev_b32_e32", ub_lshl}, {"v_and_b32_e32", ub_and},
+    {"PAIR mul24 ; add          (2 instr)", ub_mix1}, {"TRIPLE mad24 ; add ; ashr (3 instr)", ub_mix2}, {"PAIR add ; ashr            (2 instr)", ub_mix3},
+    {"GROUPED 8 mad | 8 add | 8 ashr   (x3 instr)", ub_grp_mad_add_ashr},
+    {"GROUPED 8 mad | 32 simple        (x5 instr)", ub_grp_mad_add2},
+    {"RUNS 4 mad | 4 add (indep)        (x2 instr)", ub_grp_mad4_add4},
+    {"RUNS 2 mad | 2 add (indep)        (x2 instr)", ub_grp_mad2_add2},
+    {"RUNS 1 mad | 1 add (indep)        (x2 instr)", ub_grp_mad1_add1_indep},
+    {"RUNS 1 mad | 3 add (indep)        (x2 instr)", ub_grp_mad1_add3},
 };
 
 int ubench2_count() { return (int)(sizeof(UB) / sizeof(UB[0])); }

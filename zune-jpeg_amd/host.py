@@ -162,6 +162,9 @@ def lib():
     L.zj_ubench.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.zj_ubench_name.restype = C.c_char_p
     L.zj_ubench_name.argtypes = [C.c_int]
+    L.zj_lab.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.zj_lab_name.restype = C.c_char_p
+    L.zj_lab_name.argtypes = [C.c_int]
     L.zj_ubench_clock.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float)]
     _LIB = L
     return L
@@ -331,6 +334,11 @@ class Context:
     def ubench(self, op, blocks=2048, iters=200, reps=5):
         ms = C.c_float(0)
         _check(lib().zj_ubench(self._h, op, blocks, iters, reps, C.byref(ms)), "zj_ubench", self._h)
+        return ms.value / reps
+
+    def lab(self, variant, blocks=4096, iters=20, reps=3):
+        ms = C.c_float(0)
+        _check(lib().zj_lab(self._h, variant, blocks, iters, reps, C.byref(ms)), "zj_lab", self._h)
         return ms.value / reps
 
     def ubench_clock_mhz(self, iters=200000):
