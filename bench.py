@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--frames", type=int, default=16, help="4096x4096 frames per GPU per step")
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic frames generated (tiled to --frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", choices=["onepass", "compact"], default=None, help="kernel variant (default: library default)")
     args = ap.parse_args()
 
     import numpy as np
@@ -88,6 +89,8 @@ def main():
 
     B = args.frames
     ctx = zj.Context(zj.BACKEND_HIP, local_rank)
+    if args.variant:
+        ctx.set_variant(args.variant == "compact")
     # synthetic data, SURVEY.md 8d generator; every rank decodes its own shard of the global batch
     lo, _ = shard.shard_range(B * world, rank, world)
     frames = [synth.make_frame(W, H, 2, 2, 3, seed=1234, frame_index=(lo + i) % max(args.distinct, 1))

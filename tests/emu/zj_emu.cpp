@@ -14,15 +14,18 @@
 
 using namespace zj;
 
+static int g_compact = 0;
+extern "C" void zje_set_variant(int compact) { g_compact = compact; }
+
 template <int HS, int VS, int OUT>
 static void run(const Params& p)
 {
     using C = Cfg<HS, VS, OUT>;
-    std::vector<char> lds_store(C::LDS_BYTES + 32);
+    std::vector<char> lds_store(C::LDS_BYTES_COMPACT + 32);
     // 16-byte aligned like a real LDS allocation
     int16_t* lds = (int16_t*)(((uintptr_t)lds_store.data() + 15) & ~(uintptr_t)15);
     for (int bid = 0; bid < p.total_tiles; bid++) {
-        memset(lds, 0x7B, C::LDS_BYTES); // poison: unwritten LDS must not matter
+        memset(lds, 0x7B, C::LDS_BYTES_COMPACT); // poison: unwritten LDS must not matter
         const TileId t = decode_tile(p, bid);
         for (int tid = 0; tid < C::NT; tid++) phase_setup<C, HS, VS>(p, tid, lds);
         /* __syncthreads() */
@@ -30,9 +33,14 @@ static void run(const Params& p)
             const BlockLoc L = locate<C>(p, t, tid, lds);
             U4 raw[8];
             load_block(L, raw);
-            finish_block<C>(L, raw, lds);
+            if (g_compact) classify_stage<C>(L, raw, p.qt[64 * L.comp], tid, lds);
+            else finish_block<C>(L, raw, lds);
         }
         /* __syncthreads() */
+        if (g_compact) {
+            for (int tid = 0; tid < C::NT; tid++) idct_queue<C>(tid, lds);
+            /* __syncthreads() */
+        }
         for (int tid = 0; tid < C::NT; tid++) phase_color<C, HS, VS, OUT>(p, t, tid, lds);
     }
 }

@@ -24,6 +24,10 @@ def lib():
     return _LIB
 
 
+def set_variant(compact):
+    lib().zje_set_variant(C.c_int(1 if compact else 0))
+
+
 def decode_planes(frame, planes, nframes=1, zero_fill=1, poison=0xAA):
     """frame: any ctypes struct laid out like zj_frame_desc."""
     arrs = [np.ascontiguousarray(p, np.int16) for p in planes]

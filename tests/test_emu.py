@@ -10,10 +10,18 @@ import oracle_c as oc
 MODES = {"none": (1, 1), "h": (2, 1), "v": (1, 2), "hv": (2, 2)}
 
 
+@pytest.fixture(autouse=True)
+def _default_variant():
+    yield
+    emu_c.set_variant(0)
+
+
 @pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("out_cs", [oc.RGB, oc.GRAYSCALE, oc.YCBCR])
 @pytest.mark.parametrize("wh", [(64, 64), (528, 40), (32, 8), (272, 100), (1040, 33), (2080, 16)])
-def test_emulated_kernel_matches_oracle(mode, out_cs, wh, synth):
+@pytest.mark.parametrize("compact", [0, 1])
+def test_emulated_kernel_matches_oracle(mode, out_cs, wh, synth, compact):
+    emu_c.set_variant(compact)
     hs, vs = MODES[mode]
     w, h = wh
     for adversarial in (False, True):

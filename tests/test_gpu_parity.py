@@ -22,9 +22,10 @@ def zj():
     return importlib.import_module("zune-jpeg_amd")
 
 
-@pytest.fixture(scope="module")
-def ctx(zj):
+@pytest.fixture(scope="module", params=[0, 1], ids=["onepass", "compact"])
+def ctx(zj, request):
     c = zj.Context(zj.BACKEND_HIP, 0)  # no GPU -> raises; nothing falls back to the CPU
+    c.set_variant(request.param)       # both kernel variants must be bit-exact
     yield c
     c.close()
 

@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+for lib in libzjhip.so libzjhip_twc10.so libzjhip_twc15.so; do
+  if [ -f zune-jpeg_amd/$lib ]; then
+    ZJ_LIB=$lib python bench.py --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['achieved'])"
+  fi
+done

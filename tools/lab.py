@@ -20,6 +20,10 @@ def main():
         ms = ctx.lab(v, blocks, iters, 3)
         cyc = ms * 1e-3 * mhz * 1e6 * 1024 / (blocks * 4 * iters)
         print(f"{'':16s}{L.zj_lab_name(v).decode():52s} {ms:8.3f} {cyc:22.0f}")
+    nbytes = 384 * 256 * 8192  # 805 MB in + 805 MB out, the size of one 16-frame launch
+    for v in range(L.zj_labmem_count()):
+        ms = ctx.labmem(v, nbytes, 20)
+        print(f"{'':16s}{L.zj_labmem_name(v).decode():52s} {ms:8.3f} ms {2 * nbytes / ms / 1e6:10.1f} GB/s")
     ctx.close()
 
 

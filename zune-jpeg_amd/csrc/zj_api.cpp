@@ -3,6 +3,7 @@
 // kernel launches.  There is no CPU compute path in this library.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -31,6 +32,8 @@ struct zj_ctx {
     size_t scratch_cap[N_SCRATCH] = {0, 0, 0, 0};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string last_error;
+    int debug = 0;                // ablation switches, diagnostics only (results are WRONG when set)
+    int compact = 0;              // kernel variant: 1 = DC-only compaction (ZJ_COMPACT / zj_set_variant)
 };
 
 #define ZJ_HIP(ctx, call)                                                                          \
@@ -108,6 +111,7 @@ zj_ctx* zj_ctx_create(int backend, int device, int* status)
     zj_ctx* c = new (std::nothrow) zj_ctx();
     if (!c) { *status = ZJ_ERR_NOMEM; return nullptr; }
     c->device = device;
+    if (const char* e = getenv("ZJ_COMPACT")) c->compact = atoi(e) != 0;
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
               hipMalloc((void**)&c->d_qt, QT_SLOTS * 192 * sizeof(int32_t)) == hipSuccess &&
               hipHostMalloc((void**)&c->h_qt, QT_SLOTS * 192 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess &&
@@ -210,13 +214,14 @@ static int decode_device_impl(zj_ctx* c, const zj_frame_desc* d, const Plan& pl,
     if (rc) return rc;
     Params p;
     fill_params(d, pl, nframes, d_y, d_cb, d_cr, d_out, d_qt, zero_fill, p);
+    p.debug = c->debug;
     if (zero_fill && pl.rows_covered < (int)d->height) {
         // rows below the last complete strip are never written by the reference (Q6): zeros
         const size_t off = (size_t)pl.rows_covered * d->width * pl.ncomp_out;
         for (size_t f = 0; f < nframes; f++)
             ZJ_HIP(c, hipMemsetAsync(d_out + f * pl.out_len + off, 0, pl.out_len - off, s));
     }
-    ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, p, s));
+    ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->compact, p, s));
     return ZJ_OK;
 }
 
@@ -481,6 +486,11 @@ zj_color_convert16_fn zj_choose_ycbcr_to_rgb_convert_func(int backend, int out_c
     return zj_ycbcr_to_rgb16;
 }
 
+/* kernel-variant switch for A/B measurements (both variants are bit-exact) */
+int zj_set_variant(zj_ctx* c, int compact) { if (!c) return ZJ_ERR_ARG; c->compact = compact != 0; return ZJ_OK; }
+/* ablation for tools/ablate.py: bit 0 skips the IDCT, bit 1 the colour math; output is WRONG when non-zero */
+int zj_set_ablation(zj_ctx* c, int mask) { if (!c) return ZJ_ERR_ARG; c->debug = mask; return ZJ_OK; }
+
 /* micro-benchmark hooks used by tools/ubench.py (not part of the decode path) */
 int zj_ubench_count(void) { return ubench2_count(); }
 const char* zj_ubench_name(int op) { return ubench2_name(op); }
@@ -493,6 +503,23 @@ int zj_ubench(zj_ctx* c, int op, int blocks, int iters, int reps, float* ms)
     ZJ_HIP(c, launch_ubench2(op, (int*)c->scratch[0], blocks, iters, 12345, c->stream)); // warm-up
     ZJ_HIP(c, hipEventRecord(c->ev0, c->stream));
     for (int r = 0; r < reps; r++) ZJ_HIP(c, launch_ubench2(op, (int*)c->scratch[0], blocks, iters, 12345 + r, c->stream));
+    ZJ_HIP(c, hipEventRecord(c->ev1, c->stream));
+    ZJ_HIP(c, hipEventSynchronize(c->ev1));
+    ZJ_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return ZJ_OK;
+}
+int zj_labmem_count(void) { return labmem_count(); }
+const char* zj_labmem_name(int i) { return labmem_name(i); }
+int zj_labmem(zj_ctx* c, int variant, long long bytes, int reps, float* ms)
+{
+    if (!c || !ms || bytes % (384 * 256) != 0) return ZJ_ERR_ARG;
+    ZJ_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure_scratch(c, 0, (size_t)bytes)) || (rc = ensure_scratch(c, 3, (size_t)bytes))) return rc;
+    ZJ_HIP(c, hipMemsetAsync(c->scratch[0], 1, (size_t)bytes, c->stream));
+    for (int r = 0; r < 3; r++) ZJ_HIP(c, launch_labmem(variant, c->scratch[0], c->scratch[3], bytes, c->stream));
+    ZJ_HIP(c, hipEventRecord(c->ev0, c->stream));
+    for (int r = 0; r < reps; r++) ZJ_HIP(c, launch_labmem(variant, c->scratch[0], c->scratch[3], bytes, c->stream));
     ZJ_HIP(c, hipEventRecord(c->ev1, c->stream));
     ZJ_HIP(c, hipEventSynchronize(c->ev1));
     ZJ_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));

@@ -262,7 +262,10 @@ ZJ_DEV int tri1(int near_, int far_) { return (int)(int16_t)(uint16_t)(3 * near_
 // Tile width (TWC chroma block columns) is chosen so that the tile's blocks fill the workgroup's
 // waves: with one lane per block and 256 lanes, 4:2:0->RGB has 12*TWC + 8 blocks -> TWC = 20 (248).
 template <int HS, int VS, bool CHROMA> struct TileWidth;
-template <> struct TileWidth<2, 2, true> { static constexpr int TWC = 20; };   // 248 blocks, 320 px
+#ifndef ZJ_TWC_HV
+#define ZJ_TWC_HV 20
+#endif
+template <> struct TileWidth<2, 2, true> { static constexpr int TWC = ZJ_TWC_HV; }; // 20: 248 blocks, 320 px
 template <> struct TileWidth<2, 1, true> { static constexpr int TWC = 31; };   // 8*TWC+8 = 256, 496 px
 template <> struct TileWidth<1, 2, true> { static constexpr int TWC = 64; };   // 4*TWC = 256, 512 px
 template <> struct TileWidth<1, 1, true> { static constexpr int TWC = 84; };   // 3*TWC = 252, 672 px
@@ -301,9 +304,17 @@ struct Cfg {
     static constexpr int QT_OFF = PLANAR_I16 * 2;                    // byte offset, 16-aligned
     static constexpr int LUT_OFF = QT_OFF + 3 * 64 * 4;              // row-offset tables, see phase_setup
     static constexpr int LUT_N = SH + 2;
-    static constexpr int LDS_BYTES = LUT_OFF + ((2 * LUT_N * 2 + 15) / 16) * 16;
+    static constexpr int LUT_BYTES = ((2 * LUT_N * 2 + 15) / 16) * 16;
+    static constexpr int LDS_BYTES = LUT_OFF + LUT_BYTES;
+    // extras of the compacting variant (zj_fused_kernel<.., COMPACT = 1>): raw staging for the halo
+    // blocks (full blocks stage their coefficients in their own pixel slot), the per-wave work queues
+    static constexpr int NHALO = CHROMA ? 2 * CBR * 2 * HALO : 0;    // halo blocks per tile
+    static constexpr int HSTAGE_OFF = LDS_BYTES;                     // NHALO x 128 bytes
+    static constexpr int QUEUE_OFF = HSTAGE_OFF + NHALO * 128;       // NT/64 waves x 64 entries x u32
+    static constexpr int QCNT_OFF = QUEUE_OFF + (NT / 64) * 64 * 4;
+    static constexpr int LDS_BYTES_COMPACT = QCNT_OFF + 32;
     static_assert(PLANAR_I16 % 8 == 0, "planar area must keep 16-byte alignment");
-    static_assert(NT <= 256 && NBLK <= NT, "one lane per block, at most 4 waves");
+    static_assert(NT <= 512 && NBLK <= NT, "one lane per block, at most 8 waves");
 };
 
 struct Params {
@@ -322,6 +333,7 @@ struct Params {
     int nframes;
     int zero_fill;                // 1: also write the bytes the reference leaves 0 (Q5/Q6)
     int total_tiles;
+    int debug;                    // diagnostics only (tools/ablate.py): 1 = skip the IDCT, 2 = skip colour math
 };
 
 // vertical schedule of upsample_vertical (upsampler/scalar.rs:84-144): pair k -> (near, far)
@@ -371,6 +383,7 @@ struct BlockLoc {
     int pitch;       // LDS row pitch in i16
     int comp;        // 0 Y, 1 Cb, 2 Cr
     int halo;        // 0: full block, 1: left halo (keep pixel column 7), 2: right halo (column 0)
+    int hslot;       // halo blocks: index 0..NHALO-1 (raw staging slot of the compacting variant)
     bool valid;
 };
 
@@ -378,7 +391,7 @@ template <class C>
 ZJ_DEV BlockLoc locate(const Params& p, const TileId t, const int b, int16_t* lds)
 {
     BlockLoc L;
-    L.valid = false; L.halo = 0; L.comp = 0; L.src = nullptr; L.dst = lds; L.pitch = C::TWY;
+    L.valid = false; L.halo = 0; L.hslot = 0; L.comp = 0; L.src = nullptr; L.dst = lds; L.pitch = C::TWY;
     const int ybw = p.mcu_x * (C::TWYB / C::TWC); // luma blocks per plane row (= mcu_x * HS)
     const int cbw = p.mcu_x;                      // chroma blocks per plane row
     if (b < C::NYB) {
@@ -400,8 +413,8 @@ ZJ_DEV BlockLoc locate(const Params& p, const TileId t, const int b, int16_t* ld
     const int nvalid = (cbw - cb0) < C::TWC ? (cbw - cb0) : C::TWC;
     int gcol, lcol;
     if (C::HALO) {
-        if (j == 0) { gcol = cb0 > 0 ? cb0 - 1 : cbw - 1; lcol = C::COFF - 1; L.halo = 1; }
-        else if (j == C::CCOLS - 1) { gcol = cb0 + nvalid < cbw ? cb0 + nvalid : 0; lcol = C::COFF + 8 * nvalid; L.halo = 2; }
+        if (j == 0) { gcol = cb0 > 0 ? cb0 - 1 : cbw - 1; lcol = C::COFF - 1; L.halo = 1; L.hslot = ((comp - 1) * C::CBR + brow) * 2; }
+        else if (j == C::CCOLS - 1) { gcol = cb0 + nvalid < cbw ? cb0 + nvalid : 0; lcol = C::COFF + 8 * nvalid; L.halo = 2; L.hslot = ((comp - 1) * C::CBR + brow) * 2 + 1; }
         else { if (j - 1 >= nvalid) return L; gcol = cb0 + j - 1; lcol = C::COFF + 8 * (j - 1); }
     } else {
         if (j >= nvalid) return L;
@@ -465,7 +478,7 @@ ZJ_DEV void phase_setup(const Params& p, const int tid, int16_t* lds)
 }
 
 template <class C>
-ZJ_DEV void finish_block(const BlockLoc& L, const U4 raw[8], int16_t* lds)
+ZJ_DEV void finish_block(const BlockLoc& L, const U4 raw[8], int16_t* lds, const int debug = 0)
 {
     if (!L.valid) return;
     const uint32_t* w = reinterpret_cast<const uint32_t*>(raw);
@@ -474,7 +487,7 @@ ZJ_DEV void finish_block(const BlockLoc& L, const U4 raw[8], int16_t* lds)
 #pragma unroll
     for (int i = 1; i < 32; i++) any |= w[i];
     U4 px[8];
-    if (any != 0) {
+    if (any != 0 && !(debug & 1)) {
         idct_block(raw, qt, px);
     } else {
         const uint32_t v = dc_only_value(w[0], qt[0]);
@@ -482,6 +495,104 @@ ZJ_DEV void finish_block(const BlockLoc& L, const U4 raw[8], int16_t* lds)
         for (int r = 0; r < 8; r++) { px[r].x = v; px[r].y = v; px[r].z = v; px[r].w = v; }
     }
     store_block(L, px);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Compacting variant of phase 1 (COMPACT = 1).  DC-only blocks (the reference's own shortcut,
+// scalar.rs:45-74; about a third of a photographic frame) are finished by the classifying lane; the
+// blocks that need the full IDCT are staged in LDS -- in the very slot their pixels will occupy --
+// and queued, so that the second half runs the IDCT on densely packed lanes:
+//   classify_stage   any-AC test; DC-only -> fill; else raw -> LDS slot + per-wave queue entry
+//   idct_queue       lanes 0..n-1 pop one entry each: raw from LDS -> IDCT -> pixels in place
+// Queue entry: bits 0-15 LDS offset (i16 units) of the pixel slot, 16-17 component, 18-19 halo kind,
+// 20-23 halo staging slot.  Per-wave queue segments + counts avoid atomics (deterministic order).
+// ------------------------------------------------------------------------------------------------
+template <class C> ZJ_DEV uint32_t* lds_queue(int16_t* lds) { return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds) + C::QUEUE_OFF); }
+template <class C> ZJ_DEV int* lds_qcnt(int16_t* lds) { return reinterpret_cast<int*>(reinterpret_cast<char*>(lds) + C::QCNT_OFF); }
+template <class C> ZJ_DEV int16_t* lds_hstage(int16_t* lds) { return reinterpret_cast<int16_t*>(reinterpret_cast<char*>(lds) + C::HSTAGE_OFF); }
+
+ZJ_DEV void wave_queue_push(int* qcnt, uint32_t* queue, const int tid, const bool push, const uint32_t entry)
+{
+    const int w = tid >> 6, lane = tid & 63;
+#if defined(ZJ_EMU)
+    if (lane == 0) qcnt[w] = 0; // lanes of a wave run in order in the emulator
+    if (push) queue[w * 64 + qcnt[w]++] = entry;
+#else
+    const unsigned long long m = __ballot(push);
+    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+    if (push) queue[w * 64 + rank] = entry;
+    if (lane == 0) qcnt[w] = __popcll(m);
+#endif
+}
+
+template <class C>
+ZJ_DEV void classify_stage(const BlockLoc& L, const U4 raw[8], const int32_t q0, const int tid, int16_t* lds)
+{
+    bool full = false;
+    uint32_t entry = 0;
+    if (L.valid) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(raw);
+        uint32_t any = w[0] & 0xffff0000u; // DC-only test (scalar.rs:45)
+#pragma unroll
+        for (int i = 1; i < 32; i++) any |= w[i];
+        full = any != 0;
+        if (!full) {
+            const uint32_t v = dc_only_value(w[0], q0);
+            U4 px[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) { px[r].x = v; px[r].y = v; px[r].z = v; px[r].w = v; }
+            store_block(L, px);
+        } else {
+            entry = (uint32_t)(L.dst - lds) | ((uint32_t)L.comp << 16) | ((uint32_t)L.halo << 18) | ((uint32_t)L.hslot << 20);
+            if (L.halo == 0) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) *reinterpret_cast<U4*>(L.dst + r * L.pitch) = raw[r];
+            } else {
+                U4* hs = reinterpret_cast<U4*>(lds_hstage<C>(lds) + 64 * L.hslot);
+#pragma unroll
+                for (int r = 0; r < 8; r++) hs[r] = raw[r];
+            }
+        }
+    }
+    wave_queue_push(lds_qcnt<C>(lds), lds_queue<C>(lds), tid, full, entry);
+}
+
+template <class C>
+ZJ_DEV void idct_queue(const int tid, int16_t* lds)
+{
+    const int* qc = lds_qcnt<C>(lds);
+    constexpr int NW = C::NT / 64;
+    int start[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int n = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) { start[w] = n; n += qc[w]; }
+    for (int q = tid; q < n; q += C::NT) {
+        int w = 0;
+#pragma unroll
+        for (int k = 1; k < NW; k++) w += (q >= start[k]) ? 1 : 0;
+        int base = start[0];
+#pragma unroll
+        for (int k = 1; k < NW; k++) base = (w == k) ? start[k] : base;
+        const uint32_t e = lds_queue<C>(lds)[w * 64 + (q - base)];
+        BlockLoc L;
+        L.valid = true; L.src = nullptr;
+        L.dst = lds + (e & 0xffffu);
+        L.comp = (int)((e >> 16) & 3);
+        L.halo = (int)((e >> 18) & 3);
+        L.hslot = (int)((e >> 20) & 15);
+        L.pitch = L.comp == 0 ? C::TWY : C::CPITCH;
+        U4 raw[8], px[8];
+        if (L.halo == 0) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) raw[r] = *reinterpret_cast<const U4*>(L.dst + r * L.pitch);
+        } else {
+            const U4* hs = reinterpret_cast<const U4*>(lds_hstage<C>(lds) + 64 * L.hslot);
+#pragma unroll
+            for (int r = 0; r < 8; r++) raw[r] = hs[r];
+        }
+        idct_block(raw, lds_qt<C>(lds) + 64 * L.comp, px);
+        store_block(L, px);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -637,7 +748,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const in
         RGB2 c[8];
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            c[k] = OUT == OUT_RGB ? ycc_to_rgb_pair(yp[k], cbp[k], crp[k]) : trunc3(yp[k], cbp[k], crp[k]);
+            c[k] = (OUT == OUT_RGB && !(p.debug & 2)) ? ycc_to_rgb_pair(yp[k], cbp[k], crp[k]) : trunc3(yp[k], cbp[k], crp[k]);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (HS == 2) pack_rgb4_eo(c[k], c[4 + k], d[3 * k], d[3 * k + 1], d[3 * k + 2]);

@@ -11,41 +11,56 @@
 #include "zj_device.h"
 #include "zj_launch.h"
 
+#ifndef ZJ_WAVES_PER_SIMD
+#define ZJ_WAVES_PER_SIMD 5
+#endif
+
 namespace zj {
 
 // ------------------------------------------------------------------------------------------------
 // fused tile kernel
 // ------------------------------------------------------------------------------------------------
-template <int HS, int VS, int OUT>
-__global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT)) void zj_fused_kernel(const Params p)
+template <int HS, int VS, int OUT, int COMPACT>
+// 2nd launch bound = waves per SIMD: 5 workgroups of 4 waves per CU need <= 96 VGPRs; LDS (32.7 KB
+// per workgroup for 4:2:0) allows exactly 5.  At 4 the VALU idles ~16% (profiles/r01_v4_pmc_sq.txt).
+__global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), ZJ_WAVES_PER_SIMD) void zj_fused_kernel(const Params p)
 {
     using C = Cfg<HS, VS, OUT>;
-    __shared__ __attribute__((aligned(16))) char lds_raw[C::LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) char lds_raw[COMPACT ? C::LDS_BYTES_COMPACT : C::LDS_BYTES];
     int16_t* lds = reinterpret_cast<int16_t*>(lds_raw);
     const TileId t = decode_tile(p, (int)blockIdx.x);
     const int tid = (int)threadIdx.x;
     const BlockLoc L = locate<C>(p, t, tid, lds);
     U4 raw[8];
     load_block(L, raw);          // HBM loads in flight across the barrier below
-    phase_setup<C, HS, VS>(p, tid, lds);
-    __syncthreads();
-    finish_block<C>(L, raw, lds);
+    if (COMPACT) {
+        const int32_t q0 = p.qt[64 * L.comp]; // the DC-only shortcut needs q[0] before the tables are staged
+        phase_setup<C, HS, VS>(p, tid, lds);
+        classify_stage<C>(L, raw, q0, tid, lds);
+        __syncthreads();
+        idct_queue<C>(tid, lds);
+    } else {
+        phase_setup<C, HS, VS>(p, tid, lds);
+        __syncthreads();
+        finish_block<C>(L, raw, lds, p.debug);
+    }
     __syncthreads();
     phase_color<C, HS, VS, OUT>(p, t, tid, lds);
 }
 
 template <int HS, int VS, int OUT>
-static hipError_t launch_fused_t(const Params& p, hipStream_t s)
+static hipError_t launch_fused_t(const Params& p, int compact, hipStream_t s)
 {
     using C = Cfg<HS, VS, OUT>;
     if (p.total_tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT>), dim3((unsigned)p.total_tiles), dim3(C::NT), 0, s, p);
+    if (compact) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 1>), dim3((unsigned)p.total_tiles), dim3(C::NT), 0, s, p);
+    else hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 0>), dim3((unsigned)p.total_tiles), dim3(C::NT), 0, s, p);
     return hipGetLastError();
 }
 
-hipError_t launch_fused(int hs, int vs, int out, const Params& p, hipStream_t s)
+hipError_t launch_fused(int hs, int vs, int out, int compact, const Params& p, hipStream_t s)
 {
-#define ZJ_CASE(H, V, O) if (hs == H && vs == V && out == O) return launch_fused_t<H, V, O>(p, s);
+#define ZJ_CASE(H, V, O) if (hs == H && vs == V && out == O) return launch_fused_t<H, V, O>(p, compact, s);
     ZJ_CASE(1, 1, OUT_RGB) ZJ_CASE(1, 1, OUT_GRAY) ZJ_CASE(1, 1, OUT_YCBCR)
     ZJ_CASE(2, 1, OUT_RGB) ZJ_CASE(2, 1, OUT_GRAY) ZJ_CASE(2, 1, OUT_YCBCR)
     ZJ_CASE(1, 2, OUT_RGB) ZJ_CASE(1, 2, OUT_GRAY) ZJ_CASE(1, 2, OUT_YCBCR)

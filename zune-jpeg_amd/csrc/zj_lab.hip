@@ -153,6 +153,50 @@ __global__ __launch_bounds__(256) void lab_color(int* out, int iters)
     if (acc == 0x12345678u) out[blockIdx.x * blockDim.x + threadIdx.x] = (int)acc;
 }
 
+// ---- memory-pattern lab: 384 bytes in, 384 bytes out per lane ----------------------------------
+// RD 0: coalesced 16-byte reads (lane stride 16 B)        1: the decoder's pattern, 8 x 16 B per 128-B block (lane stride 128 B)
+// WR 0: coalesced 16-byte writes                           1: the decoder's pattern, 3 x 16 B per 48-B item (lane stride 48 B)
+//    2: 48-B items re-laid through LDS so every store instruction writes contiguous 16-B chunks
+template <int RD, int WR>
+__global__ __launch_bounds__(256) void lab_mem(const U4* __restrict__ in, U4* __restrict__ out, long long T)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    U4 v[24];
+    if (RD == 0) {
+#pragma unroll
+        for (int c = 0; c < 24; c++) v[c] = in[c * T + t];
+    } else {
+#pragma unroll
+        for (int b = 0; b < 3; b++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[b * 8 + k] = in[(b * T + t) * 8 + k];
+    }
+    if (WR == 0) {
+#pragma unroll
+        for (int c = 0; c < 24; c++) out[c * T + t] = v[c];
+    } else if (WR == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) out[(i * T + t) * 3 + j] = v[i * 3 + j];
+    } else {
+        // per-wave LDS transpose: 64 lanes x 48 B = 3 KB contiguous in memory per item index i
+        __shared__ U4 stage[4][192];
+        U4* st = stage[threadIdx.x >> 6];
+        const int lane = threadIdx.x & 63;
+        const long long wave_base = (t - lane) * 3; // in U4 units, for item i add i*T*3
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            st[lane * 3 + 0] = v[i * 3 + 0]; st[lane * 3 + 1] = v[i * 3 + 1]; st[lane * 3 + 2] = v[i * 3 + 2];
+            __builtin_amdgcn_wave_barrier();
+            const U4 a = st[lane], b = st[64 + lane], c = st[128 + lane];
+            __builtin_amdgcn_wave_barrier();
+            U4* o = out + i * T * 3 + wave_base;
+            o[lane] = a; o[64 + lane] = b; o[128 + lane] = c;
+        }
+    }
+}
+
 typedef void (*lab_fn)(const int32_t*, int*, int);
 static const struct { const char* name; lab_fn fn; } LAB[] = {
     {"idct direct/direct   med3  qt=LDS (shipped)", lab_idct<0, 0, 0, 0>},
@@ -168,6 +212,64 @@ static const struct { const char* name; lab_fn fn; } LAB[] = {
     {"idct stb32/stb24     pkclamp qt=LDS", lab_idct<2, 1, 1, 0>},
     {"idct pinned/pinned   pkclamp qt=SGPR", lab_idct<3, 3, 1, 1>},
 };
+// tile-shaped copy: each workgroup writes 32 row segments of S bytes (row pitch 12288 B = 4096 px RGB)
+// and reads the same amount contiguously (RDT = 0) or as 4+2+2 block-row segments like the decoder (RDT = 1)
+template <int S, int XCD>
+__global__ __launch_bounds__(256) void lab_tile(const U4* __restrict__ in, U4* __restrict__ out, long long ntiles)
+{
+    constexpr int CPR = S / 16;            // 16-byte chunks per row segment
+    constexpr int NCH = 32 * CPR;          // chunks per tile
+    constexpr int TPR = 12288 / S;         // tiles per row
+    long long id = blockIdx.x;
+    if (XCD && (ntiles & 7) == 0) id = (id & 7) * (ntiles >> 3) + (id >> 3);
+    const long long strip = id / TPR, tx = id % TPR;
+    const U4* src = in + id * NCH;
+    U4* dst = out + strip * 32 * 768 + tx * CPR;
+    U4 v[(NCH + 255) / 256];
+#pragma unroll
+    for (int k = 0; k < (NCH + 255) / 256; k++) { const int c = threadIdx.x + 256 * k; if (c < NCH) v[k] = src[c]; }
+#pragma unroll
+    for (int k = 0; k < (NCH + 255) / 256; k++) {
+        const int c = threadIdx.x + 256 * k;
+        if (c < NCH) dst[(c / CPR) * 768 + (c % CPR)] = v[k];
+    }
+}
+
+typedef void (*labmem_fn)(const U4*, U4*, long long);
+static const struct { const char* name; labmem_fn fn; } LABMEM[] = {
+    {"copy  rd=coalesced      wr=coalesced", lab_mem<0, 0>},
+    {"copy  rd=block/lane     wr=coalesced", lab_mem<1, 0>},
+    {"copy  rd=coalesced      wr=48B/lane", lab_mem<0, 1>},
+    {"copy  rd=block/lane     wr=48B/lane (decoder)", lab_mem<1, 1>},
+    {"copy  rd=block/lane     wr=48B via LDS transpose", lab_mem<1, 2>},
+};
+typedef void (*labtile_fn)(const U4*, U4*, long long);
+static const struct { const char* name; labtile_fn fn; int seg; } LABTILE[] = {
+    {"tile copy  row segment  768 B  xcd-contiguous", lab_tile<768, 1>, 768},
+    {"tile copy  row segment 1536 B  xcd-contiguous", lab_tile<1536, 1>, 1536},
+    {"tile copy  row segment 3072 B  xcd-contiguous", lab_tile<3072, 1>, 3072},
+    {"tile copy  row segment 6144 B  xcd-contiguous", lab_tile<6144, 1>, 6144},
+    {"tile copy  row segment 12288 B xcd-contiguous", lab_tile<12288, 1>, 12288},
+    {"tile copy  row segment  768 B  round-robin", lab_tile<768, 0>, 768},
+    {"tile copy  row segment 3072 B  round-robin", lab_tile<3072, 0>, 3072},
+    {"tile copy  row segment 12288 B round-robin", lab_tile<12288, 0>, 12288},
+};
+int labmem_count() { return (int)(sizeof(LABMEM) / sizeof(LABMEM[0])) + (int)(sizeof(LABTILE) / sizeof(LABTILE[0])); }
+const char* labmem_name(int i) { const int n = (int)(sizeof(LABMEM) / sizeof(LABMEM[0])); return i < n ? LABMEM[i].name : LABTILE[i - n].name; }
+hipError_t launch_labmem(int i, const void* in, void* out, long long bytes, hipStream_t s)
+{
+    if (i < 0 || i >= labmem_count()) return hipErrorInvalidValue;
+    const int n = (int)(sizeof(LABMEM) / sizeof(LABMEM[0]));
+    if (i >= n) {
+        const long long ntiles = bytes / (32ll * LABTILE[i - n].seg);
+        hipLaunchKernelGGL(LABTILE[i - n].fn, dim3((unsigned)ntiles), dim3(256), 0, s, (const U4*)in, (U4*)out, ntiles);
+        return hipGetLastError();
+    }
+    const long long T = bytes / 384;
+    hipLaunchKernelGGL(LABMEM[i].fn, dim3((unsigned)(T / 256)), dim3(256), 0, s, (const U4*)in, (U4*)out, T);
+    return hipGetLastError();
+}
+
 int lab_count() { return (int)(sizeof(LAB) / sizeof(LAB[0])) + 1; }
 const char* lab_name(int i) { return i < lab_count() - 1 ? LAB[i].name : "colour 16px/lane (ycc->rgb + pack, EO)"; }
 hipError_t launch_lab(int i, const int32_t* qt, int* out, int blocks, int iters, hipStream_t s)

@@ -5,7 +5,7 @@
 #include "zj_device.h"
 
 namespace zj {
-hipError_t launch_fused(int hs, int vs, int out, const Params& p, hipStream_t s);
+hipError_t launch_fused(int hs, int vs, int out, int compact, const Params& p, hipStream_t s);
 const char* fused_kernel_name(int hs, int vs, int out);
 hipError_t launch_idct_strip(const int16_t* coeff, const int32_t* qt, int16_t* out, long long nblocks,
                              long long chunks, long long bpc, long long stride, hipStream_t s);
@@ -15,6 +15,9 @@ hipError_t launch_rgb16(const int16_t* ycc, uint8_t* out, hipStream_t s);
 int ubench2_count();
 const char* ubench2_name(int op);
 hipError_t launch_ubench2(int op, int* out, int blocks, int iters, int seed, hipStream_t s);
+int labmem_count();
+const char* labmem_name(int i);
+hipError_t launch_labmem(int i, const void* in, void* out, long long bytes, hipStream_t s);
 int lab_count();
 const char* lab_name(int i);
 hipError_t launch_lab(int i, const int32_t* qt, int* out, int blocks, int iters, hipStream_t s);

@@ -107,7 +107,7 @@ def abi_symbols():
 
 
 def lib_path():
-    return os.path.join(_HERE, "libzjhip.so")
+    return os.path.join(_HERE, os.environ.get("ZJ_LIB", "libzjhip.so"))  # ZJ_LIB: A/B builds (tools/ab_lib.sh)
 
 
 def lib():
@@ -160,8 +160,13 @@ def lib():
     L.zj_choose_ycbcr_to_rgb_convert_func.restype = vp
     L.zj_choose_ycbcr_to_rgb_convert_func.argtypes = [C.c_int, C.c_int]
     L.zj_ubench.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.zj_set_variant.argtypes = [vp, C.c_int]
+    L.zj_set_ablation.argtypes = [vp, C.c_int]
     L.zj_ubench_name.restype = C.c_char_p
     L.zj_ubench_name.argtypes = [C.c_int]
+    L.zj_labmem.argtypes = [vp, C.c_int, C.c_longlong, C.c_int, C.POINTER(C.c_float)]
+    L.zj_labmem_name.restype = C.c_char_p
+    L.zj_labmem_name.argtypes = [C.c_int]
     L.zj_lab.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.zj_lab_name.restype = C.c_char_p
     L.zj_lab_name.argtypes = [C.c_int]
@@ -312,6 +317,14 @@ class Context:
                "zj_time_decode_device", self._h)
         return ms.value / iters, each.value, (name.value or b"").decode()
 
+    def set_variant(self, compact):
+        """Kernel variant for A/B runs: 0 = one pass, 1 = DC-only compaction.  Both are bit-exact."""
+        _check(lib().zj_set_variant(self._h, int(bool(compact))), "zj_set_variant", self._h)
+
+    def set_ablation(self, mask):
+        """Diagnostics only: bit 0 skips the IDCT, bit 1 the colour math (output is wrong when set)."""
+        _check(lib().zj_set_ablation(self._h, int(mask)), "zj_set_ablation", self._h)
+
     def device_alloc(self, nbytes):
         p = lib().zj_device_alloc(self._h, nbytes)
         if not p:
@@ -339,6 +352,11 @@ class Context:
     def lab(self, variant, blocks=4096, iters=20, reps=3):
         ms = C.c_float(0)
         _check(lib().zj_lab(self._h, variant, blocks, iters, reps, C.byref(ms)), "zj_lab", self._h)
+        return ms.value / reps
+
+    def labmem(self, variant, nbytes, reps=20):
+        ms = C.c_float(0)
+        _check(lib().zj_labmem(self._h, variant, nbytes, reps, C.byref(ms)), "zj_labmem", self._h)
         return ms.value / reps
 
     def ubench_clock_mhz(self, iters=200000):
