@@ -17,7 +17,7 @@ using namespace zj;
 static int g_compact = 0;
 extern "C" void zje_set_variant(int compact) { g_compact = compact; }
 
-template <int HS, int VS, int OUT>
+template <int HS, int VS, int OUT, bool FAST>
 static void run(const Params& p)
 {
     using C = Cfg<HS, VS, OUT>;
@@ -33,15 +33,15 @@ static void run(const Params& p)
             const BlockLoc L = locate<C>(p, t, tid, lds);
             U4 raw[8];
             load_block(L, raw);
-            if (g_compact) classify_stage<C>(L, raw, p.qt[64 * L.comp], tid, lds);
+            if (g_compact && FAST) classify_stage<C>(L, raw, p.qt[64 * L.comp], tid, lds);
             else finish_block<C>(L, raw, lds);
         }
         /* __syncthreads() */
-        if (g_compact) {
+        if (g_compact && FAST) {
             for (int tid = 0; tid < C::NT; tid++) idct_queue<C>(tid, lds);
             /* __syncthreads() */
         }
-        for (int tid = 0; tid < C::NT; tid++) phase_color<C, HS, VS, OUT>(p, t, tid, lds);
+        for (int tid = 0; tid < C::NT; tid++) phase_color<C, HS, VS, OUT, FAST>(p, t, tid, lds);
     }
 }
 
@@ -58,14 +58,13 @@ extern "C" int zje_decode_planes(const zj_frame_desc* d, size_t nframes, const i
     Plan pl;
     int rc = make_plan(d, pl);
     if (rc) return rc;
-    if (!pl.fast) return ZJ_ERR_UNSUPPORTED;
     Params p;
     fill_params(d, pl, nframes, y, cb, cr, out, &d->qt[0][0], zero_fill, p);
     if (zero_fill && pl.rows_covered < (int)d->height) // same remainder memset as zj_api.cpp
         for (size_t f = 0; f < nframes; f++)
             memset(out + f * pl.out_len + (size_t)pl.rows_covered * d->width * pl.ncomp_out, 0,
                    (size_t)(d->height - pl.rows_covered) * d->width * pl.ncomp_out);
-#define ZJ_CASE(H, V, O) if (pl.hs == H && pl.vs == V && pl.out == O) { run<H, V, O>(p); return ZJ_OK; }
+#define ZJ_CASE(H, V, O) if (pl.hs == H && pl.vs == V && pl.out == O) { if (pl.fast) run<H, V, O, true>(p); else run<H, V, O, false>(p); return ZJ_OK; }
     ZJ_CASE(1, 1, OUT_RGB) ZJ_CASE(1, 1, OUT_GRAY) ZJ_CASE(1, 1, OUT_YCBCR)
     ZJ_CASE(2, 1, OUT_RGB) ZJ_CASE(2, 1, OUT_GRAY) ZJ_CASE(2, 1, OUT_YCBCR)
     ZJ_CASE(1, 2, OUT_RGB) ZJ_CASE(1, 2, OUT_GRAY) ZJ_CASE(1, 2, OUT_YCBCR)

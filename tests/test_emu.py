@@ -53,8 +53,25 @@ def test_emulated_batch_and_untouched_bytes(synth):
         assert (got[:, 3 * w - 16:] == 0x5C).all()  # Q6 bytes untouched
 
 
-def test_emulator_rejects_ragged_width(synth):
-    planes, qts = synth.make_frame(100, 32, 2, 2, 3, seed=1)
-    f = oc.make_frame(100, 32, 2, 2, 3, oc.RGB, qts)
-    rc, _ = emu_c.decode_planes(f, planes)
-    assert rc == -2  # ZJ_ERR_UNSUPPORTED until the ragged-width path lands
+RAGGED = [(100, 32), (37, 50), (2500, 24), (17, 16), (200, 72), (1000, 40), (24, 24), (8, 8), (5, 3), (16, 16), (1001, 33)]
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("out_cs", [oc.RGB, oc.GRAYSCALE, oc.YCBCR])
+@pytest.mark.parametrize("wh", RAGGED)
+def test_emulated_kernel_ragged_widths(mode, out_cs, wh, synth):
+    """Any width: padded rows, the RGB tail at odd offsets, P % 16 == 8, width < 16 (worker.rs:143-251)."""
+    hs, vs = MODES[mode]
+    w, h = wh
+    for adversarial in (False, True):
+        mk = synth.make_adversarial_frame if adversarial else synth.make_frame
+        planes, qts = mk(w, h, hs, vs, 3, seed=77)
+        f = oc.make_frame(w, h, hs, vs, 3, out_cs, qts)
+        rc, exp = oc.decode_planes(f, planes)
+        rce, out = emu_c.decode_planes(f, planes)
+        if rc != 0:
+            assert rce == -5  # the reference panics on this geometry -> ZJ_ERR_PANIC
+            continue
+        assert rce == 0
+        bad = np.nonzero(out != exp)[0]
+        assert bad.size == 0, (mode, out_cs, wh, adversarial, bad[:8])

@@ -217,6 +217,40 @@ def test_decode_planes_vs_oracle(ctx, zj, synth, mode, out_cs, wh):
         assert_same(ctx.decode_planes(d, planes), exp, (mode, out_cs, wh, adversarial))
 
 
+RAGGED = [(100, 32), (37, 50), (17, 16), (1001, 33), (24, 24), (5, 3), (2500, 1786)]
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("out_cs", [oc.RGB, oc.GRAYSCALE, oc.YCBCR])
+@pytest.mark.parametrize("wh", RAGGED)
+def test_decode_planes_ragged_widths(ctx, zj, synth, mode, out_cs, wh):
+    """Widths that are not multiples of 16 (tests/medium_images.rs uses 2500x1786), width < 16,
+    P % 16 == 8; where the reference panics the ABI reports ZJ_ERR_PANIC."""
+    hs, vs = MODES[mode]
+    w, h = wh
+    if w * h > 1_000_000 and (out_cs == oc.YCBCR or mode in ("h", "v")):
+        pytest.skip("large case covered for hv/none x rgb/gray")
+    planes, qts = synth.make_frame(w, h, hs, vs, 3, seed=83)
+    rc, exp = oc.decode_planes(oc.make_frame(w, h, hs, vs, 3, out_cs, qts), planes)
+    d = zj.FrameDesc.make(w, h, hs, vs, 3, out_cs, qts)
+    if rc != 0:
+        with pytest.raises(zj.ZjError) as e:
+            ctx.decode_planes(d, planes)
+        assert e.value.status == -5
+        return
+    assert_same(ctx.decode_planes(d, planes), exp, (mode, out_cs, wh))
+
+
+def test_large_image_7680x4320(ctx, zj, synth):
+    """tests/large_images.rs / benches: 7680x4320, here 4:2:0 -> RGB"""
+    w, h = 7680, 4320
+    planes, qts = synth.make_frame(w, h, 2, 2, 3, seed=5)
+    rc, exp = oc.decode_planes(oc.make_frame(w, h, 2, 2, 3, oc.RGB, qts), planes)
+    assert rc == 0
+    d = zj.FrameDesc.make(w, h, 2, 2, 3, zj.ColorSpace.RGB, qts)
+    assert_same(ctx.decode_planes(d, planes), exp, "7680x4320")
+
+
 def test_decode_grayscale_jpeg(ctx, zj, synth):
     """1-component input -> GRAYSCALE (benches/decode_grayscale.rs path)"""
     planes, qts = synth.make_frame(640, 200, 1, 1, 1, seed=4)

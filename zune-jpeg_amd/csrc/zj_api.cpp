@@ -221,7 +221,7 @@ static int decode_device_impl(zj_ctx* c, const zj_frame_desc* d, const Plan& pl,
         for (size_t f = 0; f < nframes; f++)
             ZJ_HIP(c, hipMemsetAsync(d_out + f * pl.out_len + off, 0, pl.out_len - off, s));
     }
-    ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->compact, p, s));
+    ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->compact, pl.fast ? 1 : 0, p, s));
     return ZJ_OK;
 }
 
@@ -234,7 +234,6 @@ static int check_frame_args(zj_ctx* c, const zj_frame_desc* d, size_t nframes, c
     if (nframes == 0 || nframes > (size_t)1 << 20) return ZJ_ERR_ARG;
     if (!y || !out) return ZJ_ERR_ARG;
     if (pl.out != OUT_GRAY && (!cb || !cr)) return ZJ_ERR_ARG;
-    if (!pl.fast) return ZJ_ERR_UNSUPPORTED; // ragged widths: not implemented yet
     if ((long long)nframes * pl.n_strips * pl.tiles_per_row > 0x7fffffffLL) return ZJ_ERR_ARG;
     return ZJ_OK;
 }
@@ -447,7 +446,6 @@ int zj_post_process_strip(zj_ctx* c, const int16_t* const coeff[3], const size_t
                    comps[2].width_stride != (size_t)pl.mcu_x * 8)) return ZJ_ERR_UNSUPPORTED;
     if (!coeff[0] || (chroma && (!coeff[1] || !coeff[2]))) return ZJ_ERR_ARG;
     if (out_len < pl.out_len) return ZJ_ERR_PANIC; // &mut output[start..end], worker.rs:174
-    if (!pl.fast) return ZJ_ERR_UNSUPPORTED;
     ZJ_HIP(c, hipSetDevice(c->device));
     const size_t yb = pl.y_len * 2, cbytes = chroma ? pl.c_len * 2 : 0;
     if ((rc = ensure_scratch(c, 0, yb))) return rc;

@@ -627,7 +627,27 @@ ZJ_DEV RGB2 trunc3(uint32_t a, uint32_t b, uint32_t c)
     RGB2 o; o.r = a & 0x00ff00ffu; o.g = b & 0x00ff00ffu; o.b = c & 0x00ff00ffu; return o;
 }
 
-template <class C, int HS, int VS, int OUT>
+// Generic-width store: `ndw` dwords to orow[off ..), keeping only bytes below clip_end and outside
+// [skip_lo, skip_hi) (the bytes the early-written RGB tail owns, Q5).  Dword stores when aligned.
+ZJ_DEV void store_clip(uint8_t* orow, long long off, const uint32_t* w, int ndw, long long clip_end,
+                       long long skip_lo, long long skip_hi)
+{
+    const bool aligned = ((reinterpret_cast<uintptr_t>(orow) + (uintptr_t)off) & 3) == 0;
+    for (int i = 0; i < ndw; i++) {
+        const long long o = off + 4 * i;
+        const bool whole = o + 4 <= clip_end && (o + 4 <= skip_lo || o >= skip_hi);
+        if (whole && aligned) {
+            *reinterpret_cast<uint32_t*>(orow + o) = w[i];
+        } else {
+            for (int b = 0; b < 4; b++) {
+                const long long ob = o + b;
+                if (ob < clip_end && (ob < skip_lo || ob >= skip_hi)) orow[ob] = (uint8_t)(w[i] >> (8 * b));
+            }
+        }
+    }
+}
+
+template <class C, int HS, int VS, int OUT, bool FAST = true>
 ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const int16_t* lds)
 {
     const int P = p.mcu_x * 8 * HS;       // padded row length == luma width_stride (headers.rs:338)
@@ -657,7 +677,12 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const in
             U4 o;
             o.x = perm(yw[1], yw[0], 0x06040200u); o.y = perm(yw[3], yw[2], 0x06040200u);
             o.z = perm(yw[5], yw[4], 0x06040200u); o.w = perm(yw[7], yw[6], 0x06040200u);
-            store16(orow + px0, o); // fast path: W % 16 == 0
+            if (FAST) {
+                store16(orow + px0, o); // W % 16 == 0
+            } else {                    // any width: bytes x < W of the padded row
+                const uint32_t ow4[4] = {o.x, o.y, o.z, o.w};
+                store_clip(orow, px0, ow4, 4, W, 0, 0);
+            }
             continue;
         }
 
@@ -753,6 +778,39 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const in
         for (int k = 0; k < 4; k++) {
             if (HS == 2) pack_rgb4_eo(c[k], c[4 + k], d[3 * k], d[3 * k + 1], d[3 * k + 2]);
             else pack_rgb4_nat(c[2 * k], c[2 * k + 1], d[3 * k], d[3 * k + 1], d[3 * k + 2]);
+        }
+        if (!FAST) {
+            // Any width (worker.rs:143-251 in full): per 8-pixel unit u of the padded row
+            //   width < 16            : natural layout, clipped at 3W                      (:176-198)
+            //   u < 2*elements        : main groups at 24u                                  (:201-214)
+            //   the last two units    : the "last 16 samples", written at p' (Q5)           (:221-246)
+            //   units in between      : never converted (P % 16 == 8)
+            // main bytes inside [p', p'+48) belong to the tail (it is written last).
+            const long long stride = 3ll * W;
+            const int units = P >> 3;
+            long long elems = P / 16 - 1; if (elems < 0) elems = 0;
+            const long long position = 48 * elems;
+            long long diff = 64 - (stride - position); if (diff < 0) diff = 0;
+            const long long pp = position > diff ? position - diff : 0; // p'
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int u = (px0 >> 3) + h;
+                if (u >= units) continue;
+                const uint32_t* w6 = d + 6 * h;
+                if (OUT == OUT_YCBCR || W < 16) {
+                    store_clip(orow, 24ll * u, w6, 6, stride, 0, 0);
+                } else if (u >= units - 2) {
+                    const long long off = pp + 24ll * (u - (units - 2));
+                    store_clip(orow, off, w6, 6, off + 24, 0, 0);
+                    if (u == units - 1 && p.zero_fill) { // bytes the reference never writes (Q6)
+                        const long long z0 = position > pp + 48 ? position : pp + 48;
+                        for (long long o = z0; o < stride; o++) orow[o] = 0;
+                    }
+                } else if (u < 2 * elems) {
+                    store_clip(orow, 24ll * u, w6, 6, stride, pp, pp + 48);
+                }
+            }
+            continue;
         }
         const U4 s0 = {d[0], d[1], d[2], d[3]}, s1 = {d[4], d[5], d[6], d[7]}, s2 = {d[8], d[9], d[10], d[11]};
         const int G = px0 >> 4; // 16-pixel group index in the row

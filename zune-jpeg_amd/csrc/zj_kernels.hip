@@ -20,7 +20,7 @@ namespace zj {
 // ------------------------------------------------------------------------------------------------
 // fused tile kernel
 // ------------------------------------------------------------------------------------------------
-template <int HS, int VS, int OUT, int COMPACT>
+template <int HS, int VS, int OUT, int COMPACT, bool FAST>
 // 2nd launch bound = waves per SIMD: 5 workgroups of 4 waves per CU need <= 96 VGPRs; LDS (32.7 KB
 // per workgroup for 4:2:0) allows exactly 5.  At 4 the VALU idles ~16% (profiles/r01_v4_pmc_sq.txt).
 __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), ZJ_WAVES_PER_SIMD) void zj_fused_kernel(const Params p)
@@ -45,22 +45,24 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), ZJ_WAVES_PER_SIMD) void zj_
         finish_block<C>(L, raw, lds, p.debug);
     }
     __syncthreads();
-    phase_color<C, HS, VS, OUT>(p, t, tid, lds);
+    phase_color<C, HS, VS, OUT, FAST>(p, t, tid, lds);
 }
 
 template <int HS, int VS, int OUT>
-static hipError_t launch_fused_t(const Params& p, int compact, hipStream_t s)
+static hipError_t launch_fused_t(const Params& p, int compact, int fast, hipStream_t s)
 {
     using C = Cfg<HS, VS, OUT>;
     if (p.total_tiles <= 0) return hipSuccess;
-    if (compact) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 1>), dim3((unsigned)p.total_tiles), dim3(C::NT), 0, s, p);
-    else hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 0>), dim3((unsigned)p.total_tiles), dim3(C::NT), 0, s, p);
+    const dim3 grid((unsigned)p.total_tiles), block(C::NT);
+    if (!fast) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 0, false>), grid, block, 0, s, p); // any width
+    else if (compact) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 1, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 0, true>), grid, block, 0, s, p);
     return hipGetLastError();
 }
 
-hipError_t launch_fused(int hs, int vs, int out, int compact, const Params& p, hipStream_t s)
+hipError_t launch_fused(int hs, int vs, int out, int compact, int fast, const Params& p, hipStream_t s)
 {
-#define ZJ_CASE(H, V, O) if (hs == H && vs == V && out == O) return launch_fused_t<H, V, O>(p, compact, s);
+#define ZJ_CASE(H, V, O) if (hs == H && vs == V && out == O) return launch_fused_t<H, V, O>(p, compact, fast, s);
     ZJ_CASE(1, 1, OUT_RGB) ZJ_CASE(1, 1, OUT_GRAY) ZJ_CASE(1, 1, OUT_YCBCR)
     ZJ_CASE(2, 1, OUT_RGB) ZJ_CASE(2, 1, OUT_GRAY) ZJ_CASE(2, 1, OUT_YCBCR)
     ZJ_CASE(1, 2, OUT_RGB) ZJ_CASE(1, 2, OUT_GRAY) ZJ_CASE(1, 2, OUT_YCBCR)

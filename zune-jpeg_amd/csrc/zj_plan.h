@@ -92,6 +92,12 @@ inline int make_plan(const zj_frame_desc* d, Plan& pl)
     const size_t chunk = (size_t)d->width * nout * 8 * d->h_max * d->v_max;
     if (total / chunk < (size_t)pl.n_strips) pl.n_strips = (int)(total / chunk);
     pl.fast = (d->width % 16 == 0) && d->width >= 32;
+    if (pl.out == OUT_GRAY && pl.n_strips > 0) {
+        // ycbcr_to_grayscale re-derives the row count as len/width (color_convert/scalar.rs:97-99);
+        // when padding makes that exceed the real row count it walks off its output chunk and panics.
+        const size_t P = (size_t)pl.mcu_x * 8 * d->h_max, rows = (size_t)pl.strip_rows;
+        if (rows * P / d->width != rows) return ZJ_ERR_PANIC;
+    }
     pl.rows_covered = pl.n_strips * pl.strip_rows;
     return ZJ_OK;
 }
