@@ -31,22 +31,41 @@ HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E
 BYTES_PER_PX = 6.0               # 3 B coefficients read + 3 B RGB written per pixel
 
 
-def cpu_baseline(planes, qts, budget_s=12.0):
-    """The oracle (kind "port": scalar C restatement of the reference's scalar arms), one thread, on
-    whole 4096x4096 4:2:0 frames until ~budget_s of CPU work.  Checker/baseline only -- never on
-    the product path."""
+def cpu_baseline(planes, qts, budget_s=16.0):
+    """The reference's x86 path restated (kind "port"): oracle/zj_avx2.c follows src/idct/avx2.rs,
+    src/color_convert/avx.rs and the strip-per-job pool of src/mcu.rs:356 (AVX2, N threads), timed on
+    whole 4096x4096 4:2:0 frames at 4 threads (the reference's default, src/options.rs:33) and at all
+    host cores; `value` is the faster of the two with its thread count in `cores`.  The scalar oracle
+    (1 thread) is timed beside it.  Checker/baseline only -- never on the product path."""
+    import numpy as np
+    import avx2_c
     import oracle_c as oc
     f = oc.make_frame(W, H, 2, 2, 3, oc.RGB, qts)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        rc, _ = oc.decode_planes(f, planes)
-        assert rc == 0
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s or n >= 64:
-            break
-    return {"value": round(n * W * H / 1e6 / dt, 2), "unit": "megapixels/s", "cores": 1, "kind": "port",
-            "sample": f"{n} x 4096x4096 4:2:0 frame(s), scalar C restatement (oracle/zj_oracle.c), 1 thread, {dt:.1f} s"}
+    out = np.zeros(W * H * 3, np.uint8)
+    ncpu = os.cpu_count() or 1
+
+    def run(fn, budget):
+        fn()  # warm
+        n, t0 = 0, time.perf_counter()
+        while True:
+            fn()
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget or n >= 200:
+                return n * W * H / 1e6 / dt, n, dt
+
+    res = {}
+    for t in sorted({4, ncpu}):
+        def fn(t=t):
+            rc, _ = avx2_c.decode_planes_mt(f, planes, 1, t, out)
+            assert rc == 0
+        res[t] = run(fn, budget_s * 0.4)
+    sc = run(lambda: oc.decode_planes(f, planes), budget_s * 0.2)
+    best = max(res, key=lambda t: res[t][0])
+    detail = "; ".join(f"{t} threads {res[t][0]:.0f} MP/s ({res[t][1]} frames, {res[t][2]:.1f} s)" for t in sorted(res))
+    return {"value": round(res[best][0], 1), "unit": "megapixels/s", "cores": best, "kind": "port",
+            "sample": f"restated zune-jpeg AVX2 path (oracle/zj_avx2.c) on 4096x4096 4:2:0 frames: {detail}; "
+                      f"scalar restatement 1 thread {sc[0]:.0f} MP/s; host has {ncpu} logical CPUs"}
 
 
 def load_traffic():

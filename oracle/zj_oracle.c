@@ -224,7 +224,7 @@ int zjo_upsample_v(const int16_t *in, size_t n, int16_t *out, size_t out_len)
 /* scalar.rs:148-166 upsample_hv = horizontal(vertical(input, 2*len), output_len) */
 int zjo_upsample_hv(const int16_t *in, size_t n, int16_t *out, size_t out_len)
 {
-    int16_t *first = (int16_t *)malloc((n * 2 ? n * 2 : 1) * sizeof(int16_t));
+    int16_t *first = (int16_t *)malloc((n ? n * 2 : 1) * sizeof(int16_t));
     if (!first) return ZJO_ERR_NOMEM;
     int rc = zjo_upsample_v(in, n, first, n * 2);
     if (rc == ZJO_OK) rc = zjo_upsample_h(first, n * 2, out, out_len);
