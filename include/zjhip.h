@@ -63,7 +63,19 @@ typedef enum zj_status {
     ZJ_ERR_NOMEM = -4,
     ZJ_ERR_PANIC = -5,       /* the reference would panic on these arguments */
     ZJ_ERR_NO_DEVICE = -6,   /* no usable HIP device / kernels could not be loaded */
-    ZJ_ERR_BACKEND = -7      /* backend other than ZJ_BACKEND_HIP requested */
+    ZJ_ERR_BACKEND = -7,     /* backend other than ZJ_BACKEND_HIP requested */
+    /* zj_decoder_* only: the variants of DecodeErrors (src/errors.rs:16-43); text via zj_decoder_error() */
+    ZJ_ERR_FORMAT = -20,             /* Format / FormatStatic */
+    ZJ_ERR_MAGIC = -21,              /* IllegalMagicBytes */
+    ZJ_ERR_HUFFMAN = -22,            /* HuffmanDecode */
+    ZJ_ERR_ZERO = -23,               /* ZeroError */
+    ZJ_ERR_DQT = -24,                /* DqtError */
+    ZJ_ERR_SOS = -25,                /* SosError */
+    ZJ_ERR_SOF = -26,                /* SofError */
+    ZJ_ERR_UNSUPPORTED_SCHEME = -27, /* Unsupported(UnsupportedSchemes) */
+    ZJ_ERR_MCU = -28,                /* MCUError */
+    ZJ_ERR_EXHAUSTED = -29,          /* ExhaustedData */
+    ZJ_ERR_LARGE_DIM = -30           /* LargeDimensions */
 } zj_status;
 
 /* The fields of `Components` (src/components.rs:18-43) the pixel path reads. */
@@ -148,6 +160,34 @@ int zj_decode_planes_device(zj_ctx *ctx, const zj_frame_desc *d, size_t nframes,
 int zj_time_decode_device(zj_ctx *ctx, const zj_frame_desc *d, size_t nframes, const int16_t *d_y,
                           const int16_t *d_cb, const int16_t *d_cr, uint8_t *d_out, void *stream,
                           int iters, float *ms_total, float *ms_each, const char **kernel_name);
+
+/* ---- whole decoder: the CPU front-end the path is fed by (container + Huffman on the host) ------
+ * Mirrors Decoder / ZuneJpegOptions / ImageInfo (src/decoder.rs:60,178,452,652; src/options.rs:6-40):
+ * SOF0 baseline and SOF2 progressive Huffman, 8-bit, 1 or 3 components, DRI/RST.  The entropy decode
+ * runs on the CPU into whole-image coefficient planes; zj_decoder_decode_buffer then runs the pixel
+ * path on the GPU through zj_decode_planes. */
+typedef struct zj_options {      /* zero = reference default */
+    int32_t out_colorspace;      /* ZJ_CS_RGB (default 0), ZJ_CS_GRAYSCALE, ZJ_CS_YCBCR */
+    int32_t strict_mode;         /* options.rs:38 */
+    int32_t max_width, max_height; /* options.rs:34-35, default 16384 */
+    int32_t max_scans;           /* options.rs:36, default 64 */
+} zj_options;
+typedef struct zj_image_info {   /* ImageInfo, src/decoder.rs:652-668 (+ what the GPU path needs) */
+    uint16_t width, height;
+    uint8_t components, progressive, h_max, v_max;
+    uint16_t scans, restart_interval;
+} zj_image_info;
+typedef struct zj_decoder zj_decoder;
+zj_decoder *zj_decoder_new(const zj_options *opt);            /* Decoder::new_with_options */
+void zj_decoder_free(zj_decoder *d);
+const char *zj_decoder_error(const zj_decoder *d);            /* Display text of the last DecodeErrors */
+int zj_decoder_read_headers(zj_decoder *d, const uint8_t *buf, size_t len, zj_image_info *info); /* decoder.rs:452 */
+/* CPU half only: planes stay owned by the decoder until the next call (mcu_prog.rs:73-79 layout) */
+int zj_decoder_decode_coefficients(zj_decoder *d, const uint8_t *buf, size_t len, zj_frame_desc *desc,
+                                   const int16_t **planes /*[3]*/, size_t *plane_len /*[3]*/, zj_image_info *info);
+/* Decoder::decode_buffer (decoder.rs:178): width*height*ncomp bytes into `out` */
+int zj_decoder_decode_buffer(zj_decoder *d, zj_ctx *ctx, const uint8_t *buf, size_t len, uint8_t *out,
+                             size_t out_cap, size_t *out_len, zj_image_info *info);
 
 /* ---- memory helpers ------------------------------------------------------------------------- */
 void *zj_alloc_pinned(size_t bytes); /* hipHostMalloc; NULL on failure */

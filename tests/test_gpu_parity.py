@@ -341,3 +341,36 @@ def test_full_size_4096_hv_whole_frame_vs_oracle(ctx, zj, synth):
     assert rc == 0
     d = zj.FrameDesc.make(w, h, 2, 2, 3, zj.ColorSpace.RGB, qts)
     assert_same(ctx.decode_planes(d, planes), exp, "4096 hv")
+
+
+# ---- whole decoder: CPU entropy front-end -> GPU pixel path (BASELINE.json configs[0] and [3]) ----------
+@pytest.mark.parametrize("name", ["test-baseline.jpg", "test-progressive.jpg"])
+@pytest.mark.parametrize("out_cs", [oc.RGB, oc.GRAYSCALE, oc.YCBCR])
+def test_decode_buffer_reference_images(ctx, zj, name, out_cs):
+    """Decoder::decode_buffer on the reference's own 1920x1080 test images: Huffman on the CPU, pixels on
+    the GPU; must equal the oracle pixel path run on the same coefficient planes, byte for byte."""
+    data = open(os.path.join(HERE, "golden", name), "rb").read()
+    o = zj.ZuneJpegOptions()
+    o.out_colorspace = zj.ColorSpace(out_cs)
+    dec = zj.Decoder(o, ctx)
+    out = dec.decode_buffer(data)
+    desc, planes, info = dec.decode_coefficients(data)
+    assert (info.width, info.height) == (1920, 1080)
+    rc, exp = oc.decode_planes(oc.make_frame(1920, 1080, 1, 1, 3, out_cs, list(np.ctypeslib.as_array(desc.qt))), planes)
+    assert rc == 0
+    assert_same(out, exp, (name, out_cs))
+
+
+def test_decode_buffer_synthetic_progressive_420(ctx, zj, synth):
+    """A progressive 4:2:0 stream (the reference ships none) built by tools/jpeg_enc.py"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import jpeg_enc
+    w, h = 208, 96
+    planes = jpeg_enc.small_planes(w, h, 2, 2, 3, seed=11)
+    qts = synth.quant_tables(90)
+    for enc in (jpeg_enc.encode_baseline, jpeg_enc.encode_progressive):
+        out = zj.Decoder(None, ctx).decode_buffer(enc(planes, qts, w, h, 2, 2, 3))
+        rc, exp = oc.decode_planes(oc.make_frame(w, h, 2, 2, 3, oc.RGB, qts), planes)
+        assert rc == 0
+        assert_same(out, exp, enc.__name__)

@@ -1,0 +1,137 @@
+"""CPU: the entropy front-end (zune-jpeg_amd/csrc/zj_jpeg.cpp: markers + Huffman, baseline and
+progressive) -- bit-exact coefficient round trips through tools/jpeg_enc.py, the reference's own
+error-path tests (tests/invalid_images.rs), and Pillow/libjpeg as an independent decoder."""
+import importlib
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_c as oc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import jpeg_enc  # noqa: E402
+
+MODES = {"none": (1, 1), "h": (2, 1), "v": (1, 2), "hv": (2, 2)}
+
+
+@pytest.fixture(scope="module")
+def zj():
+    return importlib.import_module("zune-jpeg_amd")
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("wh", [(64, 48), (50, 37), (17, 9)])
+@pytest.mark.parametrize("kind", ["baseline", "baseline_rst", "progressive"])
+def test_coefficient_round_trip(zj, synth, mode, wh, kind):
+    hs, vs = MODES[mode]
+    w, h = wh
+    planes = jpeg_enc.small_planes(w, h, hs, vs, 3, seed=w + h)
+    qts = synth.quant_tables(85)
+    if kind == "progressive":
+        data = jpeg_enc.encode_progressive(planes, qts, w, h, hs, vs, 3)
+    else:
+        data = jpeg_enc.encode_baseline(planes, qts, w, h, hs, vs, 3, restart=3 if kind == "baseline_rst" else 0)
+    dec = zj.Decoder()
+    desc, got, info = dec.decode_coefficients(data)
+    assert (info.width, info.height, info.components) == (w, h, 3)
+    assert (info.h_max, info.v_max) == (hs, vs)
+    assert info.progressive == (kind == "progressive")
+    assert info.scans == (10 if kind == "progressive" else 1)
+    for c in range(3):
+        assert np.array_equal(got[c], planes[c]), (mode, wh, kind, c)
+        assert np.array_equal(np.ctypeslib.as_array(desc.qt[c]), qts[c])
+
+
+@pytest.mark.parametrize("kind", ["baseline", "progressive"])
+def test_grayscale_round_trip(zj, synth, kind):
+    w, h = 70, 33
+    planes = jpeg_enc.small_planes(w, h, 1, 1, 1, seed=9)
+    qts = synth.quant_tables(90)
+    enc = jpeg_enc.encode_progressive if kind == "progressive" else jpeg_enc.encode_baseline
+    desc, got, info = zj.Decoder().decode_coefficients(enc(planes, qts, w, h, 1, 1, 1))
+    assert info.components == 1 and desc.out_colorspace == 1  # forced GRAYSCALE, headers.rs:283-290
+    assert np.array_equal(got[0], planes[0])
+
+
+@pytest.mark.parametrize("kind", ["baseline", "progressive"])
+def test_pillow_decodes_the_same_file(zj, synth, kind):
+    """4:4:4 so that only IDCT rounding differs between libjpeg and the reference's arithmetic."""
+    from PIL import Image
+    w, h = 64, 48
+    planes = jpeg_enc.small_planes(w, h, 1, 1, 3, seed=4, amp=3, dc=40)  # keeps every pixel inside 0..255
+    qts = synth.quant_tables(90)
+    enc = jpeg_enc.encode_progressive if kind == "progressive" else jpeg_enc.encode_baseline
+    data = enc(planes, qts, w, h, 1, 1, 3)
+    im = Image.open(io.BytesIO(data))
+    im.draft("YCbCr", im.size)  # libjpeg hands out YCbCr directly: no RGB round trip, no gamut clipping
+    assert im.mode == "YCbCr"
+    pil = np.asarray(im, np.int32)
+    desc, got, info = zj.Decoder().decode_coefficients(data)
+    rc, ours = oc.decode_planes(oc.make_frame(w, h, 1, 1, 3, oc.YCBCR, list(np.ctypeslib.as_array(desc.qt))), got)
+    assert rc == 0
+    d = np.abs(ours.reshape(h, w, 3).astype(np.int32) - pil)
+    assert d.max() <= 3 and d.mean() < 0.6
+
+
+def _err(zj, data):
+    with pytest.raises(zj.DecodeError) as e:
+        zj.Decoder().decode_coefficients(bytes(data))
+    return e.value
+
+
+def test_reference_invalid_image_cases(zj):
+    """tests/invalid_images.rs:3-81 -- same variants and (where asserted) the same strings"""
+    assert _err(zj, [0xff, 0xd8, 0xa4]).status == -20                                   # eof -> Format(_)
+    e = _err(zj, [0xff, 0xd8, 0xff, 0x00, 0x00, 0x00])                                  # bad_ff_marker_size
+    assert e.status == -20 and e.text == "Found a marker with invalid length : 0"
+    e = _err(zj, [255, 216, 255, 218, 232, 197, 255])                                   # bad_number_of_scans
+    assert e.status == -25 and e.text == "Bad SOS length,corrupt jpeg"
+    e = _err(zj, [255, 216, 255, 196, 0, 0])                                            # huffman_length_subtraction_overflow
+    assert e.status == -20 and e.text == "Invalid Huffman length in image"
+    e = _err(zj, [255, 216, 255, 192, 255, 1, 8, 9, 119, 48, 255, 192])                 # mul_with_overflow
+    assert e.status == -26 and e.text == "Length of start of frame differs from expected 584,value is 65281"
+    assert _err(zj, [0x12, 0x34]).status == -21                                         # IllegalMagicBytes
+
+
+def test_limits_and_unsupported(zj, synth):
+    planes = jpeg_enc.small_planes(40, 24, 1, 1, 3, seed=1)
+    data = bytearray(jpeg_enc.encode_baseline(planes, synth.quant_tables(80), 40, 24))
+    o = zj.ZuneJpegOptions()
+    o.max_width = 32
+    with pytest.raises(zj.DecodeError) as e:
+        zj.Decoder(o).decode_coefficients(bytes(data))
+    assert "greater than width limit 32" in e.value.text
+    sof = data.index(b"\xff\xc0")
+    bad = bytearray(data); bad[sof + 4] = 12                                            # 12-bit precision
+    assert "8-bit images" in _err(zj, bad).text
+    bad = bytearray(data); bad[sof + 1] = 0xC9                                          # arithmetic SOF9 is skipped as unknown
+    assert _err(zj, bad).status in (-26, -25)                                           # ... then SOS finds no frame
+    info = zj.Decoder().read_headers(bytes(data))
+    assert (info.width, info.height, info.components, info.progressive) == (40, 24, 3, 0)
+
+
+REF_IMAGES = [("test-baseline.jpg", 0, 1), ("test-progressive.jpg", 1, 10)]
+
+
+@pytest.mark.parametrize("name,prog,scans", REF_IMAGES)
+def test_reference_images_vs_pillow(zj, name, prog, scans):
+    """BASELINE.json configs[0]/[3]: the reference's 1920x1080 4:4:4 test images (copies under
+    tests/golden).  CPU entropy decode -> oracle pixel path, compared with libjpeg (Pillow)."""
+    from PIL import Image
+    path = os.path.join(ROOT, "tests", "golden", name)
+    data = open(path, "rb").read()
+    desc, planes, info = zj.Decoder().decode_coefficients(data)
+    assert (info.width, info.height, info.components, info.progressive, info.scans) == (1920, 1080, 3, prog, scans)
+    qts = list(np.ctypeslib.as_array(desc.qt))
+    rc, ours = oc.decode_planes(oc.make_frame(1920, 1080, 1, 1, 3, oc.YCBCR, qts), planes)
+    assert rc == 0
+    im = Image.open(path)
+    im.draft("YCbCr", im.size)
+    assert im.mode == "YCbCr"
+    pil = np.asarray(im, np.int32)
+    d = np.abs(ours.reshape(1080, 1920, 3).astype(np.int32) - pil)
+    assert d.max() <= 4 and d.mean() < 0.5

@@ -1,0 +1,684 @@
+// zj_jpeg.cpp -- the CPU side the north star keeps on the host: container parsing and the branchy
+// Huffman bitstream (baseline + progressive), producing whole-image planes of quantized coefficients
+// in the layout the GPU pixel path consumes, then handing them to zj_decode_planes.
+//
+// It plays the role of these reference files (paths relative to the zune-jpeg tree) and mirrors their
+// observable behaviour, written from the JPEG standard (ITU-T T.81), not from their code:
+//   src/decoder.rs:239-416   marker loop, supported schemes (SOF0 / SOF2, 8-bit, 1 or 3 components)
+//   src/headers.rs:18-339    DHT / DQT / SOF / SOS / DRI
+//   src/huffman.rs, src/bitstream.rs   Huffman tables, MSB-first bit reader with 0xFF00 stuffing
+//   src/mcu.rs:127-380       baseline scan  -> planes (the strips the reference allocates, concatenated)
+//   src/mcu_prog.rs:49-430   progressive multi-scan accumulation into whole-image planes
+// Plane layout: per component [block_row][block_col][64] int16, natural order (un-zigzagged on write,
+// src/bitstream.rs:343,359), block_cols = mcu_x * h_samp (width_stride / 8, src/headers.rs:338).
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/zjhip.h"
+
+namespace {
+
+const uint8_t kUnZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                               41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                               30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct Huff {
+    bool present = false;
+    // canonical decoding (T.81 F.2.2.3) with an 9-bit lookahead table
+    uint16_t look[512];    // (len << 8) | symbol, 0 = longer than 9 bits
+    int32_t maxcode[18];   // per length, -1 if none
+    int32_t valoff[17];
+    uint8_t vals[256];
+    int build(const uint8_t counts[17], const uint8_t* symbols, int nsym, std::string& err)
+    {
+        uint16_t codes[257];
+        uint8_t sizes[257];
+        int k = 0;
+        for (int l = 1; l <= 16; l++)
+            for (int i = 0; i < counts[l]; i++) sizes[k++] = (uint8_t)l;
+        if (k != nsym) { err = "Bogus Huffman table definition"; return -1; }
+        uint32_t code = 0;
+        int si = k ? sizes[0] : 0, p = 0;
+        while (p < k) {
+            while (p < k && sizes[p] == si) codes[p++] = (uint16_t)code++;
+            if (code > (1u << si)) { err = "Bad Huffman Table"; return -1; } // over-subscribed
+            code <<= 1;
+            si++;
+        }
+        memcpy(vals, symbols, (size_t)nsym);
+        p = 0;
+        for (int l = 1; l <= 16; l++) {
+            if (counts[l]) {
+                valoff[l] = p - (int)codes[p];
+                p += counts[l];
+                maxcode[l] = codes[p - 1];
+            } else {
+                maxcode[l] = -1;
+                valoff[l] = 0;
+            }
+        }
+        maxcode[17] = 0x7fffffff;
+        memset(look, 0, sizeof look);
+        p = 0;
+        for (int l = 1; l <= 9; l++)
+            for (int i = 0; i < counts[l]; i++, p++) {
+                int base = codes[p] << (9 - l);
+                for (int j = 0; j < (1 << (9 - l)); j++) look[base + j] = (uint16_t)((l << 8) | vals[p]);
+            }
+        present = true;
+        return 0;
+    }
+};
+
+struct BitReader {
+    const uint8_t* p;
+    const uint8_t* end;
+    uint64_t acc = 0; // bits left-aligned
+    int nbits = 0;
+    int marker = 0;   // pending marker byte (0xD0.., 0xD9 ...) found in the entropy-coded data
+    void reset() { acc = 0; nbits = 0; marker = 0; }
+    void fill()
+    {
+        while (nbits <= 56) {
+            uint32_t b = 0;
+            if (!marker && p < end) {
+                b = *p++;
+                if (b == 0xFF) {
+                    uint32_t n = p < end ? *p : 0xD9;
+                    if (n == 0) { p++; }                  // stuffed zero
+                    else {                                // marker: stop feeding, pad with zeros
+                        while (n == 0xFF && p + 1 < end) { p++; n = *p; }
+                        marker = (int)n;
+                        if (p < end) p++;
+                        b = 0;
+                    }
+                }
+            }
+            acc |= (uint64_t)b << (56 - nbits);
+            nbits += 8;
+        }
+    }
+    inline uint32_t peek(int n) { return (uint32_t)(acc >> (64 - n)); }
+    inline void drop(int n) { acc <<= n; nbits -= n; }
+    inline int32_t get(int n)
+    {
+        if (n == 0) return 0;
+        if (nbits < n) fill();
+        uint32_t v = peek(n);
+        drop(n);
+        return (int32_t)v;
+    }
+    inline int decode(const Huff& h)
+    {
+        if (nbits < 16) fill();
+        uint32_t v = peek(9);
+        uint16_t e = h.look[v];
+        if (e) { drop(e >> 8); return e & 0xff; }
+        uint32_t code = peek(16);
+        for (int l = 10; l <= 16; l++) {
+            int32_t c = (int32_t)(code >> (16 - l));
+            if (c <= h.maxcode[l]) { drop(l); return h.vals[(c + h.valoff[l]) & 0xff]; }
+        }
+        drop(16);
+        return -1;
+    }
+};
+
+inline int32_t extend(int32_t v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; } // T.81 F.2.2.1
+
+struct Comp {
+    int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
+    int32_t dc_pred = 0;
+    int bw = 0, bh = 0; // plane size in blocks
+    std::vector<int16_t> coef;
+};
+
+} // namespace
+
+struct zj_decoder {
+    // options (src/options.rs:6-40)
+    int out_colorspace = ZJ_CS_RGB;
+    int strict_mode = 0;
+    int max_width = 16384, max_height = 16384, max_scans = 64;
+    // state
+    std::string err;
+    int err_code = 0;
+    int width = 0, height = 0, ncomp = 0, progressive = 0, h_max = 1, v_max = 1, mcu_x = 0, mcu_y = 0;
+    int restart_interval = 0;
+    int seen_sof = 0, scans = 0;
+    uint16_t qt[4][64];
+    bool qt_present[4] = {false, false, false, false};
+    Huff dc[4], ac[4];
+    Comp comps[3];
+    // current scan
+    int ns = 0, order[3] = {0, 0, 0}, ss = 0, se = 63, ah = 0, al = 0;
+    uint32_t eobrun = 0;
+};
+
+namespace {
+
+int fail(zj_decoder* d, int code, const std::string& msg) { d->err = msg; d->err_code = code; return code; }
+
+struct Cursor {
+    const uint8_t* p;
+    const uint8_t* end;
+    bool u8(int& v) { if (p >= end) return false; v = *p++; return true; }
+    bool u16(int& v) { if (end - p < 2) return false; v = (p[0] << 8) | p[1]; p += 2; return true; }
+};
+
+int parse_dqt(zj_decoder* d, Cursor& c)
+{
+    int len;
+    if (!c.u16(len) || len < 2) return fail(d, ZJ_ERR_FORMAT, "Invalid DQT length");
+    len -= 2;
+    while (len > 0) {
+        int pq_tq;
+        if (!c.u8(pq_tq)) return fail(d, ZJ_ERR_FORMAT, "Could not read DQT");
+        int pq = pq_tq >> 4, tq = pq_tq & 15;
+        if (tq > 3) return fail(d, ZJ_ERR_DQT, "Too large table position for QT :" + std::to_string(tq) + ", expected between 0 and 3");
+        if (pq == 0) {
+            if (c.end - c.p < 64) return fail(d, ZJ_ERR_DQT, "Could not read DQT bytes");
+            for (int i = 0; i < 64; i++) d->qt[tq][kUnZigzag[i]] = c.p[i]; // natural order, headers.rs:533-543
+            c.p += 64;
+            len -= 65;
+        } else if (pq == 1) {
+            // headers.rs:154-174: 16-bit tables are not supported by the reference
+            return fail(d, ZJ_ERR_DQT, "Support for 16 bit quantization table is not complete");
+        } else {
+            return fail(d, ZJ_ERR_DQT, "Expected QT precision value of either 0 or 1, found " + std::to_string(pq));
+        }
+        d->qt_present[tq] = true;
+    }
+    if (len != 0) return fail(d, ZJ_ERR_DQT, "Bogus DQT length");
+    return ZJ_OK;
+}
+
+int parse_dht(zj_decoder* d, Cursor& c)
+{
+    int len;
+    if (!c.u16(len)) return fail(d, ZJ_ERR_FORMAT, "Could not read Huffman length from image");
+    if (len < 2) return fail(d, ZJ_ERR_FORMAT, "Invalid Huffman length in image");
+    len -= 2;
+    while (len > 16) {
+        int info;
+        if (!c.u8(info)) return fail(d, ZJ_ERR_HUFFMAN, "Could not read bytes into the buffer");
+        int cls = (info >> 4) & 15, idx = info & 15;
+        if (idx >= 4) return fail(d, ZJ_ERR_HUFFMAN, "Invalid DHT index " + std::to_string(idx) + ", expected between 0 and 3");
+        if (cls > 1) return fail(d, ZJ_ERR_HUFFMAN, "Invalid DHT position " + std::to_string(cls) + ", should be 0 or 1");
+        if (c.end - c.p < 16) return fail(d, ZJ_ERR_HUFFMAN, "Could not read bytes into the buffer");
+        uint8_t counts[17] = {0};
+        int sum = 0;
+        for (int i = 1; i <= 16; i++) { counts[i] = c.p[i - 1]; sum += counts[i]; }
+        c.p += 16;
+        len -= 17;
+        if (sum > 256) return fail(d, ZJ_ERR_HUFFMAN, "Encountered Huffman table with excessive length in DHT");
+        if (sum > len) return fail(d, ZJ_ERR_HUFFMAN, "Excessive Huffman table of length " + std::to_string(sum) + " found when header length is " + std::to_string(len));
+        if (c.end - c.p < sum) return fail(d, ZJ_ERR_FORMAT, "Could not read symbols into the buffer");
+        std::string e;
+        Huff& h = cls == 0 ? d->dc[idx] : d->ac[idx];
+        if (h.build(counts, c.p, sum, e)) return fail(d, ZJ_ERR_HUFFMAN, e);
+        c.p += sum;
+        len -= sum;
+    }
+    if (len > 0) return fail(d, ZJ_ERR_HUFFMAN, "Bogus Huffman table definition");
+    return ZJ_OK;
+}
+
+int parse_sof(zj_decoder* d, Cursor& c, int progressive)
+{
+    int len, prec, h, w, nc;
+    if (!c.u16(len) || !c.u8(prec) || !c.u16(h) || !c.u16(w) || !c.u8(nc)) return fail(d, ZJ_ERR_SOF, "Could not read SOF");
+    if (prec != 8) return fail(d, ZJ_ERR_SOF, "The library can only parse 8-bit images, the image has " + std::to_string(prec) + " bits of precision");
+    if (w > d->max_width) return fail(d, ZJ_ERR_FORMAT, "Image width " + std::to_string(w) + " greater than width limit " + std::to_string(d->max_width) + ". If use `set_limits` if you want to support huge images");
+    if (h > d->max_height) return fail(d, ZJ_ERR_FORMAT, "Image height " + std::to_string(h) + " greater than height limit " + std::to_string(d->max_height) + ". If use `set_limits` if you want to support huge images");
+    if (w == 0 || h == 0) return fail(d, ZJ_ERR_ZERO, "Image width or height is set to zero, cannot continue");
+    if (nc == 0) return fail(d, ZJ_ERR_SOF, "Number of components cannot be zero.");
+    if (len != 8 + 3 * nc) return fail(d, ZJ_ERR_SOF, "Length of start of frame differs from expected " + std::to_string(8 + 3 * nc) + ",value is " + std::to_string(len));
+    if (nc != 1 && nc != 3) return fail(d, ZJ_ERR_SOF, "Invalid components. Found " + std::to_string(nc) + ", expected either 1 or 3");
+    d->width = w; d->height = h; d->ncomp = nc; d->progressive = progressive;
+    d->h_max = d->v_max = 1;
+    for (int i = 0; i < nc; i++) {
+        int id, hv, tq;
+        if (!c.u8(id) || !c.u8(hv) || !c.u8(tq)) return fail(d, ZJ_ERR_FORMAT, "Could not read component data");
+        if (id < 1 || id > 3) return fail(d, ZJ_ERR_FORMAT, "Unknown component id found," + std::to_string(id) + ", expected value between 1 and 3\nNote I and Q components are not supported yet");
+        Comp& cm = d->comps[i];
+        cm = Comp();
+        cm.id = id; cm.h = hv >> 4; cm.v = hv & 15; cm.tq = tq;
+        if (tq >= 4) return fail(d, ZJ_ERR_FORMAT, "Too large quantization number :" + std::to_string(tq) + ", expected value between 0 and 4");
+        auto pow2 = [](int x) { return x > 0 && (x & (x - 1)) == 0; };
+        if (!pow2(cm.h)) return fail(d, ZJ_ERR_FORMAT, "Horizontal sample is not a power of two(" + std::to_string(cm.h) + ") cannot decode");
+        if (!pow2(cm.v)) return fail(d, ZJ_ERR_FORMAT, "Vertical sub-sample is not power of two(" + std::to_string(cm.v) + ") cannot decode");
+        if (cm.h > d->h_max) d->h_max = cm.h;
+        if (cm.v > d->v_max) d->v_max = cm.v;
+    }
+    if (nc == 1) { // grayscale with a "down-sampled" component: reset like mcu.rs:170-196
+        if ((d->comps[0].h != 1 || d->comps[0].v != 1) && d->strict_mode)
+            return fail(d, ZJ_ERR_FORMAT, "[strict-mode]: Grayscale image with down-sampled component.");
+        d->comps[0].h = d->comps[0].v = 1;
+        d->h_max = d->v_max = 1;
+    }
+    d->mcu_x = (w + 8 * d->h_max - 1) / (8 * d->h_max);
+    d->mcu_y = (h + 8 * d->v_max - 1) / (8 * d->v_max);
+    for (int i = 0; i < nc; i++) {
+        Comp& cm = d->comps[i];
+        if (!d->qt_present[cm.tq]) return fail(d, ZJ_ERR_DQT, "No quantization table for component " + std::to_string(cm.id));
+        cm.bw = d->mcu_x * cm.h;
+        cm.bh = d->mcu_y * cm.v;
+        cm.coef.assign((size_t)cm.bw * cm.bh * 64, 0);
+    }
+    if (nc == 3) {
+        // check_component_dimensions (decoder.rs:609-646): chroma must be (1,1), luma one of the four modes
+        for (int i = 1; i < 3; i++)
+            if (d->comps[i].h != 1 || d->comps[i].v != 1)
+                return fail(d, ZJ_ERR_FORMAT, "Invalid component sample for component " + std::to_string(d->comps[i].id) + ", expected (1,1)");
+        if (d->h_max > 2 || d->v_max > 2) return fail(d, ZJ_ERR_FORMAT, "Unknown down-sampling method, cannot continue");
+    }
+    d->seen_sof = 1;
+    return ZJ_OK;
+}
+
+int parse_sos(zj_decoder* d, Cursor& c)
+{
+    int ls, ns;
+    if (!c.u16(ls) || !c.u8(ns)) return fail(d, ZJ_ERR_SOS, "Could not read SOS");
+    if (ls != 6 + 2 * ns) return fail(d, ZJ_ERR_SOS, "Bad SOS length,corrupt jpeg");
+    if (ns < 1 || ns > 3) return fail(d, ZJ_ERR_SOS, "Number of components in start of scan should be less than 3 but more than 0. Found " + std::to_string(ns));
+    if (!d->seen_sof || d->ncomp == 0) return fail(d, ZJ_ERR_SOF, "Number of components cannot be zero.");
+    if (ns > d->ncomp) return fail(d, ZJ_ERR_FORMAT, "Number of scans " + std::to_string(ns) + " cannot be greater than number of components, " + std::to_string(d->ncomp));
+    bool seen[4] = {false, false, false, false};
+    for (int i = 0; i < ns; i++) {
+        int id, t;
+        if (!c.u8(id) || !c.u8(t)) return fail(d, ZJ_ERR_SOS, "Could not read SOS");
+        int j = 0;
+        while (j < d->ncomp && d->comps[j].id != id) j++;
+        if (j == d->ncomp) return fail(d, ZJ_ERR_SOF, "Invalid component id " + std::to_string(id) + ", expected a value between 0 and " + std::to_string(d->ncomp));
+        if (seen[j]) return fail(d, ZJ_ERR_SOF, "Duplicate ID " + std::to_string(id) + " seen twice in the same component");
+        seen[j] = true;
+        d->comps[j].td = (t >> 4) & 15;
+        d->comps[j].ta = t & 15;
+        d->order[i] = j;
+    }
+    int ss, se, a;
+    if (!c.u8(ss) || !c.u8(se) || !c.u8(a)) return fail(d, ZJ_ERR_SOS, "Could not read SOS");
+    d->ns = ns; d->ss = ss & 63; d->se = se & 63; d->ah = a >> 4; d->al = a & 15;
+    if (d->ah > 13) return fail(d, ZJ_ERR_SOF, "Invalid Ah parameter " + std::to_string(d->ah) + ", range should be 0-13");
+    if (d->al > 13) return fail(d, ZJ_ERR_SOF, "Invalid Al parameter " + std::to_string(d->al) + ", range should be 0-13");
+    return ZJ_OK;
+}
+
+// marker loop up to and including SOS (decoder.rs:239-301); returns ZJ_OK positioned at the scan data
+int parse_headers(zj_decoder* d, Cursor& c, bool first)
+{
+    if (first) {
+        int magic;
+        if (!c.u16(magic)) return fail(d, ZJ_ERR_FORMAT, "Could not read the first two magic bytes");
+        if (magic != 0xffd8) return fail(d, ZJ_ERR_MAGIC, "Error parsing image. Illegal start bytes:" + std::to_string(magic));
+    }
+    int last = 0, extra = 0;
+    for (;;) {
+        int m;
+        if (!c.u8(m)) return fail(d, ZJ_ERR_FORMAT, "Exhausted data while looking for a marker");
+        if (last == 0xFF && m != 0xFF) { // (0xFF fill bytes before a marker are tolerated, T.81 B.1.1.2)
+            extra = 0;
+            int rc = ZJ_OK;
+            if (m == 0xC0 || m == 0xC2) rc = parse_sof(d, c, m == 0xC2);
+            else if (m == 0xC4) rc = parse_dht(d, c);
+            else if (m == 0xDB) rc = parse_dqt(d, c);
+            else if (m == 0xDA) return parse_sos(d, c);
+            else if (m == 0xD9) return fail(d, ZJ_ERR_FORMAT, "Premature End of image");
+            else if (m == 0xCC || m == 0xDC) return fail(d, ZJ_ERR_FORMAT, "Parsing of the following header `" + std::string(m == 0xCC ? "DAC" : "DNL") + "` is not supported,cannot continue");
+            else if (m == 0xDD) {
+                int l, ri;
+                if (!c.u16(l) || l != 4 || !c.u16(ri)) return fail(d, ZJ_ERR_FORMAT, "Bad DRI length, Corrupt JPEG");
+                d->restart_interval = ri;
+            } else {
+                // Markers the reference knows but does not handle (COM, APP0/1/14, SOI, RSTn: decoder.rs:390-409)
+                // and markers it does not know at all (everything else, incl. the other SOFn: marker.rs:48-77,
+                // decoder.rs:277-292) are both skipped by their length; only the message differs.
+                const bool known = m == 0xFE || m == 0xE0 || m == 0xE1 || m == 0xEE || (m >= 0xD0 && m <= 0xD8);
+                int l;
+                if (!c.u16(l)) return fail(d, ZJ_ERR_FORMAT, "Exhausted data while reading a marker length");
+                if (l < 2) return fail(d, ZJ_ERR_FORMAT, known ? "Found a marker with invalid length:" + std::to_string(l) + "\n"
+                                                                 : "Found a marker with invalid length : " + std::to_string(l));
+                if (c.end - c.p < l - 2) c.p = c.end; else c.p += l - 2;
+            }
+            if (rc) return rc;
+            m = 0;
+        }
+        last = m;
+        if (d->strict_mode && ++extra > 3) return fail(d, ZJ_ERR_FORMAT, "[strict-mode]: Extra bytes between headers");
+    }
+}
+
+// ---- entropy-coded segments ------------------------------------------------------------------
+inline int16_t* block_at(Comp& cm, int bx, int by) { return cm.coef.data() + ((size_t)by * cm.bw + bx) * 64; }
+
+int decode_block_baseline(zj_decoder* d, BitReader& br, Comp& cm, int16_t* blk)
+{
+    const Huff& hd = d->dc[cm.td & 3];
+    const Huff& ha = d->ac[cm.ta & 3];
+    int s = br.decode(hd);
+    if (s < 0 || s > 16) return fail(d, ZJ_ERR_HUFFMAN, "Bad Huffman code in DC");
+    int32_t diff = s ? extend(br.get(s), s) : 0;
+    cm.dc_pred = (int32_t)((uint32_t)cm.dc_pred + (uint32_t)diff);
+    blk[0] = (int16_t)cm.dc_pred; // bitstream.rs:330
+    for (int k = 1; k < 64;) {
+        int rs = br.decode(ha);
+        if (rs < 0) return fail(d, ZJ_ERR_HUFFMAN, "Bad Huffman code in AC");
+        int r = rs >> 4, sz = rs & 15;
+        if (sz) {
+            k += r;
+            int32_t v = extend(br.get(sz), sz);
+            blk[kUnZigzag[k & 63]] = (int16_t)v;
+            k++;
+        } else if (r == 15) {
+            k += 16;
+        } else {
+            break; // EOB
+        }
+    }
+    return ZJ_OK;
+}
+
+// restart marker handling shared by all scan kinds (mcu.rs:386-419)
+int handle_restart(zj_decoder* d, BitReader& br, int& todo)
+{
+    todo = d->restart_interval;
+    if (br.nbits < 64) br.fill(); // make a pending marker visible
+    if (br.marker >= 0xD0 && br.marker <= 0xD7) {
+        br.reset();
+        for (int i = 0; i < d->ncomp; i++) d->comps[i].dc_pred = 0;
+        d->eobrun = 0;
+    } else if (br.marker != 0 && br.marker != 0xD9) {
+        return fail(d, ZJ_ERR_MCU, "Marker found in bitstream, possibly corrupt jpeg");
+    }
+    return ZJ_OK;
+}
+
+int scan_baseline(zj_decoder* d, BitReader& br)
+{
+    for (int i = 0; i < d->ncomp; i++) {
+        d->comps[i].dc_pred = 0;
+        if (!d->dc[d->comps[i].td & 3].present) return fail(d, ZJ_ERR_HUFFMAN, "No DC table for component " + std::to_string(d->comps[i].id));
+        if (!d->ac[d->comps[i].ta & 3].present) return fail(d, ZJ_ERR_HUFFMAN, "No AC table for component " + std::to_string(d->comps[i].id));
+    }
+    if (d->ns != d->ncomp) return fail(d, ZJ_ERR_UNSUPPORTED, "baseline scans must carry every component (src/mcu.rs:253-321)");
+    int todo = d->restart_interval ? d->restart_interval : 0x7fffffff;
+    // (2,1): the reference walks 2*mcu_x MCUs per strip (mcu.rs:145-152); MCU order is unchanged
+    for (int my = 0; my < d->mcu_y; my++)
+        for (int mx = 0; mx < d->mcu_x; mx++) {
+            for (int ci = 0; ci < d->ns; ci++) {
+                Comp& cm = d->comps[d->order[ci]];
+                for (int v = 0; v < cm.v; v++)
+                    for (int h = 0; h < cm.h; h++) {
+                        int rc = decode_block_baseline(d, br, cm, block_at(cm, mx * cm.h + h, my * cm.v + v));
+                        if (rc) return rc;
+                    }
+            }
+            if (--todo == 0) { int rc = handle_restart(d, br, todo); if (rc) return rc; }
+            if (br.marker == 0xD9 && br.nbits <= 0) return ZJ_OK;
+        }
+    return ZJ_OK;
+}
+
+int dc_first(zj_decoder* d, BitReader& br, Comp& cm, int16_t* blk)
+{
+    int s = br.decode(d->dc[cm.td & 3]);
+    if (s < 0 || s > 16) return fail(d, ZJ_ERR_HUFFMAN, "Bad Huffman code in DC");
+    int32_t diff = s ? extend(br.get(s), s) : 0;
+    cm.dc_pred = (int32_t)((uint32_t)cm.dc_pred + (uint32_t)diff);
+    blk[0] = (int16_t)((uint16_t)(int16_t)cm.dc_pred * (uint16_t)(1u << d->al)); // bitstream.rs:413
+    return ZJ_OK;
+}
+inline void dc_refine(zj_decoder* d, BitReader& br, int16_t* blk)
+{
+    if (br.get(1)) blk[0] = (int16_t)(blk[0] | (1 << d->al));
+}
+int ac_first(zj_decoder* d, BitReader& br, const Huff& ha, int16_t* blk)
+{
+    if (d->eobrun > 0) { d->eobrun--; return ZJ_OK; }
+    for (int k = d->ss; k <= d->se;) {
+        int rs = br.decode(ha);
+        if (rs < 0) return fail(d, ZJ_ERR_HUFFMAN, "Bad Huffman code in AC");
+        int r = rs >> 4, s = rs & 15;
+        if (s) {
+            k += r;
+            int32_t v = extend(br.get(s), s);
+            blk[kUnZigzag[k & 63]] = (int16_t)((uint16_t)(int16_t)v * (uint16_t)(1u << d->al));
+            k++;
+        } else if (r == 15) {
+            k += 16;
+        } else {
+            d->eobrun = (1u << r) - 1;
+            if (r) d->eobrun += (uint32_t)br.get(r);
+            break;
+        }
+    }
+    return ZJ_OK;
+}
+int ac_refine(zj_decoder* d, BitReader& br, const Huff& ha, int16_t* blk)
+{
+    const int16_t p1 = (int16_t)(1 << d->al), m1 = (int16_t)(-1 * (1 << d->al));
+    int k = d->ss;
+    if (d->eobrun == 0) {
+        for (; k <= d->se; k++) {
+            int rs = br.decode(ha);
+            if (rs < 0) return fail(d, ZJ_ERR_HUFFMAN, "Bad Huffman code in AC");
+            int r = rs >> 4, s = rs & 15;
+            int16_t val = 0;
+            if (s) {
+                val = br.get(1) ? p1 : m1; // s must be 1
+            } else if (r != 15) {
+                d->eobrun = 1u << r;
+                if (r) d->eobrun += (uint32_t)br.get(r);
+                break;
+            }
+            // skip r zero-history coefficients, refining the non-zero ones passed (T.81 G.1.2.3)
+            while (k <= d->se) {
+                int16_t* c = blk + kUnZigzag[k];
+                if (*c != 0) {
+                    if (br.get(1) && (*c & p1) == 0) *c = (int16_t)(*c >= 0 ? *c + p1 : *c + m1);
+                } else {
+                    if (--r < 0) break;
+                }
+                k++;
+            }
+            if (s && k <= d->se) blk[kUnZigzag[k]] = val;
+        }
+    }
+    if (d->eobrun > 0) {
+        for (; k <= d->se; k++) {
+            int16_t* c = blk + kUnZigzag[k];
+            if (*c != 0 && br.get(1) && (*c & p1) == 0) *c = (int16_t)(*c >= 0 ? *c + p1 : *c + m1);
+        }
+        d->eobrun--;
+    }
+    return ZJ_OK;
+}
+
+int scan_progressive(zj_decoder* d, BitReader& br)
+{
+    for (int i = 0; i < d->ncomp; i++) d->comps[i].dc_pred = 0;
+    d->eobrun = 0;
+    int todo = d->restart_interval ? d->restart_interval : 0x7fffffff;
+    if (d->ns == 1) {
+        if (d->se != 0 && d->ss == 0) return fail(d, ZJ_ERR_HUFFMAN, "Can't merge DC and AC corrupt jpeg");
+        Comp& cm = d->comps[d->order[0]];
+        // non-interleaved scan: only the blocks that cover the image (mcu_prog.rs:277-289)
+        int bw, bh;
+        if (d->order[0] == 0 || (d->h_max == 1 && d->v_max == 1)) { bw = (d->width + 7) / 8; bh = (d->height + 7) / 8; }
+        else { bw = d->mcu_x; bh = d->mcu_y; }
+        if (d->ss == 0) { if (d->ah == 0 && !d->dc[cm.td & 3].present) return fail(d, ZJ_ERR_FORMAT, "Huffman table at index  " + std::to_string(cm.td) + " not initialized"); }
+        else if (!d->ac[cm.ta & 3].present) return fail(d, ZJ_ERR_FORMAT, "Huffman table at index  " + std::to_string(cm.ta) + " not initialized");
+        const Huff& ha = d->ac[cm.ta & 3];
+        for (int by = 0; by < bh; by++)
+            for (int bx = 0; bx < bw; bx++) {
+                int16_t* blk = block_at(cm, bx, by);
+                int rc = ZJ_OK;
+                if (d->ss == 0) { if (d->ah == 0) rc = dc_first(d, br, cm, blk); else dc_refine(d, br, blk); }
+                else if (d->ah == 0) rc = ac_first(d, br, ha, blk);
+                else rc = ac_refine(d, br, ha, blk);
+                if (rc) return rc;
+                if (--todo == 0) { rc = handle_restart(d, br, todo); if (rc) return rc; }
+            }
+    } else {
+        if (d->se != 0) return fail(d, ZJ_ERR_HUFFMAN, "Can't merge dc and AC corrupt jpeg");
+        for (int i = 0; i < d->ns; i++)
+            if (d->ah == 0 && !d->dc[d->comps[d->order[i]].td & 3].present)
+                return fail(d, ZJ_ERR_FORMAT, "Huffman table at index  " + std::to_string(d->comps[d->order[i]].td) + " not initialized");
+        for (int my = 0; my < d->mcu_y; my++)
+            for (int mx = 0; mx < d->mcu_x; mx++) {
+                for (int ci = 0; ci < d->ns; ci++) {
+                    Comp& cm = d->comps[d->order[ci]];
+                    for (int v = 0; v < cm.v; v++)
+                        for (int h = 0; h < cm.h; h++) {
+                            int16_t* blk = block_at(cm, mx * cm.h + h, my * cm.v + v);
+                            if (d->ah == 0) { int rc = dc_first(d, br, cm, blk); if (rc) return rc; }
+                            else dc_refine(d, br, blk);
+                        }
+                }
+                if (--todo == 0) { int rc = handle_restart(d, br, todo); if (rc) return rc; }
+            }
+    }
+    return ZJ_OK;
+}
+
+// after a scan: find the next marker (mcu_prog.rs:436-472)
+int next_marker(BitReader& br)
+{
+    if (br.marker) { int m = br.marker; br.marker = 0; return m; }
+    while (br.p < br.end) {
+        if (*br.p++ == 0xFF) {
+            while (br.p < br.end && *br.p == 0xFF) br.p++;
+            if (br.p < br.end && *br.p != 0) return *br.p++;
+        }
+    }
+    return -1;
+}
+
+int decode_all(zj_decoder* d, const uint8_t* buf, size_t len, bool headers_only)
+{
+    d->err.clear(); d->err_code = 0; d->seen_sof = 0; d->scans = 0; d->restart_interval = 0;
+    for (int i = 0; i < 4; i++) { d->qt_present[i] = false; d->dc[i].present = false; d->ac[i].present = false; }
+    Cursor c{buf, buf + len};
+    int rc = parse_headers(d, c, true);
+    if (rc) return rc;
+    if (headers_only) return ZJ_OK;
+    if (!d->seen_sof) return fail(d, ZJ_ERR_SOF, "Number of components cannot be zero.");
+    BitReader br;
+    br.p = c.p; br.end = c.end;
+    if (!d->progressive) {
+        rc = scan_baseline(d, br);
+        d->scans = 1;
+        return rc;
+    }
+    for (;;) {
+        if (++d->scans > d->max_scans) return fail(d, ZJ_ERR_FORMAT, "Too many scans, exceeded limit of " + std::to_string(d->max_scans));
+        br.reset();
+        rc = scan_progressive(d, br);
+        if (rc) return rc;
+        // markers between scans: DHT / SOS / EOI (mcu_prog.rs:90-126)
+        for (;;) {
+            int m = next_marker(br);
+            if (m < 0) return fail(d, ZJ_ERR_FORMAT, "Marker missing where expected");
+            if (m == 0xD9) return ZJ_OK;
+            Cursor cc{br.p, br.end};
+            if (m == 0xC4) { rc = parse_dht(d, cc); br.p = cc.p; if (rc) return rc; continue; }
+            if (m == 0xDB) { rc = parse_dqt(d, cc); br.p = cc.p; if (rc) return rc; continue; }
+            if (m == 0xDD) { int l, ri; if (!cc.u16(l) || l != 4 || !cc.u16(ri)) return fail(d, ZJ_ERR_FORMAT, "Bad DRI length, Corrupt JPEG"); d->restart_interval = ri; br.p = cc.p; continue; }
+            if (m == 0xDA) { rc = parse_sos(d, cc); br.p = cc.p; if (rc) return rc; break; }
+            if (m >= 0xD0 && m <= 0xD7) continue;
+            return ZJ_OK; // anything else ends the image like the reference's `_ => break 'eoi`
+        }
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+zj_decoder* zj_decoder_new(const zj_options* opt)
+{
+    zj_decoder* d = new (std::nothrow) zj_decoder();
+    if (d && opt) {
+        d->out_colorspace = opt->out_colorspace;
+        d->strict_mode = opt->strict_mode;
+        if (opt->max_width) d->max_width = opt->max_width;
+        if (opt->max_height) d->max_height = opt->max_height;
+        if (opt->max_scans) d->max_scans = opt->max_scans;
+    }
+    return d;
+}
+void zj_decoder_free(zj_decoder* d) { delete d; }
+const char* zj_decoder_error(const zj_decoder* d) { return d ? d->err.c_str() : ""; }
+
+static void fill_info(const zj_decoder* d, zj_image_info* info, zj_frame_desc* fd)
+{
+    if (info) {
+        info->width = (uint16_t)d->width; info->height = (uint16_t)d->height;
+        info->components = (uint8_t)d->ncomp; info->progressive = (uint8_t)d->progressive;
+        info->h_max = (uint8_t)d->h_max; info->v_max = (uint8_t)d->v_max;
+        info->scans = (uint16_t)d->scans; info->restart_interval = (uint16_t)d->restart_interval;
+    }
+    if (fd) {
+        memset(fd, 0, sizeof *fd);
+        fd->width = (uint32_t)d->width; fd->height = (uint32_t)d->height;
+        fd->h_max = (uint32_t)d->h_max; fd->v_max = (uint32_t)d->v_max;
+        fd->in_components = (uint32_t)d->ncomp;
+        // single-component images are always decoded to GRAYSCALE (headers.rs:283-290)
+        fd->out_colorspace = d->ncomp == 1 ? (int)ZJ_CS_GRAYSCALE : d->out_colorspace;
+        for (int c = 0; c < 3; c++) {
+            const int tq = d->comps[c < d->ncomp ? c : 0].tq;
+            for (int k = 0; k < 64; k++) fd->qt[c][k] = d->qt[tq][k];
+        }
+    }
+}
+
+int zj_decoder_read_headers(zj_decoder* d, const uint8_t* buf, size_t len, zj_image_info* info)
+{
+    if (!d || !buf) return ZJ_ERR_ARG;
+    int rc = decode_all(d, buf, len, true);
+    if (rc) return rc;
+    fill_info(d, info, nullptr);
+    return ZJ_OK;
+}
+
+int zj_decoder_decode_coefficients(zj_decoder* d, const uint8_t* buf, size_t len, zj_frame_desc* desc,
+                                   const int16_t** planes, size_t* plane_len, zj_image_info* info)
+{
+    if (!d || !buf) return ZJ_ERR_ARG;
+    int rc = decode_all(d, buf, len, false);
+    if (rc) return rc;
+    fill_info(d, info, desc);
+    for (int c = 0; c < 3; c++) {
+        if (planes) planes[c] = c < d->ncomp ? d->comps[c].coef.data() : nullptr;
+        if (plane_len) plane_len[c] = c < d->ncomp ? d->comps[c].coef.size() : 0;
+    }
+    return ZJ_OK;
+}
+
+int zj_decoder_decode_buffer(zj_decoder* d, zj_ctx* ctx, const uint8_t* buf, size_t len, uint8_t* out,
+                             size_t out_cap, size_t* out_len, zj_image_info* info)
+{
+    if (!d || !ctx || !buf || !out) return ZJ_ERR_ARG;
+    zj_frame_desc fd;
+    const int16_t* planes[3];
+    size_t plen[3];
+    int rc = zj_decoder_decode_coefficients(d, buf, len, &fd, planes, plen, info);
+    if (rc) return rc;
+    // grayscale JPEG decoded to RGB: the reference converts nothing and returns zeros (worker.rs:131)
+    const size_t need = zj_out_len(&fd);
+    if (out_len) *out_len = need;
+    if (out_cap < need) return fail(d, ZJ_ERR_ARG, "output buffer too small");
+    if (fd.in_components == 1 && fd.out_colorspace != ZJ_CS_GRAYSCALE) { memset(out, 0, need); return ZJ_OK; }
+    rc = zj_decode_planes(ctx, &fd, planes[0], planes[1], planes[2], out);
+    if (rc) return fail(d, rc, std::string("pixel path: ") + zj_strerror(rc) + " " + zj_last_error(ctx));
+    return ZJ_OK;
+}
+
+} // extern "C"

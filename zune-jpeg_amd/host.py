@@ -73,6 +73,17 @@ class FrameDesc(C.Structure):  # zj_frame_desc
         return d
 
 
+class Options(C.Structure):  # zj_options
+    _fields_ = [("out_colorspace", C.c_int32), ("strict_mode", C.c_int32), ("max_width", C.c_int32),
+                ("max_height", C.c_int32), ("max_scans", C.c_int32)]
+
+
+class ImageInfo(C.Structure):  # zj_image_info  <->  ImageInfo, src/decoder.rs:652-668
+    _fields_ = [("width", C.c_uint16), ("height", C.c_uint16), ("components", C.c_uint8),
+                ("progressive", C.c_uint8), ("h_max", C.c_uint8), ("v_max", C.c_uint8),
+                ("scans", C.c_uint16), ("restart_interval", C.c_uint16)]
+
+
 class ZuneJpegOptions:
     """Mirror of src/options.rs:6-40 (defaults :26-40) plus the dispatch knob."""
 
@@ -99,6 +110,8 @@ ABI = [  # every symbol include/zjhip.h declares
     "zj_num_components", "zj_decode_planes", "zj_decode_planes_batch", "zj_decode_planes_device",
     "zj_time_decode_device", "zj_alloc_pinned", "zj_free_pinned", "zj_device_alloc",
     "zj_device_free", "zj_memcpy_h2d", "zj_memcpy_d2h", "zj_sync",
+    "zj_decoder_new", "zj_decoder_free", "zj_decoder_error", "zj_decoder_read_headers",
+    "zj_decoder_decode_coefficients", "zj_decoder_decode_buffer",
 ]
 
 
@@ -160,6 +173,14 @@ def lib():
     L.zj_choose_ycbcr_to_rgb_convert_func.restype = vp
     L.zj_choose_ycbcr_to_rgb_convert_func.argtypes = [C.c_int, C.c_int]
     L.zj_ubench.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.zj_decoder_new.restype = vp
+    L.zj_decoder_new.argtypes = [C.POINTER(Options)]
+    L.zj_decoder_free.argtypes = [vp]
+    L.zj_decoder_error.restype = C.c_char_p
+    L.zj_decoder_error.argtypes = [vp]
+    L.zj_decoder_read_headers.argtypes = [vp, vp, sz, C.POINTER(ImageInfo)]
+    L.zj_decoder_decode_coefficients.argtypes = [vp, vp, sz, C.POINTER(FrameDesc), C.POINTER(C.c_void_p), C.POINTER(sz), C.POINTER(ImageInfo)]
+    L.zj_decoder_decode_buffer.argtypes = [vp, vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(ImageInfo)]
     L.zj_set_variant.argtypes = [vp, C.c_int]
     L.zj_set_ablation.argtypes = [vp, C.c_int]
     L.zj_ubench_name.restype = C.c_char_p
@@ -363,3 +384,82 @@ class Context:
         cyc, ms = C.c_double(0), C.c_float(0)
         _check(lib().zj_ubench_clock(self._h, iters, C.byref(cyc), C.byref(ms)), "zj_ubench_clock", self._h)
         return cyc.value / (ms.value * 1e3)
+
+
+class DecodeError(ZjError):
+    """Mirrors DecodeErrors (src/errors.rs:16-43): .status is the variant, str() carries the text."""
+
+    def __init__(self, status, text):
+        RuntimeError.__init__(self, f"[zj status {status}] {text}")
+        self.status = status
+        self.text = text
+
+
+class Decoder:
+    """Mirror of zune_jpeg::Decoder (src/decoder.rs:60): CPU entropy decode + GPU pixel path."""
+
+    def __init__(self, options=None, ctx=None):
+        o = Options()
+        if options is not None:
+            o.out_colorspace = int(options.out_colorspace)
+            o.strict_mode = int(options.strict_mode)
+            o.max_width, o.max_height, o.max_scans = options.max_width, options.max_height, options.max_scans
+        self._d = lib().zj_decoder_new(C.byref(o))
+        self._out_cs = int(o.out_colorspace)
+        self._ctx = ctx
+        self._info = None
+
+    def close(self):
+        if getattr(self, "_d", None):
+            lib().zj_decoder_free(self._d)
+            self._d = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _raise(self, rc):
+        raise DecodeError(rc, lib().zj_decoder_error(self._d).decode(errors="replace"))
+
+    def read_headers(self, buf):  # decoder.rs:452
+        b = np.frombuffer(bytes(buf), np.uint8)
+        info = ImageInfo()
+        rc = lib().zj_decoder_read_headers(self._d, _ptr(b), b.size, C.byref(info))
+        if rc:
+            self._raise(rc)
+        self._info = info
+        return info
+
+    def info(self):  # decoder.rs:210
+        return self._info
+
+    def decode_coefficients(self, buf):
+        """CPU half only: (FrameDesc, [planes], ImageInfo); planes are copies."""
+        b = np.frombuffer(bytes(buf), np.uint8)
+        desc, info = FrameDesc(), ImageInfo()
+        ptrs = (C.c_void_p * 3)()
+        lens = (C.c_size_t * 3)()
+        rc = lib().zj_decoder_decode_coefficients(self._d, _ptr(b), b.size, C.byref(desc), ptrs, lens, C.byref(info))
+        if rc:
+            self._raise(rc)
+        planes = [np.ctypeslib.as_array(C.cast(ptrs[c], C.POINTER(C.c_int16)), shape=(lens[c],)).copy()
+                  for c in range(info.components)]
+        self._info = info
+        return desc, planes, info
+
+    def decode_buffer(self, buf):  # decoder.rs:178
+        if self._ctx is None:
+            self._ctx = Context()
+        b = np.frombuffer(bytes(buf), np.uint8)
+        info = self.read_headers(buf)
+        ncomp = 1 if info.components == 1 else ColorSpace(self._out_cs).num_components()
+        out = np.zeros(int(info.width) * int(info.height) * ncomp, np.uint8)
+        n = C.c_size_t(0)
+        rc = lib().zj_decoder_decode_buffer(self._d, self._ctx.handle, _ptr(b), b.size, _ptr(out), out.size,
+                                            C.byref(n), C.byref(info))
+        if rc:
+            self._raise(rc)
+        self._info = info
+        return out[: n.value]
