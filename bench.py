@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--frames", type=int, default=16, help="4096x4096 frames per GPU per step")
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic frames generated (tiled to --frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--variant", choices=["onepass", "compact"], default=None, help="kernel variant (default: library default)")
+    ap.add_argument("--variant", choices=["onepass", "compact", "persistent"], default=None, help="kernel variant (default: library default)")
     args = ap.parse_args()
 
     import numpy as np
@@ -109,7 +109,7 @@ def main():
     B = args.frames
     ctx = zj.Context(zj.BACKEND_HIP, local_rank)
     if args.variant:
-        ctx.set_variant(args.variant == "compact")
+        ctx.set_variant({"onepass": 0, "compact": 1, "persistent": 2}[args.variant])
     # synthetic data, SURVEY.md 8d generator; every rank decodes its own shard of the global batch
     lo, _ = shard.shard_range(B * world, rank, world)
     frames = [synth.make_frame(W, H, 2, 2, 3, seed=1234, frame_index=(lo + i) % max(args.distinct, 1))

@@ -14,8 +14,9 @@
 
 using namespace zj;
 
-static int g_compact = 0;
+static int g_compact = 0, g_persistent_wgs = 24;
 extern "C" void zje_set_variant(int compact) { g_compact = compact; }
+extern "C" void zje_set_persistent_wgs(int n) { g_persistent_wgs = n; }
 
 template <int HS, int VS, int OUT, bool FAST>
 static void run(const Params& p)
@@ -24,6 +25,25 @@ static void run(const Params& p)
     std::vector<char> lds_store(C::LDS_BYTES_COMPACT + 32);
     // 16-byte aligned like a real LDS allocation
     int16_t* lds = (int16_t*)(((uintptr_t)lds_store.data() + 15) & ~(uintptr_t)15);
+    if (g_compact == 2 && FAST) { // persistent walk: every tile exactly once, in each workgroup's order
+        const int nwg = g_persistent_wgs < p.total_tiles ? g_persistent_wgs : p.total_tiles;
+        for (int wg = 0; wg < nwg; wg++) {
+            memset(lds, 0x7B, C::LDS_BYTES_COMPACT);
+            for (int tid = 0; tid < C::NT; tid++) phase_setup<C, HS, VS>(p, tid, lds);
+            const TileWalk w = persistent_walk(p, wg, nwg);
+            for (int id = w.first; id < w.last; id += w.step) {
+                const TileId t = tile_from_id(p, id);
+                for (int tid = 0; tid < C::NT; tid++) {
+                    const BlockLoc L = locate<C>(p, t, tid, lds);
+                    U4 raw[8];
+                    load_block(L, raw);
+                    finish_block<C>(L, raw, lds);
+                }
+                for (int tid = 0; tid < C::NT; tid++) phase_color<C, HS, VS, OUT, FAST>(p, t, tid, lds);
+            }
+        }
+        return;
+    }
     for (int bid = 0; bid < p.total_tiles; bid++) {
         memset(lds, 0x7B, C::LDS_BYTES_COMPACT); // poison: unwritten LDS must not matter
         const TileId t = decode_tile(p, bid);
@@ -33,11 +53,11 @@ static void run(const Params& p)
             const BlockLoc L = locate<C>(p, t, tid, lds);
             U4 raw[8];
             load_block(L, raw);
-            if (g_compact && FAST) classify_stage<C>(L, raw, p.qt[64 * L.comp], tid, lds);
+            if (g_compact == 1 && FAST) classify_stage<C>(L, raw, p.qt[64 * L.comp], tid, lds);
             else finish_block<C>(L, raw, lds);
         }
         /* __syncthreads() */
-        if (g_compact && FAST) {
+        if (g_compact == 1 && FAST) {
             for (int tid = 0; tid < C::NT; tid++) idct_queue<C>(tid, lds);
             /* __syncthreads() */
         }

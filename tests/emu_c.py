@@ -24,8 +24,9 @@ def lib():
     return _LIB
 
 
-def set_variant(compact):
-    lib().zje_set_variant(C.c_int(1 if compact else 0))
+def set_variant(variant, persistent_wgs=24):
+    lib().zje_set_variant(C.c_int(int(variant)))
+    lib().zje_set_persistent_wgs(C.c_int(persistent_wgs))
 
 
 def decode_planes(frame, planes, nframes=1, zero_fill=1, poison=0xAA):

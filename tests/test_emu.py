@@ -19,7 +19,7 @@ def _default_variant():
 @pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("out_cs", [oc.RGB, oc.GRAYSCALE, oc.YCBCR])
 @pytest.mark.parametrize("wh", [(64, 64), (528, 40), (32, 8), (272, 100), (1040, 33), (2080, 16)])
-@pytest.mark.parametrize("compact", [0, 1])
+@pytest.mark.parametrize("compact", [0, 1, 2])
 def test_emulated_kernel_matches_oracle(mode, out_cs, wh, synth, compact):
     emu_c.set_variant(compact)
     hs, vs = MODES[mode]
@@ -34,6 +34,21 @@ def test_emulated_kernel_matches_oracle(mode, out_cs, wh, synth, compact):
         assert rc == 0
         bad = np.nonzero(out != exp)[0]
         assert bad.size == 0, (mode, out_cs, wh, adversarial, bad[:8])
+
+
+@pytest.mark.parametrize("nwg", [1, 3, 8, 16, 40, 1000])
+def test_persistent_walk_covers_every_tile_once(nwg, synth):
+    """variant 2: any grid size must decode every tile exactly once (here 3 frames x 3 strips x 4 tiles)"""
+    w, h = 1040, 96
+    frames = [synth.make_frame(w, h, 2, 2, 3, seed=9, frame_index=i) for i in range(3)]
+    planes = [np.concatenate([fr[0][c] for fr in frames]) for c in range(3)]
+    f = oc.make_frame(w, h, 2, 2, 3, oc.RGB, frames[0][1])
+    emu_c.set_variant(2, nwg)
+    rc, out = emu_c.decode_planes(f, planes, nframes=3)
+    assert rc == 0
+    for i, fr in enumerate(frames):
+        rc, exp = oc.decode_planes(f, fr[0])
+        assert np.array_equal(out[i * exp.size:(i + 1) * exp.size], exp)
 
 
 def test_emulated_batch_and_untouched_bytes(synth):

@@ -33,7 +33,7 @@ struct zj_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string last_error;
     int debug = 0;                // ablation switches, diagnostics only (results are WRONG when set)
-    int compact = 0;              // kernel variant: 1 = DC-only compaction (ZJ_COMPACT / zj_set_variant)
+    int compact = 0;              // kernel variant: 0 one pass per tile, 1 DC-only compaction, 2 persistent + prefetch
 };
 
 #define ZJ_HIP(ctx, call)                                                                          \
@@ -111,7 +111,7 @@ zj_ctx* zj_ctx_create(int backend, int device, int* status)
     zj_ctx* c = new (std::nothrow) zj_ctx();
     if (!c) { *status = ZJ_ERR_NOMEM; return nullptr; }
     c->device = device;
-    if (const char* e = getenv("ZJ_COMPACT")) c->compact = atoi(e) != 0;
+    if (const char* e = getenv("ZJ_VARIANT")) { int v = atoi(e); if (v >= 0 && v <= 2) c->compact = v; }
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
               hipMalloc((void**)&c->d_qt, QT_SLOTS * 192 * sizeof(int32_t)) == hipSuccess &&
               hipHostMalloc((void**)&c->h_qt, QT_SLOTS * 192 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess &&
@@ -485,7 +485,8 @@ zj_color_convert16_fn zj_choose_ycbcr_to_rgb_convert_func(int backend, int out_c
 }
 
 /* kernel-variant switch for A/B measurements (both variants are bit-exact) */
-int zj_set_variant(zj_ctx* c, int compact) { if (!c) return ZJ_ERR_ARG; c->compact = compact != 0; return ZJ_OK; }
+int zj_set_variant(zj_ctx* c, int variant) { if (!c || variant < 0 || variant > 2) return ZJ_ERR_ARG; c->compact = variant; return ZJ_OK; }
+int zj_set_persistent_grid(int wgs) { set_persistent_grid(wgs); return ZJ_OK; }
 /* ablation for tools/ablate.py: bit 0 skips the IDCT, bit 1 the colour math; output is WRONG when non-zero */
 int zj_set_ablation(zj_ctx* c, int mask) { if (!c) return ZJ_ERR_ARG; c->debug = mask; return ZJ_OK; }
 

@@ -131,7 +131,8 @@ ZJ_DEV void idct_1d(const int32_t s[8], const int32_t bias, int32_t o[8])
     int32_t t2 = mul24(s[2], 2217); ZJ_PIN(t2); t2 = mad24(s[6], 2217 - 7567, t2);
     // t0 = fsh(s0+s4) + bias, t1 = fsh(s0-s4) + bias                           (:93-99)
     int32_t A = wadd(wshl(s[0], 12), bias); ZJ_PIN(A);
-    const int32_t t0 = mad24(s[4], 4096, A), t1 = mad24(s[4], -4096, A);
+    int32_t t0 = wadd(wshl(s[4], 12), A); ZJ_PIN(t0); // v_lshl_add_u32
+    const int32_t t1 = mad24(s[4], -4096, A);
     const int32_t x0 = wadd(t0, t3), x3 = wsub(t0, t3), x1 = wadd(t1, t2), x2 = wsub(t1, t2);
     // odd part (scalar.rs:109-148) as the integer matrix it is; a=s7 b=s5 c=s3 d=s1
     //   u3 = d*6149 + p1 + p4 ... expanded: e.g. coefficient of d in u3 = 6149 + 4816 - 3685 - 1597
@@ -333,7 +334,7 @@ struct Params {
     int nframes;
     int zero_fill;                // 1: also write the bytes the reference leaves 0 (Q5/Q6)
     int total_tiles;
-    int debug;                    // diagnostics only (tools/ablate.py): 1 = skip the IDCT, 2 = skip colour math
+    int debug;                    // diagnostics only (tools/ablate.py): 1 skip IDCT, 2 skip colour math, 4 no loads, 8 no stores
 };
 
 // vertical schedule of upsample_vertical (upsampler/scalar.rs:84-144): pair k -> (near, far)
@@ -371,6 +372,32 @@ ZJ_DEV TileId decode_tile(const Params& p, int bid)
     t.strip = r % p.n_strips;
     t.frame = r / p.n_strips;
     return t;
+}
+
+ZJ_DEV TileId tile_from_id(const Params& p, int id)
+{
+    TileId t;
+    t.tile = id % p.tiles_per_row;
+    const int r = id / p.tiles_per_row;
+    t.strip = r % p.n_strips;
+    t.frame = r / p.n_strips;
+    return t;
+}
+
+// Persistent variant: workgroup `wg` of `nwg` walks tiles first, first + step, ... < last.  XCD x (the
+// hardware puts workgroup b on XCD b % 8) owns the contiguous tile range [x*chunk, (x+1)*chunk), and the
+// workgroups of one XCD interleave over it, so tiles processed at the same time are neighbours.
+struct TileWalk { int first, step, last; };
+ZJ_DEV TileWalk persistent_walk(const Params& p, int wg, int nwg)
+{
+    TileWalk w;
+    if (nwg % 8 != 0 || nwg < 8) { w.first = wg; w.step = nwg; w.last = p.total_tiles; return w; }
+    const int chunk = (p.total_tiles + 7) / 8, x = wg & 7;
+    const int lo = x * chunk, hi = lo + chunk < p.total_tiles ? lo + chunk : p.total_tiles;
+    w.first = lo + (wg >> 3);
+    w.step = nwg >> 3;
+    w.last = hi;
+    return w;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -451,9 +478,20 @@ template <class C> ZJ_DEV int32_t* lds_qt(int16_t* lds) { return reinterpret_cas
 //   phase_setup  stages the three quantisation tables in LDS                      that publishes QT)
 //   finish_block dequantize + IDCT (or the DC-only shortcut, Q1) -> LDS planar staging
 // ------------------------------------------------------------------------------------------------
-ZJ_DEV void load_block(const BlockLoc& L, U4 raw[8])
+#if defined(ZJ_ABLATION)
+#define ZJ_ABL(debug, bit) ((debug) & (bit))
+#else
+#define ZJ_ABL(debug, bit) 0  // the ablation switches exist only in the diagnostic build (tools/ablate.py)
+#endif
+ZJ_DEV void load_block(const BlockLoc& L, U4 raw[8], const int debug = 0)
 {
     if (!L.valid) return;
+    if (ZJ_ABL(debug, 4)) { // ablation (tools/ablate.py): no HBM reads, synthetic coefficients
+        const uint32_t v = (uint32_t)(reinterpret_cast<uintptr_t>(L.src) >> 7) & 0x000f000fu;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { raw[i].x = v + i; raw[i].y = v; raw[i].z = v >> 1; raw[i].w = 0; }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; i++) raw[i] = L.src[i];
 }
@@ -486,15 +524,21 @@ ZJ_DEV void finish_block(const BlockLoc& L, const U4 raw[8], int16_t* lds, const
     uint32_t any = w[0] & 0xffff0000u; // DC-only test (scalar.rs:45): all but coefficient 0 are zero
 #pragma unroll
     for (int i = 1; i < 32; i++) any |= w[i];
-    U4 px[8];
-    if (any != 0 && !(debug & 1)) {
+    if (any != 0 && !ZJ_ABL(debug, 1)) {
+        U4 px[8];
         idct_block(raw, qt, px);
-    } else {
+        store_block(L, px);
+    } else { // one splat row stored eight times: no 32-register fill for the shortcut lanes
         const uint32_t v = dc_only_value(w[0], qt[0]);
+        const U4 row = {v, v, v, v};
+        if (L.halo == 0) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) { px[r].x = v; px[r].y = v; px[r].z = v; px[r].w = v; }
+            for (int r = 0; r < 8; r++) *reinterpret_cast<U4*>(L.dst + r * L.pitch) = row;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) L.dst[r * L.pitch] = (int16_t)v;
+        }
     }
-    store_block(L, px);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -773,7 +817,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const in
         RGB2 c[8];
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            c[k] = (OUT == OUT_RGB && !(p.debug & 2)) ? ycc_to_rgb_pair(yp[k], cbp[k], crp[k]) : trunc3(yp[k], cbp[k], crp[k]);
+            c[k] = (OUT == OUT_RGB && !ZJ_ABL(p.debug, 2)) ? ycc_to_rgb_pair(yp[k], cbp[k], crp[k]) : trunc3(yp[k], cbp[k], crp[k]);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (HS == 2) pack_rgb4_eo(c[k], c[4 + k], d[3 * k], d[3 * k + 1], d[3 * k + 2]);
@@ -813,6 +857,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const in
             continue;
         }
         const U4 s0 = {d[0], d[1], d[2], d[3]}, s1 = {d[4], d[5], d[6], d[7]}, s2 = {d[8], d[9], d[10], d[11]};
+        if (ZJ_ABL(p.debug, 8) && (d[0] ^ d[5] ^ d[11]) != 0x12345u) continue; // ablation: (practically) no HBM writes
         const int G = px0 >> 4; // 16-pixel group index in the row
         if (OUT == OUT_YCBCR) {
             uint8_t* o = orow + 48ll * G;

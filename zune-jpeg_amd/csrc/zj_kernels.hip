@@ -32,7 +32,7 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), ZJ_WAVES_PER_SIMD) void zj_
     const int tid = (int)threadIdx.x;
     const BlockLoc L = locate<C>(p, t, tid, lds);
     U4 raw[8];
-    load_block(L, raw);          // HBM loads in flight across the barrier below
+    load_block(L, raw, p.debug); // HBM loads in flight across the barrier below
     if (COMPACT) {
         const int32_t q0 = p.qt[64 * L.comp]; // the DC-only shortcut needs q[0] before the tables are staged
         phase_setup<C, HS, VS>(p, tid, lds);
@@ -48,6 +48,55 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), ZJ_WAVES_PER_SIMD) void zj_
     phase_color<C, HS, VS, OUT, FAST>(p, t, tid, lds);
 }
 
+// Persistent form of the same pipeline: a fixed grid of workgroups, each walking many tiles.  The next
+// tile's coefficient loads are issued as soon as the IDCT has consumed the current ones, so they are in
+// flight during the whole colour phase (HBM latency hidden, smoother load/store mix); tables are staged
+// once per workgroup instead of once per tile.
+template <int HS, int VS, int OUT>
+__global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), 4) void zj_fused_persistent_kernel(const Params p)
+{
+    using C = Cfg<HS, VS, OUT>;
+    __shared__ __attribute__((aligned(16))) char lds_raw[C::LDS_BYTES];
+    int16_t* lds = reinterpret_cast<int16_t*>(lds_raw);
+    const int tid = (int)threadIdx.x;
+    const TileWalk w = persistent_walk(p, (int)blockIdx.x, (int)gridDim.x);
+    int id = w.first;
+    if (id >= w.last) return;
+    TileId t = tile_from_id(p, id);
+    BlockLoc L = locate<C>(p, t, tid, lds);
+    U4 raw[8];
+    load_block(L, raw);
+    phase_setup<C, HS, VS>(p, tid, lds);
+    __syncthreads();
+    for (;;) {
+        finish_block<C>(L, raw, lds, p.debug);
+        const int nid = id + w.step;
+        const bool more = nid < w.last;
+        TileId tn = t;
+        if (more) { // prefetch: in flight across the colour phase below
+            tn = tile_from_id(p, nid);
+            L = locate<C>(p, tn, tid, lds);
+            load_block(L, raw);
+        }
+        __syncthreads();
+        phase_color<C, HS, VS, OUT, true>(p, t, tid, lds);
+        if (!more) break;
+        __syncthreads(); // the staging area is rewritten by the next IDCT
+        t = tn;
+        id = nid;
+    }
+}
+
+static int g_persistent_wgs = 0;
+void set_persistent_grid(int wgs) { g_persistent_wgs = wgs; }
+static int persistent_grid()
+{
+    if (g_persistent_wgs > 0) return g_persistent_wgs;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus * 4;
+}
+
 template <int HS, int VS, int OUT>
 static hipError_t launch_fused_t(const Params& p, int compact, int fast, hipStream_t s)
 {
@@ -55,7 +104,11 @@ static hipError_t launch_fused_t(const Params& p, int compact, int fast, hipStre
     if (p.total_tiles <= 0) return hipSuccess;
     const dim3 grid((unsigned)p.total_tiles), block(C::NT);
     if (!fast) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 0, false>), grid, block, 0, s, p); // any width
-    else if (compact) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 1, true>), grid, block, 0, s, p);
+    else if (compact == 2) {
+        int wgs = persistent_grid();
+        if (wgs > p.total_tiles) wgs = p.total_tiles;
+        hipLaunchKernelGGL((zj_fused_persistent_kernel<HS, VS, OUT>), dim3((unsigned)wgs), block, 0, s, p);
+    } else if (compact) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 1, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 0, true>), grid, block, 0, s, p);
     return hipGetLastError();
 }

@@ -235,6 +235,18 @@ __global__ __launch_bounds__(256) void lab_tile(const U4* __restrict__ in, U4* _
     }
 }
 
+// plain streaming copies: N x 16 bytes, 1 or 4 chunks per lane (consecutive lanes -> consecutive chunks)
+template <int PER>
+__global__ __launch_bounds__(256) void lab_stream(const U4* __restrict__ in, U4* __restrict__ out, long long n)
+{
+    const long long base = ((long long)blockIdx.x * 256 * PER) + threadIdx.x;
+    U4 v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) v[k] = in[base + 256 * k];
+#pragma unroll
+    for (int k = 0; k < PER; k++) out[base + 256 * k] = v[k];
+}
+
 typedef void (*labmem_fn)(const U4*, U4*, long long);
 static const struct { const char* name; labmem_fn fn; } LABMEM[] = {
     {"copy  rd=coalesced      wr=coalesced", lab_mem<0, 0>},
@@ -242,6 +254,9 @@ static const struct { const char* name; labmem_fn fn; } LABMEM[] = {
     {"copy  rd=coalesced      wr=48B/lane", lab_mem<0, 1>},
     {"copy  rd=block/lane     wr=48B/lane (decoder)", lab_mem<1, 1>},
     {"copy  rd=block/lane     wr=48B via LDS transpose", lab_mem<1, 2>},
+    {"stream copy 1 x 16 B per lane", nullptr},
+    {"stream copy 4 x 16 B per lane", nullptr},
+    {"stream copy 8 x 16 B per lane", nullptr},
 };
 typedef void (*labtile_fn)(const U4*, U4*, long long);
 static const struct { const char* name; labtile_fn fn; int seg; } LABTILE[] = {
@@ -266,6 +281,15 @@ hipError_t launch_labmem(int i, const void* in, void* out, long long bytes, hipS
         return hipGetLastError();
     }
     const long long T = bytes / 384;
+    if (LABMEM[i].fn == nullptr) {
+        const long long nch = bytes / 16;
+        const int per = i == 5 ? 1 : (i == 6 ? 4 : 8);
+        const unsigned g = (unsigned)(nch / (256 * per));
+        if (per == 1) hipLaunchKernelGGL(lab_stream<1>, dim3(g), dim3(256), 0, s, (const U4*)in, (U4*)out, nch);
+        else if (per == 4) hipLaunchKernelGGL(lab_stream<4>, dim3(g), dim3(256), 0, s, (const U4*)in, (U4*)out, nch);
+        else hipLaunchKernelGGL(lab_stream<8>, dim3(g), dim3(256), 0, s, (const U4*)in, (U4*)out, nch);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(LABMEM[i].fn, dim3((unsigned)(T / 256)), dim3(256), 0, s, (const U4*)in, (U4*)out, T);
     return hipGetLastError();
 }

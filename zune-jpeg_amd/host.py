@@ -338,9 +338,10 @@ class Context:
                "zj_time_decode_device", self._h)
         return ms.value / iters, each.value, (name.value or b"").decode()
 
-    def set_variant(self, compact):
-        """Kernel variant for A/B runs: 0 = one pass, 1 = DC-only compaction.  Both are bit-exact."""
-        _check(lib().zj_set_variant(self._h, int(bool(compact))), "zj_set_variant", self._h)
+    def set_variant(self, variant):
+        """Kernel variant: 0 = one pass per tile, 1 = DC-only compaction, 2 = persistent + prefetch.
+        All are bit-exact."""
+        _check(lib().zj_set_variant(self._h, int(variant)), "zj_set_variant", self._h)
 
     def set_ablation(self, mask):
         """Diagnostics only: bit 0 skips the IDCT, bit 1 the colour math (output is wrong when set)."""
