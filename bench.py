@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--frames", type=int, default=16, help="4096x4096 frames per GPU per step")
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic frames generated (tiled to --frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["420-rgb", "444-rgb", "444-gray"], default="420-rgb",
+                    help="420-rgb = BASELINE.json configs[1] (the headline); the others are configs[2]")
     ap.add_argument("--variant", choices=["onepass", "compact", "persistent"], default=None, help="kernel variant (default: library default)")
     args = ap.parse_args()
 
@@ -112,13 +114,15 @@ def main():
         ctx.set_variant({"onepass": 0, "compact": 1, "persistent": 2}[args.variant])
     # synthetic data, SURVEY.md 8d generator; every rank decodes its own shard of the global batch
     lo, _ = shard.shard_range(B * world, rank, world)
-    frames = [synth.make_frame(W, H, 2, 2, 3, seed=1234, frame_index=(lo + i) % max(args.distinct, 1))
+    hs, vs, out_cs, bytes_per_px = {"420-rgb": (2, 2, zj.ColorSpace.RGB, 6.0), "444-rgb": (1, 1, zj.ColorSpace.RGB, 9.0),
+                                    "444-gray": (1, 1, zj.ColorSpace.GRAYSCALE, 3.0)}[args.workload]
+    frames = [synth.make_frame(W, H, hs, vs, 3, seed=1234, frame_index=(lo + i) % max(args.distinct, 1))
               for i in range(min(args.distinct, B))]
     qts = frames[0][1]
-    desc = zj.FrameDesc.make(W, H, 2, 2, 3, zj.ColorSpace.RGB, qts)
+    desc = zj.FrameDesc.make(W, H, hs, vs, 3, out_cs, qts)
     host = [np.concatenate([frames[i % len(frames)][0][c] for i in range(B)]) for c in range(3)]
     d_planes = [torch.from_numpy(h).to(dev) for h in host]
-    d_out = torch.empty(B * W * H * 3, dtype=torch.uint8, device=dev)
+    d_out = torch.empty(B * W * H * out_cs.num_components(), dtype=torch.uint8, device=dev)
     # a dedicated stream: launches on the legacy NULL stream serialise against every blocking stream
     # and cost ~30 us each (tools/launch_overhead.py); torch.cuda.synchronize() still covers it
     torch.cuda.synchronize()
@@ -146,16 +150,16 @@ def main():
     kernel_ms, kernel_ms_each, kname = ctx.time_decode_device(desc, B, ptrs[0], ptrs[1], ptrs[2], ptrs[3], kiters, stream)
     # trivial gather: per-rank checksum of frame 0 (all ranks decode the same synthetic seeds modulo shard)
     torch.cuda.synchronize()
-    first = d_out[: W * H * 3].cpu().numpy()
+    first = d_out[: W * H * out_cs.num_components()].cpu().numpy()
     sums = shard.gather_checksums([shard.frame_checksum(first)], world, dev)
 
     if rank == 0:
         mp_total = world * B * args.steps * W * H / 1e6
-        algo_bytes = B * W * H * BYTES_PER_PX
+        algo_bytes = B * W * H * bytes_per_px
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         tr = load_traffic()
         res = {
-            "metric": "megapixels/sec decoded (IDCT->RGB), 4K 4:2:0 baseline",
+            "metric": "megapixels/sec decoded (IDCT->RGB), 4K 4:2:0 baseline" if args.workload == "420-rgb" else f"megapixels/sec decoded, 4K {args.workload}",
             "value": round(mp_total / elapsed, 1),
             "unit": "megapixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -163,7 +167,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "i16 coefficients -> i32 fixed-point IDCT -> packed-i16 colour -> u8",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: 4096x4096 baseline 4:2:0, dequant+IDCT+h2v2+YCbCr->RGB, planes resident in HBM",
+            "config": {"workload": {"420-rgb": "configs[1]: 4096x4096 baseline 4:2:0, dequant+IDCT+h2v2+YCbCr->RGB, planes resident in HBM",
+                                    "444-rgb": "configs[2]: 4096x4096 baseline 4:4:4, dequant+IDCT+YCbCr->RGB, planes resident in HBM",
+                                    "444-gray": "configs[2]: 4096x4096 4:4:4 -> GRAYSCALE (luma only), planes resident in HBM"}[args.workload],
                        "frames_per_gpu_per_step": B, "sharding": f"image-level x{world}, no data-path collective",
                        "distinct_frames": len(frames)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -175,7 +181,7 @@ def main():
             # every rank's first frame is synthetic frame (rank*B) % distinct: identical data when B % distinct == 0
             "checksums_equal_across_ranks": (len({tuple(s) for s in sums}) == 1) if (world > 1 and B % max(args.distinct, 1) == 0) else None,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.workload == "420-rgb":
             res["cpu_baseline"] = cpu_baseline(frames[0][0], qts)
         print(json.dumps(res), flush=True)
     shard.barrier(world)

@@ -281,7 +281,7 @@ def test_decode_batch_and_device_api(ctx, zj, synth):
             assert rc == 0
             assert_same(out[i * out_len:(i + 1) * out_len], exp, f"frame {i}")
         ms, each, name = ctx.time_decode_device(d, n, bufs[0], bufs[1], bufs[2], bufs[3], 3)
-        assert ms > 0 and each > 0 and "zj_fused_kernel<2,2,0>" == name
+        assert ms > 0 and each > 0 and "zj_fused" in name and "<2, 2, 0" in name
     finally:
         for b in bufs:
             ctx.device_free(b)

@@ -260,7 +260,7 @@ int zj_time_decode_device(zj_ctx* c, const zj_frame_desc* d, size_t nframes, con
     if (iters <= 0 || !ms_total) return ZJ_ERR_ARG;
     ZJ_HIP(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    if (kernel_name) *kernel_name = fused_kernel_name(pl.hs, pl.vs, pl.out);
+    if (kernel_name) *kernel_name = fused_kernel_name(pl.hs, pl.vs, pl.out, c->compact, pl.fast ? 1 : 0);
     // (1) `iters` back-to-back launches between one event pair
     ZJ_HIP(c, hipEventRecord(c->ev0, s));
     for (int i = 0; i < iters; i++) {

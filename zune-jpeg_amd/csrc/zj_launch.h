@@ -6,7 +6,7 @@
 
 namespace zj {
 hipError_t launch_fused(int hs, int vs, int out, int compact, int fast, const Params& p, hipStream_t s);
-const char* fused_kernel_name(int hs, int vs, int out);
+const char* fused_kernel_name(int hs, int vs, int out, int variant, int fast);
 void set_persistent_grid(int wgs);
 hipError_t launch_idct_strip(const int16_t* coeff, const int32_t* qt, int16_t* out, long long nblocks,
                              long long chunks, long long bpc, long long stride, hipStream_t s);
