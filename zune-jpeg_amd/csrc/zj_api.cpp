@@ -487,6 +487,9 @@ zj_color_convert16_fn zj_choose_ycbcr_to_rgb_convert_func(int backend, int out_c
 /* kernel-variant switch for A/B measurements (both variants are bit-exact) */
 int zj_set_variant(zj_ctx* c, int variant) { if (!c || variant < 0 || variant > 2) return ZJ_ERR_ARG; c->compact = variant; return ZJ_OK; }
 int zj_set_persistent_grid(int wgs) { set_persistent_grid(wgs); return ZJ_OK; }
+/* occupancy probe (tools/occupancy.py): pad every fused launch with dynamic LDS; query workgroups per CU */
+int zj_set_pad_lds(int bytes) { set_pad_lds(bytes); return ZJ_OK; }
+int zj_fused_occupancy(int pad_lds) { return fused_occupancy_420_rgb(pad_lds); }
 /* ablation for tools/ablate.py: bit 0 skips the IDCT, bit 1 the colour math; output is WRONG when non-zero */
 int zj_set_ablation(zj_ctx* c, int mask) { if (!c) return ZJ_ERR_ARG; c->debug = mask; return ZJ_OK; }
 

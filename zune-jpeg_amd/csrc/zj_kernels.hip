@@ -98,12 +98,26 @@ static int persistent_grid()
     return cus * 4;
 }
 
+// occupancy probe of tools/occupancy.py: extra dynamic LDS per workgroup (never set by the product)
+static int g_pad_lds = 0;
+void set_pad_lds(int bytes) { g_pad_lds = bytes < 0 ? 0 : bytes; }
+int fused_occupancy_420_rgb(int pad_lds)
+{
+    int n = -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zj_fused_kernel<2, 2, OUT_RGB, 0, true>, Cfg<2, 2, OUT_RGB>::NT, (size_t)pad_lds) != hipSuccess) return -1;
+    return n;
+}
+
 template <int HS, int VS, int OUT>
 static hipError_t launch_fused_t(const Params& p, int compact, int fast, hipStream_t s)
 {
     using C = Cfg<HS, VS, OUT>;
     if (p.total_tiles <= 0) return hipSuccess;
     const dim3 grid((unsigned)p.total_tiles), block(C::NT);
+    if (g_pad_lds > 0 && fast && compact == 0) {
+        hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 0, true>), grid, block, (size_t)g_pad_lds, s, p);
+        return hipGetLastError();
+    }
     if (!fast) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 0, false>), grid, block, 0, s, p); // any width
     else if (compact == 2) {
         int wgs = persistent_grid();

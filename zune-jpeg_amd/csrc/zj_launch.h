@@ -6,6 +6,8 @@
 
 namespace zj {
 hipError_t launch_fused(int hs, int vs, int out, int compact, int fast, const Params& p, hipStream_t s);
+void set_pad_lds(int bytes);
+int fused_occupancy_420_rgb(int pad_lds);
 const char* fused_kernel_name(int hs, int vs, int out, int variant, int fast);
 void set_persistent_grid(int wgs);
 hipError_t launch_idct_strip(const int16_t* coeff, const int32_t* qt, int16_t* out, long long nblocks,
