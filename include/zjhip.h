@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ZJ_ABI_VERSION 1
+#define ZJ_ABI_VERSION 2
 
 /* ColorSpace, same order as src/misc.rs:88-106 */
 typedef enum zj_colorspace {
@@ -171,6 +171,10 @@ typedef struct zj_options {      /* zero = reference default */
     int32_t strict_mode;         /* options.rs:38 */
     int32_t max_width, max_height; /* options.rs:34-35, default 16384 */
     int32_t max_scans;           /* options.rs:36, default 64 */
+    int32_t num_threads;         /* options.rs:33, default 4.  The reference spends them on post_process strips; here
+                                    the pixel path is one GPU launch, so they decode restart segments (DRI/RSTn,
+                                    baseline) concurrently and clear the planes; 1 = strictly serial */
+    int32_t pinned_planes;       /* non-zero: coefficient planes live in pinned host memory (DMA without staging) */
 } zj_options;
 typedef struct zj_image_info {   /* ImageInfo, src/decoder.rs:652-668 (+ what the GPU path needs) */
     uint16_t width, height;
@@ -185,9 +189,31 @@ int zj_decoder_read_headers(zj_decoder *d, const uint8_t *buf, size_t len, zj_im
 /* CPU half only: planes stay owned by the decoder until the next call (mcu_prog.rs:73-79 layout) */
 int zj_decoder_decode_coefficients(zj_decoder *d, const uint8_t *buf, size_t len, zj_frame_desc *desc,
                                    const int16_t **planes /*[3]*/, size_t *plane_len /*[3]*/, zj_image_info *info);
+/* GPU half: the pixel path over the planes the last zj_decoder_decode_coefficients left in the decoder */
+int zj_decoder_finish_pixels(zj_decoder *d, zj_ctx *ctx, uint8_t *out, size_t out_cap, size_t *out_len);
 /* Decoder::decode_buffer (decoder.rs:178): width*height*ncomp bytes into `out` */
 int zj_decoder_decode_buffer(zj_decoder *d, zj_ctx *ctx, const uint8_t *buf, size_t len, uint8_t *out,
                              size_t out_cap, size_t *out_len, zj_image_info *info);
+/* restart segments the last baseline scan decoded concurrently (0 = the serial walk was used) */
+int zj_decoder_parallel_segments(const zj_decoder *d);
+
+/* ---- batches of files: `threads` persistent host workers, each with its own entropy
+ * decoder, pinned coefficient planes and GPU context on `device`; file i is decoded by whichever worker is
+ * free, so the CPU Huffman stage of one file overlaps the PCIe copies and kernels of the others.  Replaces a
+ * caller-side loop over Decoder::decode_buffer (src/decoder.rs:178; the reference's own pool is per decode,
+ * src/mcu.rs:135).  outs[i] must hold out_caps[i] >= width*height*ncomp bytes; statuses[i] (optional) gets
+ * the zj_status of file i; the return value is the first error seen (ZJ_OK if none), text via zj_pool_error. */
+typedef struct zj_pool zj_pool;
+zj_pool *zj_pool_create(int device, int threads, const zj_options *opt, int *status);
+void zj_pool_destroy(zj_pool *pool);
+int zj_pool_threads(const zj_pool *pool);
+const char *zj_pool_error(const zj_pool *pool);
+/* accumulated since creation: seconds spent inside the entropy stage and inside the GPU stage (summed over the
+ * threads of each stage) and files that reached the GPU stage */
+int zj_pool_stats(zj_pool *pool, double *entropy_seconds, double *gpu_seconds, size_t *files);
+int zj_pool_decode_files(zj_pool *pool, size_t nfiles, const uint8_t *const *bufs, const size_t *lens,
+                         uint8_t *const *outs, const size_t *out_caps, size_t *out_lens /*[nfiles] or NULL*/,
+                         zj_image_info *infos /*[nfiles] or NULL*/, int *statuses /*[nfiles] or NULL*/);
 
 /* ---- memory helpers ------------------------------------------------------------------------- */
 void *zj_alloc_pinned(size_t bytes); /* hipHostMalloc; NULL on failure */

@@ -287,6 +287,38 @@ def test_decode_batch_and_device_api(ctx, zj, synth):
             ctx.device_free(b)
 
 
+@pytest.mark.parametrize("mode,out_cs,w,h,n", [
+    ("hv", oc.RGB, 256, 72, 11),        # odd MCU row: the last 8 rows of every frame stay 0 (Q6); grouped frames
+    ("hv", oc.RGB, 4096, 2200, 2),      # 25 MB per frame: each frame is cut into strip ranges, last one ragged
+    ("none", oc.YCBCR, 1920, 1080, 3),  # 12 MB per frame, whole frames
+    ("h", oc.RGB, 1001, 57, 7),         # generic store path, H mode drops the odd MCU row
+    ("v", oc.GRAYSCALE, 2048, 3000, 1), # one large luma-only frame, split
+])
+def test_host_pipeline_units(ctx, zj, synth, mode, out_cs, w, h, n):
+    """zj_decode_planes_batch cuts the batch into units (frame groups or strip ranges) that overlap on three
+    streams: same bytes as the oracle frame by frame, and as the unpipelined single-unit path."""
+    hs, vs = MODES[mode]
+    frames = [synth.make_frame(w, h, hs, vs, 3, seed=300, frame_index=i % 3) for i in range(n)]
+    qts = frames[0][1]
+    planes = [np.concatenate([f[0][c] for f in frames]) for c in range(3)]
+    d = zj.FrameDesc.make(w, h, hs, vs, 3, out_cs, qts)
+    out = ctx.decode_planes(d, planes, nframes=n)
+    ctx.set_pipeline(0)
+    try:
+        single = ctx.decode_planes(d, planes, nframes=n)
+    finally:
+        ctx.set_pipeline(1)
+    assert_same(out, single, "pipelined vs single unit")
+    olen = out.size // n
+    exp = {}
+    for i in range(n):
+        if i % 3 not in exp:
+            rc, e = oc.decode_planes(oc.make_frame(w, h, hs, vs, 3, out_cs, qts), frames[i][0])
+            assert rc == 0
+            exp[i % 3] = e
+        assert_same(out[i * olen:(i + 1) * olen], exp[i % 3], f"frame {i}")
+
+
 def test_unsupported_and_invalid_arguments(ctx, zj, synth):
     planes, qts = synth.make_frame(64, 64, 2, 2, 3, seed=1)
     with pytest.raises(zj.ZjError) as e:  # 16-bit quantisation tables are rejected (headers.rs:154-174)
@@ -374,3 +406,40 @@ def test_decode_buffer_synthetic_progressive_420(ctx, zj, synth):
         rc, exp = oc.decode_planes(oc.make_frame(w, h, 2, 2, 3, oc.RGB, qts), planes)
         assert rc == 0
         assert_same(out, exp, enc.__name__)
+
+
+@pytest.mark.parametrize("threads", [1, 3])
+def test_pool_decodes_a_mixed_batch(zj, synth, threads):
+    """zj_pool_decode_files: several workers, each entropy decoder + GPU context; every file equals the oracle on the
+    planes it was encoded from, a broken file reports its own status without disturbing the others."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import jpeg_enc
+    qts = synth.quant_tables(88)
+    cases = []
+    for i, (w, h, hs, vs, kind) in enumerate([(208, 96, 2, 2, "rst"), (64, 64, 1, 1, "prog"), (130, 50, 2, 1, "base"),
+                                              (96, 72, 1, 2, "rst"), (320, 200, 2, 2, "prog"), (48, 40, 2, 2, "base"),
+                                              (200, 120, 2, 2, "rst")]):
+        planes = jpeg_enc.small_planes(w, h, hs, vs, 3, seed=20 + i)
+        if kind == "prog":
+            blob = jpeg_enc.encode_progressive(planes, qts, w, h, hs, vs, 3)
+        else:
+            blob = jpeg_enc.encode_baseline(planes, qts, w, h, hs, vs, 3, restart=5 if kind == "rst" else 0)
+        rc, exp = oc.decode_planes(oc.make_frame(w, h, hs, vs, 3, oc.RGB, qts), planes)
+        assert rc == 0
+        cases.append((blob, exp))
+    for name in ("test-baseline.jpg", "test-progressive.jpg"):
+        blob = open(os.path.join(HERE, "golden", name), "rb").read()
+        cases.append((blob, zj.Decoder().decode_buffer(blob)))
+    bad = bytes(cases[0][0][:40])
+    o = zj.ZuneJpegOptions()
+    o.num_threads = 2
+    with zj.Pool(threads=threads, options=o) as pool:
+        assert pool.threads == threads
+        for _ in range(2):  # the pool is reused across batches
+            outs, infos, sts = pool.decode_files([c[0] for c in cases] + [bad], raise_on_error=False)
+            assert sts[:-1] == [0] * len(cases) and sts[-1] != 0
+            for i, (blob, exp) in enumerate(cases):
+                assert_same(outs[i], exp, f"file {i}")
+        with pytest.raises(zj.DecodeError):
+            pool.decode_files([bad])

@@ -135,3 +135,71 @@ def test_reference_images_vs_pillow(zj, name, prog, scans):
     pil = np.asarray(im, np.int32)
     d = np.abs(ours.reshape(1080, 1920, 3).astype(np.int32) - pil)
     assert d.max() <= 4 and d.mean() < 0.5
+
+
+def _opts(zj, threads):
+    o = zj.ZuneJpegOptions()
+    o.num_threads = threads
+    return o
+
+
+@pytest.mark.parametrize("mode,wh,ri", [("hv", (200, 120), 13), ("none", (96, 64), 12), ("h", (130, 40), 1), ("v", (64, 200), 8)])
+def test_restart_segments_decode_concurrently(zj, synth, mode, wh, ri):
+    """DRI/RSTn (decoder.rs:376-389, mcu.rs:386-419): with num_threads > 1 the restart segments of a baseline scan are
+    decoded on several threads; same planes as the strictly serial walk."""
+    hs, vs = MODES[mode]
+    w, h = wh
+    planes = jpeg_enc.small_planes(w, h, hs, vs, 3, seed=ri)
+    data = jpeg_enc.encode_baseline(planes, synth.quant_tables(80), w, h, hs, vs, 3, restart=ri)
+    serial, par = zj.Decoder(_opts(zj, 1)), zj.Decoder(_opts(zj, 4))
+    _, a, info = serial.decode_coefficients(data)
+    _, b, _ = par.decode_coefficients(data)
+    mcus = ((w + 8 * hs - 1) // (8 * hs)) * ((h + 8 * vs - 1) // (8 * vs))
+    assert info.restart_interval == ri
+    assert serial.parallel_segments() == 0
+    assert par.parallel_segments() == (mcus + ri - 1) // ri
+    for c in range(3):
+        assert np.array_equal(a[c], b[c]) and np.array_equal(a[c], planes[c])
+
+
+def test_damaged_restart_structure_takes_the_serial_walk(zj, synth):
+    """A missing or out-of-sequence RSTn, or a bad code inside a segment: the concurrent path steps aside and the
+    serial walk produces the result (or the error text) it always did."""
+    w, h, ri = 128, 64, 4
+    planes = jpeg_enc.small_planes(w, h, 2, 2, 3, seed=9)
+    data = bytearray(jpeg_enc.encode_baseline(planes, synth.quant_tables(80), w, h, 2, 2, 3, restart=ri))
+    rst = [i for i in range(len(data) - 1) if data[i] == 0xFF and 0xD0 <= data[i + 1] <= 0xD7]
+    assert len(rst) >= 3
+
+    def both(blob):
+        res = []
+        for t in (1, 4):
+            d = zj.Decoder(_opts(zj, t))
+            try:
+                _, pl, _ = d.decode_coefficients(bytes(blob))
+                res.append(("ok", [p.copy() for p in pl], d.parallel_segments()))
+            except zj.DecodeError as e:
+                res.append(("err", (e.status, e.text), d.parallel_segments()))
+        return res
+
+    out_of_seq = bytearray(data)
+    out_of_seq[rst[1] + 1] = 0xD5
+    dropped = data[:rst[1]] + data[rst[1] + 2:]
+    truncated = data[:rst[2] + 2] + b"\xff\xd9"
+    for blob in (out_of_seq, dropped, truncated):
+        s, p = both(blob)
+        assert p[2] == 0 and s[0] == p[0]
+        if s[0] == "ok":
+            assert all(np.array_equal(x, y) for x, y in zip(s[1], p[1]))
+        else:
+            assert s[1] == p[1]
+
+
+def test_pinned_plane_option_without_device(zj, synth):
+    """pinned_planes falls back to heap planes when no HIP device can pin memory (CPU container)."""
+    planes = jpeg_enc.small_planes(64, 48, 2, 2, 3, seed=3)
+    data = jpeg_enc.encode_baseline(planes, synth.quant_tables(85), 64, 48, 2, 2, 3)
+    o = zj.ZuneJpegOptions()
+    o.pinned_planes = True
+    _, got, _ = zj.Decoder(o).decode_coefficients(data)
+    assert all(np.array_equal(g, p) for g, p in zip(got, planes))

@@ -41,7 +41,28 @@ def pinned():
     assert rc == 0
 
 
-print(f"4096x4096 4:2:0, host planes (pinned)   -> RGB on host: {rate(pinned):9.1f} MP/s   (100.7 MB over PCIe per frame)")
+print(f"4096x4096 4:2:0, host planes (pinned)   -> RGB on host: {rate(pinned):9.1f} MP/s   (100.7 MB over PCIe per frame; strip ranges overlapped on 3 streams)")
+ctx.set_pipeline(0)
+print(f"   same, one unit per call (no overlap)                  : {rate(pinned):9.1f} MP/s")
+ctx.set_pipeline(1)
+NB = 8
+bp = [L.zj_alloc_pinned(s * NB) for s in sizes]
+for p, pin in zip(planes, bp):
+    for i in range(NB):
+        C.memmove(pin + i * p.nbytes, p.ctypes.data, p.nbytes)
+
+
+def pinned_batch():
+    rc = L.zj_decode_planes_batch(ctx.handle, C.byref(desc), NB, bp[0], bp[1], bp[2], bp[3])
+    assert rc == 0
+
+
+print(f"   batch of {NB} frames (pinned), overlapped                 : {NB * rate(pinned_batch, 5):9.1f} MP/s")
+ctx.set_pipeline(0)
+print(f"   batch of {NB} frames (pinned), one unit                   : {NB * rate(pinned_batch, 5):9.1f} MP/s")
+ctx.set_pipeline(1)
+for p in bp:
+    L.zj_free_pinned(p)
 for p in pins:
     L.zj_free_pinned(p)
 for name in ("test-baseline.jpg", "test-progressive.jpg"):

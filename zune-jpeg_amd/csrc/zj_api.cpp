@@ -19,6 +19,20 @@ using namespace zj;
 namespace {
 constexpr int QT_SLOTS = 8;
 constexpr int N_SCRATCH = 4;
+constexpr int N_SLOTS = 3;                  // H2D of unit i+1 | kernel of unit i | D2H of unit i-1
+constexpr size_t UNIT_TARGET_DEFAULT = 16u << 20; // coefficient bytes per pipeline unit: every copy costs ~15 us of
+                                                   // launch overhead (tools/pcie_probe.py), so units stay large
+
+// one buffer set of the host-buffer pipeline (zj_decode_planes_batch).  Three streams, one per engine:
+// `up` carries every H2D copy, `run` every kernel, `down` every D2H copy (a stream per direction is what
+// lets the two DMA directions overlap, tools/pcie_probe.py); events order the stages of a unit and the
+// reuse of its buffers.
+struct PipeSlot {
+    void* buf[N_SCRATCH] = {nullptr, nullptr, nullptr, nullptr}; // y, cb, cr, out
+    size_t cap[N_SCRATCH] = {0, 0, 0, 0};
+    hipEvent_t up_done = nullptr, run_done = nullptr, down_done = nullptr;
+    bool used = false; // events recorded at least once since the last full synchronisation
+};
 }
 
 struct zj_ctx {
@@ -31,6 +45,9 @@ struct zj_ctx {
     void* scratch[N_SCRATCH] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_cap[N_SCRATCH] = {0, 0, 0, 0};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    PipeSlot slots[N_SLOTS];
+    hipStream_t s_up = nullptr, s_run = nullptr, s_down = nullptr;
+    int pipeline = 1;             // 0: one unit per call (no overlap), for A/B timing only
     std::string last_error;
     int debug = 0;                // ablation switches, diagnostics only (results are WRONG when set)
     int compact = 0;              // kernel variant: 0 one pass per tile, 1 DC-only compaction, 2 persistent + prefetch
@@ -52,6 +69,39 @@ static int ensure_scratch(zj_ctx* c, int i, size_t bytes)
     size_t cap = bytes + bytes / 4 + 4096;
     ZJ_HIP(c, hipMalloc(&c->scratch[i], cap));
     c->scratch_cap[i] = cap;
+    return ZJ_OK;
+}
+
+static int pipe_sync(zj_ctx* c)
+{
+    ZJ_HIP(c, hipStreamSynchronize(c->s_up));
+    ZJ_HIP(c, hipStreamSynchronize(c->s_run));
+    ZJ_HIP(c, hipStreamSynchronize(c->s_down));
+    for (PipeSlot& sl : c->slots) sl.used = false;
+    return ZJ_OK;
+}
+
+static int pipe_init(zj_ctx* c)
+{
+    if (c->s_up) return ZJ_OK;
+    ZJ_HIP(c, hipStreamCreateWithFlags(&c->s_up, hipStreamNonBlocking));
+    ZJ_HIP(c, hipStreamCreateWithFlags(&c->s_run, hipStreamNonBlocking));
+    ZJ_HIP(c, hipStreamCreateWithFlags(&c->s_down, hipStreamNonBlocking));
+    for (PipeSlot& sl : c->slots) {
+        ZJ_HIP(c, hipEventCreateWithFlags(&sl.up_done, hipEventDisableTiming));
+        ZJ_HIP(c, hipEventCreateWithFlags(&sl.run_done, hipEventDisableTiming));
+        ZJ_HIP(c, hipEventCreateWithFlags(&sl.down_done, hipEventDisableTiming));
+    }
+    return ZJ_OK;
+}
+
+static int ensure_slot(zj_ctx* c, PipeSlot& sl, int i, size_t bytes)
+{
+    if (bytes <= sl.cap[i]) return ZJ_OK;
+    if (sl.buf[i]) { int rc = pipe_sync(c); if (rc) return rc; ZJ_HIP(c, hipFree(sl.buf[i])); sl.buf[i] = nullptr; sl.cap[i] = 0; }
+    const size_t cap = bytes + bytes / 8 + 4096;
+    ZJ_HIP(c, hipMalloc(&sl.buf[i], cap));
+    sl.cap[i] = cap;
     return ZJ_OK;
 }
 
@@ -128,6 +178,16 @@ void zj_ctx_destroy(zj_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < N_SCRATCH; i++)
         if (c->scratch[i]) (void)hipFree(c->scratch[i]);
+    for (hipStream_t st : {c->s_up, c->s_run, c->s_down})
+        if (st) (void)hipStreamSynchronize(st);
+    for (PipeSlot& sl : c->slots) {
+        for (int i = 0; i < N_SCRATCH; i++)
+            if (sl.buf[i]) (void)hipFree(sl.buf[i]);
+        for (hipEvent_t ev : {sl.up_done, sl.run_done, sl.down_done})
+            if (ev) (void)hipEventDestroy(ev);
+    }
+    for (hipStream_t st : {c->s_up, c->s_run, c->s_down})
+        if (st) (void)hipStreamDestroy(st);
     if (c->d_qt) (void)hipFree(c->d_qt);
     if (c->h_qt) (void)hipHostFree(c->h_qt);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -291,27 +351,101 @@ int zj_time_decode_device(zj_ctx* c, const zj_frame_desc* d, size_t nframes, con
 int zj_decode_planes_batch(zj_ctx* c, const zj_frame_desc* d, size_t nframes, const int16_t* y,
                            const int16_t* cb, const int16_t* cr, uint8_t* out)
 {
+    // Host planes -> host pixels.  The batch is cut into units of about 16 MB of coefficients (ZJ_UNIT_MB) --
+    // several whole frames, or a strip range of one large frame (strips are independent: no filter tap
+    // crosses a strip, Q3/Q4).  Uploads, kernels and downloads run on a stream each, chained by events over
+    // N_SLOTS buffer sets, so the upload of one unit, the kernel of the previous and the download of the one
+    // before overlap (PCIe is full duplex).  Pinned host buffers (zj_alloc_pinned) make the copies asynchronous.
     Plan pl;
     int rc = check_frame_args(c, d, nframes, y, cb, cr, out, pl);
     if (rc) return rc;
     ZJ_HIP(c, hipSetDevice(c->device));
     const bool chroma = pl.out != OUT_GRAY;
-    const size_t yb = nframes * pl.y_len * 2, cbytes = chroma ? nframes * pl.c_len * 2 : 0, ob = nframes * pl.out_len;
-    if ((rc = ensure_scratch(c, 0, yb))) return rc;
-    if (chroma && ((rc = ensure_scratch(c, 1, cbytes)) || (rc = ensure_scratch(c, 2, cbytes)))) return rc;
-    if ((rc = ensure_scratch(c, 3, ob))) return rc;
-    hipStream_t s = c->stream;
-    ZJ_HIP(c, hipMemcpyAsync(c->scratch[0], y, yb, hipMemcpyHostToDevice, s));
-    if (chroma) {
-        ZJ_HIP(c, hipMemcpyAsync(c->scratch[1], cb, cbytes, hipMemcpyHostToDevice, s));
-        ZJ_HIP(c, hipMemcpyAsync(c->scratch[2], cr, cbytes, hipMemcpyHostToDevice, s));
+    const int mrps = pl.hs == 2 ? 2 : 1;                                     // MCU rows per strip
+    const size_t ystrip = (size_t)pl.mcu_x * 64 * pl.hs * pl.vs * mrps;      // i16 per strip
+    const size_t cstrip = (size_t)pl.mcu_x * 64 * mrps;
+    const size_t ostrip = (size_t)d->width * pl.ncomp_out * pl.strip_rows;   // bytes per strip
+    const size_t covered = (size_t)pl.rows_covered < d->height ? (size_t)pl.rows_covered : d->height;
+    const size_t covered_bytes = covered * d->width * pl.ncomp_out;
+    // rows below the last complete strip are never written by the reference (Q6)
+    if (covered_bytes < pl.out_len)
+        for (size_t f = 0; f < nframes; f++) memset(out + f * pl.out_len + covered_bytes, 0, pl.out_len - covered_bytes);
+    if (pl.n_strips == 0) return ZJ_OK;
+
+    size_t UNIT_TARGET = UNIT_TARGET_DEFAULT;
+    if (const char* e = getenv("ZJ_UNIT_MB")) { const long v = atol(e); if (v > 0 && v < 4096) UNIT_TARGET = (size_t)v << 20; }
+    const size_t in_frame = (pl.y_len + (chroma ? 2 * pl.c_len : 0)) * 2;
+    size_t split = 1, group = 1; // strip ranges per frame | frames per unit
+    if (c->pipeline) {
+        if (in_frame >= 2 * UNIT_TARGET) {
+            split = (in_frame + UNIT_TARGET - 1) / UNIT_TARGET;
+            if (split > (size_t)pl.n_strips) split = (size_t)pl.n_strips;
+        } else {
+            group = UNIT_TARGET / (in_frame ? in_frame : 1);
+            if (group < 1) group = 1;
+            if (group * N_SLOTS > nframes) group = (nframes + N_SLOTS - 1) / N_SLOTS; // keep every slot busy
+        }
+    } else group = nframes;
+    const size_t strips_per_unit = ((size_t)pl.n_strips + split - 1) / split;
+
+    // quantisation tables once, on the stream the kernels run on
+    if ((rc = pipe_init(c))) return rc;
+    const int32_t* d_qt = nullptr;
+    if ((rc = stage_qt(c, d->qt, c->s_run, &d_qt))) return rc;
+
+    size_t u = 0;
+    for (size_t f0 = 0; f0 < nframes; f0 += group) {
+        const size_t nfr = f0 + group <= nframes ? group : nframes - f0;
+        for (size_t s0 = 0; s0 < (size_t)pl.n_strips; s0 += strips_per_unit, u++) {
+            const size_t s1 = s0 + strips_per_unit < (size_t)pl.n_strips ? s0 + strips_per_unit : (size_t)pl.n_strips;
+            const bool whole = s0 == 0 && s1 == (size_t)pl.n_strips;
+            PipeSlot& sl = c->slots[u % N_SLOTS];
+            // unit extents: whole frames keep the frame strides; a strip range is one short "frame"
+            const size_t yel = whole ? nfr * pl.y_len : (s1 - s0) * ystrip;
+            const size_t cel = whole ? nfr * pl.c_len : (s1 - s0) * cstrip;
+            size_t obytes = whole ? nfr * pl.out_len : (s1 - s0) * ostrip;
+            if (!whole && s0 * ostrip + obytes > covered_bytes) obytes = covered_bytes - s0 * ostrip;
+            if ((rc = ensure_slot(c, sl, 0, yel * 2))) return rc;
+            if (chroma && ((rc = ensure_slot(c, sl, 1, cel * 2)) || (rc = ensure_slot(c, sl, 2, cel * 2)))) return rc;
+            if ((rc = ensure_slot(c, sl, 3, whole ? nfr * pl.out_len : (s1 - s0) * ostrip))) return rc;
+            // up: the slot's planes are free once the kernel of its previous unit has run
+            if (sl.used) ZJ_HIP(c, hipStreamWaitEvent(c->s_up, sl.run_done, 0));
+            const size_t yoff = f0 * pl.y_len + (whole ? 0 : s0 * ystrip), coff = f0 * pl.c_len + (whole ? 0 : s0 * cstrip);
+            ZJ_HIP(c, hipMemcpyAsync(sl.buf[0], y + yoff, yel * 2, hipMemcpyHostToDevice, c->s_up));
+            if (chroma) {
+                ZJ_HIP(c, hipMemcpyAsync(sl.buf[1], cb + coff, cel * 2, hipMemcpyHostToDevice, c->s_up));
+                ZJ_HIP(c, hipMemcpyAsync(sl.buf[2], cr + coff, cel * 2, hipMemcpyHostToDevice, c->s_up));
+            }
+            ZJ_HIP(c, hipEventRecord(sl.up_done, c->s_up));
+            // run: after this unit's upload and after the slot's previous download has drained its pixels
+            ZJ_HIP(c, hipStreamWaitEvent(c->s_run, sl.up_done, 0));
+            if (sl.used) ZJ_HIP(c, hipStreamWaitEvent(c->s_run, sl.down_done, 0));
+            Params p;
+            fill_params(d, pl, whole ? nfr : 1, (const int16_t*)sl.buf[0], (const int16_t*)sl.buf[1],
+                        (const int16_t*)sl.buf[2], (uint8_t*)sl.buf[3], d_qt, 1, p);
+            p.debug = c->debug;
+            if (!whole) { // strips [s0, s1) of frame f0 as a frame of its own
+                p.n_strips = (int)(s1 - s0);
+                p.height = (int)d->height - (int)s0 * pl.strip_rows;
+                p.total_tiles = p.n_strips * pl.tiles_per_row;
+            }
+            ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->compact, pl.fast ? 1 : 0, p, c->s_run));
+            ZJ_HIP(c, hipEventRecord(sl.run_done, c->s_run));
+            // down
+            ZJ_HIP(c, hipStreamWaitEvent(c->s_down, sl.run_done, 0));
+            if (whole && covered_bytes < pl.out_len) { // skip the never-written rows of every frame
+                for (size_t f = 0; f < nfr; f++)
+                    ZJ_HIP(c, hipMemcpyAsync(out + (f0 + f) * pl.out_len, (uint8_t*)sl.buf[3] + f * pl.out_len, covered_bytes,
+                                             hipMemcpyDeviceToHost, c->s_down));
+            } else {
+                ZJ_HIP(c, hipMemcpyAsync(out + f0 * pl.out_len + (whole ? 0 : s0 * ostrip), sl.buf[3], obytes,
+                                         hipMemcpyDeviceToHost, c->s_down));
+            }
+            ZJ_HIP(c, hipEventRecord(sl.down_done, c->s_down));
+            sl.used = true;
+        }
     }
-    rc = decode_device_impl(c, d, pl, nframes, (const int16_t*)c->scratch[0], (const int16_t*)c->scratch[1],
-                            (const int16_t*)c->scratch[2], (uint8_t*)c->scratch[3], s, 1);
-    if (rc) return rc;
-    ZJ_HIP(c, hipMemcpyAsync(out, c->scratch[3], ob, hipMemcpyDeviceToHost, s));
-    ZJ_HIP(c, hipStreamSynchronize(s));
-    return ZJ_OK;
+    return pipe_sync(c);
 }
 
 int zj_decode_planes(zj_ctx* c, const zj_frame_desc* d, const int16_t* y, const int16_t* cb,
@@ -486,6 +620,8 @@ zj_color_convert16_fn zj_choose_ycbcr_to_rgb_convert_func(int backend, int out_c
 
 /* kernel-variant switch for A/B measurements (both variants are bit-exact) */
 int zj_set_variant(zj_ctx* c, int variant) { if (!c || variant < 0 || variant > 2) return ZJ_ERR_ARG; c->compact = variant; return ZJ_OK; }
+/* 0 = one unit per zj_decode_planes_batch call (no copy/compute overlap); A/B timing only */
+int zj_set_pipeline(zj_ctx* c, int on) { if (!c) return ZJ_ERR_ARG; c->pipeline = on ? 1 : 0; return ZJ_OK; }
 int zj_set_persistent_grid(int wgs) { set_persistent_grid(wgs); return ZJ_OK; }
 /* occupancy probe (tools/occupancy.py): pad every fused launch with dynamic LDS; query workgroups per CU */
 int zj_set_pad_lds(int bytes) { set_pad_lds(bytes); return ZJ_OK; }

@@ -15,8 +15,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/zjhip.h"
@@ -135,8 +137,47 @@ struct Comp {
     int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
     int32_t dc_pred = 0;
     int bw = 0, bh = 0; // plane size in blocks
-    std::vector<int16_t> coef;
+    int16_t* coef = nullptr; // bw * bh * 64, owned by zj_decoder::store
+    size_t coef_len = 0;
 };
+
+// backing store of one coefficient plane: heap, or pinned host memory (zj_alloc_pinned) so that
+// zj_decode_planes can DMA it without a staging copy
+struct PlaneStore {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool pinned = false;
+    void release()
+    {
+        if (p) { if (pinned) zj_free_pinned(p); else free(p); }
+        p = nullptr; cap = 0;
+    }
+    int16_t* ensure(size_t bytes, bool want_pinned)
+    {
+        if (p && cap >= bytes && pinned == want_pinned) return (int16_t*)p;
+        release();
+        const size_t c = bytes + bytes / 8 + 4096;
+        p = want_pinned ? zj_alloc_pinned(c) : malloc(c);
+        if (!p && want_pinned) { p = malloc(c); want_pinned = false; } // no device / no pinned memory left
+        if (!p) return nullptr;
+        cap = c; pinned = want_pinned;
+        return (int16_t*)p;
+    }
+};
+
+// run fn(i) for i in [0, n) on up to `threads` std::threads (the calling thread is one of them)
+template <class F> void parallel_for(int n, int threads, F fn)
+{
+    if (threads > n) threads = n;
+    if (threads <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
+    std::atomic<int> next{0};
+    auto work = [&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)threads - 1);
+    for (int t = 1; t < threads; t++) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+}
 
 } // namespace
 
@@ -145,6 +186,10 @@ struct zj_decoder {
     int out_colorspace = ZJ_CS_RGB;
     int strict_mode = 0;
     int max_width = 16384, max_height = 16384, max_scans = 64;
+    int threads = 4;       // options.rs:33 (default 4): here, restart segments / plane zeroing in parallel
+    bool pinned = false;   // coefficient planes in pinned host memory
+    PlaneStore store[3];
+    ~zj_decoder() { for (auto& st : store) st.release(); }
     // state
     std::string err;
     int err_code = 0;
@@ -158,6 +203,7 @@ struct zj_decoder {
     // current scan
     int ns = 0, order[3] = {0, 0, 0}, ss = 0, se = 63, ah = 0, al = 0;
     uint32_t eobrun = 0;
+    int dri_parallel_segments = 0; // restart segments the last baseline scan decoded concurrently (0 = serial walk)
 };
 
 namespace {
@@ -269,7 +315,20 @@ int parse_sof(zj_decoder* d, Cursor& c, int progressive)
         if (!d->qt_present[cm.tq]) return fail(d, ZJ_ERR_DQT, "No quantization table for component " + std::to_string(cm.id));
         cm.bw = d->mcu_x * cm.h;
         cm.bh = d->mcu_y * cm.v;
-        cm.coef.assign((size_t)cm.bw * cm.bh * 64, 0);
+        cm.coef_len = (size_t)cm.bw * cm.bh * 64;
+        cm.coef = d->store[i].ensure(cm.coef_len * 2, d->pinned);
+        if (!cm.coef) return fail(d, ZJ_ERR_NOMEM, "out of memory for the coefficient planes");
+    }
+    // the entropy decoder only writes non-zero coefficients: clear the planes (in parallel when large)
+    for (int i = 0; i < nc; i++) {
+        Comp& cm = d->comps[i];
+        const size_t bytes = cm.coef_len * 2, piece = (size_t)4 << 20;
+        const int n = (int)((bytes + piece - 1) / piece);
+        char* base = (char*)cm.coef;
+        parallel_for(n, d->threads, [&](int k) {
+            const size_t o = (size_t)k * piece;
+            memset(base + o, 0, o + piece <= bytes ? piece : bytes - o);
+        });
     }
     if (nc == 3) {
         // check_component_dimensions (decoder.rs:609-646): chroma must be (1,1), luma one of the four modes
@@ -356,20 +415,22 @@ int parse_headers(zj_decoder* d, Cursor& c, bool first)
 }
 
 // ---- entropy-coded segments ------------------------------------------------------------------
-inline int16_t* block_at(Comp& cm, int bx, int by) { return cm.coef.data() + ((size_t)by * cm.bw + bx) * 64; }
+inline int16_t* block_at(Comp& cm, int bx, int by) { return cm.coef + ((size_t)by * cm.bw + bx) * 64; }
 
-int decode_block_baseline(zj_decoder* d, BitReader& br, Comp& cm, int16_t* blk)
+// one block of a baseline scan; *err is set instead of the decoder state so that restart segments can
+// run on several threads
+int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, int32_t& dc_pred, int16_t* blk, const char** err)
 {
     const Huff& hd = d->dc[cm.td & 3];
     const Huff& ha = d->ac[cm.ta & 3];
     int s = br.decode(hd);
-    if (s < 0 || s > 16) return fail(d, ZJ_ERR_HUFFMAN, "Bad Huffman code in DC");
+    if (s < 0 || s > 16) { *err = "Bad Huffman code in DC"; return ZJ_ERR_HUFFMAN; }
     int32_t diff = s ? extend(br.get(s), s) : 0;
-    cm.dc_pred = (int32_t)((uint32_t)cm.dc_pred + (uint32_t)diff);
-    blk[0] = (int16_t)cm.dc_pred; // bitstream.rs:330
+    dc_pred = (int32_t)((uint32_t)dc_pred + (uint32_t)diff);
+    blk[0] = (int16_t)dc_pred; // bitstream.rs:330
     for (int k = 1; k < 64;) {
         int rs = br.decode(ha);
-        if (rs < 0) return fail(d, ZJ_ERR_HUFFMAN, "Bad Huffman code in AC");
+        if (rs < 0) { *err = "Bad Huffman code in AC"; return ZJ_ERR_HUFFMAN; }
         int r = rs >> 4, sz = rs & 15;
         if (sz) {
             k += r;
@@ -400,6 +461,55 @@ int handle_restart(zj_decoder* d, BitReader& br, int& todo)
     return ZJ_OK;
 }
 
+// Restart markers cut a baseline scan into independently decodable segments (T.81 E.1.4: predictors
+// and the bit buffer restart at every RSTn).  Returns true when [p, end) holds exactly the nseg-1
+// sequential RST markers a well-formed scan has before its first other marker; seg[] gets the start
+// of every segment and seg[nseg] the end of the last one.
+bool find_restart_segments(const uint8_t* p, const uint8_t* end, int nseg, std::vector<const uint8_t*>& seg)
+{
+    seg.clear();
+    seg.push_back(p);
+    int expect = 0;
+    while (p < end) {
+        const uint8_t* f = (const uint8_t*)memchr(p, 0xFF, (size_t)(end - p));
+        if (!f || f + 1 >= end) { p = end; break; }
+        const uint8_t m = f[1];
+        if (m == 0x00) { p = f + 2; continue; }        // stuffed byte
+        if (m == 0xFF) { p = f + 1; continue; }        // fill byte
+        if (m >= 0xD0 && m <= 0xD7) {
+            if (m != 0xD0 + (expect & 7)) return false; // out of sequence: let the serial path decide
+            expect++;
+            seg.push_back(f + 2);
+            p = f + 2;
+            continue;
+        }
+        p = f;                                          // EOI or any other marker ends the scan
+        break;
+    }
+    seg.push_back(p);
+    return (int)seg.size() == nseg + 1;
+}
+
+int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p, const uint8_t* end, long long mcu0,
+                          long long nmcu, const char** err)
+{
+    BitReader br;
+    br.p = p; br.end = end;
+    int32_t pred[3] = {0, 0, 0};
+    for (long long i = 0; i < nmcu; i++) {
+        const int my = (int)((mcu0 + i) / d->mcu_x), mx = (int)((mcu0 + i) % d->mcu_x);
+        for (int ci = 0; ci < d->ns; ci++) {
+            Comp& cm = dm->comps[d->order[ci]];
+            for (int v = 0; v < cm.v; v++)
+                for (int h = 0; h < cm.h; h++) {
+                    int rc = decode_block_baseline(d, br, cm, pred[d->order[ci]], block_at(cm, mx * cm.h + h, my * cm.v + v), err);
+                    if (rc) return rc;
+                }
+        }
+    }
+    return ZJ_OK;
+}
+
 int scan_baseline(zj_decoder* d, BitReader& br)
 {
     for (int i = 0; i < d->ncomp; i++) {
@@ -408,6 +518,26 @@ int scan_baseline(zj_decoder* d, BitReader& br)
         if (!d->ac[d->comps[i].ta & 3].present) return fail(d, ZJ_ERR_HUFFMAN, "No AC table for component " + std::to_string(d->comps[i].id));
     }
     if (d->ns != d->ncomp) return fail(d, ZJ_ERR_UNSUPPORTED, "baseline scans must carry every component (src/mcu.rs:253-321)");
+    const long long total = (long long)d->mcu_x * d->mcu_y;
+    if (d->threads > 1 && d->restart_interval > 0 && total > d->restart_interval) {
+        // well-formed restart structure: decode the segments concurrently; anything unusual (missing or
+        // out-of-sequence markers, a bad code) is left to the serial walk below, which owns the error text
+        const int ri = d->restart_interval;
+        const int nseg = (int)((total + ri - 1) / ri);
+        std::vector<const uint8_t*> seg;
+        if (find_restart_segments(br.p, br.end, nseg, seg)) {
+            std::atomic<int> bad{0};
+            parallel_for(nseg, d->threads, [&](int k) {
+                const char* err = nullptr;
+                const long long m0 = (long long)k * ri, n = m0 + ri <= total ? ri : total - m0;
+                // a segment ends where the next RSTn (or the closing marker) begins: the reader stops there
+                if (scan_baseline_segment(d, d, seg[(size_t)k], seg[(size_t)k + 1], m0, n, &err)) bad.store(1);
+            });
+            if (!bad.load()) { br.p = seg[(size_t)nseg]; br.reset(); d->dri_parallel_segments = nseg; return ZJ_OK; }
+            for (int i = 0; i < d->ncomp; i++) memset(d->comps[i].coef, 0, d->comps[i].coef_len * 2);
+        }
+    }
+    d->dri_parallel_segments = 0;
     int todo = d->restart_interval ? d->restart_interval : 0x7fffffff;
     // (2,1): the reference walks 2*mcu_x MCUs per strip (mcu.rs:145-152); MCU order is unchanged
     for (int my = 0; my < d->mcu_y; my++)
@@ -416,8 +546,9 @@ int scan_baseline(zj_decoder* d, BitReader& br)
                 Comp& cm = d->comps[d->order[ci]];
                 for (int v = 0; v < cm.v; v++)
                     for (int h = 0; h < cm.h; h++) {
-                        int rc = decode_block_baseline(d, br, cm, block_at(cm, mx * cm.h + h, my * cm.v + v));
-                        if (rc) return rc;
+                        const char* err = nullptr;
+                        int rc = decode_block_baseline(d, br, cm, cm.dc_pred, block_at(cm, mx * cm.h + h, my * cm.v + v), &err);
+                        if (rc) return fail(d, rc, err);
                     }
             }
             if (--todo == 0) { int rc = handle_restart(d, br, todo); if (rc) return rc; }
@@ -611,11 +742,14 @@ zj_decoder* zj_decoder_new(const zj_options* opt)
         if (opt->max_width) d->max_width = opt->max_width;
         if (opt->max_height) d->max_height = opt->max_height;
         if (opt->max_scans) d->max_scans = opt->max_scans;
+        if (opt->num_threads > 0) d->threads = opt->num_threads;
+        d->pinned = opt->pinned_planes != 0;
     }
     return d;
 }
 void zj_decoder_free(zj_decoder* d) { delete d; }
 const char* zj_decoder_error(const zj_decoder* d) { return d ? d->err.c_str() : ""; }
+int zj_decoder_parallel_segments(const zj_decoder* d) { return d ? d->dri_parallel_segments : 0; }
 
 static void fill_info(const zj_decoder* d, zj_image_info* info, zj_frame_desc* fd)
 {
@@ -656,9 +790,26 @@ int zj_decoder_decode_coefficients(zj_decoder* d, const uint8_t* buf, size_t len
     if (rc) return rc;
     fill_info(d, info, desc);
     for (int c = 0; c < 3; c++) {
-        if (planes) planes[c] = c < d->ncomp ? d->comps[c].coef.data() : nullptr;
-        if (plane_len) plane_len[c] = c < d->ncomp ? d->comps[c].coef.size() : 0;
+        if (planes) planes[c] = c < d->ncomp ? d->comps[c].coef : nullptr;
+        if (plane_len) plane_len[c] = c < d->ncomp ? d->comps[c].coef_len : 0;
     }
+    return ZJ_OK;
+}
+
+int zj_decoder_finish_pixels(zj_decoder* d, zj_ctx* ctx, uint8_t* out, size_t out_cap, size_t* out_len)
+{
+    if (!d || !ctx || !out) return ZJ_ERR_ARG;
+    if (!d->seen_sof || d->err_code) return fail(d, ZJ_ERR_ARG, "no successfully decoded coefficients to finish");
+    zj_frame_desc fd;
+    fill_info(d, nullptr, &fd);
+    // grayscale JPEG decoded to RGB: the reference converts nothing and returns zeros (worker.rs:131)
+    const size_t need = zj_out_len(&fd);
+    if (out_len) *out_len = need;
+    if (out_cap < need) return fail(d, ZJ_ERR_ARG, "output buffer too small");
+    if (fd.in_components == 1 && fd.out_colorspace != ZJ_CS_GRAYSCALE) { memset(out, 0, need); return ZJ_OK; }
+    const int rc = zj_decode_planes(ctx, &fd, d->comps[0].coef, d->ncomp == 3 ? d->comps[1].coef : nullptr,
+                                    d->ncomp == 3 ? d->comps[2].coef : nullptr, out);
+    if (rc) return fail(d, rc, std::string("pixel path: ") + zj_strerror(rc) + " " + zj_last_error(ctx));
     return ZJ_OK;
 }
 
@@ -666,19 +817,9 @@ int zj_decoder_decode_buffer(zj_decoder* d, zj_ctx* ctx, const uint8_t* buf, siz
                              size_t out_cap, size_t* out_len, zj_image_info* info)
 {
     if (!d || !ctx || !buf || !out) return ZJ_ERR_ARG;
-    zj_frame_desc fd;
-    const int16_t* planes[3];
-    size_t plen[3];
-    int rc = zj_decoder_decode_coefficients(d, buf, len, &fd, planes, plen, info);
+    int rc = zj_decoder_decode_coefficients(d, buf, len, nullptr, nullptr, nullptr, info);
     if (rc) return rc;
-    // grayscale JPEG decoded to RGB: the reference converts nothing and returns zeros (worker.rs:131)
-    const size_t need = zj_out_len(&fd);
-    if (out_len) *out_len = need;
-    if (out_cap < need) return fail(d, ZJ_ERR_ARG, "output buffer too small");
-    if (fd.in_components == 1 && fd.out_colorspace != ZJ_CS_GRAYSCALE) { memset(out, 0, need); return ZJ_OK; }
-    rc = zj_decode_planes(ctx, &fd, planes[0], planes[1], planes[2], out);
-    if (rc) return fail(d, rc, std::string("pixel path: ") + zj_strerror(rc) + " " + zj_last_error(ctx));
-    return ZJ_OK;
+    return zj_decoder_finish_pixels(d, ctx, out, out_cap, out_len);
 }
 
 } // extern "C"

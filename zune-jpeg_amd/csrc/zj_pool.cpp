@@ -1,0 +1,217 @@
+// zj_pool.cpp -- batch decoding of JPEG files with a persistent two-stage host pipeline:
+//
+//   `threads` entropy workers   container parsing + Huffman (zj_jpeg.cpp) into PINNED coefficient planes
+//            | queue of decoded files (bounded by the number of plane sets)
+//   3 GPU submitters            each with its own zj_ctx: H2D -> fused kernel -> D2H (zj_api.cpp)
+//
+// The serial, branchy entropy stage (the true end-to-end bottleneck) is spread over the host
+// cores; three submitters are enough to keep both PCIe directions and the kernel queue busy (while one waits
+// for its download, another uploads) without dozens of threads contending inside the HIP runtime.  A plane
+// set (= one zj_decoder) goes back to the free list as soon as its pixels are out.
+// The reference creates a scoped_threadpool per decode for its post_process strips (src/mcu.rs:135); this
+// pool lives across calls because streams, pinned planes and device buffers are worth keeping.
+//
+// Only the C ABI of the library is used (include/zjhip.h, plus the zj_set_pipeline knob).
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/zjhip.h"
+
+extern "C" int zj_set_pipeline(zj_ctx* c, int on);
+
+namespace {
+constexpr int GPU_SUBMITTERS = 3;
+}
+
+struct zj_pool {
+    struct Batch {
+        size_t n = 0;
+        const uint8_t* const* bufs = nullptr;
+        const size_t* lens = nullptr;
+        uint8_t* const* outs = nullptr;
+        const size_t* caps = nullptr;
+        size_t* out_lens = nullptr;
+        zj_image_info* infos = nullptr;
+        int* statuses = nullptr;
+        size_t next = 0;     // next file to entropy-decode   (under mu)
+        size_t done = 0;     // files finished or failed       (under mu)
+        int first_error = 0;
+    };
+    struct Job { size_t index; zj_decoder* dec; };
+
+    std::vector<std::thread> threads;
+    std::vector<zj_decoder*> decoders;   // all plane sets
+    std::vector<zj_ctx*> ctxs;           // one per submitter
+    std::mutex mu;
+    std::condition_variable cv;          // one condition for every state change; waiters re-check
+    std::vector<zj_decoder*> free_dec;
+    std::deque<Job> ready;               // entropy-decoded, waiting for the GPU
+    Batch* batch = nullptr;
+    bool stop = false;
+    std::mutex call_mu;                  // serialises zj_pool_decode_files callers
+    std::string last_error;
+    int n_workers = 0;
+    // accumulated over the pool's life (under mu): seconds inside the entropy stage / the GPU stage, files
+    double entropy_s = 0, gpu_s = 0;
+    size_t files_done = 0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+    void finish(Batch& b, size_t i, int rc, const char* text, size_t olen, const zj_image_info* info)
+    {   // under mu
+        if (b.out_lens) b.out_lens[i] = olen;
+        if (b.infos && info) b.infos[i] = *info;
+        if (b.statuses) b.statuses[i] = rc;
+        if (rc && !b.first_error) { b.first_error = rc; last_error = "file " + std::to_string(i) + ": " + (text ? text : ""); }
+        b.done++;
+    }
+
+    void entropy_loop()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return stop || (batch && batch->next < batch->n && !free_dec.empty()); });
+            if (stop) return;
+            Batch& b = *batch;
+            const size_t i = b.next++;
+            zj_decoder* dec = free_dec.back();
+            free_dec.pop_back();
+            lk.unlock();
+            zj_image_info info;
+            memset(&info, 0, sizeof info);
+            zj_frame_desc fd;
+            const double t0 = now();
+            const int rc = zj_decoder_decode_coefficients(dec, b.bufs[i], b.lens[i], &fd, nullptr, nullptr, &info);
+            const double dt = now() - t0;
+            lk.lock();
+            entropy_s += dt;
+            if (rc) {
+                finish(b, i, rc, zj_decoder_error(dec), 0, &info);
+                free_dec.push_back(dec);
+            } else {
+                if (b.infos) b.infos[i] = info;
+                ready.push_back(Job{i, dec});
+            }
+            cv.notify_all();
+        }
+    }
+
+    void gpu_loop(zj_ctx* ctx)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return stop || !ready.empty(); });
+            if (stop) return;
+            const Job j = ready.front();
+            ready.pop_front();
+            Batch& b = *batch;
+            lk.unlock();
+            size_t olen = 0;
+            const double t0 = now();
+            const int rc = zj_decoder_finish_pixels(j.dec, ctx, b.outs[j.index], b.caps[j.index], &olen);
+            const double dt = now() - t0;
+            lk.lock();
+            gpu_s += dt;
+            files_done++;
+            finish(b, j.index, rc, rc ? zj_decoder_error(j.dec) : nullptr, olen, nullptr);
+            free_dec.push_back(j.dec);
+            cv.notify_all();
+        }
+    }
+};
+
+extern "C" {
+
+void zj_pool_destroy(zj_pool* p)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->stop = true;
+    }
+    p->cv.notify_all();
+    for (auto& th : p->threads) if (th.joinable()) th.join();
+    for (zj_decoder* d : p->decoders) zj_decoder_free(d);
+    for (zj_ctx* c : p->ctxs) zj_ctx_destroy(c);
+    delete p;
+}
+
+zj_pool* zj_pool_create(int device, int threads, const zj_options* opt, int* status)
+{
+    int dummy;
+    if (!status) status = &dummy;
+    if (threads <= 0 || threads > 1024) { *status = ZJ_ERR_ARG; return nullptr; }
+    zj_pool* p = new (std::nothrow) zj_pool();
+    if (!p) { *status = ZJ_ERR_NOMEM; return nullptr; }
+    zj_options o;
+    memset(&o, 0, sizeof o);
+    if (opt) o = *opt;
+    o.pinned_planes = getenv("ZJ_POOL_HEAP_PLANES") ? 0 : 1; // planes are DMA sources (the env knob is for A/B timing)
+    if (o.num_threads <= 0) o.num_threads = 1; // the pool is the parallelism; > 1 adds restart-segment threads per file
+    p->n_workers = threads;
+    *status = ZJ_OK;
+    for (int g = 0; g < GPU_SUBMITTERS && *status == ZJ_OK; g++) {
+        int st = ZJ_OK;
+        zj_ctx* c = zj_ctx_create(ZJ_BACKEND_HIP, device, &st);
+        if (!c) { *status = st ? st : ZJ_ERR_NOMEM; break; }
+        zj_set_pipeline(c, 0); // one unit per file: the overlap comes from the other submitters
+        p->ctxs.push_back(c);
+    }
+    // plane sets: one per entropy worker plus what the submitters hold plus one in the queue each
+    for (int k = 0; k < threads + 2 * GPU_SUBMITTERS && *status == ZJ_OK; k++) {
+        zj_decoder* d = zj_decoder_new(&o);
+        if (!d) { *status = ZJ_ERR_NOMEM; break; }
+        p->decoders.push_back(d);
+        p->free_dec.push_back(d);
+    }
+    if (*status != ZJ_OK) { zj_pool_destroy(p); return nullptr; }
+    for (int t = 0; t < threads; t++) p->threads.emplace_back([p] { p->entropy_loop(); });
+    for (zj_ctx* c : p->ctxs) p->threads.emplace_back([p, c] { p->gpu_loop(c); });
+    return p;
+}
+
+int zj_pool_threads(const zj_pool* p) { return p ? p->n_workers : 0; }
+
+const char* zj_pool_error(const zj_pool* p) { return p ? p->last_error.c_str() : ""; }
+
+int zj_pool_stats(zj_pool* p, double* entropy_seconds, double* gpu_seconds, size_t* files)
+{
+    if (!p) return ZJ_ERR_ARG;
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (entropy_seconds) *entropy_seconds = p->entropy_s;
+    if (gpu_seconds) *gpu_seconds = p->gpu_s;
+    if (files) *files = p->files_done;
+    return ZJ_OK;
+}
+
+int zj_pool_decode_files(zj_pool* p, size_t nfiles, const uint8_t* const* bufs, const size_t* lens,
+                         uint8_t* const* outs, const size_t* out_caps, size_t* out_lens, zj_image_info* infos,
+                         int* statuses)
+{
+    if (!p || (nfiles && (!bufs || !lens || !outs || !out_caps))) return ZJ_ERR_ARG;
+    if (nfiles == 0) return ZJ_OK;
+    for (size_t i = 0; i < nfiles; i++)
+        if (!bufs[i] || !outs[i]) return ZJ_ERR_ARG;
+    std::lock_guard<std::mutex> call(p->call_mu);
+    zj_pool::Batch b;
+    b.n = nfiles; b.bufs = bufs; b.lens = lens; b.outs = outs; b.caps = out_caps;
+    b.out_lens = out_lens; b.infos = infos; b.statuses = statuses;
+    std::unique_lock<std::mutex> lk(p->mu);
+    p->batch = &b;
+    p->cv.notify_all();
+    p->cv.wait(lk, [&] { return b.done == b.n; });
+    p->batch = nullptr;
+    return b.first_error;
+}
+
+} // extern "C"

@@ -75,7 +75,8 @@ class FrameDesc(C.Structure):  # zj_frame_desc
 
 class Options(C.Structure):  # zj_options
     _fields_ = [("out_colorspace", C.c_int32), ("strict_mode", C.c_int32), ("max_width", C.c_int32),
-                ("max_height", C.c_int32), ("max_scans", C.c_int32)]
+                ("max_height", C.c_int32), ("max_scans", C.c_int32), ("num_threads", C.c_int32),
+                ("pinned_planes", C.c_int32)]
 
 
 class ImageInfo(C.Structure):  # zj_image_info  <->  ImageInfo, src/decoder.rs:652-668
@@ -97,6 +98,16 @@ class ZuneJpegOptions:
         self.strict_mode = False
         self.backend = BACKEND_HIP
         self.device = 0
+        self.pinned_planes = False
+
+    def to_c(self):
+        o = Options()
+        o.out_colorspace = int(self.out_colorspace)
+        o.strict_mode = int(self.strict_mode)
+        o.max_width, o.max_height, o.max_scans = self.max_width, self.max_height, self.max_scans
+        o.num_threads = int(self.num_threads)
+        o.pinned_planes = int(bool(self.pinned_planes))
+        return o
 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -111,7 +122,10 @@ ABI = [  # every symbol include/zjhip.h declares
     "zj_time_decode_device", "zj_alloc_pinned", "zj_free_pinned", "zj_device_alloc",
     "zj_device_free", "zj_memcpy_h2d", "zj_memcpy_d2h", "zj_sync",
     "zj_decoder_new", "zj_decoder_free", "zj_decoder_error", "zj_decoder_read_headers",
-    "zj_decoder_decode_coefficients", "zj_decoder_decode_buffer",
+    "zj_decoder_decode_coefficients", "zj_decoder_finish_pixels", "zj_decoder_decode_buffer",
+    "zj_decoder_parallel_segments",
+    "zj_pool_create", "zj_pool_destroy", "zj_pool_threads", "zj_pool_error", "zj_pool_stats",
+    "zj_pool_decode_files",
 ]
 
 
@@ -181,6 +195,16 @@ def lib():
     L.zj_decoder_read_headers.argtypes = [vp, vp, sz, C.POINTER(ImageInfo)]
     L.zj_decoder_decode_coefficients.argtypes = [vp, vp, sz, C.POINTER(FrameDesc), C.POINTER(C.c_void_p), C.POINTER(sz), C.POINTER(ImageInfo)]
     L.zj_decoder_decode_buffer.argtypes = [vp, vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(ImageInfo)]
+    L.zj_decoder_parallel_segments.argtypes = [vp]
+    L.zj_pool_create.restype = vp
+    L.zj_pool_create.argtypes = [C.c_int, C.c_int, C.POINTER(Options), C.POINTER(C.c_int)]
+    L.zj_pool_destroy.argtypes = [vp]
+    L.zj_pool_threads.argtypes = [vp]
+    L.zj_pool_error.restype = C.c_char_p
+    L.zj_pool_error.argtypes = [vp]
+    L.zj_pool_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(sz)]
+    L.zj_pool_decode_files.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp]
+    L.zj_set_pipeline.argtypes = [vp, C.c_int]
     L.zj_set_variant.argtypes = [vp, C.c_int]
     L.zj_set_ablation.argtypes = [vp, C.c_int]
     L.zj_ubench_name.restype = C.c_char_p
@@ -343,6 +367,10 @@ class Context:
         All are bit-exact."""
         _check(lib().zj_set_variant(self._h, int(variant)), "zj_set_variant", self._h)
 
+    def set_pipeline(self, on):
+        """zj_decode_planes_batch: 1 (default) = units of ~8 MB overlapped over three streams, 0 = one unit."""
+        _check(lib().zj_set_pipeline(self._h, int(bool(on))), "zj_set_pipeline", self._h)
+
     def set_ablation(self, mask):
         """Diagnostics only: bit 0 skips the IDCT, bit 1 the colour math (output is wrong when set)."""
         _check(lib().zj_set_ablation(self._h, int(mask)), "zj_set_ablation", self._h)
@@ -400,11 +428,7 @@ class Decoder:
     """Mirror of zune_jpeg::Decoder (src/decoder.rs:60): CPU entropy decode + GPU pixel path."""
 
     def __init__(self, options=None, ctx=None):
-        o = Options()
-        if options is not None:
-            o.out_colorspace = int(options.out_colorspace)
-            o.strict_mode = int(options.strict_mode)
-            o.max_width, o.max_height, o.max_scans = options.max_width, options.max_height, options.max_scans
+        o = options.to_c() if options is not None else Options()
         self._d = lib().zj_decoder_new(C.byref(o))
         self._out_cs = int(o.out_colorspace)
         self._ctx = ctx
@@ -423,6 +447,10 @@ class Decoder:
 
     def _raise(self, rc):
         raise DecodeError(rc, lib().zj_decoder_error(self._d).decode(errors="replace"))
+
+    def parallel_segments(self):
+        """Restart segments the last baseline scan decoded concurrently (0 = serial walk)."""
+        return lib().zj_decoder_parallel_segments(self._d)
 
     def read_headers(self, buf):  # decoder.rs:452
         b = np.frombuffer(bytes(buf), np.uint8)
@@ -464,3 +492,70 @@ class Decoder:
             self._raise(rc)
         self._info = info
         return out[: n.value]
+
+
+class Pool:
+    """zj_pool: persistent host workers (entropy decoder + GPU context each) for batches of JPEG files."""
+
+    def __init__(self, threads=4, options=None, device=0):
+        o = options.to_c() if options is not None else Options()
+        st = C.c_int(0)
+        self._p = lib().zj_pool_create(int(device), int(threads), C.byref(o), C.byref(st))
+        if not self._p:
+            raise ZjError(st.value, "zj_pool_create")
+        self._out_cs = int(o.out_colorspace)
+
+    def close(self):
+        if getattr(self, "_p", None):
+            lib().zj_pool_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def threads(self):
+        return lib().zj_pool_threads(self._p)
+
+    def stats(self):
+        """(entropy-stage seconds, GPU-stage seconds, files) accumulated since creation."""
+        e, g, n = C.c_double(0), C.c_double(0), C.c_size_t(0)
+        lib().zj_pool_stats(self._p, C.byref(e), C.byref(g), C.byref(n))
+        return e.value, g.value, n.value
+
+    def decode_files(self, blobs, outs=None, raise_on_error=True):
+        """blobs: list of bytes-like JPEG files.  Returns (list of uint8 arrays, list of ImageInfo, statuses).
+        `outs` may supply preallocated uint8 arrays (e.g. views of pinned memory)."""
+        n = len(blobs)
+        arrs = [np.frombuffer(bytes(b), np.uint8) for b in blobs]
+        if outs is None:
+            dec = Decoder()
+            outs = []
+            for a in arrs:
+                try:
+                    info = dec.read_headers(a)
+                    nc = 1 if info.components == 1 else ColorSpace(self._out_cs).num_components()
+                    outs.append(np.zeros(int(info.width) * int(info.height) * nc, np.uint8))
+                except DecodeError:
+                    outs.append(np.zeros(16, np.uint8))
+            dec.close()
+        bufs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        lens = (C.c_size_t * n)(*[a.size for a in arrs])
+        optr = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        caps = (C.c_size_t * n)(*[o.size for o in outs])
+        olen = (C.c_size_t * n)()
+        infos = (ImageInfo * n)()
+        sts = (C.c_int * n)()
+        rc = lib().zj_pool_decode_files(self._p, n, bufs, lens, optr, caps, olen, infos, sts)
+        if rc and raise_on_error:
+            raise DecodeError(rc, lib().zj_pool_error(self._p).decode(errors="replace"))
+        return [o[: olen[i]] for i, o in enumerate(outs)], list(infos), list(sts)

@@ -80,3 +80,17 @@ def gather_checksums(local, world, device="cpu"):
     outs = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(outs, t)
     return [[int(v) & ((1 << 64) - 1) for v in o.cpu().tolist()] for o in outs]
+
+
+def effective_cpus():
+    """Host threads this process may actually run at once: min(affinity mask, cgroup v2 cpu.max quota).
+    The GPU boxes expose 256 logical CPUs but cap the container at 16 (cpu.max = 1600000 100000)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
