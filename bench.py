@@ -160,6 +160,18 @@ def main():
         algo_bytes = B * W * H * bytes_per_px
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         tr = load_traffic()
+        if tr and not (tr.get("workload", "420-rgb") == args.workload and tr.get("frames_per_launch", 16) == B):
+            tr = None  # the committed counters describe another launch shape
+        # Second bound, reported beside the HBM one: integer VALU issue.  A wave64 integer instruction occupies
+        # its SIMD for 4 cycles (16 lanes per SIMD per clock; profiles/r01_ubench_valu_issue_cost.txt), so the
+        # chip retires at most 1024 SIMDs x 2.4 GHz / 4 wave-instructions per second.
+        valu = None
+        if tr and tr.get("sq_insts_valu_per_launch"):
+            peak_wi = 1024 * 2.4e9 / 4.0
+            ach_wi = tr["sq_insts_valu_per_launch"] / (kernel_ms * 1e-3)
+            valu = {"wave_insts_per_launch": tr["sq_insts_valu_per_launch"], "achieved": round(ach_wi / 1e9, 1),
+                    "peak": round(peak_wi / 1e9, 1), "unit": "G wave64-instructions/s", "frac": round(ach_wi / peak_wi, 4),
+                    "source": tr.get("sq_source")}
         res = {
             "metric": "megapixels/sec decoded (IDCT->RGB), 4K 4:2:0 baseline" if args.workload == "420-rgb" else f"megapixels/sec decoded, 4K {args.workload}",
             "value": round(mp_total / elapsed, 1),
@@ -179,7 +191,7 @@ def main():
                          "traffic": (tr or {}).get("hbm_bytes_per_launch"),
                          "kernel": kname, "kernel_ms": round(kernel_ms, 4), "kernel_ms_single_launch": round(kernel_ms_each, 4),
                          "algorithmic_bytes_per_launch": int(algo_bytes),
-                         "traffic_source": (tr or {}).get("source")},
+                         "traffic_source": (tr or {}).get("source"), "valu_issue": valu},
             # every rank's first frame is synthetic frame (rank*B) % distinct: identical data when B % distinct == 0
             "checksums_equal_across_ranks": (len({tuple(s) for s in sums}) == 1) if (world > 1 and B % max(args.distinct, 1) == 0) else None,
         }
