@@ -88,8 +88,9 @@ def main():
     ap.add_argument("--frames", type=int, default=16, help="4096x4096 frames per GPU per step")
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic frames generated (tiled to --frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["420-rgb", "444-rgb", "444-gray"], default="420-rgb",
-                    help="420-rgb = BASELINE.json configs[1] (the headline); the others are configs[2]")
+    ap.add_argument("--workload", choices=["420-rgb", "444-rgb", "444-gray", "420-rgba", "420-chw"], default="420-rgb",
+                    help="420-rgb = BASELINE.json configs[1] (the headline); 444-* are configs[2]; 420-rgba / 420-chw are "
+                         "the output extensions (4 B/px interleaved, planar u8)")
     ap.add_argument("--variant", choices=["onepass", "compact", "persistent"], default=None, help="kernel variant (default: library default)")
     args = ap.parse_args()
 
@@ -117,11 +118,12 @@ def main():
     # synthetic data, SURVEY.md 8d generator; every rank decodes its own shard of the global batch
     lo, _ = shard.shard_range(B * world, rank, world)
     hs, vs, out_cs, bytes_per_px = {"420-rgb": (2, 2, zj.ColorSpace.RGB, 6.0), "444-rgb": (1, 1, zj.ColorSpace.RGB, 9.0),
-                                    "444-gray": (1, 1, zj.ColorSpace.GRAYSCALE, 3.0)}[args.workload]
+                                    "444-gray": (1, 1, zj.ColorSpace.GRAYSCALE, 3.0),
+                                    "420-rgba": (2, 2, zj.ColorSpace.RGBA, 7.0), "420-chw": (2, 2, zj.ColorSpace.RGB, 6.0)}[args.workload]
     frames = [synth.make_frame(W, H, hs, vs, 3, seed=1234, frame_index=(lo + i) % max(args.distinct, 1))
               for i in range(min(args.distinct, B))]
     qts = frames[0][1]
-    desc = zj.FrameDesc.make(W, H, hs, vs, 3, out_cs, qts)
+    desc = zj.FrameDesc.make(W, H, hs, vs, 3, out_cs, qts, out_layout=zj.LAYOUT_CHW if args.workload == "420-chw" else zj.LAYOUT_HWC)
     host = [np.concatenate([frames[i % len(frames)][0][c] for i in range(B)]) for c in range(3)]
     d_planes = [torch.from_numpy(h).to(dev) for h in host]
     d_out = torch.empty(B * W * H * out_cs.num_components(), dtype=torch.uint8, device=dev)
@@ -183,7 +185,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": {"420-rgb": "configs[1]: 4096x4096 baseline 4:2:0, dequant+IDCT+h2v2+YCbCr->RGB, planes resident in HBM",
                                     "444-rgb": "configs[2]: 4096x4096 baseline 4:4:4, dequant+IDCT+YCbCr->RGB, planes resident in HBM",
-                                    "444-gray": "configs[2]: 4096x4096 4:4:4 -> GRAYSCALE (luma only), planes resident in HBM"}[args.workload],
+                                    "444-gray": "configs[2]: 4096x4096 4:4:4 -> GRAYSCALE (luma only), planes resident in HBM",
+                                    "420-rgba": "extension: 4096x4096 4:2:0 -> RGBA (R G B 255), planes resident in HBM",
+                                    "420-chw": "extension: 4096x4096 4:2:0 -> planar u8 RGB (C x H x W), planes resident in HBM"}[args.workload],
                        "frames_per_gpu_per_step": B, "sharding": f"image-level x{world}, no data-path collective",
                        "distinct_frames": len(frames)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

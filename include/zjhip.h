@@ -91,10 +91,25 @@ typedef struct zj_frame_desc {
     uint32_t width, height;  /* pixels */
     uint32_t h_max, v_max;   /* luma sampling factors: (1,1) (2,1) (1,2) (2,2); chroma is (1,1) */
     uint32_t in_components;  /* 1 (grayscale JPEG) or 3 (YCbCr) */
-    int32_t out_colorspace;  /* ZJ_CS_RGB, ZJ_CS_GRAYSCALE or ZJ_CS_YCBCR */
+    int32_t out_colorspace;  /* ZJ_CS_RGB, ZJ_CS_GRAYSCALE or ZJ_CS_YCBCR; extension: ZJ_CS_RGBA / ZJ_CS_RGBX */
     int32_t qt[3][64];       /* per component, natural order, values 0..255 (8-bit DQT only,
                                 src/headers.rs:154-174) */
+    uint32_t flags;          /* 0 = the reference's bytes exactly; ZJ_FLAG_* below */
+    uint32_t out_layout;     /* ZJ_LAYOUT_HWC (0, the reference's interleaved bytes) or ZJ_LAYOUT_CHW */
 } zj_frame_desc;
+
+/* Extensions beyond the reference.  They share the reference's strips, filters and per-pixel
+ * arithmetic (so Q1-Q4 and Q7 still hold) and differ only in where bytes go; the checker is the oracle's
+ * zjo_decode_planes_plain, since no reference output exists for them:
+ *   ZJ_FLAG_PLAIN_TAIL  (RGB) every pixel x < width of a converted row is written at 3x: the last 16 samples are
+ *                       not written 16 bytes early (Q5) and no byte of the row stays 0 (Q6);
+ *   ZJ_CS_RGBA / RGBX   4 bytes per pixel, R G B 255 (the reference's own RGBA arm is malformed),
+ *                       plain placement;
+ *   ZJ_LAYOUT_CHW       (RGB) three u8 planes of width*height bytes per frame, the tensor layout ML consumers
+ *                       want, plain placement.  GRAYSCALE is accepted (one plane: identical to HWC). */
+#define ZJ_FLAG_PLAIN_TAIL 1u
+#define ZJ_LAYOUT_HWC 0u
+#define ZJ_LAYOUT_CHW 1u
 
 typedef struct zj_ctx zj_ctx;
 

@@ -261,9 +261,11 @@ def ycbcr_to_ycbcr(ch, width, h_samp, v_samp, out):
 # ---------------------------------------------------------------------------------------------
 # Worker glue  (src/worker.rs)
 # ---------------------------------------------------------------------------------------------
-def color_convert_ycbcr(blk, width, h_samp, v_samp, out_cs, output):
+def color_convert_ycbcr(blk, width, h_samp, v_samp, out_cs, output, plain=False):
     """worker.rs:143-251.  Row-vectorised: the main groups and the early-written tail are applied
-    in the reference's order (main first, tail overwrites)."""
+    in the reference's order (main first, tail overwrites).
+    plain=True is an EXTENSION (no reference output exists for it): every pixel x < width at its own
+    position, 4-byte pixels get 255 as 4th byte."""
     n = blk[0].size
     ncomp = num_components(out_cs)
     width_chunk = (n // (h_samp * v_samp)) >> 3
@@ -275,6 +277,13 @@ def color_convert_ycbcr(blk, width, h_samp, v_samp, out_cs, output):
         raise Panic("output[start..end]")
     Y, CB, CR = (np.asarray(b, np.int16)[: rows * width_chunk].reshape(rows, width_chunk) for b in blk)
     outv = output[: rows * stride].reshape(rows, stride)
+    if plain:
+        m = min(width, width_chunk)
+        px = outv.reshape(rows, width, ncomp)
+        px[:, :m, :3] = ycbcr_to_rgb_px(Y[:, :m], CB[:, :m], CR[:, :m]).reshape(rows, m, 3)
+        if ncomp == 4:
+            px[:, :m, 3] = 255
+        return
     if width < 16:
         if width_chunk > 16:
             raise Panic("copy_from_slice")
@@ -298,7 +307,7 @@ def color_convert_ycbcr(blk, width, h_samp, v_samp, out_cs, output):
     outv[:, position : position + 48] = ycbcr_to_rgb_px(Y[:, t0:], CB[:, t0:], CR[:, t0:]).reshape(rows, 48)
 
 
-def post_process(coeff, comps, in_cs, out_cs, output, width):
+def post_process(coeff, comps, in_cs, out_cs, output, width, plain=False):
     """worker.rs:32-141.  comps: list of dicts {h, v, width_stride, qt}."""
     h_samp, v_samp = comps[0]["h"], comps[0]["v"]
     x = min(num_components(in_cs), num_components(out_cs), 3)
@@ -317,7 +326,7 @@ def post_process(coeff, comps, in_cs, out_cs, output, width):
     elif in_cs == YCBCR and out_cs == YCBCR:
         ycbcr_to_ycbcr(unp, width, h_samp, v_samp, output)
     elif in_cs == YCBCR and out_cs in (RGB, RGBA, RGBX):
-        color_convert_ycbcr(unp, width, h_samp, v_samp, out_cs, output)
+        color_convert_ycbcr(unp, width, h_samp, v_samp, out_cs, output, plain)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -335,7 +344,7 @@ def plane_len(width, height, h_max, v_max, comp):
     return mcu_x * 64 * vs * hs * mcu_y
 
 
-def decode_planes(width, height, h_max, v_max, in_components, out_cs, qts, planes):
+def decode_planes(width, height, h_max, v_max, in_components, out_cs, qts, planes, plain=False):
     mcu_x, mcu_y = geometry(width, height, h_max, v_max)
     ncomp = num_components(out_cs)
     in_cs = YCBCR if in_components == 3 else GRAYSCALE
@@ -363,5 +372,5 @@ def decode_planes(width, height, h_max, v_max, in_components, out_cs, qts, plane
             coeff += [planes[1][s * c_chunk : (s + 1) * c_chunk], planes[2][s * c_chunk : (s + 1) * c_chunk]]
         else:
             coeff += [np.zeros(0, np.int16)] * 2
-        post_process(coeff, comps, in_cs, out_cs, out_vector[s * chunks_size : (s + 1) * chunks_size], width)
+        post_process(coeff, comps, in_cs, out_cs, out_vector[s * chunks_size : (s + 1) * chunks_size], width, plain)
     return out_vector[: width * height * ncomp].copy()

@@ -335,7 +335,7 @@ int zjo_ycbcr_to_ycbcr(const int16_t *const ch[3], size_t n, size_t width, size_
 /* worker.rs:143-251 color_convert_ycbcr.  color_convert_16 is always the RGB routine, even when
  * the output colour space is RGBA/RGBX (decoder.rs:127-128). */
 static int color_convert_ycbcr(const int16_t *const blk[3], size_t n, size_t width, size_t h_samp,
-                               size_t v_samp, int out_cs, uint8_t *output, size_t out_len)
+                               size_t v_samp, int out_cs, uint8_t *output, size_t out_len, int plain)
 {
     size_t ncomp = zjo_num_components(out_cs);
     size_t mcu_chunks = n / (h_samp * v_samp); /* :148 */
@@ -343,6 +343,20 @@ static int color_convert_ycbcr(const int16_t *const blk[3], size_t n, size_t wid
     size_t stride = width * ncomp;             /* :151 */
     size_t start = 0, end = stride;
     if (width_chunk == 0) return ZJO_ERR_PANIC;
+    if (plain) {
+        /* EXTENSION, not reference behaviour (SURVEY 8f-3 "RGBA/RGBX done properly"): the same rows and the
+         * same per-pixel arithmetic (scalar.rs:68-76), but every pixel x < width of a row is written at its
+         * own position -- no early tail (Q5), no untouched bytes (Q6), 4-byte pixels get 255 as 4th byte. */
+        for (size_t c0 = 0; c0 + width_chunk <= n; c0 += width_chunk, start += stride) {
+            if (start + stride > out_len) return ZJO_ERR_PANIC;
+            for (size_t xx = 0; xx < width && xx < width_chunk; xx++) {
+                uint8_t *px = output + start + xx * ncomp;
+                ycc_px(blk[0][c0 + xx], blk[1][c0 + xx], blk[2][c0 + xx], px, px + 1, px + 2);
+                if (ncomp == 4) px[3] = 255;
+            }
+        }
+        return ZJO_OK;
+    }
     uint8_t temp[16 * 4];
     memset(temp, 0, sizeof temp);
 
@@ -390,9 +404,20 @@ static int color_convert_ycbcr(const int16_t *const blk[3], size_t n, size_t wid
 }
 
 /* worker.rs:32-86 post_process + :88-141 post_process_inner */
+static int post_process_impl(const int16_t *const coeff[3], const size_t len[3],
+                             const zjo_component comps[3], int in_cs, int out_cs, uint8_t *out,
+                             size_t out_len, size_t width, int plain);
+
 int zjo_post_process(const int16_t *const coeff[3], const size_t len[3],
                      const zjo_component comps[3], int in_cs, int out_cs, uint8_t *out,
                      size_t out_len, size_t width)
+{
+    return post_process_impl(coeff, len, comps, in_cs, out_cs, out, out_len, width, 0);
+}
+
+static int post_process_impl(const int16_t *const coeff[3], const size_t len[3],
+                             const zjo_component comps[3], int in_cs, int out_cs, uint8_t *out,
+                             size_t out_len, size_t width, int plain)
 {
     size_t h_samp = comps[0].horizontal_sample, v_samp = comps[0].vertical_sample; /* :43-45 */
     size_t nin = zjo_num_components(in_cs), nout = zjo_num_components(out_cs);
@@ -436,7 +461,7 @@ int zjo_post_process(const int16_t *const coeff[3], const size_t len[3],
         } else if (in_cs == ZJO_CS_YCBCR &&
                    (out_cs == ZJO_CS_RGB || out_cs == ZJO_CS_RGBA || out_cs == ZJO_CS_RGBX)) {
             const int16_t *ch[3] = {unp[0], unp[1], unp[2]};
-            rc = color_convert_ycbcr(ch, ulen[0], width, h_samp, v_samp, out_cs, out, out_len);
+            rc = color_convert_ycbcr(ch, ulen[0], width, h_samp, v_samp, out_cs, out, out_len, plain);
         } /* else: nothing, :131-132 */
     }
     for (int i = 0; i < 3; i++) free(unp[i]);
@@ -474,8 +499,24 @@ size_t zjo_out_len(const zjo_frame *f)
     return (size_t)f->width * f->height * zjo_num_components(f->out_colorspace);
 }
 
+static int decode_planes_impl(const zjo_frame *f, const int16_t *y, const int16_t *cb, const int16_t *cr,
+                              uint8_t *out, int plain);
+
 int zjo_decode_planes(const zjo_frame *f, const int16_t *y, const int16_t *cb, const int16_t *cr,
                       uint8_t *out)
+{
+    return decode_planes_impl(f, y, cb, cr, out, 0);
+}
+
+/* EXTENSION (see color_convert_ycbcr): RGB / RGBA / RGBX with every pixel at its own position */
+int zjo_decode_planes_plain(const zjo_frame *f, const int16_t *y, const int16_t *cb, const int16_t *cr,
+                            uint8_t *out)
+{
+    return decode_planes_impl(f, y, cb, cr, out, 1);
+}
+
+static int decode_planes_impl(const zjo_frame *f, const int16_t *y, const int16_t *cb, const int16_t *cr,
+                              uint8_t *out, int plain)
 {
     size_t mcu_x, mcu_y;
     int rc = frame_geom(f, &mcu_x, &mcu_y);
@@ -525,8 +566,8 @@ int zjo_decode_planes(const zjo_frame *f, const int16_t *y, const int16_t *cb, c
             coeff[2] = cr + s * c_chunk;
             len[1] = len[2] = c_chunk;
         }                             /* else one component, :222-235: post_process(&[y, &[], &[]]) */
-        rc = zjo_post_process(coeff, len, comps, in_cs, out_cs, out_vector + s * chunks_size,
-                              chunks_size, width);
+        rc = post_process_impl(coeff, len, comps, in_cs, out_cs, out_vector + s * chunks_size,
+                               chunks_size, width, plain);
     }
     if (rc == ZJO_OK) memcpy(out, out_vector, width * height * ncomp); /* truncate, :238-242 */
     free(out_vector);

@@ -94,6 +94,12 @@ size_t zjo_plane_len(const zjo_frame *f, int comp);
 size_t zjo_out_len(const zjo_frame *f);
 int zjo_decode_planes(const zjo_frame *f, const int16_t *y, const int16_t *cb, const int16_t *cr,
                       uint8_t *out);
+/* EXTENSION beyond the reference: same strips, same per-pixel arithmetic, but every pixel
+ * x < width of every converted row is written at its own position (no early RGB tail Q5, no untouched
+ * bytes Q6); out_colorspace RGB (3 B/px) or RGBA / RGBX (4 B/px, 4th byte 255).  Checker for
+ * ZJ_FLAG_PLAIN_TAIL / ZJ_CS_RGBA / ZJ_LAYOUT_CHW of include/zjhip.h; no reference output exists for it. */
+int zjo_decode_planes_plain(const zjo_frame *f, const int16_t *y, const int16_t *cb, const int16_t *cr,
+                            uint8_t *out);
 
 #ifdef __cplusplus
 }

@@ -80,15 +80,19 @@ extern "C" int zje_decode_planes(const zj_frame_desc* d, size_t nframes, const i
     if (rc) return rc;
     Params p;
     fill_params(d, pl, nframes, y, cb, cr, out, &d->qt[0][0], zero_fill, p);
-    if (zero_fill && pl.rows_covered < (int)d->height) // same remainder memset as zj_api.cpp
+    if (zero_fill) { // same remainder memset as zj_api.cpp
+        size_t off[3], len[3];
+        const int nr = uncovered_ranges(d, pl, off, len);
         for (size_t f = 0; f < nframes; f++)
-            memset(out + f * pl.out_len + (size_t)pl.rows_covered * d->width * pl.ncomp_out, 0,
-                   (size_t)(d->height - pl.rows_covered) * d->width * pl.ncomp_out);
+            for (int r = 0; r < nr; r++) memset(out + f * pl.out_len + off[r], 0, len[r]);
+    }
 #define ZJ_CASE(H, V, O) if (pl.hs == H && pl.vs == V && pl.out == O) { if (pl.fast) run<H, V, O, true>(p); else run<H, V, O, false>(p); return ZJ_OK; }
     ZJ_CASE(1, 1, OUT_RGB) ZJ_CASE(1, 1, OUT_GRAY) ZJ_CASE(1, 1, OUT_YCBCR)
     ZJ_CASE(2, 1, OUT_RGB) ZJ_CASE(2, 1, OUT_GRAY) ZJ_CASE(2, 1, OUT_YCBCR)
     ZJ_CASE(1, 2, OUT_RGB) ZJ_CASE(1, 2, OUT_GRAY) ZJ_CASE(1, 2, OUT_YCBCR)
     ZJ_CASE(2, 2, OUT_RGB) ZJ_CASE(2, 2, OUT_GRAY) ZJ_CASE(2, 2, OUT_YCBCR)
+    ZJ_CASE(1, 1, OUT_RGBA) ZJ_CASE(2, 1, OUT_RGBA) ZJ_CASE(1, 2, OUT_RGBA) ZJ_CASE(2, 2, OUT_RGBA)
+    ZJ_CASE(1, 1, OUT_RGB_CHW) ZJ_CASE(2, 1, OUT_RGB_CHW) ZJ_CASE(1, 2, OUT_RGB_CHW) ZJ_CASE(2, 2, OUT_RGB_CHW)
 #undef ZJ_CASE
     return ZJ_ERR_UNSUPPORTED;
 }

@@ -1,6 +1,8 @@
 """CPU: the HIP workgroup phases (zune-jpeg_amd/csrc/zj_device.h), emulated thread by thread, against
 the oracle.  Checks tile / halo / wrap-around / tail indexing and the 24-bit-multiplier exactness
 claim (the emulated v_mul_i32_i24 truncates operands to 24 bits like the hardware)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -90,3 +92,53 @@ def test_emulated_kernel_ragged_widths(mode, out_cs, wh, synth):
         assert rce == 0
         bad = np.nonzero(out != exp)[0]
         assert bad.size == 0, (mode, out_cs, wh, adversarial, bad[:8])
+
+
+def _plain_expected(w, h, hs, vs, qts, planes, kind):
+    """Expected bytes of the extensions from the oracle's plain-placement restatement (zjo_decode_planes_plain)."""
+    if kind == "rgba":
+        rc, exp = oc.decode_planes(oc.make_frame(w, h, hs, vs, 3, oc.RGBA, qts), planes, plain=True)
+        return rc, exp
+    rc, rgb = oc.decode_planes(oc.make_frame(w, h, hs, vs, 3, oc.RGB, qts), planes, plain=True)
+    if kind == "chw":
+        rgb = np.ascontiguousarray(rgb.reshape(h, w, 3).transpose(2, 0, 1)).reshape(-1)
+    return rc, rgb
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("kind", ["plain", "rgba", "chw"])
+@pytest.mark.parametrize("wh", [(64, 64), (528, 40), (32, 8), (1040, 33), (100, 32), (37, 50), (17, 16), (5, 3), (250, 72)])
+def test_emulated_extensions_match_plain_oracle(mode, kind, wh, synth):
+    """ZJ_FLAG_PLAIN_TAIL, ZJ_CS_RGBA and ZJ_LAYOUT_CHW (include/zjhip.h): same strips and arithmetic as the reference,
+    every pixel at its own position; odd MCU rows (72 = 4.5 MCU rows in H/HV) still stay zero."""
+    emu_c.set_variant(0)
+    hs, vs = MODES[mode]
+    w, h = wh
+    for adversarial in (False, True):
+        mk = synth.make_adversarial_frame if adversarial else synth.make_frame
+        planes, qts = mk(w, h, hs, vs, 3, seed=77)
+        rc, exp = _plain_expected(w, h, hs, vs, qts, planes, kind)
+        assert rc == 0
+        f = oc.make_frame(w, h, hs, vs, 3, oc.RGBA if kind == "rgba" else oc.RGB, qts)
+        rc, out = emu_c.decode_planes(f, planes, flags=1 if kind == "plain" else 0, out_layout=1 if kind == "chw" else 0)
+        assert rc == 0
+        bad = np.nonzero(out != exp)[0]
+        assert bad.size == 0, (mode, kind, wh, adversarial, bad[:8])
+
+
+def test_plain_oracle_cross_check_numpy(synth):
+    """the two restatements agree on the extension too, and plain differs from the reference bytes only in the tail"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_np as onp
+    for (w, h, hs, vs) in [(64, 48, 2, 2), (100, 37, 2, 1), (17, 9, 1, 1), (250, 40, 1, 2), (8, 8, 2, 2)]:
+        planes, qts = synth.make_frame(w, h, hs, vs, 3, seed=5)
+        for cs in (oc.RGB, oc.RGBA):
+            rc, a = oc.decode_planes(oc.make_frame(w, h, hs, vs, 3, cs, qts), planes, plain=True)
+            assert rc == 0
+            assert np.array_equal(a, onp.decode_planes(w, h, hs, vs, 3, cs, qts, planes, plain=True))
+    planes, qts = synth.make_frame(64, 48, 2, 2, 3, seed=5)
+    f = oc.make_frame(64, 48, 2, 2, 3, oc.RGB, qts)
+    q = oc.decode_planes(f, planes)[1].reshape(48, 192)
+    p = oc.decode_planes(f, planes, plain=True)[1].reshape(48, 192)
+    assert np.array_equal(q[:, :128], p[:, :128]) and np.array_equal(q[:, 128:176], p[:, 144:]) and not q[:, 176:].any()

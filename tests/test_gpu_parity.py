@@ -327,8 +327,12 @@ def test_unsupported_and_invalid_arguments(ctx, zj, synth):
     with pytest.raises(zj.ZjError) as e:  # sampling factor 4 is not a mode the reference knows
         ctx.decode_planes(zj.FrameDesc.make(64, 64, 4, 1, 3, 0, qts), planes)
     assert e.value.status == -1
-    with pytest.raises(zj.ZjError):       # RGBA output is malformed in the reference
-        ctx.decode_planes(zj.FrameDesc.make(64, 64, 2, 2, 3, int(zj.ColorSpace.RGBA), qts), planes)
+    with pytest.raises(zj.ZjError):       # CMYK output is a no-op in the reference
+        ctx.decode_planes(zj.FrameDesc.make(64, 64, 2, 2, 3, int(zj.ColorSpace.CMYK), qts), planes)
+    with pytest.raises(zj.ZjError):       # unknown flag bits / layouts are argument errors
+        ctx.decode_planes(zj.FrameDesc.make(64, 64, 2, 2, 3, 0, qts, flags=6), planes)
+    with pytest.raises(zj.ZjError):
+        ctx.decode_planes(zj.FrameDesc.make(64, 64, 2, 2, 3, 0, qts, out_layout=7), planes)
 
 
 # ---- BASELINE.json full size: 4096x4096, properties that do not need the (slow) oracle everywhere ----
@@ -443,3 +447,67 @@ def test_pool_decodes_a_mixed_batch(zj, synth, threads):
                 assert_same(outs[i], exp, f"file {i}")
         with pytest.raises(zj.DecodeError):
             pool.decode_files([bad])
+
+
+def _plain_expected(w, h, hs, vs, qts, planes, kind):
+    if kind == "rgba":
+        return oc.decode_planes(oc.make_frame(w, h, hs, vs, 3, oc.RGBA, qts), planes, plain=True)
+    rc, rgb = oc.decode_planes(oc.make_frame(w, h, hs, vs, 3, oc.RGB, qts), planes, plain=True)
+    if kind == "chw":
+        rgb = np.ascontiguousarray(rgb.reshape(h, w, 3).transpose(2, 0, 1)).reshape(-1)
+    return rc, rgb
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("kind", ["plain", "rgba", "chw"])
+@pytest.mark.parametrize("wh", [(64, 64), (528, 40), (1040, 33), (100, 32), (37, 50), (5, 3), (250, 72), (1920, 1080)])
+def test_extensions_plain_rgba_chw(ctx, zj, synth, mode, kind, wh):
+    """Beyond the reference: ZJ_FLAG_PLAIN_TAIL, ZJ_CS_RGBA, ZJ_LAYOUT_CHW against the oracle's
+    plain-placement restatement; same strips / filters / arithmetic, every pixel at its own position."""
+    hs, vs = MODES[mode]
+    w, h = wh
+    for adversarial in (False, True):
+        if adversarial and w * h > 600_000:
+            continue
+        mk = synth.make_adversarial_frame if adversarial else synth.make_frame
+        planes, qts = mk(w, h, hs, vs, 3, seed=77)
+        rc, exp = _plain_expected(w, h, hs, vs, qts, planes, kind)
+        assert rc == 0
+        d = zj.FrameDesc.make(w, h, hs, vs, 3, zj.ColorSpace.RGBA if kind == "rgba" else zj.ColorSpace.RGB, qts,
+                              flags=zj.FLAG_PLAIN_TAIL if kind == "plain" else 0,
+                              out_layout=zj.LAYOUT_CHW if kind == "chw" else zj.LAYOUT_HWC)
+        assert_same(ctx.decode_planes(d, planes), exp, (mode, kind, wh, adversarial))
+
+
+@pytest.mark.parametrize("kind", ["rgba", "chw", "plain"])
+def test_extensions_batches_through_the_host_pipeline(ctx, zj, synth, kind):
+    """frame groups, an odd MCU row (rows that stay 0 in every plane), and a frame large enough to be split"""
+    for (w, h, n) in [(256, 72, 7), (4096, 2200, 2)]:
+        frames = [synth.make_frame(w, h, 2, 2, 3, seed=410, frame_index=i % 2) for i in range(n)]
+        qts = frames[0][1]
+        planes = [np.concatenate([f[0][c] for f in frames]) for c in range(3)]
+        d = zj.FrameDesc.make(w, h, 2, 2, 3, zj.ColorSpace.RGBA if kind == "rgba" else zj.ColorSpace.RGB, qts,
+                              flags=zj.FLAG_PLAIN_TAIL if kind == "plain" else 0,
+                              out_layout=zj.LAYOUT_CHW if kind == "chw" else zj.LAYOUT_HWC)
+        out = ctx.decode_planes(d, planes, nframes=n)
+        olen = out.size // n
+        for i in range(min(n, 3)):
+            rc, exp = _plain_expected(w, h, 2, 2, qts, frames[i][0], kind)
+            assert rc == 0
+            assert_same(out[i * olen:(i + 1) * olen], exp, (kind, w, h, i))
+
+
+def test_decoder_rgba_option(ctx, zj, synth):
+    """Decoder with out_colorspace RGBA: the reference's own RGBA arm is malformed; here R G B 255 per pixel"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import jpeg_enc
+    w, h = 208, 96
+    planes = jpeg_enc.small_planes(w, h, 2, 2, 3, seed=12)
+    qts = synth.quant_tables(90)
+    o = zj.ZuneJpegOptions()
+    o.out_colorspace = zj.ColorSpace.RGBA
+    out = zj.Decoder(o, ctx).decode_buffer(jpeg_enc.encode_baseline(planes, qts, w, h, 2, 2, 3))
+    rc, exp = oc.decode_planes(oc.make_frame(w, h, 2, 2, 3, oc.RGBA, qts), planes, plain=True)
+    assert rc == 0
+    assert_same(out, exp, "decoder rgba")

@@ -275,11 +275,12 @@ static int decode_device_impl(zj_ctx* c, const zj_frame_desc* d, const Plan& pl,
     Params p;
     fill_params(d, pl, nframes, d_y, d_cb, d_cr, d_out, d_qt, zero_fill, p);
     p.debug = c->debug;
-    if (zero_fill && pl.rows_covered < (int)d->height) {
+    if (zero_fill) {
         // rows below the last complete strip are never written by the reference (Q6): zeros
-        const size_t off = (size_t)pl.rows_covered * d->width * pl.ncomp_out;
+        size_t off[3], len[3];
+        const int nr = uncovered_ranges(d, pl, off, len);
         for (size_t f = 0; f < nframes; f++)
-            ZJ_HIP(c, hipMemsetAsync(d_out + f * pl.out_len + off, 0, pl.out_len - off, s));
+            for (int r = 0; r < nr; r++) ZJ_HIP(c, hipMemsetAsync(d_out + f * pl.out_len + off[r], 0, len[r], s));
     }
     ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->compact, pl.fast ? 1 : 0, p, s));
     return ZJ_OK;
@@ -368,16 +369,21 @@ int zj_decode_planes_batch(zj_ctx* c, const zj_frame_desc* d, size_t nframes, co
     const size_t covered = (size_t)pl.rows_covered < d->height ? (size_t)pl.rows_covered : d->height;
     const size_t covered_bytes = covered * d->width * pl.ncomp_out;
     // rows below the last complete strip are never written by the reference (Q6)
-    if (covered_bytes < pl.out_len)
-        for (size_t f = 0; f < nframes; f++) memset(out + f * pl.out_len + covered_bytes, 0, pl.out_len - covered_bytes);
+    {
+        size_t off[3], len[3];
+        const int nr = uncovered_ranges(d, pl, off, len);
+        for (size_t f = 0; f < nframes; f++)
+            for (int r = 0; r < nr; r++) memset(out + f * pl.out_len + off[r], 0, len[r]);
+    }
     if (pl.n_strips == 0) return ZJ_OK;
 
     size_t UNIT_TARGET = UNIT_TARGET_DEFAULT;
     if (const char* e = getenv("ZJ_UNIT_MB")) { const long v = atol(e); if (v > 0 && v < 4096) UNIT_TARGET = (size_t)v << 20; }
     const size_t in_frame = (pl.y_len + (chroma ? 2 * pl.c_len : 0)) * 2;
     size_t split = 1, group = 1; // strip ranges per frame | frames per unit
+    const bool planar = pl.out == OUT_RGB_CHW; // a strip range is not contiguous in a planar frame: whole frames only
     if (c->pipeline) {
-        if (in_frame >= 2 * UNIT_TARGET) {
+        if (in_frame >= 2 * UNIT_TARGET && !planar) {
             split = (in_frame + UNIT_TARGET - 1) / UNIT_TARGET;
             if (split > (size_t)pl.n_strips) split = (size_t)pl.n_strips;
         } else {
@@ -433,7 +439,14 @@ int zj_decode_planes_batch(zj_ctx* c, const zj_frame_desc* d, size_t nframes, co
             ZJ_HIP(c, hipEventRecord(sl.run_done, c->s_run));
             // down
             ZJ_HIP(c, hipStreamWaitEvent(c->s_down, sl.run_done, 0));
-            if (whole && covered_bytes < pl.out_len) { // skip the never-written rows of every frame
+            if (planar) { // the covered rows of every plane of every frame
+                for (size_t f = 0; f < nfr; f++)
+                    for (size_t pc = 0; pc < 3; pc++) {
+                        const size_t po = f * pl.out_len + pc * (size_t)d->width * d->height;
+                        ZJ_HIP(c, hipMemcpyAsync(out + f0 * pl.out_len + po, (uint8_t*)sl.buf[3] + po, covered * d->width,
+                                                 hipMemcpyDeviceToHost, c->s_down));
+                    }
+            } else if (whole && covered_bytes < pl.out_len) { // skip the never-written rows of every frame
                 for (size_t f = 0; f < nfr; f++)
                     ZJ_HIP(c, hipMemcpyAsync(out + (f0 + f) * pl.out_len, (uint8_t*)sl.buf[3] + f * pl.out_len, covered_bytes,
                                              hipMemcpyDeviceToHost, c->s_down));

@@ -275,7 +275,9 @@ template <> struct TileWidth<2, 1, false> { static constexpr int TWC = 64; };
 template <> struct TileWidth<1, 2, false> { static constexpr int TWC = 128; };
 template <> struct TileWidth<1, 1, false> { static constexpr int TWC = 128; }; // 128 blocks, 2 waves
 
-enum { OUT_RGB = 0, OUT_GRAY = 1, OUT_YCBCR = 2 };
+// OUT_RGBA (R G B 255 per pixel) and OUT_RGB_CHW (three u8 planes) are extensions beyond the reference
+// (SURVEY 8f-3/4); both place every pixel at its own position (no Q5/Q6), like Params::plain does for OUT_RGB.
+enum { OUT_RGB = 0, OUT_GRAY = 1, OUT_YCBCR = 2, OUT_RGBA = 3, OUT_RGB_CHW = 4 };
 
 // LDS layout (bytes): planar staging Yp[SH][TWY] | Cb[CROWS][CPITCH] | Cr[..] (i16), then the three
 // quantisation tables (int32) every lane indexes by its block's component.
@@ -335,6 +337,8 @@ struct Params {
     int zero_fill;                // 1: also write the bytes the reference leaves 0 (Q5/Q6)
     int total_tiles;
     int debug;                    // diagnostics only (tools/ablate.py): 1 skip IDCT, 2 skip colour math, 4 no loads, 8 no stores
+    int plain;                    // OUT_RGB only: 1 = the last 16 samples of a row go to their own position (no Q5/Q6)
+    long long plane_stride;       // OUT_RGB_CHW: bytes between the R, G and B planes of a frame (width * height)
 };
 
 // vertical schedule of upsample_vertical (upsampler/scalar.rs:84-144): pair k -> (near, far)
@@ -665,6 +669,23 @@ ZJ_DEV void pack_rgb4_nat(const RGB2& a, const RGB2& b, uint32_t& d0, uint32_t& 
     d1 = perm(z, m, 0x04020100u);                               // G1 B1 R2 G2
     d2 = perm(z, y, 0x07050306u);                               // B2 R3 G3 B3
 }
+// 4 pixels -> 4 x (R G B 255).  p holds pixels (A, B), q holds (C, D); returns them in that order.
+ZJ_DEV void pack_rgba4(const RGB2& p, const RGB2& q, uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d)
+{
+    const uint32_t x = sat_pk_u8_2(p.r, p.g); // Ra Rb Ga Gb
+    const uint32_t y = sat_pk_u8_2(p.b, q.b); // Ba Bb Bc Bd
+    const uint32_t z = sat_pk_u8_2(q.r, q.g); // Rc Rd Gc Gd
+    a = perm(y, x, 0x0d040200u);              // selector 0x0d = constant 0xff
+    b = perm(y, x, 0x0d050301u);
+    c = perm(y, z, 0x0d060200u);
+    d = perm(y, z, 0x0d070301u);
+}
+// one colour plane of 4 consecutive pixels; EO: p holds px (0, 2), q holds px (1, 3); else p (0, 1), q (2, 3)
+template <bool EO> ZJ_DEV uint32_t pack_plane4(uint32_t p, uint32_t q)
+{
+    const uint32_t x = sat_pk_u8_2(p, q);
+    return EO ? perm(x, x, 0x03010200u) : x;
+}
 // truncating variant (`as u8`, ycbcr_to_ycbcr, color_convert/scalar.rs:119-169): low bytes
 ZJ_DEV RGB2 trunc3(uint32_t a, uint32_t b, uint32_t c)
 {
@@ -701,8 +722,8 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const in
     const int nvalid = (cbw - cb0) < C::TWC ? (cbw - cb0) : C::TWC;
     const bool left_wrap = cb0 == 0, right_wrap = cb0 + C::TWC >= cbw;
     const int x0 = t.tile * C::TWY;
-    const int ncomp = OUT == OUT_GRAY ? 1 : 3;
-    const long long row_bytes = (long long)W * ncomp;
+    const int ncomp = OUT == OUT_GRAY ? 1 : (OUT == OUT_RGBA ? 4 : 3);
+    const long long row_bytes = OUT == OUT_RGB_CHW ? (long long)W : (long long)W * ncomp; // CHW: one plane's row
     uint8_t* const frame_out = p.out + (long long)t.frame * p.out_frame_stride;
     const int elements = P / 16 - 1; // worker.rs:171 (P >= 32 on this path)
 
@@ -817,7 +838,42 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const in
         RGB2 c[8];
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            c[k] = (OUT == OUT_RGB && !ZJ_ABL(p.debug, 2)) ? ycc_to_rgb_pair(yp[k], cbp[k], crp[k]) : trunc3(yp[k], cbp[k], crp[k]);
+            c[k] = (OUT != OUT_YCBCR && !ZJ_ABL(p.debug, 2)) ? ycc_to_rgb_pair(yp[k], cbp[k], crp[k]) : trunc3(yp[k], cbp[k], crp[k]);
+        if (OUT == OUT_RGBA) {
+            // extension: 16 pixels -> 64 bytes at their own position, any width clipped at 4W
+            uint32_t q[16];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (HS == 2) pack_rgba4(c[k], c[4 + k], q[4 * k], q[4 * k + 2], q[4 * k + 1], q[4 * k + 3]);
+                else pack_rgba4(c[2 * k], c[2 * k + 1], q[4 * k], q[4 * k + 1], q[4 * k + 2], q[4 * k + 3]);
+            }
+            if (FAST) {
+                uint8_t* o = orow + 4ll * px0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const U4 v = {q[4 * k], q[4 * k + 1], q[4 * k + 2], q[4 * k + 3]}; store16(o + 16 * k, v); }
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; h++) store_clip(orow, 4ll * (px0 + 8 * h), q + 8 * h, 8, 4ll * W, 0, 0);
+            }
+            continue;
+        }
+        if (OUT == OUT_RGB_CHW) {
+            // extension: planar u8 (tensor layout C x H x W), 16 pixels -> 16 bytes in each plane
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+                uint32_t q[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const RGB2& a = HS == 2 ? c[k] : c[2 * k];
+                    const RGB2& b = HS == 2 ? c[4 + k] : c[2 * k + 1];
+                    q[k] = pl == 0 ? pack_plane4<HS == 2>(a.r, b.r) : (pl == 1 ? pack_plane4<HS == 2>(a.g, b.g) : pack_plane4<HS == 2>(a.b, b.b));
+                }
+                uint8_t* prow = orow + (long long)pl * p.plane_stride;
+                if (FAST) { const U4 v = {q[0], q[1], q[2], q[3]}; store16(prow + px0, v); }
+                else store_clip(prow, px0, q, 4, W, 0, 0);
+            }
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (HS == 2) pack_rgb4_eo(c[k], c[4 + k], d[3 * k], d[3 * k + 1], d[3 * k + 2]);
@@ -841,7 +897,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const in
                 const int u = (px0 >> 3) + h;
                 if (u >= units) continue;
                 const uint32_t* w6 = d + 6 * h;
-                if (OUT == OUT_YCBCR || W < 16) {
+                if (OUT == OUT_YCBCR || W < 16 || p.plain) {
                     store_clip(orow, 24ll * u, w6, 6, stride, 0, 0);
                 } else if (u >= units - 2) {
                     const long long off = pp + 24ll * (u - (units - 2));
@@ -859,7 +915,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const in
         const U4 s0 = {d[0], d[1], d[2], d[3]}, s1 = {d[4], d[5], d[6], d[7]}, s2 = {d[8], d[9], d[10], d[11]};
         if (ZJ_ABL(p.debug, 8) && (d[0] ^ d[5] ^ d[11]) != 0x12345u) continue; // ablation: (practically) no HBM writes
         const int G = px0 >> 4; // 16-pixel group index in the row
-        if (OUT == OUT_YCBCR) {
+        if (OUT == OUT_YCBCR || p.plain) {
             uint8_t* o = orow + 48ll * G;
             store16(o, s0); store16(o + 16, s1); store16(o + 32, s2);
         } else {

@@ -114,6 +114,11 @@ static hipError_t launch_fused_t(const Params& p, int compact, int fast, hipStre
     using C = Cfg<HS, VS, OUT>;
     if (p.total_tiles <= 0) return hipSuccess;
     const dim3 grid((unsigned)p.total_tiles), block(C::NT);
+    if (OUT == OUT_RGBA || OUT == OUT_RGB_CHW) { // extensions: the one-pass kernel only
+        if (fast) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 0, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 0, false>), grid, block, 0, s, p);
+        return hipGetLastError();
+    }
     if (g_pad_lds > 0 && fast && compact == 0) {
         hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 0, true>), grid, block, (size_t)g_pad_lds, s, p);
         return hipGetLastError();
@@ -135,6 +140,8 @@ hipError_t launch_fused(int hs, int vs, int out, int compact, int fast, const Pa
     ZJ_CASE(2, 1, OUT_RGB) ZJ_CASE(2, 1, OUT_GRAY) ZJ_CASE(2, 1, OUT_YCBCR)
     ZJ_CASE(1, 2, OUT_RGB) ZJ_CASE(1, 2, OUT_GRAY) ZJ_CASE(1, 2, OUT_YCBCR)
     ZJ_CASE(2, 2, OUT_RGB) ZJ_CASE(2, 2, OUT_GRAY) ZJ_CASE(2, 2, OUT_YCBCR)
+    ZJ_CASE(1, 1, OUT_RGBA) ZJ_CASE(2, 1, OUT_RGBA) ZJ_CASE(1, 2, OUT_RGBA) ZJ_CASE(2, 2, OUT_RGBA)
+    ZJ_CASE(1, 1, OUT_RGB_CHW) ZJ_CASE(2, 1, OUT_RGB_CHW) ZJ_CASE(1, 2, OUT_RGB_CHW) ZJ_CASE(2, 2, OUT_RGB_CHW)
 #undef ZJ_CASE
     return hipErrorInvalidValue;
 }
@@ -145,6 +152,7 @@ const char* fused_kernel_name(int hs, int vs, int out, int variant, int fast)
     static char buf[8][96];
     static int slot = 0;
     char* b = buf[slot++ & 7];
+    if (out == OUT_RGBA || out == OUT_RGB_CHW) variant = 0;
     if (fast && variant == 2) snprintf(b, 96, "void zj::zj_fused_persistent_kernel<%d, %d, %d>(zj::Params)", hs, vs, out);
     else snprintf(b, 96, "void zj::zj_fused_kernel<%d, %d, %d, %d, %s>(zj::Params)", hs, vs, out, fast ? (variant == 1) : 0, fast ? "true" : "false");
     return b;

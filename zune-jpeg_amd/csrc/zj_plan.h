@@ -15,7 +15,8 @@ namespace zj {
 
 struct Plan {
     int hs, vs;          // luma sampling factors
-    int out;             // OUT_RGB / OUT_GRAY / OUT_YCBCR
+    int out;             // OUT_RGB / OUT_GRAY / OUT_YCBCR / OUT_RGBA / OUT_RGB_CHW
+    int plain;           // OUT_RGB with ZJ_FLAG_PLAIN_TAIL
     int mcu_x, mcu_y;
     int n_strips;        // strips the reference's zip() would process
     int strip_rows;      // luma rows per strip
@@ -70,7 +71,16 @@ inline int make_plan(const zj_frame_desc* d, Plan& pl)
     if (d->out_colorspace == ZJ_CS_GRAYSCALE) pl.out = OUT_GRAY;
     else if (d->out_colorspace == ZJ_CS_RGB && d->in_components == 3) pl.out = OUT_RGB;
     else if (d->out_colorspace == ZJ_CS_YCBCR && d->in_components == 3) pl.out = OUT_YCBCR;
-    else return ZJ_ERR_UNSUPPORTED; // RGBA/RGBX are malformed in the reference, CMYK/YCCK no-ops
+    // RGBA/RGBX are malformed in the reference itself; here they are an extension: R G B 255
+    else if ((d->out_colorspace == ZJ_CS_RGBA || d->out_colorspace == ZJ_CS_RGBX) && d->in_components == 3) pl.out = OUT_RGBA;
+    else return ZJ_ERR_UNSUPPORTED; // CMYK/YCCK are no-ops in the reference
+    if (d->flags & ~(uint32_t)ZJ_FLAG_PLAIN_TAIL) return ZJ_ERR_ARG;
+    pl.plain = (pl.out == OUT_RGB && (d->flags & ZJ_FLAG_PLAIN_TAIL)) ? 1 : 0;
+    if (d->out_layout == ZJ_LAYOUT_CHW) {
+        if (pl.out == OUT_RGB) pl.out = OUT_RGB_CHW;            // planar u8 tensor layout, every pixel at its own place
+        else if (pl.out != OUT_GRAY) return ZJ_ERR_UNSUPPORTED; // (one plane: CHW == HWC)
+        pl.plain = 0;
+    } else if (d->out_layout != ZJ_LAYOUT_HWC) return ZJ_ERR_ARG;
     pl.ncomp_out = nout;
     pl.mcu_x = (int)((d->width + 8 * d->h_max - 1) / (8 * d->h_max));  // headers.rs:317
     pl.mcu_y = (int)((d->height + 8 * d->v_max - 1) / (8 * d->v_max)); // headers.rs:319
@@ -102,6 +112,22 @@ inline int make_plan(const zj_frame_desc* d, Plan& pl)
     return ZJ_OK;
 }
 
+// Byte ranges of one frame's output that the strips never reach (rows below the last complete strip,
+// Q6: the reference leaves them 0).  HWC: one range; CHW: one per plane.  Returns the number of ranges.
+inline int uncovered_ranges(const zj_frame_desc* d, const Plan& pl, size_t off[3], size_t len[3])
+{
+    const size_t H = d->height, W = d->width;
+    const size_t covered = (size_t)pl.rows_covered < H ? (size_t)pl.rows_covered : H;
+    if (covered >= H) return 0;
+    if (pl.out == OUT_RGB_CHW) {
+        for (int c = 0; c < 3; c++) { off[c] = (size_t)c * W * H + covered * W; len[c] = (H - covered) * W; }
+        return 3;
+    }
+    off[0] = covered * W * pl.ncomp_out;
+    len[0] = pl.out_len - off[0];
+    return 1;
+}
+
 inline void fill_params(const zj_frame_desc* d, const Plan& pl, size_t nframes, const int16_t* y,
                         const int16_t* cb, const int16_t* cr, uint8_t* out, const int32_t* d_qt,
                         int zero_fill, Params& p)
@@ -115,6 +141,8 @@ inline void fill_params(const zj_frame_desc* d, const Plan& pl, size_t nframes, 
     p.nframes = (int)nframes; p.zero_fill = zero_fill;
     p.total_tiles = (int)nframes * pl.n_strips * pl.tiles_per_row;
     p.debug = 0;
+    p.plain = pl.plain;
+    p.plane_stride = (long long)d->width * d->height;
 }
 
 } // namespace zj

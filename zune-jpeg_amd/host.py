@@ -57,16 +57,21 @@ class Component(C.Structure):  # zj_component  <->  Components, src/components.r
                 ("width_stride", C.c_size_t), ("quantization_table", C.c_int32 * 64)]
 
 
+FLAG_PLAIN_TAIL = 1   # zj_frame_desc.flags: extension, every pixel at its own position (no Q5/Q6)
+LAYOUT_HWC, LAYOUT_CHW = 0, 1
+
+
 class FrameDesc(C.Structure):  # zj_frame_desc
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("h_max", C.c_uint32),
                 ("v_max", C.c_uint32), ("in_components", C.c_uint32), ("out_colorspace", C.c_int32),
-                ("qt", (C.c_int32 * 64) * 3)]
+                ("qt", (C.c_int32 * 64) * 3), ("flags", C.c_uint32), ("out_layout", C.c_uint32)]
 
     @classmethod
-    def make(cls, width, height, h_max, v_max, in_components, out_colorspace, qts):
+    def make(cls, width, height, h_max, v_max, in_components, out_colorspace, qts, flags=0, out_layout=0):
         d = cls()
         d.width, d.height, d.h_max, d.v_max = width, height, h_max, v_max
         d.in_components, d.out_colorspace = in_components, int(out_colorspace)
+        d.flags, d.out_layout = int(flags), int(out_layout)
         for c in range(3):
             q = np.asarray(qts[min(c, len(qts) - 1)], np.int32).reshape(64)
             C.memmove(d.qt[c], q.ctypes.data, 256)
