@@ -1,0 +1,214 @@
+//! FFI to `libzjhip.so` -- the MI355X arm of zune-jpeg's pixel pipeline -- plus a thin safe layer whose
+//! names follow the reference crate (`Decoder`, `ZuneJpegOptions`, `ColorSpace`, the three fn-pointer types of
+//! `src/decoder.rs:47,56` and `src/components.rs:14`).
+//!
+//! The C side is `include/zjhip.h` (ABI version 2).  Output bytes equal the reference's *scalar* arms.
+#![allow(non_camel_case_types)]
+use std::ffi::CStr;
+use std::os::raw::{c_char, c_int, c_void};
+
+pub const ZJ_ABI_VERSION: c_int = 2;
+pub const ZJ_BACKEND_HIP: c_int = 2;
+pub const ZJ_OK: c_int = 0;
+pub const ZJ_ERR_PANIC: c_int = -5;
+pub const ZJ_FLAG_PLAIN_TAIL: u32 = 1;
+pub const ZJ_LAYOUT_HWC: u32 = 0;
+pub const ZJ_LAYOUT_CHW: u32 = 1;
+
+/// `ColorSpace`, `src/misc.rs:88-106` (same discriminants).
+#[repr(i32)]
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub enum ColorSpace { RGB = 0, GRAYSCALE = 1, YCbCr = 2, CMYK = 3, YCCK = 4, RGBA = 5, RGBX = 6 }
+
+impl ColorSpace {
+    /// `misc.rs:113-121`
+    pub fn num_components(self) -> usize {
+        match self { ColorSpace::RGB | ColorSpace::YCbCr => 3, ColorSpace::GRAYSCALE => 1, _ => 4 }
+    }
+}
+
+#[repr(C)]
+pub struct zj_component {            // <-> Components, src/components.rs:18-43
+    pub horizontal_sample: usize,
+    pub vertical_sample: usize,
+    pub width_stride: usize,
+    pub quantization_table: [i32; 64],
+}
+
+#[repr(C)]
+#[derive(Clone)]
+pub struct zj_frame_desc {
+    pub width: u32, pub height: u32, pub h_max: u32, pub v_max: u32,
+    pub in_components: u32, pub out_colorspace: i32,
+    pub qt: [[i32; 64]; 3],
+    pub flags: u32, pub out_layout: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct zj_options {              // <-> ZuneJpegOptions, src/options.rs:6-40 (zero = reference default)
+    pub out_colorspace: i32, pub strict_mode: i32, pub max_width: i32, pub max_height: i32,
+    pub max_scans: i32, pub num_threads: i32, pub pinned_planes: i32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default, Debug)]
+pub struct zj_image_info {           // <-> ImageInfo, src/decoder.rs:652-668
+    pub width: u16, pub height: u16,
+    pub components: u8, pub progressive: u8, pub h_max: u8, pub v_max: u8,
+    pub scans: u16, pub restart_interval: u16,
+}
+
+#[repr(C)] pub struct zj_ctx { _private: [u8; 0] }
+#[repr(C)] pub struct zj_decoder { _private: [u8; 0] }
+#[repr(C)] pub struct zj_pool { _private: [u8; 0] }
+
+extern "C" {
+    pub fn zj_abi_version() -> c_int;
+    pub fn zj_device_count() -> c_int;
+    pub fn zj_ctx_create(backend: c_int, device: c_int, status: *mut c_int) -> *mut zj_ctx;
+    pub fn zj_ctx_destroy(ctx: *mut zj_ctx);
+    pub fn zj_default_ctx() -> *mut zj_ctx;
+    pub fn zj_strerror(status: c_int) -> *const c_char;
+    pub fn zj_last_error(ctx: *const zj_ctx) -> *const c_char;
+    pub fn zj_idct_strip(ctx: *mut zj_ctx, coeff: *const i16, n: usize, qt: *const i32, stride: usize,
+                         samp_factors: usize, v_samp: usize, out: *mut i16) -> c_int;
+    pub fn zj_upsample_h(ctx: *mut zj_ctx, inp: *const i16, n: usize, out: *mut i16, out_len: usize) -> c_int;
+    pub fn zj_upsample_v(ctx: *mut zj_ctx, inp: *const i16, n: usize, out: *mut i16, out_len: usize) -> c_int;
+    pub fn zj_upsample_hv(ctx: *mut zj_ctx, inp: *const i16, n: usize, out: *mut i16, out_len: usize) -> c_int;
+    pub fn zj_ycbcr_to_rgb16(ctx: *mut zj_ctx, y: *const i16, cb: *const i16, cr: *const i16,
+                             out: *mut u8, out_len: usize, pos: *mut usize) -> c_int;
+    pub fn zj_post_process_strip(ctx: *mut zj_ctx, coeff: *const *const i16, len: *const usize,
+                                 comps: *const zj_component, in_cs: c_int, out_cs: c_int,
+                                 out: *mut u8, out_len: usize, width: usize) -> c_int;
+    pub fn zj_plane_len(d: *const zj_frame_desc, comp: c_int) -> usize;
+    pub fn zj_out_len(d: *const zj_frame_desc) -> usize;
+    pub fn zj_num_components(colorspace: c_int) -> c_int;
+    pub fn zj_decode_planes(ctx: *mut zj_ctx, d: *const zj_frame_desc, y: *const i16, cb: *const i16,
+                            cr: *const i16, out: *mut u8) -> c_int;
+    pub fn zj_decode_planes_batch(ctx: *mut zj_ctx, d: *const zj_frame_desc, nframes: usize, y: *const i16,
+                                  cb: *const i16, cr: *const i16, out: *mut u8) -> c_int;
+    pub fn zj_decode_planes_device(ctx: *mut zj_ctx, d: *const zj_frame_desc, nframes: usize, d_y: *const i16,
+                                   d_cb: *const i16, d_cr: *const i16, d_out: *mut u8, stream: *mut c_void) -> c_int;
+    pub fn zj_alloc_pinned(bytes: usize) -> *mut c_void;
+    pub fn zj_free_pinned(p: *mut c_void);
+    pub fn zj_decoder_new(opt: *const zj_options) -> *mut zj_decoder;
+    pub fn zj_decoder_free(d: *mut zj_decoder);
+    pub fn zj_decoder_error(d: *const zj_decoder) -> *const c_char;
+    pub fn zj_decoder_read_headers(d: *mut zj_decoder, buf: *const u8, len: usize, info: *mut zj_image_info) -> c_int;
+    pub fn zj_decoder_decode_coefficients(d: *mut zj_decoder, buf: *const u8, len: usize, desc: *mut zj_frame_desc,
+                                          planes: *mut *const i16, plane_len: *mut usize, info: *mut zj_image_info) -> c_int;
+    pub fn zj_decoder_finish_pixels(d: *mut zj_decoder, ctx: *mut zj_ctx, out: *mut u8, out_cap: usize,
+                                    out_len: *mut usize) -> c_int;
+    pub fn zj_decoder_decode_buffer(d: *mut zj_decoder, ctx: *mut zj_ctx, buf: *const u8, len: usize, out: *mut u8,
+                                    out_cap: usize, out_len: *mut usize, info: *mut zj_image_info) -> c_int;
+    pub fn zj_pool_create(device: c_int, threads: c_int, opt: *const zj_options, status: *mut c_int) -> *mut zj_pool;
+    pub fn zj_pool_destroy(pool: *mut zj_pool);
+    pub fn zj_pool_error(pool: *const zj_pool) -> *const c_char;
+    pub fn zj_pool_decode_files(pool: *mut zj_pool, nfiles: usize, bufs: *const *const u8, lens: *const usize,
+                                outs: *const *mut u8, out_caps: *const usize, out_lens: *mut usize,
+                                infos: *mut zj_image_info, statuses: *mut c_int) -> c_int;
+}
+
+fn check(rc: c_int, what: &str) {
+    // the reference's pixel functions cannot fail; where it would panic, so do we
+    if rc != ZJ_OK {
+        let msg = unsafe { CStr::from_ptr(zj_strerror(rc)) }.to_string_lossy().into_owned();
+        panic!("{}: zjhip status {} ({})", what, rc, msg);
+    }
+}
+
+/// `Aligned32<[i32;64]>` of the reference (`src/misc.rs:70-72`); the HIP arm has no alignment requirement.
+#[repr(align(32))]
+pub struct Aligned32<T>(pub T);
+
+/// Drop-in for `IDCTPtr` (`src/decoder.rs:56`): `dequantize_and_idct_int` / `_avx2`.
+pub fn dequantize_and_idct_hip(vector: &[i16], qt: &Aligned32<[i32; 64]>, stride: usize, samp_factors: usize,
+                               v_samp: usize) -> Vec<i16> {
+    let mut out = vec![0i16; vector.len()];
+    check(unsafe { zj_idct_strip(zj_default_ctx(), vector.as_ptr(), vector.len(), qt.0.as_ptr(), stride,
+                                 samp_factors, v_samp, out.as_mut_ptr()) }, "zj_idct_strip");
+    out
+}
+
+macro_rules! upsampler {
+    ($name:ident, $ffi:ident) => {
+        /// Drop-in for `UpSampler` (`src/components.rs:14`).
+        pub fn $name(input: &[i16], output_len: usize) -> Vec<i16> {
+            let mut out = vec![0i16; output_len];
+            check(unsafe { $ffi(zj_default_ctx(), input.as_ptr(), input.len(), out.as_mut_ptr(), output_len) },
+                  stringify!($ffi));
+            out
+        }
+    };
+}
+upsampler!(upsample_horizontal_hip, zj_upsample_h);
+upsampler!(upsample_vertical_hip, zj_upsample_v);
+upsampler!(upsample_hv_hip, zj_upsample_hv);
+
+/// Drop-in for `ColorConvert16Ptr` (`src/decoder.rs:47`).
+pub fn ycbcr_to_rgb_hip_16(y: &[i16; 16], cb: &[i16; 16], cr: &[i16; 16], out: &mut [u8], pos: &mut usize) {
+    check(unsafe { zj_ycbcr_to_rgb16(zj_default_ctx(), y.as_ptr(), cb.as_ptr(), cr.as_ptr(), out.as_mut_ptr(),
+                                     out.len(), pos as *mut usize) }, "zj_ycbcr_to_rgb16");
+}
+
+/// `DecodeErrors` (`src/errors.rs:16-43`) flattened: the status code of `include/zjhip.h` and the reference's text.
+#[derive(Debug)]
+pub struct DecodeErrors { pub status: i32, pub message: String }
+
+/// `ZuneJpegOptions` (`src/options.rs`).
+#[derive(Clone, Copy)]
+pub struct ZuneJpegOptions { raw: zj_options }
+impl Default for ZuneJpegOptions {
+    fn default() -> Self { ZuneJpegOptions { raw: zj_options::default() } }
+}
+impl ZuneJpegOptions {
+    pub fn new() -> Self { Self::default() }
+    pub fn set_out_colorspace(mut self, cs: ColorSpace) -> Self { self.raw.out_colorspace = cs as i32; self }
+    pub fn set_strict_mode(mut self, yes: bool) -> Self { self.raw.strict_mode = yes as i32; self }
+    pub fn set_num_threads(mut self, n: usize) -> Self { self.raw.num_threads = n as i32; self }
+    pub fn set_max_width(mut self, w: u16) -> Self { self.raw.max_width = w as i32; self }
+    pub fn set_max_height(mut self, h: u16) -> Self { self.raw.max_height = h as i32; self }
+    pub fn set_max_scans(mut self, n: usize) -> Self { self.raw.max_scans = n as i32; self }
+}
+
+/// `Decoder` (`src/decoder.rs:60`): CPU entropy decode, GPU pixel path.
+pub struct Decoder { d: *mut zj_decoder, ctx: *mut zj_ctx, info: Option<zj_image_info>, out_cs: ColorSpace }
+
+impl Decoder {
+    pub fn new() -> Decoder { Decoder::new_with_options(ZuneJpegOptions::default()) }
+    pub fn new_with_options(o: ZuneJpegOptions) -> Decoder {
+        let out_cs = match o.raw.out_colorspace { 1 => ColorSpace::GRAYSCALE, 2 => ColorSpace::YCbCr,
+                                                  5 => ColorSpace::RGBA, 6 => ColorSpace::RGBX, _ => ColorSpace::RGB };
+        Decoder { d: unsafe { zj_decoder_new(&o.raw) }, ctx: unsafe { zj_default_ctx() }, info: None, out_cs }
+    }
+    fn err(&self, rc: c_int) -> DecodeErrors {
+        let m = unsafe { CStr::from_ptr(zj_decoder_error(self.d)) }.to_string_lossy().into_owned();
+        DecodeErrors { status: rc, message: m }
+    }
+    /// `decoder.rs:452`
+    pub fn read_headers(&mut self, buf: &[u8]) -> Result<(), DecodeErrors> {
+        let mut info = zj_image_info::default();
+        let rc = unsafe { zj_decoder_read_headers(self.d, buf.as_ptr(), buf.len(), &mut info) };
+        if rc != ZJ_OK { return Err(self.err(rc)); }
+        self.info = Some(info);
+        Ok(())
+    }
+    /// `decoder.rs:210`
+    pub fn info(&self) -> Option<zj_image_info> { self.info }
+    /// `decoder.rs:178`
+    pub fn decode_buffer(&mut self, buf: &[u8]) -> Result<Vec<u8>, DecodeErrors> {
+        self.read_headers(buf)?;
+        let i = self.info.unwrap();
+        let nc = if i.components == 1 { 1 } else { self.out_cs.num_components() };
+        let mut out = vec![0u8; i.width as usize * i.height as usize * nc];
+        let (mut n, mut info) = (0usize, zj_image_info::default());
+        let rc = unsafe { zj_decoder_decode_buffer(self.d, self.ctx, buf.as_ptr(), buf.len(), out.as_mut_ptr(),
+                                                   out.len(), &mut n, &mut info) };
+        if rc != ZJ_OK { return Err(self.err(rc)); }
+        out.truncate(n);
+        self.info = Some(info);
+        Ok(out)
+    }
+}
+impl Drop for Decoder { fn drop(&mut self) { unsafe { zj_decoder_free(self.d) } } }

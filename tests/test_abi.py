@@ -83,3 +83,25 @@ def test_fails_loudly_without_gpu(zj):
     assert e.value.status == -6  # ZJ_ERR_NO_DEVICE
     with pytest.raises(zj.ZjError):
         zj.Context(backend=zj.BACKEND_SCALAR)
+
+
+def test_rust_shim_declares_every_symbol():
+    """bindings/rust/src/lib.rs cannot be compiled here (no rustc): at least keep its extern block in step with
+    include/zjhip.h -- every function it declares exists in the header with the same number of parameters."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "zjhip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    rs = open(os.path.join(root, "bindings", "rust", "src", "lib.rs")).read()
+    block = rs[rs.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    decls = re.findall(r"pub fn (zj_\w+)\(([^)]*)\)", block, flags=re.S)
+    assert len(decls) >= 30
+    for name, args in decls:
+        m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", hdr, flags=re.S)
+        assert m, f"{name} is not declared in include/zjhip.h"
+        c_args = [a for a in m.group(1).split(",") if a.strip() and a.strip() != "void"]
+        r_args = [a for a in args.split(",") if a.strip()]
+        assert len(c_args) == len(r_args), (name, len(c_args), len(r_args))
+    for field in ("flags", "out_layout", "num_threads", "pinned_planes"):
+        assert field in rs
