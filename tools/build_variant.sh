@@ -1,0 +1,9 @@
+#!/bin/bash
+# build_variant.sh NAME "EXTRA FLAGS": zune-jpeg_amd/libzjhip_NAME.so with zj_kernels.hip recompiled under EXTRA
+# (the other objects are reused); select it at run time with ZJ_LIB=libzjhip_NAME.so.  A/B experiments only.
+set -e
+cd "$(dirname "$0")/../zune-jpeg_amd/csrc"
+make -s
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed $2 -c zj_kernels.hip -o /tmp/zj_kernels_$1.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o ../libzjhip_$1.so /tmp/zj_kernels_$1.o zj_ubench.o zj_lab.o zj_api.o zj_jpeg.o zj_pool.o -Wl,-soname,libzjhip.so
+echo built libzjhip_$1.so

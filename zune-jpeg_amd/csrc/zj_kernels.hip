@@ -21,6 +21,13 @@ namespace zj {
 // ------------------------------------------------------------------------------------------------
 // fused tile kernel
 // ------------------------------------------------------------------------------------------------
+// ZJ_PRIO bit 0: raise the wave priority while a tile's coefficient loads are being issued (+1 % measured,
+// tools/ab_libs.sh); bit 1: raise it for the colour phase (no gain).  Default: bit 0.
+#ifndef ZJ_PRIO
+#define ZJ_PRIO 1
+#endif
+#define ZJ_SETPRIO(bit, level) do { if (ZJ_PRIO & (bit)) __builtin_amdgcn_s_setprio(level); } while (0)
+
 template <int HS, int VS, int OUT, int COMPACT, bool FAST>
 // 2nd launch bound = waves per SIMD: 5 workgroups of 4 waves per CU need <= 96 VGPRs; LDS (32.7 KB
 // per workgroup for 4:2:0) allows exactly 5.  At 4 the VALU idles ~16% (profiles/r01_v4_pmc_sq.txt).
@@ -29,11 +36,13 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), ZJ_WAVES_PER_SIMD) void zj_
     using C = Cfg<HS, VS, OUT>;
     __shared__ __attribute__((aligned(16))) char lds_raw[COMPACT ? C::LDS_BYTES_COMPACT : C::LDS_BYTES];
     int16_t* lds = reinterpret_cast<int16_t*>(lds_raw);
+    ZJ_SETPRIO(1, 3); // issue the tile's loads ahead of other waves' arithmetic
     const TileId t = decode_tile(p, (int)blockIdx.x);
     const int tid = (int)threadIdx.x;
     const BlockLoc L = locate<C>(p, t, tid, lds);
     U4 raw[8];
     load_block(L, raw, p.debug); // HBM loads in flight across the barrier below
+    ZJ_SETPRIO(1, 0);
     if (COMPACT) {
         const int32_t q0 = p.qt[64 * L.comp]; // the DC-only shortcut needs q[0] before the tables are staged
         phase_setup<C, HS, VS>(p, tid, lds);
@@ -46,6 +55,7 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), ZJ_WAVES_PER_SIMD) void zj_
         finish_block<C>(L, raw, lds, p.debug);
     }
     __syncthreads();
+    ZJ_SETPRIO(2, 2); // (off) let a tile's last phase, the one that frees the workgroup slot, go first
     phase_color<C, HS, VS, OUT, FAST>(p, t, tid, lds);
 }
 
