@@ -52,5 +52,6 @@ if has sq; then
   python tools/pmc_summary.py $O/pmc_sq --tag $TAG-sq 2>&1 | grep -E '"(SQ|GRBM)|mean' | paste - - | tee -a $O/summary.txt
   python tools/pmc_summary.py $O/pmc_sq2 --tag $TAG-sq2 2>&1 | grep -E '"(SQ|GRBM)|mean' | paste - - | tee -a $O/summary.txt
 fi
+if has pmc && has sq; then python tools/pmc_summary.py $O --out $O/pmc_summary.json --tag $TAG > /dev/null 2>&1; fi
 find $O -name "*.csv" -size +3M -delete; find $O -name "*.db" -size +3M -delete
 du -sh $O | tee -a $O/summary.txt
