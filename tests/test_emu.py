@@ -142,3 +142,39 @@ def test_plain_oracle_cross_check_numpy(synth):
     q = oc.decode_planes(f, planes)[1].reshape(48, 192)
     p = oc.decode_planes(f, planes, plain=True)[1].reshape(48, 192)
     assert np.array_equal(q[:, :128], p[:, :128]) and np.array_equal(q[:, 128:176], p[:, 144:]) and not q[:, 176:].any()
+
+
+def test_random_geometry_sweep_all_output_kinds(synth):
+    """400 random (width, height, mode, output) cases, widths 1..700 and heights 1..90: emulated kernel == oracle
+    (reference bytes for RGB / GRAYSCALE / YCbCr, plain-placement restatement for the extensions); where the oracle
+    reports a reference panic the plan must report ZJ_ERR_PANIC (-5)."""
+    emu_c.set_variant(0)
+    rng = np.random.default_rng(20261001)
+    kinds = ["rgb", "gray", "ycbcr", "plain", "rgba", "chw"]
+    done = panics = 0
+    for case in range(400):
+        mode = list(MODES)[int(rng.integers(4))]
+        hs, vs = MODES[mode]
+        w = int(rng.integers(1, 700)) if case % 3 else int(rng.integers(1, 44)) * 16
+        h = int(rng.integers(1, 90))
+        kind = kinds[int(rng.integers(len(kinds)))]
+        planes, qts = synth.make_frame(w, h, hs, vs, 3, seed=1000 + case)
+        if kind in ("rgb", "gray", "ycbcr"):
+            cs = {"rgb": oc.RGB, "gray": oc.GRAYSCALE, "ycbcr": oc.YCBCR}[kind]
+            f = oc.make_frame(w, h, hs, vs, 3, cs, qts)
+            rc, exp = oc.decode_planes(f, planes)
+            rce, out = emu_c.decode_planes(f, planes)
+            if rc != 0:
+                assert rce == -5, (case, w, h, mode, kind, rc, rce)
+                panics += 1
+                continue
+        else:
+            rc, exp = _plain_expected(w, h, hs, vs, qts, planes, kind)
+            assert rc == 0
+            f = oc.make_frame(w, h, hs, vs, 3, oc.RGBA if kind == "rgba" else oc.RGB, qts)
+            rce, out = emu_c.decode_planes(f, planes, flags=1 if kind == "plain" else 0, out_layout=1 if kind == "chw" else 0)
+        assert rce == 0, (case, w, h, mode, kind, rce)
+        bad = np.nonzero(out != exp)[0]
+        assert bad.size == 0, (case, w, h, mode, kind, bad[:8])
+        done += 1
+    assert done > 300

@@ -511,3 +511,35 @@ def test_decoder_rgba_option(ctx, zj, synth):
     rc, exp = oc.decode_planes(oc.make_frame(w, h, 2, 2, 3, oc.RGBA, qts), planes, plain=True)
     assert rc == 0
     assert_same(out, exp, "decoder rgba")
+
+
+def test_random_geometry_sweep_all_output_kinds(ctx, zj, synth):
+    """300 random (width, height, mode, output kind) cases through the C ABI, against the oracle; reference panics
+    must come back as ZJ_ERR_PANIC."""
+    rng = np.random.default_rng(20261002)
+    kinds = ["rgb", "gray", "ycbcr", "plain", "rgba", "chw"]
+    done = 0
+    for case in range(300):
+        mode = list(MODES)[int(rng.integers(4))]
+        hs, vs = MODES[mode]
+        w = int(rng.integers(1, 900)) if case % 3 else int(rng.integers(1, 60)) * 16
+        h = int(rng.integers(1, 120))
+        kind = kinds[int(rng.integers(len(kinds)))]
+        planes, qts = synth.make_frame(w, h, hs, vs, 3, seed=3000 + case)
+        cs = {"rgb": zj.ColorSpace.RGB, "gray": zj.ColorSpace.GRAYSCALE, "ycbcr": zj.ColorSpace.YCBCR,
+              "plain": zj.ColorSpace.RGB, "rgba": zj.ColorSpace.RGBA, "chw": zj.ColorSpace.RGB}[kind]
+        d = zj.FrameDesc.make(w, h, hs, vs, 3, cs, qts, flags=zj.FLAG_PLAIN_TAIL if kind == "plain" else 0,
+                              out_layout=zj.LAYOUT_CHW if kind == "chw" else zj.LAYOUT_HWC)
+        if kind in ("rgb", "gray", "ycbcr"):
+            rc, exp = oc.decode_planes(oc.make_frame(w, h, hs, vs, 3, int(cs), qts), planes)
+            if rc != 0:
+                with pytest.raises(zj.ZjError) as e:
+                    ctx.decode_planes(d, planes)
+                assert e.value.status == -5, (case, w, h, mode, kind)
+                continue
+        else:
+            rc, exp = _plain_expected(w, h, hs, vs, qts, planes, kind)
+            assert rc == 0
+        assert_same(ctx.decode_planes(d, planes), exp, (case, w, h, mode, kind))
+        done += 1
+    assert done > 220
