@@ -5,6 +5,7 @@ import importlib
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -105,3 +106,12 @@ def test_rust_shim_declares_every_symbol():
         assert len(c_args) == len(r_args), (name, len(c_args), len(r_args))
     for field in ("flags", "out_layout", "num_threads", "pinned_planes"):
         assert field in rs
+
+
+def test_graft_entry_build_passes():
+    """the driver's build check: compiles (or finds up to date) every library and validates symbols + ABI version"""
+    import importlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    g = importlib.import_module("__graft_entry__")
+    g.build()
