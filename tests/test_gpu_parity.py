@@ -526,7 +526,7 @@ def test_random_geometry_sweep_all_output_kinds(ctx, zj, synth):
         h = int(rng.integers(1, 120))
         kind = kinds[int(rng.integers(len(kinds)))]
         planes, qts = synth.make_frame(w, h, hs, vs, 3, seed=3000 + case)
-        cs = {"rgb": zj.ColorSpace.RGB, "gray": zj.ColorSpace.GRAYSCALE, "ycbcr": zj.ColorSpace.YCBCR,
+        cs = {"rgb": zj.ColorSpace.RGB, "gray": zj.ColorSpace.GRAYSCALE, "ycbcr": zj.ColorSpace.YCbCr,
               "plain": zj.ColorSpace.RGB, "rgba": zj.ColorSpace.RGBA, "chw": zj.ColorSpace.RGB}[kind]
         d = zj.FrameDesc.make(w, h, hs, vs, 3, cs, qts, flags=zj.FLAG_PLAIN_TAIL if kind == "plain" else 0,
                               out_layout=zj.LAYOUT_CHW if kind == "chw" else zj.LAYOUT_HWC)

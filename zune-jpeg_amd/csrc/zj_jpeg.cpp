@@ -33,6 +33,8 @@ struct Huff {
     bool present = false;
     // canonical decoding (T.81 F.2.2.3) with an 9-bit lookahead table
     uint16_t look[512];    // (len << 8) | symbol, 0 = longer than 9 bits
+    int16_t fast[512];     // AC shortcut: (value << 8) | (run << 4) | (code length + magnitude bits), 0 = none;
+                           // set when code and magnitude bits both fit the 9-bit window and the value fits a byte
     int32_t maxcode[18];   // per length, -1 if none
     int32_t valoff[17];
     uint8_t vals[256];
@@ -72,6 +74,16 @@ struct Huff {
                 int base = codes[p] << (9 - l);
                 for (int j = 0; j < (1 << (9 - l)); j++) look[base + j] = (uint16_t)((l << 8) | vals[p]);
             }
+        for (int i = 0; i < 512; i++) {
+            fast[i] = 0;
+            const uint16_t e = look[i];
+            if (!e) continue;
+            const int len = e >> 8, run = (e & 0xff) >> 4, sz = e & 15;
+            if (!sz || len + sz > 9) continue;
+            const int bits = ((i << len) & 511) >> (9 - sz);
+            const int v = bits < (1 << (sz - 1)) ? bits - (1 << sz) + 1 : bits; // T.81 F.2.2.1 EXTEND
+            if (v >= -128 && v <= 127) fast[i] = (int16_t)((v * 256) | (run << 4) | (len + sz));
+        }
         present = true;
         return 0;
     }
@@ -86,6 +98,20 @@ struct BitReader {
     void reset() { acc = 0; nbits = 0; marker = 0; }
     void fill()
     {
+        // eight bytes at once while no 0xFF (stuffing or marker) is among them; the bits of a partially taken
+        // byte are OR-ed in again, unchanged, by the next fill
+        if (!marker && end - p >= 8 && nbits >= 0 && nbits <= 56) {
+            uint64_t x;
+            memcpy(&x, p, 8);
+            x = __builtin_bswap64(x);
+            const uint64_t y = ~x;
+            if (!((y - 0x0101010101010101ull) & ~y & 0x8080808080808080ull)) {
+                acc |= x >> nbits;
+                p += (63 - nbits) >> 3;
+                nbits |= 56;
+                return;
+            }
+        }
         while (nbits <= 56) {
             uint32_t b = 0;
             if (!marker && p < end) {
@@ -319,8 +345,10 @@ int parse_sof(zj_decoder* d, Cursor& c, int progressive)
         cm.coef = d->store[i].ensure(cm.coef_len * 2, d->pinned);
         if (!cm.coef) return fail(d, ZJ_ERR_NOMEM, "out of memory for the coefficient planes");
     }
-    // the entropy decoder only writes non-zero coefficients: clear the planes (in parallel when large)
-    for (int i = 0; i < nc; i++) {
+    // the entropy decoder only writes non-zero coefficients.  Progressive scans accumulate into the planes, so
+    // they are cleared up front (in parallel when large); a baseline scan clears each block right before it
+    // decodes into it (one pass over memory instead of two) and scan_baseline clears whatever it did not reach
+    for (int i = 0; i < nc && progressive; i++) {
         Comp& cm = d->comps[i];
         const size_t bytes = cm.coef_len * 2, piece = (size_t)4 << 20;
         const int n = (int)((bytes + piece - 1) / piece);
@@ -423,18 +451,37 @@ int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, in
 {
     const Huff& hd = d->dc[cm.td & 3];
     const Huff& ha = d->ac[cm.ta & 3];
+    memset(blk, 0, 128);
     int s = br.decode(hd);
     if (s < 0 || s > 16) { *err = "Bad Huffman code in DC"; return ZJ_ERR_HUFFMAN; }
     int32_t diff = s ? extend(br.get(s), s) : 0;
     dc_pred = (int32_t)((uint32_t)dc_pred + (uint32_t)diff);
     blk[0] = (int16_t)dc_pred; // bitstream.rs:330
     for (int k = 1; k < 64;) {
-        int rs = br.decode(ha);
-        if (rs < 0) { *err = "Bad Huffman code in AC"; return ZJ_ERR_HUFFMAN; }
-        int r = rs >> 4, sz = rs & 15;
+        if (br.nbits < 32) br.fill(); // a code (<= 16 bits) and its magnitude bits (<= 15) without another refill
+        const uint32_t look9 = br.peek(9);
+        const int16_t fa = ha.fast[look9];
+        if (fa) { // short code + small value: run, magnitude and sign from one table entry
+            k += (fa >> 4) & 15;
+            br.drop(fa & 15);
+            blk[kUnZigzag[k & 63]] = (int16_t)(fa >> 8);
+            k++;
+            continue;
+        }
+        int rs;
+        const uint16_t e = ha.look[look9];
+        if (e) { br.drop(e >> 8); rs = e & 0xff; }
+        else {
+            rs = br.decode(ha);
+            if (rs < 0) { *err = "Bad Huffman code in AC"; return ZJ_ERR_HUFFMAN; }
+        }
+        const int r = rs >> 4, sz = rs & 15;
         if (sz) {
             k += r;
-            int32_t v = extend(br.get(sz), sz);
+            const int32_t bits = (int32_t)br.peek(sz);
+            br.drop(sz);
+            // EXTEND (T.81 F.2.2.1) without a branch: values below 2^(sz-1) are negative
+            const int32_t v = bits + ((((bits - (1 << (sz - 1))) >> 31)) & (1 - (1 << sz)));
             blk[kUnZigzag[k & 63]] = (int16_t)v;
             k++;
         } else if (r == 15) {
@@ -534,11 +581,21 @@ int scan_baseline(zj_decoder* d, BitReader& br)
                 if (scan_baseline_segment(d, d, seg[(size_t)k], seg[(size_t)k + 1], m0, n, &err)) bad.store(1);
             });
             if (!bad.load()) { br.p = seg[(size_t)nseg]; br.reset(); d->dri_parallel_segments = nseg; return ZJ_OK; }
-            for (int i = 0; i < d->ncomp; i++) memset(d->comps[i].coef, 0, d->comps[i].coef_len * 2);
+            // (the serial walk below clears every block again before it writes into it)
         }
     }
     d->dri_parallel_segments = 0;
     int todo = d->restart_interval ? d->restart_interval : 0x7fffffff;
+    // blocks of MCUs from (mx, my) on that the walk never reached stay zero, like the reference's fresh vectors
+    auto clear_from = [&](int my0, int mx0) {
+        for (int my = my0; my < d->mcu_y; my++)
+            for (int mx = (my == my0 ? mx0 : 0); mx < d->mcu_x; mx++)
+                for (int ci = 0; ci < d->ncomp; ci++) {
+                    Comp& cm = d->comps[ci];
+                    for (int v = 0; v < cm.v; v++)
+                        for (int h = 0; h < cm.h; h++) memset(block_at(cm, mx * cm.h + h, my * cm.v + v), 0, 128);
+                }
+    };
     // (2,1): the reference walks 2*mcu_x MCUs per strip (mcu.rs:145-152); MCU order is unchanged
     for (int my = 0; my < d->mcu_y; my++)
         for (int mx = 0; mx < d->mcu_x; mx++) {
@@ -548,11 +605,11 @@ int scan_baseline(zj_decoder* d, BitReader& br)
                     for (int h = 0; h < cm.h; h++) {
                         const char* err = nullptr;
                         int rc = decode_block_baseline(d, br, cm, cm.dc_pred, block_at(cm, mx * cm.h + h, my * cm.v + v), &err);
-                        if (rc) return fail(d, rc, err);
+                        if (rc) { clear_from(my, mx); return fail(d, rc, err); }
                     }
             }
-            if (--todo == 0) { int rc = handle_restart(d, br, todo); if (rc) return rc; }
-            if (br.marker == 0xD9 && br.nbits <= 0) return ZJ_OK;
+            if (--todo == 0) { int rc = handle_restart(d, br, todo); if (rc) { clear_from(my, mx + 1); return rc; } }
+            if (br.marker == 0xD9 && br.nbits <= 0) { clear_from(my, mx + 1); return ZJ_OK; }
         }
     return ZJ_OK;
 }
