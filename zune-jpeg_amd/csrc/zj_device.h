@@ -124,28 +124,48 @@ ZJ_DEV int uniform(int v)
 #else
 #define ZJ_PIN(x) asm volatile("" : "+v"(x))
 #endif
-ZJ_DEV void idct_1d(const int32_t s[8], const int32_t bias, int32_t o[8])
+// The transform is written as two halves -- every multiply / multiply-add first, the butterfly adds after --
+// so that idct_block can put the add/shift halves of two transforms next to each other behind a scheduling
+// barrier: simple VOP2 instructions issue faster next to each other than interleaved with multiplies
+// (profiles/r01_ubench_valu_issue_cost.txt; -3.4 % on the isolated IDCT, profiles/r01_lab_*).
+struct IdctHalf { int32_t t0, t1, t2, t3, u0, u1, u2, u3; };
+ZJ_DEV IdctHalf idct_1d_mul(const int32_t s[8], const int32_t bias)
 {
+    IdctHalf h;
     // even part: t3 = (s2+s6)*2217 + s2*3135, t2 = (s2+s6)*2217 - s6*7567      (scalar.rs:81-87)
-    int32_t t3 = mul24(s[2], 2217 + 3135); ZJ_PIN(t3); t3 = mad24(s[6], 2217, t3);
-    int32_t t2 = mul24(s[2], 2217); ZJ_PIN(t2); t2 = mad24(s[6], 2217 - 7567, t2);
+    h.t3 = mul24(s[2], 2217 + 3135); ZJ_PIN(h.t3); h.t3 = mad24(s[6], 2217, h.t3);
+    h.t2 = mul24(s[2], 2217); ZJ_PIN(h.t2); h.t2 = mad24(s[6], 2217 - 7567, h.t2);
     // t0 = fsh(s0+s4) + bias, t1 = fsh(s0-s4) + bias                           (:93-99)
     int32_t A = wadd(wshl(s[0], 12), bias); ZJ_PIN(A);
-    int32_t t0 = wadd(wshl(s[4], 12), A); ZJ_PIN(t0); // v_lshl_add_u32
-    const int32_t t1 = mad24(s[4], -4096, A);
-    const int32_t x0 = wadd(t0, t3), x3 = wsub(t0, t3), x1 = wadd(t1, t2), x2 = wsub(t1, t2);
+    h.t0 = wadd(wshl(s[4], 12), A); ZJ_PIN(h.t0); // v_lshl_add_u32
+    h.t1 = mad24(s[4], -4096, A);
     // odd part (scalar.rs:109-148) as the integer matrix it is; a=s7 b=s5 c=s3 d=s1
     //   u3 = d*6149 + p1 + p4 ... expanded: e.g. coefficient of d in u3 = 6149 + 4816 - 3685 - 1597
     const int32_t a = s[7], b = s[5], c = s[3], d = s[1];
-    int32_t u3 = mul24(d, 6149 + 4816 - 3685 - 1597); ZJ_PIN(u3); u3 = mad24(a, 4816 - 3685, u3); ZJ_PIN(u3); u3 = mad24(b, 4816 - 1597, u3); ZJ_PIN(u3); u3 = mad24(c, 4816, u3);
-    int32_t u2 = mul24(c, 12586 + 4816 - 10497 - 8034); ZJ_PIN(u2); u2 = mad24(b, 4816 - 10497, u2); ZJ_PIN(u2); u2 = mad24(a, 4816 - 8034, u2); ZJ_PIN(u2); u2 = mad24(d, 4816, u2);
-    int32_t u1 = mul24(b, 8410 + 4816 - 10497 - 1597); ZJ_PIN(u1); u1 = mad24(c, 4816 - 10497, u1); ZJ_PIN(u1); u1 = mad24(d, 4816 - 1597, u1); ZJ_PIN(u1); u1 = mad24(a, 4816, u1);
-    int32_t u0 = mul24(a, 1223 + 4816 - 3685 - 8034); ZJ_PIN(u0); u0 = mad24(d, 4816 - 3685, u0); ZJ_PIN(u0); u0 = mad24(c, 4816 - 8034, u0); ZJ_PIN(u0); u0 = mad24(b, 4816, u0);
-    o[0] = wadd(x0, u3); o[7] = wsub(x0, u3);
-    o[1] = wadd(x1, u2); o[6] = wsub(x1, u2);
-    o[2] = wadd(x2, u1); o[5] = wsub(x2, u1);
-    o[3] = wadd(x3, u0); o[4] = wsub(x3, u0);
+    h.u3 = mul24(d, 6149 + 4816 - 3685 - 1597); ZJ_PIN(h.u3); h.u3 = mad24(a, 4816 - 3685, h.u3); ZJ_PIN(h.u3); h.u3 = mad24(b, 4816 - 1597, h.u3); ZJ_PIN(h.u3); h.u3 = mad24(c, 4816, h.u3);
+    h.u2 = mul24(c, 12586 + 4816 - 10497 - 8034); ZJ_PIN(h.u2); h.u2 = mad24(b, 4816 - 10497, h.u2); ZJ_PIN(h.u2); h.u2 = mad24(a, 4816 - 8034, h.u2); ZJ_PIN(h.u2); h.u2 = mad24(d, 4816, h.u2);
+    h.u1 = mul24(b, 8410 + 4816 - 10497 - 1597); ZJ_PIN(h.u1); h.u1 = mad24(c, 4816 - 10497, h.u1); ZJ_PIN(h.u1); h.u1 = mad24(d, 4816 - 1597, h.u1); ZJ_PIN(h.u1); h.u1 = mad24(a, 4816, h.u1);
+    h.u0 = mul24(a, 1223 + 4816 - 3685 - 8034); ZJ_PIN(h.u0); h.u0 = mad24(d, 4816 - 3685, h.u0); ZJ_PIN(h.u0); h.u0 = mad24(c, 4816 - 8034, h.u0); ZJ_PIN(h.u0); h.u0 = mad24(b, 4816, h.u0);
+    return h;
 }
+ZJ_DEV void idct_1d_add(const IdctHalf& h, int32_t o[8])
+{
+    const int32_t x0 = wadd(h.t0, h.t3), x3 = wsub(h.t0, h.t3), x1 = wadd(h.t1, h.t2), x2 = wsub(h.t1, h.t2);
+    o[0] = wadd(x0, h.u3); o[7] = wsub(x0, h.u3);
+    o[1] = wadd(x1, h.u2); o[6] = wsub(x1, h.u2);
+    o[2] = wadd(x2, h.u1); o[5] = wsub(x2, h.u1);
+    o[3] = wadd(x3, h.u0); o[4] = wsub(x3, h.u0);
+}
+ZJ_DEV void idct_1d(const int32_t s[8], const int32_t bias, int32_t o[8])
+{
+    const IdctHalf h = idct_1d_mul(s, bias);
+    idct_1d_add(h, o);
+}
+#if defined(ZJ_EMU)
+#define ZJ_SCHED_BARRIER() ((void)0)
+#else
+#define ZJ_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 ZJ_DEV int32_t lo16s(uint32_t v) { return (int32_t)(int16_t)(v & 0xffff); }
 ZJ_DEV int32_t hi16s(uint32_t v) { return (int32_t)v >> 16; }
@@ -186,35 +206,57 @@ ZJ_DEV void idct_block(const U4 raw[8], const int32_t* qt, U4 out[8])
 {
     const uint32_t* w = reinterpret_cast<const uint32_t*>(raw);
     int32_t tmp[64];
+    constexpr int G = 2; // transforms per group: multiply halves of G lines, barrier, their add/shift halves
     // pass 1: columns (scalar.rs:79-167), bias 512, >> 10
 #pragma unroll
-    for (int col = 0; col < 8; col++) {
-        int32_t s[8], o[8];
+    for (int c0 = 0; c0 < 8; c0 += G) {
+        IdctHalf h[G];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint32_t pair = w[k * 4 + (col >> 1)];
-            const int32_t cf = (col & 1) ? hi16s(pair) : lo16s(pair);
-            s[k] = mul24(cf, qt[k * 8 + col]); // dequantize (scalar.rs:308); q is 0..255
+        for (int g = 0; g < G; g++) {
+            const int col = c0 + g;
+            int32_t s[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t pair = w[k * 4 + (col >> 1)];
+                const int32_t cf = (col & 1) ? hi16s(pair) : lo16s(pair);
+                s[k] = mul24(cf, qt[k * 8 + col]); // dequantize (scalar.rs:308); q is 0..255
+            }
+            h[g] = idct_1d_mul(s, 512);
         }
-        idct_1d(s, 512, o);
+        ZJ_SCHED_BARRIER();
 #pragma unroll
-        for (int k = 0; k < 8; k++) tmp[k * 8 + col] = o[k] >> 10;
+        for (int g = 0; g < G; g++) {
+            int32_t o[8];
+            idct_1d_add(h[g], o);
+#pragma unroll
+            for (int k = 0; k < 8; k++) tmp[k * 8 + c0 + g] = o[k] >> 10;
+        }
+        ZJ_SCHED_BARRIER();
     }
     // pass 2: rows (scalar.rs:170-274), bias SCALE_BITS, >> 17, clamp
     constexpr int32_t bias2 = 512 + 65536 + (128 << 17);
     uint32_t* ow = reinterpret_cast<uint32_t*>(out);
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        int32_t o[8];
-        idct_1d(&tmp[r * 8], bias2, o);
+    for (int r0 = 0; r0 < 8; r0 += G) {
+        IdctHalf h[G];
 #pragma unroll
-        for (int k = 0; k < 8; k += 2) {
-            // x >> 17 == (x >> 16) >> 1: one v_perm_b32 gathers the two high halves (x >> 16 as i16), one packed
-            // shift finishes both, then both lanes are clamped at once (4 instructions per pair instead of 5)
-            const uint32_t hi = perm((uint32_t)o[k + 1], (uint32_t)o[k], 0x07060302u);
-            const s16x2 z = {0, 0}, m = {255, 255};
-            ow[r * 4 + (k >> 1)] = as_u32(pk_min(pk_max(sar(as_u16x2(hi), 1), z), m));
-        }
+        for (int g = 0; g < G; g++) h[g] = idct_1d_mul(&tmp[(r0 + g) * 8], bias2);
+        ZJ_SCHED_BARRIER();
+        int32_t o[G][8];
+#pragma unroll
+        for (int g = 0; g < G; g++) idct_1d_add(h[g], o[g]);
+        ZJ_SCHED_BARRIER();
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {
+                // x >> 17 == (x >> 16) >> 1: one v_perm_b32 gathers the two high halves (x >> 16 as i16), one packed
+                // shift finishes both, then both lanes are clamped at once (4 instructions per pair instead of 5)
+                const uint32_t hi = perm((uint32_t)o[g][k + 1], (uint32_t)o[g][k], 0x07060302u);
+                const s16x2 z = {0, 0}, m = {255, 255};
+                ow[(r0 + g) * 4 + (k >> 1)] = as_u32(pk_min(pk_max(sar(as_u16x2(hi), 1), z), m));
+            }
+        ZJ_SCHED_BARRIER();
     }
 }
 

@@ -56,6 +56,88 @@ __device__ __forceinline__ void lab_1d(const int32_t s[8], const int32_t bias, i
     o[3] = wadd(x3, u0); o[4] = wsub(x3, u0);
 }
 
+// ---- "grouped" formulation: the multiply half of G transforms, then their add/shift half, separated by
+// scheduling barriers, so that simple VOP2 instructions (add/sub/shift: ~2.3 cycles in pure runs, ~3.5-4 when
+// mixed with multiplies, profiles/r01_ubench_valu_issue_cost.txt) sit next to each other
+struct LabHalf { int32_t t0, t1, t2, t3, u0, u1, u2, u3; };
+__device__ __forceinline__ LabHalf lab_1d_mul(const int32_t s[8], const int32_t bias)
+{
+    auto K = [](int32_t& x) { asm volatile("" : "+v"(x)); };
+    LabHalf h;
+    h.t3 = mul24(s[2], 2217 + 3135); K(h.t3); h.t3 = mad24(s[6], 2217, h.t3);
+    h.t2 = mul24(s[2], 2217); K(h.t2); h.t2 = mad24(s[6], 2217 - 7567, h.t2);
+    int32_t A = wadd(wshl(s[0], 12), bias); K(A);
+    h.t0 = wadd(wshl(s[4], 12), A); K(h.t0);
+    h.t1 = mad24(s[4], -4096, A);
+    const int32_t a = s[7], b = s[5], c = s[3], d = s[1];
+    h.u3 = mul24(d, 5683); K(h.u3); h.u3 = mad24(a, 1131, h.u3); K(h.u3); h.u3 = mad24(b, 3219, h.u3); K(h.u3); h.u3 = mad24(c, 4816, h.u3);
+    h.u2 = mul24(c, -1129); K(h.u2); h.u2 = mad24(b, -5681, h.u2); K(h.u2); h.u2 = mad24(a, -3218, h.u2); K(h.u2); h.u2 = mad24(d, 4816, h.u2);
+    h.u1 = mul24(b, 1132); K(h.u1); h.u1 = mad24(c, -5681, h.u1); K(h.u1); h.u1 = mad24(d, 3219, h.u1); K(h.u1); h.u1 = mad24(a, 4816, h.u1);
+    h.u0 = mul24(a, -5680); K(h.u0); h.u0 = mad24(d, 1131, h.u0); K(h.u0); h.u0 = mad24(c, -3218, h.u0); K(h.u0); h.u0 = mad24(b, 4816, h.u0);
+    return h;
+}
+__device__ __forceinline__ void lab_1d_add(const LabHalf& h, int32_t o[8])
+{
+    const int32_t x0 = wadd(h.t0, h.t3), x3 = wsub(h.t0, h.t3), x1 = wadd(h.t1, h.t2), x2 = wsub(h.t1, h.t2);
+    o[0] = wadd(x0, h.u3); o[7] = wsub(x0, h.u3);
+    o[1] = wadd(x1, h.u2); o[6] = wsub(x1, h.u2);
+    o[2] = wadd(x2, h.u1); o[5] = wsub(x2, h.u1);
+    o[3] = wadd(x3, h.u0); o[4] = wsub(x3, h.u0);
+}
+template <int G>
+__device__ __forceinline__ void lab_block_grouped(const U4 raw[8], const int32_t* qt, U4 out[8])
+{
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(raw);
+    int32_t tmp[64];
+#pragma unroll
+    for (int c0 = 0; c0 < 8; c0 += G) {
+        LabHalf h[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int col = c0 + g;
+            int32_t s[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t pair = w[k * 4 + (col >> 1)];
+                const int32_t cf = (col & 1) ? hi16s(pair) : lo16s(pair);
+                s[k] = mul24(cf, qt[k * 8 + col]);
+            }
+            h[g] = lab_1d_mul(s, 512);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            int32_t o[8];
+            lab_1d_add(h[g], o);
+#pragma unroll
+            for (int k = 0; k < 8; k++) tmp[k * 8 + c0 + g] = o[k] >> 10;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    constexpr int32_t bias2 = 512 + 65536 + (128 << 17);
+    uint32_t* ow = reinterpret_cast<uint32_t*>(out);
+#pragma unroll
+    for (int r0 = 0; r0 < 8; r0 += G) {
+        LabHalf h[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) h[g] = lab_1d_mul(&tmp[(r0 + g) * 8], bias2);
+        __builtin_amdgcn_sched_barrier(0);
+        int32_t o[G][8];
+#pragma unroll
+        for (int g = 0; g < G; g++) lab_1d_add(h[g], o[g]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {
+                const uint32_t hi = perm((uint32_t)o[g][k + 1], (uint32_t)o[g][k], 0x07060302u);
+                const s16x2 z = {0, 0}, m = {255, 255};
+                ow[(r0 + g) * 4 + (k >> 1)] = as_u32(pk_min(pk_max(sar(as_u16x2(hi), 1), z), m));
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // FIN: 0 = med3 + lshl_or (shipped), 1 = pack first then packed clamp
 template <int V1, int V2, int FIN>
 __device__ __forceinline__ void lab_block(const U4 raw[8], const int32_t* qt, U4 out[8])
@@ -116,7 +198,9 @@ __global__ __launch_bounds__(256) void lab_idct(const int32_t* __restrict__ qt_g
     }
     for (int it = 0; it < iters; it++) {
         U4 px[8];
-        lab_block<V1, V2, FIN>(raw, qt, px);
+        if (V1 >= 10) lab_block_grouped<(V1 >= 10 ? V1 - 10 : 1)>(raw, qt, px);
+        else if (FIN == 2) idct_block(raw, qt, px); // the shipped block function
+        else lab_block<(V1 >= 10 ? 0 : V1), V2, (FIN == 2 ? 1 : FIN)>(raw, qt, px);
 #pragma unroll
         for (int i = 0; i < 8; i++) raw[i] = px[i]; // dependent chain: nothing can be hoisted
     }
@@ -211,6 +295,10 @@ static const struct { const char* name; lab_fn fn; } LAB[] = {
     {"idct pinned/stb24    pkclamp qt=LDS", lab_idct<3, 1, 1, 0>},
     {"idct stb32/stb24     pkclamp qt=LDS", lab_idct<2, 1, 1, 0>},
     {"idct pinned/pinned   pkclamp qt=SGPR", lab_idct<3, 3, 1, 1>},
+    {"idct_block as shipped (perm epilogue)  qt=LDS", lab_idct<3, 3, 2, 0>},
+    {"idct grouped x1 (mul half | add half) qt=LDS", lab_idct<11, 3, 1, 0>},
+    {"idct grouped x2                       qt=LDS", lab_idct<12, 3, 1, 0>},
+    {"idct grouped x4                       qt=LDS", lab_idct<14, 3, 1, 0>},
 };
 // tile-shaped copy: each workgroup writes 32 row segments of S bytes (row pitch 12288 B = 4096 px RGB)
 // and reads the same amount contiguously (RDT = 0) or as 4+2+2 block-row segments like the decoder (RDT = 1)
