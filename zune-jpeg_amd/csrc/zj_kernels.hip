@@ -30,7 +30,8 @@ namespace zj {
 
 template <int HS, int VS, int OUT, int COMPACT, bool FAST>
 // 2nd launch bound = waves per SIMD: 5 workgroups of 4 waves per CU need <= 96 VGPRs; LDS (32.7 KB
-// per workgroup for 4:2:0) allows exactly 5.  At 4 the VALU idles ~16% (profiles/r01_v4_pmc_sq.txt).
+// per workgroup for 4:2:0) allows exactly 5.  Measured with tools/occupancy.py: 5 and 4 workgroups per CU
+// run the same, 3 cost 7 %, 2 cost 29 % -- the bound keeps the kernel on the flat part.
 __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), ZJ_WAVES_PER_SIMD) void zj_fused_kernel(const Params p)
 {
     using C = Cfg<HS, VS, OUT>;
