@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--frames", type=int, default=16, help="4096x4096 frames per GPU per step")
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic frames generated (tiled to --frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-frame", action="store_true",
+                    help="also time ONE frame per launch (configs[1] read literally); off by default so that a profiler "
+                         "run of this command sees a single launch shape")
     ap.add_argument("--workload", choices=["420-rgb", "444-rgb", "444-gray", "420-rgba", "420-chw"], default="420-rgb",
                     help="420-rgb = BASELINE.json configs[1] (the headline); 444-* are configs[2]; 420-rgba / 420-chw are "
                          "the output extensions (4 B/px interleaved, planar u8)")
@@ -154,7 +157,9 @@ def main():
     kernel_ms, kernel_ms_each, kname = ctx.time_decode_device(desc, B, ptrs[0], ptrs[1], ptrs[2], ptrs[3], kiters, stream)
     # configs[1] read literally is ONE 4096x4096 frame per launch: time that shape too (1664 workgroups = 1.3 waves of
     # the chip's 1280 workgroup slots, so the tail of every launch is exposed); reported beside the batched figure
-    one_ms, one_ms_each, _ = ctx.time_decode_device(desc, 1, ptrs[0], ptrs[1], ptrs[2], ptrs[3], 200, stream)
+    one_ms = one_ms_each = None
+    if args.single_frame:
+        one_ms, one_ms_each, _ = ctx.time_decode_device(desc, 1, ptrs[0], ptrs[1], ptrs[2], ptrs[3], 200, stream)
     # trivial gather: per-rank checksum of frame 0 (all ranks decode the same synthetic seeds modulo shard)
     torch.cuda.synchronize()
     first = d_out[: W * H * out_cs.num_components()].cpu().numpy()
@@ -199,10 +204,11 @@ def main():
                          "kernel": kname, "kernel_ms": round(kernel_ms, 4), "kernel_ms_single_launch": round(kernel_ms_each, 4),
                          "algorithmic_bytes_per_launch": int(algo_bytes),
                          "traffic_source": (tr or {}).get("source"), "valu_issue": valu,
-                         "single_frame_launch": {"kernel_ms": round(one_ms, 4), "kernel_ms_single_launch": round(one_ms_each, 4),
-                                                 "megapixels_per_s": round(W * H / 1e6 / (one_ms * 1e-3), 1),
-                                                 "achieved": round(W * H * bytes_per_px / (one_ms * 1e-3) / 1e9, 1),
-                                                 "frac": round(W * H * bytes_per_px / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
+                         "single_frame_launch": None if one_ms is None else {
+                             "kernel_ms": round(one_ms, 4), "kernel_ms_single_launch": round(one_ms_each, 4),
+                             "megapixels_per_s": round(W * H / 1e6 / (one_ms * 1e-3), 1),
+                             "achieved": round(W * H * bytes_per_px / (one_ms * 1e-3) / 1e9, 1),
+                             "frac": round(W * H * bytes_per_px / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
             # every rank's first frame is synthetic frame (rank*B) % distinct: identical data when B % distinct == 0
             "checksums_equal_across_ranks": (len({tuple(s) for s in sums}) == 1) if (world > 1 and B % max(args.distinct, 1) == 0) else None,
         }
