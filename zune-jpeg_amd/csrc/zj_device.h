@@ -166,6 +166,15 @@ ZJ_DEV void idct_1d(const int32_t s[8], const int32_t bias, int32_t o[8])
 #else
 #define ZJ_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
+#ifndef ZJ_IDCT_G
+#define ZJ_IDCT_G 2 // 1, 2 and 4 measure the same within noise in the full kernel (tools/ab_libs.sh); 8 spills
+#endif
+// experiment knob: scheduling barriers between the stages of the colour phase (filters | colour math | packing)
+#if defined(ZJ_COLOR_STAGES) && !defined(ZJ_EMU)
+#define ZJ_COLOR_SB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define ZJ_COLOR_SB() ((void)0)
+#endif
 
 ZJ_DEV int32_t lo16s(uint32_t v) { return (int32_t)(int16_t)(v & 0xffff); }
 ZJ_DEV int32_t hi16s(uint32_t v) { return (int32_t)v >> 16; }
@@ -206,7 +215,7 @@ ZJ_DEV void idct_block(const U4 raw[8], const int32_t* qt, U4 out[8])
 {
     const uint32_t* w = reinterpret_cast<const uint32_t*>(raw);
     int32_t tmp[64];
-    constexpr int G = 2; // transforms per group: multiply halves of G lines, barrier, their add/shift halves
+    constexpr int G = ZJ_IDCT_G; // transforms per group: multiply halves of G lines, barrier, their add/shift halves
     // pass 1: columns (scalar.rs:79-167), bias 512, >> 10
 #pragma unroll
     for (int c0 = 0; c0 < 8; c0 += G) {
@@ -864,6 +873,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const in
             }
         }
 
+        ZJ_COLOR_SB();
         // ---- luma pairing to match the chroma arrangement ---------------------------------------
         uint32_t yp[8];
         if (HS == 2) {
@@ -879,6 +889,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const in
 
         uint32_t d[12];
         RGB2 c[8];
+        ZJ_COLOR_SB();
 #pragma unroll
         for (int k = 0; k < 8; k++)
             c[k] = (OUT != OUT_YCBCR && !ZJ_ABL(p.debug, 2)) ? ycc_to_rgb_pair(yp[k], cbp[k], crp[k]) : trunc3(yp[k], cbp[k], crp[k]);
@@ -917,6 +928,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const in
             }
             continue;
         }
+        ZJ_COLOR_SB();
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (HS == 2) pack_rgb4_eo(c[k], c[4 + k], d[3 * k], d[3 * k + 1], d[3 * k + 2]);
