@@ -118,7 +118,9 @@ int zj_abi_version(void);
 int zj_device_count(void);                              /* <0: zj_status */
 zj_ctx *zj_ctx_create(int backend, int device, int *status);
 void zj_ctx_destroy(zj_ctx *ctx);
-zj_ctx *zj_default_ctx(void);        /* lazily created ctx on device 0 (for fn-pointer shims) */
+zj_ctx *zj_default_ctx(void);        /* the calling thread's own lazily created ctx on device 0, for the fn-pointer
+                                        shims (the reference calls them from several worker threads at once);
+                                        recycled to the next new thread when its thread ends; never destroy it */
 const char *zj_strerror(int status);
 const char *zj_last_error(const zj_ctx *ctx);           /* detail of the last ZJ_ERR_HIP */
 

@@ -543,3 +543,40 @@ def test_random_geometry_sweep_all_output_kinds(ctx, zj, synth):
         assert_same(ctx.decode_planes(d, planes), exp, (case, w, h, mode, kind))
         done += 1
     assert done > 220
+
+
+def test_default_ctx_is_per_thread_and_safe_under_concurrency(zj, synth):
+    """The fn-pointer shims use zj_default_ctx() and the reference calls them from four worker threads at once
+    (src/mcu.rs:356, fresh threads per decode): every thread gets its own context, contexts of finished threads are
+    reused, and concurrent strip calls return the oracle's values."""
+    import ctypes as C
+    import threading
+    L = zj.lib()
+    rng = np.random.default_rng(5)
+    qt = rng.integers(1, 256, 64).astype(np.int32)
+    jobs = []
+    for i in range(8):
+        coeff = synth.make_frame(512, 8, 1, 1, 3, seed=900 + i)[0][0].astype(np.int16)  # one block row, 64 blocks
+        rc, exp = oc.idct_strip(coeff, qt, 512, 1, 1)
+        assert rc == 0
+        jobs.append((coeff, exp))
+    L.zj_idct_strip.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+    seen, errors = [], []
+
+    def worker(k):
+        ctx = L.zj_default_ctx()
+        seen.append(ctx)
+        for rep in range(20):
+            coeff, exp = jobs[(k + rep) % len(jobs)]
+            out = np.empty_like(coeff)
+            rc = L.zj_idct_strip(ctx, coeff.ctypes.data, coeff.size, qt.ctypes.data, 512, 1, 1, out.ctypes.data)
+            if rc != 0 or not np.array_equal(out, exp):
+                errors.append((k, rep, rc))
+
+    for round_ in range(2):  # second round: new threads pick up the recycled contexts
+        ts = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+    assert not errors, errors[:4]
+    assert len(set(seen[:4])) == 4            # four concurrent threads, four contexts
+    assert set(seen[4:]) <= set(seen[:4])     # recycled, not rebuilt

@@ -9,6 +9,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/zjhip.h"
 #include "zj_launch.h"
@@ -196,13 +197,33 @@ void zj_ctx_destroy(zj_ctx* c)
     delete c;
 }
 
+// The reference's fn-pointer types carry no context argument and are called concurrently from its
+// worker threads (src/mcu.rs:356), so the context the shims use is per calling thread.  The reference
+// makes a fresh pool for every decode (src/mcu.rs:135): contexts of finished threads go to a free list
+// and are handed to the next new thread instead of being rebuilt (streams, scratch, tables).
+namespace {
+std::mutex g_def_mu;
+std::vector<zj_ctx*> g_def_free;
+struct TlsDefaultCtx {
+    zj_ctx* c = nullptr;
+    ~TlsDefaultCtx() // no HIP calls here: thread-exit order against the runtime's teardown is not ours
+    {
+        if (!c) return;
+        std::lock_guard<std::mutex> lk(g_def_mu);
+        g_def_free.push_back(c);
+    }
+};
+}
+
 zj_ctx* zj_default_ctx(void)
 {
-    static std::mutex mu;
-    static zj_ctx* def = nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    if (!def) { int st; def = zj_ctx_create(ZJ_BACKEND_HIP, 0, &st); }
-    return def;
+    thread_local TlsDefaultCtx t;
+    if (!t.c) {
+        std::lock_guard<std::mutex> lk(g_def_mu);
+        if (!g_def_free.empty()) { t.c = g_def_free.back(); g_def_free.pop_back(); }
+    }
+    if (!t.c) { int st; t.c = zj_ctx_create(ZJ_BACKEND_HIP, 0, &st); }
+    return t.c;
 }
 
 int zj_num_components(int cs) { return ncomp_of(cs); }
