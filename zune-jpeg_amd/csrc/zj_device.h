@@ -161,7 +161,7 @@ ZJ_DEV void idct_1d(const int32_t s[8], const int32_t bias, int32_t o[8])
     const IdctHalf h = idct_1d_mul(s, bias);
     idct_1d_add(h, o);
 }
-#if defined(ZJ_EMU)
+#if defined(ZJ_EMU) || defined(ZJ_IDCT_NOBARRIER)
 #define ZJ_SCHED_BARRIER() ((void)0)
 #else
 #define ZJ_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
