@@ -18,11 +18,28 @@ static int g_compact = 0, g_persistent_wgs = 24;
 extern "C" void zje_set_variant(int compact) { g_compact = compact; }
 extern "C" void zje_set_persistent_wgs(int n) { g_persistent_wgs = n; }
 
+// phase 2 for every lane of the workgroup; with transposed stores (variants 4 and 7) a round is two half-steps per
+// wave: all lanes stage, then all lanes copy out (the GPU runs them back to back inside each wave)
+template <class C, int HS, int VS, int OUT, bool FAST>
+static void color_all(const Params& p, const TileId t, int16_t* lds)
+{
+    constexpr bool CAN_TS = FAST && (OUT == OUT_RGB || OUT == OUT_YCBCR);
+    if (CAN_TS && (g_compact & 4) && ts_eligible<C>(p, OUT, FAST)) {
+        for (int round = 0; round * C::NT < C::NITEMS; round++)
+            for (int w = 0; w < C::NT / 64; w++) {
+                for (int l = 0; l < 64; l++) phase_color<C, HS, VS, OUT, FAST, CAN_TS>(p, t, 64 * w + l, lds, round);
+                for (int l = 0; l < 64; l++) color_copyout<C, OUT>(p, t, 64 * w + l, lds, round);
+            }
+        return;
+    }
+    for (int tid = 0; tid < C::NT; tid++) phase_color<C, HS, VS, OUT, FAST>(p, t, tid, lds);
+}
+
 template <int HS, int VS, int OUT, bool FAST>
 static void run(const Params& p)
 {
     using C = Cfg<HS, VS, OUT>;
-    std::vector<char> lds_store(C::LDS_BYTES_COMPACT + 32);
+    std::vector<char> lds_store(C::LDS_BYTES_TS + 32);
     // 16-byte aligned like a real LDS allocation
     int16_t* lds = (int16_t*)(((uintptr_t)lds_store.data() + 15) & ~(uintptr_t)15);
     if (g_compact == 2 && FAST) { // persistent walk: every tile exactly once, in each workgroup's order
@@ -45,10 +62,28 @@ static void run(const Params& p)
         return;
     }
     for (int bid = 0; bid < p.total_tiles; bid++) {
-        memset(lds, 0x7B, C::LDS_BYTES_COMPACT); // poison: unwritten LDS must not matter
+        memset(lds, 0x7B, C::LDS_BYTES_TS); // poison: unwritten LDS must not matter
         const TileId t = decode_tile(p, bid);
         for (int tid = 0; tid < C::NT; tid++) phase_setup<C, HS, VS>(p, tid, lds);
         /* __syncthreads() */
+        if ((g_compact & 3) == 3 && FAST) { // work stealing: stage (all lanes), barrier, take + IDCT (all lanes)
+            std::vector<StealState> st(C::NT);
+            for (int tid = 0; tid < C::NT; tid++) {
+                const BlockLoc L = locate<C>(p, t, tid, lds);
+                U4 raw[8];
+                load_block(L, raw);
+                st[tid] = steal_stage<C>(L, raw, p.qt[64 * L.comp], tid, lds);
+            }
+            /* __syncthreads() */
+            for (int tid = 0; tid < C::NT; tid++) {
+                const BlockLoc L = locate<C>(p, t, tid, lds);
+                U4 raw[8];
+                load_block(L, raw); // registers survive the barrier on the GPU; the emulator reloads
+                steal_idct<C>(L, raw, st[tid], tid, lds);
+            }
+            color_all<C, HS, VS, OUT, FAST>(p, t, lds);
+            continue;
+        }
         for (int tid = 0; tid < C::NT; tid++) {
             const BlockLoc L = locate<C>(p, t, tid, lds);
             U4 raw[8];
@@ -61,7 +96,7 @@ static void run(const Params& p)
             for (int tid = 0; tid < C::NT; tid++) idct_queue<C>(tid, lds);
             /* __syncthreads() */
         }
-        for (int tid = 0; tid < C::NT; tid++) phase_color<C, HS, VS, OUT, FAST>(p, t, tid, lds);
+        color_all<C, HS, VS, OUT, FAST>(p, t, lds);
     }
 }
 

@@ -21,7 +21,7 @@ def _default_variant():
 @pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("out_cs", [oc.RGB, oc.GRAYSCALE, oc.YCBCR])
 @pytest.mark.parametrize("wh", [(64, 64), (528, 40), (32, 8), (272, 100), (1040, 33), (2080, 16)])
-@pytest.mark.parametrize("compact", [0, 1, 2])
+@pytest.mark.parametrize("compact", [0, 1, 2, 3, 4, 7])
 def test_emulated_kernel_matches_oracle(mode, out_cs, wh, synth, compact):
     emu_c.set_variant(compact)
     hs, vs = MODES[mode]

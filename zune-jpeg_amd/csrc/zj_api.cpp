@@ -51,7 +51,7 @@ struct zj_ctx {
     int pipeline = 1;             // 0: one unit per call (no overlap), for A/B timing only
     std::string last_error;
     int debug = 0;                // ablation switches, diagnostics only (results are WRONG when set)
-    int compact = 0;              // kernel variant: 0 one pass per tile, 1 DC-only compaction, 2 persistent + prefetch
+    int compact = 0;              // kernel variant: 0 one pass per tile, 1 DC-only compaction, 2 persistent + prefetch, 3 work stealing, 4 transposed stores, 7 = 3 + 4
 };
 
 #define ZJ_HIP(ctx, call)                                                                          \
@@ -162,7 +162,7 @@ zj_ctx* zj_ctx_create(int backend, int device, int* status)
     zj_ctx* c = new (std::nothrow) zj_ctx();
     if (!c) { *status = ZJ_ERR_NOMEM; return nullptr; }
     c->device = device;
-    if (const char* e = getenv("ZJ_VARIANT")) { int v = atoi(e); if (v >= 0 && v <= 2) c->compact = v; }
+    if (const char* e = getenv("ZJ_VARIANT")) { int v = atoi(e); if ((v >= 0 && v <= 4) || v == 7) c->compact = v; }
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
               hipMalloc((void**)&c->d_qt, QT_SLOTS * 192 * sizeof(int32_t)) == hipSuccess &&
               hipHostMalloc((void**)&c->h_qt, QT_SLOTS * 192 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess &&
@@ -653,7 +653,7 @@ zj_color_convert16_fn zj_choose_ycbcr_to_rgb_convert_func(int backend, int out_c
 }
 
 /* kernel-variant switch for A/B measurements (both variants are bit-exact) */
-int zj_set_variant(zj_ctx* c, int variant) { if (!c || variant < 0 || variant > 2) return ZJ_ERR_ARG; c->compact = variant; return ZJ_OK; }
+int zj_set_variant(zj_ctx* c, int variant) { if (!c || variant < 0 || (variant > 4 && variant != 7)) return ZJ_ERR_ARG; c->compact = variant; return ZJ_OK; }
 /* 0 = one unit per zj_decode_planes_batch call (no copy/compute overlap); A/B timing only */
 int zj_set_pipeline(zj_ctx* c, int on) { if (!c) return ZJ_ERR_ARG; c->pipeline = on ? 1 : 0; return ZJ_OK; }
 int zj_set_persistent_grid(int wgs) { set_persistent_grid(wgs); return ZJ_OK; }

@@ -368,6 +368,11 @@ struct Cfg {
     static constexpr int QUEUE_OFF = HSTAGE_OFF + NHALO * 128;       // NT/64 waves x 64 entries x u32
     static constexpr int QCNT_OFF = QUEUE_OFF + (NT / 64) * 64 * 4;
     static constexpr int LDS_BYTES_COMPACT = QCNT_OFF + 32;
+    // transposed-store variant (TS): per wave, 64 x 16 bytes for the third piece of every item of a round (the first
+    // two pieces reuse the item's own, already consumed, luma slot)
+    static constexpr int XSTAGE_OFF = (LDS_BYTES_COMPACT + 15) / 16 * 16;
+    static constexpr int LDS_BYTES_TS = XSTAGE_OFF + (NT / 64) * 1024;
+    static constexpr int PIECES_PER_ROW = 3 * NGRP; // 16-byte pieces of a 3-byte-per-pixel tile row
     static_assert(PLANAR_I16 % 8 == 0, "planar area must keep 16-byte alignment");
     static_assert(NT <= 512 && NBLK <= NT, "one lane per block, at most 8 waves");
 };
@@ -696,6 +701,129 @@ ZJ_DEV void idct_queue(const int tid, int16_t* lds)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Work-stealing variant of phase 1 (COMPACT = 3).  Lanes whose block is DC-only (the reference's shortcut,
+// scalar.rs:45-74) sit idle while their wave runs the IDCT for the others.  Here the LAST wave of the
+// workgroup (the donor) stages the blocks of its lanes that need the full IDCT in LDS -- in the slot their
+// pixels will occupy, like COMPACT = 1 -- and the idle lanes of the other waves take one each, so those
+// waves run their single IDCT pass with (nearly) every lane busy and the donor wave skips its pass.
+// Compared with COMPACT = 1 only one wave's blocks travel through LDS and nobody re-reads its own block.
+//   steal_stage   every lane: DC-only test, DC-only blocks are finished; donor lanes stage + queue theirs;
+//                 other waves count their idle lanes (DC-only or no block)           -> rank, per-wave counts
+//   steal_idct    idle lane i of the non-donor waves takes donor entry i (if there is one), then every
+//                 lane with work runs idct_block once; donor lanes whose entry nobody took run their own
+// ------------------------------------------------------------------------------------------------
+// rank of this lane among the lanes of its wave for which pred holds; cnt_slot[wave] = how many do
+ZJ_DEV int wave_rank(int* cnt_slot, const int tid, const bool pred)
+{
+    const int w = tid >> 6, lane = tid & 63;
+#if defined(ZJ_EMU)
+    if (lane == 0) cnt_slot[w] = 0; // lanes of a wave run in order in the emulator
+    const int r = cnt_slot[w];
+    if (pred) cnt_slot[w] = r + 1;
+    return r;
+#else
+    const unsigned long long m = __ballot(pred);
+    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+    if (lane == 0) cnt_slot[w] = __popcll(m);
+    return rank;
+#endif
+}
+
+struct StealState { bool full; int rank; }; // full: this lane's own block needs the IDCT; rank: see steal_stage
+
+template <class C>
+ZJ_DEV StealState steal_stage(const BlockLoc& L, const U4 raw[8], const int32_t q0, const int tid, int16_t* lds)
+{
+    constexpr int DONOR = C::NT / 64 - 1;
+    const int w = tid >> 6;
+    StealState st;
+    st.full = false;
+    if (L.valid) {
+        const uint32_t* wd = reinterpret_cast<const uint32_t*>(raw);
+        uint32_t any = wd[0] & 0xffff0000u; // DC-only test (scalar.rs:45)
+#pragma unroll
+        for (int i = 1; i < 32; i++) any |= wd[i];
+        st.full = any != 0;
+        if (!st.full) {
+            const uint32_t v = dc_only_value(wd[0], q0);
+            const U4 row = {v, v, v, v};
+            if (L.halo == 0) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) *reinterpret_cast<U4*>(L.dst + r * L.pitch) = row;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; r++) L.dst[r * L.pitch] = (int16_t)v;
+            }
+        }
+    }
+    if (w == DONOR) { // rank among the donor's full blocks = queue position
+        st.rank = wave_rank(lds_qcnt<C>(lds), tid, st.full);
+        if (st.full) {
+            lds_queue<C>(lds)[st.rank] = (uint32_t)(L.dst - lds) | ((uint32_t)L.comp << 16) | ((uint32_t)L.halo << 18) | ((uint32_t)L.hslot << 20);
+            if (L.halo == 0) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) *reinterpret_cast<U4*>(L.dst + r * L.pitch) = raw[r];
+            } else {
+                U4* hs = reinterpret_cast<U4*>(lds_hstage<C>(lds) + 64 * L.hslot);
+#pragma unroll
+                for (int r = 0; r < 8; r++) hs[r] = raw[r];
+            }
+        }
+    } else {          // rank among this wave's idle lanes
+        st.rank = wave_rank(lds_qcnt<C>(lds), tid, !st.full);
+    }
+    return st;
+}
+
+template <class C>
+ZJ_DEV void steal_idct(const BlockLoc& Lown, U4 raw[8], const StealState st, const int tid, int16_t* lds)
+{
+    constexpr int NW = C::NT / 64, DONOR = NW - 1;
+    const int w = tid >> 6;
+    const int* qc = lds_qcnt<C>(lds);
+    const int offered = qc[DONOR];
+    int idle_before = 0, idle_total = 0;
+#pragma unroll
+    for (int k = 0; k < DONOR; k++) {
+        const int c = qc[k];
+        idle_before += (k < w) ? c : 0;
+        idle_total += c;
+    }
+    const int taken = offered < idle_total ? offered : idle_total;
+    BlockLoc L = Lown;
+    bool work;
+    if (w == DONOR) {
+        work = st.full && st.rank >= taken; // nobody took this one (more offers than idle lanes)
+    } else {
+        const int slot = idle_before + st.rank;
+        const bool take = !st.full && slot < taken;
+        if (take) {
+            const uint32_t e = lds_queue<C>(lds)[slot];
+            L.valid = true;
+            L.dst = lds + (e & 0xffffu);
+            L.comp = (int)((e >> 16) & 3);
+            L.halo = (int)((e >> 18) & 3);
+            L.hslot = (int)((e >> 20) & 15);
+            L.pitch = L.comp == 0 ? C::TWY : C::CPITCH;
+            if (L.halo == 0) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) raw[r] = *reinterpret_cast<const U4*>(L.dst + r * L.pitch);
+            } else {
+                const U4* hs = reinterpret_cast<const U4*>(lds_hstage<C>(lds) + 64 * L.hslot);
+#pragma unroll
+                for (int r = 0; r < 8; r++) raw[r] = hs[r];
+            }
+        }
+        work = st.full || take;
+    }
+    if (work) {
+        U4 px[8];
+        idct_block(raw, lds_qt<C>(lds) + 64 * L.comp, px);
+        store_block(L, px);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Phase 2: up-sample + colour-convert + store.  One item = 16 consecutive pixels of one row.
 // ------------------------------------------------------------------------------------------------
 ZJ_DEV void store16(uint8_t* p, const U4& v) { *reinterpret_cast<U4*>(p) = v; }
@@ -764,8 +892,11 @@ ZJ_DEV void store_clip(uint8_t* orow, long long off, const uint32_t* w, int ndw,
     }
 }
 
-template <class C, int HS, int VS, int OUT, bool FAST = true>
-ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const int16_t* lds)
+// TS (transposed store, FAST RGB / YCbCr only): processes ONE round (item = tid + round * NT) and, instead of
+// storing its 48 bytes at a 48-byte lane stride, leaves them in LDS for color_copyout, which stores 16-byte pieces
+// that are contiguous across the lanes of a wave.
+template <class C, int HS, int VS, int OUT, bool FAST = true, bool TS = false>
+ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, int16_t* lds, const int round = 0)
 {
     const int P = p.mcu_x * 8 * HS;       // padded row length == luma width_stride (headers.rs:338)
     const int W = p.width;
@@ -779,7 +910,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const in
     uint8_t* const frame_out = p.out + (long long)t.frame * p.out_frame_stride;
     const int elements = P / 16 - 1; // worker.rs:171 (P >= 32 on this path)
 
-    for (int item = tid; item < C::NITEMS; item += C::NT) {
+    for (int item = TS ? tid + round * C::NT : tid; item < C::NITEMS; item += TS ? C::NITEMS : C::NT) {
         const int m = item / C::NGRP, g = item % C::NGRP;
         const int px0 = x0 + 16 * g;      // first pixel of the group in the padded row
         const int row = t.strip * C::SH + m;
@@ -970,6 +1101,26 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const in
         const U4 s0 = {d[0], d[1], d[2], d[3]}, s1 = {d[4], d[5], d[6], d[7]}, s2 = {d[8], d[9], d[10], d[11]};
         if (ZJ_ABL(p.debug, 8) && (d[0] ^ d[5] ^ d[11]) != 0x12345u) continue; // ablation: (practically) no HBM writes
         const int G = px0 >> 4; // 16-pixel group index in the row
+        if (TS) {
+            // pieces 0 and 1 into the item's own luma slot (32 bytes, read above and dead now), piece 2 into the
+            // wave's staging row.  The early RGB tail (Q5) is applied here, as a shift by one piece: the last group
+            // of a row starts in the third slot of the group before it, and the row's last piece is zero (Q6).
+            char* const yslot = reinterpret_cast<char*>(lds) + 32 * item;
+            char* const xslot = reinterpret_cast<char*>(lds) + C::XSTAGE_OFF + 1024 * (tid >> 6) + 16 * (tid & 63);
+            const bool quirk = OUT == OUT_RGB && !p.plain;
+            if (quirk && G == elements) {
+                const U4 z = {0, 0, 0, 0};
+                *reinterpret_cast<U4*>(xslot - 16) = s0; // the launcher guarantees the previous group is lane - 1
+                *reinterpret_cast<U4*>(yslot) = s1;
+                *reinterpret_cast<U4*>(yslot + 16) = s2;
+                *reinterpret_cast<U4*>(xslot) = z;
+            } else {
+                *reinterpret_cast<U4*>(yslot) = s0;
+                *reinterpret_cast<U4*>(yslot + 16) = s1;
+                if (!(quirk && G == elements - 1)) *reinterpret_cast<U4*>(xslot) = s2;
+            }
+            continue;
+        }
         if (OUT == OUT_YCBCR || p.plain) {
             uint8_t* o = orow + 48ll * G;
             store16(o, s0); store16(o + 16, s1); store16(o + 32, s2);
@@ -990,6 +1141,53 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, const in
             }
         }
     }
+}
+
+// Second half of a transposed-store round: lane L of a wave stores pieces 64*j + L (j = 0, 1, 2) of the 192 pieces
+// its wave staged, i.e. every store instruction writes 1024 contiguous bytes of the tile's rows (960-byte row
+// segments), instead of 64 pieces 48 bytes apart.
+template <class C, int OUT>
+ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid, const int16_t* lds, const int round)
+{
+    const int P = p.mcu_x * 8 * (C::TWYB / C::TWC);
+    const int x0 = t.tile * C::TWY;
+    const int nvg = (P - x0) / 16 < C::NGRP ? (P - x0) / 16 : C::NGRP; // valid 16-pixel groups of this tile
+    const long long row_bytes = 3ll * p.width;
+    uint8_t* const tile_out = p.out + (long long)t.frame * p.out_frame_stride + (long long)t.strip * C::SH * row_bytes + 3ll * x0;
+    const int w = tid >> 6, L = tid & 63;
+    const int item0 = 64 * w + round * C::NT;  // first item of this wave's round
+    const char* const ybase = reinterpret_cast<const char*>(lds) + 32 * item0;
+    const char* const xbase = reinterpret_cast<const char*>(lds) + C::XSTAGE_OFF + 1024 * w;
+    // the piece the reference never writes: the last one of a row, in the tile that holds the row's end
+    const bool row_end_here = x0 + 16 * nvg == P;
+    const int never = (OUT == OUT_RGB && !p.plain && !p.zero_fill && row_end_here) ? 3 * nvg - 1 : -1;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int q = 64 * j + L;
+        const int i = q / 3, part = q - 3 * i;
+        if (item0 + i >= C::NITEMS) continue;
+        const int Q = 3 * item0 + q;            // piece index inside the tile
+        const int m = Q / C::PIECES_PER_ROW, c = Q - m * C::PIECES_PER_ROW;
+        if (c >= 3 * nvg || t.strip * C::SH + m >= p.height || c == never) continue;
+        const char* src = part < 2 ? ybase + 32 * i + 16 * part : xbase + 16 * i;
+        store16(tile_out + m * row_bytes + 16 * c, *reinterpret_cast<const U4*>(src));
+    }
+}
+
+// Is the transposed-store variant usable for this launch?  The early-tail shift writes into the staging slot of the
+// lane before it, so the row's last group must never sit in lane 0 of a wave, and both tail groups must be in one tile.
+template <class C>
+inline bool ts_eligible(const Params& p, const int out, const bool fast)
+{
+    if (!fast || !(out == OUT_RGB || out == OUT_YCBCR)) return false;
+    if (out == OUT_YCBCR || p.plain) return true;
+    const int P = p.mcu_x * 8 * (C::TWYB / C::TWC);
+    const int tiles = (P + C::TWY - 1) / C::TWY;
+    const int nvg_last = (P - (tiles - 1) * C::TWY) / 16;
+    if (nvg_last < 2) return false;
+    for (int m = 0; m < C::SH; m++)
+        if ((m * C::NGRP + nvg_last - 1) % 64 == 0) return false;
+    return true;
 }
 
 } // namespace zj

@@ -35,7 +35,11 @@ template <int HS, int VS, int OUT, int COMPACT, bool FAST>
 __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), ZJ_WAVES_PER_SIMD) void zj_fused_kernel(const Params p)
 {
     using C = Cfg<HS, VS, OUT>;
-    __shared__ __attribute__((aligned(16))) char lds_raw[COMPACT ? C::LDS_BYTES_COMPACT : C::LDS_BYTES];
+    // COMPACT: bits 0-1 = how phase 1 spreads the IDCT (0 one lane per block, 1 compaction, 3 work stealing),
+    //          bit 2    = transposed stores in phase 2
+    constexpr int IDCT_MODE = COMPACT & 3;
+    constexpr bool TS = (COMPACT & 4) != 0;
+    __shared__ __attribute__((aligned(16))) char lds_raw[TS ? C::LDS_BYTES_TS : (IDCT_MODE ? C::LDS_BYTES_COMPACT : C::LDS_BYTES)];
     int16_t* lds = reinterpret_cast<int16_t*>(lds_raw);
     ZJ_SETPRIO(1, 3); // issue the tile's loads ahead of other waves' arithmetic
     const TileId t = decode_tile(p, (int)blockIdx.x);
@@ -44,7 +48,13 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), ZJ_WAVES_PER_SIMD) void zj_
     U4 raw[8];
     load_block(L, raw, p.debug); // HBM loads in flight across the barrier below
     ZJ_SETPRIO(1, 0);
-    if (COMPACT) {
+    if (IDCT_MODE == 3) {
+        const int32_t q0 = p.qt[64 * L.comp]; // the DC-only shortcut needs q[0] before the tables are staged
+        phase_setup<C, HS, VS>(p, tid, lds);
+        const StealState st = steal_stage<C>(L, raw, q0, tid, lds);
+        __syncthreads();
+        steal_idct<C>(L, raw, st, tid, lds);
+    } else if (IDCT_MODE) {
         const int32_t q0 = p.qt[64 * L.comp]; // the DC-only shortcut needs q[0] before the tables are staged
         phase_setup<C, HS, VS>(p, tid, lds);
         classify_stage<C>(L, raw, q0, tid, lds);
@@ -57,7 +67,16 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), ZJ_WAVES_PER_SIMD) void zj_
     }
     __syncthreads();
     ZJ_SETPRIO(2, 2); // (off) let a tile's last phase, the one that frees the workgroup slot, go first
-    phase_color<C, HS, VS, OUT, FAST>(p, t, tid, lds);
+    if (TS) {
+        // each wave stages its 64 items of a round in LDS (in place), then stores them as contiguous pieces;
+        // LDS operations of one wave execute in order, so no barrier is needed between the two halves
+        for (int round = 0; round * C::NT < C::NITEMS; round++) {
+            phase_color<C, HS, VS, OUT, FAST, true>(p, t, tid, lds, round);
+            color_copyout<C, OUT>(p, t, tid, lds, round);
+        }
+    } else {
+        phase_color<C, HS, VS, OUT, FAST>(p, t, tid, lds);
+    }
 }
 
 // Persistent form of the same pipeline: a fixed grid of workgroups, each walking many tiles.  The next
@@ -139,7 +158,14 @@ static hipError_t launch_fused_t(const Params& p, int compact, int fast, hipStre
         int wgs = persistent_grid();
         if (wgs > p.total_tiles) wgs = p.total_tiles;
         hipLaunchKernelGGL((zj_fused_persistent_kernel<HS, VS, OUT>), dim3((unsigned)wgs), block, 0, s, p);
-    } else if (compact) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 1, true>), grid, block, 0, s, p);
+    } else if ((compact == 4 || compact == 7) && ts_eligible<C>(p, OUT, true)) {
+        // transposed stores exist for the 3-byte interleaved outputs only; TSC folds to 0 elsewhere (never reached)
+        constexpr int TSC = (OUT == OUT_RGB || OUT == OUT_YCBCR) ? 4 : 0;
+        if (compact == 4) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, TSC, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, (TSC | 3), true>), grid, block, 0, s, p);
+    } else if (compact == 3 || compact == 7) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 3, true>), grid, block, 0, s, p);
+    else if (compact == 4) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 0, true>), grid, block, 0, s, p);
+    else if (compact) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 1, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 0, true>), grid, block, 0, s, p);
     return hipGetLastError();
 }
@@ -165,7 +191,7 @@ const char* fused_kernel_name(int hs, int vs, int out, int variant, int fast)
     char* b = buf[slot++ & 7];
     if (out == OUT_RGBA || out == OUT_RGB_CHW) variant = 0;
     if (fast && variant == 2) snprintf(b, 96, "void zj::zj_fused_persistent_kernel<%d, %d, %d>(zj::Params)", hs, vs, out);
-    else snprintf(b, 96, "void zj::zj_fused_kernel<%d, %d, %d, %d, %s>(zj::Params)", hs, vs, out, fast ? (variant == 1) : 0, fast ? "true" : "false");
+    else snprintf(b, 96, "void zj::zj_fused_kernel<%d, %d, %d, %d, %s>(zj::Params)", hs, vs, out, (fast && variant != 2) ? variant : 0, fast ? "true" : "false");
     return b;
 }
 

@@ -368,7 +368,7 @@ class Context:
         return ms.value / iters, each.value, (name.value or b"").decode()
 
     def set_variant(self, variant):
-        """Kernel variant: 0 = one pass per tile, 1 = DC-only compaction, 2 = persistent + prefetch.
+        """Kernel variant: 0 = one pass per tile, 1 = DC-only compaction, 2 = persistent + prefetch, 3 = work stealing.
         All are bit-exact."""
         _check(lib().zj_set_variant(self._h, int(variant)), "zj_set_variant", self._h)
 
