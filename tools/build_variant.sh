@@ -5,5 +5,7 @@ set -e
 cd "$(dirname "$0")/../zune-jpeg_amd/csrc"
 make -s
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed $2 -c zj_kernels.hip -o /tmp/zj_kernels_$1.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o ../libzjhip_$1.so /tmp/zj_kernels_$1.o zj_ubench.o zj_lab.o zj_api.o zj_jpeg.o zj_pool.o -Wl,-soname,libzjhip.so
+# zj_api.cpp sees the tile geometry through zj_plan.h: recompile it under the same flags
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed $2 -x hip -c zj_api.cpp -o /tmp/zj_api_$1.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o ../libzjhip_$1.so /tmp/zj_kernels_$1.o zj_ubench.o zj_lab.o /tmp/zj_api_$1.o zj_jpeg.o zj_pool.o -Wl,-soname,libzjhip.so
 echo built libzjhip_$1.so
