@@ -212,7 +212,7 @@ def main():
             # every rank's first frame is synthetic frame (rank*B) % distinct: identical data when B % distinct == 0
             "checksums_equal_across_ranks": (len({tuple(s) for s in sums}) == 1) if (world > 1 and B % max(args.distinct, 1) == 0) else None,
         }
-        if not args.no_cpu_baseline and args.workload == "420-rgb":
+        if not args.no_cpu_baseline and args.workload == "420-rgb" and world == 1:  # host baseline: rank 0 at N=1 only
             res["cpu_baseline"] = cpu_baseline(frames[0][0], qts)
         print(json.dumps(res), flush=True)
     shard.barrier(world)
