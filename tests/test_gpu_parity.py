@@ -580,3 +580,32 @@ def test_default_ctx_is_per_thread_and_safe_under_concurrency(zj, synth):
     assert not errors, errors[:4]
     assert len(set(seen[:4])) == 4            # four concurrent threads, four contexts
     assert set(seen[4:]) <= set(seen[:4])     # recycled, not rebuilt
+
+
+def test_decode_to_tensor_for_torch_consumers(zj, synth):
+    """device tensors in, [N, 3, H, W] / [N, H, W, 3] uint8 tensors out on torch's current stream"""
+    import torch
+    w, h, n = 320, 64, 3
+    frames = [synth.make_frame(w, h, 2, 2, 3, seed=555, frame_index=i) for i in range(n)]
+    qts = frames[0][1]
+    dev = torch.device("cuda:0")
+    y, cb, cr = [torch.from_numpy(np.concatenate([f[0][c] for f in frames])).to(dev) for c in range(3)]
+    ctx = zj.Context()
+    try:
+        for layout in (zj.LAYOUT_CHW, zj.LAYOUT_HWC):
+            d = zj.FrameDesc.make(w, h, 2, 2, 3, zj.ColorSpace.RGB, qts, out_layout=layout,
+                                  flags=zj.FLAG_PLAIN_TAIL if layout == zj.LAYOUT_HWC else 0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                t = ctx.decode_to_tensor(d, y, cb, cr)
+                torch.cuda.current_stream().synchronize()
+            assert tuple(t.shape) == ((n, 3, h, w) if layout == zj.LAYOUT_CHW else (n, h, w, 3)) and t.dtype == torch.uint8
+            for i, f in enumerate(frames):
+                rc, rgb = oc.decode_planes(oc.make_frame(w, h, 2, 2, 3, oc.RGB, qts), f[0], plain=True)
+                assert rc == 0
+                exp = rgb.reshape(h, w, 3)
+                got = t[i].cpu().numpy()
+                if layout == zj.LAYOUT_CHW:
+                    got = got.transpose(1, 2, 0)
+                assert np.array_equal(got, exp), (layout, i)
+    finally:
+        ctx.close()

@@ -357,6 +357,23 @@ class Context:
         _check(lib().zj_decode_planes_device(self._h, C.byref(desc), nframes, d_y, d_cb, d_cr, d_out, stream),
                "zj_decode_planes_device", self._h)
 
+    def decode_to_tensor(self, desc, y, cb=None, cr=None, out=None):
+        """Device-resident in, device-resident out, for PyTorch-ROCm consumers: y / cb / cr are int16
+        CUDA tensors holding N frames of coefficient planes back to back; returns a uint8 CUDA tensor shaped
+        [N, C, H, W] when desc.out_layout is LAYOUT_CHW, else [N, H, W, C].  Runs on torch's current stream."""
+        import torch
+        ylen = lib().zj_plane_len(C.byref(desc), 0)
+        n = y.numel() // ylen
+        assert n >= 1 and y.numel() == n * ylen and y.dtype == torch.int16 and y.is_cuda
+        nc = ColorSpace(desc.out_colorspace).num_components()
+        shape = (n, nc, desc.height, desc.width) if desc.out_layout == LAYOUT_CHW else (n, desc.height, desc.width, nc)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.uint8, device=y.device)
+        assert out.is_contiguous() and out.numel() == n * lib().zj_out_len(C.byref(desc))
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        self.decode_planes_device(desc, n, ptr(y), ptr(cb), ptr(cr), out.data_ptr(), torch.cuda.current_stream(y.device).cuda_stream)
+        return out
+
     def time_decode_device(self, desc, nframes, d_y, d_cb, d_cr, d_out, iters, stream=None):
         """HIP-event timing on the launch stream.  Returns (ms per launch from `iters` back-to-back
         launches, mean ms of individually bracketed launches, kernel name)."""
