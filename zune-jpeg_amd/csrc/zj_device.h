@@ -31,6 +31,11 @@ typedef uint16_t u16x2 __attribute__((vector_size(4)));  // packed pair, wrap-ar
 typedef int16_t s16x2 __attribute__((vector_size(4)));   // packed pair, arithmetic >>, min/max
 
 struct alignas(16) U4 { uint32_t x, y, z, w; };
+typedef uint32_t V4 __attribute__((vector_size(16)));    // the same 16 bytes for builtins that want a vector
+// ZJ_NT (experiment knob, tools/ab_libs.sh): bit 0 = non-temporal pixel stores, bit 1 = non-temporal coefficient loads
+#ifndef ZJ_NT
+#define ZJ_NT 0
+#endif
 
 ZJ_DEV uint32_t as_u32(u16x2 v) { uint32_t r; __builtin_memcpy(&r, &v, 4); return r; }
 ZJ_DEV uint32_t as_u32(s16x2 v) { uint32_t r; __builtin_memcpy(&r, &v, 4); return r; }
@@ -553,6 +558,13 @@ ZJ_DEV void load_block(const BlockLoc& L, U4 raw[8], const int debug = 0)
         for (int i = 0; i < 8; i++) { raw[i].x = v + i; raw[i].y = v; raw[i].z = v >> 1; raw[i].w = 0; }
         return;
     }
+#if !defined(ZJ_EMU)
+    if (ZJ_NT & 2) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const V4 t = __builtin_nontemporal_load(reinterpret_cast<const V4*>(L.src + i)); raw[i].x = t[0]; raw[i].y = t[1]; raw[i].z = t[2]; raw[i].w = t[3]; }
+        return;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < 8; i++) raw[i] = L.src[i];
 }
@@ -826,7 +838,13 @@ ZJ_DEV void steal_idct(const BlockLoc& Lown, U4 raw[8], const StealState st, con
 // ------------------------------------------------------------------------------------------------
 // Phase 2: up-sample + colour-convert + store.  One item = 16 consecutive pixels of one row.
 // ------------------------------------------------------------------------------------------------
-ZJ_DEV void store16(uint8_t* p, const U4& v) { *reinterpret_cast<U4*>(p) = v; }
+ZJ_DEV void store16(uint8_t* p, const U4& v)
+{
+#if !defined(ZJ_EMU)
+    if (ZJ_NT & 1) { const V4 t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<V4*>(p)); return; }
+#endif
+    *reinterpret_cast<U4*>(p) = v;
+}
 
 // 4 pixels -> 12 bytes from UNCLAMPED i16 pairs.  EO arrangement: (e) holds px 0,2  (o) px 1,3.
 ZJ_DEV void pack_rgb4_eo(const RGB2& e, const RGB2& o, uint32_t& d0, uint32_t& d1, uint32_t& d2)
