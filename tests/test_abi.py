@@ -122,7 +122,7 @@ def test_header_is_plain_c_and_cxx(cmd, tmp_path):
     """include/zjhip.h is the drop-in boundary: plain C99 (and C++11) with no torch / HIP types in it"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = tmp_path / "h.c"
-    src.write_text('#include "zjhip.h"\nint main(void) { return zj_abi_version == 0; }\n')
+    src.write_text('#include "zjhip.h"\nint main(void) { return ZJ_ABI_VERSION == 0; }\n')
     subprocess.check_call([cmd[0], *cmd[1:], "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)])
     hdr = open(os.path.join(root, "include", "zjhip.h")).read()
     assert "hip/hip_runtime" not in hdr and "torch" not in hdr.lower()
