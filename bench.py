@@ -157,9 +157,25 @@ def main():
     kernel_ms, kernel_ms_each, kname = ctx.time_decode_device(desc, B, ptrs[0], ptrs[1], ptrs[2], ptrs[3], kiters, stream)
     # configs[1] read literally is ONE 4096x4096 frame per launch: time that shape too (1664 workgroups = 1.3 waves of
     # the chip's 1280 workgroup slots, so the tail of every launch is exposed); reported beside the batched figure
-    one_ms = one_ms_each = None
+    one_ms = one_ms_each = one_ms_4s = None
     if args.single_frame:
         one_ms, one_ms_each, _ = ctx.time_decode_device(desc, 1, ptrs[0], ptrs[1], ptrs[2], ptrs[3], 200, stream)
+        # the same shape fed the way a frame-at-a-time caller would: launches rotating over four streams, so the tail
+        # of one frame overlaps the head of the next (tools/single_frame_streams.py)
+        four = [torch.cuda.Stream(device=dev) for _ in range(4)]
+        ysz, csz, osz = d_planes[0].numel() // B * 2, d_planes[1].numel() // B * 2, d_out.numel() // B
+
+        def rot(n):
+            for i in range(n):
+                f = i % B
+                ctx.decode_planes_device(desc, 1, ptrs[0] + f * ysz, ptrs[1] + f * csz, ptrs[2] + f * csz, ptrs[3] + f * osz,
+                                         four[i % 4].cuda_stream)
+        rot(200)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        rot(2000)
+        torch.cuda.synchronize()
+        one_ms_4s = (time.perf_counter() - t1) / 2000 * 1e3
     # trivial gather: per-rank checksum of frame 0 (all ranks decode the same synthetic seeds modulo shard)
     torch.cuda.synchronize()
     first = d_out[: W * H * out_cs.num_components()].cpu().numpy()
@@ -208,7 +224,10 @@ def main():
                              "kernel_ms": round(one_ms, 4), "kernel_ms_single_launch": round(one_ms_each, 4),
                              "megapixels_per_s": round(W * H / 1e6 / (one_ms * 1e-3), 1),
                              "achieved": round(W * H * bytes_per_px / (one_ms * 1e-3) / 1e9, 1),
-                             "frac": round(W * H * bytes_per_px / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
+                             "frac": round(W * H * bytes_per_px / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "four_streams_ms_per_frame": round(one_ms_4s, 4),
+                             "four_streams_megapixels_per_s": round(W * H / 1e6 / (one_ms_4s * 1e-3), 1),
+                             "four_streams_frac": round(W * H * bytes_per_px / (one_ms_4s * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
             # every rank's first frame is synthetic frame (rank*B) % distinct: identical data when B % distinct == 0
             "checksums_equal_across_ranks": (len({tuple(s) for s in sums}) == 1) if (world > 1 and B % max(args.distinct, 1) == 0) else None,
         }
