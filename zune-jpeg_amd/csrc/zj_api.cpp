@@ -370,8 +370,25 @@ int zj_time_decode_device(zj_ctx* c, const zj_frame_desc* d, size_t nframes, con
     return ZJ_OK;
 }
 
+static int decode_planes_batch_impl(zj_ctx* c, const zj_frame_desc* d, size_t nframes, const int16_t* y,
+                                    const int16_t* cb, const int16_t* cr, uint8_t* out);
+
 int zj_decode_planes_batch(zj_ctx* c, const zj_frame_desc* d, size_t nframes, const int16_t* y,
                            const int16_t* cb, const int16_t* cr, uint8_t* out)
+{
+    const int rc = decode_planes_batch_impl(c, d, nframes, y, cb, cr, out);
+    // an error half way leaves copies and kernels in flight on the three streams: drain them before the caller
+    // may free or reuse its buffers (the first error stays in last_error)
+    if (rc && c && c->s_up) {
+        const std::string keep = c->last_error;
+        (void)pipe_sync(c);
+        c->last_error = keep;
+    }
+    return rc;
+}
+
+static int decode_planes_batch_impl(zj_ctx* c, const zj_frame_desc* d, size_t nframes, const int16_t* y,
+                                    const int16_t* cb, const int16_t* cr, uint8_t* out)
 {
     // Host planes -> host pixels.  The batch is cut into units of about 16 MB of coefficients (ZJ_UNIT_MB) --
     // several whole frames, or a strip range of one large frame (strips are independent: no filter tap
