@@ -200,6 +200,17 @@ def test_golden_fixtures(ctx, zj, path):
     assert_same(ctx.decode_planes(d, [z["y"], z["cb"], z["cr"]]), z["expected"], os.path.basename(path))
 
 
+GOLDEN_EXT = sorted(glob.glob(os.path.join(HERE, "golden", "ext_*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLDEN_EXT, ids=[os.path.basename(p) for p in GOLDEN_EXT])
+def test_golden_extension_fixtures(ctx, zj, path):
+    z = np.load(path)
+    d = zj.FrameDesc.make(int(z["width"]), int(z["height"]), int(z["h_max"]), int(z["v_max"]), 3,
+                          int(z["out_cs"]), list(z["qt"]), flags=int(z["flags"]), out_layout=int(z["out_layout"]))
+    assert_same(ctx.decode_planes(d, [z["y"], z["cb"], z["cr"]]), z["expected"], os.path.basename(path))
+
+
 @pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("out_cs", [oc.RGB, oc.GRAYSCALE, oc.YCBCR])
 @pytest.mark.parametrize("wh", [(64, 64), (528, 40), (32, 8), (1040, 33), (1920, 1080)])

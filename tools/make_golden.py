@@ -12,6 +12,8 @@ Fixtures (all tiny):
   frame_hv_rgb_96x80.npz   a 3-strip 4:2:0 frame whose height is not a multiple of the strip
   adversarial_hv_rgb.npz   full-range coefficients / tables (wrap-around paths, Q1/Q7)
   idct_blocks.npz          256 random blocks + expected pixel blocks (incl. DC-only, wrap)
+  ext_<mode>_<kind>.npz    the output EXTENSIONS (no reference output exists): kind plain (ZJ_FLAG_PLAIN_TAIL),
+                           rgba (ZJ_CS_RGBA), chw (ZJ_LAYOUT_CHW); fields flags / out_layout say how to ask for them
 """
 import importlib
 import os
@@ -50,6 +52,18 @@ def main():
     total += save_frame("frame_hv_rgb_96x80.npz", 96, 80, 2, 2, onp.RGB, planes, qts)
     planes, qts = synth.make_adversarial_frame(64, 32, 2, 2, 3, seed=77)
     total += save_frame("adversarial_hv_rgb.npz", 64, 32, 2, 2, onp.RGB, planes, qts)
+    for mode in ("hv", "h", "none"):
+        hs, vs = MODES[mode]
+        w, h = 80, 40  # 2.5 / 1.25 strips in HV: rows below the last whole strip stay 0 in every layout
+        planes, qts = synth.make_frame(w, h, hs, vs, 3, seed=500 + hs + vs)
+        rgb = onp.decode_planes(w, h, hs, vs, 3, onp.RGB, qts, planes, plain=True)
+        rgba = onp.decode_planes(w, h, hs, vs, 3, onp.RGBA, qts, planes, plain=True)
+        for kind, out_cs, flags, layout, exp in (("plain", onp.RGB, 1, 0, rgb), ("rgba", onp.RGBA, 0, 0, rgba),
+                                                 ("chw", onp.RGB, 0, 1, np.ascontiguousarray(rgb.reshape(h, w, 3).transpose(2, 0, 1)).reshape(-1))):
+            np.savez_compressed(os.path.join(OUT, f"ext_{mode}_{kind}.npz"), y=planes[0], cb=planes[1], cr=planes[2],
+                                qt=np.stack(qts).astype(np.int32), width=w, height=h, h_max=hs, v_max=vs,
+                                out_cs=out_cs, flags=flags, out_layout=layout, expected=exp)
+            total += exp.size
     rng = np.random.default_rng(2024)
     blocks = rng.integers(-32768, 32768, size=(256, 64)).astype(np.int16)
     blocks[64:128] = rng.integers(-40, 41, size=(64, 64))
