@@ -110,12 +110,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    shard.init_process_group("nccl", rank, world)
+    # ZJ_BENCH_SAME_GPU=1 is a plumbing test only (tests the multi-rank control flow on a 1-GPU box: every rank uses
+    # cuda:0 and the collectives run on gloo/CPU tensors); the driver's runs use one GPU per rank over RCCL
+    same_gpu = os.environ.get("ZJ_BENCH_SAME_GPU") == "1"
+    gpu_index = 0 if same_gpu else local_rank
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
+    shard.init_process_group("gloo" if same_gpu else "nccl", rank, world)
+    coll_dev = "cpu" if same_gpu else dev
 
     B = args.frames
-    ctx = zj.Context(zj.BACKEND_HIP, local_rank)
+    ctx = zj.Context(zj.BACKEND_HIP, gpu_index)
     if args.variant:
         ctx.set_variant({"onepass": 0, "compact": 1, "persistent": 2, "steal": 3, "tstore": 4, "steal+tstore": 7}[args.variant])
     # synthetic data, SURVEY.md 8d generator; every rank decodes its own shard of the global batch
@@ -150,7 +155,7 @@ def main():
         step()
     torch.cuda.synchronize()
     shard.barrier(world)
-    elapsed = shard.max_over_ranks(time.perf_counter() - t0, world, dev)
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, world, coll_dev)
 
     # dominant-kernel duration, HIP events recorded on the launch stream (outside the timed region)
     kiters = max(10, min(args.steps, 50))
@@ -179,7 +184,7 @@ def main():
     # trivial gather: per-rank checksum of frame 0 (all ranks decode the same synthetic seeds modulo shard)
     torch.cuda.synchronize()
     first = d_out[: W * H * out_cs.num_components()].cpu().numpy()
-    sums = shard.gather_checksums([shard.frame_checksum(first)], world, dev)
+    sums = shard.gather_checksums([shard.frame_checksum(first)], world, coll_dev)
 
     if rank == 0:
         mp_total = world * B * args.steps * W * H / 1e6
