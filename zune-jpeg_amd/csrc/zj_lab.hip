@@ -335,6 +335,47 @@ __global__ __launch_bounds__(256) void lab_stream(const U4* __restrict__ in, U4*
     for (int k = 0; k < PER; k++) out[base + 256 * k] = v[k];
 }
 
+// What makes a burst / tile copy slower than the 1-load-1-store stream?  Same bytes per workgroup (32 KB) in
+// three shapes: MODE 0 lane-contiguous 128 B per lane (like one block per lane), 8 loads then 8 stores;
+// MODE 1 the lab_stream<8> addresses, but load k+1 is issued before store k and nothing else (a software pipeline);
+// MODE 2 a loop of eight 1-load-1-store rounds with a wait in between (fine-grained alternation, long-lived waves)
+template <int MODE>
+__global__ __launch_bounds__(256) void lab_stream8(const U4* __restrict__ in, U4* __restrict__ out, long long n)
+{
+    const long long wg = (long long)blockIdx.x * 256 * 8;
+    if (MODE == 0) {
+        const long long base = wg + threadIdx.x * 8;
+        U4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = in[base + k];
+#pragma unroll
+        for (int k = 0; k < 8; k++) out[base + k] = v[k];
+    } else if (MODE == 1) {
+        const long long base = wg + threadIdx.x;
+        U4 cur = in[base];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            U4 nxt = cur;
+            if (k < 7) nxt = in[base + 256 * (k + 1)];
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            out[base + 256 * k] = cur;
+            cur = nxt;
+        }
+    } else {
+        const long long base = wg + threadIdx.x;
+        for (int k = 0; k < 8; k++) {
+            const U4 v = in[base + 256 * k];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            out[base + 256 * k] = v;
+        }
+    }
+}
+// grid-stride form of the 1-load-1-store stream: G workgroups, each walking n / (256 G) chunks (persistent waves)
+__global__ __launch_bounds__(256) void lab_stream_persistent(const U4* __restrict__ in, U4* __restrict__ out, long long n)
+{
+    for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < n; c += (long long)gridDim.x * 256) out[c] = in[c];
+}
+
 typedef void (*labmem_fn)(const U4*, U4*, long long);
 static const struct { const char* name; labmem_fn fn; } LABMEM[] = {
     {"copy  rd=coalesced      wr=coalesced", lab_mem<0, 0>},
@@ -345,6 +386,11 @@ static const struct { const char* name; labmem_fn fn; } LABMEM[] = {
     {"stream copy 1 x 16 B per lane", nullptr},
     {"stream copy 4 x 16 B per lane", nullptr},
     {"stream copy 8 x 16 B per lane", nullptr},
+    {"burst copy 8 x 16 B, lane-contiguous 128 B per lane", nullptr},
+    {"burst copy 8 x 16 B, software-pipelined (load k+1 | store k)", nullptr},
+    {"burst copy 8 rounds of load;wait;store (long-lived waves)", nullptr},
+    {"stream copy, persistent: 2048 workgroups grid-stride", nullptr},
+    {"stream copy, persistent: 8192 workgroups grid-stride", nullptr},
 };
 typedef void (*labtile_fn)(const U4*, U4*, long long);
 static const struct { const char* name; labtile_fn fn; int seg; } LABTILE[] = {
@@ -371,6 +417,14 @@ hipError_t launch_labmem(int i, const void* in, void* out, long long bytes, hipS
     const long long T = bytes / 384;
     if (LABMEM[i].fn == nullptr) {
         const long long nch = bytes / 16;
+        if (i >= 8) {
+            const unsigned g8 = (unsigned)(nch / (256 * 8));
+            if (i == 8) hipLaunchKernelGGL(lab_stream8<0>, dim3(g8), dim3(256), 0, s, (const U4*)in, (U4*)out, nch);
+            else if (i == 9) hipLaunchKernelGGL(lab_stream8<1>, dim3(g8), dim3(256), 0, s, (const U4*)in, (U4*)out, nch);
+            else if (i == 10) hipLaunchKernelGGL(lab_stream8<2>, dim3(g8), dim3(256), 0, s, (const U4*)in, (U4*)out, nch);
+            else hipLaunchKernelGGL(lab_stream_persistent, dim3(i == 11 ? 2048 : 8192), dim3(256), 0, s, (const U4*)in, (U4*)out, nch);
+            return hipGetLastError();
+        }
         const int per = i == 5 ? 1 : (i == 6 ? 4 : 8);
         const unsigned g = (unsigned)(nch / (256 * per));
         if (per == 1) hipLaunchKernelGGL(lab_stream<1>, dim3(g), dim3(256), 0, s, (const U4*)in, (U4*)out, nch);
