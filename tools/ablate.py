@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""Needs the diagnostic build: make -C zune-jpeg_amd/csrc EXTRA=-DZJ_ABLATION OUT=$PWD/zune-jpeg_amd/libzjhip_ablate.so
-and ZJ_LIB=libzjhip_ablate.so.  Ablation: how long does the fused kernel take when the IDCT and/or the colour math are skipped?
+"""Needs the diagnostic build: tools/build_variant.sh ablate "-DZJ_ABLATION=1" and ZJ_LIB=libzjhip_ablate.so.  Ablation: how long does the fused kernel take when the IDCT and/or the colour math are skipped?
 Tells VALU-bound from memory/latency-bound (results are wrong in the ablated runs; diagnostics only)."""
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,7 +21,8 @@ ptrs = [t.data_ptr() for t in d_planes] + [d_out.data_ptr()]
 side = torch.cuda.Stream().cuda_stream
 ctx.time_decode_device(desc, B, *ptrs, 150, side)  # settle clocks
 for name, mask in (("full", 0), ("no IDCT", 1), ("no colour math", 2), ("neither", 3), ("no loads", 4), ("no stores", 8),
-                   ("no loads/stores", 12), ("no loads, no compute", 7), ("no stores, no compute", 11), ("full", 0)):
+                   ("no loads/stores", 12), ("no loads, no compute", 7), ("no stores, no compute", 11), ("no chroma LDS reads / filters", 16),
+                   ("no chroma LDS, no colour math", 18), ("full", 0)):
     ctx.set_ablation(mask)
     ms, each, _ = ctx.time_decode_device(desc, B, *ptrs, 100, side)
     print(f"{name:24s} {ms*1e3:8.1f} us/launch   {B*W*H*6/ms/1e6:8.1f} GB/s")

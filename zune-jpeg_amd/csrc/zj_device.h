@@ -32,6 +32,11 @@ typedef int16_t s16x2 __attribute__((vector_size(4)));   // packed pair, arithme
 
 struct alignas(16) U4 { uint32_t x, y, z, w; };
 typedef uint32_t V4 __attribute__((vector_size(16)));    // the same 16 bytes for builtins that want a vector
+#if defined(ZJ_ABLATION)
+#define ZJ_ABL(debug, bit) ((debug) & (bit))
+#else
+#define ZJ_ABL(debug, bit) 0  // the ablation switches exist only in the diagnostic build (tools/ablate.py)
+#endif
 // ZJ_NT (experiment knob, tools/ab_libs.sh): bit 0 = non-temporal pixel stores, bit 1 = non-temporal coefficient loads
 #ifndef ZJ_NT
 #define ZJ_NT 0
@@ -544,11 +549,6 @@ template <class C> ZJ_DEV int32_t* lds_qt(int16_t* lds) { return reinterpret_cas
 //   phase_setup  stages the three quantisation tables in LDS                      that publishes QT)
 //   finish_block dequantize + IDCT (or the DC-only shortcut, Q1) -> LDS planar staging
 // ------------------------------------------------------------------------------------------------
-#if defined(ZJ_ABLATION)
-#define ZJ_ABL(debug, bit) ((debug) & (bit))
-#else
-#define ZJ_ABL(debug, bit) 0  // the ablation switches exist only in the diagnostic build (tools/ablate.py)
-#endif
 ZJ_DEV void load_block(const BlockLoc& L, U4 raw[8], const int debug = 0)
 {
     if (!L.valid) return;
@@ -976,6 +976,11 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, int16_t*
         for (int ch = 0; ch < 2; ch++) {
             const int16_t* cp = lds + C::YSZ + ch * C::CSZ;
             uint32_t* dst = ch ? crp : cbp;
+            if (ZJ_ABL(p.debug, 16)) { // ablation: no chroma reads from LDS, no filters (output is wrong)
+#pragma unroll
+                for (int k = 0; k < 8; k++) dst[k] = yw[k] + ch;
+                continue;
+            }
             if (HS == 1) {
                 const U4* A = reinterpret_cast<const U4*>(cp + oa + 16 * g);
                 const U4 a0 = A[0], a1 = A[1];

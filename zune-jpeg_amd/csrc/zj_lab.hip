@@ -323,6 +323,24 @@ __global__ __launch_bounds__(256) void lab_tile(const U4* __restrict__ in, U4* _
     }
 }
 
+// the same 32 KB per workgroup written as ROWS row segments of S bytes (ROWS * S = 32768) at the 12288-byte pitch:
+// isolates the row-segment length from the bytes a workgroup moves
+template <int S>
+__global__ __launch_bounds__(256) void lab_tile32k(const U4* __restrict__ in, U4* __restrict__ out, long long ntiles)
+{
+    constexpr int ROWS = 32768 / S, CPR = S / 16, TPR = 12288 / S; // S in {512, 1024, 2048, 4096}; 12288 / S whole
+    long long id = blockIdx.x;
+    if ((ntiles & 7) == 0) id = (id & 7) * (ntiles >> 3) + (id >> 3);
+    const long long band = id / TPR, tx = id % TPR; // a band = ROWS full rows
+    const U4* src = in + id * 2048;
+    U4* dst = out + band * ROWS * 768 + tx * CPR;
+    U4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = src[threadIdx.x + 256 * k];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const int c = threadIdx.x + 256 * k; dst[(c / CPR) * 768 + (c % CPR)] = v[k]; }
+}
+
 // plain streaming copies: N x 16 bytes, 1 or 4 chunks per lane (consecutive lanes -> consecutive chunks)
 template <int PER>
 __global__ __launch_bounds__(256) void lab_stream(const U4* __restrict__ in, U4* __restrict__ out, long long n)
@@ -402,6 +420,10 @@ static const struct { const char* name; labtile_fn fn; int seg; } LABTILE[] = {
     {"tile copy  row segment  768 B  round-robin", lab_tile<768, 0>, 768},
     {"tile copy  row segment 3072 B  round-robin", lab_tile<3072, 0>, 3072},
     {"tile copy  row segment 12288 B round-robin", lab_tile<12288, 0>, 12288},
+    {"32 KB per workgroup as 64 rows x  512 B", lab_tile32k<512>, 1024},
+    {"32 KB per workgroup as 32 rows x 1024 B", lab_tile32k<1024>, 1024},
+    {"32 KB per workgroup as 16 rows x 2048 B", lab_tile32k<2048>, 1024},
+    {"32 KB per workgroup as  8 rows x 4096 B", lab_tile32k<4096>, 1024},
 };
 int labmem_count() { return (int)(sizeof(LABMEM) / sizeof(LABMEM[0])) + (int)(sizeof(LABTILE) / sizeof(LABTILE[0])); }
 const char* labmem_name(int i) { const int n = (int)(sizeof(LABMEM) / sizeof(LABMEM[0])); return i < n ? LABMEM[i].name : LABTILE[i - n].name; }
