@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Robustness of the CPU entropy front-end on damaged files: zj_jpeg.cpp built alone with AddressSanitizer + UBSan
+(tests/fuzz/jpeg_stubs.cpp stands in for the GPU calls) and fed thousands of mutated baseline / progressive / DRI
+files: bit flips, byte splices, truncations, marker-length edits.  Any status is fine; a sanitizer report is not.
+
+    python tools/fuzz_frontend.py [--iters 4000]      (re-executes itself under LD_PRELOAD=libasan.so)
+"""
+import argparse
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = "/tmp/libzjjpeg_asan.so"
+
+
+def build():
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fsanitize=address,undefined",
+                           "-fno-omit-frame-pointer", "-o", SO,
+                           os.path.join(ROOT, "zune-jpeg_amd", "csrc", "zj_jpeg.cpp"), os.path.join(ROOT, "tests", "fuzz", "jpeg_stubs.cpp")])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=4000)
+    ap.add_argument("--child", action="store_true")
+    a = ap.parse_args()
+    if not a.child:
+        build()
+        asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+        env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=1",
+                   UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--iters", str(a.iters)], env=env)
+        print("sanitizer-clean" if r.returncode == 0 else f"FAILED (exit {r.returncode})")
+        sys.exit(r.returncode)
+
+    import numpy as np
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tools")]
+    import importlib
+    import jpeg_enc
+    synth = importlib.import_module("zune-jpeg_amd.synth")
+    L = C.CDLL(SO)
+    L.zj_decoder_new.restype = C.c_void_p
+    L.zj_decoder_new.argtypes = [C.c_void_p]
+    L.zj_decoder_free.argtypes = [C.c_void_p]
+    L.zj_decoder_decode_coefficients.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+
+    class Opt(C.Structure):
+        _fields_ = [(n, C.c_int32) for n in ("out_colorspace", "strict_mode", "max_width", "max_height", "max_scans", "num_threads", "pinned_planes")]
+
+    qts = synth.quant_tables(85)
+    seeds = []
+    for (w, h, hs, vs) in [(64, 48, 2, 2), (50, 37, 1, 1), (40, 24, 2, 1), (33, 70, 1, 2)]:
+        pl = jpeg_enc.small_planes(w, h, hs, vs, 3, seed=w)
+        seeds.append(jpeg_enc.encode_baseline(pl, qts, w, h, hs, vs, 3))
+        seeds.append(jpeg_enc.encode_baseline(pl, qts, w, h, hs, vs, 3, restart=3))
+        seeds.append(jpeg_enc.encode_progressive(pl, qts, w, h, hs, vs, 3))
+    for name in ("test-baseline.jpg", "test-progressive.jpg"):
+        seeds.append(open(os.path.join(ROOT, "tests", "golden", name), "rb").read()[:6000])  # headers + start of data
+    rng = np.random.default_rng(7)
+    decs = []
+    for threads in (1, 3):
+        o = Opt(0, 0, 0, 0, 0, threads, 0)
+        decs.append(L.zj_decoder_new(C.byref(o)))
+    stats = {}
+    desc = (C.c_char * 1024)()
+    info = (C.c_char * 64)()
+    for it in range(a.iters):
+        b = bytearray(seeds[it % len(seeds)])
+        kind = it % 5
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 8))):
+                b[int(rng.integers(len(b)))] ^= 1 << int(rng.integers(8))
+        elif kind == 1:
+            b = b[: int(rng.integers(2, len(b)))]
+        elif kind == 2:
+            i = int(rng.integers(len(b)))
+            b[i:i] = bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8))
+        elif kind == 3:
+            i, j = sorted(int(x) for x in rng.integers(0, len(b), 2))
+            del b[i:min(j, i + 200)]
+        else:
+            i = int(rng.integers(len(b) - 4))
+            b[i:i + 2] = bytes([0xFF, int(rng.integers(0xC0, 0xFF))])
+        arr = np.frombuffer(bytes(b), np.uint8)
+        rc = L.zj_decoder_decode_coefficients(decs[it & 1], arr.ctypes.data, arr.size, desc, None, None, info)
+        stats[rc] = stats.get(rc, 0) + 1
+    for d in decs:
+        L.zj_decoder_free(d)
+    print("statuses:", dict(sorted(stats.items())))
+
+
+if __name__ == "__main__":
+    main()
