@@ -126,3 +126,15 @@ def test_header_is_plain_c_and_cxx(cmd, tmp_path):
     subprocess.check_call([cmd[0], *cmd[1:], "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)])
     hdr = open(os.path.join(root, "include", "zjhip.h")).read()
     assert "hip/hip_runtime" not in hdr and "torch" not in hdr.lower()
+
+
+def test_c_example_builds_and_links():
+    """examples/decode_file.c: the C ABI used from plain C99, linked against libzjhip.so"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    importlib.import_module("zune-jpeg_amd").lib()  # make sure the library is built
+    out = os.path.join(root, "examples", "decode_file")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "decode_file.c"), "-L", os.path.join(root, "zune-jpeg_amd"), "-lzjhip",
+                           "-Wl,-rpath," + os.path.join(root, "zune-jpeg_amd"), "-o", out])
+    assert os.path.exists(out)
+    os.remove(out)
