@@ -621,20 +621,3 @@ def test_decode_to_tensor_for_torch_consumers(zj, synth):
     finally:
         ctx.close()
 
-
-def test_c_example_decodes_the_reference_image(zj, tmp_path):
-    """examples/decode_file.c built with gcc and run on tests/golden/test-baseline.jpg: same pixels as the Python path"""
-    import subprocess
-    root = os.path.dirname(HERE)
-    exe = tmp_path / "decode_file"
-    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "decode_file.c"),
-                           "-L", os.path.join(root, "zune-jpeg_amd"), "-lzjhip", "-Wl,-rpath," + os.path.join(root, "zune-jpeg_amd"),
-                           "-o", str(exe)])
-    src = os.path.join(HERE, "golden", "test-baseline.jpg")
-    ppm = tmp_path / "out.ppm"
-    subprocess.check_call([str(exe), src, str(ppm)])
-    raw = open(ppm, "rb").read()
-    header, body = raw.split(b"\n255\n", 1)
-    assert header.startswith(b"P6") and b"1920 1080" in header
-    exp = zj.Decoder().decode_buffer(open(src, "rb").read())
-    assert np.array_equal(np.frombuffer(body, np.uint8), exp)
