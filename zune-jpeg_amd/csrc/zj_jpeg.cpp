@@ -631,6 +631,15 @@ int ac_first(zj_decoder* d, BitReader& br, const Huff& ha, int16_t* blk)
 {
     if (d->eobrun > 0) { d->eobrun--; return ZJ_OK; }
     for (int k = d->ss; k <= d->se;) {
+        if (br.nbits < 32) br.fill();
+        const int16_t fa = ha.fast[br.peek(9)];
+        if (fa) { // short code + small value from one table entry (same shortcut as the baseline scan)
+            k += (fa >> 4) & 15;
+            br.drop(fa & 15);
+            blk[kUnZigzag[k & 63]] = (int16_t)((uint16_t)(int16_t)(fa >> 8) * (uint16_t)(1u << d->al));
+            k++;
+            continue;
+        }
         int rs = br.decode(ha);
         if (rs < 0) return fail(d, ZJ_ERR_HUFFMAN, "Bad Huffman code in AC");
         int r = rs >> 4, s = rs & 15;
