@@ -220,7 +220,7 @@ def main():
                                     "420-rgba": "extension: 4096x4096 4:2:0 -> RGBA (R G B 255), planes resident in HBM",
                                     "420-chw": "extension: 4096x4096 4:2:0 -> planar u8 RGB (C x H x W), planes resident in HBM"}[args.workload],
                        "frames_per_gpu_per_step": B, "sharding": f"image-level x{world}, no data-path collective",
-                       "distinct_frames": len(frames)},
+                       "distinct_frames": len(frames), "untimed_launches_before_timing": max(args.warmup, 100)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": (tr or {}).get("hbm_bytes_per_launch"),
