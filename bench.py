@@ -212,7 +212,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "i16 coefficients -> i32 fixed-point IDCT -> packed-i16 colour -> u8",
+            "dtype": "i32",  # the IDCT's fixed-point type (i16 coefficients in, packed-i16 colour math, u8 pixels out)
             "data": "synthetic",
             "config": {"workload": {"420-rgb": "configs[1]: 4096x4096 baseline 4:2:0, dequant+IDCT+h2v2+YCbCr->RGB, planes resident in HBM",
                                     "444-rgb": "configs[2]: 4096x4096 baseline 4:4:4, dequant+IDCT+YCbCr->RGB, planes resident in HBM",
