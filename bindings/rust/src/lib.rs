@@ -12,6 +12,9 @@ pub const ZJ_BACKEND_HIP: c_int = 2;
 pub const ZJ_OK: c_int = 0;
 pub const ZJ_ERR_PANIC: c_int = -5;
 pub const ZJ_FLAG_PLAIN_TAIL: u32 = 1;
+pub const ZJ_FLAG_CLAMP_DC: u32 = 2;
+pub const ZJ_FLAG_EDGE_REPLICATE: u32 = 4;
+pub const ZJ_FLAG_CORRECTED: u32 = 7;
 pub const ZJ_LAYOUT_HWC: u32 = 0;
 pub const ZJ_LAYOUT_CHW: u32 = 1;
 

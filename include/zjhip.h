@@ -98,16 +98,26 @@ typedef struct zj_frame_desc {
     uint32_t out_layout;     /* ZJ_LAYOUT_HWC (0, the reference's interleaved bytes) or ZJ_LAYOUT_CHW */
 } zj_frame_desc;
 
-/* Extensions beyond the reference.  They share the reference's strips, filters and per-pixel
- * arithmetic (so Q1-Q4 and Q7 still hold) and differ only in where bytes go; the checker is the oracle's
- * zjo_decode_planes_plain, since no reference output exists for them:
- *   ZJ_FLAG_PLAIN_TAIL  (RGB) every pixel x < width of a converted row is written at 3x: the last 16 samples are
- *                       not written 16 bytes early (Q5) and no byte of the row stays 0 (Q6);
- *   ZJ_CS_RGBA / RGBX   4 bytes per pixel, R G B 255 (the reference's own RGBA arm is malformed),
- *                       plain placement;
- *   ZJ_LAYOUT_CHW       (RGB) three u8 planes of width*height bytes per frame, the tensor layout ML consumers
- *                       want, plain placement.  GRAYSCALE is accepted (one plane: identical to HWC). */
+/* Extensions beyond the reference, all off by default.  They keep the reference's strips and its
+ * per-pixel arithmetic (Q3 and Q7 always hold) and have no reference output; the checker is the oracle's
+ * zjo_decode_planes_ext:
+ *   ZJ_FLAG_PLAIN_TAIL      (RGB) every pixel x < width of a converted row is written at 3x: the last 16 samples
+ *                           are not written 16 bytes early (Q5) and no byte of the row stays 0 (Q6);
+ *   ZJ_FLAG_CLAMP_DC        the DC-only shortcut value is clamped to 0..255 (Q1 corrected; the reference's AVX2 arm
+ *                           does this, src/idct/avx2.rs:163-167, its scalar arm does not);
+ *   ZJ_FLAG_EDGE_REPLICATE  (h2v1 / h2v2) the horizontal chroma filter runs row by row with replicated edges
+ *                           instead of over the strip as one flat array (Q4 corrected);
+ *   ZJ_FLAG_CORRECTED       all three: the "non-quirk" mode.  What stays: the vertical schedule (Q3) and the
+ *                           dropped odd MCU row are properties of the reference's strip geometry (a corrected
+ *                           vertical filter needs taps across strips);
+ *   ZJ_CS_RGBA / RGBX       4 bytes per pixel, R G B 255 (the reference's own RGBA arm is malformed),
+ *                           plain placement;
+ *   ZJ_LAYOUT_CHW           (RGB) three u8 planes of width*height bytes per frame, the tensor layout ML consumers
+ *                           want, plain placement.  GRAYSCALE is accepted (one plane: identical to HWC). */
 #define ZJ_FLAG_PLAIN_TAIL 1u
+#define ZJ_FLAG_CLAMP_DC 2u
+#define ZJ_FLAG_EDGE_REPLICATE 4u
+#define ZJ_FLAG_CORRECTED 7u
 #define ZJ_LAYOUT_HWC 0u
 #define ZJ_LAYOUT_CHW 1u
 

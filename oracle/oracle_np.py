@@ -89,9 +89,10 @@ def idct_blocks(blocks, qt):
     return out
 
 
-def idct_strip(coeff, qt, stride, samp_factors, v_samp):
+def idct_strip(coeff, qt, stride, samp_factors, v_samp, clamp_dc=False):
     """src/idct/scalar.rs:19-282 incl. the strip layout: chunk c (= one block row) is written as a
-    raster of 8 rows x `stride`, block k at columns 8k..8k+8."""
+    raster of 8 rows x `stride`, block k at columns 8k..8k+8.
+    clamp_dc=True is an EXTENSION: the DC-only shortcut value is clamped to 0..255 (Q1 corrected)."""
     coeff = np.ascontiguousarray(coeff, dtype=np.int16)
     n = coeff.size
     out = np.zeros(n, dtype=np.int16)
@@ -108,7 +109,12 @@ def idct_strip(coeff, qt, stride, samp_factors, v_samp):
     if (nblk - 1) * 8 + 7 * stride + 8 > chunks:
         raise Panic("idct out-of-chunk write")
     blocks = coeff[: nchunks * chunks].reshape(nchunks, chunks)[:, : nblk * 64].reshape(-1, 64)
-    px = idct_blocks(blocks, qt).reshape(nchunks, nblk, 8, 8)
+    px = idct_blocks(blocks, qt)
+    if clamp_dc:
+        dc_only = ~np.any(blocks[:, 1:] != 0, axis=1)
+        px = px.copy()
+        px[dc_only] = np.clip(px[dc_only], 0, 255)
+    px = px.reshape(nchunks, nblk, 8, 8)
     view = out[: nchunks * chunks].reshape(nchunks, chunks)
     for r in range(8):
         # row r of every block lands at r*stride + 8k .. +8
@@ -307,20 +313,36 @@ def color_convert_ycbcr(blk, width, h_samp, v_samp, out_cs, output, plain=False)
     outv[:, position : position + 48] = ycbcr_to_rgb_px(Y[:, t0:], CB[:, t0:], CR[:, t0:]).reshape(rows, 48)
 
 
-def post_process(coeff, comps, in_cs, out_cs, output, width, plain=False):
-    """worker.rs:32-141.  comps: list of dicts {h, v, width_stride, qt}."""
+def upsample_h_rows(inp, row_len):
+    """EXTENSION (Q4 corrected): the horizontal triangle filter row by row with replicated edges."""
+    c = np.asarray(inp, np.int16)
+    rows = c[: (c.size // row_len) * row_len].reshape(-1, row_len).astype(np.int32)
+    left = np.concatenate([rows[:, :1], rows[:, :-1]], axis=1)
+    right = np.concatenate([rows[:, 1:], rows[:, -1:]], axis=1)
+    out = np.empty((rows.shape[0], 2 * row_len), np.int32)
+    out[:, 0::2] = (3 * rows + left + 2) >> 2
+    out[:, 1::2] = (3 * rows + right + 2) >> 2
+    return out.astype(np.int16).reshape(-1)
+
+
+def post_process(coeff, comps, in_cs, out_cs, output, width, plain=False, clamp_dc=False, edge_rep=False):
+    """worker.rs:32-141.  comps: list of dicts {h, v, width_stride, qt}.  plain / clamp_dc / edge_rep: extensions."""
     h_samp, v_samp = comps[0]["h"], comps[0]["v"]
     x = min(num_components(in_cs), num_components(out_cs), 3)
     unp = [None, None, None]
     for z in range(x):
         unp[z] = idct_strip(coeff[z], comps[z]["qt"], comps[z]["width_stride"], h_samp * v_samp,
-                            1 if z == 0 else v_samp)
+                            1 if z == 0 else v_samp, clamp_dc)
     if h_samp != 1 or v_samp != 1:
         up = {(2, 1): upsample_horizontal, (1, 2): upsample_vertical, (2, 2): upsample_hv}.get((h_samp, v_samp))
         if up is None:
             raise ValueError("Unknown down-sampling method")
         for i in range(1, x):
-            unp[i] = up(unp[i], unp[0].size)
+            if edge_rep and h_samp == 2:
+                mid = unp[i] if v_samp == 1 else upsample_vertical(unp[i], 2 * unp[i].size)
+                unp[i] = upsample_h_rows(mid, comps[i]["width_stride"])
+            else:
+                unp[i] = up(unp[i], unp[0].size)
     if in_cs in (YCBCR, GRAYSCALE) and out_cs == GRAYSCALE:
         ycbcr_to_grayscale(unp[0], width, output)
     elif in_cs == YCBCR and out_cs == YCBCR:
@@ -344,7 +366,8 @@ def plane_len(width, height, h_max, v_max, comp):
     return mcu_x * 64 * vs * hs * mcu_y
 
 
-def decode_planes(width, height, h_max, v_max, in_components, out_cs, qts, planes, plain=False):
+def decode_planes(width, height, h_max, v_max, in_components, out_cs, qts, planes, plain=False, clamp_dc=False,
+                  edge_rep=False):
     mcu_x, mcu_y = geometry(width, height, h_max, v_max)
     ncomp = num_components(out_cs)
     in_cs = YCBCR if in_components == 3 else GRAYSCALE
@@ -372,5 +395,6 @@ def decode_planes(width, height, h_max, v_max, in_components, out_cs, qts, plane
             coeff += [planes[1][s * c_chunk : (s + 1) * c_chunk], planes[2][s * c_chunk : (s + 1) * c_chunk]]
         else:
             coeff += [np.zeros(0, np.int16)] * 2
-        post_process(coeff, comps, in_cs, out_cs, out_vector[s * chunks_size : (s + 1) * chunks_size], width, plain)
+        post_process(coeff, comps, in_cs, out_cs, out_vector[s * chunks_size : (s + 1) * chunks_size], width, plain,
+                     clamp_dc, edge_rep)
     return out_vector[: width * height * ncomp].copy()

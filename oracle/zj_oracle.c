@@ -406,7 +406,7 @@ static int color_convert_ycbcr(const int16_t *const blk[3], size_t n, size_t wid
 /* worker.rs:32-86 post_process + :88-141 post_process_inner */
 static int post_process_impl(const int16_t *const coeff[3], const size_t len[3],
                              const zjo_component comps[3], int in_cs, int out_cs, uint8_t *out,
-                             size_t out_len, size_t width, int plain);
+                             size_t out_len, size_t width, int ext);
 
 int zjo_post_process(const int16_t *const coeff[3], const size_t len[3],
                      const zjo_component comps[3], int in_cs, int out_cs, uint8_t *out,
@@ -415,10 +415,48 @@ int zjo_post_process(const int16_t *const coeff[3], const size_t len[3],
     return post_process_impl(coeff, len, comps, in_cs, out_cs, out, out_len, width, 0);
 }
 
+/* EXTENSION helpers (ZJO_EXT_*, no reference behaviour): clamp the unclamped DC-only values of a plane (Q1 corrected,
+ * what src/idct/avx2.rs:163-167 does), and a horizontal up-sampler that treats every row on its own with replicated
+ * edges instead of one flat array (Q4 corrected). */
+static void ext_clamp_dc_only(const int16_t *coeff, size_t n, size_t stride, size_t samp_factors, size_t v_samp, int16_t *plane)
+{
+    size_t chunks = n * v_samp / samp_factors;
+    if (chunks == 0) return;
+    for (size_t c0 = 0; c0 + chunks <= n; c0 += chunks) {
+        size_t x = 0;
+        for (size_t b0 = 0; b0 + 64 <= chunks; b0 += 64, x += 8) {
+            const int16_t *v = coeff + c0 + b0;
+            int dc_only = 1;
+            for (int k = 1; k < 64; k++)
+                if (v[k] != 0) { dc_only = 0; break; }
+            if (!dc_only) continue;
+            for (int r = 0; r < 8; r++)
+                for (int k = 0; k < 8; k++) {
+                    int16_t *q = plane + c0 + x + (size_t)r * stride + k;
+                    if (*q < 0) *q = 0;
+                    if (*q > 255) *q = 255;
+                }
+        }
+    }
+}
+static void ext_upsample_h_rows(const int16_t *in, size_t n, size_t row_len, int16_t *out)
+{
+    for (size_t r0 = 0; r0 + row_len <= n; r0 += row_len) {
+        const int16_t *c = in + r0;
+        int16_t *o = out + 2 * r0;
+        for (size_t i = 0; i < row_len; i++) {
+            int16_t l = c[i ? i - 1 : 0], rr = c[i + 1 < row_len ? i + 1 : row_len - 1];
+            o[2 * i] = sar16(w16_add(w16_add(w16_mul(3, c[i]), l), 2), 2);
+            o[2 * i + 1] = sar16(w16_add(w16_add(w16_mul(3, c[i]), rr), 2), 2);
+        }
+    }
+}
+
 static int post_process_impl(const int16_t *const coeff[3], const size_t len[3],
                              const zjo_component comps[3], int in_cs, int out_cs, uint8_t *out,
-                             size_t out_len, size_t width, int plain)
+                             size_t out_len, size_t width, int ext)
 {
+    const int plain = ext & ZJO_EXT_PLAIN;
     size_t h_samp = comps[0].horizontal_sample, v_samp = comps[0].vertical_sample; /* :43-45 */
     size_t nin = zjo_num_components(in_cs), nout = zjo_num_components(out_cs);
     size_t x = nin < nout ? nin : nout; /* :56-59 */
@@ -434,6 +472,8 @@ static int post_process_impl(const int16_t *const coeff[3], const size_t len[3],
         ulen[z] = len[z];
         rc = zjo_idct_strip(coeff[z], len[z], comps[z].quantization_table, comps[z].width_stride,
                             h_samp * v_samp, v_samp_idct, unp[z]);
+        if (rc == ZJO_OK && (ext & ZJO_EXT_CLAMP_DC))
+            ext_clamp_dc_only(coeff[z], len[z], comps[z].width_stride, h_samp * v_samp, v_samp_idct, unp[z]);
     }
     /* post_process_inner, :103-110 */
     if (rc == ZJO_OK && (h_samp != 1 || v_samp != 1)) {
@@ -442,7 +482,19 @@ static int post_process_impl(const int16_t *const coeff[3], const size_t len[3],
             int16_t *up = (int16_t *)malloc((olen ? olen : 1) * sizeof(int16_t));
             if (!up) { rc = ZJO_ERR_NOMEM; break; }
             /* Decoder::set_upsampling, decoder.rs:478-519 (scalar arms) */
-            if (h_samp == 2 && v_samp == 1) rc = zjo_upsample_h(unp[i], ulen[i], up, olen);
+            if ((ext & ZJO_EXT_EDGE_REP) && h_samp == 2 && 2 * ulen[i] * v_samp == olen) {
+                /* rows of the chroma plane are width_stride samples long; the vertical pass keeps that row length */
+                const size_t row_len = comps[i].width_stride;
+                if (v_samp == 1) ext_upsample_h_rows(unp[i], ulen[i], row_len, up);
+                else {
+                    int16_t *mid = (int16_t *)malloc((olen / 2 ? olen / 2 : 1) * sizeof(int16_t));
+                    if (!mid) { free(up); rc = ZJO_ERR_NOMEM; break; }
+                    rc = zjo_upsample_v(unp[i], ulen[i], mid, olen / 2); /* the reference's vertical pass, Q3 unchanged */
+                    if (rc == ZJO_OK) ext_upsample_h_rows(mid, olen / 2, row_len, up);
+                    free(mid);
+                }
+            }
+            else if (h_samp == 2 && v_samp == 1) rc = zjo_upsample_h(unp[i], ulen[i], up, olen);
             else if (h_samp == 1 && v_samp == 2) rc = zjo_upsample_v(unp[i], ulen[i], up, olen);
             else if (h_samp == 2 && v_samp == 2) rc = zjo_upsample_hv(unp[i], ulen[i], up, olen);
             else rc = ZJO_ERR_ARG; /* "Unknown down-sampling method" decoder.rs:513-518 */
@@ -500,7 +552,7 @@ size_t zjo_out_len(const zjo_frame *f)
 }
 
 static int decode_planes_impl(const zjo_frame *f, const int16_t *y, const int16_t *cb, const int16_t *cr,
-                              uint8_t *out, int plain);
+                              uint8_t *out, int ext);
 
 int zjo_decode_planes(const zjo_frame *f, const int16_t *y, const int16_t *cb, const int16_t *cr,
                       uint8_t *out)
@@ -512,11 +564,18 @@ int zjo_decode_planes(const zjo_frame *f, const int16_t *y, const int16_t *cb, c
 int zjo_decode_planes_plain(const zjo_frame *f, const int16_t *y, const int16_t *cb, const int16_t *cr,
                             uint8_t *out)
 {
-    return decode_planes_impl(f, y, cb, cr, out, 1);
+    return decode_planes_impl(f, y, cb, cr, out, ZJO_EXT_PLAIN);
+}
+
+/* EXTENSION: any combination of ZJO_EXT_PLAIN / ZJO_EXT_CLAMP_DC / ZJO_EXT_EDGE_REP */
+int zjo_decode_planes_ext(const zjo_frame *f, int ext, const int16_t *y, const int16_t *cb, const int16_t *cr,
+                          uint8_t *out)
+{
+    return decode_planes_impl(f, y, cb, cr, out, ext);
 }
 
 static int decode_planes_impl(const zjo_frame *f, const int16_t *y, const int16_t *cb, const int16_t *cr,
-                              uint8_t *out, int plain)
+                              uint8_t *out, int ext)
 {
     size_t mcu_x, mcu_y;
     int rc = frame_geom(f, &mcu_x, &mcu_y);
@@ -567,7 +626,7 @@ static int decode_planes_impl(const zjo_frame *f, const int16_t *y, const int16_
             len[1] = len[2] = c_chunk;
         }                             /* else one component, :222-235: post_process(&[y, &[], &[]]) */
         rc = post_process_impl(coeff, len, comps, in_cs, out_cs, out_vector + s * chunks_size,
-                               chunks_size, width, plain);
+                               chunks_size, width, ext);
     }
     if (rc == ZJO_OK) memcpy(out, out_vector, width * height * ncomp); /* truncate, :238-242 */
     free(out_vector);

@@ -100,6 +100,15 @@ int zjo_decode_planes(const zjo_frame *f, const int16_t *y, const int16_t *cb, c
  * ZJ_FLAG_PLAIN_TAIL / ZJ_CS_RGBA / ZJ_LAYOUT_CHW of include/zjhip.h; no reference output exists for it. */
 int zjo_decode_planes_plain(const zjo_frame *f, const int16_t *y, const int16_t *cb, const int16_t *cr,
                             uint8_t *out);
+/* The full set of "corrected mode" extensions (checker for zj_frame_desc.flags): PLAIN as above; CLAMP_DC clamps the
+ * DC-only shortcut value to 0..255 (Q1; what the reference's AVX2 arm does, src/idct/avx2.rs:163-167); EDGE_REP runs
+ * the horizontal chroma filter row by row with replicated edges instead of over one flat array (Q4).  The vertical
+ * schedule (Q3) and dropped odd MCU rows are strip-geometry properties and stay. */
+#define ZJO_EXT_PLAIN 1
+#define ZJO_EXT_CLAMP_DC 2
+#define ZJO_EXT_EDGE_REP 4
+int zjo_decode_planes_ext(const zjo_frame *f, int ext, const int16_t *y, const int16_t *cb, const int16_t *cr,
+                          uint8_t *out);
 
 #ifdef __cplusplus
 }

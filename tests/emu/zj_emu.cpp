@@ -54,7 +54,7 @@ static void run(const Params& p)
                     const BlockLoc L = locate<C>(p, t, tid, lds);
                     U4 raw[8];
                     load_block(L, raw);
-                    finish_block<C>(L, raw, lds);
+                    finish_block<C>(L, raw, lds, 0, p.clamp_dc);
                 }
                 for (int tid = 0; tid < C::NT; tid++) phase_color<C, HS, VS, OUT, FAST>(p, t, tid, lds);
             }
@@ -72,7 +72,7 @@ static void run(const Params& p)
                 const BlockLoc L = locate<C>(p, t, tid, lds);
                 U4 raw[8];
                 load_block(L, raw);
-                st[tid] = steal_stage<C>(L, raw, p.qt[64 * L.comp], tid, lds);
+                st[tid] = steal_stage<C>(L, raw, p.qt[64 * L.comp], tid, lds, p.clamp_dc);
             }
             /* __syncthreads() */
             for (int tid = 0; tid < C::NT; tid++) {
@@ -88,8 +88,8 @@ static void run(const Params& p)
             const BlockLoc L = locate<C>(p, t, tid, lds);
             U4 raw[8];
             load_block(L, raw);
-            if (g_compact == 1 && FAST) classify_stage<C>(L, raw, p.qt[64 * L.comp], tid, lds);
-            else finish_block<C>(L, raw, lds);
+            if (g_compact == 1 && FAST) classify_stage<C>(L, raw, p.qt[64 * L.comp], tid, lds, p.clamp_dc);
+            else finish_block<C>(L, raw, lds, 0, p.clamp_dc);
         }
         /* __syncthreads() */
         if (g_compact == 1 && FAST) {

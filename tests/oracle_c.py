@@ -122,13 +122,21 @@ def plane_len(frame, comp):
     return lib().zjo_plane_len(C.byref(frame), C.c_int(comp))
 
 
-def decode_planes(frame, planes, plain=False):
+EXT_PLAIN, EXT_CLAMP_DC, EXT_EDGE_REP = 1, 2, 4
+
+
+def decode_planes(frame, planes, plain=False, ext=0):
     """plain=True: the oracle's EXTENSION (every pixel at its own position; RGB / RGBA / RGBX), the checker for
     ZJ_FLAG_PLAIN_TAIL, ZJ_CS_RGBA/RGBX and ZJ_LAYOUT_CHW."""
     arrs = [_i16(p) for p in planes]
     while len(arrs) < 3:
         arrs.append(np.zeros(1, np.int16))
     out = np.zeros(lib().zjo_out_len(C.byref(frame)), np.uint8)
-    fn = lib().zjo_decode_planes_plain if plain else lib().zjo_decode_planes
-    rc = fn(C.byref(frame), _p(arrs[0], C.c_int16), _p(arrs[1], C.c_int16), _p(arrs[2], C.c_int16), _p(out, C.c_uint8))
+    ext |= EXT_PLAIN if plain else 0
+    if ext:  # any combination of the extension flags (zjo_decode_planes_ext)
+        rc = lib().zjo_decode_planes_ext(C.byref(frame), C.c_int(ext), _p(arrs[0], C.c_int16), _p(arrs[1], C.c_int16),
+                                         _p(arrs[2], C.c_int16), _p(out, C.c_uint8))
+    else:
+        rc = lib().zjo_decode_planes(C.byref(frame), _p(arrs[0], C.c_int16), _p(arrs[1], C.c_int16), _p(arrs[2], C.c_int16),
+                                     _p(out, C.c_uint8))
     return rc, out

@@ -178,3 +178,31 @@ def test_random_geometry_sweep_all_output_kinds(synth):
         assert bad.size == 0, (case, w, h, mode, kind, bad[:8])
         done += 1
     assert done > 300
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("flags,out_cs,layout", [(7, oc.RGB, 0), (2, oc.GRAYSCALE, 0), (4, oc.YCBCR, 0), (6, oc.RGB, 0),
+                                                 (6, oc.RGBA, 0), (6, oc.RGB, 1), (3, oc.RGB, 0), (5, oc.RGB, 0)])
+@pytest.mark.parametrize("wh", [(64, 64), (528, 40), (32, 8), (1040, 33), (100, 32), (37, 50), (17, 16), (250, 72)])
+@pytest.mark.parametrize("compact", [0, 3])
+def test_emulated_corrected_mode_flags(mode, flags, out_cs, layout, wh, compact, synth):
+    """ZJ_FLAG_CLAMP_DC (Q1) and ZJ_FLAG_EDGE_REPLICATE (Q4), alone and combined with PLAIN_TAIL / RGBA / CHW, against
+    the oracle's zjo_decode_planes_ext; the adversarial set is where unclamped DC-only values actually occur."""
+    emu_c.set_variant(compact)
+    hs, vs = MODES[mode]
+    w, h = wh
+    for adversarial in (False, True):
+        mk = synth.make_adversarial_frame if adversarial else synth.make_frame
+        planes, qts = mk(w, h, hs, vs, 3, seed=91)
+        f = oc.make_frame(w, h, hs, vs, 3, out_cs, qts)
+        ext = flags | (oc.EXT_PLAIN if (out_cs == oc.RGBA or layout == 1) else 0)
+        rc, exp = oc.decode_planes(f, planes, ext=ext)
+        rce, out = emu_c.decode_planes(f, planes, flags=flags, out_layout=layout)
+        if rc != 0:
+            assert rce == -5
+            continue
+        if layout == 1:
+            exp = np.ascontiguousarray(exp.reshape(h, w, 3).transpose(2, 0, 1)).reshape(-1)
+        assert rce == 0
+        bad = np.nonzero(out != exp)[0]
+        assert bad.size == 0, (mode, flags, out_cs, layout, wh, adversarial, bad[:8])

@@ -341,7 +341,7 @@ def test_unsupported_and_invalid_arguments(ctx, zj, synth):
     with pytest.raises(zj.ZjError):       # CMYK output is a no-op in the reference
         ctx.decode_planes(zj.FrameDesc.make(64, 64, 2, 2, 3, int(zj.ColorSpace.CMYK), qts), planes)
     with pytest.raises(zj.ZjError):       # unknown flag bits / layouts are argument errors
-        ctx.decode_planes(zj.FrameDesc.make(64, 64, 2, 2, 3, 0, qts, flags=6), planes)
+        ctx.decode_planes(zj.FrameDesc.make(64, 64, 2, 2, 3, 0, qts, flags=8), planes)
     with pytest.raises(zj.ZjError):
         ctx.decode_planes(zj.FrameDesc.make(64, 64, 2, 2, 3, 0, qts, out_layout=7), planes)
 
@@ -621,3 +621,28 @@ def test_decode_to_tensor_for_torch_consumers(zj, synth):
     finally:
         ctx.close()
 
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("flags,out_cs,layout", [(7, oc.RGB, 0), (2, oc.GRAYSCALE, 0), (4, oc.YCBCR, 0), (6, oc.RGBA, 0), (6, oc.RGB, 1)])
+@pytest.mark.parametrize("wh", [(528, 40), (1040, 33), (100, 32), (250, 72), (1920, 1080)])
+def test_corrected_mode_flags(ctx, zj, synth, mode, flags, out_cs, layout, wh):
+    """ZJ_FLAG_CLAMP_DC / ZJ_FLAG_EDGE_REPLICATE / ZJ_FLAG_CORRECTED through the C ABI against zjo_decode_planes_ext"""
+    hs, vs = MODES[mode]
+    w, h = wh
+    for adversarial in (False, True):
+        if adversarial and w * h > 600_000:
+            continue
+        mk = synth.make_adversarial_frame if adversarial else synth.make_frame
+        planes, qts = mk(w, h, hs, vs, 3, seed=91)
+        ext = flags | (oc.EXT_PLAIN if (out_cs == oc.RGBA or layout == 1) else 0)
+        rc, exp = oc.decode_planes(oc.make_frame(w, h, hs, vs, 3, out_cs, qts), planes, ext=ext)
+        d = zj.FrameDesc.make(w, h, hs, vs, 3, out_cs, qts, flags=flags, out_layout=layout)
+        if rc != 0:
+            with pytest.raises(zj.ZjError) as e:
+                ctx.decode_planes(d, planes)
+            assert e.value.status == -5
+            continue
+        if layout == 1:
+            exp = np.ascontiguousarray(exp.reshape(h, w, 3).transpose(2, 0, 1)).reshape(-1)
+        assert_same(ctx.decode_planes(d, planes), exp, (mode, flags, out_cs, layout, wh, adversarial))

@@ -281,10 +281,11 @@ ZJ_DEV void idct_block(const U4 raw[8], const int32_t* qt, U4 out[8])
 
 // Q1: DC-only blocks take the shortcut value: i16 wrapping product, floor >> 3, + 128, NOT clamped
 // (scalar.rs:48).  Returns the value replicated in both 16-bit lanes.
-ZJ_DEV uint32_t dc_only_value(uint32_t w0, int32_t q0)
+ZJ_DEV uint32_t dc_only_value(uint32_t w0, int32_t q0, const int clamp = 0)
 {
     const int16_t dc = (int16_t)(uint16_t)((uint32_t)lo16s(w0) * (uint32_t)(int32_t)(int16_t)q0);
-    const int32_t v = ((int32_t)dc >> 3) + 128;
+    int32_t v = ((int32_t)dc >> 3) + 128;
+    if (clamp) v = v < 0 ? 0 : (v > 255 ? 255 : v); // ZJ_FLAG_CLAMP_DC (extension)
     return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16);
 }
 
@@ -406,6 +407,8 @@ struct Params {
     int debug;                    // diagnostics only (tools/ablate.py): 1 skip IDCT, 2 skip colour math, 4 no loads, 8 no stores
     int plain;                    // OUT_RGB only: 1 = the last 16 samples of a row go to their own position (no Q5/Q6)
     long long plane_stride;       // OUT_RGB_CHW: bytes between the R, G and B planes of a frame (width * height)
+    int clamp_dc;                 // extension: DC-only shortcut value clamped to 0..255 (Q1 corrected)
+    int edge_rep;                 // extension: horizontal chroma filter per row with replicated edges (Q4 corrected)
 };
 
 // vertical schedule of upsample_vertical (upsampler/scalar.rs:84-144): pair k -> (near, far)
@@ -589,7 +592,7 @@ ZJ_DEV void phase_setup(const Params& p, const int tid, int16_t* lds)
 }
 
 template <class C>
-ZJ_DEV void finish_block(const BlockLoc& L, const U4 raw[8], int16_t* lds, const int debug = 0)
+ZJ_DEV void finish_block(const BlockLoc& L, const U4 raw[8], int16_t* lds, const int debug = 0, const int clamp_dc = 0)
 {
     if (!L.valid) return;
     const uint32_t* w = reinterpret_cast<const uint32_t*>(raw);
@@ -602,7 +605,7 @@ ZJ_DEV void finish_block(const BlockLoc& L, const U4 raw[8], int16_t* lds, const
         idct_block(raw, qt, px);
         store_block(L, px);
     } else { // one splat row stored eight times: no 32-register fill for the shortcut lanes
-        const uint32_t v = dc_only_value(w[0], qt[0]);
+        const uint32_t v = dc_only_value(w[0], qt[0], clamp_dc);
         const U4 row = {v, v, v, v};
         if (L.halo == 0) {
 #pragma unroll
@@ -643,7 +646,7 @@ ZJ_DEV void wave_queue_push(int* qcnt, uint32_t* queue, const int tid, const boo
 }
 
 template <class C>
-ZJ_DEV void classify_stage(const BlockLoc& L, const U4 raw[8], const int32_t q0, const int tid, int16_t* lds)
+ZJ_DEV void classify_stage(const BlockLoc& L, const U4 raw[8], const int32_t q0, const int tid, int16_t* lds, const int clamp_dc = 0)
 {
     bool full = false;
     uint32_t entry = 0;
@@ -654,7 +657,7 @@ ZJ_DEV void classify_stage(const BlockLoc& L, const U4 raw[8], const int32_t q0,
         for (int i = 1; i < 32; i++) any |= w[i];
         full = any != 0;
         if (!full) {
-            const uint32_t v = dc_only_value(w[0], q0);
+            const uint32_t v = dc_only_value(w[0], q0, clamp_dc);
             U4 px[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) { px[r].x = v; px[r].y = v; px[r].z = v; px[r].w = v; }
@@ -744,7 +747,7 @@ ZJ_DEV int wave_rank(int* cnt_slot, const int tid, const bool pred)
 struct StealState { bool full; int rank; }; // full: this lane's own block needs the IDCT; rank: see steal_stage
 
 template <class C>
-ZJ_DEV StealState steal_stage(const BlockLoc& L, const U4 raw[8], const int32_t q0, const int tid, int16_t* lds)
+ZJ_DEV StealState steal_stage(const BlockLoc& L, const U4 raw[8], const int32_t q0, const int tid, int16_t* lds, const int clamp_dc = 0)
 {
     constexpr int DONOR = C::NT / 64 - 1;
     const int w = tid >> 6;
@@ -757,7 +760,7 @@ ZJ_DEV StealState steal_stage(const BlockLoc& L, const U4 raw[8], const int32_t 
         for (int i = 1; i < 32; i++) any |= wd[i];
         st.full = any != 0;
         if (!st.full) {
-            const uint32_t v = dc_only_value(wd[0], q0);
+            const uint32_t v = dc_only_value(wd[0], q0, clamp_dc);
             const U4 row = {v, v, v, v};
             if (L.halo == 0) {
 #pragma unroll
@@ -959,7 +962,10 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, int16_t*
         // m-1 / m+1 where the flat-array neighbour wraps to the other end of the strip (Q4)
         const bool first = HS == 2 && (g == 0) && left_wrap;                  // chroma column 0 of the strip
         const bool last = HS == 2 && (8 * g + 8 == 8 * nvalid) && right_wrap; // last chroma column
-        const bool no_left = first && m == 0, no_right = last && m == C::SH - 1;
+        // ZJ_FLAG_EDGE_REPLICATE (extension): the neighbour beyond a row's end is the end sample itself, in every row,
+        // so neither the wrap to the previous / next row nor the strip-end special cases apply
+        const bool rep_first = first && p.edge_rep, rep_last = last && p.edge_rep;
+        const bool no_left = first && m == 0 && !p.edge_rep, no_right = last && m == C::SH - 1 && !p.edge_rep;
         int oa, ob, oal, obl, oar, obr;
         if (VS == 2) {
             const int16_t* lut = lds_lut<C>(lds);
@@ -1008,6 +1014,8 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, int16_t*
                     prev = tri(prev, *reinterpret_cast<const uint32_t*>(cp + obl + lc - 2));
                     next = tri(next, *reinterpret_cast<const uint32_t*>(cp + obr + lc + 8));
                 }
+                if (rep_first) prev = vm[0] << 16; // (x, v0) with v0 := v1
+                if (rep_last) next = vm[3] >> 16;  // (v9, x) with v9 := v8
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const uint32_t L = align16(vm[k], k == 0 ? prev : vm[k - 1]); // (v_{2k},   v_{2k+1})

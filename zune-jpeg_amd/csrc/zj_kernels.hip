@@ -51,19 +51,19 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), ZJ_WAVES_PER_SIMD) void zj_
     if (IDCT_MODE == 3) {
         const int32_t q0 = p.qt[64 * L.comp]; // the DC-only shortcut needs q[0] before the tables are staged
         phase_setup<C, HS, VS>(p, tid, lds);
-        const StealState st = steal_stage<C>(L, raw, q0, tid, lds);
+        const StealState st = steal_stage<C>(L, raw, q0, tid, lds, p.clamp_dc);
         __syncthreads();
         steal_idct<C>(L, raw, st, tid, lds);
     } else if (IDCT_MODE) {
         const int32_t q0 = p.qt[64 * L.comp]; // the DC-only shortcut needs q[0] before the tables are staged
         phase_setup<C, HS, VS>(p, tid, lds);
-        classify_stage<C>(L, raw, q0, tid, lds);
+        classify_stage<C>(L, raw, q0, tid, lds, p.clamp_dc);
         __syncthreads();
         idct_queue<C>(tid, lds);
     } else {
         phase_setup<C, HS, VS>(p, tid, lds);
         __syncthreads();
-        finish_block<C>(L, raw, lds, p.debug);
+        finish_block<C>(L, raw, lds, p.debug, p.clamp_dc);
     }
     __syncthreads();
     ZJ_SETPRIO(2, 2); // (off) let a tile's last phase, the one that frees the workgroup slot, go first
@@ -100,7 +100,7 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), 4) void zj_fused_persistent
     phase_setup<C, HS, VS>(p, tid, lds);
     __syncthreads();
     for (;;) {
-        finish_block<C>(L, raw, lds, p.debug);
+        finish_block<C>(L, raw, lds, p.debug, p.clamp_dc);
         const int nid = id + w.step;
         const bool more = nid < w.last;
         TileId tn = t;

@@ -17,6 +17,8 @@ struct Plan {
     int hs, vs;          // luma sampling factors
     int out;             // OUT_RGB / OUT_GRAY / OUT_YCBCR / OUT_RGBA / OUT_RGB_CHW
     int plain;           // OUT_RGB with ZJ_FLAG_PLAIN_TAIL
+    int clamp_dc;        // ZJ_FLAG_CLAMP_DC
+    int edge_rep;        // ZJ_FLAG_EDGE_REPLICATE (meaningful when hs == 2)
     int mcu_x, mcu_y;
     int n_strips;        // strips the reference's zip() would process
     int strip_rows;      // luma rows per strip
@@ -74,7 +76,9 @@ inline int make_plan(const zj_frame_desc* d, Plan& pl)
     // RGBA/RGBX are malformed in the reference itself; here they are an extension: R G B 255
     else if ((d->out_colorspace == ZJ_CS_RGBA || d->out_colorspace == ZJ_CS_RGBX) && d->in_components == 3) pl.out = OUT_RGBA;
     else return ZJ_ERR_UNSUPPORTED; // CMYK/YCCK are no-ops in the reference
-    if (d->flags & ~(uint32_t)ZJ_FLAG_PLAIN_TAIL) return ZJ_ERR_ARG;
+    if (d->flags & ~(uint32_t)ZJ_FLAG_CORRECTED) return ZJ_ERR_ARG;
+    pl.clamp_dc = (d->flags & ZJ_FLAG_CLAMP_DC) ? 1 : 0;
+    pl.edge_rep = ((d->flags & ZJ_FLAG_EDGE_REPLICATE) && pl.hs == 2) ? 1 : 0;
     pl.plain = (pl.out == OUT_RGB && (d->flags & ZJ_FLAG_PLAIN_TAIL)) ? 1 : 0;
     if (d->out_layout == ZJ_LAYOUT_CHW) {
         if (pl.out == OUT_RGB) pl.out = OUT_RGB_CHW;            // planar u8 tensor layout, every pixel at its own place
@@ -142,6 +146,8 @@ inline void fill_params(const zj_frame_desc* d, const Plan& pl, size_t nframes, 
     p.total_tiles = (int)nframes * pl.n_strips * pl.tiles_per_row;
     p.debug = 0;
     p.plain = pl.plain;
+    p.clamp_dc = pl.clamp_dc;
+    p.edge_rep = pl.edge_rep;
     p.plane_stride = (long long)d->width * d->height;
 }
 

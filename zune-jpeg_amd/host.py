@@ -58,6 +58,9 @@ class Component(C.Structure):  # zj_component  <->  Components, src/components.r
 
 
 FLAG_PLAIN_TAIL = 1   # zj_frame_desc.flags: extension, every pixel at its own position (no Q5/Q6)
+FLAG_CLAMP_DC = 2     # extension: DC-only shortcut value clamped to 0..255 (Q1 corrected)
+FLAG_EDGE_REPLICATE = 4  # extension: horizontal chroma filter per row with replicated edges (Q4 corrected)
+FLAG_CORRECTED = 7
 LAYOUT_HWC, LAYOUT_CHW = 0, 1
 
 
