@@ -171,6 +171,12 @@ ZJ_DEV void idct_1d(const int32_t s[8], const int32_t bias, int32_t o[8])
     const IdctHalf h = idct_1d_mul(s, bias);
     idct_1d_add(h, o);
 }
+// keeps a rarely taken, wave-uniform branch a branch (an empty asm statement cannot be if-converted into selects)
+#if defined(ZJ_EMU)
+#define ZJ_NO_IF_CONVERT() ((void)0)
+#else
+#define ZJ_NO_IF_CONVERT() asm volatile("" ::: "memory")
+#endif
 #if defined(ZJ_EMU) || defined(ZJ_IDCT_NOBARRIER)
 #define ZJ_SCHED_BARRIER() ((void)0)
 #else
@@ -1014,8 +1020,11 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, int16_t*
                     prev = tri(prev, *reinterpret_cast<const uint32_t*>(cp + obl + lc - 2));
                     next = tri(next, *reinterpret_cast<const uint32_t*>(cp + obr + lc + 8));
                 }
-                if (rep_first) prev = vm[0] << 16; // (x, v0) with v0 := v1
-                if (rep_last) next = vm[3] >> 16;  // (v9, x) with v9 := v8
+                if (p.edge_rep) { // uniform branch (kernel argument): the default path pays no select for it
+                    ZJ_NO_IF_CONVERT();
+                    if (rep_first) prev = vm[0] << 16; // (x, v0) with v0 := v1
+                    if (rep_last) next = vm[3] >> 16;  // (v9, x) with v9 := v8
+                }
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const uint32_t L = align16(vm[k], k == 0 ? prev : vm[k - 1]); // (v_{2k},   v_{2k+1})
