@@ -52,6 +52,7 @@ pub struct zj_frame_desc {
 pub struct zj_options {              // <-> ZuneJpegOptions, src/options.rs:6-40 (zero = reference default)
     pub out_colorspace: i32, pub strict_mode: i32, pub max_width: i32, pub max_height: i32,
     pub max_scans: i32, pub num_threads: i32, pub pinned_planes: i32,
+    pub flags: u32, pub out_layout: u32,
 }
 
 #[repr(C)]
@@ -173,6 +174,8 @@ impl ZuneJpegOptions {
     pub fn set_max_width(mut self, w: u16) -> Self { self.raw.max_width = w as i32; self }
     pub fn set_max_height(mut self, h: u16) -> Self { self.raw.max_height = h as i32; self }
     pub fn set_max_scans(mut self, n: usize) -> Self { self.raw.max_scans = n as i32; self }
+    /// extension: ZJ_FLAG_* (0 = the reference's bytes; ZJ_FLAG_CORRECTED = the non-quirk mode)
+    pub fn set_flags(mut self, flags: u32) -> Self { self.raw.flags = flags; self }
 }
 
 /// `Decoder` (`src/decoder.rs:60`): CPU entropy decode, GPU pixel path.

@@ -202,6 +202,8 @@ typedef struct zj_options {      /* zero = reference default */
                                     the pixel path is one GPU launch, so they decode restart segments (DRI/RSTn,
                                     baseline) concurrently and clear the planes; 1 = strictly serial */
     int32_t pinned_planes;       /* non-zero: coefficient planes live in pinned host memory (DMA without staging) */
+    uint32_t flags;              /* ZJ_FLAG_* for the pixel path (0 = the reference's bytes), see zj_frame_desc */
+    uint32_t out_layout;         /* ZJ_LAYOUT_HWC (0) or ZJ_LAYOUT_CHW */
 } zj_options;
 typedef struct zj_image_info {   /* ImageInfo, src/decoder.rs:652-668 (+ what the GPU path needs) */
     uint16_t width, height;

@@ -508,6 +508,29 @@ def test_extensions_batches_through_the_host_pipeline(ctx, zj, synth, kind):
             assert_same(out[i * olen:(i + 1) * olen], exp, (kind, w, h, i))
 
 
+def test_decoder_corrected_mode_and_planar_options(ctx, zj, synth):
+    """zj_options.flags / out_layout reach the pixel path: Decoder with ZJ_FLAG_CORRECTED and with planar output"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import jpeg_enc
+    w, h = 208, 96
+    planes = jpeg_enc.small_planes(w, h, 2, 2, 3, seed=13)
+    qts = synth.quant_tables(90)
+    blob = jpeg_enc.encode_baseline(planes, qts, w, h, 2, 2, 3)
+    f = oc.make_frame(w, h, 2, 2, 3, oc.RGB, qts)
+    o = zj.ZuneJpegOptions()
+    o.flags = zj.FLAG_CORRECTED
+    rc, exp = oc.decode_planes(f, planes, ext=7)
+    assert rc == 0
+    assert_same(zj.Decoder(o, ctx).decode_buffer(blob), exp, "decoder corrected")
+    o = zj.ZuneJpegOptions()
+    o.out_layout = zj.LAYOUT_CHW
+    rc, exp = oc.decode_planes(f, planes, plain=True)
+    assert rc == 0
+    assert_same(zj.Decoder(o, ctx).decode_buffer(blob), np.ascontiguousarray(exp.reshape(h, w, 3).transpose(2, 0, 1)).reshape(-1),
+                "decoder chw")
+
+
 def test_decoder_rgba_option(ctx, zj, synth):
     """Decoder with out_colorspace RGBA: the reference's own RGBA arm is malformed; here R G B 255 per pixel"""
     import sys

@@ -47,7 +47,7 @@ def main():
     L.zj_decoder_decode_coefficients.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 
     class Opt(C.Structure):
-        _fields_ = [(n, C.c_int32) for n in ("out_colorspace", "strict_mode", "max_width", "max_height", "max_scans", "num_threads", "pinned_planes")]
+        _fields_ = [(n, C.c_int32) for n in ("out_colorspace", "strict_mode", "max_width", "max_height", "max_scans", "num_threads", "pinned_planes", "flags", "out_layout")]
 
     qts = synth.quant_tables(85)
     seeds = []
@@ -61,7 +61,7 @@ def main():
     rng = np.random.default_rng(7)
     decs = []
     for threads in (1, 3):
-        o = Opt(0, 0, 0, 0, 0, threads, 0)
+        o = Opt(0, 0, 0, 0, 0, threads, 0, 0, 0)
         decs.append(L.zj_decoder_new(C.byref(o)))
     stats = {}
     desc = (C.c_char * 1024)()

@@ -214,6 +214,7 @@ struct zj_decoder {
     int max_width = 16384, max_height = 16384, max_scans = 64;
     int threads = 4;       // options.rs:33 (default 4): here, restart segments / plane zeroing in parallel
     bool pinned = false;   // coefficient planes in pinned host memory
+    uint32_t flags = 0, out_layout = 0; // extensions of the pixel path, passed through to zj_frame_desc
     PlaneStore store[3];
     ~zj_decoder() { for (auto& st : store) st.release(); }
     // state
@@ -810,6 +811,8 @@ zj_decoder* zj_decoder_new(const zj_options* opt)
         if (opt->max_scans) d->max_scans = opt->max_scans;
         if (opt->num_threads > 0) d->threads = opt->num_threads;
         d->pinned = opt->pinned_planes != 0;
+        d->flags = opt->flags;
+        d->out_layout = opt->out_layout;
     }
     return d;
 }
@@ -832,6 +835,8 @@ static void fill_info(const zj_decoder* d, zj_image_info* info, zj_frame_desc* f
         fd->in_components = (uint32_t)d->ncomp;
         // single-component images are always decoded to GRAYSCALE (headers.rs:283-290)
         fd->out_colorspace = d->ncomp == 1 ? (int)ZJ_CS_GRAYSCALE : d->out_colorspace;
+        fd->flags = d->flags;
+        fd->out_layout = d->out_layout;
         for (int c = 0; c < 3; c++) {
             const int tq = d->comps[c < d->ncomp ? c : 0].tq;
             for (int k = 0; k < 64; k++) fd->qt[c][k] = d->qt[tq][k];

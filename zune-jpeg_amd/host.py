@@ -84,7 +84,7 @@ class FrameDesc(C.Structure):  # zj_frame_desc
 class Options(C.Structure):  # zj_options
     _fields_ = [("out_colorspace", C.c_int32), ("strict_mode", C.c_int32), ("max_width", C.c_int32),
                 ("max_height", C.c_int32), ("max_scans", C.c_int32), ("num_threads", C.c_int32),
-                ("pinned_planes", C.c_int32)]
+                ("pinned_planes", C.c_int32), ("flags", C.c_uint32), ("out_layout", C.c_uint32)]
 
 
 class ImageInfo(C.Structure):  # zj_image_info  <->  ImageInfo, src/decoder.rs:652-668
@@ -107,6 +107,8 @@ class ZuneJpegOptions:
         self.backend = BACKEND_HIP
         self.device = 0
         self.pinned_planes = False
+        self.flags = 0          # FLAG_* extensions of the pixel path (0 = the reference's bytes)
+        self.out_layout = LAYOUT_HWC
 
     def to_c(self):
         o = Options()
@@ -115,6 +117,7 @@ class ZuneJpegOptions:
         o.max_width, o.max_height, o.max_scans = self.max_width, self.max_height, self.max_scans
         o.num_threads = int(self.num_threads)
         o.pinned_planes = int(bool(self.pinned_planes))
+        o.flags, o.out_layout = int(self.flags), int(self.out_layout)
         return o
 
 
