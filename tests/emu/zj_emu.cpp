@@ -68,18 +68,19 @@ static void run(const Params& p)
         /* __syncthreads() */
         if ((g_compact & 3) == 3 && FAST) { // work stealing: stage (all lanes), barrier, take + IDCT (all lanes)
             std::vector<StealState> st(C::NT);
+            const int donor = (t.tile + t.strip + t.frame) % (C::NT / 64); // rotates like the kernel's
             for (int tid = 0; tid < C::NT; tid++) {
                 const BlockLoc L = locate<C>(p, t, tid, lds);
                 U4 raw[8];
                 load_block(L, raw);
-                st[tid] = steal_stage<C>(L, raw, p.qt[64 * L.comp], tid, lds, p.clamp_dc);
+                st[tid] = steal_stage<C>(L, raw, p.qt[64 * L.comp], tid, lds, p.clamp_dc, donor);
             }
             /* __syncthreads() */
             for (int tid = 0; tid < C::NT; tid++) {
                 const BlockLoc L = locate<C>(p, t, tid, lds);
                 U4 raw[8];
                 load_block(L, raw); // registers survive the barrier on the GPU; the emulator reloads
-                steal_idct<C>(L, raw, st[tid], tid, lds);
+                steal_idct<C>(L, raw, st[tid], tid, lds, donor);
             }
             color_all<C, HS, VS, OUT, FAST>(p, t, lds);
             continue;

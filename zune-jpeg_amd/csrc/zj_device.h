@@ -753,9 +753,9 @@ ZJ_DEV int wave_rank(int* cnt_slot, const int tid, const bool pred)
 struct StealState { bool full; int rank; }; // full: this lane's own block needs the IDCT; rank: see steal_stage
 
 template <class C>
-ZJ_DEV StealState steal_stage(const BlockLoc& L, const U4 raw[8], const int32_t q0, const int tid, int16_t* lds, const int clamp_dc = 0)
+ZJ_DEV StealState steal_stage(const BlockLoc& L, const U4 raw[8], const int32_t q0, const int tid, int16_t* lds, const int clamp_dc = 0,
+                              const int DONOR = C::NT / 64 - 1)
 {
-    constexpr int DONOR = C::NT / 64 - 1;
     const int w = tid >> 6;
     StealState st;
     st.full = false;
@@ -797,16 +797,17 @@ ZJ_DEV StealState steal_stage(const BlockLoc& L, const U4 raw[8], const int32_t 
 }
 
 template <class C>
-ZJ_DEV void steal_idct(const BlockLoc& Lown, U4 raw[8], const StealState st, const int tid, int16_t* lds)
+ZJ_DEV void steal_idct(const BlockLoc& Lown, U4 raw[8], const StealState st, const int tid, int16_t* lds,
+                       const int DONOR = C::NT / 64 - 1)
 {
-    constexpr int NW = C::NT / 64, DONOR = NW - 1;
+    constexpr int NW = C::NT / 64;
     const int w = tid >> 6;
     const int* qc = lds_qcnt<C>(lds);
     const int offered = qc[DONOR];
     int idle_before = 0, idle_total = 0;
 #pragma unroll
-    for (int k = 0; k < DONOR; k++) {
-        const int c = qc[k];
+    for (int k = 0; k < NW; k++) {
+        const int c = (k == DONOR) ? 0 : qc[k];
         idle_before += (k < w) ? c : 0;
         idle_total += c;
     }

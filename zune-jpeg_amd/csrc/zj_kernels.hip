@@ -23,6 +23,9 @@ namespace zj {
 // ------------------------------------------------------------------------------------------------
 // ZJ_PRIO bit 0: raise the wave priority while a tile's coefficient loads are being issued (+1 % measured,
 // tools/ab_libs.sh); bit 1: raise it for the colour phase (no gain).  Default: bit 0.
+#ifndef ZJ_STEAL_ROTATE
+#define ZJ_STEAL_ROTATE 1
+#endif
 #ifndef ZJ_PRIO
 #define ZJ_PRIO 1
 #endif
@@ -51,9 +54,11 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), ZJ_WAVES_PER_SIMD) void zj_
     if (IDCT_MODE == 3) {
         const int32_t q0 = p.qt[64 * L.comp]; // the DC-only shortcut needs q[0] before the tables are staged
         phase_setup<C, HS, VS>(p, tid, lds);
-        const StealState st = steal_stage<C>(L, raw, q0, tid, lds, p.clamp_dc);
+        // the donor wave changes from tile to tile: a wave stays on its SIMD, so a fixed donor would relieve one SIMD only
+        const int donor = ZJ_STEAL_ROTATE ? (t.tile + t.strip + t.frame) % (C::NT / 64) : C::NT / 64 - 1;
+        const StealState st = steal_stage<C>(L, raw, q0, tid, lds, p.clamp_dc, donor);
         __syncthreads();
-        steal_idct<C>(L, raw, st, tid, lds);
+        steal_idct<C>(L, raw, st, tid, lds, donor);
     } else if (IDCT_MODE) {
         const int32_t q0 = p.qt[64 * L.comp]; // the DC-only shortcut needs q[0] before the tables are staged
         phase_setup<C, HS, VS>(p, tid, lds);
