@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--workload", choices=["420-rgb", "444-rgb", "444-gray", "420-rgba", "420-chw"], default="420-rgb",
                     help="420-rgb = BASELINE.json configs[1] (the headline); 444-* are configs[2]; 420-rgba / 420-chw are "
                          "the output extensions (4 B/px interleaved, planar u8)")
-    ap.add_argument("--variant", choices=["onepass", "compact", "persistent", "steal", "tstore", "steal+tstore"], default=None, help="kernel variant (default: library default)")
+    ap.add_argument("--variant", choices=["packed", "wide", "packed-direct"], default=None, help="kernel variant (default: library default)")
     args = ap.parse_args()
 
     import numpy as np
@@ -122,7 +122,7 @@ def main():
     B = args.frames
     ctx = zj.Context(zj.BACKEND_HIP, gpu_index)
     if args.variant:
-        ctx.set_variant({"onepass": 0, "compact": 1, "persistent": 2, "steal": 3, "tstore": 4, "steal+tstore": 7}[args.variant])
+        ctx.set_variant({"packed": 0, "wide": 1, "packed-direct": 2}[args.variant])
     # synthetic data, SURVEY.md 8d generator; every rank decodes its own shard of the global batch
     lo, _ = shard.shard_range(B * world, rank, world)
     hs, vs, out_cs, bytes_per_px = {"420-rgb": (2, 2, zj.ColorSpace.RGB, 6.0), "444-rgb": (1, 1, zj.ColorSpace.RGB, 9.0),

@@ -14,90 +14,70 @@
 
 using namespace zj;
 
-static int g_compact = 0, g_persistent_wgs = 24;
-extern "C" void zje_set_variant(int compact) { g_compact = compact; }
-extern "C" void zje_set_persistent_wgs(int n) { g_persistent_wgs = n; }
+static int g_variant = 0; // 0 packed generation (staged stores where they apply), 1 wide generation, 2 packed with direct stores
+extern "C" void zje_set_variant(int v) { g_variant = v; }
+// statistics of the last zje_decode_planes call: blocks by class (classify_block), tiles redone wide
+static long long g_cls[3] = {0, 0, 0}, g_redo = 0;
+extern "C" void zje_stats(long long out[4]) { out[0] = g_cls[0]; out[1] = g_cls[1]; out[2] = g_cls[2]; out[3] = g_redo; }
 
-// phase 2 for every lane of the workgroup; with transposed stores (variants 4 and 7) a round is two half-steps per
-// wave: all lanes stage, then all lanes copy out (the GPU runs them back to back inside each wave)
 template <class C, int HS, int VS, int OUT, bool FAST>
-static void color_all(const Params& p, const TileId t, int16_t* lds)
+static void tile_wide(const Params& p, const TileId t, char* lds)
 {
-    constexpr bool CAN_TS = FAST && (OUT == OUT_RGB || OUT == OUT_YCBCR);
-    if (CAN_TS && (g_compact & 4) && ts_eligible<C>(p, OUT, FAST)) {
-        for (int round = 0; round * C::NT < C::NITEMS; round++)
-            for (int w = 0; w < C::NT / 64; w++) {
-                for (int l = 0; l < 64; l++) phase_color<C, HS, VS, OUT, FAST, CAN_TS>(p, t, 64 * w + l, lds, round);
-                for (int l = 0; l < 64; l++) color_copyout<C, OUT>(p, t, 64 * w + l, lds, round);
-            }
-        return;
+    for (int tid = 0; tid < C::NT; tid++) phase_setup<C, HS, VS, GEN_WIDE>(p, tid, lds);
+    /* __syncthreads() */
+    for (int tid = 0; tid < C::NT; tid++) {
+        const BlockLoc L = locate<C, GEN_WIDE>(p, t, tid, lds);
+        U4 raw[8];
+        load_block(L, raw);
+        finish_block<C, GEN_WIDE, false>(L, raw, lds, 0, p.clamp_dc);
     }
-    for (int tid = 0; tid < C::NT; tid++) phase_color<C, HS, VS, OUT, FAST>(p, t, tid, lds);
+    /* __syncthreads() */
+    for (int tid = 0; tid < C::NT; tid++) phase_color<C, HS, VS, OUT, GEN_WIDE, FAST>(p, t, tid, lds);
 }
 
 template <int HS, int VS, int OUT, bool FAST>
 static void run(const Params& p)
 {
     using C = Cfg<HS, VS, OUT>;
-    std::vector<char> lds_store(C::LDS_BYTES_TS + 32);
+    constexpr bool NEED_Y16 = OUT == OUT_RGB || OUT == OUT_RGBA || OUT == OUT_RGB_CHW;
+    constexpr bool CAN_TS = FAST && C::TSCAP;
+    std::vector<char> lds_store(C::LDS_PACKED + 32);
     // 16-byte aligned like a real LDS allocation
-    int16_t* lds = (int16_t*)(((uintptr_t)lds_store.data() + 15) & ~(uintptr_t)15);
-    if (g_compact == 2 && FAST) { // persistent walk: every tile exactly once, in each workgroup's order
-        const int nwg = g_persistent_wgs < p.total_tiles ? g_persistent_wgs : p.total_tiles;
-        for (int wg = 0; wg < nwg; wg++) {
-            memset(lds, 0x7B, C::LDS_BYTES_COMPACT);
-            for (int tid = 0; tid < C::NT; tid++) phase_setup<C, HS, VS>(p, tid, lds);
-            const TileWalk w = persistent_walk(p, wg, nwg);
-            for (int id = w.first; id < w.last; id += w.step) {
-                const TileId t = tile_from_id(p, id);
-                for (int tid = 0; tid < C::NT; tid++) {
-                    const BlockLoc L = locate<C>(p, t, tid, lds);
-                    U4 raw[8];
-                    load_block(L, raw);
-                    finish_block<C>(L, raw, lds, 0, p.clamp_dc);
-                }
-                for (int tid = 0; tid < C::NT; tid++) phase_color<C, HS, VS, OUT, FAST>(p, t, tid, lds);
-            }
-        }
-        return;
-    }
+    char* lds = (char*)(((uintptr_t)lds_store.data() + 15) & ~(uintptr_t)15);
+    const bool ts = CAN_TS && g_variant == 0 && ts_eligible<C>(p, OUT, FAST);
     for (int bid = 0; bid < p.total_tiles; bid++) {
-        memset(lds, 0x7B, C::LDS_BYTES_TS); // poison: unwritten LDS must not matter
+        memset(lds, 0x7B, C::LDS_PACKED); // poison: unwritten LDS must not matter
         const TileId t = decode_tile(p, bid);
-        for (int tid = 0; tid < C::NT; tid++) phase_setup<C, HS, VS>(p, tid, lds);
+        if (g_variant == 1) { tile_wide<C, HS, VS, OUT, FAST>(p, t, lds); continue; }
+        for (int tid = 0; tid < C::NT; tid++) phase_setup<C, HS, VS, GEN_PACKED>(p, tid, lds);
         /* __syncthreads() */
-        if ((g_compact & 3) == 3 && FAST) { // work stealing: stage (all lanes), barrier, take + IDCT (all lanes)
-            std::vector<StealState> st(C::NT);
-            const int donor = (t.tile + t.strip + t.frame) % (C::NT / 64); // rotates like the kernel's
-            for (int tid = 0; tid < C::NT; tid++) {
-                const BlockLoc L = locate<C>(p, t, tid, lds);
-                U4 raw[8];
-                load_block(L, raw);
-                st[tid] = steal_stage<C>(L, raw, p.qt[64 * L.comp], tid, lds, p.clamp_dc, donor);
-            }
-            /* __syncthreads() */
-            for (int tid = 0; tid < C::NT; tid++) {
-                const BlockLoc L = locate<C>(p, t, tid, lds);
-                U4 raw[8];
-                load_block(L, raw); // registers survive the barrier on the GPU; the emulator reloads
-                steal_idct<C>(L, raw, st[tid], tid, lds, donor);
-            }
-            color_all<C, HS, VS, OUT, FAST>(p, t, lds);
-            continue;
-        }
         for (int tid = 0; tid < C::NT; tid++) {
-            const BlockLoc L = locate<C>(p, t, tid, lds);
+            const BlockLoc L = locate<C, GEN_PACKED>(p, t, tid, lds);
             U4 raw[8];
             load_block(L, raw);
-            if (g_compact == 1 && FAST) classify_stage<C>(L, raw, p.qt[64 * L.comp], tid, lds, p.clamp_dc);
-            else finish_block<C>(L, raw, lds, 0, p.clamp_dc);
+            if (L.valid) g_cls[classify_block((const uint32_t*)raw, lds_tab<C, GEN_PACKED>(lds) + TAB_DW * L.comp + 32)]++;
+            finish_block<C, GEN_PACKED, NEED_Y16>(L, raw, lds, 0, p.clamp_dc);
         }
         /* __syncthreads() */
-        if (g_compact == 1 && FAST) {
-            for (int tid = 0; tid < C::NT; tid++) idct_queue<C>(tid, lds);
-            /* __syncthreads() */
+        if (NEED_Y16 && *lds_flag<C>(lds) != 0) { // Q1 value outside a byte: the whole tile again, wide
+            g_redo++;
+            memset(lds, 0x7B, C::LDS_PACKED);
+            tile_wide<C, HS, VS, OUT, FAST>(p, t, lds);
+            continue;
         }
-        color_all<C, HS, VS, OUT, FAST>(p, t, lds);
+        if (ts) {
+            // a round is, per wave: all lanes compute (they read the luma bytes the staging reuses), all lanes stage,
+            // all lanes copy out -- the GPU runs these back to back inside each wave, lanes in lockstep
+            for (int round = 0; round * C::NT < C::NITEMS; round++)
+                for (int w = 0; w < C::NW; w++) {
+                    ItemOut io[64];
+                    for (int l = 0; l < 64; l++) phase_color<C, HS, VS, OUT, GEN_PACKED, FAST, CAN_TS>(p, t, 64 * w + l, lds, round, &io[l]);
+                    for (int l = 0; l < 64; l++) stage_item<C>(io[l], 64 * w + l, lds, round);
+                    for (int l = 0; l < 64; l++) color_copyout<C, OUT>(p, t, 64 * w + l, lds, round);
+                }
+        } else {
+            for (int tid = 0; tid < C::NT; tid++) phase_color<C, HS, VS, OUT, GEN_PACKED, FAST>(p, t, tid, lds);
+        }
     }
 }
 
@@ -115,7 +95,8 @@ extern "C" int zje_decode_planes(const zj_frame_desc* d, size_t nframes, const i
     int rc = make_plan(d, pl);
     if (rc) return rc;
     Params p;
-    fill_params(d, pl, nframes, y, cb, cr, out, &d->qt[0][0], zero_fill, p);
+    fill_params(d, pl, nframes, y, cb, cr, out, zero_fill, p);
+    g_cls[0] = g_cls[1] = g_cls[2] = g_redo = 0;
     if (zero_fill) { // same remainder memset as zj_api.cpp
         size_t off[3], len[3];
         const int nr = uncovered_ranges(d, pl, off, len);
@@ -132,3 +113,39 @@ extern "C" int zje_decode_planes(const zj_frame_desc* d, size_t nframes, const i
 #undef ZJ_CASE
     return ZJ_ERR_UNSUPPORTED;
 }
+
+// ---- block level: the two transforms and the guard on their own (tests/test_packed_idct.py) -------------------
+// coeff: nblocks x 64 (natural order), q: 64 entries 0..255
+extern "C" void zje_classify(const int16_t* coeff, size_t nblocks, const int32_t q[64], int* cls)
+{
+    uint32_t tab[TAB_DW];
+    build_table(q, tab);
+    for (size_t b = 0; b < nblocks; b++) cls[b] = classify_block((const uint32_t*)(coeff + 64 * b), tab + 32);
+}
+// idct_block_packed WITHOUT consulting the guard (so a test can show both that it is exact under the guard and that
+// the guard is needed); out: nblocks x 64 bytes, row-major 8x8
+extern "C" void zje_idct_packed(const int16_t* coeff, size_t nblocks, const int32_t q[64], uint8_t* out)
+{
+    uint32_t tab[TAB_DW];
+    build_table(q, tab);
+    for (size_t b = 0; b < nblocks; b++) {
+        U4 raw[8];
+        memcpy(raw, coeff + 64 * b, 128);
+        uint32_t px[16];
+        idct_block_packed(raw, tab, px);
+        memcpy(out + 64 * b, px, 64);
+    }
+}
+// idct_block (wide); out: nblocks x 64 int16
+extern "C" void zje_idct_wide(const int16_t* coeff, size_t nblocks, const int32_t q[64], int16_t* out)
+{
+    uint32_t tab[TAB_DW];
+    build_table(q, tab);
+    for (size_t b = 0; b < nblocks; b++) {
+        U4 raw[8], px[8];
+        memcpy(raw, coeff + 64 * b, 128);
+        idct_block(raw, (const uint16_t*)tab, px);
+        memcpy(out + 64 * b, px, 128);
+    }
+}
+extern "C" int zje_guard_limit(void) { return GUARD_LIMIT; }

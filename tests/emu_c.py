@@ -24,9 +24,16 @@ def lib():
     return _LIB
 
 
-def set_variant(variant, persistent_wgs=24):
+def set_variant(variant):
+    """0 = packed generation (default), 1 = wide generation (round 1), 2 = packed with direct stores"""
     lib().zje_set_variant(C.c_int(int(variant)))
-    lib().zje_set_persistent_wgs(C.c_int(persistent_wgs))
+
+
+def stats():
+    """(DC-only blocks, packed-IDCT blocks, wide-IDCT blocks, tiles redone wide) of the last decode_planes call"""
+    a = (C.c_longlong * 4)()
+    lib().zje_stats(a)
+    return tuple(int(x) for x in a)
 
 
 class FrameDesc(C.Structure):  # zj_frame_desc (include/zjhip.h)
@@ -54,3 +61,34 @@ def decode_planes(frame, planes, nframes=1, zero_fill=1, poison=0xAA, flags=0, o
                                  C.c_void_p(arrs[1].ctypes.data), C.c_void_p(arrs[2].ctypes.data),
                                  C.c_void_p(out.ctypes.data), C.c_int(zero_fill))
     return rc, out
+
+
+def _q(q):
+    return np.ascontiguousarray(q, np.int32)
+
+
+def classify(coeff, q):
+    """classify_block per block: 0 DC-only, 1 packed transform exact, 2 wide transform.  coeff: (n, 64) int16"""
+    c = np.ascontiguousarray(coeff, np.int16).reshape(-1, 64)
+    out = np.zeros(c.shape[0], np.int32)
+    lib().zje_classify(C.c_void_p(c.ctypes.data), C.c_size_t(c.shape[0]), C.c_void_p(_q(q).ctypes.data), C.c_void_p(out.ctypes.data))
+    return out
+
+
+def idct_packed(coeff, q):
+    """idct_block_packed on every block, guard NOT consulted; (n, 64) uint8"""
+    c = np.ascontiguousarray(coeff, np.int16).reshape(-1, 64)
+    out = np.zeros((c.shape[0], 64), np.uint8)
+    lib().zje_idct_packed(C.c_void_p(c.ctypes.data), C.c_size_t(c.shape[0]), C.c_void_p(_q(q).ctypes.data), C.c_void_p(out.ctypes.data))
+    return out
+
+
+def idct_wide(coeff, q):
+    c = np.ascontiguousarray(coeff, np.int16).reshape(-1, 64)
+    out = np.zeros((c.shape[0], 64), np.int16)
+    lib().zje_idct_wide(C.c_void_p(c.ctypes.data), C.c_size_t(c.shape[0]), C.c_void_p(_q(q).ctypes.data), C.c_void_p(out.ctypes.data))
+    return out
+
+
+def guard_limit():
+    return int(lib().zje_guard_limit())

@@ -21,7 +21,7 @@ def _default_variant():
 @pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("out_cs", [oc.RGB, oc.GRAYSCALE, oc.YCBCR])
 @pytest.mark.parametrize("wh", [(64, 64), (528, 40), (32, 8), (272, 100), (1040, 33), (2080, 16)])
-@pytest.mark.parametrize("compact", [0, 1, 2, 3, 4, 7])
+@pytest.mark.parametrize("compact", [0, 1, 2])
 def test_emulated_kernel_matches_oracle(mode, out_cs, wh, synth, compact):
     emu_c.set_variant(compact)
     hs, vs = MODES[mode]
@@ -36,21 +36,6 @@ def test_emulated_kernel_matches_oracle(mode, out_cs, wh, synth, compact):
         assert rc == 0
         bad = np.nonzero(out != exp)[0]
         assert bad.size == 0, (mode, out_cs, wh, adversarial, bad[:8])
-
-
-@pytest.mark.parametrize("nwg", [1, 3, 8, 16, 40, 1000])
-def test_persistent_walk_covers_every_tile_once(nwg, synth):
-    """variant 2: any grid size must decode every tile exactly once (here 3 frames x 3 strips x 4 tiles)"""
-    w, h = 1040, 96
-    frames = [synth.make_frame(w, h, 2, 2, 3, seed=9, frame_index=i) for i in range(3)]
-    planes = [np.concatenate([fr[0][c] for fr in frames]) for c in range(3)]
-    f = oc.make_frame(w, h, 2, 2, 3, oc.RGB, frames[0][1])
-    emu_c.set_variant(2, nwg)
-    rc, out = emu_c.decode_planes(f, planes, nframes=3)
-    assert rc == 0
-    for i, fr in enumerate(frames):
-        rc, exp = oc.decode_planes(f, fr[0])
-        assert np.array_equal(out[i * exp.size:(i + 1) * exp.size], exp)
 
 
 def test_emulated_batch_and_untouched_bytes(synth):
@@ -184,7 +169,7 @@ def test_random_geometry_sweep_all_output_kinds(synth):
 @pytest.mark.parametrize("flags,out_cs,layout", [(7, oc.RGB, 0), (2, oc.GRAYSCALE, 0), (4, oc.YCBCR, 0), (6, oc.RGB, 0),
                                                  (6, oc.RGBA, 0), (6, oc.RGB, 1), (3, oc.RGB, 0), (5, oc.RGB, 0)])
 @pytest.mark.parametrize("wh", [(64, 64), (528, 40), (32, 8), (1040, 33), (100, 32), (37, 50), (17, 16), (250, 72)])
-@pytest.mark.parametrize("compact", [0, 3])
+@pytest.mark.parametrize("compact", [0, 1])
 def test_emulated_corrected_mode_flags(mode, flags, out_cs, layout, wh, compact, synth):
     """ZJ_FLAG_CLAMP_DC (Q1) and ZJ_FLAG_EDGE_REPLICATE (Q4), alone and combined with PLAIN_TAIL / RGBA / CHW, against
     the oracle's zjo_decode_planes_ext; the adversarial set is where unclamped DC-only values actually occur."""

@@ -18,7 +18,6 @@
 using namespace zj;
 
 namespace {
-constexpr int QT_SLOTS = 8;
 constexpr int N_SCRATCH = 4;
 constexpr int N_SLOTS = 3;                  // H2D of unit i+1 | kernel of unit i | D2H of unit i-1
 constexpr size_t UNIT_TARGET_DEFAULT = 16u << 20; // coefficient bytes per pipeline unit: every copy costs ~15 us of
@@ -39,10 +38,6 @@ struct PipeSlot {
 struct zj_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    int32_t* d_qt = nullptr;      // QT_SLOTS x [3][64]
-    int32_t* h_qt = nullptr;      // pinned mirror
-    int qt_slot = -1;             // slot holding the tables of the last frame desc
-    int qt_used = 0;
     void* scratch[N_SCRATCH] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_cap[N_SCRATCH] = {0, 0, 0, 0};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -51,7 +46,7 @@ struct zj_ctx {
     int pipeline = 1;             // 0: one unit per call (no overlap), for A/B timing only
     std::string last_error;
     int debug = 0;                // ablation switches, diagnostics only (results are WRONG when set)
-    int compact = 0;              // kernel variant: 0 one pass per tile, 1 DC-only compaction, 2 persistent + prefetch, 3 work stealing, 4 transposed stores, 7 = 3 + 4
+    int variant = 0;              // kernel variant: 0 packed generation (default), 1 wide generation (round 1), 2 packed with direct stores
 };
 
 #define ZJ_HIP(ctx, call)                                                                          \
@@ -106,23 +101,6 @@ static int ensure_slot(zj_ctx* c, PipeSlot& sl, int i, size_t bytes)
     return ZJ_OK;
 }
 
-// uploads (or finds) the 3x64 quantisation tables; returns the device pointer in *out
-static int stage_qt(zj_ctx* c, const int32_t qt[3][64], hipStream_t s, const int32_t** out)
-{
-    if (c->qt_slot >= 0 && memcmp(c->h_qt + 192 * c->qt_slot, qt, 192 * sizeof(int32_t)) == 0) {
-        *out = c->d_qt + 192 * c->qt_slot;
-        return ZJ_OK;
-    }
-    int slot = c->qt_used % QT_SLOTS;
-    if (c->qt_used >= QT_SLOTS) ZJ_HIP(c, hipStreamSynchronize(s)); // slot may still be read by an old launch
-    c->qt_used++;
-    memcpy(c->h_qt + 192 * slot, qt, 192 * sizeof(int32_t));
-    ZJ_HIP(c, hipMemcpyAsync(c->d_qt + 192 * slot, c->h_qt + 192 * slot, 192 * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    c->qt_slot = slot;
-    *out = c->d_qt + 192 * slot;
-    return ZJ_OK;
-}
-
 extern "C" {
 
 int zj_abi_version(void) { return ZJ_ABI_VERSION; }
@@ -162,10 +140,8 @@ zj_ctx* zj_ctx_create(int backend, int device, int* status)
     zj_ctx* c = new (std::nothrow) zj_ctx();
     if (!c) { *status = ZJ_ERR_NOMEM; return nullptr; }
     c->device = device;
-    if (const char* e = getenv("ZJ_VARIANT")) { int v = atoi(e); if ((v >= 0 && v <= 4) || v == 7) c->compact = v; }
+    if (const char* e = getenv("ZJ_VARIANT")) { int v = atoi(e); if (v >= 0 && v <= 2) c->variant = v; }
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipMalloc((void**)&c->d_qt, QT_SLOTS * 192 * sizeof(int32_t)) == hipSuccess &&
-              hipHostMalloc((void**)&c->h_qt, QT_SLOTS * 192 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess &&
               hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
     if (!ok) { zj_ctx_destroy(c); *status = ZJ_ERR_NO_DEVICE; return nullptr; }
     *status = ZJ_OK;
@@ -189,8 +165,6 @@ void zj_ctx_destroy(zj_ctx* c)
     }
     for (hipStream_t st : {c->s_up, c->s_run, c->s_down})
         if (st) (void)hipStreamDestroy(st);
-    if (c->d_qt) (void)hipFree(c->d_qt);
-    if (c->h_qt) (void)hipHostFree(c->h_qt);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -290,11 +264,8 @@ static int decode_device_impl(zj_ctx* c, const zj_frame_desc* d, const Plan& pl,
                               const int16_t* d_y, const int16_t* d_cb, const int16_t* d_cr,
                               uint8_t* d_out, hipStream_t s, int zero_fill)
 {
-    const int32_t* d_qt = nullptr;
-    int rc = stage_qt(c, d->qt, s, &d_qt);
-    if (rc) return rc;
-    Params p;
-    fill_params(d, pl, nframes, d_y, d_cb, d_cr, d_out, d_qt, zero_fill, p);
+    Params p; // carries the quantisation tables by value: nothing to stage, nothing to order across streams
+    fill_params(d, pl, nframes, d_y, d_cb, d_cr, d_out, zero_fill, p);
     p.debug = c->debug;
     if (zero_fill) {
         // rows below the last complete strip are never written by the reference (Q6): zeros
@@ -303,7 +274,7 @@ static int decode_device_impl(zj_ctx* c, const zj_frame_desc* d, const Plan& pl,
         for (size_t f = 0; f < nframes; f++)
             for (int r = 0; r < nr; r++) ZJ_HIP(c, hipMemsetAsync(d_out + f * pl.out_len + off[r], 0, len[r], s));
     }
-    ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->compact, pl.fast ? 1 : 0, p, s));
+    ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->variant, pl.fast ? 1 : 0, p, s));
     return ZJ_OK;
 }
 
@@ -342,7 +313,11 @@ int zj_time_decode_device(zj_ctx* c, const zj_frame_desc* d, size_t nframes, con
     if (iters <= 0 || !ms_total) return ZJ_ERR_ARG;
     ZJ_HIP(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    if (kernel_name) *kernel_name = fused_kernel_name(pl.hs, pl.vs, pl.out, c->compact, pl.fast ? 1 : 0);
+    if (kernel_name) {
+        Params p;
+        fill_params(d, pl, nframes, d_y, d_cb, d_cr, d_out, 1, p);
+        *kernel_name = fused_kernel_name(pl.hs, pl.vs, pl.out, c->variant, pl.fast ? 1 : 0, p);
+    }
     // (1) `iters` back-to-back launches between one event pair
     ZJ_HIP(c, hipEventRecord(c->ev0, s));
     for (int i = 0; i < iters; i++) {
@@ -432,10 +407,7 @@ static int decode_planes_batch_impl(zj_ctx* c, const zj_frame_desc* d, size_t nf
     } else group = nframes;
     const size_t strips_per_unit = ((size_t)pl.n_strips + split - 1) / split;
 
-    // quantisation tables once, on the stream the kernels run on
     if ((rc = pipe_init(c))) return rc;
-    const int32_t* d_qt = nullptr;
-    if ((rc = stage_qt(c, d->qt, c->s_run, &d_qt))) return rc;
 
     size_t u = 0;
     for (size_t f0 = 0; f0 < nframes; f0 += group) {
@@ -466,14 +438,14 @@ static int decode_planes_batch_impl(zj_ctx* c, const zj_frame_desc* d, size_t nf
             if (sl.used) ZJ_HIP(c, hipStreamWaitEvent(c->s_run, sl.down_done, 0));
             Params p;
             fill_params(d, pl, whole ? nfr : 1, (const int16_t*)sl.buf[0], (const int16_t*)sl.buf[1],
-                        (const int16_t*)sl.buf[2], (uint8_t*)sl.buf[3], d_qt, 1, p);
+                        (const int16_t*)sl.buf[2], (uint8_t*)sl.buf[3], 1, p);
             p.debug = c->debug;
             if (!whole) { // strips [s0, s1) of frame f0 as a frame of its own
                 p.n_strips = (int)(s1 - s0);
                 p.height = (int)d->height - (int)s0 * pl.strip_rows;
                 p.total_tiles = p.n_strips * pl.tiles_per_row;
             }
-            ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->compact, pl.fast ? 1 : 0, p, c->s_run));
+            ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->variant, pl.fast ? 1 : 0, p, c->s_run));
             ZJ_HIP(c, hipEventRecord(sl.run_done, c->s_run));
             // down
             ZJ_HIP(c, hipStreamWaitEvent(c->s_down, sl.run_done, 0));
@@ -523,13 +495,9 @@ int zj_idct_strip(zj_ctx* c, const int16_t* coeff, size_t n, const int32_t qt[64
     int rc;
     if ((rc = ensure_scratch(c, 0, n * 2)) || (rc = ensure_scratch(c, 1, n * 2))) return rc;
     hipStream_t s = c->stream;
-    int32_t qt3[3][64];
-    memcpy(qt3[0], qt, 256); memcpy(qt3[1], qt, 256); memcpy(qt3[2], qt, 256);
-    const int32_t* d_qt = nullptr;
-    if ((rc = stage_qt(c, qt3, s, &d_qt))) return rc;
     ZJ_HIP(c, hipMemcpyAsync(c->scratch[0], coeff, n * 2, hipMemcpyHostToDevice, s));
     ZJ_HIP(c, hipMemsetAsync(c->scratch[1], 0, n * 2, s)); // vec![0; len], scalar.rs:26
-    ZJ_HIP(c, launch_idct_strip((const int16_t*)c->scratch[0], d_qt, (int16_t*)c->scratch[1],
+    ZJ_HIP(c, launch_idct_strip((const int16_t*)c->scratch[0], qt, (int16_t*)c->scratch[1],
                                 (long long)(nchunks * bpc), (long long)chunks, (long long)bpc, (long long)stride, s));
     ZJ_HIP(c, hipMemcpyAsync(out, c->scratch[1], n * 2, hipMemcpyDeviceToHost, s));
     ZJ_HIP(c, hipStreamSynchronize(s));
@@ -670,10 +638,9 @@ zj_color_convert16_fn zj_choose_ycbcr_to_rgb_convert_func(int backend, int out_c
 }
 
 /* kernel-variant switch for A/B measurements (both variants are bit-exact) */
-int zj_set_variant(zj_ctx* c, int variant) { if (!c || variant < 0 || (variant > 4 && variant != 7)) return ZJ_ERR_ARG; c->compact = variant; return ZJ_OK; }
+int zj_set_variant(zj_ctx* c, int variant) { if (!c || variant < 0 || variant > 2) return ZJ_ERR_ARG; c->variant = variant; return ZJ_OK; }
 /* 0 = one unit per zj_decode_planes_batch call (no copy/compute overlap); A/B timing only */
 int zj_set_pipeline(zj_ctx* c, int on) { if (!c) return ZJ_ERR_ARG; c->pipeline = on ? 1 : 0; return ZJ_OK; }
-int zj_set_persistent_grid(int wgs) { set_persistent_grid(wgs); return ZJ_OK; }
 /* occupancy probe (tools/occupancy.py): pad every fused launch with dynamic LDS; query workgroups per CU */
 int zj_set_pad_lds(int bytes) { set_pad_lds(bytes); return ZJ_OK; }
 int zj_fused_occupancy(int pad_lds) { return fused_occupancy_420_rgb(pad_lds); }
@@ -724,11 +691,9 @@ int zj_lab(zj_ctx* c, int variant, int blocks, int iters, int reps, float* ms)
     if (rc) return rc;
     int32_t qt3[3][64];
     for (int k = 0; k < 3; k++) for (int i = 0; i < 64; i++) qt3[k][i] = 1 + ((i * 7 + k * 3) % 29);
-    const int32_t* d_qt = nullptr;
-    if ((rc = stage_qt(c, qt3, c->stream, &d_qt))) return rc;
-    ZJ_HIP(c, launch_lab(variant, d_qt, (int*)c->scratch[0], blocks, iters, c->stream)); // warm-up
+    ZJ_HIP(c, launch_lab(variant, qt3, (int*)c->scratch[0], blocks, iters, c->stream)); // warm-up
     ZJ_HIP(c, hipEventRecord(c->ev0, c->stream));
-    for (int r = 0; r < reps; r++) ZJ_HIP(c, launch_lab(variant, d_qt, (int*)c->scratch[0], blocks, iters, c->stream));
+    for (int r = 0; r < reps; r++) ZJ_HIP(c, launch_lab(variant, qt3, (int*)c->scratch[0], blocks, iters, c->stream));
     ZJ_HIP(c, hipEventRecord(c->ev1, c->stream));
     ZJ_HIP(c, hipEventSynchronize(c->ev1));
     ZJ_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));

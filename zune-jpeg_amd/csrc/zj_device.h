@@ -1,9 +1,16 @@
 // zj_device.h -- device-side code of the MI355X pixel path (dequantize + 8x8 integer IDCT, chroma
-// up-sampling, YCbCr->RGB/gray/YCbCr), written for gfx950 (wave64, LDS, packed-i16 VALU).
+// up-sampling, YCbCr->RGB/gray/YCbCr), written for gfx950 (wave64, LDS, packed-i16 VALU, v_dot2_i32_i16).
 //
 // The arithmetic restates zune-jpeg's SCALAR arms bit-exactly (paths relative to the reference):
 //   src/idct/scalar.rs:19-282, src/upsampler/scalar.rs:5-166, src/color_convert/scalar.rs:52-169,
 //   src/worker.rs:32-251.  Quirk numbers (Q1..Q8) refer to SURVEY.md section 8a.
+//
+// Two kernel generations share this file:
+//   GEN_WIDE    round 1: 24-bit multiply-add IDCT, int16 planar staging in LDS, 48-byte-per-lane stores.  Exact
+//               for every input without any range check; it is also the fall-back of the packed generation.
+//   GEN_PACKED  round 2: the IDCT runs on packed i16 pairs with v_dot2_i32_i16 whenever a cheap L1 bound proves
+//               that this is exact (classify_block), luma is staged as bytes, and the 3-byte interleaved outputs
+//               leave through an LDS transpose so that every store instruction writes contiguous memory.
 //
 // The same header is compiled (a) by hipcc into libzjhip.so and (b) by g++ into the CPU
 // *emulation* harness under tests/emu/, which runs every workgroup phase thread by thread so the
@@ -31,6 +38,7 @@ typedef uint16_t u16x2 __attribute__((vector_size(4)));  // packed pair, wrap-ar
 typedef int16_t s16x2 __attribute__((vector_size(4)));   // packed pair, arithmetic >>, min/max
 
 struct alignas(16) U4 { uint32_t x, y, z, w; };
+struct alignas(8) U2 { uint32_t x, y; };
 typedef uint32_t V4 __attribute__((vector_size(16)));    // the same 16 bytes for builtins that want a vector
 #if defined(ZJ_ABLATION)
 #define ZJ_ABL(debug, bit) ((debug) & (bit))
@@ -66,6 +74,49 @@ ZJ_DEV int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint
 ZJ_DEV int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
 ZJ_DEV int32_t mad24(int32_t a, int32_t b, int32_t c) { return wadd(mul24(a, b), c); }
 ZJ_DEV int32_t wshl(int32_t a, int s) { return (int32_t)((uint32_t)a << s); }
+
+// v_dot2_i32_i16 / v_dot2c_i32_i16: a.lo*b.lo + a.hi*b.hi + c, the halves read as signed 16-bit, the sum
+// wrapping mod 2^32 (no clamp) -- gfx950's counterpart of the pmaddwd the reference's AVX2 arm is built on
+ZJ_DEV int32_t dot2(uint32_t a, uint32_t b, int32_t c)
+{
+#if defined(ZJ_EMU)
+    const int32_t al = (int16_t)(a & 0xffff), ah = (int16_t)(a >> 16), bl = (int16_t)(b & 0xffff), bh = (int16_t)(b >> 16);
+    return (int32_t)((uint32_t)(al * bl) + (uint32_t)(ah * bh) + (uint32_t)c);
+#else
+    typedef short v2s __attribute__((ext_vector_type(2)));
+    v2s x, y;
+    __builtin_memcpy(&x, &a, 4);
+    __builtin_memcpy(&y, &b, 4);
+    return __builtin_amdgcn_sdot2(x, y, c, false);
+#endif
+}
+// a packed pair of signed 16-bit constants (lo, hi)
+constexpr uint32_t pk16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | (((uint32_t)hi & 0xffffu) << 16); }
+
+// v_sad_u16: |a.lo - b.lo| + |a.hi - b.hi| + c, the halves read as UNSIGNED 16-bit
+ZJ_DEV uint32_t sad_u16(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(ZJ_EMU)
+    const int32_t al = (int32_t)(a & 0xffff), ah = (int32_t)(a >> 16), bl = (int32_t)(b & 0xffff), bh = (int32_t)(b >> 16);
+    return (uint32_t)((al > bl ? al - bl : bl - al) + (ah > bh ? ah - bh : bh - ah)) + c;
+#else
+    return __builtin_amdgcn_sad_u16(a, b, c);
+#endif
+}
+
+// {(a >> sh)[15:0], (b >> sh)[15:0]} as a packed pair: an arithmetic shift and a second one whose SDWA form writes
+// its low half into the destination's high word (2 instructions; the compiler's own sequence is shift, shift, bfi)
+ZJ_DEV uint32_t pack_sar(int32_t a, int32_t b, const int sh)
+{
+#if defined(ZJ_EMU)
+    return ((uint32_t)(a >> sh) & 0xffffu) | ((uint32_t)(b >> sh) << 16);
+#else
+    uint32_t r;
+    asm("v_ashrrev_i32_e32 %0, %1, %2" : "=v"(r) : "s"(sh), "v"(a));
+    asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(r) : "s"(sh), "v"(b));
+    return r;
+#endif
+}
 
 // v_perm_b32: bytes {s0[3..0] -> 7..4, s1[3..0] -> 3..0}; selector byte i picks result byte i.
 ZJ_DEV uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel)
@@ -114,18 +165,6 @@ ZJ_DEV int uniform(int v)
 #endif
 }
 
-// ------------------------------------------------------------------------------------------------
-// 8x8 dequantize + IDCT of ONE block held by ONE lane (64 coefficients in 8 x 16-byte registers).
-//
-// Algebra: every step of the reference butterfly (scalar.rs:79-274) is +,-,* by constants and <<
-// in wrapping i32, i.e. ring operations mod 2^32, so any re-association is bit-exact.  The odd
-// part is expanded into its 4x4 integer matrix so that the only multiplicands are the pass inputs
-// themselves: dequantized coefficients |c*q| <= 32768*255 < 2^23 in pass 1 and (x >> 10) in
-// [-2^21, 2^21) in pass 2.  Both always fit the signed 24-bit operand of v_mul_i32_i24 /
-// v_mad_i32_i24, which makes the full-rate 24-bit multiplier exact for EVERY input (including the
-// wrap-around adversarial ones) without any range check.  Requires 0 <= q <= 255 (8-bit DQT,
-// headers.rs:154-174), enforced by the host side.
-// ------------------------------------------------------------------------------------------------
 // pin(): keeps a partial sum opaque so the compiler cannot re-associate a multiply-add chain into
 // mul + mul + add3 (one instruction more per output); every VALU instruction costs ~4 cycles per
 // wave on gfx950 (profiles/r01_ubench_valu_issue_cost.txt), so instruction count is the metric.
@@ -134,6 +173,108 @@ ZJ_DEV int uniform(int v)
 #else
 #define ZJ_PIN(x) asm volatile("" : "+v"(x))
 #endif
+// keeps a rarely taken, wave-uniform branch a branch (an empty asm statement cannot be if-converted into selects)
+#if defined(ZJ_EMU)
+#define ZJ_NO_IF_CONVERT() ((void)0)
+#else
+#define ZJ_NO_IF_CONVERT() asm volatile("" ::: "memory")
+#endif
+#if defined(ZJ_EMU) || defined(ZJ_IDCT_NOBARRIER)
+#define ZJ_SCHED_BARRIER() ((void)0)
+#else
+#define ZJ_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifndef ZJ_IDCT_G
+#define ZJ_IDCT_G 2 // 1, 2 and 4 measure the same within noise in the full kernel (tools/ab_libs.sh); 8 spills
+#endif
+// experiment knob: scheduling barriers between the stages of the colour phase (filters | colour math | packing)
+#if defined(ZJ_COLOR_STAGES) && !defined(ZJ_EMU)
+#define ZJ_COLOR_SB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define ZJ_COLOR_SB() ((void)0)
+#endif
+// a compiler-level fence between the LDS writes and reads of one wave's transpose (the hardware executes the LDS
+// operations of a wave in order; nothing is needed there)
+#if defined(ZJ_EMU)
+#define ZJ_WAVE_FENCE() ((void)0)
+#else
+#define ZJ_WAVE_FENCE() __builtin_amdgcn_wave_barrier()
+#endif
+
+ZJ_DEV int32_t lo16s(uint32_t v) { return (int32_t)(int16_t)(v & 0xffff); }
+ZJ_DEV int32_t hi16s(uint32_t v) { return (int32_t)v >> 16; }
+
+// v_sat_pk_u8_i16: {0, 0, sat_u8(hi16), sat_u8(lo16)} -- the two 16-bit lanes clamped to 0..255 and
+// packed into bytes 0 and 1 (replaces v_pk_max_i16 + v_pk_min_i16 and half of the byte packing)
+ZJ_DEV uint32_t sat_pk_u8(uint32_t v)
+{
+#if defined(ZJ_EMU)
+    int lo = (int16_t)(v & 0xffff), hi = (int16_t)(v >> 16);
+    lo = lo < 0 ? 0 : (lo > 255 ? 255 : lo);
+    hi = hi < 0 ? 0 : (hi > 255 ? 255 : hi);
+    return (uint32_t)lo | ((uint32_t)hi << 8);
+#else
+    uint32_t r;
+    asm("v_sat_pk_u8_i16_e32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+#endif
+}
+
+// lo = sat_pk_u8(a) in bits 0..15, sat_pk_u8(b) in bits 16..31 (SDWA write into the high word)
+ZJ_DEV uint32_t sat_pk_u8_2(uint32_t a, uint32_t b)
+{
+#if defined(ZJ_EMU)
+    return sat_pk_u8(a) | (sat_pk_u8(b) << 16);
+#else
+    uint32_t r;
+    asm("v_sat_pk_u8_i16_e32 %0, %1" : "=v"(r) : "v"(a));
+    asm("v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(r) : "v"(b));
+    return r;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Quantisation tables as the kernels see them: per component 44 dwords,
+//   [0, 32)   the 64 entries as packed u16 pairs, natural order (pair i = entries 2i, 2i+1)
+//   [32, 44)  the constants of the packed-IDCT guard (classify_block): wt[4], wb[4], th[4]
+// They travel BY VALUE in the kernel arguments (Params::tab): no device-side table, hence no ordering
+// between an upload and the launches of other streams to get wrong.
+// ------------------------------------------------------------------------------------------------
+constexpr int TAB_DW = 44;                 // dwords per component
+constexpr int TAB_BYTES = 3 * TAB_DW * 4;  // 528
+constexpr int GUARD_LIMIT = 5904;          // see classify_block
+
+// host side (zj_plan.h, the emulator): q[64] natural order, each 0..255
+inline void build_table(const int32_t q[64], uint32_t tab[TAB_DW])
+{
+    for (int i = 0; i < 32; i++) tab[i] = ((uint32_t)q[2 * i] & 0xffffu) | (((uint32_t)q[2 * i + 1] & 0xffffu) << 16);
+    for (int jj = 0; jj < 4; jj++) {
+        int wt = 0, wb = 0;
+        for (int k = 0; k < 8; k++)
+            for (int h = 0; h < 2; h++) {
+                const int v = q[8 * k + 2 * jj + h];
+                if (k < 4) wt = v > wt ? v : wt; else wb = v > wb ? v : wb;
+            }
+        tab[32 + jj] = (uint32_t)wt;
+        tab[36 + jj] = (uint32_t)wb;
+        tab[40 + jj] = (uint32_t)(262144 * (wt + wb) - GUARD_LIMIT);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 8x8 dequantize + IDCT of ONE block held by ONE lane (64 coefficients in 8 x 16-byte registers).
+//
+// Algebra: every step of the reference butterfly (scalar.rs:79-274) is +,-,* by constants and <<
+// in wrapping i32, i.e. ring operations mod 2^32, so any re-association is bit-exact.  The odd
+// part is expanded into its 4x4 integer matrix so that the only multiplicands are the pass inputs
+// themselves: dequantized coefficients |c*q| <= 32768*255 < 2^23 in pass 1 and (x >> 10) in
+// [-2^21, 2^21) in pass 2.
+//
+// WIDE form (idct_block): both always fit the signed 24-bit operand of v_mul_i32_i24 / v_mad_i32_i24,
+// which makes the full-rate 24-bit multiplier exact for EVERY input (including the wrap-around
+// adversarial ones) without any range check.  Requires 0 <= q <= 255 (8-bit DQT, headers.rs:154-174),
+// enforced by the host side.
+// ------------------------------------------------------------------------------------------------
 // The transform is written as two halves -- every multiply / multiply-add first, the butterfly adds after --
 // so that idct_block can put the add/shift halves of two transforms next to each other behind a scheduling
 // barrier: simple VOP2 instructions issue faster next to each other than interleaved with multiplies
@@ -171,63 +312,11 @@ ZJ_DEV void idct_1d(const int32_t s[8], const int32_t bias, int32_t o[8])
     const IdctHalf h = idct_1d_mul(s, bias);
     idct_1d_add(h, o);
 }
-// keeps a rarely taken, wave-uniform branch a branch (an empty asm statement cannot be if-converted into selects)
-#if defined(ZJ_EMU)
-#define ZJ_NO_IF_CONVERT() ((void)0)
-#else
-#define ZJ_NO_IF_CONVERT() asm volatile("" ::: "memory")
-#endif
-#if defined(ZJ_EMU) || defined(ZJ_IDCT_NOBARRIER)
-#define ZJ_SCHED_BARRIER() ((void)0)
-#else
-#define ZJ_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
-#endif
-#ifndef ZJ_IDCT_G
-#define ZJ_IDCT_G 2 // 1, 2 and 4 measure the same within noise in the full kernel (tools/ab_libs.sh); 8 spills
-#endif
-// experiment knob: scheduling barriers between the stages of the colour phase (filters | colour math | packing)
-#if defined(ZJ_COLOR_STAGES) && !defined(ZJ_EMU)
-#define ZJ_COLOR_SB() __builtin_amdgcn_sched_barrier(0)
-#else
-#define ZJ_COLOR_SB() ((void)0)
-#endif
 
-ZJ_DEV int32_t lo16s(uint32_t v) { return (int32_t)(int16_t)(v & 0xffff); }
-ZJ_DEV int32_t hi16s(uint32_t v) { return (int32_t)v >> 16; }
-
-// v_sat_pk_u8_i16: {0, 0, sat_u8(hi16), sat_u8(lo16)} -- the two 16-bit lanes clamped to 0..255 and
-// packed into bytes 0 and 1 (replaces v_pk_max_i16 + v_pk_min_i16 and half of the byte packing)
-ZJ_DEV uint32_t sat_pk_u8(uint32_t v)
-{
-#if defined(ZJ_EMU)
-    int lo = (int16_t)(v & 0xffff), hi = (int16_t)(v >> 16);
-    lo = lo < 0 ? 0 : (lo > 255 ? 255 : lo);
-    hi = hi < 0 ? 0 : (hi > 255 ? 255 : hi);
-    return (uint32_t)lo | ((uint32_t)hi << 8);
-#else
-    uint32_t r;
-    asm("v_sat_pk_u8_i16_e32 %0, %1" : "=v"(r) : "v"(v));
-    return r;
-#endif
-}
-
-// lo = sat_pk_u8(a) in bits 0..15, sat_pk_u8(b) in bits 16..31 (SDWA write into the high word)
-ZJ_DEV uint32_t sat_pk_u8_2(uint32_t a, uint32_t b)
-{
-#if defined(ZJ_EMU)
-    return sat_pk_u8(a) | (sat_pk_u8(b) << 16);
-#else
-    uint32_t r;
-    asm("v_sat_pk_u8_i16_e32 %0, %1" : "=v"(r) : "v"(a));
-    asm("v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(r) : "v"(b));
-    return r;
-#endif
-}
-
-// raw[r] = coefficient row r (8 x i16, natural order).  qt: this lane's 64 x int32 table (LDS).
-// out[r] = pixel row r as 8 packed i16 (4 dwords): level-shifted (+128) and clamped to 0..255
+// raw[r] = coefficient row r (8 x i16, natural order).  qt: the block's 64 table entries (u16, LDS or kernel
+// arguments).  out[r] = pixel row r as 8 packed i16 (4 dwords): level-shifted (+128) and clamped to 0..255
 // (SCALE_BITS scalar.rs:6, clamp :302-305).  The caller handles DC-only blocks (scalar.rs:45-74).
-ZJ_DEV void idct_block(const U4 raw[8], const int32_t* qt, U4 out[8])
+ZJ_DEV void idct_block(const U4 raw[8], const uint16_t* qt, U4 out[8])
 {
     const uint32_t* w = reinterpret_cast<const uint32_t*>(raw);
     int32_t tmp[64];
@@ -244,7 +333,7 @@ ZJ_DEV void idct_block(const U4 raw[8], const int32_t* qt, U4 out[8])
             for (int k = 0; k < 8; k++) {
                 const uint32_t pair = w[k * 4 + (col >> 1)];
                 const int32_t cf = (col & 1) ? hi16s(pair) : lo16s(pair);
-                s[k] = mul24(cf, qt[k * 8 + col]); // dequantize (scalar.rs:308); q is 0..255
+                s[k] = mul24(cf, (int32_t)qt[k * 8 + col]); // dequantize (scalar.rs:308); q is 0..255
             }
             h[g] = idct_1d_mul(s, 512);
         }
@@ -281,6 +370,123 @@ ZJ_DEV void idct_block(const U4 raw[8], const int32_t* qt, U4 out[8])
                 const s16x2 z = {0, 0}, m = {255, 255};
                 ow[(r0 + g) * 4 + (k >> 1)] = as_u32(pk_min(pk_max(sar(as_u16x2(hi), 1), z), m));
             }
+        ZJ_SCHED_BARRIER();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PACKED form (idct_block_packed): the same integers from 16-bit operands.
+//
+// v_dot2_i32_i16 multiplies two signed 16-bit pairs and adds both products to a 32-bit accumulator: two of
+// the butterfly's multiply-adds per instruction, 22 instructions per 1-D transform instead of 36.  The matrix
+// entries all fit 16 bits (|entry| <= 5683); the INPUTS must too:
+//   (1) every dequantized coefficient s = c*q of the block fits i16  (v_pk_mul_lo_u16 then yields s itself),
+//   (2) every pass-1 result (x >> 10) fits i16, i.e. |x| < 2^25.
+// With B_j = sum_k |s[k][j]| (column j):  |x| <= 5683 * B_j + 512, so B_j <= 5904 gives (2), and (1) follows
+// from |s| <= B_j.  classify_block bounds B_j from the QUANTIZED coefficients with v_sad_u16 (32 instructions
+// for the block): for column pair jj, a_k = |c[k][2jj]| + |c[k][2jj+1]|, weighted by the largest table entry
+// of rows 0-3 (wt) and of rows 4-7 (wb) of that column pair:
+//   B_2jj, B_2jj+1  <=  wt * sum_{k<4} a_k + wb * sum_{k>=4} a_k  <=  GUARD_LIMIT  for all four jj.
+// Blocks that pass take the packed transform; the others (extreme contrast at low quantisation, adversarial
+// test vectors) take idct_block.  Both produce the reference's integers, so which one ran is unobservable.
+// ------------------------------------------------------------------------------------------------
+struct PackedHalf { int32_t x0, x1, x2, x3, u0, u1, u2, u3; };
+// p04 = (s0, s4), p26 = (s2, s6), p13 = (s1, s3), p57 = (s5, s7)
+ZJ_DEV PackedHalf idct_1d_dot(const uint32_t p04, const uint32_t p26, const uint32_t p13, const uint32_t p57, const int32_t bias)
+{
+    PackedHalf h;
+    const int32_t t0 = dot2(p04, pk16(4096, 4096), bias);   // fsh(s0+s4) + bias      (scalar.rs:93-99)
+    const int32_t t1 = dot2(p04, pk16(4096, -4096), bias);  // fsh(s0-s4) + bias
+    // t3 = 5352*s2 + 2217*s6, t2 = 2217*s2 - 5350*s6 (scalar.rs:81-87), folded into x0..x3
+    h.x0 = dot2(p26, pk16(5352, 2217), t0);
+    h.x3 = dot2(p26, pk16(-5352, -2217), t0);
+    h.x1 = dot2(p26, pk16(2217, -5350), t1);
+    h.x2 = dot2(p26, pk16(-2217, 5350), t1);
+    // odd part (scalar.rs:109-148) as the 4x4 integer matrix; d = s1, c = s3, b = s5, a = s7
+    h.u3 = dot2(p57, pk16(3219, 1131), dot2(p13, pk16(5683, 4816), 0));
+    h.u2 = dot2(p57, pk16(-5681, -3218), dot2(p13, pk16(4816, -1129), 0));
+    h.u1 = dot2(p57, pk16(1132, 4816), dot2(p13, pk16(3219, -5681), 0));
+    h.u0 = dot2(p57, pk16(4816, -5680), dot2(p13, pk16(1131, -3218), 0));
+    return h;
+}
+ZJ_DEV void idct_1d_dot_add(const PackedHalf& h, int32_t o[8])
+{
+    o[0] = wadd(h.x0, h.u3); o[7] = wsub(h.x0, h.u3);
+    o[1] = wadd(h.x1, h.u2); o[6] = wsub(h.x1, h.u2);
+    o[2] = wadd(h.x2, h.u1); o[5] = wsub(h.x2, h.u1);
+    o[3] = wadd(h.x3, h.u0); o[4] = wsub(h.x3, h.u0);
+}
+
+// 0: DC-only (scalar.rs:45)   1: the packed transform is exact for this block   2: take the wide transform
+// w = the block's 32 coefficient dwords, g = the component's guard constants (tab + 32)
+ZJ_DEV int classify_block(const uint32_t* w, const uint32_t* g)
+{
+    uint32_t any = w[0] & 0xffff0000u; // all but coefficient 0 are zero?
+#pragma unroll
+    for (int i = 1; i < 32; i++) any |= w[i];
+    if (any == 0) return 0;
+    // v_sad_u16 against 0x8000 per half: 65536 - (|lo| + |hi|) for signed halves (|-32768| included)
+    int32_t bad = 0;
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) {
+        uint32_t st = 0, sb = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) st = sad_u16(w[4 * k + jj], 0x80008000u, st);
+#pragma unroll
+        for (int k = 4; k < 8; k++) sb = sad_u16(w[4 * k + jj], 0x80008000u, sb);
+        // wt * (262144 - st) + wb * (262144 - sb) <= GUARD_LIMIT  <=>  wt*st + wb*sb - th >= 0
+        const int32_t d = mad24((int32_t)g[4 + jj], (int32_t)sb, mad24((int32_t)g[jj], (int32_t)st, -(int32_t)g[8 + jj]));
+        bad |= d;
+    }
+    return bad < 0 ? 2 : 1;
+}
+
+// raw: as idct_block.  qp: the component's 32 packed table pairs.  out[2r], out[2r+1] = pixel row r as 8 BYTES,
+// level-shifted and clamped to 0..255.  Precondition: classify_block(...) == 1.
+ZJ_DEV void idct_block_packed(const U4 raw[8], const uint32_t* qp, uint32_t out[16])
+{
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(raw);
+    uint32_t D[32]; // dequantized pairs (s[k][2jj], s[k][2jj+1]), scalar.rs:308
+#pragma unroll
+    for (int i = 0; i < 32; i++) D[i] = as_u32(as_u16x2(w[i]) * as_u16x2(qp[i]));
+    // pass 1: columns (scalar.rs:79-167), bias 512, >> 10.  Two columns per group, chosen so that their results
+    // pair up as pass 2 wants them: T[i][g] = (tmp[i][CA[g]], tmp[i][CB[g]]) = p04, p26, p13, p57 of row i.
+    uint32_t T[8][4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int ca = g == 0 ? 0 : (g == 1 ? 2 : (g == 2 ? 1 : 5)), cb = g == 0 ? 4 : (g == 1 ? 6 : (g == 2 ? 3 : 7));
+        PackedHalf h[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int col = e ? cb : ca, jj = col >> 1;
+            const uint32_t sel = (col & 1) ? 0x07060302u : 0x05040100u; // the column's halves of two row registers
+            const uint32_t p04 = perm(D[4 * 4 + jj], D[0 * 4 + jj], sel), p26 = perm(D[6 * 4 + jj], D[2 * 4 + jj], sel);
+            const uint32_t p13 = perm(D[3 * 4 + jj], D[1 * 4 + jj], sel), p57 = perm(D[7 * 4 + jj], D[5 * 4 + jj], sel);
+            h[e] = idct_1d_dot(p04, p26, p13, p57, 512);
+        }
+        ZJ_SCHED_BARRIER();
+        int32_t oa[8], ob[8];
+        idct_1d_dot_add(h[0], oa);
+        idct_1d_dot_add(h[1], ob);
+#pragma unroll
+        for (int i = 0; i < 8; i++) T[i][g] = pack_sar(oa[i], ob[i], 10);
+        ZJ_SCHED_BARRIER();
+    }
+    // pass 2: rows (scalar.rs:170-274), bias SCALE_BITS, >> 17, clamp -> bytes
+    constexpr int32_t bias2 = 512 + 65536 + (128 << 17);
+#pragma unroll
+    for (int r0 = 0; r0 < 8; r0 += 2) {
+        PackedHalf h[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) h[e] = idct_1d_dot(T[r0 + e][0], T[r0 + e][1], T[r0 + e][2], T[r0 + e][3], bias2);
+        ZJ_SCHED_BARRIER();
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            int32_t o[8];
+            idct_1d_dot_add(h[e], o);
+            out[2 * (r0 + e)] = sat_pk_u8_2(pack_sar(o[0], o[1], 17), pack_sar(o[2], o[3], 17));
+            out[2 * (r0 + e) + 1] = sat_pk_u8_2(pack_sar(o[4], o[5], 17), pack_sar(o[6], o[7], 17));
+        }
         ZJ_SCHED_BARRIER();
     }
 }
@@ -347,9 +553,13 @@ template <> struct TileWidth<1, 1, false> { static constexpr int TWC = 128; }; /
 // OUT_RGBA (R G B 255 per pixel) and OUT_RGB_CHW (three u8 planes) are extensions beyond the reference
 // (SURVEY 8f-3/4); both place every pixel at its own position (no Q5/Q6), like Params::plain does for OUT_RGB.
 enum { OUT_RGB = 0, OUT_GRAY = 1, OUT_YCBCR = 2, OUT_RGBA = 3, OUT_RGB_CHW = 4 };
+enum { GEN_WIDE = 0, GEN_PACKED = 1 };
 
-// LDS layout (bytes): planar staging Yp[SH][TWY] | Cb[CROWS][CPITCH] | Cr[..] (i16), then the three
-// quantisation tables (int32) every lane indexes by its block's component.
+// LDS layouts (byte offsets).
+//   GEN_WIDE    Yp[SH][TWY] i16 | Cb[CROWS][CPITCH] i16 | Cr[..] | tables | vertical LUT
+//   GEN_PACKED  Yb[SH][TWY] u8  | Cb[CROWS][CPITCH] i16 | Cr[..] | tables | vertical LUT | flag | store staging
+// The packed kernel's allocation covers the wide layout too: a tile whose luma cannot be staged as bytes (an
+// unclamped DC-only value outside 0..255, Q1) is redone by the wide code in the same workgroup.
 template <int HS, int VS, int OUT>
 struct Cfg {
     static constexpr bool CHROMA = OUT != OUT_GRAY;
@@ -366,31 +576,32 @@ struct Cfg {
     static constexpr int NCB = CBR * CCOLS;            // chroma blocks per tile and component
     static constexpr int CPITCH = TWC * 8 + (HALO ? 16 : 0); // i16 per chroma LDS row
     static constexpr int COFF = HALO ? 8 : 0;          // LDS column of chroma column 0
-    static constexpr int YSZ = SH * TWY;               // i16 elements
-    static constexpr int CSZ = CROWS * CPITCH;
+    static constexpr int YSZ = SH * TWY;               // luma samples per tile
+    static constexpr int CSZ = CROWS * CPITCH;         // chroma samples per tile and component
     static constexpr int NGRP = TWY / 16;              // 16-pixel groups per tile row
     static constexpr int NITEMS = SH * NGRP;
     static constexpr int NBLK = NYB + (CHROMA ? 2 * NCB : 0);        // blocks per tile
     static constexpr int NT = (NBLK + 63) / 64 * 64;                 // threads per workgroup
-    static constexpr int PLANAR_I16 = YSZ + (CHROMA ? 2 * CSZ : 0);
-    static constexpr int QT_OFF = PLANAR_I16 * 2;                    // byte offset, 16-aligned
-    static constexpr int LUT_OFF = QT_OFF + 3 * 64 * 4;              // row-offset tables, see phase_setup
+    static constexpr int NW = NT / 64;
     static constexpr int LUT_N = SH + 2;
     static constexpr int LUT_BYTES = ((2 * LUT_N * 2 + 15) / 16) * 16;
-    static constexpr int LDS_BYTES = LUT_OFF + LUT_BYTES;
-    // extras of the compacting variant (zj_fused_kernel<.., COMPACT = 1>): raw staging for the halo
-    // blocks (full blocks stage their coefficients in their own pixel slot), the per-wave work queues
-    static constexpr int NHALO = CHROMA ? 2 * CBR * 2 * HALO : 0;    // halo blocks per tile
-    static constexpr int HSTAGE_OFF = LDS_BYTES;                     // NHALO x 128 bytes
-    static constexpr int QUEUE_OFF = HSTAGE_OFF + NHALO * 128;       // NT/64 waves x 64 entries x u32
-    static constexpr int QCNT_OFF = QUEUE_OFF + (NT / 64) * 64 * 4;
-    static constexpr int LDS_BYTES_COMPACT = QCNT_OFF + 32;
-    // transposed-store variant (TS): per wave, 64 x 16 bytes for the third piece of every item of a round (the first
-    // two pieces reuse the item's own, already consumed, luma slot)
-    static constexpr int XSTAGE_OFF = (LDS_BYTES_COMPACT + 15) / 16 * 16;
-    static constexpr int LDS_BYTES_TS = XSTAGE_OFF + (NT / 64) * 1024;
+    static constexpr int CBYTES = CHROMA ? 2 * CSZ * 2 : 0;
+    static constexpr bool TSCAP = OUT == OUT_RGB || OUT == OUT_YCBCR; // 3-byte interleaved outputs: staged stores
+    template <int GEN> struct L {
+        static constexpr int YPX = GEN == GEN_PACKED ? 1 : 2;        // bytes per staged luma sample
+        // Cb plane, then Cr.  Packed: a wave's round reuses the 16 luma bytes of each of its 64 items as store staging
+        // (piece_addr), also for item numbers beyond NITEMS in a partly filled round: the luma area is padded to whole rounds
+        static constexpr int C_OFF = GEN == GEN_PACKED ? (NITEMS + 63) / 64 * 64 * 16 : YSZ * 2;
+        static constexpr int TAB_OFF = C_OFF + CBYTES;
+        static constexpr int LUT_OFF = TAB_OFF + TAB_BYTES;
+        static constexpr int FLAG_OFF = LUT_OFF + LUT_BYTES;         // GEN_PACKED: "redo this tile wide"
+        static constexpr int X_OFF = FLAG_OFF + 16;                  // GEN_PACKED: per wave 2 KB of store staging
+        static constexpr int BYTES = GEN == GEN_PACKED ? X_OFF + (TSCAP ? NW * 2048 : 0) : FLAG_OFF;
+        static_assert(C_OFF % 16 == 0 && TAB_OFF % 16 == 0, "16-byte alignment of the planes");
+    };
+    static constexpr int LDS_WIDE = L<GEN_WIDE>::BYTES;
+    static constexpr int LDS_PACKED = L<GEN_PACKED>::BYTES > LDS_WIDE ? L<GEN_PACKED>::BYTES : LDS_WIDE;
     static constexpr int PIECES_PER_ROW = 3 * NGRP; // 16-byte pieces of a 3-byte-per-pixel tile row
-    static_assert(PLANAR_I16 % 8 == 0, "planar area must keep 16-byte alignment");
     static_assert(NT <= 512 && NBLK <= NT, "one lane per block, at most 8 waves");
 };
 
@@ -399,7 +610,6 @@ struct Params {
     const int16_t* cb;
     const int16_t* cr;
     uint8_t* out;
-    const int32_t* qt;            // [3][64]
     long long y_frame_stride;     // i16 elements between frames
     long long c_frame_stride;
     long long out_frame_stride;   // bytes between frames
@@ -415,6 +625,7 @@ struct Params {
     long long plane_stride;       // OUT_RGB_CHW: bytes between the R, G and B planes of a frame (width * height)
     int clamp_dc;                 // extension: DC-only shortcut value clamped to 0..255 (Q1 corrected)
     int edge_rep;                 // extension: horizontal chroma filter per row with replicated edges (Q4 corrected)
+    uint32_t tab[3 * TAB_DW];     // the three quantisation tables + guard constants (build_table), by value
 };
 
 // vertical schedule of upsample_vertical (upsampler/scalar.rs:84-144): pair k -> (near, far)
@@ -454,51 +665,25 @@ ZJ_DEV TileId decode_tile(const Params& p, int bid)
     return t;
 }
 
-ZJ_DEV TileId tile_from_id(const Params& p, int id)
-{
-    TileId t;
-    t.tile = id % p.tiles_per_row;
-    const int r = id / p.tiles_per_row;
-    t.strip = r % p.n_strips;
-    t.frame = r / p.n_strips;
-    return t;
-}
-
-// Persistent variant: workgroup `wg` of `nwg` walks tiles first, first + step, ... < last.  XCD x (the
-// hardware puts workgroup b on XCD b % 8) owns the contiguous tile range [x*chunk, (x+1)*chunk), and the
-// workgroups of one XCD interleave over it, so tiles processed at the same time are neighbours.
-struct TileWalk { int first, step, last; };
-ZJ_DEV TileWalk persistent_walk(const Params& p, int wg, int nwg)
-{
-    TileWalk w;
-    if (nwg % 8 != 0 || nwg < 8) { w.first = wg; w.step = nwg; w.last = p.total_tiles; return w; }
-    const int chunk = (p.total_tiles + 7) / 8, x = wg & 7;
-    const int lo = x * chunk, hi = lo + chunk < p.total_tiles ? lo + chunk : p.total_tiles;
-    w.first = lo + (wg >> 3);
-    w.step = nwg >> 3;
-    w.last = hi;
-    return w;
-}
-
 // ------------------------------------------------------------------------------------------------
 // Block b of a tile: where its 64 coefficients live in HBM and where its pixels go in LDS.
 //   b in [0, NYB): luma; then NCB Cb blocks; then NCB Cr blocks (halo columns first/last per row)
 // ------------------------------------------------------------------------------------------------
 struct BlockLoc {
     const U4* src;   // 8 x 16 bytes of coefficients
-    int16_t* dst;    // LDS address of the block's pixel (0,0) -- or of the single halo column
-    int pitch;       // LDS row pitch in i16
+    char* dst;       // LDS address of the block's pixel (0,0) -- or of the single halo column
+    int pitch;       // LDS row pitch in BYTES
     int comp;        // 0 Y, 1 Cb, 2 Cr
     int halo;        // 0: full block, 1: left halo (keep pixel column 7), 2: right halo (column 0)
-    int hslot;       // halo blocks: index 0..NHALO-1 (raw staging slot of the compacting variant)
     bool valid;
 };
 
-template <class C>
-ZJ_DEV BlockLoc locate(const Params& p, const TileId t, const int b, int16_t* lds)
+template <class C, int GEN>
+ZJ_DEV BlockLoc locate(const Params& p, const TileId t, const int b, char* lds)
 {
+    using LL = typename C::template L<GEN>;
     BlockLoc L;
-    L.valid = false; L.halo = 0; L.hslot = 0; L.comp = 0; L.src = nullptr; L.dst = lds; L.pitch = C::TWY;
+    L.valid = false; L.halo = 0; L.comp = 0; L.src = nullptr; L.dst = lds; L.pitch = C::TWY * LL::YPX;
     const int ybw = p.mcu_x * (C::TWYB / C::TWC); // luma blocks per plane row (= mcu_x * HS)
     const int cbw = p.mcu_x;                      // chroma blocks per plane row
     if (b < C::NYB) {
@@ -507,7 +692,7 @@ ZJ_DEV BlockLoc locate(const Params& p, const TileId t, const int b, int16_t* ld
         if (gcol >= ybw) return L;
         const long long blk = (long long)(t.strip * C::YBR + brow) * ybw + gcol;
         L.src = reinterpret_cast<const U4*>(p.y + (long long)t.frame * p.y_frame_stride + blk * 64);
-        L.dst = lds + (brow * 8) * C::TWY + bcol * 8;
+        L.dst = lds + ((brow * 8) * C::TWY + bcol * 8) * LL::YPX;
         L.valid = true;
         return L;
     }
@@ -520,8 +705,8 @@ ZJ_DEV BlockLoc locate(const Params& p, const TileId t, const int b, int16_t* ld
     const int nvalid = (cbw - cb0) < C::TWC ? (cbw - cb0) : C::TWC;
     int gcol, lcol;
     if (C::HALO) {
-        if (j == 0) { gcol = cb0 > 0 ? cb0 - 1 : cbw - 1; lcol = C::COFF - 1; L.halo = 1; L.hslot = ((comp - 1) * C::CBR + brow) * 2; }
-        else if (j == C::CCOLS - 1) { gcol = cb0 + nvalid < cbw ? cb0 + nvalid : 0; lcol = C::COFF + 8 * nvalid; L.halo = 2; L.hslot = ((comp - 1) * C::CBR + brow) * 2 + 1; }
+        if (j == 0) { gcol = cb0 > 0 ? cb0 - 1 : cbw - 1; lcol = C::COFF - 1; L.halo = 1; }
+        else if (j == C::CCOLS - 1) { gcol = cb0 + nvalid < cbw ? cb0 + nvalid : 0; lcol = C::COFF + 8 * nvalid; L.halo = 2; }
         else { if (j - 1 >= nvalid) return L; gcol = cb0 + j - 1; lcol = C::COFF + 8 * (j - 1); }
     } else {
         if (j >= nvalid) return L;
@@ -530,13 +715,14 @@ ZJ_DEV BlockLoc locate(const Params& p, const TileId t, const int b, int16_t* ld
     const long long blk = (long long)(t.strip * C::CBR + brow) * cbw + gcol;
     const int16_t* plane = (comp == 1 ? p.cb : p.cr) + (long long)t.frame * p.c_frame_stride;
     L.src = reinterpret_cast<const U4*>(plane + blk * 64);
-    L.dst = lds + C::YSZ + (comp - 1) * C::CSZ + (brow * 8) * C::CPITCH + lcol;
-    L.pitch = C::CPITCH;
+    L.dst = lds + LL::C_OFF + ((comp - 1) * C::CSZ + (brow * 8) * C::CPITCH + lcol) * 2;
+    L.pitch = C::CPITCH * 2;
     L.comp = comp;
     L.valid = true;
     return L;
 }
 
+// a block's 8 pixel rows as packed i16 -> LDS (wide luma, chroma of both generations)
 ZJ_DEV void store_block(const BlockLoc& L, const U4 px[8])
 {
     if (L.halo == 0) {
@@ -546,16 +732,31 @@ ZJ_DEV void store_block(const BlockLoc& L, const U4 px[8])
         // only one pixel column of a halo block is ever read: its last (left) / first (right)
 #pragma unroll
         for (int r = 0; r < 8; r++)
-            L.dst[r * L.pitch] = (int16_t)(L.halo == 1 ? (px[r].w >> 16) : (px[r].x & 0xffffu));
+            *reinterpret_cast<int16_t*>(L.dst + r * L.pitch) = (int16_t)(L.halo == 1 ? (px[r].w >> 16) : (px[r].x & 0xffffu));
+    }
+}
+// one splat row stored eight times (DC-only blocks): no 32-register fill for the shortcut lanes
+ZJ_DEV void store_splat(const BlockLoc& L, const uint32_t v)
+{
+    const U4 row = {v, v, v, v};
+    if (L.halo == 0) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) *reinterpret_cast<U4*>(L.dst + r * L.pitch) = row;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; r++) *reinterpret_cast<int16_t*>(L.dst + r * L.pitch) = (int16_t)v;
     }
 }
 
-template <class C> ZJ_DEV int32_t* lds_qt(int16_t* lds) { return reinterpret_cast<int32_t*>(reinterpret_cast<char*>(lds) + C::QT_OFF); }
+template <class C, int GEN> ZJ_DEV uint32_t* lds_tab(char* lds) { return reinterpret_cast<uint32_t*>(lds + C::template L<GEN>::TAB_OFF); }
+template <class C, int GEN> ZJ_DEV int16_t* lds_lut(char* lds) { return reinterpret_cast<int16_t*>(lds + C::template L<GEN>::LUT_OFF); }
+template <class C, int GEN> ZJ_DEV const int16_t* lds_lut(const char* lds) { return reinterpret_cast<const int16_t*>(lds + C::template L<GEN>::LUT_OFF); }
+template <class C> ZJ_DEV uint32_t* lds_flag(char* lds) { return reinterpret_cast<uint32_t*>(lds + C::template L<GEN_PACKED>::FLAG_OFF); }
 
 // ------------------------------------------------------------------------------------------------
 // Phase 1 (one lane per block, every wave full whatever the component mix):
 //   load_block   issues the lane's 8 x 16-byte coefficient loads                 (before the barrier
-//   phase_setup  stages the three quantisation tables in LDS                      that publishes QT)
+//   phase_setup  stages the three quantisation tables in LDS                      that publishes them)
 //   finish_block dequantize + IDCT (or the DC-only shortcut, Q1) -> LDS planar staging
 // ------------------------------------------------------------------------------------------------
 ZJ_DEV void load_block(const BlockLoc& L, U4 raw[8], const int debug = 0)
@@ -578,269 +779,92 @@ ZJ_DEV void load_block(const BlockLoc& L, U4 raw[8], const int debug = 0)
     for (int i = 0; i < 8; i++) raw[i] = L.src[i];
 }
 
-template <class C> ZJ_DEV int16_t* lds_lut(int16_t* lds) { return reinterpret_cast<int16_t*>(reinterpret_cast<char*>(lds) + C::LUT_OFF); }
-template <class C> ZJ_DEV const int16_t* lds_lut(const int16_t* lds) { return reinterpret_cast<const int16_t*>(reinterpret_cast<const char*>(lds) + C::LUT_OFF); }
-
-// Stages the three quantisation tables and, for vertically sub-sampled modes, the LDS offsets of the
-// two chroma rows (weights 3 and 1) behind every up-sampled row m = -1 .. SH (Q3): lutA[m+1], lutB[m+1].
-template <class C, int HS, int VS>
-ZJ_DEV void phase_setup(const Params& p, const int tid, int16_t* lds)
+// Stages the tables and, for vertically sub-sampled modes, the LDS offsets (bytes) of the two chroma rows
+// (weights 3 and 1) behind every up-sampled row m = -1 .. SH (Q3): lutA[m+1], lutB[m+1].
+template <class C, int HS, int VS, int GEN>
+ZJ_DEV void phase_setup(const Params& p, const int tid, char* lds)
 {
-    for (int i = tid; i < 192; i += C::NT) lds_qt<C>(lds)[i] = p.qt[i];
+    for (int i = tid; i < 3 * TAB_DW; i += C::NT) lds_tab<C, GEN>(lds)[i] = p.tab[i];
     if (C::CHROMA && VS == 2) {
         for (int i = tid; i < C::LUT_N; i += C::NT) {
             int ra = 0, rb = 0;
             if (i >= 1 && i <= C::SH) vrows<HS, VS>(i - 1, ra, rb);
-            lds_lut<C>(lds)[i] = (int16_t)(ra * C::CPITCH);
-            lds_lut<C>(lds)[C::LUT_N + i] = (int16_t)(rb * C::CPITCH);
+            lds_lut<C, GEN>(lds)[i] = (int16_t)(ra * C::CPITCH * 2);
+            lds_lut<C, GEN>(lds)[C::LUT_N + i] = (int16_t)(rb * C::CPITCH * 2);
         }
+    }
+    if (GEN == GEN_PACKED && tid == 0) *lds_flag<C>(lds) = 0;
+}
+
+// i16 pixel rows (idct_block's output) -> bytes: values are 0..255 already
+ZJ_DEV void rows_to_bytes(const U4 px[8], uint32_t b[16])
+{
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        b[2 * r] = perm(px[r].y, px[r].x, 0x06040200u);
+        b[2 * r + 1] = perm(px[r].w, px[r].z, 0x06040200u);
+    }
+}
+// bytes -> i16 pixel rows
+ZJ_DEV void bytes_to_rows(const uint32_t b[16], U4 px[8])
+{
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        px[r].x = perm(0, b[2 * r], 0x0c010c00u); px[r].y = perm(0, b[2 * r], 0x0c030c02u);
+        px[r].z = perm(0, b[2 * r + 1], 0x0c010c00u); px[r].w = perm(0, b[2 * r + 1], 0x0c030c02u);
     }
 }
 
-template <class C>
-ZJ_DEV void finish_block(const BlockLoc& L, const U4 raw[8], int16_t* lds, const int debug = 0, const int clamp_dc = 0)
+// GEN_WIDE: the round-1 form.  GEN_PACKED: luma leaves as bytes, chroma as i16; NEED_Y16 = the output does
+// arithmetic on luma (RGB family), so an unclamped DC-only luma value outside 0..255 (Q1) cannot be staged as
+// a byte: the lane raises the tile's flag and the workgroup redoes the tile with the wide code.  (Gray and
+// YCbCr outputs truncate luma to its low byte anyway, Q7.)
+template <class C, int GEN, bool NEED_Y16>
+ZJ_DEV void finish_block(const BlockLoc& L, const U4 raw[8], char* lds, const int debug = 0, const int clamp_dc = 0)
 {
     if (!L.valid) return;
     const uint32_t* w = reinterpret_cast<const uint32_t*>(raw);
-    const int32_t* qt = lds_qt<C>(lds) + 64 * L.comp;
-    uint32_t any = w[0] & 0xffff0000u; // DC-only test (scalar.rs:45): all but coefficient 0 are zero
-#pragma unroll
-    for (int i = 1; i < 32; i++) any |= w[i];
-    if (any != 0 && !ZJ_ABL(debug, 1)) {
-        U4 px[8];
-        idct_block(raw, qt, px);
-        store_block(L, px);
-    } else { // one splat row stored eight times: no 32-register fill for the shortcut lanes
-        const uint32_t v = dc_only_value(w[0], qt[0], clamp_dc);
-        const U4 row = {v, v, v, v};
-        if (L.halo == 0) {
-#pragma unroll
-            for (int r = 0; r < 8; r++) *reinterpret_cast<U4*>(L.dst + r * L.pitch) = row;
-        } else {
-#pragma unroll
-            for (int r = 0; r < 8; r++) L.dst[r * L.pitch] = (int16_t)v;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Compacting variant of phase 1 (COMPACT = 1).  DC-only blocks (the reference's own shortcut,
-// scalar.rs:45-74; about a third of a photographic frame) are finished by the classifying lane; the
-// blocks that need the full IDCT are staged in LDS -- in the very slot their pixels will occupy --
-// and queued, so that the second half runs the IDCT on densely packed lanes:
-//   classify_stage   any-AC test; DC-only -> fill; else raw -> LDS slot + per-wave queue entry
-//   idct_queue       lanes 0..n-1 pop one entry each: raw from LDS -> IDCT -> pixels in place
-// Queue entry: bits 0-15 LDS offset (i16 units) of the pixel slot, 16-17 component, 18-19 halo kind,
-// 20-23 halo staging slot.  Per-wave queue segments + counts avoid atomics (deterministic order).
-// ------------------------------------------------------------------------------------------------
-template <class C> ZJ_DEV uint32_t* lds_queue(int16_t* lds) { return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds) + C::QUEUE_OFF); }
-template <class C> ZJ_DEV int* lds_qcnt(int16_t* lds) { return reinterpret_cast<int*>(reinterpret_cast<char*>(lds) + C::QCNT_OFF); }
-template <class C> ZJ_DEV int16_t* lds_hstage(int16_t* lds) { return reinterpret_cast<int16_t*>(reinterpret_cast<char*>(lds) + C::HSTAGE_OFF); }
-
-ZJ_DEV void wave_queue_push(int* qcnt, uint32_t* queue, const int tid, const bool push, const uint32_t entry)
-{
-    const int w = tid >> 6, lane = tid & 63;
-#if defined(ZJ_EMU)
-    if (lane == 0) qcnt[w] = 0; // lanes of a wave run in order in the emulator
-    if (push) queue[w * 64 + qcnt[w]++] = entry;
-#else
-    const unsigned long long m = __ballot(push);
-    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-    if (push) queue[w * 64 + rank] = entry;
-    if (lane == 0) qcnt[w] = __popcll(m);
-#endif
-}
-
-template <class C>
-ZJ_DEV void classify_stage(const BlockLoc& L, const U4 raw[8], const int32_t q0, const int tid, int16_t* lds, const int clamp_dc = 0)
-{
-    bool full = false;
-    uint32_t entry = 0;
-    if (L.valid) {
-        const uint32_t* w = reinterpret_cast<const uint32_t*>(raw);
-        uint32_t any = w[0] & 0xffff0000u; // DC-only test (scalar.rs:45)
+    const uint32_t* tab = lds_tab<C, GEN>(lds) + TAB_DW * L.comp;
+    if (GEN == GEN_WIDE) {
+        uint32_t any = w[0] & 0xffff0000u; // DC-only test (scalar.rs:45): all but coefficient 0 are zero
 #pragma unroll
         for (int i = 1; i < 32; i++) any |= w[i];
-        full = any != 0;
-        if (!full) {
-            const uint32_t v = dc_only_value(w[0], q0, clamp_dc);
+        if (any != 0 && !ZJ_ABL(debug, 1)) {
             U4 px[8];
-#pragma unroll
-            for (int r = 0; r < 8; r++) { px[r].x = v; px[r].y = v; px[r].z = v; px[r].w = v; }
+            idct_block(raw, reinterpret_cast<const uint16_t*>(tab), px);
             store_block(L, px);
         } else {
-            entry = (uint32_t)(L.dst - lds) | ((uint32_t)L.comp << 16) | ((uint32_t)L.halo << 18) | ((uint32_t)L.hslot << 20);
-            if (L.halo == 0) {
-#pragma unroll
-                for (int r = 0; r < 8; r++) *reinterpret_cast<U4*>(L.dst + r * L.pitch) = raw[r];
-            } else {
-                U4* hs = reinterpret_cast<U4*>(lds_hstage<C>(lds) + 64 * L.hslot);
-#pragma unroll
-                for (int r = 0; r < 8; r++) hs[r] = raw[r];
-            }
+            store_splat(L, dc_only_value(w[0], (int32_t)(tab[0] & 0xffffu), clamp_dc));
         }
+        return;
     }
-    wave_queue_push(lds_qcnt<C>(lds), lds_queue<C>(lds), tid, full, entry);
-}
-
-template <class C>
-ZJ_DEV void idct_queue(const int tid, int16_t* lds)
-{
-    const int* qc = lds_qcnt<C>(lds);
-    constexpr int NW = C::NT / 64;
-    int start[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int n = 0;
+    int cls = classify_block(w, tab + 32);
+    if (ZJ_ABL(debug, 1)) cls = 0;
+    if (cls == 0) {
+        const uint32_t v = dc_only_value(w[0], (int32_t)(tab[0] & 0xffffu), clamp_dc);
+        if (L.comp != 0) { store_splat(L, v); return; }
+        if (NEED_Y16 && (v & 0xffffu) > 255u) *lds_flag<C>(lds) = 1; // benign race: every writer stores 1
+        const uint32_t b = (v & 0xffu) * 0x01010101u;
+        const U2 row = {b, b};
 #pragma unroll
-    for (int w = 0; w < NW; w++) { start[w] = n; n += qc[w]; }
-    for (int q = tid; q < n; q += C::NT) {
-        int w = 0;
-#pragma unroll
-        for (int k = 1; k < NW; k++) w += (q >= start[k]) ? 1 : 0;
-        int base = start[0];
-#pragma unroll
-        for (int k = 1; k < NW; k++) base = (w == k) ? start[k] : base;
-        const uint32_t e = lds_queue<C>(lds)[w * 64 + (q - base)];
-        BlockLoc L;
-        L.valid = true; L.src = nullptr;
-        L.dst = lds + (e & 0xffffu);
-        L.comp = (int)((e >> 16) & 3);
-        L.halo = (int)((e >> 18) & 3);
-        L.hslot = (int)((e >> 20) & 15);
-        L.pitch = L.comp == 0 ? C::TWY : C::CPITCH;
-        U4 raw[8], px[8];
-        if (L.halo == 0) {
-#pragma unroll
-            for (int r = 0; r < 8; r++) raw[r] = *reinterpret_cast<const U4*>(L.dst + r * L.pitch);
-        } else {
-            const U4* hs = reinterpret_cast<const U4*>(lds_hstage<C>(lds) + 64 * L.hslot);
-#pragma unroll
-            for (int r = 0; r < 8; r++) raw[r] = hs[r];
-        }
-        idct_block(raw, lds_qt<C>(lds) + 64 * L.comp, px);
-        store_block(L, px);
+        for (int r = 0; r < 8; r++) *reinterpret_cast<U2*>(L.dst + r * L.pitch) = row;
+        return;
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Work-stealing variant of phase 1 (COMPACT = 3).  Lanes whose block is DC-only (the reference's shortcut,
-// scalar.rs:45-74) sit idle while their wave runs the IDCT for the others.  Here the LAST wave of the
-// workgroup (the donor) stages the blocks of its lanes that need the full IDCT in LDS -- in the slot their
-// pixels will occupy, like COMPACT = 1 -- and the idle lanes of the other waves take one each, so those
-// waves run their single IDCT pass with (nearly) every lane busy and the donor wave skips its pass.
-// Compared with COMPACT = 1 only one wave's blocks travel through LDS and nobody re-reads its own block.
-//   steal_stage   every lane: DC-only test, DC-only blocks are finished; donor lanes stage + queue theirs;
-//                 other waves count their idle lanes (DC-only or no block)           -> rank, per-wave counts
-//   steal_idct    idle lane i of the non-donor waves takes donor entry i (if there is one), then every
-//                 lane with work runs idct_block once; donor lanes whose entry nobody took run their own
-// ------------------------------------------------------------------------------------------------
-// rank of this lane among the lanes of its wave for which pred holds; cnt_slot[wave] = how many do
-ZJ_DEV int wave_rank(int* cnt_slot, const int tid, const bool pred)
-{
-    const int w = tid >> 6, lane = tid & 63;
-#if defined(ZJ_EMU)
-    if (lane == 0) cnt_slot[w] = 0; // lanes of a wave run in order in the emulator
-    const int r = cnt_slot[w];
-    if (pred) cnt_slot[w] = r + 1;
-    return r;
-#else
-    const unsigned long long m = __ballot(pred);
-    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-    if (lane == 0) cnt_slot[w] = __popcll(m);
-    return rank;
-#endif
-}
-
-struct StealState { bool full; int rank; }; // full: this lane's own block needs the IDCT; rank: see steal_stage
-
-template <class C>
-ZJ_DEV StealState steal_stage(const BlockLoc& L, const U4 raw[8], const int32_t q0, const int tid, int16_t* lds, const int clamp_dc = 0,
-                              const int DONOR = C::NT / 64 - 1)
-{
-    const int w = tid >> 6;
-    StealState st;
-    st.full = false;
-    if (L.valid) {
-        const uint32_t* wd = reinterpret_cast<const uint32_t*>(raw);
-        uint32_t any = wd[0] & 0xffff0000u; // DC-only test (scalar.rs:45)
-#pragma unroll
-        for (int i = 1; i < 32; i++) any |= wd[i];
-        st.full = any != 0;
-        if (!st.full) {
-            const uint32_t v = dc_only_value(wd[0], q0, clamp_dc);
-            const U4 row = {v, v, v, v};
-            if (L.halo == 0) {
-#pragma unroll
-                for (int r = 0; r < 8; r++) *reinterpret_cast<U4*>(L.dst + r * L.pitch) = row;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 8; r++) L.dst[r * L.pitch] = (int16_t)v;
-            }
-        }
-    }
-    if (w == DONOR) { // rank among the donor's full blocks = queue position
-        st.rank = wave_rank(lds_qcnt<C>(lds), tid, st.full);
-        if (st.full) {
-            lds_queue<C>(lds)[st.rank] = (uint32_t)(L.dst - lds) | ((uint32_t)L.comp << 16) | ((uint32_t)L.halo << 18) | ((uint32_t)L.hslot << 20);
-            if (L.halo == 0) {
-#pragma unroll
-                for (int r = 0; r < 8; r++) *reinterpret_cast<U4*>(L.dst + r * L.pitch) = raw[r];
-            } else {
-                U4* hs = reinterpret_cast<U4*>(lds_hstage<C>(lds) + 64 * L.hslot);
-#pragma unroll
-                for (int r = 0; r < 8; r++) hs[r] = raw[r];
-            }
-        }
-    } else {          // rank among this wave's idle lanes
-        st.rank = wave_rank(lds_qcnt<C>(lds), tid, !st.full);
-    }
-    return st;
-}
-
-template <class C>
-ZJ_DEV void steal_idct(const BlockLoc& Lown, U4 raw[8], const StealState st, const int tid, int16_t* lds,
-                       const int DONOR = C::NT / 64 - 1)
-{
-    constexpr int NW = C::NT / 64;
-    const int w = tid >> 6;
-    const int* qc = lds_qcnt<C>(lds);
-    const int offered = qc[DONOR];
-    int idle_before = 0, idle_total = 0;
-#pragma unroll
-    for (int k = 0; k < NW; k++) {
-        const int c = (k == DONOR) ? 0 : qc[k];
-        idle_before += (k < w) ? c : 0;
-        idle_total += c;
-    }
-    const int taken = offered < idle_total ? offered : idle_total;
-    BlockLoc L = Lown;
-    bool work;
-    if (w == DONOR) {
-        work = st.full && st.rank >= taken; // nobody took this one (more offers than idle lanes)
+    uint32_t b[16];
+    if (cls == 1) {
+        idct_block_packed(raw, tab, b);
     } else {
-        const int slot = idle_before + st.rank;
-        const bool take = !st.full && slot < taken;
-        if (take) {
-            const uint32_t e = lds_queue<C>(lds)[slot];
-            L.valid = true;
-            L.dst = lds + (e & 0xffffu);
-            L.comp = (int)((e >> 16) & 3);
-            L.halo = (int)((e >> 18) & 3);
-            L.hslot = (int)((e >> 20) & 15);
-            L.pitch = L.comp == 0 ? C::TWY : C::CPITCH;
-            if (L.halo == 0) {
-#pragma unroll
-                for (int r = 0; r < 8; r++) raw[r] = *reinterpret_cast<const U4*>(L.dst + r * L.pitch);
-            } else {
-                const U4* hs = reinterpret_cast<const U4*>(lds_hstage<C>(lds) + 64 * L.hslot);
-#pragma unroll
-                for (int r = 0; r < 8; r++) raw[r] = hs[r];
-            }
-        }
-        work = st.full || take;
-    }
-    if (work) {
+        ZJ_NO_IF_CONVERT();
         U4 px[8];
-        idct_block(raw, lds_qt<C>(lds) + 64 * L.comp, px);
+        idct_block(raw, reinterpret_cast<const uint16_t*>(tab), px);
+        rows_to_bytes(px, b);
+    }
+    if (L.comp == 0) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const U2 row = {b[2 * r], b[2 * r + 1]}; *reinterpret_cast<U2*>(L.dst + r * L.pitch) = row; }
+    } else {
+        U4 px[8];
+        bytes_to_rows(b, px);
         store_block(L, px);
     }
 }
@@ -920,12 +944,49 @@ ZJ_DEV void store_clip(uint8_t* orow, long long off, const uint32_t* w, int ndw,
     }
 }
 
-// TS (transposed store, FAST RGB / YCbCr only): processes ONE round (item = tid + round * NT) and, instead of
-// storing its 48 bytes at a 48-byte lane stride, leaves them in LDS for color_copyout, which stores 16-byte pieces
-// that are contiguous across the lanes of a wave.
-template <class C, int HS, int VS, int OUT, bool FAST = true, bool TS = false>
-ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, int16_t* lds, const int round = 0)
+// What a lane hands to the staged-store half of a round (TS): its item's 48 output bytes and where they go.
+//   kind 0: nothing (no item)   1: pieces 3L, 3L+1, 3L+2            2: as 1 without the third piece
+//        3: the row's last group under the early-tail quirk (Q5): pieces 3L-1, 3L, 3L+1, then zeros in 3L+2 (Q6)
+struct ItemOut { U4 s0, s1, s2; int kind; };
+
+// LDS address of piece q (0..191) of a wave's round: the first 64 pieces reuse the luma bytes the wave's 64 items
+// have just consumed (16 bytes each, contiguous because consecutive items are consecutive 16-pixel groups), the
+// other 128 live in the wave's 2 KB of staging.
+template <class C>
+ZJ_DEV char* piece_addr(char* lds, const int item0, const int wave, const int q)
 {
+    using LL = typename C::template L<GEN_PACKED>;
+    char* const ybase = lds + 16 * item0;
+    char* const xbase = lds + LL::X_OFF + 2048 * wave - 1024;
+    return (q < 64 ? ybase : xbase) + 16 * q;
+}
+
+template <class C>
+ZJ_DEV void stage_item(const ItemOut& io, const int tid, char* lds, const int round)
+{
+    if (io.kind == 0) return;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int item0 = 64 * wave + round * C::NT;
+    if (io.kind == 3) {
+        const U4 z = {0, 0, 0, 0};
+        *reinterpret_cast<U4*>(piece_addr<C>(lds, item0, wave, 3 * lane - 1)) = io.s0; // launcher: lane > 0 here
+        *reinterpret_cast<U4*>(piece_addr<C>(lds, item0, wave, 3 * lane)) = io.s1;
+        *reinterpret_cast<U4*>(piece_addr<C>(lds, item0, wave, 3 * lane + 1)) = io.s2;
+        *reinterpret_cast<U4*>(piece_addr<C>(lds, item0, wave, 3 * lane + 2)) = z;
+        return;
+    }
+    *reinterpret_cast<U4*>(piece_addr<C>(lds, item0, wave, 3 * lane)) = io.s0;
+    *reinterpret_cast<U4*>(piece_addr<C>(lds, item0, wave, 3 * lane + 1)) = io.s1;
+    if (io.kind == 1) *reinterpret_cast<U4*>(piece_addr<C>(lds, item0, wave, 3 * lane + 2)) = io.s2;
+}
+
+// TS (staged stores, GEN_PACKED, FAST RGB / YCbCr only): processes ONE round (item = tid + round * NT) and, instead
+// of storing its 48 bytes at a 48-byte lane stride, returns them in *io for stage_item; color_copyout then stores
+// 16-byte pieces that are contiguous across the lanes of a wave.
+template <class C, int HS, int VS, int OUT, int GEN, bool FAST = true, bool TS = false>
+ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* lds, const int round = 0, ItemOut* io = nullptr)
+{
+    using LL = typename C::template L<GEN>;
     const int P = p.mcu_x * 8 * HS;       // padded row length == luma width_stride (headers.rs:338)
     const int W = p.width;
     const int cbw = p.mcu_x;
@@ -937,35 +998,59 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, int16_t*
     const long long row_bytes = OUT == OUT_RGB_CHW ? (long long)W : (long long)W * ncomp; // CHW: one plane's row
     uint8_t* const frame_out = p.out + (long long)t.frame * p.out_frame_stride;
     const int elements = P / 16 - 1; // worker.rs:171 (P >= 32 on this path)
+    if (TS) io->kind = 0;
 
     for (int item = TS ? tid + round * C::NT : tid; item < C::NITEMS; item += TS ? C::NITEMS : C::NT) {
         const int m = item / C::NGRP, g = item % C::NGRP;
         const int px0 = x0 + 16 * g;      // first pixel of the group in the padded row
         const int row = t.strip * C::SH + m;
         if (px0 >= P || row >= p.height) continue;
-        const U4* yrow = reinterpret_cast<const U4*>(lds + m * C::TWY + 16 * g);
-        const U4 ya = yrow[0], yb = yrow[1];
-        const uint32_t yw[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
         uint8_t* const orow = frame_out + (long long)row * row_bytes;
-
-        if (OUT == OUT_GRAY) {
-            // ycbcr_to_grayscale (color_convert/scalar.rs:91-114): `as u8` truncation (Q7)
-            U4 o;
-            o.x = perm(yw[1], yw[0], 0x06040200u); o.y = perm(yw[3], yw[2], 0x06040200u);
-            o.z = perm(yw[5], yw[4], 0x06040200u); o.w = perm(yw[7], yw[6], 0x06040200u);
-            if (FAST) {
-                store16(orow + px0, o); // W % 16 == 0
-            } else {                    // any width: bytes x < W of the padded row
-                const uint32_t ow4[4] = {o.x, o.y, o.z, o.w};
-                store_clip(orow, px0, ow4, 4, W, 0, 0);
+        // ---- luma: yp[] = packed i16 pairs in the arrangement the chroma code produces -----------------
+        //   HS == 2: [0..3] = (Y[4k], Y[4k+2]), [4..7] = (Y[4k+1], Y[4k+3]);  HS == 1: natural pairs (Y[2k], Y[2k+1])
+        uint32_t yp[8];
+        if (GEN == GEN_PACKED) {
+            const U4 yv = *reinterpret_cast<const U4*>(lds + 16 * item);
+            if (OUT == OUT_GRAY) {
+                // ycbcr_to_grayscale (color_convert/scalar.rs:91-114): `as u8` truncation (Q7) == the staged byte
+                if (FAST) store16(orow + px0, yv); // W % 16 == 0
+                else { const uint32_t ow4[4] = {yv.x, yv.y, yv.z, yv.w}; store_clip(orow, px0, ow4, 4, W, 0, 0); }
+                continue;
             }
-            continue;
+            const uint32_t yb[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (HS == 2) { yp[k] = perm(0, yb[k], 0x0c020c00u); yp[4 + k] = perm(0, yb[k], 0x0c030c01u); }
+                else { yp[2 * k] = perm(0, yb[k], 0x0c010c00u); yp[2 * k + 1] = perm(0, yb[k], 0x0c030c02u); }
+            }
+        } else {
+            const U4* yrow = reinterpret_cast<const U4*>(lds + 32 * item);
+            const U4 ya = yrow[0], yb = yrow[1];
+            const uint32_t yw[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+            if (OUT == OUT_GRAY) {
+                U4 o;
+                o.x = perm(yw[1], yw[0], 0x06040200u); o.y = perm(yw[3], yw[2], 0x06040200u);
+                o.z = perm(yw[5], yw[4], 0x06040200u); o.w = perm(yw[7], yw[6], 0x06040200u);
+                if (FAST) store16(orow + px0, o);
+                else { const uint32_t ow4[4] = {o.x, o.y, o.z, o.w}; store_clip(orow, px0, ow4, 4, W, 0, 0); }
+                continue;
+            }
+            if (HS == 2) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    yp[k] = perm(yw[2 * k + 1], yw[2 * k], 0x05040100u);     // (Y[4k],   Y[4k+2])
+                    yp[4 + k] = perm(yw[2 * k + 1], yw[2 * k], 0x07060302u); // (Y[4k+1], Y[4k+3])
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) yp[k] = yw[k];
+            }
         }
 
         // ---- chroma for the 16 pixels (raw samples), packed pairs ---------------------------------
         uint32_t cbp[8], crp[8]; // HS==2: [0..3] = E_k (px 4k, 4k+2), [4..7] = O_k (px 4k+1, 4k+3)
                                  // HS==1: natural pairs (px 2k, 2k+1)
-        // LDS offsets (i16 elements) of the chroma rows behind up-sampled row m, and behind rows
+        // LDS offsets (bytes) of the chroma rows behind up-sampled row m, and behind rows
         // m-1 / m+1 where the flat-array neighbour wraps to the other end of the strip (Q4)
         const bool first = HS == 2 && (g == 0) && left_wrap;                  // chroma column 0 of the strip
         const bool last = HS == 2 && (8 * g + 8 == 8 * nvalid) && right_wrap; // last chroma column
@@ -975,31 +1060,31 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, int16_t*
         const bool no_left = first && m == 0 && !p.edge_rep, no_right = last && m == C::SH - 1 && !p.edge_rep;
         int oa, ob, oal, obl, oar, obr;
         if (VS == 2) {
-            const int16_t* lut = lds_lut<C>(lds);
+            const int16_t* lut = lds_lut<C, GEN>(lds);
             const int im = m + 1, il = im - (first ? 1 : 0), ir = im + (last ? 1 : 0);
             oa = lut[im]; ob = lut[C::LUT_N + im];
             oal = lut[il]; obl = lut[C::LUT_N + il];
             oar = lut[ir]; obr = lut[C::LUT_N + ir];
         } else {
-            oa = ob = m * C::CPITCH;
-            oal = obl = (first && m > 0 ? m - 1 : m) * C::CPITCH;
-            oar = obr = (last && m < C::SH - 1 ? m + 1 : m) * C::CPITCH;
+            oa = ob = m * C::CPITCH * 2;
+            oal = obl = (first && m > 0 ? m - 1 : m) * C::CPITCH * 2;
+            oar = obr = (last && m < C::SH - 1 ? m + 1 : m) * C::CPITCH * 2;
         }
 #pragma unroll
         for (int ch = 0; ch < 2; ch++) {
-            const int16_t* cp = lds + C::YSZ + ch * C::CSZ;
+            const char* cp = lds + LL::C_OFF + ch * C::CSZ * 2;
             uint32_t* dst = ch ? crp : cbp;
             if (ZJ_ABL(p.debug, 16)) { // ablation: no chroma reads from LDS, no filters (output is wrong)
 #pragma unroll
-                for (int k = 0; k < 8; k++) dst[k] = yw[k] + ch;
+                for (int k = 0; k < 8; k++) dst[k] = yp[k] + ch;
                 continue;
             }
             if (HS == 1) {
-                const U4* A = reinterpret_cast<const U4*>(cp + oa + 16 * g);
+                const U4* A = reinterpret_cast<const U4*>(cp + oa + 32 * g);
                 const U4 a0 = A[0], a1 = A[1];
                 uint32_t v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
                 if (VS == 2) {
-                    const U4* B = reinterpret_cast<const U4*>(cp + ob + 16 * g);
+                    const U4* B = reinterpret_cast<const U4*>(cp + ob + 32 * g);
                     const U4 b0 = B[0], b1 = B[1];
                     const uint32_t f[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
@@ -1008,18 +1093,18 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, int16_t*
 #pragma unroll
                 for (int k = 0; k < 8; k++) dst[k] = v[k];
             } else {
-                const int lc = C::COFF + 8 * g; // LDS column of this group's first chroma sample
+                const int lc = (C::COFF + 8 * g) * 2; // LDS byte column of this group's first chroma sample
                 const U4 a = *reinterpret_cast<const U4*>(cp + oa + lc);
                 uint32_t vm[4] = {a.x, a.y, a.z, a.w}; // (v1,v2) (v3,v4) (v5,v6) (v7,v8)
                 // the neighbours come as aligned pairs: (x, v0) left of the group, (v9, x) right of it
-                uint32_t prev = *reinterpret_cast<const uint32_t*>(cp + oal + lc - 2);
-                uint32_t next = *reinterpret_cast<const uint32_t*>(cp + oar + lc + 8);
+                uint32_t prev = *reinterpret_cast<const uint32_t*>(cp + oal + lc - 4);
+                uint32_t next = *reinterpret_cast<const uint32_t*>(cp + oar + lc + 16);
                 if (VS == 2) {
                     const U4 b = *reinterpret_cast<const U4*>(cp + ob + lc);
                     vm[0] = tri(vm[0], b.x); vm[1] = tri(vm[1], b.y);
                     vm[2] = tri(vm[2], b.z); vm[3] = tri(vm[3], b.w);
-                    prev = tri(prev, *reinterpret_cast<const uint32_t*>(cp + obl + lc - 2));
-                    next = tri(next, *reinterpret_cast<const uint32_t*>(cp + obr + lc + 8));
+                    prev = tri(prev, *reinterpret_cast<const uint32_t*>(cp + obl + lc - 4));
+                    next = tri(next, *reinterpret_cast<const uint32_t*>(cp + obr + lc + 16));
                 }
                 if (p.edge_rep) { // uniform branch (kernel argument): the default path pays no select for it
                     ZJ_NO_IF_CONVERT();
@@ -1043,20 +1128,6 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, int16_t*
                     dst[7] = (o7 & 0x0000ffffu) | (vm[3] & 0xffff0000u);                 // px 15 = in[n-1]
                 }
             }
-        }
-
-        ZJ_COLOR_SB();
-        // ---- luma pairing to match the chroma arrangement ---------------------------------------
-        uint32_t yp[8];
-        if (HS == 2) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                yp[k] = perm(yw[2 * k + 1], yw[2 * k], 0x05040100u);     // (Y[4k],   Y[4k+2])
-                yp[4 + k] = perm(yw[2 * k + 1], yw[2 * k], 0x07060302u); // (Y[4k+1], Y[4k+3])
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; k++) yp[k] = yw[k];
         }
 
         uint32_t d[12];
@@ -1142,27 +1213,15 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, int16_t*
         const U4 s0 = {d[0], d[1], d[2], d[3]}, s1 = {d[4], d[5], d[6], d[7]}, s2 = {d[8], d[9], d[10], d[11]};
         if (ZJ_ABL(p.debug, 8) && (d[0] ^ d[5] ^ d[11]) != 0x12345u) continue; // ablation: (practically) no HBM writes
         const int G = px0 >> 4; // 16-pixel group index in the row
+        const bool quirk = OUT == OUT_RGB && !p.plain;
         if (TS) {
-            // pieces 0 and 1 into the item's own luma slot (32 bytes, read above and dead now), piece 2 into the
-            // wave's staging row.  The early RGB tail (Q5) is applied here, as a shift by one piece: the last group
-            // of a row starts in the third slot of the group before it, and the row's last piece is zero (Q6).
-            char* const yslot = reinterpret_cast<char*>(lds) + 32 * item;
-            char* const xslot = reinterpret_cast<char*>(lds) + C::XSTAGE_OFF + 1024 * (tid >> 6) + 16 * (tid & 63);
-            const bool quirk = OUT == OUT_RGB && !p.plain;
-            if (quirk && G == elements) {
-                const U4 z = {0, 0, 0, 0};
-                *reinterpret_cast<U4*>(xslot - 16) = s0; // the launcher guarantees the previous group is lane - 1
-                *reinterpret_cast<U4*>(yslot) = s1;
-                *reinterpret_cast<U4*>(yslot + 16) = s2;
-                *reinterpret_cast<U4*>(xslot) = z;
-            } else {
-                *reinterpret_cast<U4*>(yslot) = s0;
-                *reinterpret_cast<U4*>(yslot + 16) = s1;
-                if (!(quirk && G == elements - 1)) *reinterpret_cast<U4*>(xslot) = s2;
-            }
+            // The early RGB tail (Q5) is a shift by one piece: the last group of a row starts in the third slot of the
+            // group before it, and the row's last piece is zero (Q6) or never stored (color_copyout)
+            io->s0 = s0; io->s1 = s1; io->s2 = s2;
+            io->kind = (quirk && G == elements) ? 3 : ((quirk && G == elements - 1) ? 2 : 1);
             continue;
         }
-        if (OUT == OUT_YCBCR || p.plain) {
+        if (!quirk) {
             uint8_t* o = orow + 48ll * G;
             store16(o, s0); store16(o + 16, s1); store16(o + 32, s2);
         } else {
@@ -1184,11 +1243,11 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, int16_t*
     }
 }
 
-// Second half of a transposed-store round: lane L of a wave stores pieces 64*j + L (j = 0, 1, 2) of the 192 pieces
-// its wave staged, i.e. every store instruction writes 1024 contiguous bytes of the tile's rows (960-byte row
-// segments), instead of 64 pieces 48 bytes apart.
+// Second half of a staged-store round: lane L of a wave stores pieces 64*j + L (j = 0, 1, 2) of the 192 pieces
+// its wave staged, i.e. every store instruction writes 1024 contiguous bytes of the tile's rows (row segments of
+// PIECES_PER_ROW pieces), instead of 64 pieces 48 bytes apart.
 template <class C, int OUT>
-ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid, const int16_t* lds, const int round)
+ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid, char* lds, const int round)
 {
     const int P = p.mcu_x * 8 * (C::TWYB / C::TWC);
     const int x0 = t.tile * C::TWY;
@@ -1197,26 +1256,23 @@ ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid, const 
     uint8_t* const tile_out = p.out + (long long)t.frame * p.out_frame_stride + (long long)t.strip * C::SH * row_bytes + 3ll * x0;
     const int w = tid >> 6, L = tid & 63;
     const int item0 = 64 * w + round * C::NT;  // first item of this wave's round
-    const char* const ybase = reinterpret_cast<const char*>(lds) + 32 * item0;
-    const char* const xbase = reinterpret_cast<const char*>(lds) + C::XSTAGE_OFF + 1024 * w;
     // the piece the reference never writes: the last one of a row, in the tile that holds the row's end
     const bool row_end_here = x0 + 16 * nvg == P;
     const int never = (OUT == OUT_RGB && !p.plain && !p.zero_fill && row_end_here) ? 3 * nvg - 1 : -1;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         const int q = 64 * j + L;
-        const int i = q / 3, part = q - 3 * i;
-        if (item0 + i >= C::NITEMS) continue;
         const int Q = 3 * item0 + q;            // piece index inside the tile
+        if (Q >= 3 * C::NITEMS) continue;
         const int m = Q / C::PIECES_PER_ROW, c = Q - m * C::PIECES_PER_ROW;
         if (c >= 3 * nvg || t.strip * C::SH + m >= p.height || c == never) continue;
-        const char* src = part < 2 ? ybase + 32 * i + 16 * part : xbase + 16 * i;
-        store16(tile_out + m * row_bytes + 16 * c, *reinterpret_cast<const U4*>(src));
+        const U4 v = *reinterpret_cast<const U4*>(piece_addr<C>(lds, item0, w, q));
+        store16(tile_out + m * row_bytes + 16 * c, v);
     }
 }
 
-// Is the transposed-store variant usable for this launch?  The early-tail shift writes into the staging slot of the
-// lane before it, so the row's last group must never sit in lane 0 of a wave, and both tail groups must be in one tile.
+// Are staged stores usable for this launch?  The early-tail shift writes into the piece before the lane's own, so
+// the row's last group must never sit in lane 0 of a wave, and both tail groups must be in one tile.
 template <class C>
 inline bool ts_eligible(const Params& p, const int out, const bool fast)
 {

@@ -23,114 +23,72 @@ namespace zj {
 // ------------------------------------------------------------------------------------------------
 // ZJ_PRIO bit 0: raise the wave priority while a tile's coefficient loads are being issued (+1 % measured,
 // tools/ab_libs.sh); bit 1: raise it for the colour phase (no gain).  Default: bit 0.
-#ifndef ZJ_STEAL_ROTATE
-#define ZJ_STEAL_ROTATE 1
-#endif
 #ifndef ZJ_PRIO
 #define ZJ_PRIO 1
 #endif
 #define ZJ_SETPRIO(bit, level) do { if (ZJ_PRIO & (bit)) __builtin_amdgcn_s_setprio(level); } while (0)
 
-template <int HS, int VS, int OUT, int COMPACT, bool FAST>
-// 2nd launch bound = waves per SIMD: 5 workgroups of 4 waves per CU need <= 96 VGPRs; LDS (32.7 KB
+// the round-1 pipeline for one tile: int16 staging, 24-bit IDCT, 48-byte-per-lane stores
+template <class C, int HS, int VS, int OUT, bool FAST>
+__device__ __forceinline__ void tile_wide(const Params& p, const TileId t, const int tid, char* lds)
+{
+    ZJ_SETPRIO(1, 3); // issue the tile's loads ahead of other waves' arithmetic
+    const BlockLoc L = locate<C, GEN_WIDE>(p, t, tid, lds);
+    U4 raw[8];
+    load_block(L, raw, p.debug); // HBM loads in flight across the barrier below
+    ZJ_SETPRIO(1, 0);
+    phase_setup<C, HS, VS, GEN_WIDE>(p, tid, lds);
+    __syncthreads();
+    finish_block<C, GEN_WIDE, false>(L, raw, lds, p.debug, p.clamp_dc);
+    __syncthreads();
+    ZJ_SETPRIO(2, 2); // (off) let a tile's last phase, the one that frees the workgroup slot, go first
+    phase_color<C, HS, VS, OUT, GEN_WIDE, FAST>(p, t, tid, lds);
+}
+
+template <int HS, int VS, int OUT, int GEN, bool FAST, bool TS>
+// 2nd launch bound = waves per SIMD: 5 workgroups of 4 waves per CU need <= 96 VGPRs; LDS (at most 32.7 KB
 // per workgroup for 4:2:0) allows exactly 5.  Measured with tools/occupancy.py: 5 and 4 workgroups per CU
 // run the same, 3 cost 7 %, 2 cost 29 % -- the bound keeps the kernel on the flat part.
 __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), ZJ_WAVES_PER_SIMD) void zj_fused_kernel(const Params p)
 {
     using C = Cfg<HS, VS, OUT>;
-    // COMPACT: bits 0-1 = how phase 1 spreads the IDCT (0 one lane per block, 1 compaction, 3 work stealing),
-    //          bit 2    = transposed stores in phase 2
-    constexpr int IDCT_MODE = COMPACT & 3;
-    constexpr bool TS = (COMPACT & 4) != 0;
-    __shared__ __attribute__((aligned(16))) char lds_raw[TS ? C::LDS_BYTES_TS : (IDCT_MODE ? C::LDS_BYTES_COMPACT : C::LDS_BYTES)];
-    int16_t* lds = reinterpret_cast<int16_t*>(lds_raw);
-    ZJ_SETPRIO(1, 3); // issue the tile's loads ahead of other waves' arithmetic
+    __shared__ __attribute__((aligned(16))) char lds[GEN == GEN_PACKED ? C::LDS_PACKED : C::LDS_WIDE];
     const TileId t = decode_tile(p, (int)blockIdx.x);
     const int tid = (int)threadIdx.x;
-    const BlockLoc L = locate<C>(p, t, tid, lds);
+    if (GEN == GEN_WIDE) { tile_wide<C, HS, VS, OUT, FAST>(p, t, tid, lds); return; }
+    // luma enters arithmetic for the RGB family only; gray / YCbCr outputs keep its low byte (Q7)
+    constexpr bool NEED_Y16 = OUT == OUT_RGB || OUT == OUT_RGBA || OUT == OUT_RGB_CHW;
+    ZJ_SETPRIO(1, 3);
+    const BlockLoc L = locate<C, GEN_PACKED>(p, t, tid, lds);
     U4 raw[8];
-    load_block(L, raw, p.debug); // HBM loads in flight across the barrier below
+    load_block(L, raw, p.debug);
     ZJ_SETPRIO(1, 0);
-    if (IDCT_MODE == 3) {
-        const int32_t q0 = p.qt[64 * L.comp]; // the DC-only shortcut needs q[0] before the tables are staged
-        phase_setup<C, HS, VS>(p, tid, lds);
-        // the donor wave changes from tile to tile: a wave stays on its SIMD, so a fixed donor would relieve one SIMD only
-        const int donor = ZJ_STEAL_ROTATE ? (t.tile + t.strip + t.frame) % (C::NT / 64) : C::NT / 64 - 1;
-        const StealState st = steal_stage<C>(L, raw, q0, tid, lds, p.clamp_dc, donor);
-        __syncthreads();
-        steal_idct<C>(L, raw, st, tid, lds, donor);
-    } else if (IDCT_MODE) {
-        const int32_t q0 = p.qt[64 * L.comp]; // the DC-only shortcut needs q[0] before the tables are staged
-        phase_setup<C, HS, VS>(p, tid, lds);
-        classify_stage<C>(L, raw, q0, tid, lds, p.clamp_dc);
-        __syncthreads();
-        idct_queue<C>(tid, lds);
-    } else {
-        phase_setup<C, HS, VS>(p, tid, lds);
-        __syncthreads();
-        finish_block<C>(L, raw, lds, p.debug, p.clamp_dc);
-    }
+    phase_setup<C, HS, VS, GEN_PACKED>(p, tid, lds);
     __syncthreads();
-    ZJ_SETPRIO(2, 2); // (off) let a tile's last phase, the one that frees the workgroup slot, go first
+    finish_block<C, GEN_PACKED, NEED_Y16>(L, raw, lds, p.debug, p.clamp_dc);
+    __syncthreads();
+    if (NEED_Y16 && __builtin_amdgcn_readfirstlane((int)*lds_flag<C>(lds)) != 0) {
+        // a DC-only luma block of this tile decodes outside 0..255 (Q1: the scalar shortcut does not clamp): the byte
+        // staging cannot carry it, the whole tile is redone by the wide code (never seen on valid 8-bit JPEG data)
+        __syncthreads(); // everyone has read the flag before the wide layout overwrites it
+        tile_wide<C, HS, VS, OUT, FAST>(p, t, tid, lds);
+        return;
+    }
+    ZJ_SETPRIO(2, 2);
     if (TS) {
-        // each wave stages its 64 items of a round in LDS (in place), then stores them as contiguous pieces;
-        // LDS operations of one wave execute in order, so no barrier is needed between the two halves
+        // each wave stages its 64 items of a round in LDS, then stores them as contiguous pieces; LDS operations
+        // of one wave execute in order, so no barrier is needed between the halves or between rounds
         for (int round = 0; round * C::NT < C::NITEMS; round++) {
-            phase_color<C, HS, VS, OUT, FAST, true>(p, t, tid, lds, round);
+            ItemOut io;
+            phase_color<C, HS, VS, OUT, GEN_PACKED, FAST, true>(p, t, tid, lds, round, &io);
+            stage_item<C>(io, tid, lds, round);
+            ZJ_WAVE_FENCE();
             color_copyout<C, OUT>(p, t, tid, lds, round);
+            ZJ_WAVE_FENCE();
         }
     } else {
-        phase_color<C, HS, VS, OUT, FAST>(p, t, tid, lds);
+        phase_color<C, HS, VS, OUT, GEN_PACKED, FAST>(p, t, tid, lds);
     }
-}
-
-// Persistent form of the same pipeline: a fixed grid of workgroups, each walking many tiles.  The next
-// tile's coefficient loads are issued as soon as the IDCT has consumed the current ones, so they are in
-// flight during the whole colour phase (HBM latency hidden, smoother load/store mix); tables are staged
-// once per workgroup instead of once per tile.
-template <int HS, int VS, int OUT>
-__global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), 4) void zj_fused_persistent_kernel(const Params p)
-{
-    using C = Cfg<HS, VS, OUT>;
-    __shared__ __attribute__((aligned(16))) char lds_raw[C::LDS_BYTES];
-    int16_t* lds = reinterpret_cast<int16_t*>(lds_raw);
-    const int tid = (int)threadIdx.x;
-    const TileWalk w = persistent_walk(p, (int)blockIdx.x, (int)gridDim.x);
-    int id = w.first;
-    if (id >= w.last) return;
-    TileId t = tile_from_id(p, id);
-    BlockLoc L = locate<C>(p, t, tid, lds);
-    U4 raw[8];
-    load_block(L, raw);
-    phase_setup<C, HS, VS>(p, tid, lds);
-    __syncthreads();
-    for (;;) {
-        finish_block<C>(L, raw, lds, p.debug, p.clamp_dc);
-        const int nid = id + w.step;
-        const bool more = nid < w.last;
-        TileId tn = t;
-        if (more) { // prefetch: in flight across the colour phase below
-            tn = tile_from_id(p, nid);
-            L = locate<C>(p, tn, tid, lds);
-            load_block(L, raw);
-        }
-        __syncthreads();
-        phase_color<C, HS, VS, OUT, true>(p, t, tid, lds);
-        if (!more) break;
-        __syncthreads(); // the staging area is rewritten by the next IDCT
-        t = tn;
-        id = nid;
-    }
-}
-
-static int g_persistent_wgs = 0;
-void set_persistent_grid(int wgs) { g_persistent_wgs = wgs; }
-static int persistent_grid()
-{
-    if (g_persistent_wgs > 0) return g_persistent_wgs;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return cus * 4;
 }
 
 // occupancy probe of tools/occupancy.py: extra dynamic LDS per workgroup (never set by the product)
@@ -139,45 +97,40 @@ void set_pad_lds(int bytes) { g_pad_lds = bytes < 0 ? 0 : bytes; }
 int fused_occupancy_420_rgb(int pad_lds)
 {
     int n = -1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zj_fused_kernel<2, 2, OUT_RGB, 0, true>, Cfg<2, 2, OUT_RGB>::NT, (size_t)pad_lds) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zj_fused_kernel<2, 2, OUT_RGB, GEN_PACKED, true, true>, Cfg<2, 2, OUT_RGB>::NT, (size_t)pad_lds) != hipSuccess) return -1;
     return n;
 }
 
+// variant: 0 = packed generation (staged stores where they apply), 1 = wide generation (round 1), 2 = packed with
+// direct stores.  All are bit-exact; 1 and 2 exist for A/B measurements and as the parity cross-check.
+static void pick(int variant, int out, bool fast, bool ts_ok, int& gen, bool& ts)
+{
+    gen = variant == 1 ? GEN_WIDE : GEN_PACKED;
+    ts = gen == GEN_PACKED && variant == 0 && fast && (out == OUT_RGB || out == OUT_YCBCR) && ts_ok;
+}
+
 template <int HS, int VS, int OUT>
-static hipError_t launch_fused_t(const Params& p, int compact, int fast, hipStream_t s)
+static hipError_t launch_fused_t(const Params& p, int variant, int fast, hipStream_t s)
 {
     using C = Cfg<HS, VS, OUT>;
     if (p.total_tiles <= 0) return hipSuccess;
     const dim3 grid((unsigned)p.total_tiles), block(C::NT);
-    if (OUT == OUT_RGBA || OUT == OUT_RGB_CHW) { // extensions: the one-pass kernel only
-        if (fast) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 0, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 0, false>), grid, block, 0, s, p);
-        return hipGetLastError();
-    }
-    if (g_pad_lds > 0 && fast && compact == 0) {
-        hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 0, true>), grid, block, (size_t)g_pad_lds, s, p);
-        return hipGetLastError();
-    }
-    if (!fast) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 0, false>), grid, block, 0, s, p); // any width
-    else if (compact == 2) {
-        int wgs = persistent_grid();
-        if (wgs > p.total_tiles) wgs = p.total_tiles;
-        hipLaunchKernelGGL((zj_fused_persistent_kernel<HS, VS, OUT>), dim3((unsigned)wgs), block, 0, s, p);
-    } else if ((compact == 4 || compact == 7) && ts_eligible<C>(p, OUT, true)) {
-        // transposed stores exist for the 3-byte interleaved outputs only; TSC folds to 0 elsewhere (never reached)
-        constexpr int TSC = (OUT == OUT_RGB || OUT == OUT_YCBCR) ? 4 : 0;
-        if (compact == 4) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, TSC, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, (TSC | 3), true>), grid, block, 0, s, p);
-    } else if (compact == 3 || compact == 7) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 3, true>), grid, block, 0, s, p);
-    else if (compact == 4) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 0, true>), grid, block, 0, s, p);
-    else if (compact) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 1, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, 0, true>), grid, block, 0, s, p);
+    int gen; bool ts;
+    pick(variant, OUT, fast != 0, ts_eligible<C>(p, OUT, fast != 0), gen, ts);
+    const size_t dyn = (size_t)g_pad_lds;
+    constexpr bool TSC = C::TSCAP; // staged stores exist for the 3-byte interleaved outputs only
+    if (gen == GEN_WIDE) {
+        if (fast) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, GEN_WIDE, true, false>), grid, block, dyn, s, p);
+        else hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, GEN_WIDE, false, false>), grid, block, dyn, s, p);
+    } else if (!fast) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, GEN_PACKED, false, false>), grid, block, dyn, s, p);
+    else if (ts && TSC) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, GEN_PACKED, true, TSC>), grid, block, dyn, s, p);
+    else hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, GEN_PACKED, true, false>), grid, block, dyn, s, p);
     return hipGetLastError();
 }
 
-hipError_t launch_fused(int hs, int vs, int out, int compact, int fast, const Params& p, hipStream_t s)
+hipError_t launch_fused(int hs, int vs, int out, int variant, int fast, const Params& p, hipStream_t s)
 {
-#define ZJ_CASE(H, V, O) if (hs == H && vs == V && out == O) return launch_fused_t<H, V, O>(p, compact, fast, s);
+#define ZJ_CASE(H, V, O) if (hs == H && vs == V && out == O) return launch_fused_t<H, V, O>(p, variant, fast, s);
     ZJ_CASE(1, 1, OUT_RGB) ZJ_CASE(1, 1, OUT_GRAY) ZJ_CASE(1, 1, OUT_YCBCR)
     ZJ_CASE(2, 1, OUT_RGB) ZJ_CASE(2, 1, OUT_GRAY) ZJ_CASE(2, 1, OUT_YCBCR)
     ZJ_CASE(1, 2, OUT_RGB) ZJ_CASE(1, 2, OUT_GRAY) ZJ_CASE(1, 2, OUT_YCBCR)
@@ -188,15 +141,23 @@ hipError_t launch_fused(int hs, int vs, int out, int compact, int fast, const Pa
     return hipErrorInvalidValue;
 }
 
-const char* fused_kernel_name(int hs, int vs, int out, int variant, int fast)
+template <int HS, int VS, int OUT>
+static bool ts_ok_t(const Params& p, int fast) { return ts_eligible<Cfg<HS, VS, OUT>>(p, OUT, fast != 0); }
+
+const char* fused_kernel_name(int hs, int vs, int out, int variant, int fast, const Params& p)
 {
     // the demangled name rocprofv3 prints for the instantiation launch_fused() picks
-    static char buf[8][96];
+    static char buf[8][112];
     static int slot = 0;
     char* b = buf[slot++ & 7];
-    if (out == OUT_RGBA || out == OUT_RGB_CHW) variant = 0;
-    if (fast && variant == 2) snprintf(b, 96, "void zj::zj_fused_persistent_kernel<%d, %d, %d>(zj::Params)", hs, vs, out);
-    else snprintf(b, 96, "void zj::zj_fused_kernel<%d, %d, %d, %d, %s>(zj::Params)", hs, vs, out, (fast && variant != 2) ? variant : 0, fast ? "true" : "false");
+    bool ok = false;
+#define ZJ_CASE(H, V, O) if (hs == H && vs == V && out == O) ok = ts_ok_t<H, V, O>(p, fast);
+    ZJ_CASE(1, 1, OUT_RGB) ZJ_CASE(2, 1, OUT_RGB) ZJ_CASE(1, 2, OUT_RGB) ZJ_CASE(2, 2, OUT_RGB)
+    ZJ_CASE(1, 1, OUT_YCBCR) ZJ_CASE(2, 1, OUT_YCBCR) ZJ_CASE(1, 2, OUT_YCBCR) ZJ_CASE(2, 2, OUT_YCBCR)
+#undef ZJ_CASE
+    int gen; bool ts;
+    pick(variant, out, fast != 0, ok, gen, ts);
+    snprintf(b, 112, "void zj::zj_fused_kernel<%d, %d, %d, %d, %s, %s>(zj::Params)", hs, vs, out, gen, fast ? "true" : "false", ts ? "true" : "false");
     return b;
 }
 
@@ -204,8 +165,8 @@ const char* fused_kernel_name(int hs, int vs, int out, int variant, int fast)
 // strip-level kernels (fn-pointer compatible API; not the hot path)
 // ------------------------------------------------------------------------------------------------
 // dequantize_and_idct_int (src/idct/scalar.rs:19-282): one lane per block.  `out` pre-zeroed.
-__global__ __launch_bounds__(64) void zj_idct_strip_kernel(const int16_t* __restrict__ coeff,
-                                                           const int32_t* __restrict__ qt,
+struct Tab1 { uint32_t t[TAB_DW]; }; // one component's table (build_table), by value like Params::tab
+__global__ __launch_bounds__(64) void zj_idct_strip_kernel(const int16_t* __restrict__ coeff, const Tab1 tab,
                                                            int16_t* __restrict__ out, long long nblocks,
                                                            long long chunks, long long bpc, long long stride)
 {
@@ -221,11 +182,11 @@ __global__ __launch_bounds__(64) void zj_idct_strip_kernel(const int16_t* __rest
 #pragma unroll
     for (int i = 1; i < 32; i++) any |= cw[i];
     if (any == 0) { // DC-only shortcut (scalar.rs:45-74)
-        const uint32_t v = dc_only_value(cw[0], qt[0]);
+        const uint32_t v = dc_only_value(cw[0], (int32_t)(tab.t[0] & 0xffffu));
 #pragma unroll
         for (int i = 0; i < 8; i++) { px[i].x = v; px[i].y = v; px[i].z = v; px[i].w = v; }
     } else {
-        idct_block(raw, qt, px);
+        idct_block(raw, reinterpret_cast<const uint16_t*>(tab.t), px);
     }
     int16_t* dst = out + c * chunks + k * 8; // pos = x = 8k (scalar.rs:277-278)
 #pragma unroll
@@ -284,11 +245,13 @@ __global__ void zj_rgb16_kernel(const int16_t* __restrict__ ycc /* y[16] cb[16] 
     out[3 * i] = (uint8_t)sat_pk_u8(c.r); out[3 * i + 1] = (uint8_t)sat_pk_u8(c.g); out[3 * i + 2] = (uint8_t)sat_pk_u8(c.b);
 }
 
-hipError_t launch_idct_strip(const int16_t* coeff, const int32_t* qt, int16_t* out, long long nblocks,
+hipError_t launch_idct_strip(const int16_t* coeff, const int32_t qt[64], int16_t* out, long long nblocks,
                              long long chunks, long long bpc, long long stride, hipStream_t s)
 {
     if (nblocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(zj_idct_strip_kernel, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, s, coeff, qt,
+    Tab1 tab;
+    build_table(qt, tab.t);
+    hipLaunchKernelGGL(zj_idct_strip_kernel, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, s, coeff, tab,
                        out, nblocks, chunks, bpc, stride);
     return hipGetLastError();
 }

@@ -8,203 +8,48 @@
 
 namespace zj {
 
-// ---- 1-D pass variants (all compute the same integers mod 2^32) -------------------------------
-// V0: odd part as direct 4x4 matrix, 24-bit mul/mad (the shipped form)
-// V1: stb butterfly (9 muls + adds) with 24-bit mul/mad -- exact only when sums fit 24 bits (pass 2)
-// V2: stb butterfly with full 32-bit multiplies (v_mul_lo_u32), exact everywhere
-template <int V>
-__device__ __forceinline__ void lab_1d(const int32_t s[8], const int32_t bias, int32_t o[8])
+// ---- the block transforms in isolation -------------------------------------------------------------
+// MODE 0: idct_block (wide: 24-bit multiply-adds, exact for every input; round 1's transform)
+// MODE 1: classify_block + idct_block_packed (v_dot2_i32_i16 on 16-bit pairs), what a full block costs in round 2
+// MODE 2: idct_block_packed alone
+struct LabTab { uint32_t t[3 * TAB_DW]; };
+template <int MODE>
+__global__ __launch_bounds__(256) void lab_idct(const LabTab tabs, int* out, int iters)
 {
-    if (V == 0) { idct_1d(s, bias, o); return; }
-    if (V == 3) { // direct matrix with the multiply-add chains pinned (no re-association), 3-op even head
-        auto K = [](int32_t& x) { asm volatile("" : "+v"(x)); };
-        int32_t t3 = mul24(s[2], 2217 + 3135); K(t3); t3 = mad24(s[6], 2217, t3);
-        int32_t t2 = mul24(s[2], 2217); K(t2); t2 = mad24(s[6], 2217 - 7567, t2);
-        int32_t A = wadd(wshl(s[0], 12), bias); K(A);
-        const int32_t t0 = mad24(s[4], 4096, A), t1 = mad24(s[4], -4096, A);
-        const int32_t x0 = wadd(t0, t3), x3 = wsub(t0, t3), x1 = wadd(t1, t2), x2 = wsub(t1, t2);
-        const int32_t a = s[7], b = s[5], c = s[3], d = s[1];
-        int32_t u3 = mul24(d, 5683); K(u3); u3 = mad24(a, 1131, u3); K(u3); u3 = mad24(b, 3219, u3); K(u3); u3 = mad24(c, 4816, u3);
-        int32_t u2 = mul24(c, -1129); K(u2); u2 = mad24(b, -5681, u2); K(u2); u2 = mad24(a, -3218, u2); K(u2); u2 = mad24(d, 4816, u2);
-        int32_t u1 = mul24(b, 1132); K(u1); u1 = mad24(c, -5681, u1); K(u1); u1 = mad24(d, 3219, u1); K(u1); u1 = mad24(a, 4816, u1);
-        int32_t u0 = mul24(a, -5680); K(u0); u0 = mad24(d, 1131, u0); K(u0); u0 = mad24(c, -3218, u0); K(u0); u0 = mad24(b, 4816, u0);
-        o[0] = wadd(x0, u3); o[7] = wsub(x0, u3);
-        o[1] = wadd(x1, u2); o[6] = wsub(x1, u2);
-        o[2] = wadd(x2, u1); o[5] = wsub(x2, u1);
-        o[3] = wadd(x3, u0); o[4] = wsub(x3, u0);
-        return;
-    }
-    auto M = [](int32_t a, int32_t k) -> int32_t { return V == 1 ? mul24(a, k) : (int32_t)((uint32_t)a * (uint32_t)k); };
-    const int32_t p1e = M(wadd(s[2], s[6]), 2217);
-    const int32_t t2 = wadd(p1e, M(s[6], -7567));
-    const int32_t t3 = wadd(p1e, M(s[2], 3135));
-    const int32_t t0 = wadd(wshl(wadd(s[0], s[4]), 12), bias);
-    const int32_t t1 = wadd(wshl(wsub(s[0], s[4]), 12), bias);
-    const int32_t x0 = wadd(t0, t3), x3 = wsub(t0, t3), x1 = wadd(t1, t2), x2 = wsub(t1, t2);
-    int32_t a = s[7], b = s[5], c = s[3], d = s[1];
-    const int32_t p3 = wadd(a, c), p4 = wadd(b, d), p1 = wadd(a, d), p2 = wadd(b, c);
-    const int32_t p5 = M(wadd(p3, p4), 4816);
-    const int32_t P1 = wadd(p5, M(p1, -3685)), P2 = wadd(p5, M(p2, -10497));
-    const int32_t P3 = M(p3, -8034), P4 = M(p4, -1597);
-    const int32_t u3 = wadd(M(d, 6149), wadd(P1, P4));
-    const int32_t u2 = wadd(M(c, 12586), wadd(P2, P3));
-    const int32_t u1 = wadd(M(b, 8410), wadd(P2, P4));
-    const int32_t u0 = wadd(M(a, 1223), wadd(P1, P3));
-    o[0] = wadd(x0, u3); o[7] = wsub(x0, u3);
-    o[1] = wadd(x1, u2); o[6] = wsub(x1, u2);
-    o[2] = wadd(x2, u1); o[5] = wsub(x2, u1);
-    o[3] = wadd(x3, u0); o[4] = wsub(x3, u0);
-}
-
-// ---- "grouped" formulation: the multiply half of G transforms, then their add/shift half, separated by
-// scheduling barriers, so that simple VOP2 instructions (add/sub/shift: ~2.3 cycles in pure runs, ~3.5-4 when
-// mixed with multiplies, profiles/r01_ubench_valu_issue_cost.txt) sit next to each other
-struct LabHalf { int32_t t0, t1, t2, t3, u0, u1, u2, u3; };
-__device__ __forceinline__ LabHalf lab_1d_mul(const int32_t s[8], const int32_t bias)
-{
-    auto K = [](int32_t& x) { asm volatile("" : "+v"(x)); };
-    LabHalf h;
-    h.t3 = mul24(s[2], 2217 + 3135); K(h.t3); h.t3 = mad24(s[6], 2217, h.t3);
-    h.t2 = mul24(s[2], 2217); K(h.t2); h.t2 = mad24(s[6], 2217 - 7567, h.t2);
-    int32_t A = wadd(wshl(s[0], 12), bias); K(A);
-    h.t0 = wadd(wshl(s[4], 12), A); K(h.t0);
-    h.t1 = mad24(s[4], -4096, A);
-    const int32_t a = s[7], b = s[5], c = s[3], d = s[1];
-    h.u3 = mul24(d, 5683); K(h.u3); h.u3 = mad24(a, 1131, h.u3); K(h.u3); h.u3 = mad24(b, 3219, h.u3); K(h.u3); h.u3 = mad24(c, 4816, h.u3);
-    h.u2 = mul24(c, -1129); K(h.u2); h.u2 = mad24(b, -5681, h.u2); K(h.u2); h.u2 = mad24(a, -3218, h.u2); K(h.u2); h.u2 = mad24(d, 4816, h.u2);
-    h.u1 = mul24(b, 1132); K(h.u1); h.u1 = mad24(c, -5681, h.u1); K(h.u1); h.u1 = mad24(d, 3219, h.u1); K(h.u1); h.u1 = mad24(a, 4816, h.u1);
-    h.u0 = mul24(a, -5680); K(h.u0); h.u0 = mad24(d, 1131, h.u0); K(h.u0); h.u0 = mad24(c, -3218, h.u0); K(h.u0); h.u0 = mad24(b, 4816, h.u0);
-    return h;
-}
-__device__ __forceinline__ void lab_1d_add(const LabHalf& h, int32_t o[8])
-{
-    const int32_t x0 = wadd(h.t0, h.t3), x3 = wsub(h.t0, h.t3), x1 = wadd(h.t1, h.t2), x2 = wsub(h.t1, h.t2);
-    o[0] = wadd(x0, h.u3); o[7] = wsub(x0, h.u3);
-    o[1] = wadd(x1, h.u2); o[6] = wsub(x1, h.u2);
-    o[2] = wadd(x2, h.u1); o[5] = wsub(x2, h.u1);
-    o[3] = wadd(x3, h.u0); o[4] = wsub(x3, h.u0);
-}
-template <int G>
-__device__ __forceinline__ void lab_block_grouped(const U4 raw[8], const int32_t* qt, U4 out[8])
-{
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(raw);
-    int32_t tmp[64];
-#pragma unroll
-    for (int c0 = 0; c0 < 8; c0 += G) {
-        LabHalf h[G];
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-            const int col = c0 + g;
-            int32_t s[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const uint32_t pair = w[k * 4 + (col >> 1)];
-                const int32_t cf = (col & 1) ? hi16s(pair) : lo16s(pair);
-                s[k] = mul24(cf, qt[k * 8 + col]);
-            }
-            h[g] = lab_1d_mul(s, 512);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-            int32_t o[8];
-            lab_1d_add(h[g], o);
-#pragma unroll
-            for (int k = 0; k < 8; k++) tmp[k * 8 + c0 + g] = o[k] >> 10;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    constexpr int32_t bias2 = 512 + 65536 + (128 << 17);
-    uint32_t* ow = reinterpret_cast<uint32_t*>(out);
-#pragma unroll
-    for (int r0 = 0; r0 < 8; r0 += G) {
-        LabHalf h[G];
-#pragma unroll
-        for (int g = 0; g < G; g++) h[g] = lab_1d_mul(&tmp[(r0 + g) * 8], bias2);
-        __builtin_amdgcn_sched_barrier(0);
-        int32_t o[G][8];
-#pragma unroll
-        for (int g = 0; g < G; g++) lab_1d_add(h[g], o[g]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < G; g++)
-#pragma unroll
-            for (int k = 0; k < 8; k += 2) {
-                const uint32_t hi = perm((uint32_t)o[g][k + 1], (uint32_t)o[g][k], 0x07060302u);
-                const s16x2 z = {0, 0}, m = {255, 255};
-                ow[(r0 + g) * 4 + (k >> 1)] = as_u32(pk_min(pk_max(sar(as_u16x2(hi), 1), z), m));
-            }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// FIN: 0 = med3 + lshl_or (shipped), 1 = pack first then packed clamp
-template <int V1, int V2, int FIN>
-__device__ __forceinline__ void lab_block(const U4 raw[8], const int32_t* qt, U4 out[8])
-{
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(raw);
-    int32_t tmp[64];
-#pragma unroll
-    for (int col = 0; col < 8; col++) {
-        int32_t s[8], o[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint32_t pair = w[k * 4 + (col >> 1)];
-            const int32_t cf = (col & 1) ? hi16s(pair) : lo16s(pair);
-            s[k] = mul24(cf, qt[k * 8 + col]);
-        }
-        lab_1d<V1>(s, 512, o);
-#pragma unroll
-        for (int k = 0; k < 8; k++) tmp[k * 8 + col] = o[k] >> 10;
-    }
-    constexpr int32_t bias2 = 512 + 65536 + (128 << 17);
-    uint32_t* ow = reinterpret_cast<uint32_t*>(out);
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        int32_t o[8];
-        lab_1d<V2>(&tmp[r * 8], bias2, o);
-#pragma unroll
-        for (int k = 0; k < 8; k += 2) {
-            int32_t p0 = o[k] >> 17, p1 = o[k + 1] >> 17;
-            if (FIN == 0) {
-                p0 = p0 < 0 ? 0 : (p0 > 255 ? 255 : p0);
-                p1 = p1 < 0 ? 0 : (p1 > 255 ? 255 : p1);
-                ow[r * 4 + (k >> 1)] = (uint32_t)p0 | ((uint32_t)p1 << 16);
-            } else {
-                // (x >> 17) always fits 15 bits: pack, then clamp both lanes with packed min/max
-                const uint32_t pk = ((uint32_t)p0 & 0xffffu) | ((uint32_t)p1 << 16);
-                const s16x2 z = {0, 0}, m = {255, 255};
-                ow[r * 4 + (k >> 1)] = as_u32(pk_min(pk_max(as_s16x2(pk), z), m));
-            }
-        }
-    }
-}
-
-template <int V1, int V2, int FIN, int QSRC>
-__global__ __launch_bounds__(256) void lab_idct(const int32_t* __restrict__ qt_g, int* out, int iters)
-{
-    __shared__ int32_t qt_l[192];
-    if (threadIdx.x < 192) qt_l[threadIdx.x] = qt_g[threadIdx.x];
+    __shared__ uint32_t tab_l[3 * TAB_DW];
+    if (threadIdx.x < 3 * TAB_DW) tab_l[threadIdx.x] = tabs.t[threadIdx.x];
     __syncthreads();
-    const int32_t* qt = QSRC == 0 ? (const int32_t*)(qt_l + 64 * (threadIdx.x % 3)) : qt_g;
+    const uint32_t* tab = tab_l + TAB_DW * (threadIdx.x % 3);
     U4 raw[8];
     uint32_t seed = threadIdx.x * 2654435761u + blockIdx.x;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        seed = seed * 1664525u + 1013904223u; raw[i].x = seed & 0x003f003f;
-        seed = seed * 1664525u + 1013904223u; raw[i].y = seed & 0x001f001f;
-        seed = seed * 1664525u + 1013904223u; raw[i].z = seed & 0x000f000f;
-        seed = seed * 1664525u + 1013904223u; raw[i].w = seed & 0x00070007;
-    }
-    for (int it = 0; it < iters; it++) {
-        U4 px[8];
-        if (V1 >= 10) lab_block_grouped<(V1 >= 10 ? V1 - 10 : 1)>(raw, qt, px);
-        else if (FIN == 2) idct_block(raw, qt, px); // the shipped block function
-        else lab_block<(V1 >= 10 ? 0 : V1), V2, (FIN == 2 ? 1 : FIN)>(raw, qt, px);
-#pragma unroll
-        for (int i = 0; i < 8; i++) raw[i] = px[i]; // dependent chain: nothing can be hoisted
+        seed = seed * 1664525u + 1013904223u; raw[i].x = seed & 0x00070007;
+        seed = seed * 1664525u + 1013904223u; raw[i].y = seed & 0x00030003;
+        seed = seed * 1664525u + 1013904223u; raw[i].z = seed & 0x00010001;
+        seed = seed * 1664525u + 1013904223u; raw[i].w = seed & 0x00010001;
     }
     uint32_t acc = 0;
+    for (int it = 0; it < iters; it++) {
+        if (MODE == 0) {
+            U4 px[8];
+            idct_block(raw, reinterpret_cast<const uint16_t*>(tab), px);
+#pragma unroll
+            for (int i = 0; i < 8; i++) { raw[i].x = px[i].x & 0x00070007; raw[i].y = px[i].y & 0x00030003; raw[i].z = px[i].z & 0x00010001; raw[i].w = px[i].w & 0x00010001; }
+        } else {
+            uint32_t b[16];
+            const int cls = MODE == 1 ? classify_block(reinterpret_cast<const uint32_t*>(raw), tab + 32) : 1;
+            if (cls == 1) idct_block_packed(raw, tab, b);
+            else {
+#pragma unroll
+                for (int i = 0; i < 16; i++) b[i] = (uint32_t)cls;
+            }
+            // dependent chain: the next block's coefficients come from this block's pixels (kept small: guard passes)
+#pragma unroll
+            for (int i = 0; i < 8; i++) { raw[i].x = b[2 * i] & 0x00070007; raw[i].y = b[2 * i + 1] & 0x00030003; raw[i].z = (b[2 * i] >> 8) & 0x00010001; raw[i].w = (b[2 * i + 1] >> 8) & 0x00010001; }
+        }
+        acc += raw[0].x;
+    }
 #pragma unroll
     for (int i = 0; i < 8; i++) acc ^= raw[i].x ^ raw[i].y ^ raw[i].z ^ raw[i].w;
     if (acc == (uint32_t)iters * 0x00010001u) out[blockIdx.x * blockDim.x + threadIdx.x] = (int)acc;
@@ -281,24 +126,11 @@ __global__ __launch_bounds__(256) void lab_mem(const U4* __restrict__ in, U4* __
     }
 }
 
-typedef void (*lab_fn)(const int32_t*, int*, int);
+typedef void (*lab_fn)(const LabTab, int*, int);
 static const struct { const char* name; lab_fn fn; } LAB[] = {
-    {"idct direct/direct   med3  qt=LDS (shipped)", lab_idct<0, 0, 0, 0>},
-    {"idct direct/direct   med3  qt=SGPR", lab_idct<0, 0, 0, 1>},
-    {"idct direct/stb24    med3  qt=LDS", lab_idct<0, 1, 0, 0>},
-    {"idct stb32/stb24     med3  qt=LDS", lab_idct<2, 1, 0, 0>},
-    {"idct stb32/stb32     med3  qt=LDS", lab_idct<2, 2, 0, 0>},
-    {"idct direct/direct   pkclamp qt=LDS", lab_idct<0, 0, 1, 0>},
-    {"idct direct/stb24    pkclamp qt=LDS", lab_idct<0, 1, 1, 0>},
-    {"idct pinned/pinned   med3  qt=LDS", lab_idct<3, 3, 0, 0>},
-    {"idct pinned/pinned   pkclamp qt=LDS", lab_idct<3, 3, 1, 0>},
-    {"idct pinned/stb24    pkclamp qt=LDS", lab_idct<3, 1, 1, 0>},
-    {"idct stb32/stb24     pkclamp qt=LDS", lab_idct<2, 1, 1, 0>},
-    {"idct pinned/pinned   pkclamp qt=SGPR", lab_idct<3, 3, 1, 1>},
-    {"idct_block as shipped (perm epilogue)  qt=LDS", lab_idct<3, 3, 2, 0>},
-    {"idct grouped x1 (mul half | add half) qt=LDS", lab_idct<11, 3, 1, 0>},
-    {"idct grouped x2                       qt=LDS", lab_idct<12, 3, 1, 0>},
-    {"idct grouped x4                       qt=LDS", lab_idct<14, 3, 1, 0>},
+    {"idct wide   (24-bit multiply-adds, round 1)", lab_idct<0>},
+    {"idct packed (v_dot2_i32_i16) incl. classify", lab_idct<1>},
+    {"idct packed (v_dot2_i32_i16) transform only", lab_idct<2>},
 };
 // tile-shaped copy: each workgroup writes 32 row segments of S bytes (row pitch 12288 B = 4096 px RGB)
 // and reads the same amount contiguously (RDT = 0) or as 4+2+2 block-row segments like the decoder (RDT = 1)
@@ -460,11 +292,13 @@ hipError_t launch_labmem(int i, const void* in, void* out, long long bytes, hipS
 
 int lab_count() { return (int)(sizeof(LAB) / sizeof(LAB[0])) + 1; }
 const char* lab_name(int i) { return i < lab_count() - 1 ? LAB[i].name : "colour 16px/lane (ycc->rgb + pack, EO)"; }
-hipError_t launch_lab(int i, const int32_t* qt, int* out, int blocks, int iters, hipStream_t s)
+hipError_t launch_lab(int i, const int32_t qt[3][64], int* out, int blocks, int iters, hipStream_t s)
 {
     if (i < 0 || i >= lab_count()) return hipErrorInvalidValue;
+    LabTab tabs;
+    for (int c = 0; c < 3; c++) build_table(qt[c], tabs.t + TAB_DW * c);
     if (i == lab_count() - 1) hipLaunchKernelGGL(lab_color<0>, dim3(blocks), dim3(256), 0, s, out, iters);
-    else hipLaunchKernelGGL(LAB[i].fn, dim3(blocks), dim3(256), 0, s, qt, out, iters);
+    else hipLaunchKernelGGL(LAB[i].fn, dim3(blocks), dim3(256), 0, s, tabs, out, iters);
     return hipGetLastError();
 }
 

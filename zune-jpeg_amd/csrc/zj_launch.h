@@ -5,12 +5,11 @@
 #include "zj_device.h"
 
 namespace zj {
-hipError_t launch_fused(int hs, int vs, int out, int compact, int fast, const Params& p, hipStream_t s);
+hipError_t launch_fused(int hs, int vs, int out, int variant, int fast, const Params& p, hipStream_t s);
 void set_pad_lds(int bytes);
 int fused_occupancy_420_rgb(int pad_lds);
-const char* fused_kernel_name(int hs, int vs, int out, int variant, int fast);
-void set_persistent_grid(int wgs);
-hipError_t launch_idct_strip(const int16_t* coeff, const int32_t* qt, int16_t* out, long long nblocks,
+const char* fused_kernel_name(int hs, int vs, int out, int variant, int fast, const Params& p);
+hipError_t launch_idct_strip(const int16_t* coeff, const int32_t qt[64], int16_t* out, long long nblocks,
                              long long chunks, long long bpc, long long stride, hipStream_t s);
 hipError_t launch_upsample_h(const int16_t* in, long long n, int16_t* out, long long out_len, long long m, hipStream_t s);
 hipError_t launch_upsample_v(const int16_t* in, long long stride, int16_t* out, long long out_len, hipStream_t s);
@@ -23,6 +22,6 @@ const char* labmem_name(int i);
 hipError_t launch_labmem(int i, const void* in, void* out, long long bytes, hipStream_t s);
 int lab_count();
 const char* lab_name(int i);
-hipError_t launch_lab(int i, const int32_t* qt, int* out, int blocks, int iters, hipStream_t s);
+hipError_t launch_lab(int i, const int32_t qt[3][64], int* out, int blocks, int iters, hipStream_t s);
 hipError_t launch_ub_clock(unsigned long long* out, int blocks, int iters, hipStream_t s);
 } // namespace zj

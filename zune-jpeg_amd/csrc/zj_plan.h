@@ -133,10 +133,12 @@ inline int uncovered_ranges(const zj_frame_desc* d, const Plan& pl, size_t off[3
 }
 
 inline void fill_params(const zj_frame_desc* d, const Plan& pl, size_t nframes, const int16_t* y,
-                        const int16_t* cb, const int16_t* cr, uint8_t* out, const int32_t* d_qt,
-                        int zero_fill, Params& p)
+                        const int16_t* cb, const int16_t* cr, uint8_t* out, int zero_fill, Params& p)
 {
-    p.y = y; p.cb = cb; p.cr = cr; p.out = out; p.qt = d_qt;
+    p.y = y; p.cb = cb; p.cr = cr; p.out = out;
+    // the tables travel in the kernel arguments (no device copy to order against other streams); the reference
+    // snapshots them per component at SOF time (headers.rs:327), d->qt is that snapshot
+    for (int c = 0; c < 3; c++) build_table(d->qt[c], p.tab + TAB_DW * c);
     p.y_frame_stride = (long long)pl.y_len;
     p.c_frame_stride = (long long)pl.c_len;
     p.out_frame_stride = (long long)pl.out_len;

@@ -67,6 +67,16 @@ namespace zj {
 #define I_MAX(r) "v_max_i32_e32 " #r ", %9, " #r "\n"
 #define I_LSHL(r) "v_lshlrev_b32_e32 " #r ", 3, " #r "\n"
 #define I_AND(r) "v_and_b32_e32 " #r ", %9, " #r "\n"
+// round 2: the packed IDCT's instructions
+#define I_DOT2C(r) "v_dot2c_i32_i16_e32 " #r ", 0x08a914e8, %9\n"
+#define I_DOT2CS(r) "v_dot2c_i32_i16_e32 " #r ", %8, %9\n"
+#define I_DOT2(r) "v_dot2_i32_i16 " #r ", %9, %8, " #r "\n"
+#define I_DOT2Z(r) "v_dot2_i32_i16 " #r ", " #r ", %8, 0\n"
+#define I_SAD16(r) "v_sad_u16 " #r ", %9, %8, " #r "\n"
+#define I_ASHR_SDWA(r) "v_ashrrev_i32_sdwa " #r ", %8, %9 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n"
+#define I_ASHRS(r) "v_ashrrev_i32_e32 " #r ", %8, " #r "\n"
+#define I_SATPK_SDWA(r) "v_sat_pk_u8_i16_sdwa " #r ", %9 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n"
+#define I_MIX_DOT(r) "v_dot2c_i32_i16_e32 " #r ", 0x08a914e8, %9\n v_add_u32_e32 " #r ", %9, " #r "\n"
 
 UB_KERNEL(ub_add, I_ADD)
 UB_KERNEL(ub_add64, I_ADD64)
@@ -108,6 +118,15 @@ UB_KERNEL(ub_mix3, I_MIX3)
 UB_KERNEL(ub_max, I_MAX)
 UB_KERNEL(ub_lshl, I_LSHL)
 UB_KERNEL(ub_and, I_AND)
+UB_KERNEL(ub_dot2c, I_DOT2C)
+UB_KERNEL(ub_dot2cs, I_DOT2CS)
+UB_KERNEL(ub_dot2, I_DOT2)
+UB_KERNEL(ub_dot2z, I_DOT2Z)
+UB_KERNEL(ub_sad16, I_SAD16)
+UB_KERNEL(ub_ashr_sdwa, I_ASHR_SDWA)
+UB_KERNEL(ub_ashrs, I_ASHRS)
+UB_KERNEL(ub_satpk_sdwa, I_SATPK_SDWA)
+UB_KERNEL(ub_mix_dot, I_MIX_DOT)
 
 #define UB_KERNEL_BODY(NAME, BODY)                                                                     \
     __global__ __launch_bounds__(256) void NAME(int* out, int iters, int seed)                         \
@@ -158,6 +177,11 @@ static const struct { const char* name; ub_fn fn; } UB[] = {
     {"v_pk_add_u16", ub_pkadd}, {"v_pk_sub_i16", ub_pksub}, {"v_pk_mul_lo_u16", ub_pkmul}, {"v_pk_mad_u16", ub_pkmad},
     {"v_pk_ashrrev_i16", ub_pkashr}, {"v_pk_max_i16", ub_pkmax}, {"v_pk_min_i16", ub_pkmin},
     {"v_max_i32_e32", ub_max}, {"v_lshlrev_b32_e32", ub_lshl}, {"v_and_b32_e32", ub_and},
+    {"v_dot2c_i32_i16_e32 v,lit,v", ub_dot2c}, {"v_dot2c_i32_i16_e32 v,s,v", ub_dot2cs}, {"v_dot2_i32_i16 v,v,s,v", ub_dot2},
+    {"v_dot2_i32_i16 v,v,s,0", ub_dot2z}, {"v_sad_u16 v,v,s,v", ub_sad16},
+    {"v_ashrrev_i32_sdwa (word_1, preserve)", ub_ashr_sdwa}, {"v_ashrrev_i32_e32 v,s,v", ub_ashrs},
+    {"v_sat_pk_u8_i16_sdwa (word_1, preserve)", ub_satpk_sdwa},
+    {"PAIR dot2c ; add          (2 instr)", ub_mix_dot},
     {"PAIR mul24 ; add          (2 instr)", ub_mix1}, {"TRIPLE mad24 ; add ; ashr (3 instr)", ub_mix2}, {"PAIR add ; ashr            (2 instr)", ub_mix3},
     {"GROUPED 8 mad | 8 add | 8 ashr   (x3 instr)", ub_grp_mad_add_ashr},
     {"GROUPED 8 mad | 32 simple        (x5 instr)", ub_grp_mad_add2},

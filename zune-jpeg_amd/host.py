@@ -391,8 +391,8 @@ class Context:
         return ms.value / iters, each.value, (name.value or b"").decode()
 
     def set_variant(self, variant):
-        """Kernel variant: 0 = one pass per tile, 1 = DC-only compaction, 2 = persistent + prefetch, 3 = work stealing.
-        All are bit-exact."""
+        """Kernel variant: 0 = packed generation (dot2 IDCT under an exact guard, byte luma staging, staged stores;
+        the default), 1 = wide generation (round 1's kernel), 2 = packed with direct stores.  All are bit-exact."""
         _check(lib().zj_set_variant(self._h, int(variant)), "zj_set_variant", self._h)
 
     def set_pipeline(self, on):
