@@ -75,19 +75,31 @@ ZJ_DEV int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint
 ZJ_DEV int32_t mad24(int32_t a, int32_t b, int32_t c) { return wadd(mul24(a, b), c); }
 ZJ_DEV int32_t wshl(int32_t a, int s) { return (int32_t)((uint32_t)a << s); }
 
-// v_dot2_i32_i16 / v_dot2c_i32_i16: a.lo*b.lo + a.hi*b.hi + c, the halves read as signed 16-bit, the sum
-// wrapping mod 2^32 (no clamp) -- gfx950's counterpart of the pmaddwd the reference's AVX2 arm is built on
-ZJ_DEV int32_t dot2(uint32_t a, uint32_t b, int32_t c)
+// v_dot2_i32_i16: a.lo*b.lo + a.hi*b.hi + c, the halves read as signed 16-bit, the sum wrapping mod 2^32 (no
+// clamp) -- gfx950's counterpart of the pmaddwd the reference's AVX2 arm is built on.  `k` is a compile-time pair of
+// constants.  Written as the three-address VOP3P form in inline asm: left to itself the compiler picks the
+// two-address v_dot2c_i32_i16 and pays a v_mov for every accumulator that is used twice or starts at zero
+// (132 moves per block, a fifth of the transform).
+ZJ_DEV int32_t dot2(uint32_t a, uint32_t k, int32_t c)
 {
 #if defined(ZJ_EMU)
-    const int32_t al = (int16_t)(a & 0xffff), ah = (int16_t)(a >> 16), bl = (int16_t)(b & 0xffff), bh = (int16_t)(b >> 16);
+    const int32_t al = (int16_t)(a & 0xffff), ah = (int16_t)(a >> 16), bl = (int16_t)(k & 0xffff), bh = (int16_t)(k >> 16);
     return (int32_t)((uint32_t)(al * bl) + (uint32_t)(ah * bh) + (uint32_t)c);
 #else
-    typedef short v2s __attribute__((ext_vector_type(2)));
-    v2s x, y;
-    __builtin_memcpy(&x, &a, 4);
-    __builtin_memcpy(&y, &b, 4);
-    return __builtin_amdgcn_sdot2(x, y, c, false);
+    int32_t r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c));
+    return r;
+#endif
+}
+// the same with a zero accumulator (inline constant)
+ZJ_DEV int32_t dot2z(uint32_t a, uint32_t k)
+{
+#if defined(ZJ_EMU)
+    return dot2(a, k, 0);
+#else
+    int32_t r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "s"(k));
+    return r;
 #endif
 }
 // a packed pair of signed 16-bit constants (lo, hi)
@@ -177,7 +189,7 @@ ZJ_DEV int uniform(int v)
 #if defined(ZJ_EMU)
 #define ZJ_NO_IF_CONVERT() ((void)0)
 #else
-#define ZJ_NO_IF_CONVERT() asm volatile("" ::: "memory")
+#define ZJ_NO_IF_CONVERT() asm volatile("") // (no memory clobber: that would force register arrays into scratch)
 #endif
 #if defined(ZJ_EMU) || defined(ZJ_IDCT_NOBARRIER)
 #define ZJ_SCHED_BARRIER() ((void)0)
@@ -192,6 +204,12 @@ ZJ_DEV int uniform(int v)
 #define ZJ_COLOR_SB() __builtin_amdgcn_sched_barrier(0)
 #else
 #define ZJ_COLOR_SB() ((void)0)
+#endif
+// a use the compiler cannot move: everything the value depends on is issued before this point
+#if defined(ZJ_EMU)
+#define ZJ_USE(x) ((void)(x))
+#else
+#define ZJ_USE(x) asm volatile("" ::"v"(x))
 #endif
 // a compiler-level fence between the LDS writes and reads of one wave's transpose (the hardware executes the LDS
 // operations of a wave in order; nothing is needed there)
@@ -403,10 +421,10 @@ ZJ_DEV PackedHalf idct_1d_dot(const uint32_t p04, const uint32_t p26, const uint
     h.x1 = dot2(p26, pk16(2217, -5350), t1);
     h.x2 = dot2(p26, pk16(-2217, 5350), t1);
     // odd part (scalar.rs:109-148) as the 4x4 integer matrix; d = s1, c = s3, b = s5, a = s7
-    h.u3 = dot2(p57, pk16(3219, 1131), dot2(p13, pk16(5683, 4816), 0));
-    h.u2 = dot2(p57, pk16(-5681, -3218), dot2(p13, pk16(4816, -1129), 0));
-    h.u1 = dot2(p57, pk16(1132, 4816), dot2(p13, pk16(3219, -5681), 0));
-    h.u0 = dot2(p57, pk16(4816, -5680), dot2(p13, pk16(1131, -3218), 0));
+    h.u3 = dot2(p57, pk16(3219, 1131), dot2z(p13, pk16(5683, 4816)));
+    h.u2 = dot2(p57, pk16(-5681, -3218), dot2z(p13, pk16(4816, -1129)));
+    h.u1 = dot2(p57, pk16(1132, 4816), dot2z(p13, pk16(3219, -5681)));
+    h.u0 = dot2(p57, pk16(4816, -5680), dot2z(p13, pk16(1131, -3218)));
     return h;
 }
 ZJ_DEV void idct_1d_dot_add(const PackedHalf& h, int32_t o[8])
@@ -554,6 +572,7 @@ template <> struct TileWidth<1, 1, false> { static constexpr int TWC = 128; }; /
 // (SURVEY 8f-3/4); both place every pixel at its own position (no Q5/Q6), like Params::plain does for OUT_RGB.
 enum { OUT_RGB = 0, OUT_GRAY = 1, OUT_YCBCR = 2, OUT_RGBA = 3, OUT_RGB_CHW = 4 };
 enum { GEN_WIDE = 0, GEN_PACKED = 1 };
+constexpr int XSTAGE = 2080; // staged stores: bytes of LDS staging per wave (129 pieces, rounded up), see piece_addr
 
 // LDS layouts (byte offsets).
 //   GEN_WIDE    Yp[SH][TWY] i16 | Cb[CROWS][CPITCH] i16 | Cr[..] | tables | vertical LUT
@@ -595,13 +614,22 @@ struct Cfg {
         static constexpr int TAB_OFF = C_OFF + CBYTES;
         static constexpr int LUT_OFF = TAB_OFF + TAB_BYTES;
         static constexpr int FLAG_OFF = LUT_OFF + LUT_BYTES;         // GEN_PACKED: "redo this tile wide"
-        static constexpr int X_OFF = FLAG_OFF + 16;                  // GEN_PACKED: per wave 2 KB of store staging
-        static constexpr int BYTES = GEN == GEN_PACKED ? X_OFF + (TSCAP ? NW * 2048 : 0) : FLAG_OFF;
+        static constexpr int X_OFF = FLAG_OFF + 16;                  // GEN_PACKED: per wave 2080 bytes of store staging (XSTAGE)
+        static constexpr int BYTES = GEN == GEN_PACKED ? X_OFF + (TSCAP ? NW * XSTAGE : 0) : FLAG_OFF;
         static_assert(C_OFF % 16 == 0 && TAB_OFF % 16 == 0, "16-byte alignment of the planes");
     };
     static constexpr int LDS_WIDE = L<GEN_WIDE>::BYTES;
     static constexpr int LDS_PACKED = L<GEN_PACKED>::BYTES > LDS_WIDE ? L<GEN_PACKED>::BYTES : LDS_WIDE;
     static constexpr int PIECES_PER_ROW = 3 * NGRP; // 16-byte pieces of a 3-byte-per-pixel tile row
+    // division of a piece index by PIECES_PER_ROW as multiply + shift, exact over every index color_copyout forms
+    static constexpr int PPR_MAGIC = (1 << 20) / PIECES_PER_ROW + 1;
+    static constexpr bool ppr_magic_ok()
+    {
+        for (int q = 0; q < 3 * ((NITEMS + NT - 1) / NT * NT) + 192; q++)
+            if ((int)(((unsigned)q * (unsigned)PPR_MAGIC) >> 20) != q / PIECES_PER_ROW) return false;
+        return true;
+    }
+    static_assert(ppr_magic_ok(), "PPR_MAGIC");
     static_assert(NT <= 512 && NBLK <= NT, "one lane per block, at most 8 waves");
 };
 
@@ -949,16 +977,17 @@ ZJ_DEV void store_clip(uint8_t* orow, long long off, const uint32_t* w, int ndw,
 //        3: the row's last group under the early-tail quirk (Q5): pieces 3L-1, 3L, 3L+1, then zeros in 3L+2 (Q6)
 struct ItemOut { U4 s0, s1, s2; int kind; };
 
-// LDS address of piece q (0..191) of a wave's round: the first 64 pieces reuse the luma bytes the wave's 64 items
-// have just consumed (16 bytes each, contiguous because consecutive items are consecutive 16-pixel groups), the
-// other 128 live in the wave's 2 KB of staging.
+// LDS address of piece q (0..191) of a wave's round.  Pieces 0..62 (the 48-byte items of lanes 0..20) reuse the luma
+// bytes the wave's 64 items have just consumed (16 bytes each, contiguous because consecutive items are consecutive
+// 16-pixel groups); pieces 63..191 (lanes 21..63) live in the wave's XSTAGE bytes of staging.  The split falls on an
+// item boundary, so a lane's three pieces are contiguous and only ONE piece address per lane needs a select.
 template <class C>
 ZJ_DEV char* piece_addr(char* lds, const int item0, const int wave, const int q)
 {
     using LL = typename C::template L<GEN_PACKED>;
     char* const ybase = lds + 16 * item0;
-    char* const xbase = lds + LL::X_OFF + 2048 * wave - 1024;
-    return (q < 64 ? ybase : xbase) + 16 * q;
+    char* const xbase = lds + LL::X_OFF + XSTAGE * wave - 16 * 63;
+    return (q < 63 ? ybase : xbase) + 16 * q;
 }
 
 template <class C>
@@ -967,7 +996,7 @@ ZJ_DEV void stage_item(const ItemOut& io, const int tid, char* lds, const int ro
     if (io.kind == 0) return;
     const int wave = tid >> 6, lane = tid & 63;
     const int item0 = 64 * wave + round * C::NT;
-    if (io.kind == 3) {
+    if (io.kind == 3) { // rare: one lane per row of the tile that holds the row's end
         const U4 z = {0, 0, 0, 0};
         *reinterpret_cast<U4*>(piece_addr<C>(lds, item0, wave, 3 * lane - 1)) = io.s0; // launcher: lane > 0 here
         *reinterpret_cast<U4*>(piece_addr<C>(lds, item0, wave, 3 * lane)) = io.s1;
@@ -975,9 +1004,10 @@ ZJ_DEV void stage_item(const ItemOut& io, const int tid, char* lds, const int ro
         *reinterpret_cast<U4*>(piece_addr<C>(lds, item0, wave, 3 * lane + 2)) = z;
         return;
     }
-    *reinterpret_cast<U4*>(piece_addr<C>(lds, item0, wave, 3 * lane)) = io.s0;
-    *reinterpret_cast<U4*>(piece_addr<C>(lds, item0, wave, 3 * lane + 1)) = io.s1;
-    if (io.kind == 1) *reinterpret_cast<U4*>(piece_addr<C>(lds, item0, wave, 3 * lane + 2)) = io.s2;
+    U4* const dst = reinterpret_cast<U4*>(piece_addr<C>(lds, item0, wave, 3 * lane)); // 48 contiguous bytes
+    dst[0] = io.s0;
+    dst[1] = io.s1;
+    if (io.kind == 1) dst[2] = io.s2;
 }
 
 // TS (staged stores, GEN_PACKED, FAST RGB / YCbCr only): processes ONE round (item = tid + round * NT) and, instead
@@ -1249,26 +1279,50 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
 template <class C, int OUT>
 ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid, char* lds, const int round)
 {
+    using LL = typename C::template L<GEN_PACKED>;
     const int P = p.mcu_x * 8 * (C::TWYB / C::TWC);
     const int x0 = t.tile * C::TWY;
     const int nvg = (P - x0) / 16 < C::NGRP ? (P - x0) / 16 : C::NGRP; // valid 16-pixel groups of this tile
-    const long long row_bytes = 3ll * p.width;
+    const uint32_t row_bytes = 3u * (uint32_t)p.width;
+    // everything up to here is uniform: a scalar base address, 32-bit per-lane offsets below
     uint8_t* const tile_out = p.out + (long long)t.frame * p.out_frame_stride + (long long)t.strip * C::SH * row_bytes + 3ll * x0;
-    const int w = tid >> 6, L = tid & 63;
+    const int w = uniform(tid >> 6), L = tid & 63;
     const int item0 = 64 * w + round * C::NT;  // first item of this wave's round
+    if (item0 >= C::NITEMS) return;            // (the last round of a tile is partly empty)
     // the piece the reference never writes: the last one of a row, in the tile that holds the row's end
     const bool row_end_here = x0 + 16 * nvg == P;
     const int never = (OUT == OUT_RGB && !p.plain && !p.zero_fill && row_end_here) ? 3 * nvg - 1 : -1;
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        const int q = 64 * j + L;
-        const int Q = 3 * item0 + q;            // piece index inside the tile
-        if (Q >= 3 * C::NITEMS) continue;
-        const int m = Q / C::PIECES_PER_ROW, c = Q - m * C::PIECES_PER_ROW;
-        if (c >= 3 * nvg || t.strip * C::SH + m >= p.height || c == never) continue;
-        const U4 v = *reinterpret_cast<const U4*>(piece_addr<C>(lds, item0, w, q));
-        store16(tile_out + m * row_bytes + 16 * c, v);
+    const int rows_left = p.height - t.strip * C::SH; // > 0
+    const char* const ybase = lds + 16 * item0;
+    const char* const xbase = lds + LL::X_OFF + XSTAGE * w - 16 * 63;
+    const char* const src0 = (L < 63 ? ybase : xbase) + 16 * L;
+    const char* const src1 = xbase + 16 * (64 + L);
+    const char* const src2 = xbase + 16 * (128 + L);
+    auto offset = [&](const int j, int& m, int& c) -> uint32_t {
+        const int Q = 3 * item0 + 64 * j + L;   // piece index inside the tile
+        m = (int)(((uint32_t)Q * (uint32_t)C::PPR_MAGIC) >> 20); // Q / PIECES_PER_ROW (3 instructions; checked in Cfg)
+        c = Q - m * C::PIECES_PER_ROW;
+        return (uint32_t)mul24(m, (int32_t)row_bytes) + 16u * (uint32_t)c; // m < 32, row_bytes < 2^18
+    };
+    int m0, c0, m1, c1, m2, c2;
+    const uint32_t o0 = offset(0, m0, c0), o1 = offset(1, m1, c1), o2 = offset(2, m2, c2);
+    // interior tiles (all but the last of a row, all but a clipped last strip), whole rounds: no per-piece test,
+    // three LDS reads, one wait, three stores
+    const bool plain_round = nvg == C::NGRP && rows_left >= C::SH && never < 0 && item0 + 64 <= C::NITEMS;
+    if (plain_round) {
+        const U4 v0 = *reinterpret_cast<const U4*>(src0), v1 = *reinterpret_cast<const U4*>(src1), v2 = *reinterpret_cast<const U4*>(src2);
+        store16(tile_out + o0, v0);
+        store16(tile_out + o1, v1);
+        store16(tile_out + o2, v2);
+        return;
     }
+    ZJ_NO_IF_CONVERT();
+    auto valid = [&](const int j, const int m, const int c) -> bool {
+        return 3 * item0 + 64 * j + L < 3 * C::NITEMS && c < 3 * nvg && m < rows_left && c != never;
+    };
+    if (valid(0, m0, c0)) store16(tile_out + o0, *reinterpret_cast<const U4*>(src0));
+    if (valid(1, m1, c1)) store16(tile_out + o1, *reinterpret_cast<const U4*>(src1));
+    if (valid(2, m2, c2)) store16(tile_out + o2, *reinterpret_cast<const U4*>(src2));
 }
 
 // Are staged stores usable for this launch?  The early-tail shift writes into the piece before the lane's own, so

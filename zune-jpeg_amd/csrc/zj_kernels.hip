@@ -66,18 +66,25 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), ZJ_WAVES_PER_SIMD) void zj_
     phase_setup<C, HS, VS, GEN_PACKED>(p, tid, lds);
     __syncthreads();
     finish_block<C, GEN_PACKED, NEED_Y16>(L, raw, lds, p.debug, p.clamp_dc);
+    // The coefficient loads are consumed inside exec-masked regions, so on the paths that skip those regions the
+    // compiler still counts them as outstanding and would put `s_waitcnt vmcnt(0)` in front of every later reuse of
+    // their registers -- in the store rounds below that wait also drains the round's own stores (gfx9 has one counter
+    // for loads and stores) and serialises them.  One explicit wait here (free: the data arrived before the IDCT) tells
+    // the wait-count pass that nothing is pending.
+    __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0) only
     __syncthreads();
-    if (NEED_Y16 && __builtin_amdgcn_readfirstlane((int)*lds_flag<C>(lds)) != 0) {
-        // a DC-only luma block of this tile decodes outside 0..255 (Q1: the scalar shortcut does not clamp): the byte
-        // staging cannot carry it, the whole tile is redone by the wide code (never seen on valid 8-bit JPEG data)
+    // a DC-only luma block of this tile decodes outside 0..255 (Q1: the scalar shortcut does not clamp): the byte
+    // staging cannot carry it, the whole tile is redone by the wide code (never seen on valid 8-bit JPEG data)
+    const bool redo = NEED_Y16 && __builtin_amdgcn_readfirstlane((int)*lds_flag<C>(lds)) != 0;
+    if (redo) {
         __syncthreads(); // everyone has read the flag before the wide layout overwrites it
         tile_wide<C, HS, VS, OUT, FAST>(p, t, tid, lds);
-        return;
-    }
-    ZJ_SETPRIO(2, 2);
-    if (TS) {
+    } else if (TS) {
         // each wave stages its 64 items of a round in LDS, then stores them as contiguous pieces; LDS operations
         // of one wave execute in order, so no barrier is needed between the halves or between rounds
+        ZJ_SETPRIO(2, 2);
+        __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0), free here; see above
+#pragma unroll
         for (int round = 0; round * C::NT < C::NITEMS; round++) {
             ItemOut io;
             phase_color<C, HS, VS, OUT, GEN_PACKED, FAST, true>(p, t, tid, lds, round, &io);
@@ -87,6 +94,8 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), ZJ_WAVES_PER_SIMD) void zj_
             ZJ_WAVE_FENCE();
         }
     } else {
+        ZJ_SETPRIO(2, 2);
+        __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0), free here; see above
         phase_color<C, HS, VS, OUT, GEN_PACKED, FAST>(p, t, tid, lds);
     }
 }
