@@ -7,7 +7,7 @@
 use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const ZJ_ABI_VERSION: c_int = 2;
+pub const ZJ_ABI_VERSION: c_int = 3;
 pub const ZJ_BACKEND_HIP: c_int = 2;
 pub const ZJ_OK: c_int = 0;
 pub const ZJ_ERR_PANIC: c_int = -5;
@@ -96,6 +96,7 @@ extern "C" {
                                    d_cb: *const i16, d_cr: *const i16, d_out: *mut u8, stream: *mut c_void) -> c_int;
     pub fn zj_alloc_pinned(bytes: usize) -> *mut c_void;
     pub fn zj_free_pinned(p: *mut c_void);
+    pub fn zj_set_thread_device(device: c_int) -> c_int;
     pub fn zj_decoder_new(opt: *const zj_options) -> *mut zj_decoder;
     pub fn zj_decoder_free(d: *mut zj_decoder);
     pub fn zj_decoder_error(d: *const zj_decoder) -> *const c_char;

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ZJ_ABI_VERSION 2
+#define ZJ_ABI_VERSION 3
 
 /* ColorSpace, same order as src/misc.rs:88-106 */
 typedef enum zj_colorspace {
@@ -245,7 +245,10 @@ int zj_pool_decode_files(zj_pool *pool, size_t nfiles, const uint8_t *const *buf
                          zj_image_info *infos /*[nfiles] or NULL*/, int *statuses /*[nfiles] or NULL*/);
 
 /* ---- memory helpers ------------------------------------------------------------------------- */
-void *zj_alloc_pinned(size_t bytes); /* hipHostMalloc; NULL on failure */
+void *zj_alloc_pinned(size_t bytes); /* hipHostMalloc, portable (usable as a DMA source/target from every device); NULL on failure */
+/* binds the CALLING thread to `device` (hipSetDevice): host threads that only allocate pinned memory or fill planes for a
+ * context on device N call this first, so they neither initialise nor pin against device 0 */
+int zj_set_thread_device(int device);
 void zj_free_pinned(void *p);
 void *zj_device_alloc(zj_ctx *ctx, size_t bytes);
 void zj_device_free(zj_ctx *ctx, void *p);

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import oracle_c as oc
+import ref_walk
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -134,7 +135,104 @@ def test_reference_images_vs_pillow(zj, name, prog, scans):
     assert im.mode == "YCbCr"
     pil = np.asarray(im, np.int32)
     d = np.abs(ours.reshape(1080, 1920, 3).astype(np.int32) - pil)
+    if not prog:
+        # the reference never decodes the last 7 MCUs of this image (it leaves the row loop once its reader has come
+        # across EOI, src/mcu.rs:337-343; test_reference_eoi_cut below): they stay zero coefficients = mid grey
+        rows = ref_walk.decoded_mcus_per_row(data)
+        assert [(i, n) for i, n in enumerate(rows) if n != 240] == [(134, 233)]
+        d[134 * 8:, 233 * 8:] = 0
     assert d.max() <= 4 and d.mean() < 0.5
+
+
+_CUTS = {}
+
+
+def _flat_tail_planes(w, h, hs, vs, busy_rows, seed):
+    """random blocks in the first `busy_rows` MCU rows, then DC-only blocks with a constant non-zero DC: the last
+    MCUs cost only their shortest codes, and a decoded block is never all-zero"""
+    planes = jpeg_enc.small_planes(w, h, hs, vs, 3, seed=seed)
+    mcu_x = (w + 8 * hs - 1) // (8 * hs)
+    out = []
+    for c, pl in enumerate(planes):
+        ch, cv = (hs, vs) if c == 0 else (1, 1)
+        bw = mcu_x * ch
+        b = np.array(pl, np.int16).reshape(-1, bw, 64)
+        b[busy_rows * cv:] = 0
+        b[busy_rows * cv:, :, 0] = (50, 20, -30)[c]
+        out.append(b.reshape(-1))
+    return out
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("wh", [(64, 48), (200, 40), (17, 33)])
+@pytest.mark.parametrize("restart", [0, 5])
+@pytest.mark.parametrize("threads", [1, 4])
+def test_reference_eoi_cut(zj, synth, mode, wh, restart, threads):
+    """Which MCUs get entropy-decoded at all: the front-end against the bit-level model of the reference's reader
+    and MCU loop (oracle/ref_walk.py).  Flat image tails make the last MCUs cheap enough for the reference to
+    come across EOI before it has decoded them."""
+    hs, vs = MODES[mode]
+    w, h = wh
+    mcu_x, mcu_y = (w + 8 * hs - 1) // (8 * hs), (h + 8 * vs - 1) // (8 * vs)
+    cut_somewhere = False
+    for busy_rows in (0, 1, mcu_y):
+        planes = _flat_tail_planes(w, h, hs, vs, busy_rows, seed=w + h + busy_rows)
+        data = jpeg_enc.encode_baseline(planes, synth.quant_tables(85), w, h, hs, vs, 3, restart=restart)
+        rows = ref_walk.decoded_mcus_per_row(data)
+        desc, got, info = zj.Decoder(_opts(zj, threads)).decode_coefficients(data)
+        y = np.array(got[0], np.int16).reshape(mcu_y * vs, mcu_x * hs, 64)
+        cb = np.array(got[1], np.int16).reshape(mcu_y, mcu_x, 64)
+        for my in range(mcu_y):
+            n = rows[my]
+            if n is None:      # an MCU row the reference never walks (odd last row of (2,1)/(2,2)): its pixels are
+                continue       # dropped by the pixel path whatever the front-end puts there
+            cut_somewhere |= n < mcu_x
+            exp_y = np.array(planes[0], np.int16).reshape(mcu_y * vs, mcu_x * hs, 64)
+            exp_cb = np.array(planes[1], np.int16).reshape(mcu_y, mcu_x, 64)
+            assert np.array_equal(y[my * vs:(my + 1) * vs, :n * hs], exp_y[my * vs:(my + 1) * vs, :n * hs]), (busy_rows, my)
+            assert np.array_equal(cb[my, :n], exp_cb[my, :n])
+            if busy_rows < mcu_y:  # (random tails are too expensive for a cut; values there are covered by the round trips)
+                assert not y[my * vs:(my + 1) * vs, n * hs:].any() and not cb[my, n:].any(), (busy_rows, my, n)
+    _CUTS[(mode, wh, restart)] = cut_somewhere
+
+
+@pytest.mark.parametrize("subsampling", [0, 1, 2], ids=["444", "422", "420"])
+@pytest.mark.parametrize("wh", [(64, 48), (200, 40), (17, 33), (640, 64), (1000, 24)])
+@pytest.mark.parametrize("restart_rows", [0, 1])
+@pytest.mark.parametrize("threads", [1, 4])
+def test_reference_eoi_cut_libjpeg_files(zj, subsampling, wh, restart_rows, threads):
+    """the same on files written by libjpeg (Pillow) with the standard Huffman tables, whose flat MCUs cost 6-18 bits:
+    the reference drops up to a handful of MCUs at the end of such images"""
+    from PIL import Image
+    w, h = wh
+    rng = np.random.default_rng(w * h)
+    a = np.zeros((h, w, 3), np.uint8)
+    a[:] = (200, 60, 30)                       # far from grey: every decoded chroma DC is non-zero
+    a[:8] = rng.integers(0, 256, (8, w, 3))    # one busy MCU row on top
+    b = io.BytesIO()
+    kw = dict(quality=90, subsampling=subsampling)
+    if restart_rows:
+        kw["restart_marker_rows"] = restart_rows
+    Image.fromarray(a).save(b, "JPEG", **kw)
+    data = b.getvalue()
+    rows = ref_walk.decoded_mcus_per_row(data)
+    hs, vs = [(1, 1), (2, 1), (2, 2)][subsampling]
+    mcu_x = (w + 8 * hs - 1) // (8 * hs)
+    desc, planes, info = zj.Decoder(_opts(zj, threads)).decode_coefficients(data)
+    assert bool(info.restart_interval) == bool(restart_rows)
+    cb = np.array(planes[1], np.int16).reshape(-1, mcu_x, 64)
+    first_flat = 16 // (8 * vs) if vs == 2 else 1      # MCU rows made only of flat pixels
+    for r in range(first_flat, cb.shape[0]):
+        if rows[r] is None:
+            continue
+        n = rows[r]
+        assert (cb[r, :n, 0] != 0).all() and not cb[r, n:].any(), (r, n, rows)
+    _CUTS[("pillow", subsampling, wh, restart_rows)] = any(n is not None and n < mcu_x for n in rows)
+
+
+def test_reference_eoi_cut_was_exercised():
+    """the cases above must contain images where the reference drops MCUs (else they test nothing)"""
+    assert sum(_CUTS.values()) >= 6, _CUTS
 
 
 def _opts(zj, threads):

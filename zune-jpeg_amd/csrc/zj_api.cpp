@@ -223,8 +223,16 @@ size_t zj_out_len(const zj_frame_desc* d)
 void* zj_alloc_pinned(size_t bytes)
 {
     void* p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    // portable: the planes of a zj_pool are filled by entropy threads and read by submitter threads' contexts
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) return nullptr;
     return p;
+}
+int zj_set_thread_device(int device)
+{
+    const int n = zj_device_count();
+    if (n <= 0) return ZJ_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return ZJ_ERR_ARG;
+    return hipSetDevice(device) == hipSuccess ? ZJ_OK : ZJ_ERR_HIP;
 }
 void zj_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
 void* zj_device_alloc(zj_ctx* c, size_t bytes)

@@ -95,7 +95,21 @@ struct BitReader {
     uint64_t acc = 0; // bits left-aligned
     int nbits = 0;
     int marker = 0;   // pending marker byte (0xD0.., 0xD9 ...) found in the entropy-coded data
-    void reset() { acc = 0; nbits = 0; marker = 0; }
+    // bookkeeping for reference_saw_eoi(): the restart interval's first byte, stuffed zeros skipped since then, the
+    // first 0xFF of the pending marker, zero bits appended after it (or after the end of the data), and the length in
+    // bits of the last symbol a block decoded
+    const uint8_t* istart = nullptr;
+    const uint8_t* mpos = nullptr;
+    uint32_t stuffed = 0;
+    int pad = 0;
+    int last_sym = 0;
+    void reset() { acc = 0; nbits = 0; marker = 0; istart = p; mpos = nullptr; stuffed = 0; pad = 0; }
+    // bits consumed since istart (zero padding included once the real bits are used up)
+    long long consumed() const
+    {
+        const long long fed = (long long)((marker ? mpos : p) - istart) - (long long)stuffed;
+        return 8 * fed - ((long long)nbits - pad);
+    }
     void fill()
     {
         // eight bytes at once while no 0xFF (stuffing or marker) is among them; the bits of a partially taken
@@ -118,14 +132,18 @@ struct BitReader {
                 b = *p++;
                 if (b == 0xFF) {
                     uint32_t n = p < end ? *p : 0xD9;
-                    if (n == 0) { p++; }                  // stuffed zero
+                    if (n == 0) { p++; stuffed++; }       // stuffed zero
                     else {                                // marker: stop feeding, pad with zeros
+                        mpos = p - 1;
                         while (n == 0xFF && p + 1 < end) { p++; n = *p; }
                         marker = (int)n;
                         if (p < end) p++;
                         b = 0;
+                        pad += 8;
                     }
                 }
+            } else {
+                pad += 8; // zeros after a marker or after the end of the data
             }
             acc |= (uint64_t)b << (56 - nbits);
             nbits += 8;
@@ -146,13 +164,14 @@ struct BitReader {
         if (nbits < 16) fill();
         uint32_t v = peek(9);
         uint16_t e = h.look[v];
-        if (e) { drop(e >> 8); return e & 0xff; }
+        if (e) { drop(e >> 8); last_sym = e >> 8; return e & 0xff; }
         uint32_t code = peek(16);
         for (int l = 10; l <= 16; l++) {
             int32_t c = (int32_t)(code >> (16 - l));
-            if (c <= h.maxcode[l]) { drop(l); return h.vals[(c + h.valoff[l]) & 0xff]; }
+            if (c <= h.maxcode[l]) { drop(l); last_sym = l; return h.vals[(c + h.valoff[l]) & 0xff]; }
         }
         drop(16);
+        last_sym = 16;
         return -1;
     }
 };
@@ -165,6 +184,8 @@ struct Comp {
     int bw = 0, bh = 0; // plane size in blocks
     int16_t* coef = nullptr; // bw * bh * 64, owned by zj_decoder::store
     size_t coef_len = 0;
+    uint16_t q[64] = {0};    // the component's table as it stood when SOF was parsed (headers.rs:327 copies it there;
+                             // a DQT after SOF does not reach a frame's components in the reference)
 };
 
 // backing store of one coefficient plane: heap, or pinned host memory (zj_alloc_pinned) so that
@@ -223,6 +244,7 @@ struct zj_decoder {
     int width = 0, height = 0, ncomp = 0, progressive = 0, h_max = 1, v_max = 1, mcu_x = 0, mcu_y = 0;
     int restart_interval = 0;
     int seen_sof = 0, scans = 0;
+    bool coef_valid = false; // the planes hold the coefficients of a complete, successful decode_all
     uint16_t qt[4][64];
     bool qt_present[4] = {false, false, false, false};
     Huff dc[4], ac[4];
@@ -340,6 +362,7 @@ int parse_sof(zj_decoder* d, Cursor& c, int progressive)
     for (int i = 0; i < nc; i++) {
         Comp& cm = d->comps[i];
         if (!d->qt_present[cm.tq]) return fail(d, ZJ_ERR_DQT, "No quantization table for component " + std::to_string(cm.id));
+        memcpy(cm.q, d->qt[cm.tq], sizeof cm.q);
         cm.bw = d->mcu_x * cm.h;
         cm.bh = d->mcu_y * cm.v;
         cm.coef_len = (size_t)cm.bw * cm.bh * 64;
@@ -465,13 +488,14 @@ int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, in
         if (fa) { // short code + small value: run, magnitude and sign from one table entry
             k += (fa >> 4) & 15;
             br.drop(fa & 15);
+            br.last_sym = fa & 15;
             blk[kUnZigzag[k & 63]] = (int16_t)(fa >> 8);
             k++;
             continue;
         }
         int rs;
         const uint16_t e = ha.look[look9];
-        if (e) { br.drop(e >> 8); rs = e & 0xff; }
+        if (e) { br.drop(e >> 8); br.last_sym = e >> 8; rs = e & 0xff; }
         else {
             rs = br.decode(ha);
             if (rs < 0) { *err = "Bad Huffman code in AC"; return ZJ_ERR_HUFFMAN; }
@@ -481,6 +505,7 @@ int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, in
             k += r;
             const int32_t bits = (int32_t)br.peek(sz);
             br.drop(sz);
+            br.last_sym += sz;
             // EXTEND (T.81 F.2.2.1) without a branch: values below 2^(sz-1) are negative
             const int32_t v = bits + ((((bits - (1 << (sz - 1))) >> 31)) & (1 - (1 << sz)));
             blk[kUnZigzag[k & 63]] = (int16_t)v;
@@ -507,6 +532,67 @@ int handle_restart(zj_decoder* d, BitReader& br, int& todo)
         return fail(d, ZJ_ERR_MCU, "Marker found in bitstream, possibly corrupt jpeg");
     }
     return ZJ_OK;
+}
+
+// ---- the reference's early exit at EOI (src/mcu.rs:337-343) -------------------------------------------------------
+// After every MCU the reference tests `stream.marker`: once its bit reader has come ACROSS the EOI marker -- which
+// happens while it refills, up to ~90 bits before the last coded bit is consumed -- it leaves the loop over the MCUs of
+// the current row; every later row then decodes exactly one MCU (from the bits that are left, then zeros) and leaves
+// again.  MCUs it never decodes keep the zeros of their fresh buffers.  On images whose last MCUs are cheap (a flat
+// lower right corner costs 6-18 bits per MCU) the last few MCUs are therefore never decoded: the reference's own
+// test-images/test-baseline.jpg loses 7 (tests/test_jpeg_frontend.py).  Reproducing the output needs the exact moment:
+//   src/bitstream.rs:150-262  refill() appends 4 data bytes whenever it is called with bits_left <= 32 (stuffed
+//   zeros are skipped, a marker ends the refill and is recorded); decode_mcu_block calls it before every AC symbol
+//   (:334) and decode_dc when bits_left < 16 (:278).  Hence, right after the refill of an AC call site that follows C
+//   consumed bits, the reader has read min(D, 4 * (C / 32 + 2)) of the D data bytes that precede the marker, and it
+//   has seen the marker iff 4 * (C / 32 + 2) > D.  The last call site of an MCU is the one in front of its last
+//   symbol.  (Checked against a state-machine model of the reader over 200 000 random symbol streams; it assumes DC
+//   symbols of at most 16 bits -- with longer ones the reference consumes bits it never loaded, src/bitstream.rs:278.)
+struct EoiCut {
+    const uint8_t* eoi = nullptr; // first 0xFF of the EOI marker that ends the scan, or null: no cut logic
+    long long rowlen = 0;         // MCUs the reference decodes per row loop (2 * mcu_x for (2,1) sampling, mcu.rs:145-152)
+    bool seen = false;
+    long long cut_row = -1;
+};
+// data bytes of the current restart interval that precede the marker at `eoi`
+long long interval_data_bytes(const BitReader& br, const uint8_t* eoi)
+{
+    const uint8_t* from = br.marker ? br.mpos : br.p; // stuffed zeros before this point are in br.stuffed already
+    long long st = br.stuffed;
+    for (const uint8_t* q = from; q + 1 < eoi; q++)
+        if (q[0] == 0xFF && q[1] == 0x00) { st++; q++; }
+    return (long long)(eoi - br.istart) - st;
+}
+// call after an MCU has been decoded (and after the restart handling that may follow it)
+inline void eoi_cut_after_mcu(EoiCut& cut, const BitReader& br, long long mcu_index)
+{
+    if (!cut.eoi) return;
+    if (!cut.seen) {
+        const uint8_t* at = br.marker ? br.mpos : br.p;
+        if (cut.eoi - at > 64) return; // the reader cannot have reached the marker's refill group yet
+        const long long c_last = br.consumed() - br.last_sym;
+        if (c_last < 0 || 4 * (c_last / 32 + 2) <= interval_data_bytes(br, cut.eoi)) return;
+        cut.seen = true;
+    }
+    cut.cut_row = mcu_index / cut.rowlen;
+}
+// first marker in [p, end) that is neither a stuffed 0xFF00, a fill byte nor RSTn: *is_eoi tells whether it is EOI;
+// returns the first 0xFF of the marker (fill bytes in front of it included), or null
+const uint8_t* find_scan_end(const uint8_t* p, const uint8_t* end, bool* is_eoi)
+{
+    const uint8_t* const start = p;
+    *is_eoi = false;
+    while (p < end) {
+        const uint8_t* f = (const uint8_t*)memchr(p, 0xFF, (size_t)(end - p));
+        if (!f || f + 1 >= end) return nullptr;
+        const uint8_t m = f[1];
+        if (m == 0x00 || (m >= 0xD0 && m <= 0xD7)) { p = f + 2; continue; }
+        if (m == 0xFF) { p = f + 1; continue; }
+        *is_eoi = m == 0xD9;
+        while (f > start && f[-1] == 0xFF) f--; // fill bytes belong to the marker
+        return f;
+    }
+    return nullptr;
 }
 
 // Restart markers cut a baseline scan into independently decodable segments (T.81 E.1.4: predictors
@@ -538,14 +624,29 @@ bool find_restart_segments(const uint8_t* p, const uint8_t* end, int nseg, std::
     return (int)seg.size() == nseg + 1;
 }
 
+inline void clear_mcu(zj_decoder* dm, int mx, int my)
+{
+    for (int ci = 0; ci < dm->ncomp; ci++) {
+        Comp& cm = dm->comps[ci];
+        for (int v = 0; v < cm.v; v++)
+            for (int h = 0; h < cm.h; h++) memset(block_at(cm, mx * cm.h + h, my * cm.v + v), 0, 128);
+    }
+}
+
+long long eoi_rowlen(const zj_decoder* d) { return (d->ncomp == 3 && d->h_max == 2 && d->v_max == 1) ? 2ll * d->mcu_x : d->mcu_x; }
+
+// eoi: first 0xFF of the EOI marker when this segment is the one that ends with it, else null
 int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p, const uint8_t* end, long long mcu0,
-                          long long nmcu, const char** err)
+                          long long nmcu, const char** err, const uint8_t* eoi = nullptr)
 {
     BitReader br;
-    br.p = p; br.end = end;
+    br.p = p; br.end = end; br.istart = p;
+    EoiCut cut;
+    cut.eoi = eoi; cut.rowlen = eoi_rowlen(d);
     int32_t pred[3] = {0, 0, 0};
     for (long long i = 0; i < nmcu; i++) {
         const int my = (int)((mcu0 + i) / d->mcu_x), mx = (int)((mcu0 + i) % d->mcu_x);
+        if (cut.seen && (mcu0 + i) / cut.rowlen == cut.cut_row) { clear_mcu(dm, mx, my); continue; }
         for (int ci = 0; ci < d->ns; ci++) {
             Comp& cm = dm->comps[d->order[ci]];
             for (int v = 0; v < cm.v; v++)
@@ -554,6 +655,7 @@ int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p,
                     if (rc) return rc;
                 }
         }
+        eoi_cut_after_mcu(cut, br, mcu0 + i);
     }
     return ZJ_OK;
 }
@@ -579,7 +681,12 @@ int scan_baseline(zj_decoder* d, BitReader& br)
                 const char* err = nullptr;
                 const long long m0 = (long long)k * ri, n = m0 + ri <= total ? ri : total - m0;
                 // a segment ends where the next RSTn (or the closing marker) begins: the reader stops there
-                if (scan_baseline_segment(d, d, seg[(size_t)k], seg[(size_t)k + 1], m0, n, &err)) bad.store(1);
+                const uint8_t* eoi = nullptr; // the last segment ends at the scan's closing marker
+                if (k == nseg - 1 && seg[(size_t)nseg] + 1 < br.end && seg[(size_t)nseg][1] == 0xD9) {
+                    eoi = seg[(size_t)nseg];
+                    while (eoi > seg[(size_t)k] && eoi[-1] == 0xFF) eoi--;
+                }
+                if (scan_baseline_segment(d, d, seg[(size_t)k], seg[(size_t)k + 1], m0, n, &err, eoi)) bad.store(1);
             });
             if (!bad.load()) { br.p = seg[(size_t)nseg]; br.reset(); d->dri_parallel_segments = nseg; return ZJ_OK; }
             // (the serial walk below clears every block again before it writes into it)
@@ -587,6 +694,13 @@ int scan_baseline(zj_decoder* d, BitReader& br)
     }
     d->dri_parallel_segments = 0;
     int todo = d->restart_interval ? d->restart_interval : 0x7fffffff;
+    EoiCut cut;
+    {
+        bool is_eoi = false;
+        const uint8_t* e = find_scan_end(br.p, br.end, &is_eoi);
+        cut.eoi = (e && is_eoi) ? e : nullptr;
+        cut.rowlen = eoi_rowlen(d);
+    }
     // blocks of MCUs from (mx, my) on that the walk never reached stay zero, like the reference's fresh vectors
     auto clear_from = [&](int my0, int mx0) {
         for (int my = my0; my < d->mcu_y; my++)
@@ -600,6 +714,9 @@ int scan_baseline(zj_decoder* d, BitReader& br)
     // (2,1): the reference walks 2*mcu_x MCUs per strip (mcu.rs:145-152); MCU order is unchanged
     for (int my = 0; my < d->mcu_y; my++)
         for (int mx = 0; mx < d->mcu_x; mx++) {
+            const long long m = (long long)my * d->mcu_x + mx;
+            // the reference left this row's loop at an earlier MCU (see EoiCut): the block keeps its zeros
+            if (cut.seen && m / cut.rowlen == cut.cut_row) { clear_mcu(d, mx, my); continue; }
             for (int ci = 0; ci < d->ns; ci++) {
                 Comp& cm = d->comps[d->order[ci]];
                 for (int v = 0; v < cm.v; v++)
@@ -609,8 +726,13 @@ int scan_baseline(zj_decoder* d, BitReader& br)
                         if (rc) { clear_from(my, mx); return fail(d, rc, err); }
                     }
             }
-            if (--todo == 0) { int rc = handle_restart(d, br, todo); if (rc) { clear_from(my, mx + 1); return rc; } }
-            if (br.marker == 0xD9 && br.nbits <= 0) { clear_from(my, mx + 1); return ZJ_OK; }
+            bool restarted = false;
+            if (--todo == 0) {
+                restarted = br.marker >= 0xD0 && br.marker <= 0xD7;
+                int rc = handle_restart(d, br, todo);
+                if (rc) { clear_from(my, mx + 1); return rc; }
+            }
+            if (!restarted) eoi_cut_after_mcu(cut, br, m); // (a restart clears the reference's pending marker, mcu.rs:400-408)
         }
     return ZJ_OK;
 }
@@ -762,6 +884,7 @@ int next_marker(BitReader& br)
 int decode_all(zj_decoder* d, const uint8_t* buf, size_t len, bool headers_only)
 {
     d->err.clear(); d->err_code = 0; d->seen_sof = 0; d->scans = 0; d->restart_interval = 0;
+    d->coef_valid = false;
     for (int i = 0; i < 4; i++) { d->qt_present[i] = false; d->dc[i].present = false; d->ac[i].present = false; }
     Cursor c{buf, buf + len};
     int rc = parse_headers(d, c, true);
@@ -769,10 +892,11 @@ int decode_all(zj_decoder* d, const uint8_t* buf, size_t len, bool headers_only)
     if (headers_only) return ZJ_OK;
     if (!d->seen_sof) return fail(d, ZJ_ERR_SOF, "Number of components cannot be zero.");
     BitReader br;
-    br.p = c.p; br.end = c.end;
+    br.p = c.p; br.end = c.end; br.istart = c.p;
     if (!d->progressive) {
         rc = scan_baseline(d, br);
         d->scans = 1;
+        d->coef_valid = rc == ZJ_OK;
         return rc;
     }
     for (;;) {
@@ -784,13 +908,14 @@ int decode_all(zj_decoder* d, const uint8_t* buf, size_t len, bool headers_only)
         for (;;) {
             int m = next_marker(br);
             if (m < 0) return fail(d, ZJ_ERR_FORMAT, "Marker missing where expected");
-            if (m == 0xD9) return ZJ_OK;
+            if (m == 0xD9) { d->coef_valid = true; return ZJ_OK; }
             Cursor cc{br.p, br.end};
             if (m == 0xC4) { rc = parse_dht(d, cc); br.p = cc.p; if (rc) return rc; continue; }
             if (m == 0xDB) { rc = parse_dqt(d, cc); br.p = cc.p; if (rc) return rc; continue; }
             if (m == 0xDD) { int l, ri; if (!cc.u16(l) || l != 4 || !cc.u16(ri)) return fail(d, ZJ_ERR_FORMAT, "Bad DRI length, Corrupt JPEG"); d->restart_interval = ri; br.p = cc.p; continue; }
             if (m == 0xDA) { rc = parse_sos(d, cc); br.p = cc.p; if (rc) return rc; break; }
             if (m >= 0xD0 && m <= 0xD7) continue;
+            d->coef_valid = true;
             return ZJ_OK; // anything else ends the image like the reference's `_ => break 'eoi`
         }
     }
@@ -838,8 +963,8 @@ static void fill_info(const zj_decoder* d, zj_image_info* info, zj_frame_desc* f
         fd->flags = d->flags;
         fd->out_layout = d->out_layout;
         for (int c = 0; c < 3; c++) {
-            const int tq = d->comps[c < d->ncomp ? c : 0].tq;
-            for (int k = 0; k < 64; k++) fd->qt[c][k] = d->qt[tq][k];
+            const Comp& cm = d->comps[c < d->ncomp ? c : 0];
+            for (int k = 0; k < 64; k++) fd->qt[c][k] = cm.q[k]; // the SOF-time snapshot, not d->qt as it stands now
         }
     }
 }
@@ -870,7 +995,8 @@ int zj_decoder_decode_coefficients(zj_decoder* d, const uint8_t* buf, size_t len
 int zj_decoder_finish_pixels(zj_decoder* d, zj_ctx* ctx, uint8_t* out, size_t out_cap, size_t* out_len)
 {
     if (!d || !ctx || !out) return ZJ_ERR_ARG;
-    if (!d->seen_sof || d->err_code) return fail(d, ZJ_ERR_ARG, "no successfully decoded coefficients to finish");
+    // read_headers alone allocates the planes but decodes nothing into them: only a complete decode_all counts
+    if (!d->seen_sof || d->err_code || !d->coef_valid) return fail(d, ZJ_ERR_ARG, "no successfully decoded coefficients to finish");
     zj_frame_desc fd;
     fill_info(d, nullptr, &fd);
     // grayscale JPEG decoded to RGB: the reference converts nothing and returns zeros (worker.rs:131)

@@ -62,6 +62,7 @@ struct zj_pool {
     std::mutex call_mu;                  // serialises zj_pool_decode_files callers
     std::string last_error;
     int n_workers = 0;
+    int device = 0;                      // every thread of the pool binds to it
     // accumulated over the pool's life (under mu): seconds inside the entropy stage / the GPU stage, files
     double entropy_s = 0, gpu_s = 0;
     size_t files_done = 0;
@@ -78,6 +79,9 @@ struct zj_pool {
 
     void entropy_loop()
     {
+        // the planes this thread fills are pinned (zj_alloc_pinned) and DMA'd by the submitters' contexts on `device`:
+        // bind the thread there, so a pool on device N never touches device 0
+        (void)zj_set_thread_device(device);
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
             cv.wait(lk, [&] { return stop || (batch && batch->next < batch->n && !free_dec.empty()); });
@@ -159,6 +163,7 @@ zj_pool* zj_pool_create(int device, int threads, const zj_options* opt, int* sta
     o.pinned_planes = getenv("ZJ_POOL_HEAP_PLANES") ? 0 : 1; // planes are DMA sources (the env knob is for A/B timing)
     if (o.num_threads <= 0) o.num_threads = 1; // the pool is the parallelism; > 1 adds restart-segment threads per file
     p->n_workers = threads;
+    p->device = device;
     *status = ZJ_OK;
     for (int g = 0; g < GPU_SUBMITTERS && *status == ZJ_OK; g++) {
         int st = ZJ_OK;

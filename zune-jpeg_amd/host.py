@@ -16,6 +16,7 @@ arms live in the host application (the Rust crate), not in this library.
 import ctypes as C
 import enum
 import os
+import sys
 
 import numpy as np
 
@@ -130,7 +131,7 @@ ABI = [  # every symbol include/zjhip.h declares
     "zj_upsample_hv", "zj_ycbcr_to_rgb16", "zj_post_process_strip", "zj_choose_idct_func",
     "zj_choose_upsample_func", "zj_choose_ycbcr_to_rgb_convert_func", "zj_plane_len", "zj_out_len",
     "zj_num_components", "zj_decode_planes", "zj_decode_planes_batch", "zj_decode_planes_device",
-    "zj_time_decode_device", "zj_alloc_pinned", "zj_free_pinned", "zj_device_alloc",
+    "zj_time_decode_device", "zj_alloc_pinned", "zj_free_pinned", "zj_set_thread_device", "zj_device_alloc",
     "zj_device_free", "zj_memcpy_h2d", "zj_memcpy_d2h", "zj_sync",
     "zj_decoder_new", "zj_decoder_free", "zj_decoder_error", "zj_decoder_read_headers",
     "zj_decoder_decode_coefficients", "zj_decoder_finish_pixels", "zj_decoder_decode_buffer",
@@ -148,6 +149,26 @@ def lib_path():
     return os.path.join(_HERE, os.environ.get("ZJ_LIB", "libzjhip.so"))  # ZJ_LIB: A/B builds (tools/ab_lib.sh)
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (soname libamdhip64.so.7, asked for as `libamdhip64.so`);
+    libzjhip.so asks for `libamdhip64.so.7` and would otherwise bring in /opt/rocm's copy.  Two HIP runtimes in one
+    process do not coexist: whichever initialises second reports "No HIP GPUs are available".  When a torch wheel with
+    a bundled runtime is installed, its copy is opened first (without importing torch), so libzjhip.so binds to it by
+    soname and decode_to_tensor / torch streams work whatever the import order.  ZJ_SYSTEM_HIP=1 keeps the system copy."""
+    if os.environ.get("ZJ_SYSTEM_HIP") or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:  # noqa: BLE001 -- best effort; the plain load below still works without torch in the process
+        pass
+
+
 def lib():
     """Loads libzjhip.so; raises (never falls back) when it is missing."""
     global _LIB
@@ -157,6 +178,7 @@ def lib():
     if not os.path.exists(p):
         raise ImportError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "or `make -C zune-jpeg_amd/csrc` (there is no CPU fallback)")
+    _share_torch_hip_runtime()
     L = C.CDLL(p)
     vp, sz, i16p, i32p, u8p = C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p
     L.zj_strerror.restype = C.c_char_p
@@ -185,6 +207,7 @@ def lib():
     L.zj_alloc_pinned.restype = vp
     L.zj_alloc_pinned.argtypes = [sz]
     L.zj_free_pinned.argtypes = [vp]
+    L.zj_set_thread_device.argtypes = [C.c_int]
     L.zj_device_alloc.restype = vp
     L.zj_device_alloc.argtypes = [vp, sz]
     L.zj_device_free.argtypes = [vp, vp]
