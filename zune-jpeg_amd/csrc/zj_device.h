@@ -45,9 +45,11 @@ typedef uint32_t V4 __attribute__((vector_size(16)));    // the same 16 bytes fo
 #else
 #define ZJ_ABL(debug, bit) 0  // the ablation switches exist only in the diagnostic build (tools/ablate.py)
 #endif
-// ZJ_NT (experiment knob, tools/ab_libs.sh): bit 0 = non-temporal pixel stores, bit 1 = non-temporal coefficient loads
+// ZJ_NT (tools/ab_libs.sh): bit 0 = non-temporal pixel stores everywhere, bit 1 = non-temporal coefficient loads,
+// bit 2 = non-temporal stores in color_copyout only.  Default 4: the staged stores write whole lines that nobody reads
+// again (+1.5 % measured); the 48-byte-per-lane direct stores of the other paths LOSE 2.5 % with it (round 1).
 #ifndef ZJ_NT
-#define ZJ_NT 0
+#define ZJ_NT 4
 #endif
 
 ZJ_DEV uint32_t as_u32(u16x2 v) { uint32_t r; __builtin_memcpy(&r, &v, 4); return r; }
@@ -509,6 +511,44 @@ ZJ_DEV void idct_block_packed(const U4 raw[8], const uint32_t* qp, uint32_t out[
     }
 }
 
+// The same for a HALO block, of which the colour phase reads one pixel column only (the last column of the block left
+// of the tile, the first of the one right of it): pass 1 in full, pass 2 reduced to the one output per row --
+// o0 = x0 + u3 or o7 = x0 - u3, five dot products instead of fourteen.  col[r] = that pixel of row r (0..255).
+ZJ_DEV void idct_block_packed_halo(const U4 raw[8], const uint32_t* qp, const bool last_col, int32_t col[8])
+{
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(raw);
+    uint32_t D[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) D[i] = as_u32(as_u16x2(w[i]) * as_u16x2(qp[i]));
+    uint32_t T[8][4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int ca = g == 0 ? 0 : (g == 1 ? 2 : (g == 2 ? 1 : 5)), cb = g == 0 ? 4 : (g == 1 ? 6 : (g == 2 ? 3 : 7));
+        PackedHalf h[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int c = e ? cb : ca, jj = c >> 1;
+            const uint32_t sel = (c & 1) ? 0x07060302u : 0x05040100u;
+            const uint32_t p04 = perm(D[4 * 4 + jj], D[0 * 4 + jj], sel), p26 = perm(D[6 * 4 + jj], D[2 * 4 + jj], sel);
+            const uint32_t p13 = perm(D[3 * 4 + jj], D[1 * 4 + jj], sel), p57 = perm(D[7 * 4 + jj], D[5 * 4 + jj], sel);
+            h[e] = idct_1d_dot(p04, p26, p13, p57, 512);
+        }
+        int32_t oa[8], ob[8];
+        idct_1d_dot_add(h[0], oa);
+        idct_1d_dot_add(h[1], ob);
+#pragma unroll
+        for (int i = 0; i < 8; i++) T[i][g] = pack_sar(oa[i], ob[i], 10);
+    }
+    constexpr int32_t bias2 = 512 + 65536 + (128 << 17);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int32_t x0 = dot2(T[r][1], pk16(5352, 2217), dot2(T[r][0], pk16(4096, 4096), bias2));
+        const int32_t u3 = dot2(T[r][3], pk16(3219, 1131), dot2z(T[r][2], pk16(5683, 4816)));
+        const int32_t o = (last_col ? wsub(x0, u3) : wadd(x0, u3)) >> 17;
+        col[r] = o < 0 ? 0 : (o > 255 ? 255 : o);
+    }
+}
+
 // Q1: DC-only blocks take the shortcut value: i16 wrapping product, floor >> 3, + 128, NOT clamped
 // (scalar.rs:48).  Returns the value replicated in both 16-bit lanes.
 ZJ_DEV uint32_t dc_only_value(uint32_t w0, int32_t q0, const int clamp = 0)
@@ -556,10 +596,14 @@ ZJ_DEV int tri1(int near_, int far_) { return (int)(int16_t)(uint16_t)(3 * near_
 // Tile width (TWC chroma block columns) is chosen so that the tile's blocks fill the workgroup's
 // waves: with one lane per block and 256 lanes, 4:2:0->RGB has 12*TWC + 8 blocks -> TWC = 20 (248).
 template <int HS, int VS, bool CHROMA> struct TileWidth;
+// 4:2:0 -> RGB: 12*TWC + 8 blocks.  Round 1 ran TWC = 20 (248 of 256 lanes busy).  With the packed generation TWC = 16
+// measures 2.5 % faster (tools/ab_libs.sh, profiles/r02_*): 256 pixels = exactly two colour rounds per wave, 4096-pixel
+// rows split into whole tiles, and the blocks sort into pure waves (128 luma | 64 chroma | 8 halo).  12 and 24 are
+// 10-30 % slower, 10 equals 20.
 #ifndef ZJ_TWC_HV
-#define ZJ_TWC_HV 20
+#define ZJ_TWC_HV 16
 #endif
-template <> struct TileWidth<2, 2, true> { static constexpr int TWC = ZJ_TWC_HV; }; // 20: 248 blocks, 320 px
+template <> struct TileWidth<2, 2, true> { static constexpr int TWC = ZJ_TWC_HV; };
 template <> struct TileWidth<2, 1, true> { static constexpr int TWC = 31; };   // 8*TWC+8 = 256, 496 px
 template <> struct TileWidth<1, 2, true> { static constexpr int TWC = 64; };   // 4*TWC = 256, 512 px
 template <> struct TileWidth<1, 1, true> { static constexpr int TWC = 84; };   // 3*TWC = 252, 672 px
@@ -606,6 +650,8 @@ struct Cfg {
     static constexpr int LUT_BYTES = ((2 * LUT_N * 2 + 15) / 16) * 16;
     static constexpr int CBYTES = CHROMA ? 2 * CSZ * 2 : 0;
     static constexpr bool TSCAP = OUT == OUT_RGB || OUT == OUT_YCBCR; // 3-byte interleaved outputs: staged stores
+    // the halo blocks (one pixel column each) sit alone in the last wave: they take the single-column transform
+    static constexpr bool HALO_PURE = CHROMA && HALO && (NYB + 2 * CBR * TWC) % 64 == 0;
     template <int GEN> struct L {
         static constexpr int YPX = GEN == GEN_PACKED ? 1 : 2;        // bytes per staged luma sample
         // Cb plane, then Cr.  Packed: a wave's round reuses the 16 luma bytes of each of its 64 items as store staging
@@ -725,10 +771,23 @@ ZJ_DEV BlockLoc locate(const Params& p, const TileId t, const int b, char* lds)
         return L;
     }
     if (!C::CHROMA || b >= C::NBLK) return L;
+    // chroma: the full blocks of Cb, the full blocks of Cr, then the halo blocks (both components) -- with TWC = 16
+    // that fills waves 0-1 with luma, wave 2 with chroma and leaves the 8 halo blocks alone in the last wave, which
+    // then runs the single-column transform (idct_block_packed_halo) as a wave-uniform branch
     const int cb_ = b - C::NYB;
-    const int comp = cb_ < C::NCB ? 1 : 2;
-    const int bb = comp == 1 ? cb_ : cb_ - C::NCB;
-    const int brow = bb / C::CCOLS, j = bb % C::CCOLS;
+    constexpr int NFULL = C::CBR * C::TWC; // full chroma blocks per component
+    int comp, brow, j;
+    if (cb_ < 2 * NFULL) {
+        comp = cb_ < NFULL ? 1 : 2;
+        const int bb = comp == 1 ? cb_ : cb_ - NFULL;
+        brow = bb / C::TWC;
+        j = bb % C::TWC + C::HALO;
+    } else {
+        const int hb = cb_ - 2 * NFULL;      // (comp, brow, side)
+        comp = 1 + hb / (2 * C::CBR);
+        brow = (hb / 2) % C::CBR;
+        j = (hb & 1) ? C::CCOLS - 1 : 0;
+    }
     const int cb0 = t.tile * C::TWC;
     const int nvalid = (cbw - cb0) < C::TWC ? (cbw - cb0) : C::TWC;
     int gcol, lcol;
@@ -878,6 +937,14 @@ ZJ_DEV void finish_block(const BlockLoc& L, const U4 raw[8], char* lds, const in
         for (int r = 0; r < 8; r++) *reinterpret_cast<U2*>(L.dst + r * L.pitch) = row;
         return;
     }
+    if (C::HALO_PURE && L.halo != 0 && cls == 1) { // wave-uniform: the halo blocks have a wave of their own
+        ZJ_NO_IF_CONVERT();
+        int32_t col[8];
+        idct_block_packed_halo(raw, tab, L.halo == 1, col);
+#pragma unroll
+        for (int r = 0; r < 8; r++) *reinterpret_cast<int16_t*>(L.dst + r * L.pitch) = (int16_t)col[r];
+        return;
+    }
     uint32_t b[16];
     if (cls == 1) {
         idct_block_packed(raw, tab, b);
@@ -900,10 +967,10 @@ ZJ_DEV void finish_block(const BlockLoc& L, const U4 raw[8], char* lds, const in
 // ------------------------------------------------------------------------------------------------
 // Phase 2: up-sample + colour-convert + store.  One item = 16 consecutive pixels of one row.
 // ------------------------------------------------------------------------------------------------
-ZJ_DEV void store16(uint8_t* p, const U4& v)
+ZJ_DEV void store16(uint8_t* p, const U4& v, const bool staged = false)
 {
 #if !defined(ZJ_EMU)
-    if (ZJ_NT & 1) { const V4 t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<V4*>(p)); return; }
+    if ((ZJ_NT & 1) || ((ZJ_NT & 4) && staged)) { const V4 t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<V4*>(p)); return; }
 #endif
     *reinterpret_cast<U4*>(p) = v;
 }
@@ -1311,18 +1378,18 @@ ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid, char* 
     const bool plain_round = nvg == C::NGRP && rows_left >= C::SH && never < 0 && item0 + 64 <= C::NITEMS;
     if (plain_round) {
         const U4 v0 = *reinterpret_cast<const U4*>(src0), v1 = *reinterpret_cast<const U4*>(src1), v2 = *reinterpret_cast<const U4*>(src2);
-        store16(tile_out + o0, v0);
-        store16(tile_out + o1, v1);
-        store16(tile_out + o2, v2);
+        store16(tile_out + o0, v0, true);
+        store16(tile_out + o1, v1, true);
+        store16(tile_out + o2, v2, true);
         return;
     }
     ZJ_NO_IF_CONVERT();
     auto valid = [&](const int j, const int m, const int c) -> bool {
         return 3 * item0 + 64 * j + L < 3 * C::NITEMS && c < 3 * nvg && m < rows_left && c != never;
     };
-    if (valid(0, m0, c0)) store16(tile_out + o0, *reinterpret_cast<const U4*>(src0));
-    if (valid(1, m1, c1)) store16(tile_out + o1, *reinterpret_cast<const U4*>(src1));
-    if (valid(2, m2, c2)) store16(tile_out + o2, *reinterpret_cast<const U4*>(src2));
+    if (valid(0, m0, c0)) store16(tile_out + o0, *reinterpret_cast<const U4*>(src0), true);
+    if (valid(1, m1, c1)) store16(tile_out + o1, *reinterpret_cast<const U4*>(src1), true);
+    if (valid(2, m2, c2)) store16(tile_out + o2, *reinterpret_cast<const U4*>(src2), true);
 }
 
 // Are staged stores usable for this launch?  The early-tail shift writes into the piece before the lane's own, so

@@ -12,8 +12,15 @@
 #include "zj_device.h"
 #include "zj_launch.h"
 
+// launch bound, waves per SIMD.  Wide generation: 5 (the 24-bit transform holds 64 x i32 between its passes: 89 VGPRs;
+// 32.4 KB of LDS per workgroup allow 5 as well).  Packed generation: 6 -- its hot path fits 80 VGPRs (the spills the
+// bound causes, 44 bytes, are all inside the wide code it falls back to), a 256-pixel tile needs 26.4 KB of LDS, and six
+// workgroups per CU measure 1 % faster than five (tools/ab_libs.sh, profiles/r02_*).
 #ifndef ZJ_WAVES_PER_SIMD
 #define ZJ_WAVES_PER_SIMD 5
+#endif
+#ifndef ZJ_WAVES_PER_SIMD_PACKED
+#define ZJ_WAVES_PER_SIMD_PACKED 6
 #endif
 
 namespace zj {
@@ -49,7 +56,7 @@ template <int HS, int VS, int OUT, int GEN, bool FAST, bool TS>
 // 2nd launch bound = waves per SIMD: 5 workgroups of 4 waves per CU need <= 96 VGPRs; LDS (at most 32.7 KB
 // per workgroup for 4:2:0) allows exactly 5.  Measured with tools/occupancy.py: 5 and 4 workgroups per CU
 // run the same, 3 cost 7 %, 2 cost 29 % -- the bound keeps the kernel on the flat part.
-__global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), ZJ_WAVES_PER_SIMD) void zj_fused_kernel(const Params p)
+__global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAVES_PER_SIMD_PACKED : ZJ_WAVES_PER_SIMD)) void zj_fused_kernel(const Params p)
 {
     using C = Cfg<HS, VS, OUT>;
     __shared__ __attribute__((aligned(16))) char lds[GEN == GEN_PACKED ? C::LDS_PACKED : C::LDS_WIDE];
