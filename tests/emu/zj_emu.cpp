@@ -51,12 +51,23 @@ static void run(const Params& p)
         if (g_variant == 1) { tile_wide<C, HS, VS, OUT, FAST>(p, t, lds); continue; }
         for (int tid = 0; tid < C::NT; tid++) phase_setup<C, HS, VS, GEN_PACKED>(p, tid, lds);
         /* __syncthreads() */
-        for (int tid = 0; tid < C::NT; tid++) {
+        const int nblock_lanes = C::HALO_PURE ? C::HALO_T0 : C::NT;
+        for (int tid = 0; tid < nblock_lanes; tid++) {
             const BlockLoc L = locate<C, GEN_PACKED>(p, t, tid, lds);
             U4 raw[8];
             load_block(L, raw);
             if (L.valid) g_cls[classify_block((const uint32_t*)raw, lds_tab<C, GEN_PACKED>(lds) + TAB_DW * L.comp + 32)]++;
             finish_block<C, GEN_PACKED, NEED_Y16>(L, raw, lds, 0, p.clamp_dc);
+        }
+        if (C::HALO_PURE) { // the halo wave: one lane per block column; all lanes do pass 1, then all do pass 2
+            HaloLane H[64];
+            for (int hl = 0; hl < 64; hl++) {
+                H[hl] = halo_locate<C>(p, t, hl, lds);
+                int32_t s8[8];
+                halo_load(H[hl], s8);
+                halo_pass1<C>(H[hl], s8, lds);
+            }
+            for (int hl = 0; hl < 64; hl++) halo_pass2<C>(H[hl], lds, p.clamp_dc);
         }
         /* __syncthreads() */
         if (NEED_Y16 && *lds_flag<C>(lds) != 0) { // Q1 value outside a byte: the whole tile again, wide

@@ -511,44 +511,6 @@ ZJ_DEV void idct_block_packed(const U4 raw[8], const uint32_t* qp, uint32_t out[
     }
 }
 
-// The same for a HALO block, of which the colour phase reads one pixel column only (the last column of the block left
-// of the tile, the first of the one right of it): pass 1 in full, pass 2 reduced to the one output per row --
-// o0 = x0 + u3 or o7 = x0 - u3, five dot products instead of fourteen.  col[r] = that pixel of row r (0..255).
-ZJ_DEV void idct_block_packed_halo(const U4 raw[8], const uint32_t* qp, const bool last_col, int32_t col[8])
-{
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(raw);
-    uint32_t D[32];
-#pragma unroll
-    for (int i = 0; i < 32; i++) D[i] = as_u32(as_u16x2(w[i]) * as_u16x2(qp[i]));
-    uint32_t T[8][4];
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        const int ca = g == 0 ? 0 : (g == 1 ? 2 : (g == 2 ? 1 : 5)), cb = g == 0 ? 4 : (g == 1 ? 6 : (g == 2 ? 3 : 7));
-        PackedHalf h[2];
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-            const int c = e ? cb : ca, jj = c >> 1;
-            const uint32_t sel = (c & 1) ? 0x07060302u : 0x05040100u;
-            const uint32_t p04 = perm(D[4 * 4 + jj], D[0 * 4 + jj], sel), p26 = perm(D[6 * 4 + jj], D[2 * 4 + jj], sel);
-            const uint32_t p13 = perm(D[3 * 4 + jj], D[1 * 4 + jj], sel), p57 = perm(D[7 * 4 + jj], D[5 * 4 + jj], sel);
-            h[e] = idct_1d_dot(p04, p26, p13, p57, 512);
-        }
-        int32_t oa[8], ob[8];
-        idct_1d_dot_add(h[0], oa);
-        idct_1d_dot_add(h[1], ob);
-#pragma unroll
-        for (int i = 0; i < 8; i++) T[i][g] = pack_sar(oa[i], ob[i], 10);
-    }
-    constexpr int32_t bias2 = 512 + 65536 + (128 << 17);
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const int32_t x0 = dot2(T[r][1], pk16(5352, 2217), dot2(T[r][0], pk16(4096, 4096), bias2));
-        const int32_t u3 = dot2(T[r][3], pk16(3219, 1131), dot2z(T[r][2], pk16(5683, 4816)));
-        const int32_t o = (last_col ? wsub(x0, u3) : wadd(x0, u3)) >> 17;
-        col[r] = o < 0 ? 0 : (o > 255 ? 255 : o);
-    }
-}
-
 // Q1: DC-only blocks take the shortcut value: i16 wrapping product, floor >> 3, + 128, NOT clamped
 // (scalar.rs:48).  Returns the value replicated in both 16-bit lanes.
 ZJ_DEV uint32_t dc_only_value(uint32_t w0, int32_t q0, const int clamp = 0)
@@ -650,8 +612,10 @@ struct Cfg {
     static constexpr int LUT_BYTES = ((2 * LUT_N * 2 + 15) / 16) * 16;
     static constexpr int CBYTES = CHROMA ? 2 * CSZ * 2 : 0;
     static constexpr bool TSCAP = OUT == OUT_RGB || OUT == OUT_YCBCR; // 3-byte interleaved outputs: staged stores
-    // the halo blocks (one pixel column each) sit alone in the last wave: they take the single-column transform
-    static constexpr bool HALO_PURE = CHROMA && HALO && (NYB + 2 * CBR * TWC) % 64 == 0;
+    // the 8 halo blocks (one pixel column each is ever read) have the last wave to themselves: that wave works with
+    // one lane per block COLUMN instead of one lane per block (halo_pass1 / halo_pass2)
+    static constexpr bool HALO_PURE = CHROMA && HALO && (NYB + 2 * CBR * TWC) % 64 == 0 && 2 * CBR * 2 * 8 == 64;
+    static constexpr int HALO_T0 = NYB + 2 * CBR * TWC; // first lane of that wave
     template <int GEN> struct L {
         static constexpr int YPX = GEN == GEN_PACKED ? 1 : 2;        // bytes per staged luma sample
         // Cb plane, then Cr.  Packed: a wave's round reuses the 16 luma bytes of each of its 64 items as store staging
@@ -902,6 +866,98 @@ ZJ_DEV void bytes_to_rows(const uint32_t b[16], U4 px[8])
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Halo blocks, one lane per block COLUMN (GEN_PACKED with Cfg::HALO_PURE).
+// The colour phase reads ONE pixel column of a halo block (the last column of the block left of the tile, the first of
+// the one right of it).  A lane per block would spend a whole wave pass (8 of 64 lanes busy) on the tile's 8 halo
+// blocks -- 10 % of the tile's VALU work.  Here lane 8*h + j of the halo wave owns column j of halo block h:
+//   halo_locate  where the block's coefficients are, where its pixel column goes
+//   halo_load    the column's 8 coefficients (2-byte loads, in flight across the table barrier)
+//   halo_pass1   dequantize, column transform (pass 1 of scalar.rs:79-167, the exact 24-bit form: no guard), results
+//                to an LDS scratch (the store staging area, free until the colour phase), with the lane's "any AC" flag
+//   halo_pass2   lane i of a block reads row i of the scratch, forms the one output of that row -- o0 = x0 + u3 or
+//                o7 = x0 - u3 (scalar.rs:233-246), five multiply-adds per half -- or the DC-only shortcut value (Q1)
+// About 110 instructions per lane instead of 515.  All 64 lanes of a wave: LDS operations execute in order, no barrier.
+// Scratch per block (80 dwords): [k][j] pass-1 results (64), [64 + j] flags (8), [72] the block's DC coefficient.
+// ------------------------------------------------------------------------------------------------
+struct HaloLane { const int16_t* src; char* dst; int pitch; int comp; int hb; int j; bool last_col; };
+
+template <class C>
+ZJ_DEV HaloLane halo_locate(const Params& p, const TileId t, const int hl /* 0..63 */, char* lds)
+{
+    using LL = typename C::template L<GEN_PACKED>;
+    HaloLane H;
+    H.hb = hl >> 3; H.j = hl & 7;
+    H.comp = 1 + H.hb / (2 * C::CBR);
+    const int brow = (H.hb / 2) % C::CBR, side = H.hb & 1;
+    const int cbw = p.mcu_x, cb0 = t.tile * C::TWC;
+    const int nvalid = (cbw - cb0) < C::TWC ? (cbw - cb0) : C::TWC;
+    // the neighbour beyond the strip's first / last column is the other end of the row (Q4: one flat array)
+    const int gcol = side == 0 ? (cb0 > 0 ? cb0 - 1 : cbw - 1) : (cb0 + nvalid < cbw ? cb0 + nvalid : 0);
+    const int lcol = side == 0 ? C::COFF - 1 : C::COFF + 8 * nvalid;
+    const long long blk = (long long)(t.strip * C::CBR + brow) * cbw + gcol;
+    const int16_t* plane = (H.comp == 1 ? p.cb : p.cr) + (long long)t.frame * p.c_frame_stride;
+    H.src = plane + blk * 64 + H.j;
+    H.dst = lds + LL::C_OFF + ((H.comp - 1) * C::CSZ + (brow * 8) * C::CPITCH + lcol) * 2;
+    H.pitch = C::CPITCH * 2;
+    H.last_col = side == 0; // left halo: the block's LAST pixel column
+    return H;
+}
+ZJ_DEV void halo_load(const HaloLane& H, int32_t s[8])
+{
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] = H.src[8 * k];
+}
+template <class C> ZJ_DEV int32_t* lds_halo_scratch(char* lds, const int hb) { return reinterpret_cast<int32_t*>(lds + C::template L<GEN_PACKED>::X_OFF) + 80 * hb; }
+
+template <class C>
+ZJ_DEV void halo_pass1(const HaloLane& H, const int32_t s[8], char* lds)
+{
+    const uint16_t* q = reinterpret_cast<const uint16_t*>(lds_tab<C, GEN_PACKED>(lds) + TAB_DW * H.comp);
+    int32_t* sc = lds_halo_scratch<C>(lds, H.hb);
+    int32_t any = H.j == 0 ? 0 : s[0];
+    int32_t d[8], o[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (k > 0) any |= s[k];
+        d[k] = mul24(s[k], (int32_t)q[8 * k + H.j]); // dequantize (scalar.rs:308)
+    }
+    idct_1d(d, 512, o);
+#pragma unroll
+    for (int k = 0; k < 8; k++) sc[8 * k + H.j] = o[k] >> 10;
+    sc[64 + H.j] = any;
+    if (H.j == 0) sc[72] = s[0];
+}
+
+template <class C>
+ZJ_DEV void halo_pass2(const HaloLane& H, char* lds, const int clamp_dc)
+{
+    const int32_t* sc = lds_halo_scratch<C>(lds, H.hb);
+    const int i = H.j; // this lane finishes row i of its block
+    const U4 f0 = *reinterpret_cast<const U4*>(sc + 64), f1 = *reinterpret_cast<const U4*>(sc + 68);
+    const uint32_t any = f0.x | f0.y | f0.z | f0.w | f1.x | f1.y | f1.z | f1.w;
+    int32_t v;
+    if (any == 0) { // DC-only block (scalar.rs:45-74): the shortcut value, not clamped (Q1)
+        const uint16_t* q = reinterpret_cast<const uint16_t*>(lds_tab<C, GEN_PACKED>(lds) + TAB_DW * H.comp);
+        v = (int32_t)(int16_t)(dc_only_value((uint32_t)sc[72], (int32_t)q[0], clamp_dc) & 0xffffu);
+    } else {
+        const U4 a = *reinterpret_cast<const U4*>(sc + 8 * i), b = *reinterpret_cast<const U4*>(sc + 8 * i + 4);
+        const int32_t t0 = (int32_t)a.x, t1 = (int32_t)a.y, t2 = (int32_t)a.z, t3 = (int32_t)a.w;
+        const int32_t t4 = (int32_t)b.x, t5 = (int32_t)b.y, t6 = (int32_t)b.z, t7 = (int32_t)b.w;
+        constexpr int32_t bias2 = 512 + 65536 + (128 << 17);
+        // x0 = fsh(t0 + t4) + (t2 + t6) * 2217 + t2 * 3135 + bias; u3 = the first row of the odd 4x4 matrix (idct_1d_mul)
+        int32_t x0 = mad24(t2, 2217 + 3135, wadd(wshl(wadd(t0, t4), 12), bias2));
+        x0 = mad24(t6, 2217, x0);
+        int32_t u3 = mul24(t1, 6149 + 4816 - 3685 - 1597);
+        u3 = mad24(t7, 4816 - 3685, u3);
+        u3 = mad24(t5, 4816 - 1597, u3);
+        u3 = mad24(t3, 4816, u3);
+        v = (H.last_col ? wsub(x0, u3) : wadd(x0, u3)) >> 17;
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    }
+    *reinterpret_cast<int16_t*>(H.dst + i * H.pitch) = (int16_t)v;
+}
+
 // GEN_WIDE: the round-1 form.  GEN_PACKED: luma leaves as bytes, chroma as i16; NEED_Y16 = the output does
 // arithmetic on luma (RGB family), so an unclamped DC-only luma value outside 0..255 (Q1) cannot be staged as
 // a byte: the lane raises the tile's flag and the workgroup redoes the tile with the wide code.  (Gray and
@@ -935,14 +991,6 @@ ZJ_DEV void finish_block(const BlockLoc& L, const U4 raw[8], char* lds, const in
         const U2 row = {b, b};
 #pragma unroll
         for (int r = 0; r < 8; r++) *reinterpret_cast<U2*>(L.dst + r * L.pitch) = row;
-        return;
-    }
-    if (C::HALO_PURE && L.halo != 0 && cls == 1) { // wave-uniform: the halo blocks have a wave of their own
-        ZJ_NO_IF_CONVERT();
-        int32_t col[8];
-        idct_block_packed_halo(raw, tab, L.halo == 1, col);
-#pragma unroll
-        for (int r = 0; r < 8; r++) *reinterpret_cast<int16_t*>(L.dst + r * L.pitch) = (int16_t)col[r];
         return;
     }
     uint32_t b[16];

@@ -66,13 +66,29 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAV
     // luma enters arithmetic for the RGB family only; gray / YCbCr outputs keep its low byte (Q7)
     constexpr bool NEED_Y16 = OUT == OUT_RGB || OUT == OUT_RGBA || OUT == OUT_RGB_CHW;
     ZJ_SETPRIO(1, 3);
-    const BlockLoc L = locate<C, GEN_PACKED>(p, t, tid, lds);
+    // the wave of the halo blocks works with one lane per block column (zj_device.h: halo_*); a wave-uniform split
+    const bool halo_wave = C::HALO_PURE && __builtin_amdgcn_readfirstlane(tid) >= C::HALO_T0;
+    BlockLoc L;
+    HaloLane H;
     U4 raw[8];
-    load_block(L, raw, p.debug);
+    int32_t hs8[8];
+    if (halo_wave) {
+        H = halo_locate<C>(p, t, tid - C::HALO_T0, lds);
+        halo_load(H, hs8);
+    } else {
+        L = locate<C, GEN_PACKED>(p, t, tid, lds);
+        load_block(L, raw, p.debug);
+    }
     ZJ_SETPRIO(1, 0);
     phase_setup<C, HS, VS, GEN_PACKED>(p, tid, lds);
     __syncthreads();
-    finish_block<C, GEN_PACKED, NEED_Y16>(L, raw, lds, p.debug, p.clamp_dc);
+    if (halo_wave) {
+        halo_pass1<C>(H, hs8, lds);
+        ZJ_WAVE_FENCE();
+        halo_pass2<C>(H, lds, p.clamp_dc);
+    } else {
+        finish_block<C, GEN_PACKED, NEED_Y16>(L, raw, lds, p.debug, p.clamp_dc);
+    }
     // The coefficient loads are consumed inside exec-masked regions, so on the paths that skip those regions the
     // compiler still counts them as outstanding and would put `s_waitcnt vmcnt(0)` in front of every later reuse of
     // their registers -- in the store rounds below that wait also drains the round's own stores (gfx9 has one counter
