@@ -568,7 +568,17 @@ template <int HS, int VS, bool CHROMA> struct TileWidth;
 template <> struct TileWidth<2, 2, true> { static constexpr int TWC = ZJ_TWC_HV; };
 template <> struct TileWidth<2, 1, true> { static constexpr int TWC = 31; };   // 8*TWC+8 = 256, 496 px
 template <> struct TileWidth<1, 2, true> { static constexpr int TWC = 64; };   // 4*TWC = 256, 512 px
-template <> struct TileWidth<1, 1, true> { static constexpr int TWC = 84; };   // 3*TWC = 252, 672 px
+// 4:4:4 with chroma: 3*TWC blocks.  Round 1 ran TWC = 84 (252 lanes busy, 672 pixels).  TWC = 64 with 256 threads is
+// 15 % faster (tools/ab_libs_w.sh 444-rgb): 192 blocks on three waves (the fourth idles through the IDCT), but 512 pixels
+// x 8 rows = 256 items = exactly one colour round for four waves, and 4096-pixel rows split into whole tiles (672 leaves a
+// 10 % tile).  80: +3 %, 42: -2 %, 64 with 192 threads: +12 %.
+#ifndef ZJ_TWC_444
+#define ZJ_TWC_444 64
+#endif
+#ifndef ZJ_NT_MIN_444
+#define ZJ_NT_MIN_444 256
+#endif
+template <> struct TileWidth<1, 1, true> { static constexpr int TWC = ZJ_TWC_444; };
 template <> struct TileWidth<2, 2, false> { static constexpr int TWC = 32; };  // 8*TWC = 256 luma blocks
 template <> struct TileWidth<2, 1, false> { static constexpr int TWC = 64; };
 template <> struct TileWidth<1, 2, false> { static constexpr int TWC = 128; };
@@ -606,7 +616,9 @@ struct Cfg {
     static constexpr int NGRP = TWY / 16;              // 16-pixel groups per tile row
     static constexpr int NITEMS = SH * NGRP;
     static constexpr int NBLK = NYB + (CHROMA ? 2 * NCB : 0);        // blocks per tile
-    static constexpr int NT = (NBLK + 63) / 64 * 64;                 // threads per workgroup
+    static constexpr int NT_BLK = (NBLK + 63) / 64 * 64;            // one lane per block
+    static constexpr int NT_MIN = (HS == 1 && VS == 1 && CHROMA) ? ZJ_NT_MIN_444 : 0;
+    static constexpr int NT = NT_BLK > NT_MIN ? NT_BLK : NT_MIN;     // threads per workgroup
     static constexpr int NW = NT / 64;
     static constexpr int LUT_N = SH + 2;
     static constexpr int LUT_BYTES = ((2 * LUT_N * 2 + 15) / 16) * 16;
@@ -1138,6 +1150,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
     const int cb0 = t.tile * C::TWC;
     const int nvalid = (cbw - cb0) < C::TWC ? (cbw - cb0) : C::TWC;
     const bool left_wrap = cb0 == 0, right_wrap = cb0 + C::TWC >= cbw;
+    const bool edge_tile = HS == 2 && (left_wrap || right_wrap); // workgroup-uniform
     const int x0 = t.tile * C::TWY;
     const int ncomp = OUT == OUT_GRAY ? 1 : (OUT == OUT_RGBA ? 4 : 3);
     const long long row_bytes = OUT == OUT_RGB_CHW ? (long long)W : (long long)W * ncomp; // CHW: one plane's row
@@ -1197,24 +1210,35 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
                                  // HS==1: natural pairs (px 2k, 2k+1)
         // LDS offsets (bytes) of the chroma rows behind up-sampled row m, and behind rows
         // m-1 / m+1 where the flat-array neighbour wraps to the other end of the strip (Q4)
-        const bool first = HS == 2 && (g == 0) && left_wrap;                  // chroma column 0 of the strip
-        const bool last = HS == 2 && (8 * g + 8 == 8 * nvalid) && right_wrap; // last chroma column
+        // Only the first / last tile of a row (a workgroup-uniform property) holds the strip's first / last chroma
+        // column: every other tile skips the wrap logic and the patches below on a scalar branch.
+        bool first = false, last = false;
+        int oa, ob, oal, obl, oar, obr;
+        if (VS == 2) {
+            const int16_t* lut = lds_lut<C, GEN>(lds);
+            oa = lut[m + 1]; ob = lut[C::LUT_N + m + 1];
+        } else {
+            oa = ob = m * C::CPITCH * 2;
+        }
+        oal = oar = oa; obl = obr = ob;
+        if (edge_tile) {
+            ZJ_NO_IF_CONVERT();
+            first = (g == 0) && left_wrap;                  // chroma column 0 of the strip
+            last = (8 * g + 8 == 8 * nvalid) && right_wrap; // last chroma column
+            if (VS == 2) {
+                const int16_t* lut = lds_lut<C, GEN>(lds);
+                const int im = m + 1, il = im - (first ? 1 : 0), ir = im + (last ? 1 : 0);
+                oal = lut[il]; obl = lut[C::LUT_N + il];
+                oar = lut[ir]; obr = lut[C::LUT_N + ir];
+            } else {
+                oal = obl = (first && m > 0 ? m - 1 : m) * C::CPITCH * 2;
+                oar = obr = (last && m < C::SH - 1 ? m + 1 : m) * C::CPITCH * 2;
+            }
+        }
         // ZJ_FLAG_EDGE_REPLICATE (extension): the neighbour beyond a row's end is the end sample itself, in every row,
         // so neither the wrap to the previous / next row nor the strip-end special cases apply
         const bool rep_first = first && p.edge_rep, rep_last = last && p.edge_rep;
         const bool no_left = first && m == 0 && !p.edge_rep, no_right = last && m == C::SH - 1 && !p.edge_rep;
-        int oa, ob, oal, obl, oar, obr;
-        if (VS == 2) {
-            const int16_t* lut = lds_lut<C, GEN>(lds);
-            const int im = m + 1, il = im - (first ? 1 : 0), ir = im + (last ? 1 : 0);
-            oa = lut[im]; ob = lut[C::LUT_N + im];
-            oal = lut[il]; obl = lut[C::LUT_N + il];
-            oar = lut[ir]; obr = lut[C::LUT_N + ir];
-        } else {
-            oa = ob = m * C::CPITCH * 2;
-            oal = obl = (first && m > 0 ? m - 1 : m) * C::CPITCH * 2;
-            oar = obr = (last && m < C::SH - 1 ? m + 1 : m) * C::CPITCH * 2;
-        }
 #pragma unroll
         for (int ch = 0; ch < 2; ch++) {
             const char* cp = lds + LL::C_OFF + ch * C::CSZ * 2;
@@ -1265,12 +1289,15 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
                     dst[4 + k] = as_u32(sar(t3 + as_u16x2(R), 2)); // odd outputs:  px 4k+1, 4k+3
                 }
                 // the three unfiltered / mis-weighted samples of a strip (upsampler/scalar.rs:13,55,57)
-                if (no_left) dst[0] = (dst[0] & 0xffff0000u) | (vm[0] & 0xffffu);       // out[0] = in[0]
-                if (no_right) {
-                    const uint32_t o7 = dst[7];
-                    // out[2n-2] = (3*in[n-2] + in[n-1] + 2) >> 2  == the odd output of column n-2
-                    dst[3] = (dst[3] & 0x0000ffffu) | (o7 << 16);                        // px 14 <- O(px 13)
-                    dst[7] = (o7 & 0x0000ffffu) | (vm[3] & 0xffff0000u);                 // px 15 = in[n-1]
+                if (edge_tile) {
+                    ZJ_NO_IF_CONVERT();
+                    if (no_left) dst[0] = (dst[0] & 0xffff0000u) | (vm[0] & 0xffffu);       // out[0] = in[0]
+                    if (no_right) {
+                        const uint32_t o7 = dst[7];
+                        // out[2n-2] = (3*in[n-2] + in[n-1] + 2) >> 2  == the odd output of column n-2
+                        dst[3] = (dst[3] & 0x0000ffffu) | (o7 << 16);                        // px 14 <- O(px 13)
+                        dst[7] = (o7 & 0x0000ffffu) | (vm[3] & 0xffff0000u);                 // px 15 = in[n-1]
+                    }
                 }
             }
         }
