@@ -582,7 +582,13 @@ template <> struct TileWidth<1, 1, true> { static constexpr int TWC = ZJ_TWC_444
 template <> struct TileWidth<2, 2, false> { static constexpr int TWC = 32; };  // 8*TWC = 256 luma blocks
 template <> struct TileWidth<2, 1, false> { static constexpr int TWC = 64; };
 template <> struct TileWidth<1, 2, false> { static constexpr int TWC = 128; };
-template <> struct TileWidth<1, 1, false> { static constexpr int TWC = 128; }; // 128 blocks, 2 waves
+#ifndef ZJ_TWC_GRAY
+#define ZJ_TWC_GRAY 128
+#endif
+#ifndef ZJ_NT_MIN_GRAY
+#define ZJ_NT_MIN_GRAY 256 // 128 blocks = two waves of IDCT, but 512 items: four waves for the copy-out phase (+3.5 %)
+#endif
+template <> struct TileWidth<1, 1, false> { static constexpr int TWC = ZJ_TWC_GRAY; }; // 128 blocks, 2 waves
 
 // OUT_RGBA (R G B 255 per pixel) and OUT_RGB_CHW (three u8 planes) are extensions beyond the reference
 // (SURVEY 8f-3/4); both place every pixel at its own position (no Q5/Q6), like Params::plain does for OUT_RGB.
@@ -617,7 +623,7 @@ struct Cfg {
     static constexpr int NITEMS = SH * NGRP;
     static constexpr int NBLK = NYB + (CHROMA ? 2 * NCB : 0);        // blocks per tile
     static constexpr int NT_BLK = (NBLK + 63) / 64 * 64;            // one lane per block
-    static constexpr int NT_MIN = (HS == 1 && VS == 1 && CHROMA) ? ZJ_NT_MIN_444 : 0;
+    static constexpr int NT_MIN = (HS == 1 && VS == 1) ? (CHROMA ? ZJ_NT_MIN_444 : ZJ_NT_MIN_GRAY) : 0;
     static constexpr int NT = NT_BLK > NT_MIN ? NT_BLK : NT_MIN;     // threads per workgroup
     static constexpr int NW = NT / 64;
     static constexpr int LUT_N = SH + 2;
