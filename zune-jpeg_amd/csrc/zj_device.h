@@ -643,7 +643,10 @@ struct Cfg {
         static constexpr int LUT_OFF = TAB_OFF + TAB_BYTES;
         static constexpr int FLAG_OFF = LUT_OFF + LUT_BYTES;         // GEN_PACKED: "redo this tile wide"
         static constexpr int X_OFF = FLAG_OFF + 16;                  // GEN_PACKED: per wave 2080 bytes of store staging (XSTAGE)
-        static constexpr int BYTES = GEN == GEN_PACKED ? X_OFF + (TSCAP ? NW * XSTAGE : 0) : FLAG_OFF;
+        // after X_OFF: the store staging of the 3-byte outputs, and (before the colour phase) the halo wave's scratch
+        static constexpr int X_STAGE = TSCAP ? NW * XSTAGE : 0;
+        static constexpr int X_HALO = HALO_PURE ? 8 * 80 * 4 : 0;
+        static constexpr int BYTES = GEN == GEN_PACKED ? X_OFF + (X_STAGE > X_HALO ? X_STAGE : X_HALO) : FLAG_OFF;
         static_assert(C_OFF % 16 == 0 && TAB_OFF % 16 == 0, "16-byte alignment of the planes");
     };
     static constexpr int LDS_WIDE = L<GEN_WIDE>::BYTES;
