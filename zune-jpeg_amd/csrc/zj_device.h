@@ -594,7 +594,6 @@ template <> struct TileWidth<1, 1, false> { static constexpr int TWC = ZJ_TWC_GR
 // (SURVEY 8f-3/4); both place every pixel at its own position (no Q5/Q6), like Params::plain does for OUT_RGB.
 enum { OUT_RGB = 0, OUT_GRAY = 1, OUT_YCBCR = 2, OUT_RGBA = 3, OUT_RGB_CHW = 4 };
 enum { GEN_WIDE = 0, GEN_PACKED = 1 };
-constexpr int XSTAGE = 2080; // staged stores: bytes of LDS staging per wave (129 pieces, rounded up), see piece_addr
 
 // LDS layouts (byte offsets).
 //   GEN_WIDE    Yp[SH][TWY] i16 | Cb[CROWS][CPITCH] i16 | Cr[..] | tables | vertical LUT
@@ -629,7 +628,12 @@ struct Cfg {
     static constexpr int LUT_N = SH + 2;
     static constexpr int LUT_BYTES = ((2 * LUT_N * 2 + 15) / 16) * 16;
     static constexpr int CBYTES = CHROMA ? 2 * CSZ * 2 : 0;
-    static constexpr bool TSCAP = OUT == OUT_RGB || OUT == OUT_YCBCR; // 3-byte interleaved outputs: staged stores
+    // interleaved outputs leave through staged stores: PPI 16-byte pieces per 16-pixel item (3 or 4 bytes per pixel)
+    static constexpr bool TSCAP = OUT == OUT_RGB || OUT == OUT_YCBCR || OUT == OUT_RGBA;
+    static constexpr int PPI = OUT == OUT_RGBA ? 4 : 3;
+    // pieces of a wave's round that reuse the round's luma bytes (whole items only), and the staging for the rest
+    static constexpr int INPL = 64 / PPI * PPI;                       // 63 | 64
+    static constexpr int XSTAGE = ((64 * PPI - INPL) * 16 + 31) / 32 * 32; // 2080 | 3072 bytes per wave
     // the 8 halo blocks (one pixel column each is ever read) have the last wave to themselves: that wave works with
     // one lane per block COLUMN instead of one lane per block (halo_pass1 / halo_pass2)
     static constexpr bool HALO_PURE = CHROMA && HALO && (NYB + 2 * CBR * TWC) % 64 == 0 && 2 * CBR * 2 * 8 == 64;
@@ -651,12 +655,12 @@ struct Cfg {
     };
     static constexpr int LDS_WIDE = L<GEN_WIDE>::BYTES;
     static constexpr int LDS_PACKED = L<GEN_PACKED>::BYTES > LDS_WIDE ? L<GEN_PACKED>::BYTES : LDS_WIDE;
-    static constexpr int PIECES_PER_ROW = 3 * NGRP; // 16-byte pieces of a 3-byte-per-pixel tile row
+    static constexpr int PIECES_PER_ROW = PPI * NGRP; // 16-byte pieces of a tile row
     // division of a piece index by PIECES_PER_ROW as multiply + shift, exact over every index color_copyout forms
     static constexpr int PPR_MAGIC = (1 << 20) / PIECES_PER_ROW + 1;
     static constexpr bool ppr_magic_ok()
     {
-        for (int q = 0; q < 3 * ((NITEMS + NT - 1) / NT * NT) + 192; q++)
+        for (int q = 0; q < PPI * ((NITEMS + NT - 1) / NT * NT) + 64 * PPI; q++)
             if ((int)(((unsigned)q * (unsigned)PPR_MAGIC) >> 20) != q / PIECES_PER_ROW) return false;
         return true;
     }
@@ -1109,21 +1113,22 @@ ZJ_DEV void store_clip(uint8_t* orow, long long off, const uint32_t* w, int ndw,
 }
 
 // What a lane hands to the staged-store half of a round (TS): its item's 48 output bytes and where they go.
-//   kind 0: nothing (no item)   1: pieces 3L, 3L+1, 3L+2            2: as 1 without the third piece
+//   kind 0: nothing (no item)   1: pieces PPI*L ... PPI*L + PPI-1   2: (RGB) as 1 without the third piece
 //        3: the row's last group under the early-tail quirk (Q5): pieces 3L-1, 3L, 3L+1, then zeros in 3L+2 (Q6)
-struct ItemOut { U4 s0, s1, s2; int kind; };
+struct ItemOut { U4 s0, s1, s2, s3; int kind; };
 
-// LDS address of piece q (0..191) of a wave's round.  Pieces 0..62 (the 48-byte items of lanes 0..20) reuse the luma
-// bytes the wave's 64 items have just consumed (16 bytes each, contiguous because consecutive items are consecutive
-// 16-pixel groups); pieces 63..191 (lanes 21..63) live in the wave's XSTAGE bytes of staging.  The split falls on an
-// item boundary, so a lane's three pieces are contiguous and only ONE piece address per lane needs a select.
+// LDS address of piece q (0 .. 64*PPI-1) of a wave's round.  The first INPL pieces (whole items: lanes 0..20 for the
+// 48-byte items, 0..15 for the 64-byte ones) reuse the luma bytes the wave's 64 items have just consumed (16 bytes each,
+// contiguous because consecutive items are consecutive 16-pixel groups); the others live in the wave's XSTAGE bytes of
+// staging.  The split falls on an item boundary, so a lane's pieces are contiguous and only ONE address per lane needs a
+// select.
 template <class C>
 ZJ_DEV char* piece_addr(char* lds, const int item0, const int wave, const int q)
 {
     using LL = typename C::template L<GEN_PACKED>;
     char* const ybase = lds + 16 * item0;
-    char* const xbase = lds + LL::X_OFF + XSTAGE * wave - 16 * 63;
-    return (q < 63 ? ybase : xbase) + 16 * q;
+    char* const xbase = lds + LL::X_OFF + C::XSTAGE * wave - 16 * C::INPL;
+    return (q < C::INPL ? ybase : xbase) + 16 * q;
 }
 
 template <class C>
@@ -1132,7 +1137,7 @@ ZJ_DEV void stage_item(const ItemOut& io, const int tid, char* lds, const int ro
     if (io.kind == 0) return;
     const int wave = tid >> 6, lane = tid & 63;
     const int item0 = 64 * wave + round * C::NT;
-    if (io.kind == 3) { // rare: one lane per row of the tile that holds the row's end
+    if (C::PPI == 3 && io.kind == 3) { // rare: one lane per row of the tile that holds the row's end
         const U4 z = {0, 0, 0, 0};
         *reinterpret_cast<U4*>(piece_addr<C>(lds, item0, wave, 3 * lane - 1)) = io.s0; // launcher: lane > 0 here
         *reinterpret_cast<U4*>(piece_addr<C>(lds, item0, wave, 3 * lane)) = io.s1;
@@ -1140,10 +1145,11 @@ ZJ_DEV void stage_item(const ItemOut& io, const int tid, char* lds, const int ro
         *reinterpret_cast<U4*>(piece_addr<C>(lds, item0, wave, 3 * lane + 2)) = z;
         return;
     }
-    U4* const dst = reinterpret_cast<U4*>(piece_addr<C>(lds, item0, wave, 3 * lane)); // 48 contiguous bytes
+    U4* const dst = reinterpret_cast<U4*>(piece_addr<C>(lds, item0, wave, C::PPI * lane)); // PPI * 16 contiguous bytes
     dst[0] = io.s0;
     dst[1] = io.s1;
-    if (io.kind == 1) dst[2] = io.s2;
+    if (C::PPI == 4) { dst[2] = io.s2; dst[3] = io.s3; }
+    else if (io.kind == 1) dst[2] = io.s2;
 }
 
 // TS (staged stores, GEN_PACKED, FAST RGB / YCbCr only): processes ONE round (item = tid + round * NT) and, instead
@@ -1325,7 +1331,11 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
                 if (HS == 2) pack_rgba4(c[k], c[4 + k], q[4 * k], q[4 * k + 2], q[4 * k + 1], q[4 * k + 3]);
                 else pack_rgba4(c[2 * k], c[2 * k + 1], q[4 * k], q[4 * k + 1], q[4 * k + 2], q[4 * k + 3]);
             }
-            if (FAST) {
+            if (TS) {
+                io->s0 = U4{q[0], q[1], q[2], q[3]}; io->s1 = U4{q[4], q[5], q[6], q[7]};
+                io->s2 = U4{q[8], q[9], q[10], q[11]}; io->s3 = U4{q[12], q[13], q[14], q[15]};
+                io->kind = 1;
+            } else if (FAST) {
                 uint8_t* o = orow + 4ll * px0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) { const U4 v = {q[4 * k], q[4 * k + 1], q[4 * k + 2], q[4 * k + 3]}; store16(o + 16 * k, v); }
@@ -1424,19 +1434,20 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
     }
 }
 
-// Second half of a staged-store round: lane L of a wave stores pieces 64*j + L (j = 0, 1, 2) of the 192 pieces
+// Second half of a staged-store round: lane L of a wave stores pieces 64*j + L (j = 0 .. PPI-1) of the 64*PPI pieces
 // its wave staged, i.e. every store instruction writes 1024 contiguous bytes of the tile's rows (row segments of
-// PIECES_PER_ROW pieces), instead of 64 pieces 48 bytes apart.
+// PIECES_PER_ROW pieces), instead of 64 pieces 48 (64) bytes apart.
 template <class C, int OUT>
 ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid, char* lds, const int round)
 {
     using LL = typename C::template L<GEN_PACKED>;
+    constexpr int PPI = C::PPI;
     const int P = p.mcu_x * 8 * (C::TWYB / C::TWC);
     const int x0 = t.tile * C::TWY;
     const int nvg = (P - x0) / 16 < C::NGRP ? (P - x0) / 16 : C::NGRP; // valid 16-pixel groups of this tile
-    const uint32_t row_bytes = 3u * (uint32_t)p.width;
+    const uint32_t row_bytes = (uint32_t)(PPI == 4 ? 4 : 3) * (uint32_t)p.width;
     // everything up to here is uniform: a scalar base address, 32-bit per-lane offsets below
-    uint8_t* const tile_out = p.out + (long long)t.frame * p.out_frame_stride + (long long)t.strip * C::SH * row_bytes + 3ll * x0;
+    uint8_t* const tile_out = p.out + (long long)t.frame * p.out_frame_stride + (long long)t.strip * C::SH * row_bytes + (long long)(PPI == 4 ? 4 : 3) * x0;
     const int w = uniform(tid >> 6), L = tid & 63;
     const int item0 = 64 * w + round * C::NT;  // first item of this wave's round
     if (item0 >= C::NITEMS) return;            // (the last round of a tile is partly empty)
@@ -1445,35 +1456,35 @@ ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid, char* 
     const int never = (OUT == OUT_RGB && !p.plain && !p.zero_fill && row_end_here) ? 3 * nvg - 1 : -1;
     const int rows_left = p.height - t.strip * C::SH; // > 0
     const char* const ybase = lds + 16 * item0;
-    const char* const xbase = lds + LL::X_OFF + XSTAGE * w - 16 * 63;
-    const char* const src0 = (L < 63 ? ybase : xbase) + 16 * L;
-    const char* const src1 = xbase + 16 * (64 + L);
-    const char* const src2 = xbase + 16 * (128 + L);
-    auto offset = [&](const int j, int& m, int& c) -> uint32_t {
-        const int Q = 3 * item0 + 64 * j + L;   // piece index inside the tile
-        m = (int)(((uint32_t)Q * (uint32_t)C::PPR_MAGIC) >> 20); // Q / PIECES_PER_ROW (3 instructions; checked in Cfg)
-        c = Q - m * C::PIECES_PER_ROW;
-        return (uint32_t)mul24(m, (int32_t)row_bytes) + 16u * (uint32_t)c; // m < 32, row_bytes < 2^18
-    };
-    int m0, c0, m1, c1, m2, c2;
-    const uint32_t o0 = offset(0, m0, c0), o1 = offset(1, m1, c1), o2 = offset(2, m2, c2);
+    const char* const xbase = lds + LL::X_OFF + C::XSTAGE * w - 16 * C::INPL;
+    const char* src[PPI];
+    uint32_t off[PPI];
+    int mm[PPI], cc[PPI];
+#pragma unroll
+    for (int j = 0; j < PPI; j++) {
+        src[j] = (j == 0 && L < C::INPL ? ybase : xbase) + 16 * (64 * j + L);
+        const int Q = PPI * item0 + 64 * j + L;   // piece index inside the tile
+        mm[j] = (int)(((uint32_t)Q * (uint32_t)C::PPR_MAGIC) >> 20); // Q / PIECES_PER_ROW (3 instructions; checked in Cfg)
+        cc[j] = Q - mm[j] * C::PIECES_PER_ROW;
+        off[j] = (uint32_t)mul24(mm[j], (int32_t)row_bytes) + 16u * (uint32_t)cc[j]; // m < 32, row_bytes < 2^18
+    }
     // interior tiles (all but the last of a row, all but a clipped last strip), whole rounds: no per-piece test,
-    // three LDS reads, one wait, three stores
+    // PPI LDS reads, one wait, PPI stores
     const bool plain_round = nvg == C::NGRP && rows_left >= C::SH && never < 0 && item0 + 64 <= C::NITEMS;
     if (plain_round) {
-        const U4 v0 = *reinterpret_cast<const U4*>(src0), v1 = *reinterpret_cast<const U4*>(src1), v2 = *reinterpret_cast<const U4*>(src2);
-        store16(tile_out + o0, v0, true);
-        store16(tile_out + o1, v1, true);
-        store16(tile_out + o2, v2, true);
+        U4 v[PPI];
+#pragma unroll
+        for (int j = 0; j < PPI; j++) v[j] = *reinterpret_cast<const U4*>(src[j]);
+#pragma unroll
+        for (int j = 0; j < PPI; j++) store16(tile_out + off[j], v[j], true);
         return;
     }
     ZJ_NO_IF_CONVERT();
-    auto valid = [&](const int j, const int m, const int c) -> bool {
-        return 3 * item0 + 64 * j + L < 3 * C::NITEMS && c < 3 * nvg && m < rows_left && c != never;
-    };
-    if (valid(0, m0, c0)) store16(tile_out + o0, *reinterpret_cast<const U4*>(src0), true);
-    if (valid(1, m1, c1)) store16(tile_out + o1, *reinterpret_cast<const U4*>(src1), true);
-    if (valid(2, m2, c2)) store16(tile_out + o2, *reinterpret_cast<const U4*>(src2), true);
+#pragma unroll
+    for (int j = 0; j < PPI; j++) {
+        const bool ok = PPI * item0 + 64 * j + L < PPI * C::NITEMS && cc[j] < PPI * nvg && mm[j] < rows_left && cc[j] != never;
+        if (ok) store16(tile_out + off[j], *reinterpret_cast<const U4*>(src[j]), true);
+    }
 }
 
 // Are staged stores usable for this launch?  The early-tail shift writes into the piece before the lane's own, so
@@ -1481,8 +1492,8 @@ ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid, char* 
 template <class C>
 inline bool ts_eligible(const Params& p, const int out, const bool fast)
 {
-    if (!fast || !(out == OUT_RGB || out == OUT_YCBCR)) return false;
-    if (out == OUT_YCBCR || p.plain) return true;
+    if (!fast || !(out == OUT_RGB || out == OUT_YCBCR || out == OUT_RGBA)) return false;
+    if (out != OUT_RGB || p.plain) return true;
     const int P = p.mcu_x * 8 * (C::TWYB / C::TWC);
     const int tiles = (P + C::TWY - 1) / C::TWY;
     const int nvg_last = (P - (tiles - 1) * C::TWY) / 16;

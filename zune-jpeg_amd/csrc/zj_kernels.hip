@@ -138,7 +138,7 @@ int fused_occupancy_420_rgb(int pad_lds)
 static void pick(int variant, int out, bool fast, bool ts_ok, int& gen, bool& ts)
 {
     gen = variant == 1 ? GEN_WIDE : GEN_PACKED;
-    ts = gen == GEN_PACKED && variant == 0 && fast && (out == OUT_RGB || out == OUT_YCBCR) && ts_ok;
+    ts = gen == GEN_PACKED && variant == 0 && fast && (out == OUT_RGB || out == OUT_YCBCR || out == OUT_RGBA) && ts_ok;
 }
 
 template <int HS, int VS, int OUT>
@@ -186,6 +186,7 @@ const char* fused_kernel_name(int hs, int vs, int out, int variant, int fast, co
 #define ZJ_CASE(H, V, O) if (hs == H && vs == V && out == O) ok = ts_ok_t<H, V, O>(p, fast);
     ZJ_CASE(1, 1, OUT_RGB) ZJ_CASE(2, 1, OUT_RGB) ZJ_CASE(1, 2, OUT_RGB) ZJ_CASE(2, 2, OUT_RGB)
     ZJ_CASE(1, 1, OUT_YCBCR) ZJ_CASE(2, 1, OUT_YCBCR) ZJ_CASE(1, 2, OUT_YCBCR) ZJ_CASE(2, 2, OUT_YCBCR)
+    ZJ_CASE(1, 1, OUT_RGBA) ZJ_CASE(2, 1, OUT_RGBA) ZJ_CASE(1, 2, OUT_RGBA) ZJ_CASE(2, 2, OUT_RGBA)
 #undef ZJ_CASE
     int gen; bool ts;
     pick(variant, out, fast != 0, ok, gen, ts);
