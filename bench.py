@@ -91,8 +91,8 @@ def main():
     ap.add_argument("--single-frame", action="store_true",
                     help="also time ONE frame per launch (configs[1] read literally); off by default so that a profiler "
                          "run of this command sees a single launch shape")
-    ap.add_argument("--workload", choices=["420-rgb", "444-rgb", "444-gray", "420-rgba", "420-chw"], default="420-rgb",
-                    help="420-rgb = BASELINE.json configs[1] (the headline); 444-* are configs[2]; 420-rgba / 420-chw are "
+    ap.add_argument("--workload", choices=["420-rgb", "444-rgb", "444-gray", "422-rgb", "440-rgb", "420-rgba", "420-chw"], default="420-rgb",
+                    help="420-rgb = BASELINE.json configs[1] (the headline); 444-* are configs[2]; 422 / 440 the reference's other sampling modes; 420-rgba / 420-chw are "
                          "the output extensions (4 B/px interleaved, planar u8)")
     ap.add_argument("--variant", choices=["packed", "wide", "packed-direct"], default=None, help="kernel variant (default: library default)")
     args = ap.parse_args()
@@ -127,6 +127,7 @@ def main():
     lo, _ = shard.shard_range(B * world, rank, world)
     hs, vs, out_cs, bytes_per_px = {"420-rgb": (2, 2, zj.ColorSpace.RGB, 6.0), "444-rgb": (1, 1, zj.ColorSpace.RGB, 9.0),
                                     "444-gray": (1, 1, zj.ColorSpace.GRAYSCALE, 3.0),
+                                    "422-rgb": (2, 1, zj.ColorSpace.RGB, 7.0), "440-rgb": (1, 2, zj.ColorSpace.RGB, 7.0),
                                     "420-rgba": (2, 2, zj.ColorSpace.RGBA, 7.0), "420-chw": (2, 2, zj.ColorSpace.RGB, 6.0)}[args.workload]
     frames = [synth.make_frame(W, H, hs, vs, 3, seed=1234, frame_index=(lo + i) % max(args.distinct, 1))
               for i in range(min(args.distinct, B))]
@@ -217,6 +218,8 @@ def main():
             "config": {"workload": {"420-rgb": "configs[1]: 4096x4096 baseline 4:2:0, dequant+IDCT+h2v2+YCbCr->RGB, planes resident in HBM",
                                     "444-rgb": "configs[2]: 4096x4096 baseline 4:4:4, dequant+IDCT+YCbCr->RGB, planes resident in HBM",
                                     "444-gray": "configs[2]: 4096x4096 4:4:4 -> GRAYSCALE (luma only), planes resident in HBM",
+                                    "422-rgb": "4096x4096 baseline 4:2:2 (h2v1), dequant+IDCT+horizontal upsample+YCbCr->RGB (the reference's benches/decode.rs horizontal case)",
+                                    "440-rgb": "4096x4096 baseline 4:4:0 (h1v2), dequant+IDCT+vertical upsample+YCbCr->RGB (the reference's benches/decode.rs vertical case)",
                                     "420-rgba": "extension: 4096x4096 4:2:0 -> RGBA (R G B 255), planes resident in HBM",
                                     "420-chw": "extension: 4096x4096 4:2:0 -> planar u8 RGB (C x H x W), planes resident in HBM"}[args.workload],
                        "frames_per_gpu_per_step": B, "sharding": f"image-level x{world}, no data-path collective",

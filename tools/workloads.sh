@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 OUT=${1:-gpurun_out/workloads.txt}
 : > $OUT
-for w in 420-rgb 444-rgb 444-gray 420-rgba 420-chw; do
+for w in 420-rgb 444-rgb 444-gray 422-rgb 440-rgb 420-rgba 420-chw; do
   python bench.py --no-cpu-baseline --workload $w 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('$w', d['value'], 'MP/s', d['ms_per_step'], 'ms/step', r['kernel_ms'], 'ms/launch', r['achieved'], 'GB/s', r['frac'])" | tee -a $OUT
 done
 for v in packed wide packed-direct packed; do

@@ -566,7 +566,15 @@ template <int HS, int VS, bool CHROMA> struct TileWidth;
 #define ZJ_TWC_HV 16
 #endif
 template <> struct TileWidth<2, 2, true> { static constexpr int TWC = ZJ_TWC_HV; };
-template <> struct TileWidth<2, 1, true> { static constexpr int TWC = 31; };   // 8*TWC+8 = 256, 496 px
+// 4:2:2 -> RGB: 8*TWC + 8 blocks.  TWC = 16 (256 pixels x 16 rows; 64 luma | 64 chroma | 8 halo blocks = pure waves, 192
+// threads) is 8 % faster than round 1's 31 (tools/ab_libs_w.sh 422-rgb); 24: +5 %, 32: -14 %, 16 on 256 threads: +4 %.
+#ifndef ZJ_TWC_H
+#define ZJ_TWC_H 16
+#endif
+#ifndef ZJ_NT_MIN_H
+#define ZJ_NT_MIN_H 0
+#endif
+template <> struct TileWidth<2, 1, true> { static constexpr int TWC = ZJ_TWC_H; };   // 8*TWC+8 blocks (31: 256, 496 px)
 template <> struct TileWidth<1, 2, true> { static constexpr int TWC = 64; };   // 4*TWC = 256, 512 px
 // 4:4:4 with chroma: 3*TWC blocks.  Round 1 ran TWC = 84 (252 lanes busy, 672 pixels).  TWC = 64 with 256 threads is
 // 15 % faster (tools/ab_libs_w.sh 444-rgb): 192 blocks on three waves (the fourth idles through the IDCT), but 512 pixels
@@ -622,7 +630,7 @@ struct Cfg {
     static constexpr int NITEMS = SH * NGRP;
     static constexpr int NBLK = NYB + (CHROMA ? 2 * NCB : 0);        // blocks per tile
     static constexpr int NT_BLK = (NBLK + 63) / 64 * 64;            // one lane per block
-    static constexpr int NT_MIN = (HS == 1 && VS == 1) ? (CHROMA ? ZJ_NT_MIN_444 : ZJ_NT_MIN_GRAY) : 0;
+    static constexpr int NT_MIN = (HS == 1 && VS == 1) ? (CHROMA ? ZJ_NT_MIN_444 : ZJ_NT_MIN_GRAY) : ((HS == 2 && VS == 1 && CHROMA) ? ZJ_NT_MIN_H : 0);
     static constexpr int NT = NT_BLK > NT_MIN ? NT_BLK : NT_MIN;     // threads per workgroup
     static constexpr int NW = NT / 64;
     static constexpr int LUT_N = SH + 2;

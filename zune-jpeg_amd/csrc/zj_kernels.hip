@@ -67,7 +67,7 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAV
     constexpr bool NEED_Y16 = OUT == OUT_RGB || OUT == OUT_RGBA || OUT == OUT_RGB_CHW;
     ZJ_SETPRIO(1, 3);
     // the wave of the halo blocks works with one lane per block column (zj_device.h: halo_*); a wave-uniform split
-    const bool halo_wave = C::HALO_PURE && __builtin_amdgcn_readfirstlane(tid) >= C::HALO_T0;
+    const bool halo_wave = C::HALO_PURE && (__builtin_amdgcn_readfirstlane(tid) >> 6) == C::HALO_T0 / 64;
     BlockLoc L;
     HaloLane H;
     U4 raw[8];
