@@ -164,14 +164,13 @@ struct BitReader {
         if (nbits < 16) fill();
         uint32_t v = peek(9);
         uint16_t e = h.look[v];
-        if (e) { drop(e >> 8); last_sym = e >> 8; return e & 0xff; }
+        if (e) { drop(e >> 8); return e & 0xff; }
         uint32_t code = peek(16);
         for (int l = 10; l <= 16; l++) {
             int32_t c = (int32_t)(code >> (16 - l));
-            if (c <= h.maxcode[l]) { drop(l); last_sym = l; return h.vals[(c + h.valoff[l]) & 0xff]; }
+            if (c <= h.maxcode[l]) { drop(l); return h.vals[(c + h.valoff[l]) & 0xff]; }
         }
         drop(16);
-        last_sym = 16;
         return -1;
     }
 };
@@ -497,8 +496,10 @@ int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, in
         const uint16_t e = ha.look[look9];
         if (e) { br.drop(e >> 8); br.last_sym = e >> 8; rs = e & 0xff; }
         else {
+            const int before = br.nbits; // >= 32 here: decode() does not refill, the difference is the code's length
             rs = br.decode(ha);
             if (rs < 0) { *err = "Bad Huffman code in AC"; return ZJ_ERR_HUFFMAN; }
+            br.last_sym = before - br.nbits;
         }
         const int r = rs >> 4, sz = rs & 15;
         if (sz) {

@@ -151,11 +151,14 @@ def lib_path():
 
 def _share_torch_hip_runtime():
     """PyTorch-ROCm wheels bundle their own libamdhip64.so (soname libamdhip64.so.7, asked for as `libamdhip64.so`);
-    libzjhip.so asks for `libamdhip64.so.7` and would otherwise bring in /opt/rocm's copy.  Two HIP runtimes in one
-    process do not coexist: whichever initialises second reports "No HIP GPUs are available".  When a torch wheel with
-    a bundled runtime is installed, its copy is opened first (without importing torch), so libzjhip.so binds to it by
-    soname and decode_to_tensor / torch streams work whatever the import order.  ZJ_SYSTEM_HIP=1 keeps the system copy."""
-    if os.environ.get("ZJ_SYSTEM_HIP") or "torch" in sys.modules:
+    libzjhip.so asks for `libamdhip64.so.7` and otherwise brings in /opt/rocm's copy.  Two HIP runtimes in one process
+    do not coexist: whichever initialises second reports "No HIP GPUs are available".  A process that uses both must
+    therefore `import torch` BEFORE the first call into this module (bench.py and tests/conftest.py do), or set
+    ZJ_TORCH_HIP=1, which opens the wheel's copy here (without importing torch) so that libzjhip.so binds to it by
+    soname.  It is not the default: the runtime bundled with torch 2.10+rocm7.0 runs the three-stream host pipeline of
+    zj_decode_planes at half the rate of ROCm 7.2's (5.9 k against 11.9 k megapixels/s for one 4096x4096 frame,
+    tools/e2e.py), so torch-free processes keep the system runtime."""
+    if not os.environ.get("ZJ_TORCH_HIP") or "torch" in sys.modules:
         return
     try:
         import importlib.util
