@@ -470,6 +470,9 @@ inline int16_t* block_at(Comp& cm, int bx, int by) { return cm.coef + ((size_t)b
 
 // one block of a baseline scan; *err is set instead of the decoder state so that restart segments can
 // run on several threads
+// TRACK: also record the bit length of the block's last symbol (BitReader::last_sym) -- needed only near the end of
+// the scan, where reference_saw_eoi() looks at it; the hot instantiation carries no bookkeeping
+template <bool TRACK>
 int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, int32_t& dc_pred, int16_t* blk, const char** err)
 {
     const Huff& hd = d->dc[cm.td & 3];
@@ -487,26 +490,26 @@ int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, in
         if (fa) { // short code + small value: run, magnitude and sign from one table entry
             k += (fa >> 4) & 15;
             br.drop(fa & 15);
-            br.last_sym = fa & 15;
+            if (TRACK) br.last_sym = fa & 15;
             blk[kUnZigzag[k & 63]] = (int16_t)(fa >> 8);
             k++;
             continue;
         }
         int rs;
         const uint16_t e = ha.look[look9];
-        if (e) { br.drop(e >> 8); br.last_sym = e >> 8; rs = e & 0xff; }
+        if (e) { br.drop(e >> 8); if (TRACK) br.last_sym = e >> 8; rs = e & 0xff; }
         else {
             const int before = br.nbits; // >= 32 here: decode() does not refill, the difference is the code's length
             rs = br.decode(ha);
             if (rs < 0) { *err = "Bad Huffman code in AC"; return ZJ_ERR_HUFFMAN; }
-            br.last_sym = before - br.nbits;
+            if (TRACK) br.last_sym = before - br.nbits;
         }
         const int r = rs >> 4, sz = rs & 15;
         if (sz) {
             k += r;
             const int32_t bits = (int32_t)br.peek(sz);
             br.drop(sz);
-            br.last_sym += sz;
+            if (TRACK) br.last_sym += sz;
             // EXTEND (T.81 F.2.2.1) without a branch: values below 2^(sz-1) are negative
             const int32_t v = bits + ((((bits - (1 << (sz - 1))) >> 31)) & (1 - (1 << sz)));
             blk[kUnZigzag[k & 63]] = (int16_t)v;
@@ -648,11 +651,14 @@ int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p,
     for (long long i = 0; i < nmcu; i++) {
         const int my = (int)((mcu0 + i) / d->mcu_x), mx = (int)((mcu0 + i) % d->mcu_x);
         if (cut.seen && (mcu0 + i) / cut.rowlen == cut.cut_row) { clear_mcu(dm, mx, my); continue; }
+        const bool near_end = cut.eoi && cut.eoi - br.p <= 4096; // an MCU is at most 6 blocks x 64 x 27 bits = 1.3 KB
         for (int ci = 0; ci < d->ns; ci++) {
             Comp& cm = dm->comps[d->order[ci]];
             for (int v = 0; v < cm.v; v++)
                 for (int h = 0; h < cm.h; h++) {
-                    int rc = decode_block_baseline(d, br, cm, pred[d->order[ci]], block_at(cm, mx * cm.h + h, my * cm.v + v), err);
+                    int16_t* blk = block_at(cm, mx * cm.h + h, my * cm.v + v);
+                    int rc = near_end ? decode_block_baseline<true>(d, br, cm, pred[d->order[ci]], blk, err)
+                                      : decode_block_baseline<false>(d, br, cm, pred[d->order[ci]], blk, err);
                     if (rc) return rc;
                 }
         }
@@ -718,12 +724,15 @@ int scan_baseline(zj_decoder* d, BitReader& br)
             const long long m = (long long)my * d->mcu_x + mx;
             // the reference left this row's loop at an earlier MCU (see EoiCut): the block keeps its zeros
             if (cut.seen && m / cut.rowlen == cut.cut_row) { clear_mcu(d, mx, my); continue; }
+            const bool near_end = cut.eoi && cut.eoi - br.p <= 4096; // an MCU is at most 6 blocks x 64 x 27 bits = 1.3 KB
             for (int ci = 0; ci < d->ns; ci++) {
                 Comp& cm = d->comps[d->order[ci]];
                 for (int v = 0; v < cm.v; v++)
                     for (int h = 0; h < cm.h; h++) {
                         const char* err = nullptr;
-                        int rc = decode_block_baseline(d, br, cm, cm.dc_pred, block_at(cm, mx * cm.h + h, my * cm.v + v), &err);
+                        int16_t* blk = block_at(cm, mx * cm.h + h, my * cm.v + v);
+                        int rc = near_end ? decode_block_baseline<true>(d, br, cm, cm.dc_pred, blk, &err)
+                                          : decode_block_baseline<false>(d, br, cm, cm.dc_pred, blk, &err);
                         if (rc) { clear_from(my, mx); return fail(d, rc, err); }
                     }
             }
