@@ -646,6 +646,51 @@ def test_decode_to_tensor_for_torch_consumers(zj, synth):
 
 
 
+def test_single_frame_decodes_replay_from_a_hip_graph(zj, synth):
+    """zj_decode_planes_device is a pure kernel launch (tables by value, no staging, no synchronisation): a run of
+    single-frame decodes over two branches can be captured into a HIP graph and replayed (tools/single_frame_graph.py)"""
+    import torch
+    w, h, nf = 512, 96, 6
+    frames = [synth.make_frame(w, h, 2, 2, 3, seed=77, frame_index=i) for i in range(nf)]
+    qts = frames[0][1]
+    desc = zj.FrameDesc.make(w, h, 2, 2, 3, zj.ColorSpace.RGB, qts)
+    dev = torch.device("cuda:0")
+    d = [torch.from_numpy(np.concatenate([f[0][c] for f in frames])).to(dev) for c in range(3)]
+    out = torch.zeros(nf * w * h * 3, dtype=torch.uint8, device=dev)
+    yl, cl, ol = frames[0][0][0].size * 2, frames[0][0][1].size * 2, w * h * 3
+    ctx = zj.Context()
+    try:
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        cap = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(cap):
+            g.capture_begin()
+            fork = torch.cuda.Event()
+            fork.record(cap)
+            for s in streams:
+                s.wait_event(fork)
+            for f in range(nf):
+                ctx.decode_planes_device(desc, 1, d[0].data_ptr() + f * yl, d[1].data_ptr() + f * cl, d[2].data_ptr() + f * cl,
+                                         out.data_ptr() + f * ol, streams[f % 2].cuda_stream)
+            for s in streams:
+                e = torch.cuda.Event()
+                e.record(s)
+                cap.wait_event(e)
+            g.capture_end()
+        for _ in range(2):
+            out.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            for i, f in enumerate(frames):
+                rc, exp = oc.decode_planes(oc.make_frame(w, h, 2, 2, 3, oc.RGB, qts), f[0])
+                assert rc == 0
+                assert np.array_equal(got[i * ol:(i + 1) * ol], exp), i
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("flags,out_cs,layout", [(7, oc.RGB, 0), (2, oc.GRAYSCALE, 0), (4, oc.YCBCR, 0), (6, oc.RGBA, 0), (6, oc.RGB, 1)])
 @pytest.mark.parametrize("wh", [(528, 40), (1040, 33), (100, 32), (250, 72), (1920, 1080)])
