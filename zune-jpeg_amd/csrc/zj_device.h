@@ -120,14 +120,17 @@ ZJ_DEV uint32_t sad_u16(uint32_t a, uint32_t b, uint32_t c)
 
 // {(a >> sh)[15:0], (b >> sh)[15:0]} as a packed pair: an arithmetic shift and a second one whose SDWA form writes
 // its low half into the destination's high word (2 instructions; the compiler's own sequence is shift, shift, bfi)
-ZJ_DEV uint32_t pack_sar(int32_t a, int32_t b, const int sh)
+template <int SH>
+ZJ_DEV uint32_t pack_sar(int32_t a, int32_t b)
 {
 #if defined(ZJ_EMU)
-    return ((uint32_t)(a >> sh) & 0xffffu) | ((uint32_t)(b >> sh) << 16);
+    return ((uint32_t)(a >> SH) & 0xffffu) | ((uint32_t)(b >> SH) << 16);
 #else
+    // the shift count as an inline constant: with an SGPR operand the e32 shift issues in 4.1 cycles instead of 2.3
+    // (profiles/r01_ubench_valu_issue_cost.txt: simple VOP2 instructions are fast only with VGPR / inline operands)
     uint32_t r;
-    asm("v_ashrrev_i32_e32 %0, %1, %2" : "=v"(r) : "s"(sh), "v"(a));
-    asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(r) : "s"(sh), "v"(b));
+    asm("v_ashrrev_i32_e32 %0, %1, %2" : "=v"(r) : "n"(SH), "v"(a));
+    asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(r) : "n"(SH), "v"(b));
     return r;
 #endif
 }
@@ -489,7 +492,7 @@ ZJ_DEV void idct_block_packed(const U4 raw[8], const uint32_t* qp, uint32_t out[
         idct_1d_dot_add(h[0], oa);
         idct_1d_dot_add(h[1], ob);
 #pragma unroll
-        for (int i = 0; i < 8; i++) T[i][g] = pack_sar(oa[i], ob[i], 10);
+        for (int i = 0; i < 8; i++) T[i][g] = pack_sar<10>(oa[i], ob[i]);
         ZJ_SCHED_BARRIER();
     }
     // pass 2: rows (scalar.rs:170-274), bias SCALE_BITS, >> 17, clamp -> bytes
@@ -504,8 +507,8 @@ ZJ_DEV void idct_block_packed(const U4 raw[8], const uint32_t* qp, uint32_t out[
         for (int e = 0; e < 2; e++) {
             int32_t o[8];
             idct_1d_dot_add(h[e], o);
-            out[2 * (r0 + e)] = sat_pk_u8_2(pack_sar(o[0], o[1], 17), pack_sar(o[2], o[3], 17));
-            out[2 * (r0 + e) + 1] = sat_pk_u8_2(pack_sar(o[4], o[5], 17), pack_sar(o[6], o[7], 17));
+            out[2 * (r0 + e)] = sat_pk_u8_2(pack_sar<17>(o[0], o[1]), pack_sar<17>(o[2], o[3]));
+            out[2 * (r0 + e) + 1] = sat_pk_u8_2(pack_sar<17>(o[4], o[5]), pack_sar<17>(o[6], o[7]));
         }
         ZJ_SCHED_BARRIER();
     }
