@@ -559,7 +559,7 @@ ZJ_DEV int tri1(int near_, int far_) { return (int)(int16_t)(uint16_t)(3 * near_
 // because the reference filters the strip as ONE flat array (Q4) the neighbour of the first/last
 // column is the other end of the previous/next row, so the halo wraps around with a row shift.
 // Tile width (TWC chroma block columns) is chosen so that the tile's blocks fill the workgroup's
-// waves: with one lane per block and 256 lanes, 4:2:0->RGB has 12*TWC + 8 blocks -> TWC = 20 (248).
+// waves (one lane per block); the values below are measured choices, see the comments at each.
 template <int HS, int VS, bool CHROMA> struct TileWidth;
 // 4:2:0 -> RGB: 12*TWC + 8 blocks.  Round 1 ran TWC = 20 (248 of 256 lanes busy).  With the packed generation TWC = 16
 // measures 2.5 % faster (tools/ab_libs.sh, profiles/r02_*): 256 pixels = exactly two colour rounds per wave, 4096-pixel

@@ -1,8 +1,10 @@
 // zj_kernels.hip -- gfx950 kernels of the pixel path and their launchers.
 //
-//   zj_fused_kernel<HS,VS,OUT>  whole hot path per tile: dequantize + IDCT -> LDS planar staging ->
+//   zj_fused_kernel<HS,VS,OUT,GEN,FAST,TS>
+//                               whole hot path per tile: dequantize + IDCT -> LDS planar staging ->
 //                               up-sample + colour-convert -> global store.  One HBM read of the
 //                               coefficients, one HBM write of the pixels (6 B/px for 4:2:0->RGB).
+//                               GEN: packed (round 2) | wide (round 1); TS: staged, lane-contiguous stores
 //   zj_idct_strip_kernel        IDCTPtr-compatible strip IDCT  (src/idct/scalar.rs:19)
 //   zj_upsample_{h,v}_kernel    UpSampler-compatible flat-array filters (src/upsampler/scalar.rs)
 //   zj_rgb16_kernel             ColorConvert16Ptr (src/color_convert/scalar.rs:52)
@@ -53,9 +55,7 @@ __device__ __forceinline__ void tile_wide(const Params& p, const TileId t, const
 }
 
 template <int HS, int VS, int OUT, int GEN, bool FAST, bool TS>
-// 2nd launch bound = waves per SIMD: 5 workgroups of 4 waves per CU need <= 96 VGPRs; LDS (at most 32.7 KB
-// per workgroup for 4:2:0) allows exactly 5.  Measured with tools/occupancy.py: 5 and 4 workgroups per CU
-// run the same, 3 cost 7 %, 2 cost 29 % -- the bound keeps the kernel on the flat part.
+// launch bounds: see ZJ_WAVES_PER_SIMD / ZJ_WAVES_PER_SIMD_PACKED above
 __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAVES_PER_SIMD_PACKED : ZJ_WAVES_PER_SIMD)) void zj_fused_kernel(const Params p)
 {
     using C = Cfg<HS, VS, OUT>;
