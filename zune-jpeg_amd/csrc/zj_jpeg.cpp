@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <emmintrin.h> // _mm_stream_si128: the coefficient planes are written once and read by DMA
 
 #include <atomic>
 #include <new>
@@ -473,11 +474,19 @@ inline int16_t* block_at(Comp& cm, int bx, int by) { return cm.coef + ((size_t)b
 // TRACK: also record the bit length of the block's last symbol (BitReader::last_sym) -- needed only near the end of
 // the scan, where reference_saw_eoi() looks at it; the hot instantiation carries no bookkeeping
 template <bool TRACK>
-int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, int32_t& dc_pred, int16_t* blk, const char** err)
+int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, int32_t& dc_pred, int16_t* out, const char** err)
 {
     const Huff& hd = d->dc[cm.td & 3];
     const Huff& ha = d->ac[cm.ta & 3];
+    // The block is assembled in a cached 128-byte buffer and leaves with non-temporal stores: the planes (50 MB for a
+    // 4096x4096 4:2:0 frame) are written once and read by DMA, so allocating their lines in the cache only costs a
+    // read-for-ownership per line.
+    alignas(16) int16_t blk[64];
     memset(blk, 0, 128);
+    struct Flush {
+        const int16_t* src; int16_t* dst;
+        ~Flush() { for (int i = 0; i < 8; i++) _mm_stream_si128((__m128i*)dst + i, _mm_load_si128((const __m128i*)src + i)); }
+    } flush{blk, out};
     int s = br.decode(hd);
     if (s < 0 || s > 16) { *err = "Bad Huffman code in DC"; return ZJ_ERR_HUFFMAN; }
     int32_t diff = s ? extend(br.get(s), s) : 0;
@@ -664,6 +673,7 @@ int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p,
         }
         eoi_cut_after_mcu(cut, br, mcu0 + i);
     }
+    _mm_sfence(); // the blocks left with streaming stores (decode_block_baseline)
     return ZJ_OK;
 }
 
@@ -710,6 +720,7 @@ int scan_baseline(zj_decoder* d, BitReader& br)
     }
     // blocks of MCUs from (mx, my) on that the walk never reached stay zero, like the reference's fresh vectors
     auto clear_from = [&](int my0, int mx0) {
+        _mm_sfence(); // order the streaming stores of the blocks decoded so far before the ordinary stores below
         for (int my = my0; my < d->mcu_y; my++)
             for (int mx = (my == my0 ? mx0 : 0); mx < d->mcu_x; mx++)
                 for (int ci = 0; ci < d->ncomp; ci++) {
@@ -744,6 +755,7 @@ int scan_baseline(zj_decoder* d, BitReader& br)
             }
             if (!restarted) eoi_cut_after_mcu(cut, br, m); // (a restart clears the reference's pending marker, mcu.rs:400-408)
         }
+    _mm_sfence(); // the blocks left with streaming stores (decode_block_baseline)
     return ZJ_OK;
 }
 
