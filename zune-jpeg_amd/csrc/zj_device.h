@@ -46,7 +46,8 @@ typedef uint32_t V4 __attribute__((vector_size(16)));    // the same 16 bytes fo
 #define ZJ_ABL(debug, bit) 0  // the ablation switches exist only in the diagnostic build (tools/ablate.py)
 #endif
 // ZJ_NT (tools/ab_libs.sh): bit 0 = non-temporal pixel stores everywhere, bit 1 = non-temporal coefficient loads,
-// bit 2 = non-temporal stores in color_copyout only.  Default 4: the staged stores write whole lines that nobody reads
+// bit 2 = non-temporal stores where a store instruction writes whole, lane-contiguous lines (the staged stores of
+// color_copyout, the grayscale rows).  Default 4: these lines are written once and nobody reads them
 // again (+1.5 % measured); the 48-byte-per-lane direct stores of the other paths LOSE 2.5 % with it (round 1).
 #ifndef ZJ_NT
 #define ZJ_NT 4
@@ -1197,7 +1198,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
             const U4 yv = *reinterpret_cast<const U4*>(lds + 16 * item);
             if (OUT == OUT_GRAY) {
                 // ycbcr_to_grayscale (color_convert/scalar.rs:91-114): `as u8` truncation (Q7) == the staged byte
-                if (FAST) store16(orow + px0, yv); // W % 16 == 0
+                if (FAST) store16(orow + px0, yv, true); // W % 16 == 0; lane-contiguous whole lines: streaming stores (+3.7 %)
                 else { const uint32_t ow4[4] = {yv.x, yv.y, yv.z, yv.w}; store_clip(orow, px0, ow4, 4, W, 0, 0); }
                 continue;
             }
