@@ -7,7 +7,7 @@
 use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const ZJ_ABI_VERSION: c_int = 3;
+pub const ZJ_ABI_VERSION: c_int = 4;
 pub const ZJ_BACKEND_HIP: c_int = 2;
 pub const ZJ_OK: c_int = 0;
 pub const ZJ_ERR_PANIC: c_int = -5;
@@ -53,6 +53,7 @@ pub struct zj_options {              // <-> ZuneJpegOptions, src/options.rs:6-40
     pub out_colorspace: i32, pub strict_mode: i32, pub max_width: i32, pub max_height: i32,
     pub max_scans: i32, pub num_threads: i32, pub pinned_planes: i32,
     pub flags: u32, pub out_layout: u32,
+    pub entropy: i32,                // 0 CPU walker, 1 baseline scans of 32 KB and more on the GPU, 2 every eligible scan
 }
 
 #[repr(C)]
@@ -103,8 +104,14 @@ extern "C" {
     pub fn zj_decoder_read_headers(d: *mut zj_decoder, buf: *const u8, len: usize, info: *mut zj_image_info) -> c_int;
     pub fn zj_decoder_decode_coefficients(d: *mut zj_decoder, buf: *const u8, len: usize, desc: *mut zj_frame_desc,
                                           planes: *mut *const i16, plane_len: *mut usize, info: *mut zj_image_info) -> c_int;
+    pub fn zj_decoder_prepare(d: *mut zj_decoder, buf: *const u8, len: usize, desc: *mut zj_frame_desc,
+                              info: *mut zj_image_info) -> c_int;
     pub fn zj_decoder_finish_pixels(d: *mut zj_decoder, ctx: *mut zj_ctx, out: *mut u8, out_cap: usize,
                                     out_len: *mut usize) -> c_int;
+    pub fn zj_decoder_finish_pixels_device(d: *mut zj_decoder, ctx: *mut zj_ctx, d_out: *mut u8, out_cap: usize,
+                                           out_len: *mut usize) -> c_int;
+    pub fn zj_decode_scan(ctx: *mut zj_ctx, d: *const zj_frame_desc, blob: *const c_void, blob_bytes: usize,
+                          out: *mut u8, out_on_device: c_int, status_bits: *mut u32) -> c_int;
     pub fn zj_decoder_decode_buffer(d: *mut zj_decoder, ctx: *mut zj_ctx, buf: *const u8, len: usize, out: *mut u8,
                                     out_cap: usize, out_len: *mut usize, info: *mut zj_image_info) -> c_int;
     pub fn zj_pool_create(device: c_int, threads: c_int, opt: *const zj_options, status: *mut c_int) -> *mut zj_pool;

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ZJ_ABI_VERSION 3
+#define ZJ_ABI_VERSION 4
 
 /* ColorSpace, same order as src/misc.rs:88-106 */
 typedef enum zj_colorspace {
@@ -75,7 +75,10 @@ typedef enum zj_status {
     ZJ_ERR_UNSUPPORTED_SCHEME = -27, /* Unsupported(UnsupportedSchemes) */
     ZJ_ERR_MCU = -28,                /* MCUError */
     ZJ_ERR_EXHAUSTED = -29,          /* ExhaustedData */
-    ZJ_ERR_LARGE_DIM = -30           /* LargeDimensions */
+    ZJ_ERR_LARGE_DIM = -30,          /* LargeDimensions */
+    /* zj_decode_scan only (not an error): the device met something in the scan that only the CPU walker treats the way
+     * the reference does (a damaged stream, the reference's early exit before the last row loop): decode on the CPU */
+    ZJ_RETRY_CPU = 1
 } zj_status;
 
 /* The fields of `Components` (src/components.rs:18-43) the pixel path reads. */
@@ -188,6 +191,19 @@ int zj_time_decode_device(zj_ctx *ctx, const zj_frame_desc *d, size_t nframes, c
                           const int16_t *d_cb, const int16_t *d_cr, uint8_t *d_out, void *stream,
                           int iters, float *ms_total, float *ms_each, const char **kernel_name);
 
+/* Host planes -> pixels that stay in HBM (d_out: device pointer, 16-byte aligned). Synchronous. */
+int zj_decode_planes_to_device(zj_ctx *ctx, const zj_frame_desc *d, const int16_t *y, const int16_t *cb,
+                               const int16_t *cr, uint8_t *d_out);
+/* A prepared baseline scan (zj_decoder_prepare / zj_decoder_scan_blob; host memory, pinned for an asynchronous upload)
+ * -> pixels: upload, Huffman decoding on the device into whole-frame planes in HBM, pixel kernel, and -- unless
+ * out_on_device -- the download.  Replaces the MCU walk of src/mcu.rs:231-351.  Synchronous.  ZJ_RETRY_CPU with
+ * *status_bits (optional) when the device hands the scan back. */
+int zj_decode_scan(zj_ctx *ctx, const zj_frame_desc *d, const void *blob, size_t blob_bytes, uint8_t *out,
+                   int out_on_device, unsigned *status_bits);
+/* of the last zj_decode_scan on ctx: synchronisation rounds; with ZJ_HUFF_TIME set in the environment, milliseconds of
+ * upload + rounds | prefix sums + write pass | pixel kernel (+ download) */
+int zj_scan_stats(const zj_ctx *ctx, int *rounds, float ms[3]);
+
 /* ---- whole decoder: the CPU front-end the path is fed by (container + Huffman on the host) ------
  * Mirrors Decoder / ZuneJpegOptions / ImageInfo (src/decoder.rs:60,178,452,652; src/options.rs:6-40):
  * SOF0 baseline and SOF2 progressive Huffman, 8-bit, 1 or 3 components, DRI/RST.  The entropy decode
@@ -204,7 +220,13 @@ typedef struct zj_options {      /* zero = reference default */
     int32_t pinned_planes;       /* non-zero: coefficient planes live in pinned host memory (DMA without staging) */
     uint32_t flags;              /* ZJ_FLAG_* for the pixel path (0 = the reference's bytes), see zj_frame_desc */
     uint32_t out_layout;         /* ZJ_LAYOUT_HWC (0) or ZJ_LAYOUT_CHW */
+    int32_t entropy;             /* where baseline Huffman scans are decoded: ZJ_ENTROPY_CPU (0), ZJ_ENTROPY_GPU (scans of
+                                    32 KB and more on the device, the rest and everything the device hands back on the
+                                    CPU), ZJ_ENTROPY_GPU_ALWAYS (every eligible scan).  Progressive files: always CPU */
 } zj_options;
+#define ZJ_ENTROPY_CPU 0
+#define ZJ_ENTROPY_GPU 1
+#define ZJ_ENTROPY_GPU_ALWAYS 2
 typedef struct zj_image_info {   /* ImageInfo, src/decoder.rs:652-668 (+ what the GPU path needs) */
     uint16_t width, height;
     uint8_t components, progressive, h_max, v_max;
@@ -218,8 +240,21 @@ int zj_decoder_read_headers(zj_decoder *d, const uint8_t *buf, size_t len, zj_im
 /* CPU half only: planes stay owned by the decoder until the next call (mcu_prog.rs:73-79 layout) */
 int zj_decoder_decode_coefficients(zj_decoder *d, const uint8_t *buf, size_t len, zj_frame_desc *desc,
                                    const int16_t **planes /*[3]*/, size_t *plane_len /*[3]*/, zj_image_info *info);
-/* GPU half: the pixel path over the planes the last zj_decoder_decode_coefficients left in the decoder */
+/* Stage 1 on the CPU, whatever the options say it is: with entropy == ZJ_ENTROPY_CPU the same as
+ * zj_decoder_decode_coefficients; with a GPU setting, headers + the byte-level preparation of a baseline scan
+ * (stuffing removed, restart segments located, sub-sequence grid: csrc/zj_huff.h), leaving the Huffman decoding itself
+ * (src/mcu.rs:231-351, src/bitstream.rs:314-373) to zj_decoder_finish_pixels.  `buf` must then stay valid until the
+ * pixels are finished (a scan the device hands back is decoded from it on the CPU). */
+int zj_decoder_prepare(zj_decoder *d, const uint8_t *buf, size_t len, zj_frame_desc *desc, zj_image_info *info);
+/* GPU half: the pixel path over the planes the last zj_decoder_decode_coefficients / zj_decoder_prepare left in the
+ * decoder; after a zj_decoder_prepare that left a scan for the device: entropy stage + pixel path on the GPU */
 int zj_decoder_finish_pixels(zj_decoder *d, zj_ctx *ctx, uint8_t *out, size_t out_cap, size_t *out_len);
+/* the same with the pixels left in HBM (d_out: device pointer on ctx's device, 16-byte aligned) for consumers on the GPU */
+int zj_decoder_finish_pixels_device(zj_decoder *d, zj_ctx *ctx, uint8_t *d_out, size_t out_cap, size_t *out_len);
+/* diagnostics: the prepared scan of the last zj_decoder_prepare (ZJ_ERR_ARG: none); the status bits (csrc/zj_huff.h
+ * HUFF_ST_*) with which the device handed the last scan back to the CPU (0: it did not) */
+int zj_decoder_scan_blob(const zj_decoder *d, const void **blob, size_t *len);
+unsigned zj_decoder_gpu_status(const zj_decoder *d);
 /* Decoder::decode_buffer (decoder.rs:178): width*height*ncomp bytes into `out` */
 int zj_decoder_decode_buffer(zj_decoder *d, zj_ctx *ctx, const uint8_t *buf, size_t len, uint8_t *out,
                              size_t out_cap, size_t *out_len, zj_image_info *info);
@@ -254,6 +289,7 @@ void *zj_device_alloc(zj_ctx *ctx, size_t bytes);
 void zj_device_free(zj_ctx *ctx, void *p);
 int zj_memcpy_h2d(zj_ctx *ctx, void *dst, const void *src, size_t bytes);
 int zj_memcpy_d2h(zj_ctx *ctx, void *dst, const void *src, size_t bytes);
+int zj_device_memset(zj_ctx *ctx, void *d_ptr, int value, size_t bytes);
 int zj_sync(zj_ctx *ctx);
 
 #ifdef __cplusplus

@@ -160,3 +160,63 @@ extern "C" void zje_idct_wide(const int16_t* coeff, size_t nblocks, const int32_
     }
 }
 extern "C" int zje_guard_limit(void) { return GUARD_LIMIT; }
+
+// ---- the GPU entropy stage (zj_huff_device.h), thread by thread -----------------------------------------------------
+#include "../../zune-jpeg_amd/csrc/zj_huff_device.h"
+
+// planes must be zero-filled by the caller (the product clears them with hipMemsetAsync).  stats: [0] rounds run,
+// [1] sub-sequences, [2] sub-sequence decodes over all sync rounds, [3] first-seen MCU of the EOI rule
+extern "C" int zje_huff_decode(const uint8_t* blob, int16_t* y, int16_t* cb, int16_t* cr, uint32_t* status, uint32_t* stats)
+{
+    const HuffScan* g = huff_hdr(blob);
+    if (g->magic != HUFF_MAGIC) return ZJ_ERR_ARG;
+    const uint32_t nsub = g->nsub;
+    std::vector<unsigned long long> exitv(nsub);
+    std::vector<HuffI4> aux(nsub), base(nsub);
+    std::vector<uint8_t> changed(2 * (size_t)nsub);
+    std::vector<uint32_t> ctl(2 + HUFF_MAX_ROUNDS + 1, 0);
+    ctl[1] = 0xffffffffu;
+    HuffArgs a;
+    a.blob = blob; a.exit = exitv.data(); a.aux = aux.data(); a.base = base.data(); a.changed = changed.data();
+    a.ctl = ctl.data(); a.plane[0] = y; a.plane[1] = cb; a.plane[2] = cr; a.round = 0;
+    std::vector<HuffLds> lds(1);
+    HuffLds& L = lds[0];
+    const uint32_t nwg = (nsub + HUFF_WG - 1) / HUFF_WG;
+    uint32_t work = 0;
+    int round = 0;
+    for (;; round++) {
+        if (round > HUFF_MAX_ROUNDS) { ctl[0] |= HUFF_ST_NO_SYNC; break; }
+        a.round = round;
+        for (uint32_t wg = 0; wg < nwg; wg++) {
+            bool any = false;
+            for (int tid = 0; tid < HUFF_WG; tid++) any |= huff_sync_needed(a, wg * HUFF_WG + tid, nsub, huff_subs(blob));
+            if (!any) { for (int tid = 0; tid < HUFF_WG; tid++) if (wg * HUFF_WG + tid < nsub) changed[(size_t)(round & 1) * nsub + wg * HUFF_WG + tid] = 0; continue; }
+            memset((void*)&L, 0x7B, sizeof L);
+            for (int tid = 0; tid < HUFF_WG; tid++) huff_stage<HUFF_WG>(blob, (int)wg, tid, L);
+            for (int tid = 0; tid < HUFF_WG; tid++) {
+                if (huff_sync_needed(a, wg * HUFF_WG + tid, nsub, huff_subs(blob))) work++;
+                huff_sync_thread(a, L, wg * HUFF_WG + tid);
+            }
+        }
+        if (round >= 1 && ctl[2 + round] == 0) break;
+    }
+    if (!(ctl[0] & HUFF_ST_NO_SYNC)) {
+        const int NT = 1024;
+        std::vector<HuffAgg> agg(NT);
+        const uint32_t chunk = (nsub + NT - 1) / NT;
+        for (int t = 0; t < NT; t++) agg[t] = huff_scan_chunk(a, (uint32_t)t, chunk);
+        huff_scan_combine(agg.data(), NT);
+        for (int t = 0; t < NT; t++) huff_scan_apply(a, (uint32_t)t, chunk, agg[t]);
+        for (uint32_t wg = 0; wg < nwg; wg++) {
+            memset((void*)&L, 0x7B, sizeof L);
+            for (int tid = 0; tid < HUFF_WG; tid++) huff_stage<HUFF_WG>(blob, (int)wg, tid, L);
+            for (int tid = 0; tid < HUFF_WG; tid++) huff_write_thread(a, L, wg * HUFF_WG + tid);
+        }
+        uint32_t first = 0;
+        const uint32_t pieces = huff_cut_plan(a, &first);
+        for (uint32_t p = 0; p < pieces; p++) huff_cut_clear(a, first, p);
+    }
+    if (status) *status = ctl[0];
+    if (stats) { stats[0] = (uint32_t)round; stats[1] = nsub; stats[2] = work; stats[3] = ctl[1]; }
+    return ZJ_OK;
+}

@@ -16,7 +16,9 @@ def lib():
         so = os.path.join(HERE, "emu", "libzjemu.so")
         srcs = [os.path.join(HERE, "emu", "zj_emu.cpp"),
                 os.path.join(ROOT, "zune-jpeg_amd", "csrc", "zj_device.h"),
-                os.path.join(ROOT, "zune-jpeg_amd", "csrc", "zj_plan.h")]
+                os.path.join(ROOT, "zune-jpeg_amd", "csrc", "zj_plan.h"),
+                os.path.join(ROOT, "zune-jpeg_amd", "csrc", "zj_huff.h"),
+                os.path.join(ROOT, "zune-jpeg_amd", "csrc", "zj_huff_device.h")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fno-strict-aliasing",
                                    "-Wall", "-Wno-unknown-pragmas", "-o", so, srcs[0]])
@@ -92,3 +94,20 @@ def idct_wide(coeff, q):
 
 def guard_limit():
     return int(lib().zje_guard_limit())
+
+
+def huff_decode(blob, plane_lens):
+    """The GPU entropy stage (zj_huff_device.h) thread by thread over a prepared scan (host.Decoder.scan_blob()).
+    Returns (planes, status bits, dict(rounds, nsub, decodes, first_seen))."""
+    blob = np.ascontiguousarray(blob, np.uint8)
+    planes = [np.zeros(max(int(n), 8), np.int16) for n in plane_lens]
+    while len(planes) < 3:
+        planes.append(np.zeros(8, np.int16))
+    status = C.c_uint32(0)
+    stats = (C.c_uint32 * 4)()
+    rc = lib().zje_huff_decode(C.c_void_p(blob.ctypes.data), C.c_void_p(planes[0].ctypes.data),
+                               C.c_void_p(planes[1].ctypes.data), C.c_void_p(planes[2].ctypes.data),
+                               C.byref(status), stats)
+    if rc:
+        raise RuntimeError(f"zje_huff_decode: {rc}")
+    return planes[: len(plane_lens)], int(status.value), dict(rounds=stats[0], nsub=stats[1], decodes=stats[2], first_seen=stats[3])

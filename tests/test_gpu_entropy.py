@@ -1,0 +1,156 @@
+"""GPU: the entropy stage on the device (zune-jpeg_amd/csrc/zj_huff.hip) through the C ABI -- zj_decoder_prepare /
+zj_decoder_finish_pixels / zj_decode_scan / zj_pool with zj_options.entropy -- against the product's CPU walker on the
+same files (pixels must be identical; tests/test_jpeg_frontend.py pins that walker to the reference), plus the golden
+reference file with its early exit at EOI, damaged scans (handed back, then equal to the CPU path) and pixels that stay
+in HBM."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from test_huff_emu import pil_jpeg
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def zj():
+    return importlib.import_module("zune-jpeg_amd")
+
+
+@pytest.fixture(scope="module")
+def ctx(zj):
+    c = zj.Context(zj.BACKEND_HIP, 0)
+    yield c
+    c.close()
+
+
+def decoders(zj, ctx, cs=None, sub=None):
+    old = os.environ.get("ZJ_HUFF_SUB")
+    if sub:
+        os.environ["ZJ_HUFF_SUB"] = str(sub)
+    try:
+        og, oc_ = zj.ZuneJpegOptions(), zj.ZuneJpegOptions()
+        og.entropy = zj.ENTROPY_GPU_ALWAYS
+        if cs is not None:
+            og.out_colorspace = oc_.out_colorspace = cs
+        return zj.Decoder(og, ctx), zj.Decoder(oc_, ctx)
+    finally:
+        if sub:
+            if old is None:
+                del os.environ["ZJ_HUFF_SUB"]
+            else:
+                os.environ["ZJ_HUFF_SUB"] = old
+
+
+CASES = {
+    "420": dict(quality=90), "444": dict(quality=90, subsampling=0), "422": dict(quality=90, subsampling=1),
+    "gray": dict(quality=50, gray=True), "420-opt": dict(quality=75, optimize=True),
+    "420-ri7": dict(quality=90, restart_marker_blocks=7), "420-ri1": dict(quality=90, restart_marker_blocks=1),
+    "420-q20": dict(quality=20), "420-rows": dict(quality=90, restart_marker_rows=1),
+    "444-flat": dict(quality=30, subsampling=0, flat=True), "420-q98": dict(quality=98),
+}
+
+
+@pytest.mark.parametrize("sub", [16, 64, 128])
+@pytest.mark.parametrize("case", list(CASES))
+@pytest.mark.parametrize("wh", [(333, 211), (1601, 1203)])
+def test_files_decode_to_the_same_pixels(zj, ctx, case, wh, sub):
+    data = pil_jpeg(wh[0], wh[1], seed=len(case) + sub, **CASES[case])
+    g, c = decoders(zj, ctx, sub=sub)
+    got = g.decode_buffer(data)
+    assert g.gpu_status() == 0, [v for k, v in zj.HUFF_ST.items() if g.gpu_status() & k]
+    assert np.array_equal(got, c.decode_buffer(data))
+
+
+@pytest.mark.parametrize("cs", ["RGB", "GRAYSCALE", "YCBCR", "RGBA"])
+def test_output_colorspaces(zj, ctx, cs):
+    data = pil_jpeg(640, 427, quality=88, seed=3)
+    g, c = decoders(zj, ctx, cs=getattr(zj.ColorSpace, cs))
+    assert np.array_equal(g.decode_buffer(data), c.decode_buffer(data))
+    assert g.gpu_status() == 0
+
+
+def test_planes_on_the_device_equal_the_cpu_walker(zj, ctx):
+    """zj_decode_scan with YCbCr output at quality 100 is a weak view of the planes; compare the pixels of every
+    colourspace instead, and the prepared scan through the low-level entry."""
+    data = pil_jpeg(1024, 768, quality=93, seed=8)
+    g, c = decoders(zj, ctx)
+    desc, info = g.prepare(data)
+    blob = g.scan_blob()
+    assert blob is not None
+    out, rc, st = ctx.decode_scan(desc, blob)
+    assert rc == 0 and st == 0
+    assert np.array_equal(out, c.decode_buffer(data))
+    rounds, _ = ctx.scan_stats()
+    assert 1 <= rounds <= 8
+
+
+def test_reference_file_with_the_eoi_cut(zj, ctx):
+    data = open(os.path.join(ROOT, "tests", "golden", "test-baseline.jpg"), "rb").read()
+    for sub in (32, 128):
+        g, c = decoders(zj, ctx, sub=sub)
+        got = g.decode_buffer(data)
+        assert g.gpu_status() == 0
+        assert np.array_equal(got, c.decode_buffer(data))
+
+
+def test_damaged_scans_fall_back_to_the_cpu_walker(zj, ctx):
+    base = pil_jpeg(320, 200, quality=85, seed=5)
+    sos = base.index(b"\xff\xda") + 14
+    rng = np.random.default_rng(12)
+    handed = 0
+    for trial in range(40):
+        b = bytearray(base)
+        if trial % 3 == 2:
+            b = b[: sos + int(rng.integers(8, len(base) - sos - 2))] + b"\xff\xd9"
+        else:
+            k = int(rng.integers(sos, len(b) - 2))
+            b[k] ^= 1 << int(rng.integers(0, 8))
+        g, c = decoders(zj, ctx)
+        try:
+            want = c.decode_buffer(bytes(b))
+        except zj.DecodeError as e:
+            with pytest.raises(zj.DecodeError) as ei:
+                g.decode_buffer(bytes(b))
+            assert ei.value.status == e.status
+            continue
+        assert np.array_equal(g.decode_buffer(bytes(b)), want), trial
+        handed += g.gpu_status() != 0
+    assert handed
+
+
+def test_pixels_stay_in_hbm(zj, ctx):
+    data = pil_jpeg(800, 600, quality=90, seed=21)
+    g, c = decoders(zj, ctx)
+    want = c.decode_buffer(data)
+    g.prepare(data)
+    p = ctx.device_alloc(want.size + 64)
+    try:
+        n = g.finish_pixels_device(p, want.size)
+        assert n == want.size
+        got = np.zeros(want.size, np.uint8)
+        ctx.d2h(got, p)
+        assert np.array_equal(got, want)
+        # the CPU-entropy path into HBM
+        c.prepare(data)
+        assert c.finish_pixels_device(p, want.size) == want.size
+        ctx.d2h(got, p)
+        assert np.array_equal(got, want)
+    finally:
+        ctx.device_free(p)
+
+
+def test_pool_with_the_device_entropy_stage(zj):
+    files = [pil_jpeg(640 + 16 * k, 480, quality=80 + k, seed=k, **({"restart_marker_rows": 1} if k % 2 else {})) for k in range(12)]
+    o = zj.ZuneJpegOptions()
+    o.entropy = zj.ENTROPY_GPU_ALWAYS
+    with zj.Pool(4, o) as pool:
+        outs, infos, sts = pool.decode_files(files)
+    assert all(s == 0 for s in sts)
+    with zj.Pool(4) as pool:
+        want, _, _ = pool.decode_files(files)
+    for a, b in zip(outs, want):
+        assert np.array_equal(a, b)

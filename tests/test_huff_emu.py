@@ -1,0 +1,179 @@
+"""CPU: the GPU entropy stage (zune-jpeg_amd/csrc/zj_huff_device.h) run thread by thread by the emulation harness
+(tests/emu) over scans the product's front-end prepared (zj_decoder_prepare), against the planes of the product's CPU
+walker (zj_decoder_decode_coefficients) -- which tests/test_jpeg_frontend.py pins to the encoder's coefficients, to
+Pillow/libjpeg and to the reference's walk (oracle/ref_walk.py).  The same comparisons run on the GPU in
+tests/test_gpu_entropy.py."""
+import importlib
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import emu_c
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import jpeg_enc  # noqa: E402
+
+MODES = {"none": (1, 1), "h": (2, 1), "v": (1, 2), "hv": (2, 2)}
+
+
+@pytest.fixture(scope="module")
+def zj():
+    return importlib.import_module("zune-jpeg_amd")
+
+
+def gpu_vs_cpu(zj, data, sub=None, expect_status=0):
+    """prepare + emulate; returns (stats, status).  Asserts equal planes when the device keeps the scan."""
+    old = os.environ.get("ZJ_HUFF_SUB")
+    if sub:
+        os.environ["ZJ_HUFF_SUB"] = str(sub)
+    try:
+        o = zj.ZuneJpegOptions()
+        o.entropy = zj.ENTROPY_GPU_ALWAYS
+        d = zj.Decoder(o)
+    finally:
+        if sub:
+            if old is None:
+                del os.environ["ZJ_HUFF_SUB"]
+            else:
+                os.environ["ZJ_HUFF_SUB"] = old
+    desc, info = d.prepare(data)
+    blob = d.scan_blob()
+    assert blob is not None, "the front-end did not prepare the scan for the device"
+    _, want, _ = zj.Decoder().decode_coefficients(data)
+    got, status, st = emu_c.huff_decode(blob, [p.size for p in want])
+    if expect_status is not None:
+        assert status == expect_status, (status, st)
+    if status == 0:
+        for c, (a, b) in enumerate(zip(got, want)):
+            assert np.array_equal(a, b), (c, st, np.nonzero(a != b)[0][:8])
+    return st, status
+
+
+def pil_jpeg(w, h, quality, subsampling=2, gray=False, seed=0, flat=False, **kw):
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = (128 + 80 * np.sin(xx / 37.0 + seed) * np.cos(yy / 23.0))[..., None] + rng.normal(0, 0 if flat else 18, (h, w, 3))
+    im = Image.fromarray(np.clip(img, 0, 255).astype(np.uint8))
+    if gray:
+        im = im.convert("L")
+    else:
+        kw["subsampling"] = subsampling
+    b = io.BytesIO()
+    im.save(b, "JPEG", quality=quality, **kw)
+    return b.getvalue()
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("wh", [(64, 48), (50, 37), (17, 9), (200, 120)])
+@pytest.mark.parametrize("restart", [0, 3])
+def test_encoder_round_trip(zj, synth, mode, wh, restart):
+    """jpeg_enc writes one table pair for all components: the place in the MCU only heals from the front, one
+    sub-sequence per round -- the slowest way through the rounds."""
+    hs, vs = MODES[mode]
+    w, h = wh
+    planes = jpeg_enc.small_planes(w, h, hs, vs, 3, seed=w + h)
+    data = jpeg_enc.encode_baseline(planes, synth.quant_tables(85), w, h, hs, vs, 3, restart=restart)
+    st, _ = gpu_vs_cpu(zj, data, sub=16 if w < 100 else 64)
+    assert st["nsub"] > 1
+
+
+def test_grayscale_and_extreme_coefficients(zj, synth):
+    w, h = 120, 64
+    planes = jpeg_enc.small_planes(w, h, 1, 1, 1, seed=3, amp=900, dc=1000)  # 10-bit magnitudes, long runs
+    gpu_vs_cpu(zj, jpeg_enc.encode_baseline(planes, synth.quant_tables(90), w, h, 1, 1, 1), sub=32)
+
+
+@pytest.mark.parametrize("sub", [16, 48, 128])
+@pytest.mark.parametrize("case", ["420", "444", "422", "gray", "420-opt", "420-ri7", "420-ri1", "420-q20", "420-rows", "444-flat"])
+def test_libjpeg_files(zj, case, sub):
+    kw = dict(quality=90)
+    if case == "444":
+        kw.update(subsampling=0)
+    elif case == "422":
+        kw.update(subsampling=1)
+    elif case == "gray":
+        kw.update(gray=True, quality=50)
+    elif case == "420-opt":
+        kw.update(optimize=True, quality=75)     # optimised tables: many codes longer than 9 bits
+    elif case == "420-ri7":
+        kw.update(restart_marker_blocks=7)
+    elif case == "420-ri1":
+        kw.update(restart_marker_blocks=1)       # a restart segment per MCU: sub-sequences of ~40 bytes
+    elif case == "420-q20":
+        kw.update(quality=20)
+    elif case == "420-rows":
+        kw.update(restart_marker_rows=1)
+    elif case == "444-flat":
+        kw.update(subsampling=0, flat=True, quality=30)   # cheap last MCUs: the reference's early exit at EOI
+    w, h = (333, 211) if case != "420-opt" else (520, 301)
+    st, _ = gpu_vs_cpu(zj, pil_jpeg(w, h, seed=len(case), **kw), sub=sub)
+    if "ri" not in case:
+        assert st["rounds"] <= 6, st  # real tables: a wrong guess falls into step within a few sub-sequences
+
+
+def test_reference_file_with_the_eoi_cut(zj):
+    """tests/golden/test-baseline.jpg: the reference never decodes the last 7 MCUs of the last row (oracle/ref_walk.py,
+    tests/test_jpeg_frontend.py); the device stage finds the same MCU with the same rule and clears them."""
+    data = open(os.path.join(ROOT, "tests", "golden", "test-baseline.jpg"), "rb").read()
+    st, _ = gpu_vs_cpu(zj, data)
+    assert st["first_seen"] == 240 * 135 - 8
+    st, _ = gpu_vs_cpu(zj, data, sub=32)
+    assert st["first_seen"] == 240 * 135 - 8
+
+
+def test_damaged_scans_are_handed_back_or_equal(zj):
+    """Bit flips and truncation: whatever the device keeps (status 0) must equal the CPU walker's planes; everything
+    else must come back with a status.  Never a crash, never an endless loop."""
+    base = pil_jpeg(160, 96, quality=85, seed=5)
+    sos = base.index(b"\xff\xda") + 14
+    rng = np.random.default_rng(11)
+    kept = handed = 0
+    for trial in range(60):
+        b = bytearray(base)
+        if trial % 3 == 2:
+            b = b[: sos + int(rng.integers(8, len(base) - sos - 2))] + b"\xff\xd9"
+        else:
+            for _ in range(1 + trial % 2):
+                k = int(rng.integers(sos, len(b) - 2))
+                b[k] ^= 1 << int(rng.integers(0, 8))
+        o = zj.ZuneJpegOptions()
+        o.entropy = zj.ENTROPY_GPU_ALWAYS
+        d = zj.Decoder(o)
+        try:
+            d.prepare(bytes(b))
+        except zj.DecodeError:
+            continue
+        blob = d.scan_blob()
+        if blob is None:
+            continue  # a stray marker in the data: the front-end kept the scan
+        try:
+            _, want, _ = zj.Decoder().decode_coefficients(bytes(b))
+        except zj.DecodeError:
+            want = None
+        got, status, st = emu_c.huff_decode(blob, [(160 // 16 + 0) * 16 // 8 * (96 // 8) * 64, 10 * 6 * 64, 10 * 6 * 64])
+        if status == 0:
+            assert want is not None, (trial, "the CPU walker rejects what the device kept")
+            for a, w_ in zip(got, want):
+                assert np.array_equal(a[: w_.size], w_), trial
+            kept += 1
+        else:
+            handed += 1
+    assert kept and handed
+
+
+def test_shared_tables_are_left_to_the_cpu_unless_forced(zj, synth):
+    planes = jpeg_enc.small_planes(64, 48, 2, 2, 3, seed=1)
+    data = jpeg_enc.encode_baseline(planes, synth.quant_tables(85), 64, 48, 2, 2, 3)
+    o = zj.ZuneJpegOptions()
+    o.entropy = zj.ENTROPY_GPU
+    d = zj.Decoder(o)
+    d.prepare(data)
+    assert d.scan_blob() is None  # (also: far below the 32 KB a trip to the device is worth)
+    big = pil_jpeg(640, 480, quality=92, seed=2)
+    d.prepare(big)
+    assert d.scan_blob() is not None

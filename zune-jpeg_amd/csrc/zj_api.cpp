@@ -47,6 +47,12 @@ struct zj_ctx {
     std::string last_error;
     int debug = 0;                // ablation switches, diagnostics only (results are WRONG when set)
     int variant = 0;              // kernel variant: 0 packed generation (default), 1 wide generation (round 1), 2 packed with direct stores
+    // GPU entropy stage (zj_decode_scan): blob + working set, the three planes (contiguous), control words read back
+    void* hbuf = nullptr; size_t hbuf_cap = 0;
+    void* hplanes = nullptr; size_t hplanes_cap = 0;
+    uint32_t* h_ctl = nullptr;    // pinned
+    int huff_rounds = 0;          // synchronisation rounds of the last scan
+    float huff_ms[3] = {0, 0, 0}; // with ZJ_HUFF_TIME: upload + sync rounds | scan + write + cut | pixel kernel (+ download) of the last scan
 };
 
 #define ZJ_HIP(ctx, call)                                                                          \
@@ -155,6 +161,9 @@ void zj_ctx_destroy(zj_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < N_SCRATCH; i++)
         if (c->scratch[i]) (void)hipFree(c->scratch[i]);
+    if (c->hbuf) (void)hipFree(c->hbuf);
+    if (c->hplanes) (void)hipFree(c->hplanes);
+    if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     for (hipStream_t st : {c->s_up, c->s_run, c->s_down})
         if (st) (void)hipStreamSynchronize(st);
     for (PipeSlot& sl : c->slots) {
@@ -483,6 +492,136 @@ int zj_decode_planes(zj_ctx* c, const zj_frame_desc* d, const int16_t* y, const 
                      const int16_t* cr, uint8_t* out)
 {
     return zj_decode_planes_batch(c, d, 1, y, cb, cr, out);
+}
+
+/* Host planes -> pixels that STAY in HBM (d_out: device pointer, 16-byte aligned): for consumers on the same GPU. */
+int zj_decode_planes_to_device(zj_ctx* c, const zj_frame_desc* d, const int16_t* y, const int16_t* cb, const int16_t* cr,
+                               uint8_t* d_out)
+{
+    Plan pl;
+    int rc = check_frame_args(c, d, 1, y, cb, cr, d_out, pl);
+    if (rc) return rc;
+    if ((uintptr_t)d_out & 15) return ZJ_ERR_ARG;
+    ZJ_HIP(c, hipSetDevice(c->device));
+    const bool chroma = pl.out != OUT_GRAY;
+    if ((rc = ensure_scratch(c, 0, pl.y_len * 2))) return rc;
+    if (chroma && ((rc = ensure_scratch(c, 1, pl.c_len * 2)) || (rc = ensure_scratch(c, 2, pl.c_len * 2)))) return rc;
+    ZJ_HIP(c, hipMemcpyAsync(c->scratch[0], y, pl.y_len * 2, hipMemcpyHostToDevice, c->stream));
+    if (chroma) {
+        ZJ_HIP(c, hipMemcpyAsync(c->scratch[1], cb, pl.c_len * 2, hipMemcpyHostToDevice, c->stream));
+        ZJ_HIP(c, hipMemcpyAsync(c->scratch[2], cr, pl.c_len * 2, hipMemcpyHostToDevice, c->stream));
+    }
+    rc = decode_device_impl(c, d, pl, 1, (const int16_t*)c->scratch[0], (const int16_t*)c->scratch[1],
+                            (const int16_t*)c->scratch[2], d_out, c->stream, 1);
+    if (rc) return rc;
+    ZJ_HIP(c, hipStreamSynchronize(c->stream));
+    return ZJ_OK;
+}
+
+int zj_device_memset(zj_ctx* c, void* d_ptr, int value, size_t bytes)
+{
+    if (!c || !d_ptr) return ZJ_ERR_ARG;
+    ZJ_HIP(c, hipSetDevice(c->device));
+    ZJ_HIP(c, hipMemsetAsync(d_ptr, value, bytes, c->stream));
+    ZJ_HIP(c, hipStreamSynchronize(c->stream));
+    return ZJ_OK;
+}
+
+/* ---- GPU entropy stage + pixel path: a prepared baseline scan (zj_huff.h) -> pixels ------------------------------- */
+static int ensure_buf(zj_ctx* c, void** p, size_t* cap, size_t bytes)
+{
+    if (bytes <= *cap) return ZJ_OK;
+    if (*p) { ZJ_HIP(c, hipStreamSynchronize(c->stream)); ZJ_HIP(c, hipFree(*p)); *p = nullptr; *cap = 0; }
+    const size_t want = bytes + bytes / 4 + 4096;
+    ZJ_HIP(c, hipMalloc(p, want));
+    *cap = want;
+    return ZJ_OK;
+}
+
+int zj_decode_scan(zj_ctx* c, const zj_frame_desc* d, const void* blob, size_t blob_bytes, uint8_t* out, int out_on_device,
+                   unsigned* status_bits)
+{
+    if (status_bits) *status_bits = 0;
+    if (!c || !d || !blob || !out || blob_bytes < sizeof(HuffScan)) return ZJ_ERR_ARG;
+    const HuffScan* h = (const HuffScan*)blob;
+    if (h->magic != HUFF_MAGIC || h->blob_bytes != blob_bytes || h->nsub == 0 || h->ncomp != d->in_components) return ZJ_ERR_ARG;
+    Plan pl;
+    int rc = make_plan(d, pl);
+    if (rc) return rc;
+    const bool chroma = h->ncomp == 3;
+    const size_t ylen = zj_plane_len(d, 0), clen = chroma ? zj_plane_len(d, 1) : 0;
+    if (ylen != (size_t)h->comp[0].bw * h->comp[0].bh * 64) return ZJ_ERR_ARG;
+    if (chroma && (clen != (size_t)h->comp[1].bw * h->comp[1].bh * 64 || clen != (size_t)h->comp[2].bw * h->comp[2].bh * 64)) return ZJ_ERR_ARG;
+    if (out_on_device && ((uintptr_t)out & 15)) return ZJ_ERR_ARG;
+    ZJ_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const size_t nsub = h->nsub;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_exit = up(blob_bytes), o_aux = o_exit + up(nsub * 8), o_base = o_aux + up(nsub * 16),
+                 o_chg = o_base + up(nsub * 16), o_ctl = o_chg + up(nsub * 2), ctl_words = 2 + HUFF_MAX_ROUNDS + 1,
+                 total = o_ctl + up(ctl_words * 4);
+    if ((rc = ensure_buf(c, &c->hbuf, &c->hbuf_cap, total))) return rc;
+    const size_t yb = up(ylen * 2), cbytes = up(clen * 2);
+    if ((rc = ensure_buf(c, &c->hplanes, &c->hplanes_cap, yb + 2 * cbytes))) return rc;
+    if (!c->h_ctl) ZJ_HIP(c, hipHostMalloc((void**)&c->h_ctl, ctl_words * 4, hipHostMallocPortable));
+    if (!out_on_device && (rc = ensure_scratch(c, 3, pl.out_len))) return rc;
+    uint8_t* base = (uint8_t*)c->hbuf;
+    HuffArgs a;
+    a.blob = base;
+    a.exit = (unsigned long long*)(base + o_exit);
+    a.aux = (HuffI4*)(base + o_aux);
+    a.base = (HuffI4*)(base + o_base);
+    a.changed = base + o_chg;
+    a.ctl = (uint32_t*)(base + o_ctl);
+    a.plane[0] = (int16_t*)c->hplanes;
+    a.plane[1] = (int16_t*)((uint8_t*)c->hplanes + yb);
+    a.plane[2] = (int16_t*)((uint8_t*)c->hplanes + yb + cbytes);
+    a.round = 0;
+    const bool timing = getenv("ZJ_HUFF_TIME") != nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (timing) { for (auto& e : ev) ZJ_HIP(c, hipEventCreate(&e)); ZJ_HIP(c, hipEventRecord(ev[0], s)); }
+    ZJ_HIP(c, hipMemcpyAsync(base, blob, blob_bytes, hipMemcpyHostToDevice, s));
+    ZJ_HIP(c, hipMemsetAsync(a.ctl, 0, ctl_words * 4, s));
+    ZJ_HIP(c, hipMemsetAsync(a.ctl + 1, 0xff, 4, s));
+    ZJ_HIP(c, hipMemsetAsync(c->hplanes, 0, yb + 2 * cbytes, s)); // the write pass stores non-zero coefficients only
+    // synchronisation rounds: 0, then groups of four with one look at the change counters per group
+    ZJ_HIP(c, launch_huff_sync(a, (uint32_t)nsub, s));
+    int round = 0;
+    bool synced = false;
+    while (!synced && round < HUFF_MAX_ROUNDS) {
+        const int group = round + 4 <= HUFF_MAX_ROUNDS ? 4 : HUFF_MAX_ROUNDS - round;
+        for (int k = 0; k < group; k++) { a.round = ++round; ZJ_HIP(c, launch_huff_sync(a, (uint32_t)nsub, s)); }
+        ZJ_HIP(c, hipMemcpyAsync(c->h_ctl, a.ctl, ctl_words * 4, hipMemcpyDeviceToHost, s));
+        ZJ_HIP(c, hipStreamSynchronize(s));
+        for (int r = round - group + 1; r <= round; r++)
+            if (c->h_ctl[2 + r] == 0) { synced = true; break; }
+    }
+    c->huff_rounds = round;
+    if (!synced) { if (status_bits) *status_bits = HUFF_ST_NO_SYNC; return ZJ_RETRY_CPU; }
+    if (timing) ZJ_HIP(c, hipEventRecord(ev[1], s));
+    ZJ_HIP(c, launch_huff_finish(a, (uint32_t)nsub, s));
+    if (timing) ZJ_HIP(c, hipEventRecord(ev[2], s));
+    uint8_t* d_out = out_on_device ? out : (uint8_t*)c->scratch[3];
+    rc = decode_device_impl(c, d, pl, 1, a.plane[0], chroma ? a.plane[1] : nullptr, chroma ? a.plane[2] : nullptr, d_out, s, 1);
+    if (rc) return rc;
+    if (!out_on_device) ZJ_HIP(c, hipMemcpyAsync(out, d_out, pl.out_len, hipMemcpyDeviceToHost, s));
+    ZJ_HIP(c, hipMemcpyAsync(c->h_ctl, a.ctl, 8, hipMemcpyDeviceToHost, s));
+    if (timing) ZJ_HIP(c, hipEventRecord(ev[3], s));
+    ZJ_HIP(c, hipStreamSynchronize(s));
+    if (timing) {
+        for (int k = 0; k < 3; k++) ZJ_HIP(c, hipEventElapsedTime(&c->huff_ms[k], ev[k], ev[k + 1]));
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    }
+    if (status_bits) *status_bits = c->h_ctl[0];
+    return c->h_ctl[0] ? ZJ_RETRY_CPU : ZJ_OK;
+}
+
+int zj_scan_stats(const zj_ctx* c, int* rounds, float ms[3])
+{
+    if (!c) return ZJ_ERR_ARG;
+    if (rounds) *rounds = c->huff_rounds;
+    if (ms) for (int k = 0; k < 3; k++) ms[k] = c->huff_ms[k];
+    return ZJ_OK;
 }
 
 /* ---- strip level ---------------------------------------------------------------------------- */

@@ -1,0 +1,80 @@
+// zj_huff.h -- the GPU entropy stage for baseline Huffman scans (device side): the scan descriptor the
+// CPU front-end prepares (zj_jpeg.cpp, prepare_scan) and the device code consumes (zj_huff_device.h, zj_huff.hip).
+//
+// What it replaces: the serial walk of src/mcu.rs:231-351 with src/bitstream.rs:314-373 (decode_mcu_block) per block.
+// A Huffman stream has no index, so the scan is cut into SUB-SEQUENCES of at most 128 bytes, one per GPU thread, and
+// decoded by self-synchronisation (Klein & Wiseman 2003; Weissenberger & Schmidt 2018/2021 for JPEG on GPUs):
+//
+//   round 0      every thread decodes its sub-sequence as if a block began at its first bit, and records where -- and in
+//                which state (block of the MCU, zig-zag index) -- it crossed into the next sub-sequence;
+//   round r      a thread whose predecessor's exit state changed in round r-1 decodes again from that state; a wrong
+//                guess usually falls into step with the true parse within a few hundred bits, so the set of threads
+//                that still change shrinks quickly; the rounds end when no exit state changed.  At that fixed point
+//                exit[i] = F_i(exit[i-1]) for every i, and exit[first of a segment] started from the known state, so the
+//                chain IS the serial parse;
+//   scan         exclusive prefix sums over the blocks each sub-sequence completed and the DC differences it saw give
+//                every thread its first block index and its DC predictors (segmented by restart interval);
+//   write        every thread decodes once more and scatters the coefficients into the zeroed whole-frame planes the
+//                pixel kernel reads (src/mcu_prog.rs:62-79 layout).
+//
+// Only the host can do the byte-level work cheaply ahead of time: it removes the stuffed zeros (T.81 B.1.1.5), cuts the
+// scan at its RSTn markers into segments (each starts a fresh bit stream with zero predictors, T.81 E.1.4) and lays the
+// sub-sequence grid over every segment.  All of it travels as ONE blob (header, tables, grid, bytes) = one H2D copy.
+#pragma once
+
+#include <stdint.h>
+
+namespace zj {
+
+constexpr int HUFF_SUB_MAX = 128;   // bytes a sub-sequence spans at most (its start is 16-byte aligned)
+constexpr int HUFF_WG = 256;        // sub-sequences (threads) per workgroup: at most 32 KB of stream staged in LDS
+constexpr int HUFF_L1_BITS = 9;     // first-level window of a decoding table
+constexpr int HUFF_L2_BITS = 7;     // second level: the remaining bits of a 16-bit code
+constexpr int HUFF_TAB_BUDGET = 9216; // u16 entries all tables of a scan may take together (18 KB of LDS): a table is
+                                      // 512 + 128 x (distinct 9-bit prefixes of its codes longer than 9 bits)
+constexpr int HUFF_MAX_TABS = 6;    // distinct (class, id) tables of a 3-component scan
+constexpr int HUFF_MAX_BPM = 10;    // blocks per MCU (T.81 B.2.3)
+constexpr int HUFF_MAX_ROUNDS = 96; // synchronisation rounds before the scan is handed back to the CPU walker
+constexpr uint32_t HUFF_MAGIC = 0x5a4a4853u;
+constexpr uint32_t HUFF_FIRST = 0x80000000u, HUFF_LAST = 0x40000000u, HUFF_SEG_MASK = 0x3fffffffu;
+
+// status bits the device raises; any of them sends the file to the CPU walker (zj_jpeg.cpp), which owns the
+// reference-compatible treatment of damaged streams
+constexpr uint32_t HUFF_ST_BAD_CODE = 1, HUFF_ST_RUN_OVER = 2, HUFF_ST_EXHAUSTED = 4, HUFF_ST_CUT_EARLY = 8,
+                   HUFF_ST_PHASE = 16, HUFF_ST_NO_SYNC = 32;
+
+// table entry (u16): 0 = no such code; bit 15 clear: (code length << 8) | symbol; bit 15 set: low byte = second-level
+// table number, indexed by the 7 bits that follow the first 9
+struct HuffBlk { uint8_t comp, hx, vy, pad; uint16_t dc_off, ac_off; }; // one block of the MCU, in scan order; its tables (entry offsets)
+struct HuffComp { uint32_t h, v, bw, bh; };                       // sampling factors, plane size in blocks
+struct HuffSub { uint32_t start, seg; };                          // byte offset in the stream; segment | HUFF_FIRST | HUFF_LAST
+struct HuffSeg { uint32_t start, end; };                          // byte range of a restart segment in the stream (end exact)
+
+struct HuffScan { // header of the blob; every off_* is a byte offset from the header, 16-byte aligned
+    uint32_t magic, blob_bytes;
+    uint32_t nsub, nseg;
+    uint32_t ri_mcus;          // MCUs per segment (the whole scan when there is no DRI)
+    uint32_t bpm, ncomp, mcu_x, mcu_y, total_mcus;
+    uint32_t is_eoi;           // the scan ends with EOI: the reference's early exit applies (zj_jpeg.cpp EoiCut)
+    uint32_t rowlen;           // MCUs per row loop of the reference (mcu.rs:145-152)
+    uint32_t tab_entries;      // u16 entries of all decoding tables together (even)
+    uint32_t off_tab, off_sub, off_seg, off_stream, stream_bytes; // stream_bytes: multiple of 16, >= 32 zero bytes at the end
+    HuffBlk blk[HUFF_MAX_BPM];
+    HuffComp comp[3];
+};
+
+struct alignas(16) HuffI4 { int32_t x, y, z, w; };
+
+// device-side working set of one scan
+struct HuffArgs {
+    const uint8_t* blob;       // device copy of the blob
+    unsigned long long* exit;  // [nsub] packed exit state of every sub-sequence
+    HuffI4* aux;               // [nsub] blocks completed, DC difference sums per component
+    HuffI4* base;              // [nsub] first block index, DC predictors (after the scan kernel)
+    uint8_t* changed;          // [2][nsub] exit state changed in the round of that parity
+    uint32_t* ctl;             // [0] status bits, [1] first MCU at which the reference has seen EOI, [2 + r] changes of round r
+    int16_t* plane[3];
+    int round;
+};
+
+} // namespace zj

@@ -1,0 +1,387 @@
+// zj_huff_device.h -- device code of the GPU entropy stage (see zj_huff.h for the algorithm and what it replaces).
+// Per-thread functions only; the kernels around them are in zj_huff.hip.  Like zj_device.h this header is also compiled
+// by g++ into the CPU emulation harness (tests/emu, ZJ_EMU), which runs the threads of a workgroup one after another:
+// test infrastructure, never part of libzjhip.so.
+//
+// The parse restates src/bitstream.rs:314-373 (decode_mcu_block: DC difference, then run/size symbols until EOB or 64
+// coefficients; EXTEND per T.81 F.2.2.1) and src/huffman.rs:73-276 (canonical codes) in the form of the product's CPU
+// walker (zj_jpeg.cpp decode_block_baseline), whose planes it must reproduce bit for bit.
+#pragma once
+
+#include "zj_huff.h"
+
+#if defined(ZJ_EMU)
+#ifndef ZJ_DEV
+#define ZJ_DEV inline
+#endif
+#else
+#include <hip/hip_runtime.h>
+#ifndef ZJ_DEV
+#define ZJ_DEV __device__ __forceinline__
+#endif
+#endif
+
+namespace zj {
+
+// ---- LDS image of a workgroup --------------------------------------------------------------------------------------
+constexpr int HUFF_W_WORDS = HUFF_WG * HUFF_SUB_MAX / 4 + 8;     // stream words staged: 256 sub-sequences + the overrun of the last
+constexpr int HUFF_W_SLOTS = HUFF_W_WORDS + HUFF_W_WORDS / 32 + 1;
+struct HuffLds {
+    uint32_t W[HUFF_W_SLOTS];                 // big-endian stream words; word k lives in slot k + k/32, so that lanes
+                                              // 32 words (one sub-sequence) apart hit different banks
+    uint16_t T[HUFF_TAB_BUDGET];              // decoding tables
+    HuffScan hdr;
+    uint8_t unz[64];                          // zig-zag index -> natural position
+    uint32_t w0, nwords;                      // first stream word staged, count
+    int any;                                  // some thread of the workgroup has work this round
+};
+ZJ_DEV uint32_t huff_slot(uint32_t k) { return k + (k >> 5); }
+
+#if defined(ZJ_EMU)
+ZJ_DEV void huff_or(uint32_t* p, uint32_t v) { *p |= v; }
+ZJ_DEV void huff_min(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
+ZJ_DEV void huff_add(uint32_t* p, uint32_t v) { *p += v; }
+ZJ_DEV uint32_t huff_bswap(uint32_t v) { return __builtin_bswap32(v); }
+#else
+ZJ_DEV void huff_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+ZJ_DEV void huff_min(uint32_t* p, uint32_t v) { atomicMin(p, v); }
+ZJ_DEV void huff_add(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
+ZJ_DEV uint32_t huff_bswap(uint32_t v) { return __builtin_bswap32(v); }
+#endif
+
+ZJ_DEV const HuffScan* huff_hdr(const uint8_t* blob) { return (const HuffScan*)blob; }
+ZJ_DEV const HuffSub* huff_subs(const uint8_t* blob) { return (const HuffSub*)(blob + huff_hdr(blob)->off_sub); }
+ZJ_DEV const HuffSeg* huff_segs(const uint8_t* blob) { return (const HuffSeg*)(blob + huff_hdr(blob)->off_seg); }
+
+// T.81 figure A.6, zig-zag index -> natural order (src/misc.rs:24-33 UN_ZIGZAG)
+ZJ_DEV uint32_t huff_unzigzag(int k)
+{
+    // packed 4 x 6 bits... kept as a byte table: the compiler places it in constant memory
+    const uint8_t t[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                           41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                           30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+    return t[k];
+}
+
+// Cooperative staging by the NT threads of workgroup `wg`: header, tables, the zig-zag table and the stream bytes of
+// the workgroup's sub-sequences (+ 32 bytes: a symbol that begins before a limit may end up to 31 bits after it).
+// A barrier must follow.
+template <int NT>
+ZJ_DEV void huff_stage(const uint8_t* blob, int wg, int tid, HuffLds& L)
+{
+    const HuffScan* g = huff_hdr(blob);
+    const HuffSub* subs = huff_subs(blob);
+    const uint32_t nsub = g->nsub;
+    const uint32_t f = (uint32_t)wg * HUFF_WG;
+    const uint32_t l1 = f + HUFF_WG < nsub ? f + HUFF_WG : nsub; // one past the last sub-sequence of the workgroup
+    const uint32_t b0 = subs[f].start;
+    const uint32_t b1 = l1 < nsub ? subs[l1].start : g->stream_bytes - 32;
+    uint32_t nwords = (b1 - b0) / 4 + 8;
+    const uint32_t left = (g->stream_bytes - b0) / 4;
+    if (nwords > left) nwords = left;
+    if (nwords > (uint32_t)HUFF_W_WORDS) nwords = HUFF_W_WORDS; // (cannot happen: the host keeps spans <= 128 bytes)
+    const uint32_t* src = (const uint32_t*)(blob + g->off_stream) + b0 / 4;
+    for (uint32_t k = (uint32_t)tid; k < nwords; k += NT) L.W[huff_slot(k)] = huff_bswap(src[k]);
+    const uint32_t* tsrc = (const uint32_t*)(blob + g->off_tab);
+    uint32_t* tdst = (uint32_t*)L.T;
+    const uint32_t tw = g->tab_entries / 2;
+    for (uint32_t k = (uint32_t)tid; k < tw; k += NT) tdst[k] = tsrc[k];
+    const uint32_t* hsrc = (const uint32_t*)blob;
+    uint32_t* hdst = (uint32_t*)&L.hdr;
+    for (uint32_t k = (uint32_t)tid; k < sizeof(HuffScan) / 4; k += NT) hdst[k] = hsrc[k];
+    if (tid < 64) L.unz[tid] = (uint8_t)huff_unzigzag(tid);
+    if (tid == 0) { L.w0 = b0 / 4; L.nwords = nwords; }
+}
+
+// ---- the parse -------------------------------------------------------------------------------------------------------
+struct HuffState { uint32_t pos, j, z; }; // bit position in the stream; block of the MCU; zig-zag index of the next coefficient (0: DC)
+ZJ_DEV unsigned long long huff_pack(HuffState s) { return ((unsigned long long)s.pos << 16) | (unsigned long long)(s.j << 8) | s.z; }
+ZJ_DEV HuffState huff_unpack(unsigned long long v) { HuffState s; s.pos = (uint32_t)(v >> 16); s.j = (uint32_t)(v >> 8) & 255; s.z = (uint32_t)v & 255; return s; }
+
+struct HuffWrite { // what only the write pass carries
+    int16_t* plane[3];
+    uint32_t blk, blk_end;  // block in progress (scan order, absolute), end of the restart segment
+    int32_t pred[3];        // DC predictors
+    uint32_t mcu, mx, my;   // MCU in progress
+    uint32_t seg_start_bits, eoi_d; // for the reference's early exit at EOI (zj_jpeg.cpp EoiCut): start of the segment,
+    int eoi_seg;                    // data bytes in front of the marker; whether this is the segment that ends with EOI
+    uint32_t* ctl;
+};
+
+ZJ_DEV int16_t* huff_block_ptr(const HuffScan& h, const HuffWrite& w, const HuffBlk b)
+{
+    const HuffComp c = h.comp[b.comp];
+    const size_t bx = (size_t)w.mx * c.h + b.hx, by = (size_t)w.my * c.v + b.vy;
+    int16_t* base = b.comp == 0 ? w.plane[0] : b.comp == 1 ? w.plane[1] : w.plane[2]; // (selects, not an indexed array)
+    return base + (by * c.bw + bx) * 64;
+}
+
+// Decodes symbols from state `s` while they BEGIN before bit `limit`.  Sync rounds (WRITE false) only track the state,
+// the blocks completed and the DC differences; the write pass stores coefficients, stops at the end of its segment's
+// blocks and raises status bits for anything a well-formed scan cannot contain.
+// Garbage in (a wrong guess) must be harmless: every read is bounded, every symbol advances by at least one bit.
+template <bool WRITE>
+ZJ_DEV HuffState huff_run(const HuffLds& L, HuffState s, uint32_t limit, bool last_sub, HuffI4& aux, HuffWrite* w)
+{
+    const HuffScan& h = L.hdr;
+    const uint32_t nwords = L.nwords;
+    const uint32_t rel = s.pos - L.w0 * 32u;
+    uint32_t next = rel >> 5;
+    const uint32_t off = rel & 31;
+    const uint32_t wa = next < nwords ? L.W[huff_slot(next)] : 0u;
+    const uint32_t wb = next + 1 < nwords ? L.W[huff_slot(next + 1)] : 0u;
+    unsigned long long buf = (((unsigned long long)wa << 32) | wb) << off; // next unread bits, left-aligned
+    int avail = 64 - (int)off;
+    next += 2;
+    uint32_t pos = s.pos, j = s.j, z = s.z;
+    int32_t n = 0, d0 = 0, d1 = 0, d2 = 0; // blocks completed, DC differences per component
+    int32_t p0 = 0, p1 = 0, p2 = 0;        // DC predictors (write pass)
+    if (WRITE) { p0 = w->pred[0]; p1 = w->pred[1]; p2 = w->pred[2]; }
+    uint32_t status = 0;
+    if (j >= h.bpm) j = 0; // (only a corrupted exit word could say so)
+    HuffBlk bi = h.blk[j];
+    uint32_t dcb = bi.dc_off, acb = bi.ac_off;
+    int16_t* dst = nullptr;
+    if (WRITE) dst = huff_block_ptr(h, *w, bi);
+    for (;;) {
+        if (WRITE && w->blk >= w->blk_end) break;
+        if (pos >= limit) {
+            if (WRITE && last_sub) status |= HUFF_ST_EXHAUSTED; // blocks are missing and the segment has no more bits
+            break;
+        }
+        if (avail < 32) {
+            const uint32_t x = next < nwords ? L.W[huff_slot(next)] : 0u;
+            buf |= (unsigned long long)x << (32 - avail);
+            avail += 32;
+            next++;
+        }
+        const uint32_t peek = (uint32_t)(buf >> 48);
+        const bool is_dc = z == 0;
+        const uint32_t tb = is_dc ? dcb : acb;
+        uint32_t e = L.T[tb + (peek >> HUFF_L2_BITS)];
+        if (e & 0x8000u) e = L.T[tb + (1u << HUFF_L1_BITS) + ((e & 0xffu) << HUFF_L2_BITS) + (peek & ((1u << HUFF_L2_BITS) - 1))];
+        uint32_t len = e >> 8, sym = e & 0xffu;
+        if (len == 0) { len = 16; sym = 0; if (WRITE) status |= HUFF_ST_BAD_CODE; }
+        uint32_t sz = is_dc ? sym : (sym & 15u);
+        if (sz > 16) { sz = 16; if (WRITE) status |= HUFF_ST_BAD_CODE; } // zj_jpeg.cpp: "Bad Huffman code in DC"
+        const uint32_t run = is_dc ? 0u : sym >> 4;
+        const uint32_t bits = sz ? (uint32_t)((buf << len) >> (64 - sz)) : 0u;
+        const int32_t val = sz ? (int32_t)bits - ((bits >> (sz - 1)) ? 0 : (int32_t)((1u << sz) - 1u)) : 0; // EXTEND
+        const uint32_t total = len + sz;
+        const uint32_t sym_start = pos;
+        buf <<= total;
+        avail -= (int)total;
+        pos += total;
+        uint32_t znew;
+        if (is_dc) {
+            if (bi.comp == 0) d0 += val; else if (bi.comp == 1) d1 += val; else d2 += val;
+            if (WRITE) {
+                int32_t p;
+                if (bi.comp == 0) p = p0 = (int32_t)((uint32_t)p0 + (uint32_t)val);
+                else if (bi.comp == 1) p = p1 = (int32_t)((uint32_t)p1 + (uint32_t)val);
+                else p = p2 = (int32_t)((uint32_t)p2 + (uint32_t)val);
+                dst[0] = (int16_t)p; // bitstream.rs:330
+            }
+            znew = 1;
+        } else if (sz) {
+            const uint32_t zz = z + run;
+            if (zz <= 63) { if (WRITE) dst[L.unz[zz]] = (int16_t)val; }
+            else if (WRITE) status |= HUFF_ST_RUN_OVER;
+            znew = zz + 1;
+        } else {
+            znew = run == 15 ? z + 16 : 64; // ZRL / EOB
+        }
+        z = znew;
+        if (z >= 64) { // the block is complete
+            z = 0;
+            n++;
+            j++;
+            if (WRITE) w->blk++;
+            if (j == h.bpm) {
+                j = 0;
+                if (WRITE) {
+                    if (w->eoi_seg) {
+                        // the reference has come across EOI iff 4 * (C / 32 + 2) > D, C = bits consumed in front of the
+                        // MCU's last symbol (zj_jpeg.cpp eoi_cut_after_mcu); C grows with the MCU index, so the first MCU
+                        // that satisfies it is the minimum
+                        const uint32_t c_last = sym_start - w->seg_start_bits;
+                        if (4u * (c_last / 32u + 2u) > w->eoi_d) huff_min(&w->ctl[1], w->mcu);
+                    }
+                    w->mcu++;
+                    if (++w->mx == h.mcu_x) { w->mx = 0; w->my++; }
+                }
+            }
+            bi = h.blk[j];
+            dcb = bi.dc_off;
+            acb = bi.ac_off;
+            if (WRITE && w->blk < w->blk_end) dst = huff_block_ptr(h, *w, bi);
+        }
+    }
+    aux.x = n; aux.y = d0; aux.z = d1; aux.w = d2;
+    if (WRITE && status) huff_or(&w->ctl[0], status);
+    HuffState o;
+    o.pos = pos; o.j = j; o.z = z;
+    return o;
+}
+
+// bit limit of sub-sequence i: where the next one of the same segment begins, or the exact end of the segment
+ZJ_DEV uint32_t huff_limit(const uint8_t* blob, const HuffSub* subs, uint32_t i, const HuffSub sub)
+{
+    if (sub.seg & HUFF_LAST) return huff_segs(blob)[sub.seg & HUFF_SEG_MASK].end * 8u;
+    return subs[i + 1].start * 8u;
+}
+
+// does sub-sequence i have work in round `round`?
+ZJ_DEV bool huff_sync_needed(const HuffArgs& a, uint32_t i, uint32_t nsub, const HuffSub* subs)
+{
+    if (i >= nsub) return false;
+    if (a.round == 0) return true;
+    if (subs[i].seg & HUFF_FIRST) return false; // its entry state is known, round 0 was final
+    return a.changed[(size_t)((a.round - 1) & 1) * nsub + i - 1] != 0;
+}
+
+// one thread of a synchronisation round (after staging)
+ZJ_DEV void huff_sync_thread(const HuffArgs& a, const HuffLds& L, uint32_t i)
+{
+    const uint32_t nsub = L.hdr.nsub;
+    if (i >= nsub) return;
+    const HuffSub* subs = huff_subs(a.blob);
+    uint8_t* ch = a.changed + (size_t)(a.round & 1) * nsub;
+    if (!huff_sync_needed(a, i, nsub, subs)) { ch[i] = 0; return; }
+    const HuffSub sub = subs[i];
+    HuffState s;
+    if (a.round == 0) { s.pos = sub.start * 8u; s.j = 0; s.z = 0; }
+    else s = huff_unpack(a.exit[i - 1]);
+    HuffI4 aux;
+    const HuffState o = huff_run<false>(L, s, huff_limit(a.blob, subs, i, sub), false, aux, nullptr);
+    const unsigned long long packed = huff_pack(o);
+    const bool differs = a.round == 0 || packed != a.exit[i];
+    a.exit[i] = packed;
+    a.aux[i] = aux;
+    ch[i] = differs ? 1 : 0;
+    if (differs && a.round) huff_add(&a.ctl[2 + a.round], 1u);
+}
+
+// one thread of the write pass (after staging)
+ZJ_DEV void huff_write_thread(const HuffArgs& a, const HuffLds& L, uint32_t i)
+{
+    const HuffScan& h = L.hdr;
+    if (i >= h.nsub) return;
+    const HuffSub* subs = huff_subs(a.blob);
+    const HuffSub sub = subs[i];
+    const uint32_t k = sub.seg & HUFF_SEG_MASK;
+    const HuffSeg seg = huff_segs(a.blob)[k];
+    HuffState s;
+    if (sub.seg & HUFF_FIRST) { s.pos = sub.start * 8u; s.j = 0; s.z = 0; }
+    else s = huff_unpack(a.exit[i - 1]);
+    const HuffI4 b = a.base[i];
+    HuffWrite w;
+    w.plane[0] = a.plane[0]; w.plane[1] = a.plane[1]; w.plane[2] = a.plane[2];
+    const uint32_t total_blocks = h.total_mcus * h.bpm;
+    const unsigned long long end64 = (unsigned long long)(k + 1) * h.ri_mcus * h.bpm;
+    w.blk = (uint32_t)b.x;
+    w.blk_end = end64 < total_blocks ? (uint32_t)end64 : total_blocks;
+    if (w.blk >= w.blk_end) return;
+    w.pred[0] = b.y; w.pred[1] = b.z; w.pred[2] = b.w;
+    w.mcu = w.blk / h.bpm;
+    if (w.blk - w.mcu * h.bpm != s.j) { huff_or(&a.ctl[0], HUFF_ST_PHASE); return; }
+    w.my = w.mcu / h.mcu_x;
+    w.mx = w.mcu - w.my * h.mcu_x;
+    w.seg_start_bits = seg.start * 8u;
+    w.eoi_d = seg.end - seg.start;
+    w.eoi_seg = h.is_eoi && k + 1 == h.nseg;
+    w.ctl = a.ctl;
+    HuffI4 aux;
+    (void)huff_run<true>(L, s, huff_limit(a.blob, subs, i, sub), (sub.seg & HUFF_LAST) != 0, aux, &w);
+}
+
+// ---- prefix sums: first block and DC predictors of every sub-sequence ----------------------------------------------
+// A segmented exclusive scan of aux[] in three phases over NT threads with contiguous chunks; a sub-sequence that
+// begins a restart segment restarts the sums at (first block of the segment, 0, 0, 0).
+struct HuffAgg { int32_t v[4]; int reset; }; // running value at the end of a chunk; `reset`: absolute (a segment began inside)
+ZJ_DEV void huff_scan_step(const HuffScan* g, const HuffSub sub, HuffAgg& r)
+{
+    if (sub.seg & HUFF_FIRST) {
+        const unsigned long long b = (unsigned long long)(sub.seg & HUFF_SEG_MASK) * g->ri_mcus * g->bpm;
+        const unsigned long long cap = (unsigned long long)g->total_mcus * g->bpm;
+        r.v[0] = (int32_t)(b < cap ? b : cap);
+        r.v[1] = r.v[2] = r.v[3] = 0;
+        r.reset = 1;
+    }
+}
+ZJ_DEV void huff_scan_add(HuffAgg& r, const HuffI4 a)
+{
+    r.v[0] = (int32_t)((uint32_t)r.v[0] + (uint32_t)a.x);
+    r.v[1] = (int32_t)((uint32_t)r.v[1] + (uint32_t)a.y);
+    r.v[2] = (int32_t)((uint32_t)r.v[2] + (uint32_t)a.z);
+    r.v[3] = (int32_t)((uint32_t)r.v[3] + (uint32_t)a.w);
+}
+// phase A: aggregate of chunk t
+ZJ_DEV HuffAgg huff_scan_chunk(const HuffArgs& a, uint32_t t, uint32_t chunk)
+{
+    const HuffScan* g = huff_hdr(a.blob);
+    const HuffSub* subs = huff_subs(a.blob);
+    HuffAgg r;
+    r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0; r.reset = 0;
+    const uint32_t i0 = t * chunk, i1 = i0 + chunk < g->nsub ? i0 + chunk : g->nsub;
+    for (uint32_t i = i0; i < i1; i++) { huff_scan_step(g, subs[i], r); huff_scan_add(r, a.aux[i]); }
+    return r;
+}
+// phase B (one thread): exclusive combination of the chunk aggregates, in place
+ZJ_DEV void huff_scan_combine(HuffAgg* agg, uint32_t nchunks)
+{
+    HuffAgg run;
+    run.v[0] = run.v[1] = run.v[2] = run.v[3] = 0; run.reset = 0;
+    for (uint32_t t = 0; t < nchunks; t++) {
+        const HuffAgg mine = agg[t];
+        agg[t] = run;
+        if (mine.reset) run = mine;
+        else for (int q = 0; q < 4; q++) run.v[q] = (int32_t)((uint32_t)run.v[q] + (uint32_t)mine.v[q]);
+    }
+}
+// phase C: chunk t again, from its incoming value
+ZJ_DEV void huff_scan_apply(const HuffArgs& a, uint32_t t, uint32_t chunk, HuffAgg r)
+{
+    const HuffScan* g = huff_hdr(a.blob);
+    const HuffSub* subs = huff_subs(a.blob);
+    const uint32_t i0 = t * chunk, i1 = i0 + chunk < g->nsub ? i0 + chunk : g->nsub;
+    for (uint32_t i = i0; i < i1; i++) {
+        huff_scan_step(g, subs[i], r);
+        HuffI4 b;
+        b.x = r.v[0]; b.y = r.v[1]; b.z = r.v[2]; b.w = r.v[3];
+        a.base[i] = b;
+        huff_scan_add(r, a.aux[i]);
+    }
+}
+
+// ---- the reference's early exit at EOI ---------------------------------------------------------------------------------
+// ctl[1] = first MCU after which the reference leaves its row loop (or >= total_mcus: none).  The MCUs that follow it
+// in the same row loop keep the zeros of the reference's fresh buffers.  The cut has to fall into the LAST row loop
+// (anything earlier shifts later MCUs, zj_jpeg.cpp scan_baseline: left to the CPU walker).  Returns the number of
+// 16-byte pieces to clear and fills first/count; `piece` p of them is cleared by huff_cut_clear.
+ZJ_DEV uint32_t huff_cut_plan(const HuffArgs& a, uint32_t* first_mcu)
+{
+    const HuffScan* g = huff_hdr(a.blob);
+    const uint32_t fs = a.ctl[1];
+    if (fs >= g->total_mcus || fs + 1 >= g->total_mcus) return 0;
+    if (fs / g->rowlen != (g->total_mcus - 1) / g->rowlen) { huff_or(&a.ctl[0], HUFF_ST_CUT_EARLY); return 0; }
+    *first_mcu = fs + 1;
+    return (g->total_mcus - fs - 1) * g->bpm * 8u;
+}
+ZJ_DEV void huff_cut_clear(const HuffArgs& a, uint32_t first_mcu, uint32_t piece)
+{
+    const HuffScan* g = huff_hdr(a.blob);
+    const uint32_t per_mcu = g->bpm * 8u;
+    const uint32_t m = first_mcu + piece / per_mcu, rest = piece % per_mcu;
+    const HuffBlk b = g->blk[rest / 8u];
+    const HuffComp c = g->comp[b.comp];
+    const uint32_t my = m / g->mcu_x, mx = m - my * g->mcu_x;
+    const size_t bx = (size_t)mx * c.h + b.hx, by = (size_t)my * c.v + b.vy;
+    int16_t* base = b.comp == 0 ? a.plane[0] : b.comp == 1 ? a.plane[1] : a.plane[2];
+    HuffI4* p = (HuffI4*)(base + (by * c.bw + bx) * 64) + (rest & 7u);
+    HuffI4 zero;
+    zero.x = zero.y = zero.z = zero.w = 0;
+    *p = zero;
+}
+
+} // namespace zj

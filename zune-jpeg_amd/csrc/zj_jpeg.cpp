@@ -12,6 +12,7 @@
 // Plane layout: per component [block_row][block_col][64] int16, natural order (un-zigzagged on write,
 // src/bitstream.rs:343,359), block_cols = mcu_x * h_samp (width_stride / 8, src/headers.rs:338).
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <emmintrin.h> // _mm_stream_si128: the coefficient planes are written once and read by DMA
@@ -23,6 +24,7 @@
 #include <vector>
 
 #include "../../include/zjhip.h"
+#include "zj_huff.h"
 
 namespace {
 
@@ -39,8 +41,10 @@ struct Huff {
     int32_t maxcode[18];   // per length, -1 if none
     int32_t valoff[17];
     uint8_t vals[256];
+    uint8_t nlen[17];      // codes per length, as the DHT segment gave them (for the GPU tables, gpu_table())
     int build(const uint8_t counts[17], const uint8_t* symbols, int nsym, std::string& err)
     {
+        memcpy(nlen, counts, 17);
         uint16_t codes[257];
         uint8_t sizes[257];
         int k = 0;
@@ -235,9 +239,17 @@ struct zj_decoder {
     int max_width = 16384, max_height = 16384, max_scans = 64;
     int threads = 4;       // options.rs:33 (default 4): here, restart segments / plane zeroing in parallel
     bool pinned = false;   // coefficient planes in pinned host memory
+    int entropy = 0;       // zj_options.entropy: 0 CPU walker, 1 GPU for baseline scans worth it, 2 GPU for every eligible scan
+    int sub_bytes = 128;   // sub-sequence size of the GPU entropy stage (ZJ_HUFF_SUB: 16..128, multiple of 16)
+    PlaneStore blob_store; // the scan as the GPU entropy stage wants it (zj_huff.h), pinned when the planes are
+    size_t blob_len = 0;
+    unsigned gpu_status = 0;             // HUFF_ST_* bits of the last device scan (0: it was used as it stood)
+    bool scan_ready = false;             // blob_store holds the prepared scan of the image whose headers are parsed
+    const uint8_t* src = nullptr;        // the caller's file (must stay valid until the pixels are finished): the CPU
+    size_t src_len = 0;                  // walker decodes it if the device hands the scan back
     uint32_t flags = 0, out_layout = 0; // extensions of the pixel path, passed through to zj_frame_desc
     PlaneStore store[3];
-    ~zj_decoder() { for (auto& st : store) st.release(); }
+    ~zj_decoder() { for (auto& st : store) st.release(); blob_store.release(); }
     // state
     std::string err;
     int err_code = 0;
@@ -891,6 +903,179 @@ int scan_progressive(zj_decoder* d, BitReader& br)
 }
 
 // after a scan: find the next marker (mcu_prog.rs:436-472)
+// ---- the scan as the GPU entropy stage wants it (zj_huff.h) --------------------------------------------------------
+// Two-level decoding table: 512 first-level entries indexed by the next 9 bits; codes longer than 9 bits hang off their
+// 9-bit prefix in a 128-entry second level.  Returns the entries used, or -1 if they exceed `room`.
+int gpu_table(const Huff& h, uint16_t* out, int room)
+{
+    constexpr int L1 = 1 << zj::HUFF_L1_BITS, L2 = 1 << zj::HUFF_L2_BITS;
+    if (room < L1) return -1;
+    memset(out, 0, L1 * sizeof(uint16_t));
+    uint32_t code = 0;
+    int k = 0, links = 0;
+    for (int l = 1; l <= 16; l++) {
+        for (int i = 0; i < h.nlen[l]; i++, k++, code++) {
+            const uint16_t e = (uint16_t)((l << 8) | h.vals[k]);
+            if (l <= zj::HUFF_L1_BITS) {
+                const uint32_t base = code << (zj::HUFF_L1_BITS - l);
+                for (uint32_t q = 0; q < (1u << (zj::HUFF_L1_BITS - l)); q++) out[base + q] = e;
+            } else {
+                const uint32_t prefix = code >> (l - zj::HUFF_L1_BITS);
+                if (!out[prefix]) {
+                    if (links == 255 || L1 + (links + 1) * L2 > room) return -1;
+                    memset(out + L1 + links * L2, 0, L2 * sizeof(uint16_t));
+                    out[prefix] = (uint16_t)(0x8000 | links++);
+                }
+                const uint32_t sub = (uint32_t)L1 + ((out[prefix] & 0xffu) << zj::HUFF_L2_BITS);
+                const uint32_t low = (code << (16 - l)) & (uint32_t)(L2 - 1);
+                for (uint32_t q = 0; q < (1u << (16 - l)); q++) out[sub + low + q] = e;
+            }
+        }
+        code <<= 1;
+    }
+    return L1 + links * L2;
+}
+
+// copies [s, e) without the zero that follows every 0xFF (T.81 B.1.1.5); (size_t)-1: a 0xFF followed by anything else
+size_t unstuff(const uint8_t* s, const uint8_t* e, uint8_t* dst)
+{
+    uint8_t* const d0 = dst;
+    while (s < e) {
+        const uint8_t* f = (const uint8_t*)memchr(s, 0xFF, (size_t)(e - s));
+        if (!f) { memcpy(dst, s, (size_t)(e - s)); dst += e - s; break; }
+        const size_t n = (size_t)(f - s) + 1;
+        memcpy(dst, s, n);
+        dst += n;
+        if (f + 1 >= e || f[1] != 0x00) return (size_t)-1;
+        s = f + 2;
+    }
+    return (size_t)(dst - d0);
+}
+
+// ZJ_OK: d->blob_store holds the scan.  ZJ_ERR_UNSUPPORTED: not a scan for the device (not an error: the caller runs
+// the CPU walker, which also owns every message about damaged files).
+int prepare_scan(zj_decoder* d, const uint8_t* p, const uint8_t* end)
+{
+    using namespace zj;
+    d->scan_ready = false;
+    auto why = [](int n) { if (getenv("ZJ_HUFF_DEBUG")) fprintf(stderr, "prepare_scan: left to the CPU walker (reason %d)\n", n); return (int)ZJ_ERR_UNSUPPORTED; };
+    if (d->progressive || d->ns != d->ncomp) return why(1);
+    for (int i = 0; i < d->ncomp; i++)
+        if (!d->dc[d->comps[i].td & 3].present || !d->ac[d->comps[i].ta & 3].present) return why(2);
+    const long long total = (long long)d->mcu_x * d->mcu_y;
+    std::vector<const uint8_t*> seg;
+    int nseg = 1;
+    long long ri = total;
+    bool is_eoi = false;
+    if (d->restart_interval > 0 && total > d->restart_interval) {
+        ri = d->restart_interval;
+        nseg = (int)((total + ri - 1) / ri);
+        if (!find_restart_segments(p, end, nseg, seg)) return why(3);
+        is_eoi = seg[(size_t)nseg] + 1 < end && seg[(size_t)nseg][1] == 0xD9;
+    } else {
+        const uint8_t* e = find_scan_end(p, end, &is_eoi);
+        if (!e) return why(4);
+        seg.push_back(p);
+        seg.push_back(e);
+    }
+    const size_t scan_bytes = (size_t)(seg[(size_t)nseg] - p);
+    if (d->entropy < 2 && scan_bytes < (size_t)32 << 10) return why(5); // not worth a trip
+    if (scan_bytes > (size_t)200 << 20 || (size_t)nseg > HUFF_SEG_MASK / 2) return why(6); // 32-bit bit positions
+    // the MCU's blocks in scan order, distinct tables
+    HuffScan h;
+    memset(&h, 0, sizeof h);
+    int ntab = 0, tab_key[HUFF_MAX_TABS], tab_off[HUFF_MAX_TABS], tab_used = 0;
+    std::vector<uint16_t> tabs((size_t)HUFF_TAB_BUDGET);
+    auto table_index = [&](int cls, int id) { // entry offset of the table, -1: the tables do not fit the device's LDS budget
+        const int key = cls * 4 + id;
+        for (int t = 0; t < ntab; t++) if (tab_key[t] == key) return tab_off[t];
+        const int n = gpu_table(cls ? d->ac[id] : d->dc[id], tabs.data() + tab_used, HUFF_TAB_BUDGET - tab_used);
+        if (n < 0) return -1;
+        tab_key[ntab] = key;
+        tab_off[ntab++] = tab_used;
+        tab_used += n;
+        return tab_used - n;
+    };
+    int bpm = 0;
+    for (int ci = 0; ci < d->ns; ci++) {
+        const Comp& cm = d->comps[d->order[ci]];
+        const int tdc = table_index(0, cm.td & 3), tac = table_index(1, cm.ta & 3);
+        if (tdc < 0 || tac < 0) return why(12);
+        for (int v = 0; v < cm.v; v++)
+            for (int hh = 0; hh < cm.h; hh++) {
+                if (bpm == HUFF_MAX_BPM) return why(7);
+                HuffBlk& b = h.blk[bpm++];
+                b.comp = (uint8_t)d->order[ci]; b.hx = (uint8_t)hh; b.vy = (uint8_t)v;
+                b.dc_off = (uint16_t)tdc; b.ac_off = (uint16_t)tac;
+            }
+    }
+    if (d->entropy < 2 && bpm > 1) {
+        // When every block of the MCU decodes with the same pair of tables the parse does not depend on the block's
+        // place in the MCU, so a wrong guess of that place never corrects itself: it only heals one sub-sequence per
+        // round from the front.  No encoder of YCbCr files shares luma and chroma tables; leave the odd one to the CPU.
+        bool same = true;
+        for (int b = 1; b < bpm; b++) same = same && h.blk[b].dc_off == h.blk[0].dc_off && h.blk[b].ac_off == h.blk[0].ac_off;
+        if (same) return why(13);
+    }
+    for (int i = 0; i < d->ncomp; i++) {
+        h.comp[i].h = (uint32_t)d->comps[i].h; h.comp[i].v = (uint32_t)d->comps[i].v;
+        h.comp[i].bw = (uint32_t)d->comps[i].bw; h.comp[i].bh = (uint32_t)d->comps[i].bh;
+    }
+    const size_t sub = (size_t)d->sub_bytes;
+    const size_t max_sub = scan_bytes / sub + (size_t)nseg + 1;
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t off_tab = up16(sizeof(HuffScan));
+    const size_t off_sub = up16(off_tab + (size_t)tab_used * 2);
+    const size_t off_seg = up16(off_sub + (max_sub + 1) * sizeof(HuffSub));
+    const size_t off_stream = up16(off_seg + (size_t)nseg * sizeof(HuffSeg));
+    const size_t cap = off_stream + scan_bytes + 16 * (size_t)nseg + 64;
+    uint8_t* blob = (uint8_t*)d->blob_store.ensure(cap, d->pinned);
+    if (!blob) return why(8);
+    memcpy(blob + off_tab, tabs.data(), (size_t)tab_used * 2);
+    HuffSub* subs = (HuffSub*)(blob + off_sub);
+    HuffSeg* segs = (HuffSeg*)(blob + off_seg);
+    uint8_t* stream = blob + off_stream;
+    size_t o = 0, nsub = 0;
+    for (int k = 0; k < nseg; k++) {
+        const uint8_t* s0 = seg[(size_t)k];
+        const uint8_t* s1 = seg[(size_t)k + 1] - (k + 1 < nseg ? 2 : 0); // without the RSTn that follows
+        while (s1 > s0 && s1[-1] == 0xFF) s1--;                          // fill bytes belong to the marker
+        if (s1 < s0) return why(10);
+        const size_t len = unstuff(s0, s1, stream + o);
+        if (len == (size_t)-1) return why(11);
+        segs[k].start = (uint32_t)o;
+        segs[k].end = (uint32_t)(o + len);
+        const size_t first = nsub;
+        for (size_t b = 0; b == 0 || b < len; b += sub) {
+            subs[nsub].start = (uint32_t)(o + b);
+            subs[nsub].seg = (uint32_t)k;
+            nsub++;
+        }
+        subs[first].seg |= HUFF_FIRST;
+        subs[nsub - 1].seg |= HUFF_LAST;
+        const size_t next = up16(o + len);
+        memset(stream + o + len, 0, next - (o + len));
+        o = next;
+    }
+    memset(stream + o, 0, 32);
+    subs[nsub].start = (uint32_t)o; // sentinel
+    subs[nsub].seg = 0;
+    h.magic = HUFF_MAGIC;
+    h.blob_bytes = (uint32_t)(off_stream + o + 32);
+    h.nsub = (uint32_t)nsub; h.nseg = (uint32_t)nseg; h.ri_mcus = (uint32_t)ri;
+    h.bpm = (uint32_t)bpm; h.ncomp = (uint32_t)d->ncomp;
+    h.mcu_x = (uint32_t)d->mcu_x; h.mcu_y = (uint32_t)d->mcu_y; h.total_mcus = (uint32_t)total;
+    h.is_eoi = is_eoi ? 1 : 0;
+    h.rowlen = (uint32_t)eoi_rowlen(d);
+    h.tab_entries = (uint32_t)tab_used;
+    h.off_tab = (uint32_t)off_tab; h.off_sub = (uint32_t)off_sub; h.off_seg = (uint32_t)off_seg;
+    h.off_stream = (uint32_t)off_stream; h.stream_bytes = (uint32_t)(o + 32);
+    memcpy(blob, &h, sizeof h);
+    d->blob_len = h.blob_bytes;
+    d->scan_ready = true;
+    return ZJ_OK;
+}
+
 int next_marker(BitReader& br)
 {
     if (br.marker) { int m = br.marker; br.marker = 0; return m; }
@@ -903,10 +1088,12 @@ int next_marker(BitReader& br)
     return -1;
 }
 
-int decode_all(zj_decoder* d, const uint8_t* buf, size_t len, bool headers_only)
+// for_device: a baseline scan the GPU entropy stage can take is only PREPARED (prepare_scan: scan_ready instead of
+// coef_valid); everything else is decoded here as always
+int decode_all(zj_decoder* d, const uint8_t* buf, size_t len, bool headers_only, bool for_device = false)
 {
     d->err.clear(); d->err_code = 0; d->seen_sof = 0; d->scans = 0; d->restart_interval = 0;
-    d->coef_valid = false;
+    d->coef_valid = false; d->scan_ready = false; d->src = nullptr; d->src_len = 0;
     for (int i = 0; i < 4; i++) { d->qt_present[i] = false; d->dc[i].present = false; d->ac[i].present = false; }
     Cursor c{buf, buf + len};
     int rc = parse_headers(d, c, true);
@@ -916,6 +1103,10 @@ int decode_all(zj_decoder* d, const uint8_t* buf, size_t len, bool headers_only)
     BitReader br;
     br.p = c.p; br.end = c.end; br.istart = c.p;
     if (!d->progressive) {
+        if (for_device && d->entropy && prepare_scan(d, c.p, c.end) == ZJ_OK) {
+            d->scans = 1; d->src = buf; d->src_len = len;
+            return ZJ_OK;
+        }
         rc = scan_baseline(d, br);
         d->scans = 1;
         d->coef_valid = rc == ZJ_OK;
@@ -960,6 +1151,11 @@ zj_decoder* zj_decoder_new(const zj_options* opt)
         d->pinned = opt->pinned_planes != 0;
         d->flags = opt->flags;
         d->out_layout = opt->out_layout;
+        d->entropy = opt->entropy;
+    }
+    if (d) {
+        if (const char* e = getenv("ZJ_ENTROPY")) d->entropy = atoi(e); // A/B switch for whole applications
+        if (const char* e = getenv("ZJ_HUFF_SUB")) { const int v = atoi(e); if (v >= 16 && v <= zj::HUFF_SUB_MAX && v % 16 == 0) d->sub_bytes = v; }
     }
     return d;
 }
@@ -1014,29 +1210,85 @@ int zj_decoder_decode_coefficients(zj_decoder* d, const uint8_t* buf, size_t len
     return ZJ_OK;
 }
 
-int zj_decoder_finish_pixels(zj_decoder* d, zj_ctx* ctx, uint8_t* out, size_t out_cap, size_t* out_len)
+int zj_decoder_prepare(zj_decoder* d, const uint8_t* buf, size_t len, zj_frame_desc* desc, zj_image_info* info)
+{
+    if (!d || !buf) return ZJ_ERR_ARG;
+    int rc = decode_all(d, buf, len, false, true);
+    if (rc) return rc;
+    fill_info(d, info, desc);
+    return ZJ_OK;
+}
+
+int zj_decoder_scan_blob(const zj_decoder* d, const void** blob, size_t* len)
+{
+    if (!d || !d->scan_ready) return ZJ_ERR_ARG;
+    if (blob) *blob = d->blob_store.p;
+    if (len) *len = d->blob_len;
+    return ZJ_OK;
+}
+
+static int finish_impl(zj_decoder* d, zj_ctx* ctx, uint8_t* out, size_t out_cap, size_t* out_len, int on_device)
 {
     if (!d || !ctx || !out) return ZJ_ERR_ARG;
-    // read_headers alone allocates the planes but decodes nothing into them: only a complete decode_all counts
-    if (!d->seen_sof || d->err_code || !d->coef_valid) return fail(d, ZJ_ERR_ARG, "no successfully decoded coefficients to finish");
+    // read_headers alone allocates the planes but decodes nothing into them: only a complete decode_all (or a prepared
+    // scan) counts
+    if (!d->seen_sof || d->err_code || (!d->coef_valid && !d->scan_ready)) return fail(d, ZJ_ERR_ARG, "no successfully decoded coefficients to finish");
     zj_frame_desc fd;
     fill_info(d, nullptr, &fd);
     // grayscale JPEG decoded to RGB: the reference converts nothing and returns zeros (worker.rs:131)
     const size_t need = zj_out_len(&fd);
     if (out_len) *out_len = need;
     if (out_cap < need) return fail(d, ZJ_ERR_ARG, "output buffer too small");
-    if (fd.in_components == 1 && fd.out_colorspace != ZJ_CS_GRAYSCALE) { memset(out, 0, need); return ZJ_OK; }
-    const int rc = zj_decode_planes(ctx, &fd, d->comps[0].coef, d->ncomp == 3 ? d->comps[1].coef : nullptr,
-                                    d->ncomp == 3 ? d->comps[2].coef : nullptr, out);
+    const bool zeros = fd.in_components == 1 && fd.out_colorspace != ZJ_CS_GRAYSCALE;
+    if (d->scan_ready && !zeros) {
+        unsigned status = 0;
+        const int rc = zj_decode_scan(ctx, &fd, d->blob_store.p, d->blob_len, out, on_device, &status);
+        d->gpu_status = status;
+        if (rc == ZJ_OK) return ZJ_OK;
+        if (rc != ZJ_RETRY_CPU) return fail(d, rc, std::string("GPU entropy stage: ") + zj_strerror(rc) + " " + zj_last_error(ctx));
+        // the device met something only the CPU walker treats the way the reference does: decode the file there
+        const uint8_t* src = d->src;
+        const size_t src_len = d->src_len;
+        const int rc2 = decode_all(d, src, src_len, false, false);
+        if (rc2) return rc2;
+    } else if (d->scan_ready) {
+        // (nothing is decoded for the all-zero output; a damaged scan would have been an error on the CPU path)
+        const uint8_t* src = d->src;
+        const size_t src_len = d->src_len;
+        const int rc2 = decode_all(d, src, src_len, false, false);
+        if (rc2) return rc2;
+    }
+    if (zeros) {
+        if (on_device) { const int rc = zj_device_memset(ctx, out, 0, need); if (rc) return fail(d, rc, "memset"); }
+        else memset(out, 0, need);
+        return ZJ_OK;
+    }
+    int rc;
+    if (on_device) rc = zj_decode_planes_to_device(ctx, &fd, d->comps[0].coef, d->ncomp == 3 ? d->comps[1].coef : nullptr,
+                                                   d->ncomp == 3 ? d->comps[2].coef : nullptr, out);
+    else rc = zj_decode_planes(ctx, &fd, d->comps[0].coef, d->ncomp == 3 ? d->comps[1].coef : nullptr,
+                               d->ncomp == 3 ? d->comps[2].coef : nullptr, out);
     if (rc) return fail(d, rc, std::string("pixel path: ") + zj_strerror(rc) + " " + zj_last_error(ctx));
     return ZJ_OK;
 }
+
+int zj_decoder_finish_pixels(zj_decoder* d, zj_ctx* ctx, uint8_t* out, size_t out_cap, size_t* out_len)
+{
+    return finish_impl(d, ctx, out, out_cap, out_len, 0);
+}
+
+int zj_decoder_finish_pixels_device(zj_decoder* d, zj_ctx* ctx, uint8_t* d_out, size_t out_cap, size_t* out_len)
+{
+    return finish_impl(d, ctx, d_out, out_cap, out_len, 1);
+}
+
+unsigned zj_decoder_gpu_status(const zj_decoder* d) { return d ? d->gpu_status : 0; }
 
 int zj_decoder_decode_buffer(zj_decoder* d, zj_ctx* ctx, const uint8_t* buf, size_t len, uint8_t* out,
                              size_t out_cap, size_t* out_len, zj_image_info* info)
 {
     if (!d || !ctx || !buf || !out) return ZJ_ERR_ARG;
-    int rc = zj_decoder_decode_coefficients(d, buf, len, nullptr, nullptr, nullptr, info);
+    int rc = zj_decoder_prepare(d, buf, len, nullptr, info);
     if (rc) return rc;
     return zj_decoder_finish_pixels(d, ctx, out, out_cap, out_len);
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "zj_device.h"
+#include "zj_huff.h"
 
 namespace zj {
 hipError_t launch_fused(int hs, int vs, int out, int variant, int fast, const Params& p, hipStream_t s);
@@ -23,5 +24,7 @@ hipError_t launch_labmem(int i, const void* in, void* out, long long bytes, hipS
 int lab_count();
 const char* lab_name(int i);
 hipError_t launch_lab(int i, const int32_t qt[3][64], int* out, int blocks, int iters, hipStream_t s);
+hipError_t launch_huff_sync(const HuffArgs& a, uint32_t nsub, hipStream_t s);   // one synchronisation round (a.round)
+hipError_t launch_huff_finish(const HuffArgs& a, uint32_t nsub, hipStream_t s); // prefix sums, write pass, EOI cut
 hipError_t launch_ub_clock(unsigned long long* out, int blocks, int iters, hipStream_t s);
 } // namespace zj

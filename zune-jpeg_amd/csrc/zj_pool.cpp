@@ -95,7 +95,7 @@ struct zj_pool {
             memset(&info, 0, sizeof info);
             zj_frame_desc fd;
             const double t0 = now();
-            const int rc = zj_decoder_decode_coefficients(dec, b.bufs[i], b.lens[i], &fd, nullptr, nullptr, &info);
+            const int rc = zj_decoder_prepare(dec, b.bufs[i], b.lens[i], &fd, &info); // Huffman here, or only the byte-level preparation for the device (zj_options.entropy)
             const double dt = now() - t0;
             lk.lock();
             entropy_s += dt;

@@ -82,10 +82,18 @@ class FrameDesc(C.Structure):  # zj_frame_desc
         return d
 
 
+ENTROPY_CPU, ENTROPY_GPU, ENTROPY_GPU_ALWAYS = 0, 1, 2
+RETRY_CPU = 1  # zj_decode_scan: the device hands the scan back
+# csrc/zj_huff.h HUFF_ST_*
+HUFF_ST = {1: "bad code", 2: "run past 63", 4: "bits exhausted", 8: "EOI cut before the last row loop", 16: "phase",
+           32: "no synchronisation"}
+
+
 class Options(C.Structure):  # zj_options
     _fields_ = [("out_colorspace", C.c_int32), ("strict_mode", C.c_int32), ("max_width", C.c_int32),
                 ("max_height", C.c_int32), ("max_scans", C.c_int32), ("num_threads", C.c_int32),
-                ("pinned_planes", C.c_int32), ("flags", C.c_uint32), ("out_layout", C.c_uint32)]
+                ("pinned_planes", C.c_int32), ("flags", C.c_uint32), ("out_layout", C.c_uint32),
+                ("entropy", C.c_int32)]
 
 
 class ImageInfo(C.Structure):  # zj_image_info  <->  ImageInfo, src/decoder.rs:652-668
@@ -110,6 +118,7 @@ class ZuneJpegOptions:
         self.pinned_planes = False
         self.flags = 0          # FLAG_* extensions of the pixel path (0 = the reference's bytes)
         self.out_layout = LAYOUT_HWC
+        self.entropy = ENTROPY_CPU  # ENTROPY_GPU / ENTROPY_GPU_ALWAYS: baseline Huffman scans on the device
 
     def to_c(self):
         o = Options()
@@ -119,6 +128,7 @@ class ZuneJpegOptions:
         o.num_threads = int(self.num_threads)
         o.pinned_planes = int(bool(self.pinned_planes))
         o.flags, o.out_layout = int(self.flags), int(self.out_layout)
+        o.entropy = int(self.entropy)
         return o
 
 
@@ -132,7 +142,9 @@ ABI = [  # every symbol include/zjhip.h declares
     "zj_choose_upsample_func", "zj_choose_ycbcr_to_rgb_convert_func", "zj_plane_len", "zj_out_len",
     "zj_num_components", "zj_decode_planes", "zj_decode_planes_batch", "zj_decode_planes_device",
     "zj_time_decode_device", "zj_alloc_pinned", "zj_free_pinned", "zj_set_thread_device", "zj_device_alloc",
-    "zj_device_free", "zj_memcpy_h2d", "zj_memcpy_d2h", "zj_sync",
+    "zj_device_free", "zj_memcpy_h2d", "zj_memcpy_d2h", "zj_sync", "zj_device_memset",
+    "zj_decode_planes_to_device", "zj_decode_scan", "zj_scan_stats", "zj_decoder_prepare",
+    "zj_decoder_finish_pixels_device", "zj_decoder_scan_blob", "zj_decoder_gpu_status",
     "zj_decoder_new", "zj_decoder_free", "zj_decoder_error", "zj_decoder_read_headers",
     "zj_decoder_decode_coefficients", "zj_decoder_finish_pixels", "zj_decoder_decode_buffer",
     "zj_decoder_parallel_segments",
@@ -233,6 +245,16 @@ def lib():
     L.zj_decoder_decode_coefficients.argtypes = [vp, vp, sz, C.POINTER(FrameDesc), C.POINTER(C.c_void_p), C.POINTER(sz), C.POINTER(ImageInfo)]
     L.zj_decoder_decode_buffer.argtypes = [vp, vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(ImageInfo)]
     L.zj_decoder_parallel_segments.argtypes = [vp]
+    L.zj_decoder_prepare.argtypes = [vp, vp, sz, C.POINTER(FrameDesc), C.POINTER(ImageInfo)]
+    L.zj_decoder_finish_pixels.argtypes = [vp, vp, vp, sz, C.POINTER(sz)]
+    L.zj_decoder_finish_pixels_device.argtypes = [vp, vp, vp, sz, C.POINTER(sz)]
+    L.zj_decoder_scan_blob.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(sz)]
+    L.zj_decoder_gpu_status.restype = C.c_uint
+    L.zj_decoder_gpu_status.argtypes = [vp]
+    L.zj_decode_scan.argtypes = [vp, C.POINTER(FrameDesc), vp, sz, vp, C.c_int, C.POINTER(C.c_uint)]
+    L.zj_decode_planes_to_device.argtypes = [vp, C.POINTER(FrameDesc), i16p, i16p, i16p, vp]
+    L.zj_scan_stats.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_float)]
+    L.zj_device_memset.argtypes = [vp, vp, C.c_int, sz]
     L.zj_pool_create.restype = vp
     L.zj_pool_create.argtypes = [C.c_int, C.c_int, C.POINTER(Options), C.POINTER(C.c_int)]
     L.zj_pool_destroy.argtypes = [vp]
@@ -448,6 +470,29 @@ class Context:
     def sync(self):
         _check(lib().zj_sync(self._h), "zj_sync", self._h)
 
+    def scan_stats(self):
+        """(synchronisation rounds, [ms upload + rounds, ms prefix sums + write pass, ms pixel kernel + download]) of the
+        last scan the GPU entropy stage decoded on this context; the times need ZJ_HUFF_TIME in the environment."""
+        r = C.c_int(0)
+        ms = (C.c_float * 3)()
+        _check(lib().zj_scan_stats(self._h, C.byref(r), ms), "zj_scan_stats", self._h)
+        return r.value, [float(x) for x in ms]
+
+    def decode_scan(self, desc, blob, out=None, device_out=None):
+        """zj_decode_scan: a prepared scan -> pixels (host array, or a device pointer with device_out).  Returns
+        (pixels or None, return code, status bits)."""
+        blob = np.ascontiguousarray(blob, np.uint8)
+        st = C.c_uint(0)
+        if device_out is not None:
+            rc = lib().zj_decode_scan(self._h, C.byref(desc), _ptr(blob), blob.size, device_out, 1, C.byref(st))
+            return None, rc, st.value
+        if out is None:
+            out = np.zeros(lib().zj_out_len(C.byref(desc)), np.uint8)
+        rc = lib().zj_decode_scan(self._h, C.byref(desc), _ptr(blob), blob.size, _ptr(out), 0, C.byref(st))
+        if rc < 0:
+            _check(rc, "zj_decode_scan", self._h)
+        return out, rc, st.value
+
     def ubench(self, op, blocks=2048, iters=200, reps=5):
         ms = C.c_float(0)
         _check(lib().zj_ubench(self._h, op, blocks, iters, reps, C.byref(ms)), "zj_ubench", self._h)
@@ -531,6 +576,52 @@ class Decoder:
                   for c in range(info.components)]
         self._info = info
         return desc, planes, info
+
+    def prepare(self, buf):
+        """Stage 1 (CPU) as the options ask: (FrameDesc, ImageInfo).  With a GPU entropy setting a baseline scan is
+        only prepared (scan_blob() then returns it); `buf` is kept alive by this object until the next call."""
+        self._src = np.frombuffer(bytes(buf), np.uint8)
+        desc, info = FrameDesc(), ImageInfo()
+        rc = lib().zj_decoder_prepare(self._d, _ptr(self._src), self._src.size, C.byref(desc), C.byref(info))
+        if rc:
+            self._raise(rc)
+        self._info = info
+        return desc, info
+
+    def scan_blob(self):
+        """The prepared scan (csrc/zj_huff.h) of the last prepare() as a uint8 array, or None."""
+        p, n = C.c_void_p(), C.c_size_t(0)
+        if lib().zj_decoder_scan_blob(self._d, C.byref(p), C.byref(n)):
+            return None
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).copy()
+
+    def gpu_status(self):
+        """HUFF_ST bits with which the device handed the last scan back to the CPU walker (0: it kept it)."""
+        return int(lib().zj_decoder_gpu_status(self._d))
+
+    def finish_pixels(self, out=None):
+        """Stage 2 after prepare() / decode_coefficients(): the pixels as a uint8 array."""
+        if self._ctx is None:
+            self._ctx = Context()
+        info = self._info
+        ncomp = 1 if info.components == 1 else ColorSpace(self._out_cs).num_components()
+        if out is None:
+            out = np.zeros(int(info.width) * int(info.height) * ncomp, np.uint8)
+        n = C.c_size_t(0)
+        rc = lib().zj_decoder_finish_pixels(self._d, self._ctx.handle, _ptr(out), out.size, C.byref(n))
+        if rc:
+            self._raise(rc)
+        return out[: n.value]
+
+    def finish_pixels_device(self, d_out, cap):
+        """Stage 2 with the pixels left in HBM at device pointer d_out; returns their length in bytes."""
+        if self._ctx is None:
+            self._ctx = Context()
+        n = C.c_size_t(0)
+        rc = lib().zj_decoder_finish_pixels_device(self._d, self._ctx.handle, d_out, cap, C.byref(n))
+        if rc:
+            self._raise(rc)
+        return n.value
 
     def decode_buffer(self, buf):  # decoder.rs:178
         if self._ctx is None:
