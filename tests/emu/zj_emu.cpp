@@ -174,10 +174,13 @@ extern "C" int zje_huff_decode(const uint8_t* blob, int16_t* y, int16_t* cb, int
     std::vector<unsigned long long> exitv(nsub);
     std::vector<HuffI4> aux(nsub), base(nsub);
     std::vector<uint8_t> changed(2 * (size_t)nsub);
-    std::vector<uint32_t> ctl(2 + HUFF_MAX_ROUNDS + 1, 0);
-    ctl[1] = 0xffffffffu;
+    std::vector<uint32_t> ctl(HUFF_CTL_WORDS, 0);
+    ctl[HUFF_CTL_SEEN] = 0xffffffffu;
+    const uint32_t nscan = (nsub + HUFF_SCAN_WG - 1) / HUFF_SCAN_WG;
+    std::vector<HuffAgg> wgagg(nscan), wgpre(nscan);
     HuffArgs a;
     a.blob = blob; a.exit = exitv.data(); a.aux = aux.data(); a.base = base.data(); a.changed = changed.data();
+    a.wgagg = wgagg.data(); a.wgpre = wgpre.data();
     a.ctl = ctl.data(); a.plane[0] = y; a.plane[1] = cb; a.plane[2] = cr; a.round = 0;
     std::vector<HuffLds> lds(1);
     HuffLds& L = lds[0];
@@ -187,29 +190,36 @@ extern "C" int zje_huff_decode(const uint8_t* blob, int16_t* y, int16_t* cb, int
     for (;; round++) {
         if (round > HUFF_MAX_ROUNDS) { ctl[0] |= HUFF_ST_NO_SYNC; break; }
         a.round = round;
-        for (uint32_t wg = 0; wg < nwg; wg++) {
+        // the device runs all threads of a round at once: nobody sees an exit state of the SAME round.  Descending
+        // order gives exactly that here (thread i reads exit[i - 1] before thread i - 1 rewrites it).
+        for (uint32_t wg = nwg; wg-- > 0;) {
             bool any = false;
             for (int tid = 0; tid < HUFF_WG; tid++) any |= huff_sync_needed(a, wg * HUFF_WG + tid, nsub, huff_subs(blob));
             if (!any) { for (int tid = 0; tid < HUFF_WG; tid++) if (wg * HUFF_WG + tid < nsub) changed[(size_t)(round & 1) * nsub + wg * HUFF_WG + tid] = 0; continue; }
             memset((void*)&L, 0x7B, sizeof L);
-            for (int tid = 0; tid < HUFF_WG; tid++) huff_stage<HUFF_WG>(blob, (int)wg, tid, L);
-            for (int tid = 0; tid < HUFF_WG; tid++) {
+            for (int tid = 0; tid < HUFF_WG; tid++) huff_stage<HUFF_WG>(blob, (int)wg, tid, huff_sync_needed(a, wg * HUFF_WG + tid, nsub, huff_subs(blob)), L);
+            for (int tid = HUFF_WG; tid-- > 0;) {
                 if (huff_sync_needed(a, wg * HUFF_WG + tid, nsub, huff_subs(blob))) work++;
                 huff_sync_thread(a, L, wg * HUFF_WG + tid);
             }
         }
-        if (round >= 1 && ctl[2 + round] == 0) break;
+        if (round >= 1 && ctl[HUFF_CTL_ROUND0 + round] == 0) break;
     }
     if (!(ctl[0] & HUFF_ST_NO_SYNC)) {
-        const int NT = 1024;
-        std::vector<HuffAgg> agg(NT);
-        const uint32_t chunk = (nsub + NT - 1) / NT;
-        for (int t = 0; t < NT; t++) agg[t] = huff_scan_chunk(a, (uint32_t)t, chunk);
-        huff_scan_combine(agg.data(), NT);
-        for (int t = 0; t < NT; t++) huff_scan_apply(a, (uint32_t)t, chunk, agg[t]);
+        for (uint32_t w = 0; w < nscan; w++) { // a prefix-sum workgroup: the scan the device does in log steps
+            HuffAgg run = huff_scan_identity();
+            for (uint32_t t = 0; t < (uint32_t)HUFF_SCAN_WG; t++) {
+                const uint32_t i = w * HUFF_SCAN_WG + t;
+                const HuffAgg el = huff_scan_element(a, i);
+                huff_scan_store(a, i, run);
+                run = huff_scan_op(run, el);
+            }
+            wgagg[w] = run;
+        }
+        huff_scan_totals(a, nscan);
         for (uint32_t wg = 0; wg < nwg; wg++) {
             memset((void*)&L, 0x7B, sizeof L);
-            for (int tid = 0; tid < HUFF_WG; tid++) huff_stage<HUFF_WG>(blob, (int)wg, tid, L);
+            for (int tid = 0; tid < HUFF_WG; tid++) huff_stage<HUFF_WG>(blob, (int)wg, tid, true, L);
             for (int tid = 0; tid < HUFF_WG; tid++) huff_write_thread(a, L, wg * HUFF_WG + tid);
         }
         uint32_t first = 0;
@@ -217,6 +227,6 @@ extern "C" int zje_huff_decode(const uint8_t* blob, int16_t* y, int16_t* cb, int
         for (uint32_t p = 0; p < pieces; p++) huff_cut_clear(a, first, p);
     }
     if (status) *status = ctl[0];
-    if (stats) { stats[0] = (uint32_t)round; stats[1] = nsub; stats[2] = work; stats[3] = ctl[1]; }
+    if (stats) { stats[0] = (uint32_t)round; stats[1] = nsub; stats[2] = work; stats[3] = ctl[HUFF_CTL_SEEN]; }
     return ZJ_OK;
 }

@@ -39,11 +39,14 @@ def main():
     ap.add_argument("--files", type=int, default=64)
     ap.add_argument("--distinct", type=int, default=4)
     ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--entropy", choices=["cpu", "gpu"], default="cpu", help="where baseline Huffman scans are decoded")
+    ap.add_argument("--restart-rows", type=int, default=1, help="restart interval in MCU rows (0: none)")
     args = ap.parse_args()
+    ENT = zj.ENTROPY_GPU if args.entropy == "gpu" else zj.ENTROPY_CPU
     S = args.size
-    blobs = [make_jpeg(S, s) for s in range(args.distinct)]
+    blobs = [make_jpeg(S, s, args.restart_rows) for s in range(args.distinct)]
     mp = S * S / 1e6
-    print(f"{args.distinct} distinct {S}x{S} 4:2:0 q90 files, {sum(map(len, blobs)) / len(blobs) / 1e6:.2f} MB each; "
+    print(f"entropy stage: {args.entropy}; {args.distinct} distinct {S}x{S} 4:2:0 q90 files (restart rows {args.restart_rows}), {sum(map(len, blobs)) / len(blobs) / 1e6:.2f} MB each; "
           f"host has {os.cpu_count()} logical CPUs, cgroup quota {EFF}")
     ctx = zj.Context()
     ref = None
@@ -53,6 +56,7 @@ def main():
         o = zj.ZuneJpegOptions()
         o.num_threads = t
         o.pinned_planes = True
+        o.entropy = ENT
         dec = zj.Decoder(o, ctx)
         out = dec.decode_buffer(blobs[0])
         if ref is None:
@@ -73,7 +77,9 @@ def main():
     for workers in (1, 4, 8, 16, 32, 64):
         if workers > (os.cpu_count() or 1):
             continue
-        with zj.Pool(threads=workers) as pool:
+        po = zj.ZuneJpegOptions()
+        po.entropy = ENT
+        with zj.Pool(threads=workers, options=po) as pool:
             for _ in range(2):  # warm every worker: pinned planes, streams, device buffers
                 pool.decode_files(files, outs=outs)
             e0, g0, n0 = pool.stats()
@@ -86,6 +92,36 @@ def main():
                   f"   per file: entropy {(e1-e0)/(n1-n0)*1e3:6.1f} ms, GPU stage {(g1-g0)/(n1-n0)*1e3:6.2f} ms")
     for p in pins:
         L.zj_free_pinned(p)
+    # files -> pixels that STAY in HBM (consumers on the GPU): T host threads, each with its own decoder, context and
+    # device buffer (ctypes releases the GIL inside the library)
+    import threading
+    for T in (1, 2, 4, 8):
+        per = max(8, args.files // T)
+        def work(k, res):
+            c = zj.Context()
+            o = zj.ZuneJpegOptions()
+            o.num_threads = 1
+            o.pinned_planes = True
+            o.entropy = ENT
+            d = zj.Decoder(o, c)
+            p = c.device_alloc(S * S * 3)
+            for i in range(2):
+                d.prepare(blobs[i % len(blobs)]); d.finish_pixels_device(p, S * S * 3)
+            res[k] = (c, d, p)
+        res = [None] * T
+        th = [threading.Thread(target=work, args=(k, res)) for k in range(T)]
+        [t.start() for t in th]; [t.join() for t in th]
+        def run(k):
+            c, d, p = res[k]
+            for i in range(per):
+                d.prepare(blobs[(i + k) % len(blobs)]); d.finish_pixels_device(p, S * S * 3)
+        th = [threading.Thread(target=run, args=(k,)) for k in range(T)]
+        t0 = time.perf_counter()
+        [t.start() for t in th]; [t.join() for t in th]
+        dt = time.perf_counter() - t0
+        print(f"pixels stay in HBM, {T} host threads: {T * per} files in {dt*1e3:8.1f} ms  {T*per/dt:8.1f} files/s  {T*per*mp/dt:9.1f} MP/s")
+        for c, d, p in res:
+            c.device_free(p); d.close(); c.close()
 
 
 if __name__ == "__main__":

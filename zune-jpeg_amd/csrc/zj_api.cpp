@@ -558,8 +558,9 @@ int zj_decode_scan(zj_ctx* c, const zj_frame_desc* d, const void* blob, size_t b
     const size_t nsub = h->nsub;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_exit = up(blob_bytes), o_aux = o_exit + up(nsub * 8), o_base = o_aux + up(nsub * 16),
-                 o_chg = o_base + up(nsub * 16), o_ctl = o_chg + up(nsub * 2), ctl_words = 2 + HUFF_MAX_ROUNDS + 1,
-                 total = o_ctl + up(ctl_words * 4);
+                 o_chg = o_base + up(nsub * 16), o_ctl = o_chg + up(nsub * 2), ctl_words = HUFF_CTL_WORDS,
+                 nscan = (nsub + HUFF_SCAN_WG - 1) / HUFF_SCAN_WG, o_agg = o_ctl + up(ctl_words * 4),
+                 o_pre = o_agg + up(nscan * sizeof(HuffAgg)), total = o_pre + up(nscan * sizeof(HuffAgg));
     if ((rc = ensure_buf(c, &c->hbuf, &c->hbuf_cap, total))) return rc;
     const size_t yb = up(ylen * 2), cbytes = up(clen * 2);
     if ((rc = ensure_buf(c, &c->hplanes, &c->hplanes_cap, yb + 2 * cbytes))) return rc;
@@ -573,6 +574,8 @@ int zj_decode_scan(zj_ctx* c, const zj_frame_desc* d, const void* blob, size_t b
     a.base = (HuffI4*)(base + o_base);
     a.changed = base + o_chg;
     a.ctl = (uint32_t*)(base + o_ctl);
+    a.wgagg = (HuffAgg*)(base + o_agg);
+    a.wgpre = (HuffAgg*)(base + o_pre);
     a.plane[0] = (int16_t*)c->hplanes;
     a.plane[1] = (int16_t*)((uint8_t*)c->hplanes + yb);
     a.plane[2] = (int16_t*)((uint8_t*)c->hplanes + yb + cbytes);
@@ -582,21 +585,23 @@ int zj_decode_scan(zj_ctx* c, const zj_frame_desc* d, const void* blob, size_t b
     if (timing) { for (auto& e : ev) ZJ_HIP(c, hipEventCreate(&e)); ZJ_HIP(c, hipEventRecord(ev[0], s)); }
     ZJ_HIP(c, hipMemcpyAsync(base, blob, blob_bytes, hipMemcpyHostToDevice, s));
     ZJ_HIP(c, hipMemsetAsync(a.ctl, 0, ctl_words * 4, s));
-    ZJ_HIP(c, hipMemsetAsync(a.ctl + 1, 0xff, 4, s));
+    ZJ_HIP(c, hipMemsetAsync(a.ctl + HUFF_CTL_SEEN, 0xff, 4, s));
     ZJ_HIP(c, hipMemsetAsync(c->hplanes, 0, yb + 2 * cbytes, s)); // the write pass stores non-zero coefficients only
-    // synchronisation rounds: 0, then groups of four with one look at the change counters per group
+    // synchronisation rounds: 0, then groups (8, 8, 16, 32, ...) with one look at the change counters per group: a
+    // round nobody needs costs microseconds, a look costs a stream synchronisation
     ZJ_HIP(c, launch_huff_sync(a, (uint32_t)nsub, s));
-    int round = 0;
+    int round = 0, group_size = 8;
     bool synced = false;
     while (!synced && round < HUFF_MAX_ROUNDS) {
-        const int group = round + 4 <= HUFF_MAX_ROUNDS ? 4 : HUFF_MAX_ROUNDS - round;
+        const int group = round + group_size <= HUFF_MAX_ROUNDS ? group_size : HUFF_MAX_ROUNDS - round;
+        if (round >= 8) group_size *= 2;
         for (int k = 0; k < group; k++) { a.round = ++round; ZJ_HIP(c, launch_huff_sync(a, (uint32_t)nsub, s)); }
         ZJ_HIP(c, hipMemcpyAsync(c->h_ctl, a.ctl, ctl_words * 4, hipMemcpyDeviceToHost, s));
         ZJ_HIP(c, hipStreamSynchronize(s));
         for (int r = round - group + 1; r <= round; r++)
-            if (c->h_ctl[2 + r] == 0) { synced = true; break; }
+            if (c->h_ctl[HUFF_CTL_ROUND0 + r] == 0) { synced = true; c->huff_rounds = r; break; }
     }
-    c->huff_rounds = round;
+    if (!synced) c->huff_rounds = round;
     if (!synced) { if (status_bits) *status_bits = HUFF_ST_NO_SYNC; return ZJ_RETRY_CPU; }
     if (timing) ZJ_HIP(c, hipEventRecord(ev[1], s));
     ZJ_HIP(c, launch_huff_finish(a, (uint32_t)nsub, s));
@@ -612,8 +617,8 @@ int zj_decode_scan(zj_ctx* c, const zj_frame_desc* d, const void* blob, size_t b
         for (int k = 0; k < 3; k++) ZJ_HIP(c, hipEventElapsedTime(&c->huff_ms[k], ev[k], ev[k + 1]));
         for (auto& e : ev) (void)hipEventDestroy(e);
     }
-    if (status_bits) *status_bits = c->h_ctl[0];
-    return c->h_ctl[0] ? ZJ_RETRY_CPU : ZJ_OK;
+    if (status_bits) *status_bits = c->h_ctl[HUFF_CTL_STATUS];
+    return c->h_ctl[HUFF_CTL_STATUS] ? ZJ_RETRY_CPU : ZJ_OK;
 }
 
 int zj_scan_stats(const zj_ctx* c, int* rounds, float ms[3])

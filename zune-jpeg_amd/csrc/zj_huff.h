@@ -28,13 +28,14 @@ namespace zj {
 
 constexpr int HUFF_SUB_MAX = 128;   // bytes a sub-sequence spans at most (its start is 16-byte aligned)
 constexpr int HUFF_WG = 256;        // sub-sequences (threads) per workgroup: at most 32 KB of stream staged in LDS
-constexpr int HUFF_L1_BITS = 9;     // first-level window of a decoding table
-constexpr int HUFF_L2_BITS = 7;     // second level: the remaining bits of a 16-bit code
+constexpr int HUFF_L1_DC = 9;       // first-level window of a DC table (12 categories: longer codes are rare)
+constexpr int HUFF_L1_AC = 11;      // ... of an AC table: a lane that meets a longer code sends its whole wave through
+                                    // the second lookup, so "longer" has to be rare per WAVE (64 symbols), not per symbol
 constexpr int HUFF_TAB_BUDGET = 9216; // u16 entries all tables of a scan may take together (18 KB of LDS): a table is
-                                      // 512 + 128 x (distinct 9-bit prefixes of its codes longer than 9 bits)
+                                      // 2^L1 + 2^(16 - L1) x (distinct L1-bit prefixes of its codes longer than L1 bits)
 constexpr int HUFF_MAX_TABS = 6;    // distinct (class, id) tables of a 3-component scan
 constexpr int HUFF_MAX_BPM = 10;    // blocks per MCU (T.81 B.2.3)
-constexpr int HUFF_MAX_ROUNDS = 96; // synchronisation rounds before the scan is handed back to the CPU walker
+constexpr int HUFF_MAX_ROUNDS = 384; // synchronisation rounds before the scan is handed back to the CPU walker
 constexpr uint32_t HUFF_MAGIC = 0x5a4a4853u;
 constexpr uint32_t HUFF_FIRST = 0x80000000u, HUFF_LAST = 0x40000000u, HUFF_SEG_MASK = 0x3fffffffu;
 
@@ -43,9 +44,14 @@ constexpr uint32_t HUFF_FIRST = 0x80000000u, HUFF_LAST = 0x40000000u, HUFF_SEG_M
 constexpr uint32_t HUFF_ST_BAD_CODE = 1, HUFF_ST_RUN_OVER = 2, HUFF_ST_EXHAUSTED = 4, HUFF_ST_CUT_EARLY = 8,
                    HUFF_ST_PHASE = 16, HUFF_ST_NO_SYNC = 32;
 
-// table entry (u16): 0 = no such code; bit 15 clear: (code length << 8) | symbol; bit 15 set: low byte = second-level
-// table number, indexed by the 7 bits that follow the first 9
-struct HuffBlk { uint8_t comp, hx, vy, pad; uint16_t dc_off, ac_off; }; // one block of the MCU, in scan order; its tables (entry offsets)
+// table entry (u16): 0 = no such code.  Bit 15 set: low byte = second-level table number, indexed by the 16 - L1 bits
+// that follow the first L1.  Bit 15 clear: everything the symbol does to the parse --
+//   bits 0-4   bits consumed: code length + magnitude bits (1..31)
+//   bits 5-10  advance of the zig-zag index: DC symbols 1; AC run/size run + 1; ZRL 16; EOB (any run with size 0) 63
+//   bits 11-14 magnitude bits (DC: the symbol itself; AC: its low nibble)
+// (a DC symbol whose code + magnitude exceed 31 bits -- size 16, or 15 after a 16-bit code -- has no entry: the CPU walker
+// accepts sizes up to 16 and gets such a file)
+struct HuffBlk { uint8_t comp, hx, vy, pad; };                    // one block of the MCU, in scan order
 struct HuffComp { uint32_t h, v, bw, bh; };                       // sampling factors, plane size in blocks
 struct HuffSub { uint32_t start, seg; };                          // byte offset in the stream; segment | HUFF_FIRST | HUFF_LAST
 struct HuffSeg { uint32_t start, end; };                          // byte range of a restart segment in the stream (end exact)
@@ -59,11 +65,20 @@ struct HuffScan { // header of the blob; every off_* is a byte offset from the h
     uint32_t rowlen;           // MCUs per row loop of the reference (mcu.rs:145-152)
     uint32_t tab_entries;      // u16 entries of all decoding tables together (even)
     uint32_t off_tab, off_sub, off_seg, off_stream, stream_bytes; // stream_bytes: multiple of 16, >= 32 zero bytes at the end
+    uint32_t comp_of_blk;      // 2 bits per block of the MCU: its component
+    uint16_t dc_off[4], ac_off[4]; // per component: entry offset of its decoding tables
     HuffBlk blk[HUFF_MAX_BPM];
     HuffComp comp[3];
 };
 
 struct alignas(16) HuffI4 { int32_t x, y, z, w; };
+// prefix sums (blocks completed, DC difference sums per component): a running value; `reset`: it is absolute because a
+// restart segment began inside the range it covers
+struct HuffAgg { int32_t v[4]; int32_t reset; };
+constexpr int HUFF_SCAN_WG = 1024;  // sub-sequences per workgroup of the prefix-sum kernel
+// control words
+constexpr int HUFF_CTL_STATUS = 0, HUFF_CTL_SEEN = 1, HUFF_CTL_TICKET = 2, HUFF_CTL_ROUND0 = 3,
+              HUFF_CTL_WORDS = HUFF_CTL_ROUND0 + HUFF_MAX_ROUNDS + 1;
 
 // device-side working set of one scan
 struct HuffArgs {
@@ -71,8 +86,12 @@ struct HuffArgs {
     unsigned long long* exit;  // [nsub] packed exit state of every sub-sequence
     HuffI4* aux;               // [nsub] blocks completed, DC difference sums per component
     HuffI4* base;              // [nsub] first block index, DC predictors (after the scan kernel)
-    uint8_t* changed;          // [2][nsub] exit state changed in the round of that parity
-    uint32_t* ctl;             // [0] status bits, [1] first MCU at which the reference has seen EOI, [2 + r] changes of round r
+    uint8_t* changed;          // [2][nsub] exit state changed in the round of that parity; after the rounds [0][i]: base[i]
+                               // is relative to its prefix-sum workgroup (add wgpre)
+    HuffAgg* wgagg;            // [ceil(nsub / HUFF_SCAN_WG)] totals of the prefix-sum workgroups
+    HuffAgg* wgpre;            // the same, exclusive prefix
+    uint32_t* ctl;             // HUFF_CTL_*: status bits, first MCU at which the reference has seen EOI, ticket of the
+                               // prefix-sum workgroups, changes of round r at [HUFF_CTL_ROUND0 + r]
     int16_t* plane[3];
     int round;
 };

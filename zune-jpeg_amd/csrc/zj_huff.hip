@@ -1,7 +1,7 @@
 // zj_huff.hip -- kernels of the GPU entropy stage (zj_huff.h: algorithm; zj_huff_device.h: the per-thread code).
-// gfx950: one sub-sequence per lane, 256 per workgroup; the workgroup's stream bytes (<= 32 KB) and the decoding tables
-// (<= 18 KB) are staged in LDS with coalesced loads, after which a lane touches global memory only to publish its exit
-// state or to scatter coefficients.
+// gfx950: one sub-sequence per lane, 256 per workgroup; every lane that has work stages its own stream bytes in LDS
+// (<= 32 KB per workgroup, bank-skewed), the workgroup stages the decoding tables (<= 18 KB); after that a lane touches
+// global memory only to publish its exit state or to scatter coefficients.
 #include <hip/hip_runtime.h>
 
 #include "zj_huff_device.h"
@@ -20,7 +20,7 @@ __global__ __launch_bounds__(HUFF_WG) void zj_huff_sync_kernel(HuffArgs a)
         if (i < nsub) a.changed[(size_t)(a.round & 1) * nsub + i] = 0;
         return;
     }
-    huff_stage<HUFF_WG>(a.blob, (int)blockIdx.x, (int)threadIdx.x, L);
+    huff_stage<HUFF_WG>(a.blob, (int)blockIdx.x, (int)threadIdx.x, need, L);
     __syncthreads();
     huff_sync_thread(a, L, i);
 }
@@ -28,23 +28,38 @@ __global__ __launch_bounds__(HUFF_WG) void zj_huff_sync_kernel(HuffArgs a)
 __global__ __launch_bounds__(HUFF_WG) void zj_huff_write_kernel(HuffArgs a)
 {
     __shared__ HuffLds L;
-    huff_stage<HUFF_WG>(a.blob, (int)blockIdx.x, (int)threadIdx.x, L);
+    huff_stage<HUFF_WG>(a.blob, (int)blockIdx.x, (int)threadIdx.x, true, L);
     __syncthreads();
     huff_write_thread(a, L, blockIdx.x * HUFF_WG + threadIdx.x);
 }
 
-constexpr int HUFF_SCAN_NT = 1024;
-__global__ __launch_bounds__(HUFF_SCAN_NT) void zj_huff_scan_kernel(HuffArgs a)
+__global__ __launch_bounds__(HUFF_SCAN_WG) void zj_huff_scan_kernel(HuffArgs a)
 {
-    __shared__ HuffAgg agg[HUFF_SCAN_NT];
-    const uint32_t nsub = huff_hdr(a.blob)->nsub;
-    const uint32_t chunk = (nsub + HUFF_SCAN_NT - 1) / HUFF_SCAN_NT;
-    const uint32_t t = threadIdx.x;
-    agg[t] = huff_scan_chunk(a, t, chunk);
+    // Hillis-Steele over the workgroup's 1024 elements, double-buffered in LDS
+    __shared__ HuffAgg buf[2][HUFF_SCAN_WG];
+    __shared__ uint32_t ticket;
+    const uint32_t t = threadIdx.x, i = blockIdx.x * HUFF_SCAN_WG + t;
+    buf[0][t] = huff_scan_element(a, i);
     __syncthreads();
-    if (t == 0) huff_scan_combine(agg, HUFF_SCAN_NT);
+    int cur = 0;
+    for (uint32_t d = 1; d < HUFF_SCAN_WG; d <<= 1) {
+        HuffAgg v = buf[cur][t];
+        if (t >= d) v = huff_scan_op(buf[cur][t - d], v);
+        buf[cur ^ 1][t] = v;
+        cur ^= 1;
+        __syncthreads();
+    }
+    huff_scan_store(a, i, t ? buf[cur][t - 1] : huff_scan_identity());
+    if (t == HUFF_SCAN_WG - 1) {
+        a.wgagg[blockIdx.x] = buf[cur][t];
+        __threadfence();
+        ticket = atomicAdd(&a.ctl[HUFF_CTL_TICKET], 1u);
+    }
     __syncthreads();
-    huff_scan_apply(a, t, chunk, agg[t]);
+    if (ticket == gridDim.x - 1 && t == 0) { // the last workgroup to finish: every total is visible
+        __threadfence();
+        huff_scan_totals(a, gridDim.x);
+    }
 }
 
 __global__ __launch_bounds__(256) void zj_huff_cut_kernel(HuffArgs a)
@@ -61,7 +76,7 @@ hipError_t launch_huff_sync(const HuffArgs& a, uint32_t nsub, hipStream_t s)
 }
 hipError_t launch_huff_finish(const HuffArgs& a, uint32_t nsub, hipStream_t s)
 {
-    hipLaunchKernelGGL(zj_huff_scan_kernel, dim3(1), dim3(HUFF_SCAN_NT), 0, s, a);
+    hipLaunchKernelGGL(zj_huff_scan_kernel, dim3((nsub + HUFF_SCAN_WG - 1) / HUFF_SCAN_WG), dim3(HUFF_SCAN_WG), 0, s, a);
     hipLaunchKernelGGL(zj_huff_write_kernel, dim3((nsub + HUFF_WG - 1) / HUFF_WG), dim3(HUFF_WG), 0, s, a);
     hipLaunchKernelGGL(zj_huff_cut_kernel, dim3(1), dim3(256), 0, s, a);
     return hipGetLastError();

@@ -29,13 +29,14 @@ constexpr int HUFF_W_SLOTS = HUFF_W_WORDS + HUFF_W_WORDS / 32 + 1;
 struct HuffLds {
     uint32_t W[HUFF_W_SLOTS];                 // big-endian stream words; word k lives in slot k + k/32, so that lanes
                                               // 32 words (one sub-sequence) apart hit different banks
-    uint16_t T[HUFF_TAB_BUDGET];              // decoding tables
+    alignas(16) uint16_t T[HUFF_TAB_BUDGET];  // decoding tables
     HuffScan hdr;
     uint8_t unz[64];                          // zig-zag index -> natural position
     uint32_t w0, nwords;                      // first stream word staged, count
     int any;                                  // some thread of the workgroup has work this round
 };
 ZJ_DEV uint32_t huff_slot(uint32_t k) { return k + (k >> 5); }
+struct alignas(16) HuffU4 { uint32_t x, y, z, w; };
 
 #if defined(ZJ_EMU)
 ZJ_DEV void huff_or(uint32_t* p, uint32_t v) { *p |= v; }
@@ -63,34 +64,49 @@ ZJ_DEV uint32_t huff_unzigzag(int k)
     return t[k];
 }
 
-// Cooperative staging by the NT threads of workgroup `wg`: header, tables, the zig-zag table and the stream bytes of
-// the workgroup's sub-sequences (+ 32 bytes: a symbol that begins before a limit may end up to 31 bits after it).
-// A barrier must follow.
+// Staging by the NT threads of workgroup `wg`.  Cooperative: header, decoding tables, zig-zag table.  Per thread: the
+// stream words of ITS sub-sequence (+ 16 bytes: a symbol that begins before the limit may end up to 31 bits after it),
+// and only if `mine` says the thread will decode -- in the later rounds few do.  16-byte loads, all issued before the
+// first LDS write.  A barrier must follow.
 template <int NT>
-ZJ_DEV void huff_stage(const uint8_t* blob, int wg, int tid, HuffLds& L)
+ZJ_DEV void huff_stage(const uint8_t* blob, int wg, int tid, bool mine, HuffLds& L)
 {
     const HuffScan* g = huff_hdr(blob);
     const HuffSub* subs = huff_subs(blob);
     const uint32_t nsub = g->nsub;
     const uint32_t f = (uint32_t)wg * HUFF_WG;
-    const uint32_t l1 = f + HUFF_WG < nsub ? f + HUFF_WG : nsub; // one past the last sub-sequence of the workgroup
     const uint32_t b0 = subs[f].start;
-    const uint32_t b1 = l1 < nsub ? subs[l1].start : g->stream_bytes - 32;
-    uint32_t nwords = (b1 - b0) / 4 + 8;
-    const uint32_t left = (g->stream_bytes - b0) / 4;
-    if (nwords > left) nwords = left;
-    if (nwords > (uint32_t)HUFF_W_WORDS) nwords = HUFF_W_WORDS; // (cannot happen: the host keeps spans <= 128 bytes)
-    const uint32_t* src = (const uint32_t*)(blob + g->off_stream) + b0 / 4;
-    for (uint32_t k = (uint32_t)tid; k < nwords; k += NT) L.W[huff_slot(k)] = huff_bswap(src[k]);
-    const uint32_t* tsrc = (const uint32_t*)(blob + g->off_tab);
-    uint32_t* tdst = (uint32_t*)L.T;
-    const uint32_t tw = g->tab_entries / 2;
-    for (uint32_t k = (uint32_t)tid; k < tw; k += NT) tdst[k] = tsrc[k];
+    const uint32_t nwords_all = (g->stream_bytes - b0) / 4; // what the stream holds from the workgroup's first byte on
+    const uint32_t nwords = nwords_all < (uint32_t)HUFF_W_WORDS ? nwords_all : (uint32_t)HUFF_W_WORDS;
+    const HuffU4* src = (const HuffU4*)(blob + g->off_stream + b0);
+    if (mine && f + (uint32_t)tid < nsub) {
+        const uint32_t q0 = (subs[f + (uint32_t)tid].start - b0) / 16; // first 16-byte piece of the sub-sequence
+        constexpr int PIECES = HUFF_SUB_MAX / 16 + 1;
+        HuffU4 v[PIECES];
+#pragma unroll
+        for (int q = 0; q < PIECES; q++) {
+            v[q].x = v[q].y = v[q].z = v[q].w = 0;
+            if ((q0 + q) * 4 + 3 < nwords) v[q] = src[q0 + q];
+        }
+#pragma unroll
+        for (int q = 0; q < PIECES; q++) {
+            const uint32_t k = (q0 + q) * 4;
+            if (k + 3 < nwords) {
+                const uint32_t sl = huff_slot(k); // the four words of a piece share their 32-word group: contiguous slots
+                L.W[sl] = huff_bswap(v[q].x); L.W[sl + 1] = huff_bswap(v[q].y);
+                L.W[sl + 2] = huff_bswap(v[q].z); L.W[sl + 3] = huff_bswap(v[q].w);
+            }
+        }
+    }
+    const HuffU4* tsrc = (const HuffU4*)(blob + g->off_tab);
+    HuffU4* tdst = (HuffU4*)L.T;
+    const uint32_t tq = (g->tab_entries + 7) / 8;
+    for (uint32_t k = (uint32_t)tid; k < tq; k += NT) tdst[k] = tsrc[k];
     const uint32_t* hsrc = (const uint32_t*)blob;
     uint32_t* hdst = (uint32_t*)&L.hdr;
     for (uint32_t k = (uint32_t)tid; k < sizeof(HuffScan) / 4; k += NT) hdst[k] = hsrc[k];
     if (tid < 64) L.unz[tid] = (uint8_t)huff_unzigzag(tid);
-    if (tid == 0) { L.w0 = b0 / 4; L.nwords = nwords; }
+    if (tid == 0) { L.w0 = b0 / 4; L.nwords = nwords & ~3u; }
 }
 
 // ---- the parse -------------------------------------------------------------------------------------------------------
@@ -116,82 +132,96 @@ ZJ_DEV int16_t* huff_block_ptr(const HuffScan& h, const HuffWrite& w, const Huff
     return base + (by * c.bw + bx) * 64;
 }
 
+// the 32 bits that follow `off` consumed bits of hi (1 <= off <= 32; off == 32: lo itself): one v_alignbit_b32
+ZJ_DEV uint32_t huff_window(uint32_t hi, uint32_t lo, uint32_t off)
+{
+#if defined(ZJ_EMU)
+    return (uint32_t)(((((unsigned long long)hi << 32) | lo) >> (32u - off)) & 0xffffffffu);
+#else
+    return __builtin_amdgcn_alignbit(hi, lo, 32u - off);
+#endif
+}
+
 // Decodes symbols from state `s` while they BEGIN before bit `limit`.  Sync rounds (WRITE false) only track the state,
 // the blocks completed and the DC differences; the write pass stores coefficients, stops at the end of its segment's
 // blocks and raises status bits for anything a well-formed scan cannot contain.
 // Garbage in (a wrong guess) must be harmless: every read is bounded, every symbol advances by at least one bit.
+//
+// One table entry (zj_huff.h) carries all a symbol does to the state -- bits consumed (code + magnitude) and the
+// advance of the zig-zag index (DC: 1, run + 1, ZRL: 16, EOB: 63) -- so a sync round needs the magnitude bits of DC
+// symbols only.  The bit window is 32 bits rebuilt per symbol from two cached stream words (a code is at most 16
+// bits, its magnitude at most 15); a third word is always in flight from LDS.
 template <bool WRITE>
 ZJ_DEV HuffState huff_run(const HuffLds& L, HuffState s, uint32_t limit, bool last_sub, HuffI4& aux, HuffWrite* w)
 {
     const HuffScan& h = L.hdr;
     const uint32_t nwords = L.nwords;
     const uint32_t rel = s.pos - L.w0 * 32u;
-    uint32_t next = rel >> 5;
-    const uint32_t off = rel & 31;
-    const uint32_t wa = next < nwords ? L.W[huff_slot(next)] : 0u;
-    const uint32_t wb = next + 1 < nwords ? L.W[huff_slot(next + 1)] : 0u;
-    unsigned long long buf = (((unsigned long long)wa << 32) | wb) << off; // next unread bits, left-aligned
-    int avail = 64 - (int)off;
-    next += 2;
+    uint32_t k = rel >> 5, off = rel & 31;
+    if (off == 0) { off = 32; k -= 1; } // (k may wrap for the very first bit: the word is never looked at)
+    uint32_t hi = k < nwords ? L.W[huff_slot(k)] : 0u;
+    uint32_t lo = k + 1 < nwords ? L.W[huff_slot(k + 1)] : 0u;
+    uint32_t nx = k + 2 < nwords ? L.W[huff_slot(k + 2)] : 0u;
+    k += 3;
     uint32_t pos = s.pos, j = s.j, z = s.z;
     int32_t n = 0, d0 = 0, d1 = 0, d2 = 0; // blocks completed, DC differences per component
     int32_t p0 = 0, p1 = 0, p2 = 0;        // DC predictors (write pass)
     if (WRITE) { p0 = w->pred[0]; p1 = w->pred[1]; p2 = w->pred[2]; }
     uint32_t status = 0;
     if (j >= h.bpm) j = 0; // (only a corrupted exit word could say so)
-    HuffBlk bi = h.blk[j];
-    uint32_t dcb = bi.dc_off, acb = bi.ac_off;
+    // per component: table offsets; per block of the MCU: its component (2 bits each) -- registers, not LDS, because
+    // every iteration of a wave has some lane at a block boundary
+    const uint32_t cmask = h.comp_of_blk;
+    const uint32_t dc0 = h.dc_off[0], dc1 = h.dc_off[1], dc2 = h.dc_off[2], ac0 = h.ac_off[0], ac1 = h.ac_off[1], ac2 = h.ac_off[2];
+    uint32_t comp = (cmask >> (2 * j)) & 3u;
+    uint32_t dcb = comp == 0 ? dc0 : comp == 1 ? dc1 : dc2, acb = comp == 0 ? ac0 : comp == 1 ? ac1 : ac2;
     int16_t* dst = nullptr;
-    if (WRITE) dst = huff_block_ptr(h, *w, bi);
+    if (WRITE) dst = huff_block_ptr(h, *w, h.blk[j]);
     for (;;) {
         if (WRITE && w->blk >= w->blk_end) break;
         if (pos >= limit) {
             if (WRITE && last_sub) status |= HUFF_ST_EXHAUSTED; // blocks are missing and the segment has no more bits
             break;
         }
-        if (avail < 32) {
-            const uint32_t x = next < nwords ? L.W[huff_slot(next)] : 0u;
-            buf |= (unsigned long long)x << (32 - avail);
-            avail += 32;
-            next++;
-        }
-        const uint32_t peek = (uint32_t)(buf >> 48);
+        const uint32_t win = huff_window(hi, lo, off);
         const bool is_dc = z == 0;
         const uint32_t tb = is_dc ? dcb : acb;
-        uint32_t e = L.T[tb + (peek >> HUFF_L2_BITS)];
-        if (e & 0x8000u) e = L.T[tb + (1u << HUFF_L1_BITS) + ((e & 0xffu) << HUFF_L2_BITS) + (peek & ((1u << HUFF_L2_BITS) - 1))];
-        uint32_t len = e >> 8, sym = e & 0xffu;
-        if (len == 0) { len = 16; sym = 0; if (WRITE) status |= HUFF_ST_BAD_CODE; }
-        uint32_t sz = is_dc ? sym : (sym & 15u);
-        if (sz > 16) { sz = 16; if (WRITE) status |= HUFF_ST_BAD_CODE; } // zj_jpeg.cpp: "Bad Huffman code in DC"
-        const uint32_t run = is_dc ? 0u : sym >> 4;
-        const uint32_t bits = sz ? (uint32_t)((buf << len) >> (64 - sz)) : 0u;
-        const int32_t val = sz ? (int32_t)bits - ((bits >> (sz - 1)) ? 0 : (int32_t)((1u << sz) - 1u)) : 0; // EXTEND
-        const uint32_t total = len + sz;
+        const uint32_t l1 = is_dc ? (uint32_t)HUFF_L1_DC : (uint32_t)HUFF_L1_AC;
+        uint32_t e = L.T[tb + (win >> (32u - l1))];
+        if (e & 0x8000u) e = L.T[tb + (1u << l1) + ((e & 0xffu) << (16u - l1)) + ((win >> 16) & ((1u << (16u - l1)) - 1u))];
+        uint32_t total = e & 31u, zadv = (e >> 5) & 63u;
+        if (total == 0) { total = 16; zadv = 1; e = 0; if (WRITE) status |= HUFF_ST_BAD_CODE; } // no such code: any fixed step
         const uint32_t sym_start = pos;
-        buf <<= total;
-        avail -= (int)total;
-        pos += total;
-        uint32_t znew;
-        if (is_dc) {
-            if (bi.comp == 0) d0 += val; else if (bi.comp == 1) d1 += val; else d2 += val;
-            if (WRITE) {
-                int32_t p;
-                if (bi.comp == 0) p = p0 = (int32_t)((uint32_t)p0 + (uint32_t)val);
-                else if (bi.comp == 1) p = p1 = (int32_t)((uint32_t)p1 + (uint32_t)val);
-                else p = p2 = (int32_t)((uint32_t)p2 + (uint32_t)val);
-                dst[0] = (int16_t)p; // bitstream.rs:330
+        if (is_dc || WRITE) {
+            const uint32_t sz = (e >> 11) & 15u, len = total - sz;
+            const uint32_t bits = sz ? (win << len) >> (32u - sz) : 0u;
+            const int32_t val = sz ? (int32_t)bits - ((bits >> (sz - 1)) ? 0 : (int32_t)((1u << sz) - 1u)) : 0; // EXTEND
+            if (is_dc) {
+                d0 += comp == 0 ? val : 0;
+                d1 += comp == 1 ? val : 0;
+                d2 += comp == 2 ? val : 0;
+                if (WRITE) {
+                    p0 = (int32_t)((uint32_t)p0 + (uint32_t)(comp == 0 ? val : 0));
+                    p1 = (int32_t)((uint32_t)p1 + (uint32_t)(comp == 1 ? val : 0));
+                    p2 = (int32_t)((uint32_t)p2 + (uint32_t)(comp == 2 ? val : 0));
+                    dst[0] = (int16_t)(comp == 0 ? p0 : comp == 1 ? p1 : p2); // bitstream.rs:330
+                }
+            } else if (WRITE && sz) {
+                const uint32_t zz = z + zadv - 1;
+                if (zz <= 63) dst[L.unz[zz]] = (int16_t)val;
+                else status |= HUFF_ST_RUN_OVER;
             }
-            znew = 1;
-        } else if (sz) {
-            const uint32_t zz = z + run;
-            if (zz <= 63) { if (WRITE) dst[L.unz[zz]] = (int16_t)val; }
-            else if (WRITE) status |= HUFF_ST_RUN_OVER;
-            znew = zz + 1;
-        } else {
-            znew = run == 15 ? z + 16 : 64; // ZRL / EOB
         }
-        z = znew;
+        z += zadv;
+        pos += total;
+        off += total;
+        if (off > 32) {
+            off -= 32;
+            hi = lo;
+            lo = nx;
+            nx = k < nwords ? L.W[huff_slot(k)] : 0u;
+            k++;
+        }
         if (z >= 64) { // the block is complete
             z = 0;
             n++;
@@ -205,20 +235,20 @@ ZJ_DEV HuffState huff_run(const HuffLds& L, HuffState s, uint32_t limit, bool la
                         // MCU's last symbol (zj_jpeg.cpp eoi_cut_after_mcu); C grows with the MCU index, so the first MCU
                         // that satisfies it is the minimum
                         const uint32_t c_last = sym_start - w->seg_start_bits;
-                        if (4u * (c_last / 32u + 2u) > w->eoi_d) huff_min(&w->ctl[1], w->mcu);
+                        if (4u * (c_last / 32u + 2u) > w->eoi_d) huff_min(&w->ctl[HUFF_CTL_SEEN], w->mcu);
                     }
                     w->mcu++;
                     if (++w->mx == h.mcu_x) { w->mx = 0; w->my++; }
                 }
             }
-            bi = h.blk[j];
-            dcb = bi.dc_off;
-            acb = bi.ac_off;
-            if (WRITE && w->blk < w->blk_end) dst = huff_block_ptr(h, *w, bi);
+            comp = (cmask >> (2 * j)) & 3u;
+            dcb = comp == 0 ? dc0 : comp == 1 ? dc1 : dc2;
+            acb = comp == 0 ? ac0 : comp == 1 ? ac1 : ac2;
+            if (WRITE && w->blk < w->blk_end) dst = huff_block_ptr(h, *w, h.blk[j]);
         }
     }
     aux.x = n; aux.y = d0; aux.z = d1; aux.w = d2;
-    if (WRITE && status) huff_or(&w->ctl[0], status);
+    if (WRITE && status) huff_or(&w->ctl[HUFF_CTL_STATUS], status);
     HuffState o;
     o.pos = pos; o.j = j; o.z = z;
     return o;
@@ -259,7 +289,7 @@ ZJ_DEV void huff_sync_thread(const HuffArgs& a, const HuffLds& L, uint32_t i)
     a.exit[i] = packed;
     a.aux[i] = aux;
     ch[i] = differs ? 1 : 0;
-    if (differs && a.round) huff_add(&a.ctl[2 + a.round], 1u);
+    if (differs && a.round) huff_add(&a.ctl[HUFF_CTL_ROUND0 + a.round], 1u);
 }
 
 // one thread of the write pass (after staging)
@@ -274,7 +304,12 @@ ZJ_DEV void huff_write_thread(const HuffArgs& a, const HuffLds& L, uint32_t i)
     HuffState s;
     if (sub.seg & HUFF_FIRST) { s.pos = sub.start * 8u; s.j = 0; s.z = 0; }
     else s = huff_unpack(a.exit[i - 1]);
-    const HuffI4 b = a.base[i];
+    HuffI4 b = a.base[i];
+    if (a.changed[i]) { // relative to its prefix-sum workgroup
+        const HuffAgg p = a.wgpre[i / HUFF_SCAN_WG];
+        b.x = (int32_t)((uint32_t)b.x + (uint32_t)p.v[0]); b.y = (int32_t)((uint32_t)b.y + (uint32_t)p.v[1]);
+        b.z = (int32_t)((uint32_t)b.z + (uint32_t)p.v[2]); b.w = (int32_t)((uint32_t)b.w + (uint32_t)p.v[3]);
+    }
     HuffWrite w;
     w.plane[0] = a.plane[0]; w.plane[1] = a.plane[1]; w.plane[2] = a.plane[2];
     const uint32_t total_blocks = h.total_mcus * h.bpm;
@@ -284,7 +319,7 @@ ZJ_DEV void huff_write_thread(const HuffArgs& a, const HuffLds& L, uint32_t i)
     if (w.blk >= w.blk_end) return;
     w.pred[0] = b.y; w.pred[1] = b.z; w.pred[2] = b.w;
     w.mcu = w.blk / h.bpm;
-    if (w.blk - w.mcu * h.bpm != s.j) { huff_or(&a.ctl[0], HUFF_ST_PHASE); return; }
+    if (w.blk - w.mcu * h.bpm != s.j) { huff_or(&a.ctl[HUFF_CTL_STATUS], HUFF_ST_PHASE); return; }
     w.my = w.mcu / h.mcu_x;
     w.mx = w.mcu - w.my * h.mcu_x;
     w.seg_start_bits = seg.start * 8u;
@@ -296,62 +331,55 @@ ZJ_DEV void huff_write_thread(const HuffArgs& a, const HuffLds& L, uint32_t i)
 }
 
 // ---- prefix sums: first block and DC predictors of every sub-sequence ----------------------------------------------
-// A segmented exclusive scan of aux[] in three phases over NT threads with contiguous chunks; a sub-sequence that
-// begins a restart segment restarts the sums at (first block of the segment, 0, 0, 0).
-struct HuffAgg { int32_t v[4]; int reset; }; // running value at the end of a chunk; `reset`: absolute (a segment began inside)
-ZJ_DEV void huff_scan_step(const HuffScan* g, const HuffSub sub, HuffAgg& r)
+// A segmented exclusive scan of aux[]: a sub-sequence that begins a restart segment restarts the sums at (first block
+// of the segment, 0, 0, 0).  Two levels: workgroups of HUFF_SCAN_WG sub-sequences scan themselves (one element per
+// thread) and publish their totals; the workgroup that finishes last scans the totals; the write pass adds the
+// workgroup's prefix to the values that are still relative (changed[i]).
+ZJ_DEV HuffAgg huff_scan_identity() { HuffAgg r; r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0; r.reset = 0; return r; }
+// left then right
+ZJ_DEV HuffAgg huff_scan_op(const HuffAgg l, const HuffAgg r)
 {
-    if (sub.seg & HUFF_FIRST) {
-        const unsigned long long b = (unsigned long long)(sub.seg & HUFF_SEG_MASK) * g->ri_mcus * g->bpm;
-        const unsigned long long cap = (unsigned long long)g->total_mcus * g->bpm;
-        r.v[0] = (int32_t)(b < cap ? b : cap);
-        r.v[1] = r.v[2] = r.v[3] = 0;
-        r.reset = 1;
-    }
+    if (r.reset) return r;
+    HuffAgg o;
+    for (int q = 0; q < 4; q++) o.v[q] = (int32_t)((uint32_t)l.v[q] + (uint32_t)r.v[q]);
+    o.reset = l.reset;
+    return o;
 }
-ZJ_DEV void huff_scan_add(HuffAgg& r, const HuffI4 a)
+ZJ_DEV int32_t huff_seg_first_block(const HuffScan* g, const HuffSub sub)
 {
-    r.v[0] = (int32_t)((uint32_t)r.v[0] + (uint32_t)a.x);
-    r.v[1] = (int32_t)((uint32_t)r.v[1] + (uint32_t)a.y);
-    r.v[2] = (int32_t)((uint32_t)r.v[2] + (uint32_t)a.z);
-    r.v[3] = (int32_t)((uint32_t)r.v[3] + (uint32_t)a.w);
+    const unsigned long long b = (unsigned long long)(sub.seg & HUFF_SEG_MASK) * g->ri_mcus * g->bpm;
+    const unsigned long long cap = (unsigned long long)g->total_mcus * g->bpm;
+    return (int32_t)(b < cap ? b : cap);
 }
-// phase A: aggregate of chunk t
-ZJ_DEV HuffAgg huff_scan_chunk(const HuffArgs& a, uint32_t t, uint32_t chunk)
+// what sub-sequence i contributes: its counts, or -- at the head of a segment -- the absolute value after it
+ZJ_DEV HuffAgg huff_scan_element(const HuffArgs& a, uint32_t i)
 {
     const HuffScan* g = huff_hdr(a.blob);
-    const HuffSub* subs = huff_subs(a.blob);
+    if (i >= g->nsub) return huff_scan_identity();
+    const HuffSub sub = huff_subs(a.blob)[i];
+    const HuffI4 x = a.aux[i];
     HuffAgg r;
-    r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0; r.reset = 0;
-    const uint32_t i0 = t * chunk, i1 = i0 + chunk < g->nsub ? i0 + chunk : g->nsub;
-    for (uint32_t i = i0; i < i1; i++) { huff_scan_step(g, subs[i], r); huff_scan_add(r, a.aux[i]); }
+    r.v[0] = x.x; r.v[1] = x.y; r.v[2] = x.z; r.v[3] = x.w;
+    r.reset = 0;
+    if (sub.seg & HUFF_FIRST) { r.v[0] = (int32_t)((uint32_t)r.v[0] + (uint32_t)huff_seg_first_block(g, sub)); r.reset = 1; }
     return r;
 }
-// phase B (one thread): exclusive combination of the chunk aggregates, in place
-ZJ_DEV void huff_scan_combine(HuffAgg* agg, uint32_t nchunks)
-{
-    HuffAgg run;
-    run.v[0] = run.v[1] = run.v[2] = run.v[3] = 0; run.reset = 0;
-    for (uint32_t t = 0; t < nchunks; t++) {
-        const HuffAgg mine = agg[t];
-        agg[t] = run;
-        if (mine.reset) run = mine;
-        else for (int q = 0; q < 4; q++) run.v[q] = (int32_t)((uint32_t)run.v[q] + (uint32_t)mine.v[q]);
-    }
-}
-// phase C: chunk t again, from its incoming value
-ZJ_DEV void huff_scan_apply(const HuffArgs& a, uint32_t t, uint32_t chunk, HuffAgg r)
+// excl: the scan of the elements in front of i within its workgroup
+ZJ_DEV void huff_scan_store(const HuffArgs& a, uint32_t i, const HuffAgg excl)
 {
     const HuffScan* g = huff_hdr(a.blob);
-    const HuffSub* subs = huff_subs(a.blob);
-    const uint32_t i0 = t * chunk, i1 = i0 + chunk < g->nsub ? i0 + chunk : g->nsub;
-    for (uint32_t i = i0; i < i1; i++) {
-        huff_scan_step(g, subs[i], r);
-        HuffI4 b;
-        b.x = r.v[0]; b.y = r.v[1]; b.z = r.v[2]; b.w = r.v[3];
-        a.base[i] = b;
-        huff_scan_add(r, a.aux[i]);
-    }
+    if (i >= g->nsub) return;
+    const HuffSub sub = huff_subs(a.blob)[i];
+    HuffI4 b;
+    if (sub.seg & HUFF_FIRST) { b.x = huff_seg_first_block(g, sub); b.y = b.z = b.w = 0; a.changed[i] = 0; }
+    else { b.x = excl.v[0]; b.y = excl.v[1]; b.z = excl.v[2]; b.w = excl.v[3]; a.changed[i] = excl.reset ? 0 : 1; }
+    a.base[i] = b;
+}
+// (one thread) exclusive scan of the workgroup totals
+ZJ_DEV void huff_scan_totals(const HuffArgs& a, uint32_t nwg)
+{
+    HuffAgg run = huff_scan_identity();
+    for (uint32_t w = 0; w < nwg; w++) { a.wgpre[w] = run; run = huff_scan_op(run, a.wgagg[w]); }
 }
 
 // ---- the reference's early exit at EOI ---------------------------------------------------------------------------------
@@ -362,9 +390,9 @@ ZJ_DEV void huff_scan_apply(const HuffArgs& a, uint32_t t, uint32_t chunk, HuffA
 ZJ_DEV uint32_t huff_cut_plan(const HuffArgs& a, uint32_t* first_mcu)
 {
     const HuffScan* g = huff_hdr(a.blob);
-    const uint32_t fs = a.ctl[1];
+    const uint32_t fs = a.ctl[HUFF_CTL_SEEN];
     if (fs >= g->total_mcus || fs + 1 >= g->total_mcus) return 0;
-    if (fs / g->rowlen != (g->total_mcus - 1) / g->rowlen) { huff_or(&a.ctl[0], HUFF_ST_CUT_EARLY); return 0; }
+    if (fs / g->rowlen != (g->total_mcus - 1) / g->rowlen) { huff_or(&a.ctl[HUFF_CTL_STATUS], HUFF_ST_CUT_EARLY); return 0; }
     *first_mcu = fs + 1;
     return (g->total_mcus - fs - 1) * g->bpm * 8u;
 }

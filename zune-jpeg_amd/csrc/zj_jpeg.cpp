@@ -904,29 +904,33 @@ int scan_progressive(zj_decoder* d, BitReader& br)
 
 // after a scan: find the next marker (mcu_prog.rs:436-472)
 // ---- the scan as the GPU entropy stage wants it (zj_huff.h) --------------------------------------------------------
-// Two-level decoding table: 512 first-level entries indexed by the next 9 bits; codes longer than 9 bits hang off their
-// 9-bit prefix in a 128-entry second level.  Returns the entries used, or -1 if they exceed `room`.
-int gpu_table(const Huff& h, uint16_t* out, int room)
+// Two-level decoding table: 2^B first-level entries indexed by the next B bits (B = 9 for DC, 11 for AC tables); codes
+// longer than B bits hang off their B-bit prefix in a second level of 2^(16-B) entries.  Returns the entries used, or
+// -1 if they exceed `room`.
+int gpu_table(const Huff& h, bool ac, uint16_t* out, int room)
 {
-    constexpr int L1 = 1 << zj::HUFF_L1_BITS, L2 = 1 << zj::HUFF_L2_BITS;
+    const int B = ac ? zj::HUFF_L1_AC : zj::HUFF_L1_DC, L1 = 1 << B, L2 = 1 << (16 - B);
     if (room < L1) return -1;
     memset(out, 0, L1 * sizeof(uint16_t));
     uint32_t code = 0;
     int k = 0, links = 0;
     for (int l = 1; l <= 16; l++) {
         for (int i = 0; i < h.nlen[l]; i++, k++, code++) {
-            const uint16_t e = (uint16_t)((l << 8) | h.vals[k]);
-            if (l <= zj::HUFF_L1_BITS) {
-                const uint32_t base = code << (zj::HUFF_L1_BITS - l);
-                for (uint32_t q = 0; q < (1u << (zj::HUFF_L1_BITS - l)); q++) out[base + q] = e;
+            // entry: bits consumed | zig-zag advance << 5 | magnitude bits << 11 (zj_huff.h)
+            const int sym = h.vals[k], sz = ac ? (sym & 15) : sym, run = ac ? sym >> 4 : 0;
+            const int zadv = !ac ? 1 : sz ? run + 1 : run == 15 ? 16 : 63;
+            const uint16_t e = (sz > 15 || l + sz > 31) ? 0 : (uint16_t)((l + sz) | (zadv << 5) | (sz << 11));
+            if (l <= B) {
+                const uint32_t base = code << (B - l);
+                for (uint32_t q = 0; q < (1u << (B - l)); q++) out[base + q] = e;
             } else {
-                const uint32_t prefix = code >> (l - zj::HUFF_L1_BITS);
+                const uint32_t prefix = code >> (l - B);
                 if (!out[prefix]) {
                     if (links == 255 || L1 + (links + 1) * L2 > room) return -1;
                     memset(out + L1 + links * L2, 0, L2 * sizeof(uint16_t));
                     out[prefix] = (uint16_t)(0x8000 | links++);
                 }
-                const uint32_t sub = (uint32_t)L1 + ((out[prefix] & 0xffu) << zj::HUFF_L2_BITS);
+                const uint32_t sub = (uint32_t)L1 + ((out[prefix] & 0xffu) << (16 - B));
                 const uint32_t low = (code << (16 - l)) & (uint32_t)(L2 - 1);
                 for (uint32_t q = 0; q < (1u << (16 - l)); q++) out[sub + low + q] = e;
             }
@@ -989,7 +993,7 @@ int prepare_scan(zj_decoder* d, const uint8_t* p, const uint8_t* end)
     auto table_index = [&](int cls, int id) { // entry offset of the table, -1: the tables do not fit the device's LDS budget
         const int key = cls * 4 + id;
         for (int t = 0; t < ntab; t++) if (tab_key[t] == key) return tab_off[t];
-        const int n = gpu_table(cls ? d->ac[id] : d->dc[id], tabs.data() + tab_used, HUFF_TAB_BUDGET - tab_used);
+        const int n = gpu_table(cls ? d->ac[id] : d->dc[id], cls != 0, tabs.data() + tab_used, HUFF_TAB_BUDGET - tab_used);
         if (n < 0) return -1;
         tab_key[ntab] = key;
         tab_off[ntab++] = tab_used;
@@ -1001,12 +1005,14 @@ int prepare_scan(zj_decoder* d, const uint8_t* p, const uint8_t* end)
         const Comp& cm = d->comps[d->order[ci]];
         const int tdc = table_index(0, cm.td & 3), tac = table_index(1, cm.ta & 3);
         if (tdc < 0 || tac < 0) return why(12);
+        h.dc_off[d->order[ci]] = (uint16_t)tdc;
+        h.ac_off[d->order[ci]] = (uint16_t)tac;
         for (int v = 0; v < cm.v; v++)
             for (int hh = 0; hh < cm.h; hh++) {
                 if (bpm == HUFF_MAX_BPM) return why(7);
+                h.comp_of_blk |= (uint32_t)d->order[ci] << (2 * bpm);
                 HuffBlk& b = h.blk[bpm++];
                 b.comp = (uint8_t)d->order[ci]; b.hx = (uint8_t)hh; b.vy = (uint8_t)v;
-                b.dc_off = (uint16_t)tdc; b.ac_off = (uint16_t)tac;
             }
     }
     if (d->entropy < 2 && bpm > 1) {
@@ -1014,7 +1020,8 @@ int prepare_scan(zj_decoder* d, const uint8_t* p, const uint8_t* end)
         // place in the MCU, so a wrong guess of that place never corrects itself: it only heals one sub-sequence per
         // round from the front.  No encoder of YCbCr files shares luma and chroma tables; leave the odd one to the CPU.
         bool same = true;
-        for (int b = 1; b < bpm; b++) same = same && h.blk[b].dc_off == h.blk[0].dc_off && h.blk[b].ac_off == h.blk[0].ac_off;
+        for (int b = 1; b < bpm; b++)
+            same = same && h.dc_off[h.blk[b].comp] == h.dc_off[h.blk[0].comp] && h.ac_off[h.blk[b].comp] == h.ac_off[h.blk[0].comp];
         if (same) return why(13);
     }
     for (int i = 0; i < d->ncomp; i++) {
