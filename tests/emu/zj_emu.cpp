@@ -173,13 +173,13 @@ extern "C" int zje_huff_decode(const uint8_t* blob, int16_t* y, int16_t* cb, int
     const uint32_t nsub = g->nsub;
     std::vector<unsigned long long> exitv(nsub);
     std::vector<HuffI4> aux(nsub), base(nsub);
-    std::vector<uint8_t> changed(2 * (size_t)nsub);
+    std::vector<uint8_t> changed(2 * (size_t)nsub), rel(nsub);
     std::vector<uint32_t> ctl(HUFF_CTL_WORDS, 0);
     ctl[HUFF_CTL_SEEN] = 0xffffffffu;
     const uint32_t nscan = (nsub + HUFF_SCAN_WG - 1) / HUFF_SCAN_WG;
     std::vector<HuffAgg> wgagg(nscan), wgpre(nscan);
     HuffArgs a;
-    a.blob = blob; a.exit = exitv.data(); a.aux = aux.data(); a.base = base.data(); a.changed = changed.data();
+    a.blob = blob; a.exit = exitv.data(); a.aux = aux.data(); a.base = base.data(); a.changed = changed.data(); a.rel = rel.data();
     a.wgagg = wgagg.data(); a.wgpre = wgpre.data();
     a.ctl = ctl.data(); a.plane[0] = y; a.plane[1] = cb; a.plane[2] = cr; a.round = 0;
     std::vector<HuffLds> lds(1);

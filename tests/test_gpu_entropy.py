@@ -85,7 +85,20 @@ def test_planes_on_the_device_equal_the_cpu_walker(zj, ctx):
     assert rc == 0 and st == 0
     assert np.array_equal(out, c.decode_buffer(data))
     rounds, _ = ctx.scan_stats()
-    assert 1 <= rounds <= 8
+    assert 1 <= rounds <= 32
+
+
+def test_more_rounds_than_planned(zj, ctx, monkeypatch):
+    """The rounds are launched ahead and looked at once, after the pixels: with too few planned (here 1) the stage adds
+    rounds, clears what the premature write pass scattered and runs the rest again."""
+    data = pil_jpeg(1201, 801, quality=95, seed=13)
+    g, c = decoders(zj, ctx)
+    want = c.decode_buffer(data)
+    monkeypatch.setenv("ZJ_HUFF_ROUNDS", "1")
+    got = g.decode_buffer(data)
+    assert g.gpu_status() == 0
+    assert np.array_equal(got, want)
+    assert ctx.scan_stats()[0] > 1
 
 
 def test_reference_file_with_the_eoi_cut(zj, ctx):

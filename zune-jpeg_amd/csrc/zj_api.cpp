@@ -558,7 +558,7 @@ int zj_decode_scan(zj_ctx* c, const zj_frame_desc* d, const void* blob, size_t b
     const size_t nsub = h->nsub;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_exit = up(blob_bytes), o_aux = o_exit + up(nsub * 8), o_base = o_aux + up(nsub * 16),
-                 o_chg = o_base + up(nsub * 16), o_ctl = o_chg + up(nsub * 2), ctl_words = HUFF_CTL_WORDS,
+                 o_chg = o_base + up(nsub * 16), o_rel = o_chg + up(nsub * 2), o_ctl = o_rel + up(nsub), ctl_words = HUFF_CTL_WORDS,
                  nscan = (nsub + HUFF_SCAN_WG - 1) / HUFF_SCAN_WG, o_agg = o_ctl + up(ctl_words * 4),
                  o_pre = o_agg + up(nscan * sizeof(HuffAgg)), total = o_pre + up(nscan * sizeof(HuffAgg));
     if ((rc = ensure_buf(c, &c->hbuf, &c->hbuf_cap, total))) return rc;
@@ -573,6 +573,7 @@ int zj_decode_scan(zj_ctx* c, const zj_frame_desc* d, const void* blob, size_t b
     a.aux = (HuffI4*)(base + o_aux);
     a.base = (HuffI4*)(base + o_base);
     a.changed = base + o_chg;
+    a.rel = base + o_rel;
     a.ctl = (uint32_t*)(base + o_ctl);
     a.wgagg = (HuffAgg*)(base + o_agg);
     a.wgpre = (HuffAgg*)(base + o_pre);
@@ -587,32 +588,52 @@ int zj_decode_scan(zj_ctx* c, const zj_frame_desc* d, const void* blob, size_t b
     ZJ_HIP(c, hipMemsetAsync(a.ctl, 0, ctl_words * 4, s));
     ZJ_HIP(c, hipMemsetAsync(a.ctl + HUFF_CTL_SEEN, 0xff, 4, s));
     ZJ_HIP(c, hipMemsetAsync(c->hplanes, 0, yb + 2 * cbytes, s)); // the write pass stores non-zero coefficients only
-    // synchronisation rounds: 0, then groups (8, 8, 16, 32, ...) with one look at the change counters per group: a
-    // round nobody needs costs microseconds, a look costs a stream synchronisation
-    ZJ_HIP(c, launch_huff_sync(a, (uint32_t)nsub, s));
-    int round = 0, group_size = 8;
+    // Synchronisation rounds.  A wrong guess of a sub-sequence's entry state falls into step with the true parse
+    // within ~1 KB of 4:2:0 data, i.e. after 1024 / sub_bytes rounds; rounds are cheap to launch and no-ops once one
+    // of them changed nothing, a look at the counters costs a stream synchronisation.  So: launch what is normally
+    // enough, go on with the prefix sums, the write pass and the pixel kernel, and look once at the end.  Only if the
+    // last round still changed something: more rounds (looking after each group), then the rest again.
+    const uint32_t sub_bytes = h->sub_bytes >= 16 && h->sub_bytes <= (uint32_t)HUFF_SUB_MAX ? h->sub_bytes : (uint32_t)HUFF_SUB_MAX;
+    int planned = (int)(1536 / sub_bytes) + 2;
+    if (const char* e = getenv("ZJ_HUFF_ROUNDS")) { const int v = atoi(e); if (v >= 1) planned = v; }
+    if (planned > HUFF_MAX_ROUNDS) planned = HUFF_MAX_ROUNDS;
+    uint8_t* d_out = out_on_device ? out : (uint8_t*)c->scratch[3];
+    int round = 0;
     bool synced = false;
-    while (!synced && round < HUFF_MAX_ROUNDS) {
-        const int group = round + group_size <= HUFF_MAX_ROUNDS ? group_size : HUFF_MAX_ROUNDS - round;
-        if (round >= 8) group_size *= 2;
-        for (int k = 0; k < group; k++) { a.round = ++round; ZJ_HIP(c, launch_huff_sync(a, (uint32_t)nsub, s)); }
+    ZJ_HIP(c, launch_huff_sync(a, (uint32_t)nsub, s));
+    for (int pass = 0; !synced; pass++) {
+        if (pass == 0) {
+            while (round < planned) { a.round = ++round; ZJ_HIP(c, launch_huff_sync(a, (uint32_t)nsub, s)); }
+        } else {
+            if (round >= HUFF_MAX_ROUNDS) { c->huff_rounds = round; if (status_bits) *status_bits = HUFF_ST_NO_SYNC; return ZJ_RETRY_CPU; }
+            // (the planes may hold coefficients scattered from a wrong parse; the counters of the finish kernels restart)
+            int group = 16;
+            while (!synced && round < HUFF_MAX_ROUNDS) {
+                const int first = round + 1;
+                for (int k = 0; k < group && round < HUFF_MAX_ROUNDS; k++) { a.round = ++round; ZJ_HIP(c, launch_huff_sync(a, (uint32_t)nsub, s)); }
+                ZJ_HIP(c, hipMemcpyAsync(c->h_ctl, a.ctl, ctl_words * 4, hipMemcpyDeviceToHost, s));
+                ZJ_HIP(c, hipStreamSynchronize(s));
+                for (int r = first; r <= round; r++)
+                    if (c->h_ctl[HUFF_CTL_ROUND0 + r] == 0) { synced = true; break; }
+                group *= 2;
+            }
+            if (!synced) continue; // -> NO_SYNC above
+            ZJ_HIP(c, hipMemsetAsync(a.ctl, 0, HUFF_CTL_ROUND0 * 4, s));
+            ZJ_HIP(c, hipMemsetAsync(a.ctl + HUFF_CTL_SEEN, 0xff, 4, s));
+            ZJ_HIP(c, hipMemsetAsync(c->hplanes, 0, yb + 2 * cbytes, s));
+        }
+        if (timing && pass == 0) ZJ_HIP(c, hipEventRecord(ev[1], s));
+        ZJ_HIP(c, launch_huff_finish(a, (uint32_t)nsub, s));
+        if (timing && pass == 0) ZJ_HIP(c, hipEventRecord(ev[2], s));
+        rc = decode_device_impl(c, d, pl, 1, a.plane[0], chroma ? a.plane[1] : nullptr, chroma ? a.plane[2] : nullptr, d_out, s, 1);
+        if (rc) return rc;
+        if (!out_on_device) ZJ_HIP(c, hipMemcpyAsync(out, d_out, pl.out_len, hipMemcpyDeviceToHost, s));
         ZJ_HIP(c, hipMemcpyAsync(c->h_ctl, a.ctl, ctl_words * 4, hipMemcpyDeviceToHost, s));
+        if (timing && pass == 0) ZJ_HIP(c, hipEventRecord(ev[3], s));
         ZJ_HIP(c, hipStreamSynchronize(s));
-        for (int r = round - group + 1; r <= round; r++)
+        for (int r = 1; r <= round; r++)
             if (c->h_ctl[HUFF_CTL_ROUND0 + r] == 0) { synced = true; c->huff_rounds = r; break; }
     }
-    if (!synced) c->huff_rounds = round;
-    if (!synced) { if (status_bits) *status_bits = HUFF_ST_NO_SYNC; return ZJ_RETRY_CPU; }
-    if (timing) ZJ_HIP(c, hipEventRecord(ev[1], s));
-    ZJ_HIP(c, launch_huff_finish(a, (uint32_t)nsub, s));
-    if (timing) ZJ_HIP(c, hipEventRecord(ev[2], s));
-    uint8_t* d_out = out_on_device ? out : (uint8_t*)c->scratch[3];
-    rc = decode_device_impl(c, d, pl, 1, a.plane[0], chroma ? a.plane[1] : nullptr, chroma ? a.plane[2] : nullptr, d_out, s, 1);
-    if (rc) return rc;
-    if (!out_on_device) ZJ_HIP(c, hipMemcpyAsync(out, d_out, pl.out_len, hipMemcpyDeviceToHost, s));
-    ZJ_HIP(c, hipMemcpyAsync(c->h_ctl, a.ctl, 8, hipMemcpyDeviceToHost, s));
-    if (timing) ZJ_HIP(c, hipEventRecord(ev[3], s));
-    ZJ_HIP(c, hipStreamSynchronize(s));
     if (timing) {
         for (int k = 0; k < 3; k++) ZJ_HIP(c, hipEventElapsedTime(&c->huff_ms[k], ev[k], ev[k + 1]));
         for (auto& e : ev) (void)hipEventDestroy(e);

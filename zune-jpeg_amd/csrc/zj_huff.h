@@ -65,6 +65,7 @@ struct HuffScan { // header of the blob; every off_* is a byte offset from the h
     uint32_t rowlen;           // MCUs per row loop of the reference (mcu.rs:145-152)
     uint32_t tab_entries;      // u16 entries of all decoding tables together (even)
     uint32_t off_tab, off_sub, off_seg, off_stream, stream_bytes; // stream_bytes: multiple of 16, >= 32 zero bytes at the end
+    uint32_t sub_bytes;        // nominal sub-sequence size (the last one of a segment is shorter)
     uint32_t comp_of_blk;      // 2 bits per block of the MCU: its component
     uint16_t dc_off[4], ac_off[4]; // per component: entry offset of its decoding tables
     HuffBlk blk[HUFF_MAX_BPM];
@@ -86,8 +87,8 @@ struct HuffArgs {
     unsigned long long* exit;  // [nsub] packed exit state of every sub-sequence
     HuffI4* aux;               // [nsub] blocks completed, DC difference sums per component
     HuffI4* base;              // [nsub] first block index, DC predictors (after the scan kernel)
-    uint8_t* changed;          // [2][nsub] exit state changed in the round of that parity; after the rounds [0][i]: base[i]
-                               // is relative to its prefix-sum workgroup (add wgpre)
+    uint8_t* changed;          // [2][nsub] exit state changed in the round of that parity
+    uint8_t* rel;              // [nsub] base[i] is relative to its prefix-sum workgroup (add wgpre)
     HuffAgg* wgagg;            // [ceil(nsub / HUFF_SCAN_WG)] totals of the prefix-sum workgroups
     HuffAgg* wgpre;            // the same, exclusive prefix
     uint32_t* ctl;             // HUFF_CTL_*: status bits, first MCU at which the reference has seen EOI, ticket of the

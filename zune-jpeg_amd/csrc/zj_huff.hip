@@ -15,6 +15,9 @@ __global__ __launch_bounds__(HUFF_WG) void zj_huff_sync_kernel(HuffArgs a)
     const uint32_t i = blockIdx.x * HUFF_WG + threadIdx.x;
     const HuffScan* g = huff_hdr(a.blob);
     const uint32_t nsub = g->nsub;
+    // the rounds are launched ahead of any look at their outcome: once a round changed nothing, the rest are no-ops
+    // (they leave the flags alone: the rounds after them return here as well)
+    if (a.round >= 2 && a.ctl[HUFF_CTL_ROUND0 + a.round - 1] == 0) return;
     const bool need = huff_sync_needed(a, i, nsub, huff_subs(a.blob));
     if (!__syncthreads_or(need ? 1 : 0)) { // nobody's entry state moved: no staging either
         if (i < nsub) a.changed[(size_t)(a.round & 1) * nsub + i] = 0;

@@ -305,7 +305,7 @@ ZJ_DEV void huff_write_thread(const HuffArgs& a, const HuffLds& L, uint32_t i)
     if (sub.seg & HUFF_FIRST) { s.pos = sub.start * 8u; s.j = 0; s.z = 0; }
     else s = huff_unpack(a.exit[i - 1]);
     HuffI4 b = a.base[i];
-    if (a.changed[i]) { // relative to its prefix-sum workgroup
+    if (a.rel[i]) { // relative to its prefix-sum workgroup
         const HuffAgg p = a.wgpre[i / HUFF_SCAN_WG];
         b.x = (int32_t)((uint32_t)b.x + (uint32_t)p.v[0]); b.y = (int32_t)((uint32_t)b.y + (uint32_t)p.v[1]);
         b.z = (int32_t)((uint32_t)b.z + (uint32_t)p.v[2]); b.w = (int32_t)((uint32_t)b.w + (uint32_t)p.v[3]);
@@ -334,7 +334,7 @@ ZJ_DEV void huff_write_thread(const HuffArgs& a, const HuffLds& L, uint32_t i)
 // A segmented exclusive scan of aux[]: a sub-sequence that begins a restart segment restarts the sums at (first block
 // of the segment, 0, 0, 0).  Two levels: workgroups of HUFF_SCAN_WG sub-sequences scan themselves (one element per
 // thread) and publish their totals; the workgroup that finishes last scans the totals; the write pass adds the
-// workgroup's prefix to the values that are still relative (changed[i]).
+// workgroup's prefix to the values that are still relative (rel[i]).
 ZJ_DEV HuffAgg huff_scan_identity() { HuffAgg r; r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0; r.reset = 0; return r; }
 // left then right
 ZJ_DEV HuffAgg huff_scan_op(const HuffAgg l, const HuffAgg r)
@@ -371,8 +371,8 @@ ZJ_DEV void huff_scan_store(const HuffArgs& a, uint32_t i, const HuffAgg excl)
     if (i >= g->nsub) return;
     const HuffSub sub = huff_subs(a.blob)[i];
     HuffI4 b;
-    if (sub.seg & HUFF_FIRST) { b.x = huff_seg_first_block(g, sub); b.y = b.z = b.w = 0; a.changed[i] = 0; }
-    else { b.x = excl.v[0]; b.y = excl.v[1]; b.z = excl.v[2]; b.w = excl.v[3]; a.changed[i] = excl.reset ? 0 : 1; }
+    if (sub.seg & HUFF_FIRST) { b.x = huff_seg_first_block(g, sub); b.y = b.z = b.w = 0; a.rel[i] = 0; }
+    else { b.x = excl.v[0]; b.y = excl.v[1]; b.z = excl.v[2]; b.w = excl.v[3]; a.rel[i] = excl.reset ? 0 : 1; }
     a.base[i] = b;
 }
 // (one thread) exclusive scan of the workgroup totals

@@ -1073,6 +1073,7 @@ int prepare_scan(zj_decoder* d, const uint8_t* p, const uint8_t* end)
     h.bpm = (uint32_t)bpm; h.ncomp = (uint32_t)d->ncomp;
     h.mcu_x = (uint32_t)d->mcu_x; h.mcu_y = (uint32_t)d->mcu_y; h.total_mcus = (uint32_t)total;
     h.is_eoi = is_eoi ? 1 : 0;
+    h.sub_bytes = (uint32_t)sub;
     h.rowlen = (uint32_t)eoi_rowlen(d);
     h.tab_entries = (uint32_t)tab_used;
     h.off_tab = (uint32_t)off_tab; h.off_sub = (uint32_t)off_sub; h.off_seg = (uint32_t)off_seg;
