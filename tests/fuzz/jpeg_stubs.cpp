@@ -15,6 +15,9 @@ size_t zj_out_len(const zj_frame_desc* d)
     return (size_t)d->width * d->height * nc;
 }
 int zj_decode_planes(zj_ctx*, const zj_frame_desc*, const int16_t*, const int16_t*, const int16_t*, uint8_t*) { return ZJ_ERR_NO_DEVICE; }
+int zj_decode_planes_to_device(zj_ctx*, const zj_frame_desc*, const int16_t*, const int16_t*, const int16_t*, uint8_t*) { return ZJ_ERR_NO_DEVICE; }
+int zj_decode_scan(zj_ctx*, const zj_frame_desc*, const void*, size_t, uint8_t*, int, unsigned*) { return ZJ_ERR_NO_DEVICE; }
+int zj_device_memset(zj_ctx*, void*, int, size_t) { return ZJ_ERR_NO_DEVICE; }
 const char* zj_strerror(int) { return "stub"; }
 const char* zj_last_error(const zj_ctx*) { return ""; }
 }

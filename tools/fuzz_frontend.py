@@ -2,6 +2,9 @@
 """Robustness of the CPU entropy front-end on damaged files: zj_jpeg.cpp built alone with AddressSanitizer + UBSan
 (tests/fuzz/jpeg_stubs.cpp stands in for the GPU calls) and fed thousands of mutated baseline / progressive / DRI
 files: bit flips, byte splices, truncations, marker-length edits.  Any status is fine; a sanitizer report is not.
+Every third file also goes through zj_decoder_prepare with the device entropy setting (the byte-level preparation of
+the scan), and what it prepares through the DEVICE code of the entropy stage (zj_huff_device.h) run thread by thread by
+the emulation harness, also built with the sanitizers: a damaged scan must neither read nor write out of bounds there.
 
     python tools/fuzz_frontend.py [--iters 4000]      (re-executes itself under LD_PRELOAD=libasan.so)
 """
@@ -13,12 +16,16 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SO = "/tmp/libzjjpeg_asan.so"
+EMU = "/tmp/libzjemu_asan.so"
 
 
 def build():
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fsanitize=address,undefined",
                            "-fno-omit-frame-pointer", "-o", SO,
                            os.path.join(ROOT, "zune-jpeg_amd", "csrc", "zj_jpeg.cpp"), os.path.join(ROOT, "tests", "fuzz", "jpeg_stubs.cpp")])
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fno-strict-aliasing", "-fsanitize=address,undefined",
+                           "-fno-sanitize=alignment", "-fno-omit-frame-pointer", "-Wno-unknown-pragmas", "-o", EMU,
+                           os.path.join(ROOT, "tests", "emu", "zj_emu.cpp")])
 
 
 def main():
@@ -45,9 +52,13 @@ def main():
     L.zj_decoder_new.argtypes = [C.c_void_p]
     L.zj_decoder_free.argtypes = [C.c_void_p]
     L.zj_decoder_decode_coefficients.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.zj_decoder_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.zj_decoder_scan_blob.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    E = C.CDLL(EMU)
+    E.zje_huff_decode.argtypes = [C.c_void_p] * 6
 
     class Opt(C.Structure):
-        _fields_ = [(n, C.c_int32) for n in ("out_colorspace", "strict_mode", "max_width", "max_height", "max_scans", "num_threads", "pinned_planes", "flags", "out_layout")]
+        _fields_ = [(n, C.c_int32) for n in ("out_colorspace", "strict_mode", "max_width", "max_height", "max_scans", "num_threads", "pinned_planes", "flags", "out_layout", "entropy")]
 
     qts = synth.quant_tables(85)
     seeds = []
@@ -61,8 +72,11 @@ def main():
     rng = np.random.default_rng(7)
     decs = []
     for threads in (1, 3):
-        o = Opt(0, 0, 0, 0, 0, threads, 0, 0, 0)
+        o = Opt(0, 0, 0, 0, 0, threads, 0, 0, 0, 0)
         decs.append(L.zj_decoder_new(C.byref(o)))
+    o = Opt(0, 0, 0, 0, 0, 1, 0, 0, 0, 2)
+    gdec = L.zj_decoder_new(C.byref(o))
+    emu_runs = emu_kept = 0
     stats = {}
     desc = (C.c_char * 1024)()
     info = (C.c_char * 64)()
@@ -86,6 +100,19 @@ def main():
         arr = np.frombuffer(bytes(b), np.uint8)
         rc = L.zj_decoder_decode_coefficients(decs[it & 1], arr.ctypes.data, arr.size, desc, None, None, info)
         stats[rc] = stats.get(rc, 0) + 1
+        if it % 3 == 0 and L.zj_decoder_prepare(gdec, arr.ctypes.data, arr.size, desc, info) == 0:
+            p, n = C.c_void_p(), C.c_size_t(0)
+            if L.zj_decoder_scan_blob(gdec, C.byref(p), C.byref(n)) == 0:
+                st = C.c_uint32(0)
+                # planes of exactly the size the scan's header states (HuffScan.comp[i].bw * bh * 64, zj_huff.h), so
+                # that a store past a plane is a heap overflow the sanitizer sees
+                hdr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(46,))
+                planes = [np.zeros(max(64, int(hdr[34 + 4 * c + 2]) * int(hdr[34 + 4 * c + 3]) * 64), np.int16) for c in range(3)]
+                E.zje_huff_decode(p, planes[0].ctypes.data, planes[1].ctypes.data, planes[2].ctypes.data, C.byref(st), None)
+                emu_runs += 1
+                emu_kept += st.value == 0
+    print(f"device entropy stage (emulated): {emu_runs} prepared scans, {emu_kept} kept by the device")
+    L.zj_decoder_free(gdec)
     for d in decs:
         L.zj_decoder_free(d)
     print("statuses:", dict(sorted(stats.items())))
