@@ -120,6 +120,9 @@ extern "C" {
     pub fn zj_pool_decode_files(pool: *mut zj_pool, nfiles: usize, bufs: *const *const u8, lens: *const usize,
                                 outs: *const *mut u8, out_caps: *const usize, out_lens: *mut usize,
                                 infos: *mut zj_image_info, statuses: *mut c_int) -> c_int;
+    pub fn zj_pool_decode_files_device(pool: *mut zj_pool, nfiles: usize, bufs: *const *const u8, lens: *const usize,
+                                       d_outs: *const *mut u8, out_caps: *const usize, out_lens: *mut usize,
+                                       infos: *mut zj_image_info, statuses: *mut c_int) -> c_int;
 }
 
 fn check(rc: c_int, what: &str) {

@@ -279,6 +279,12 @@ int zj_pool_decode_files(zj_pool *pool, size_t nfiles, const uint8_t *const *buf
                          uint8_t *const *outs, const size_t *out_caps, size_t *out_lens /*[nfiles] or NULL*/,
                          zj_image_info *infos /*[nfiles] or NULL*/, int *statuses /*[nfiles] or NULL*/);
 
+/* the same with device pointers (on the pool's device, 16-byte aligned) as outputs: the pixels stay in HBM for a
+ * consumer on the GPU, nothing crosses PCIe but the compressed files (with a GPU entropy setting) or the planes */
+int zj_pool_decode_files_device(zj_pool *pool, size_t nfiles, const uint8_t *const *bufs, const size_t *lens,
+                                uint8_t *const *d_outs, const size_t *out_caps, size_t *out_lens /*[nfiles] or NULL*/,
+                                zj_image_info *infos /*[nfiles] or NULL*/, int *statuses /*[nfiles] or NULL*/);
+
 /* ---- memory helpers ------------------------------------------------------------------------- */
 void *zj_alloc_pinned(size_t bytes); /* hipHostMalloc, portable (usable as a DMA source/target from every device); NULL on failure */
 /* binds the CALLING thread to `device` (hipSetDevice): host threads that only allocate pinned memory or fill planes for a

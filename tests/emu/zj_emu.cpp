@@ -230,3 +230,4 @@ extern "C" int zje_huff_decode(const uint8_t* blob, int16_t* y, int16_t* cb, int
     if (stats) { stats[0] = (uint32_t)round; stats[1] = nsub; stats[2] = work; stats[3] = ctl[HUFF_CTL_SEEN]; }
     return ZJ_OK;
 }
+

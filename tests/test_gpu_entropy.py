@@ -167,3 +167,23 @@ def test_pool_with_the_device_entropy_stage(zj):
         want, _, _ = pool.decode_files(files)
     for a, b in zip(outs, want):
         assert np.array_equal(a, b)
+
+
+def test_pool_leaves_pixels_in_hbm(zj, ctx):
+    files = [pil_jpeg(512 + 16 * k, 384, quality=85, seed=30 + k) for k in range(6)]
+    with zj.Pool(2) as pool:
+        want, _, _ = pool.decode_files(files)
+    o = zj.ZuneJpegOptions()
+    o.entropy = zj.ENTROPY_GPU_ALWAYS
+    ptrs = [ctx.device_alloc(w.size + 64) for w in want]
+    try:
+        with zj.Pool(2, o) as pool:
+            lens, _, sts = pool.decode_files_device(files, ptrs, [w.size for w in want])
+        assert all(s == 0 for s in sts) and lens == [w.size for w in want]
+        for p, w in zip(ptrs, want):
+            got = np.zeros(w.size, np.uint8)
+            ctx.d2h(got, p)
+            assert np.array_equal(got, w)
+    finally:
+        for p in ptrs:
+            ctx.device_free(p)

@@ -31,7 +31,10 @@
 extern "C" int zj_set_pipeline(zj_ctx* c, int on);
 
 namespace {
-constexpr int GPU_SUBMITTERS = 3;
+// Three submitters keep both PCIe directions and the kernel queue busy when planes go up and pixels come down.  With
+// the entropy stage on the device a file is a dozen short, latency-bound kernels (zj_huff.hip) and almost no upload:
+// more files in flight fill the GPU better.
+constexpr int GPU_SUBMITTERS = 3, GPU_SUBMITTERS_DEVICE_ENTROPY = 8;
 }
 
 struct zj_pool {
@@ -44,6 +47,7 @@ struct zj_pool {
         size_t* out_lens = nullptr;
         zj_image_info* infos = nullptr;
         int* statuses = nullptr;
+        bool on_device = false; // outs[] are device pointers on the pool's device: the pixels stay in HBM
         size_t next = 0;     // next file to entropy-decode   (under mu)
         size_t done = 0;     // files finished or failed       (under mu)
         int first_error = 0;
@@ -122,7 +126,8 @@ struct zj_pool {
             lk.unlock();
             size_t olen = 0;
             const double t0 = now();
-            const int rc = zj_decoder_finish_pixels(j.dec, ctx, b.outs[j.index], b.caps[j.index], &olen);
+            const int rc = b.on_device ? zj_decoder_finish_pixels_device(j.dec, ctx, b.outs[j.index], b.caps[j.index], &olen)
+                                       : zj_decoder_finish_pixels(j.dec, ctx, b.outs[j.index], b.caps[j.index], &olen);
             const double dt = now() - t0;
             lk.lock();
             gpu_s += dt;
@@ -165,7 +170,9 @@ zj_pool* zj_pool_create(int device, int threads, const zj_options* opt, int* sta
     p->n_workers = threads;
     p->device = device;
     *status = ZJ_OK;
-    for (int g = 0; g < GPU_SUBMITTERS && *status == ZJ_OK; g++) {
+    int submitters = o.entropy ? GPU_SUBMITTERS_DEVICE_ENTROPY : GPU_SUBMITTERS;
+    if (const char* e = getenv("ZJ_POOL_SUBMITTERS")) { const int v = atoi(e); if (v >= 1 && v <= 64) submitters = v; }
+    for (int g = 0; g < submitters && *status == ZJ_OK; g++) {
         int st = ZJ_OK;
         zj_ctx* c = zj_ctx_create(ZJ_BACKEND_HIP, device, &st);
         if (!c) { *status = st ? st : ZJ_ERR_NOMEM; break; }
@@ -173,7 +180,7 @@ zj_pool* zj_pool_create(int device, int threads, const zj_options* opt, int* sta
         p->ctxs.push_back(c);
     }
     // plane sets: one per entropy worker plus what the submitters hold plus one in the queue each
-    for (int k = 0; k < threads + 2 * GPU_SUBMITTERS && *status == ZJ_OK; k++) {
+    for (int k = 0; k < threads + 2 * submitters && *status == ZJ_OK; k++) {
         zj_decoder* d = zj_decoder_new(&o);
         if (!d) { *status = ZJ_ERR_NOMEM; break; }
         p->decoders.push_back(d);
@@ -199,9 +206,25 @@ int zj_pool_stats(zj_pool* p, double* entropy_seconds, double* gpu_seconds, size
     return ZJ_OK;
 }
 
+static int pool_decode(zj_pool* p, size_t nfiles, const uint8_t* const* bufs, const size_t* lens, uint8_t* const* outs,
+                       const size_t* out_caps, size_t* out_lens, zj_image_info* infos, int* statuses, bool on_device);
+
 int zj_pool_decode_files(zj_pool* p, size_t nfiles, const uint8_t* const* bufs, const size_t* lens,
                          uint8_t* const* outs, const size_t* out_caps, size_t* out_lens, zj_image_info* infos,
                          int* statuses)
+{
+    return pool_decode(p, nfiles, bufs, lens, outs, out_caps, out_lens, infos, statuses, false);
+}
+
+int zj_pool_decode_files_device(zj_pool* p, size_t nfiles, const uint8_t* const* bufs, const size_t* lens,
+                                uint8_t* const* d_outs, const size_t* out_caps, size_t* out_lens, zj_image_info* infos,
+                                int* statuses)
+{
+    return pool_decode(p, nfiles, bufs, lens, d_outs, out_caps, out_lens, infos, statuses, true);
+}
+
+static int pool_decode(zj_pool* p, size_t nfiles, const uint8_t* const* bufs, const size_t* lens, uint8_t* const* outs,
+                       const size_t* out_caps, size_t* out_lens, zj_image_info* infos, int* statuses, bool on_device)
 {
     if (!p || (nfiles && (!bufs || !lens || !outs || !out_caps))) return ZJ_ERR_ARG;
     if (nfiles == 0) return ZJ_OK;
@@ -210,7 +233,7 @@ int zj_pool_decode_files(zj_pool* p, size_t nfiles, const uint8_t* const* bufs, 
     std::lock_guard<std::mutex> call(p->call_mu);
     zj_pool::Batch b;
     b.n = nfiles; b.bufs = bufs; b.lens = lens; b.outs = outs; b.caps = out_caps;
-    b.out_lens = out_lens; b.infos = infos; b.statuses = statuses;
+    b.out_lens = out_lens; b.infos = infos; b.statuses = statuses; b.on_device = on_device;
     std::unique_lock<std::mutex> lk(p->mu);
     p->batch = &b;
     p->cv.notify_all();

@@ -144,7 +144,7 @@ ABI = [  # every symbol include/zjhip.h declares
     "zj_time_decode_device", "zj_alloc_pinned", "zj_free_pinned", "zj_set_thread_device", "zj_device_alloc",
     "zj_device_free", "zj_memcpy_h2d", "zj_memcpy_d2h", "zj_sync", "zj_device_memset",
     "zj_decode_planes_to_device", "zj_decode_scan", "zj_scan_stats", "zj_decoder_prepare",
-    "zj_decoder_finish_pixels_device", "zj_decoder_scan_blob", "zj_decoder_gpu_status",
+    "zj_decoder_finish_pixels_device", "zj_decoder_scan_blob", "zj_decoder_gpu_status", "zj_pool_decode_files_device",
     "zj_decoder_new", "zj_decoder_free", "zj_decoder_error", "zj_decoder_read_headers",
     "zj_decoder_decode_coefficients", "zj_decoder_finish_pixels", "zj_decoder_decode_buffer",
     "zj_decoder_parallel_segments",
@@ -263,6 +263,7 @@ def lib():
     L.zj_pool_error.argtypes = [vp]
     L.zj_pool_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(sz)]
     L.zj_pool_decode_files.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp]
+    L.zj_pool_decode_files_device.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp]
     L.zj_set_pipeline.argtypes = [vp, C.c_int]
     L.zj_set_variant.argtypes = [vp, C.c_int]
     L.zj_set_ablation.argtypes = [vp, C.c_int]
@@ -676,6 +677,22 @@ class Pool:
         e, g, n = C.c_double(0), C.c_double(0), C.c_size_t(0)
         lib().zj_pool_stats(self._p, C.byref(e), C.byref(g), C.byref(n))
         return e.value, g.value, n.value
+
+    def decode_files_device(self, blobs, d_outs, caps, raise_on_error=True):
+        """blobs -> pixels left in HBM at the device pointers d_outs (capacities caps).  Returns (lengths, infos, statuses)."""
+        n = len(blobs)
+        arrs = [np.frombuffer(bytes(b), np.uint8) for b in blobs]
+        bufs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        lens = (C.c_size_t * n)(*[a.size for a in arrs])
+        optr = (C.c_void_p * n)(*d_outs)
+        capv = (C.c_size_t * n)(*caps)
+        olen = (C.c_size_t * n)()
+        infos = (ImageInfo * n)()
+        sts = (C.c_int * n)()
+        rc = lib().zj_pool_decode_files_device(self._p, n, bufs, lens, optr, capv, olen, infos, sts)
+        if rc and raise_on_error:
+            raise DecodeError(rc, lib().zj_pool_error(self._p).decode(errors="replace"))
+        return list(olen), list(infos), list(sts)
 
     def decode_files(self, blobs, outs=None, raise_on_error=True):
         """blobs: list of bytes-like JPEG files.  Returns (list of uint8 arrays, list of ImageInfo, statuses).
