@@ -95,20 +95,21 @@ def main():
     # files -> pixels that STAY in HBM (consumers on the GPU): T host threads, each with its own decoder, context and
     # device buffer (ctypes releases the GIL inside the library)
     import threading
-    dptr = [ctx.device_alloc(S * S * 3) for _ in range(8)]
+    NB = 32
+    dptr = [ctx.device_alloc(S * S * 3) for _ in range(NB)]
     for workers in (1, 4, 16):
         po = zj.ZuneJpegOptions()
         po.entropy = ENT
         with zj.Pool(threads=workers, options=po) as pool:
-            fl = [files[i % len(files)] for i in range(8)]
+            fl = [files[i % len(files)] for i in range(NB)]
             for _ in range(2):
-                pool.decode_files_device(fl, dptr, [S * S * 3] * 8)
+                pool.decode_files_device(fl, dptr, [S * S * 3] * NB)
             t0 = time.perf_counter()
-            reps = max(1, args.files // 8)
+            reps = max(2, args.files // NB)
             for _ in range(reps):
-                pool.decode_files_device(fl, dptr, [S * S * 3] * 8)
+                pool.decode_files_device(fl, dptr, [S * S * 3] * NB)
             dt = time.perf_counter() - t0
-            print(f"zj_pool into HBM, {workers:3d} workers: {8 * reps} files in {dt*1e3:8.1f} ms  {8*reps/dt:8.1f} files/s  {8*reps*mp/dt:9.1f} MP/s")
+            print(f"zj_pool into HBM, {workers:3d} workers: {NB * reps} files in {dt*1e3:8.1f} ms  {NB*reps/dt:8.1f} files/s  {NB*reps*mp/dt:9.1f} MP/s")
     for p in dptr:
         ctx.device_free(p)
     for T in (1, 2, 4, 8, 16):

@@ -336,6 +336,18 @@ int parse_dht(zj_decoder* d, Cursor& c)
     return ZJ_OK;
 }
 
+// host coefficient planes of the frame (pinned on request): for every scan the CPU decodes
+int ensure_planes(zj_decoder* d)
+{
+    for (int i = 0; i < d->ncomp; i++) {
+        Comp& cm = d->comps[i];
+        if (cm.coef) continue;
+        cm.coef = d->store[i].ensure(cm.coef_len * 2, d->pinned);
+        if (!cm.coef) return fail(d, ZJ_ERR_NOMEM, "out of memory for the coefficient planes");
+    }
+    return ZJ_OK;
+}
+
 int parse_sof(zj_decoder* d, Cursor& c, int progressive)
 {
     int len, prec, h, w, nc;
@@ -378,9 +390,9 @@ int parse_sof(zj_decoder* d, Cursor& c, int progressive)
         cm.bw = d->mcu_x * cm.h;
         cm.bh = d->mcu_y * cm.v;
         cm.coef_len = (size_t)cm.bw * cm.bh * 64;
-        cm.coef = d->store[i].ensure(cm.coef_len * 2, d->pinned);
-        if (!cm.coef) return fail(d, ZJ_ERR_NOMEM, "out of memory for the coefficient planes");
+        cm.coef = nullptr; // ensure_planes(): a scan that goes to the device entropy stage never needs host planes
     }
+    if (progressive) { const int rc = ensure_planes(d); if (rc) return rc; }
     // the entropy decoder only writes non-zero coefficients.  Progressive scans accumulate into the planes, so
     // they are cleared up front (in parallel when large); a baseline scan clears each block right before it
     // decodes into it (one pass over memory instead of two) and scan_baseline clears whatever it did not reach
@@ -1115,6 +1127,7 @@ int decode_all(zj_decoder* d, const uint8_t* buf, size_t len, bool headers_only,
             d->scans = 1; d->src = buf; d->src_len = len;
             return ZJ_OK;
         }
+        if ((rc = ensure_planes(d))) return rc;
         rc = scan_baseline(d, br);
         d->scans = 1;
         d->coef_valid = rc == ZJ_OK;
