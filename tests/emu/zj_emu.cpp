@@ -231,3 +231,4 @@ extern "C" int zje_huff_decode(const uint8_t* blob, int16_t* y, int16_t* cb, int
     return ZJ_OK;
 }
 
+

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from test_huff_emu import pil_jpeg
+from test_huff_emu import document_like, pil_jpeg
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -99,6 +99,19 @@ def test_more_rounds_than_planned(zj, ctx, monkeypatch):
     assert g.gpu_status() == 0
     assert np.array_equal(got, want)
     assert ctx.scan_stats()[0] > 1
+
+
+@pytest.mark.parametrize("kind", ["page", "page-gray", "mixed"])
+@pytest.mark.parametrize("mode", ["GPU", "GPU_ALWAYS"])
+def test_flat_areas_whatever_path_they_take(zj, ctx, kind, mode):
+    """Flat areas converge one sub-sequence per round (tests/test_huff_emu.py): the scan may stay on the CPU, crawl
+    through extra rounds or come back from the device -- the pixels are the same."""
+    data = document_like(1600, 1200, mixed=kind == "mixed", gray=kind == "page-gray")
+    o = zj.ZuneJpegOptions()
+    o.entropy = getattr(zj, "ENTROPY_" + mode)
+    g = zj.Decoder(o, ctx)
+    assert np.array_equal(g.decode_buffer(data), zj.Decoder(None, ctx).decode_buffer(data))
+    assert g.gpu_status() in (0, 32)
 
 
 def test_reference_file_with_the_eoi_cut(zj, ctx):

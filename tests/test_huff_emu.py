@@ -170,6 +170,38 @@ def test_damaged_scans_are_handed_back_or_equal(zj):
     assert kept and handed
 
 
+def document_like(w, h, mixed=False, gray=False, **kw):
+    """white page, a few bars; mixed: the lower half is noise"""
+    from PIL import Image
+    a = np.full((h, w, 3), 255, np.uint8)
+    a[h // 10:h // 10 + 30, w // 20:w - w // 20] = 0
+    a[h // 3:h // 3 + 50, w // 6:w - w // 4] = (200, 30, 30)
+    if mixed:
+        a[h // 2:] = np.random.default_rng(3).integers(0, 256, (h - h // 2, w, 3), dtype=np.uint8)
+    im = Image.fromarray(a)
+    if gray:
+        im = im.convert("L")
+    b = io.BytesIO()
+    im.save(b, "JPEG", quality=85, **kw)
+    return b.getvalue()
+
+
+def test_flat_pages_crawl_and_are_left_to_the_cpu(zj):
+    """A stream of identical tiny blocks is periodic: an out-of-step decoder settles into a cycle of its own, the true
+    state advances one sub-sequence per round.  Still exact when forced; the front-end keeps such scans (few bits per
+    block) on the CPU, where they are cheap."""
+    data = document_like(2048, 1536)
+    st, status = gpu_vs_cpu(zj, data, expect_status=None)
+    assert status in (0, 32) and st["rounds"] * 4 > st["nsub"], st  # busy images: ~10 rounds for thousands
+    o = zj.ZuneJpegOptions()
+    o.entropy = zj.ENTROPY_GPU
+    d = zj.Decoder(o)
+    d.prepare(document_like(2048, 1536))  # 40 KB of scan for 3 megapixels
+    assert d.scan_blob() is None
+    d.prepare(document_like(1024, 768, mixed=True))
+    assert d.scan_blob() is not None
+
+
 def test_shared_tables_are_left_to_the_cpu_unless_forced(zj, synth):
     planes = jpeg_enc.small_planes(64, 48, 2, 2, 3, seed=1)
     data = jpeg_enc.encode_baseline(planes, synth.quant_tables(85), 64, 48, 2, 2, 3)

@@ -596,7 +596,8 @@ int zj_decode_scan(zj_ctx* c, const zj_frame_desc* d, const void* blob, size_t b
     const uint32_t sub_bytes = h->sub_bytes >= 16 && h->sub_bytes <= (uint32_t)HUFF_SUB_MAX ? h->sub_bytes : (uint32_t)HUFF_SUB_MAX;
     int planned = (int)(1536 / sub_bytes) + 2;
     if (const char* e = getenv("ZJ_HUFF_ROUNDS")) { const int v = atoi(e); if (v >= 1) planned = v; }
-    if (planned > HUFF_MAX_ROUNDS) planned = HUFF_MAX_ROUNDS;
+    const int max_rounds = h->round_budget >= 1 && h->round_budget <= (uint32_t)HUFF_MAX_ROUNDS ? (int)h->round_budget : HUFF_MAX_ROUNDS;
+    if (planned > max_rounds) planned = max_rounds;
     uint8_t* d_out = out_on_device ? out : (uint8_t*)c->scratch[3];
     int round = 0;
     bool synced = false;
@@ -605,12 +606,12 @@ int zj_decode_scan(zj_ctx* c, const zj_frame_desc* d, const void* blob, size_t b
         if (pass == 0) {
             while (round < planned) { a.round = ++round; ZJ_HIP(c, launch_huff_sync(a, (uint32_t)nsub, s)); }
         } else {
-            if (round >= HUFF_MAX_ROUNDS) { c->huff_rounds = round; if (status_bits) *status_bits = HUFF_ST_NO_SYNC; return ZJ_RETRY_CPU; }
+            if (round >= max_rounds) { c->huff_rounds = round; if (status_bits) *status_bits = HUFF_ST_NO_SYNC; return ZJ_RETRY_CPU; }
             // (the planes may hold coefficients scattered from a wrong parse; the counters of the finish kernels restart)
             int group = 16;
-            while (!synced && round < HUFF_MAX_ROUNDS) {
+            while (!synced && round < max_rounds) {
                 const int first = round + 1;
-                for (int k = 0; k < group && round < HUFF_MAX_ROUNDS; k++) { a.round = ++round; ZJ_HIP(c, launch_huff_sync(a, (uint32_t)nsub, s)); }
+                for (int k = 0; k < group && round < max_rounds; k++) { a.round = ++round; ZJ_HIP(c, launch_huff_sync(a, (uint32_t)nsub, s)); }
                 ZJ_HIP(c, hipMemcpyAsync(c->h_ctl, a.ctl, ctl_words * 4, hipMemcpyDeviceToHost, s));
                 ZJ_HIP(c, hipStreamSynchronize(s));
                 for (int r = first; r <= round; r++)

@@ -66,6 +66,7 @@ struct HuffScan { // header of the blob; every off_* is a byte offset from the h
     uint32_t tab_entries;      // u16 entries of all decoding tables together (even)
     uint32_t off_tab, off_sub, off_seg, off_stream, stream_bytes; // stream_bytes: multiple of 16, >= 32 zero bytes at the end
     uint32_t sub_bytes;        // nominal sub-sequence size (the last one of a segment is shorter)
+    uint32_t round_budget;     // synchronisation rounds worth spending before the CPU walker is the faster way out
     uint32_t comp_of_blk;      // 2 bits per block of the MCU: its component
     uint16_t dc_off[4], ac_off[4]; // per component: entry offset of its decoding tables
     HuffBlk blk[HUFF_MAX_BPM];

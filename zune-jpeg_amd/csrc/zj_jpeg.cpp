@@ -1040,7 +1040,18 @@ int prepare_scan(zj_decoder* d, const uint8_t* p, const uint8_t* end)
         h.comp[i].h = (uint32_t)d->comps[i].h; h.comp[i].v = (uint32_t)d->comps[i].v;
         h.comp[i].bw = (uint32_t)d->comps[i].bw; h.comp[i].bh = (uint32_t)d->comps[i].bh;
     }
+    // Flat areas defeat self-synchronisation: a stream of identical tiny blocks is periodic, a decoder that starts out
+    // of step settles into a cycle of its own and stays there, so the true state only advances one sub-sequence per round
+    // (a scanned page with white margins: 260 rounds for 580 sub-sequences).  Such scans are also the ones the CPU
+    // walker is quickest with (few symbols per block), so they stay there: under 16 bits per block on average.  Mixed
+    // images pass this test and may still crawl; the round budget below is what the CPU walker would need instead.
+    const double blocks = (double)total * bpm;
+    if (d->entropy < 2 && (double)scan_bytes * 8.0 < 16.0 * blocks) return why(14);
     const size_t sub = (size_t)d->sub_bytes;
+    const double cpu_us = (double)scan_bytes * 0.008 + blocks * 0.05, round_us = 10.0 + 0.27 * (double)sub;
+    long long budget = d->entropy >= 2 ? HUFF_MAX_ROUNDS : (long long)(cpu_us / round_us);
+    if (budget < 16) budget = 16;
+    if (budget > HUFF_MAX_ROUNDS) budget = HUFF_MAX_ROUNDS;
     const size_t max_sub = scan_bytes / sub + (size_t)nseg + 1;
     auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t off_tab = up16(sizeof(HuffScan));
@@ -1086,6 +1097,7 @@ int prepare_scan(zj_decoder* d, const uint8_t* p, const uint8_t* end)
     h.mcu_x = (uint32_t)d->mcu_x; h.mcu_y = (uint32_t)d->mcu_y; h.total_mcus = (uint32_t)total;
     h.is_eoi = is_eoi ? 1 : 0;
     h.sub_bytes = (uint32_t)sub;
+    h.round_budget = (uint32_t)budget;
     h.rowlen = (uint32_t)eoi_rowlen(d);
     h.tab_entries = (uint32_t)tab_used;
     h.off_tab = (uint32_t)off_tab; h.off_sub = (uint32_t)off_sub; h.off_seg = (uint32_t)off_seg;
