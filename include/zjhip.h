@@ -200,9 +200,10 @@ int zj_decode_planes_to_device(zj_ctx *ctx, const zj_frame_desc *d, const int16_
  * *status_bits (optional) when the device hands the scan back. */
 int zj_decode_scan(zj_ctx *ctx, const zj_frame_desc *d, const void *blob, size_t blob_bytes, uint8_t *out,
                    int out_on_device, unsigned *status_bits);
-/* of the last zj_decode_scan on ctx: synchronisation rounds; with ZJ_HUFF_TIME set in the environment, milliseconds of
+/* of the last zj_decode_scan on ctx: synchronisation rounds; ms[3] = host milliseconds spent submitting (everything in
+ * front of the final synchronisation); with ZJ_HUFF_TIME set in the environment, ms[0..2] = device milliseconds of
  * upload + rounds | prefix sums + write pass | pixel kernel (+ download) */
-int zj_scan_stats(const zj_ctx *ctx, int *rounds, float ms[3]);
+int zj_scan_stats(const zj_ctx *ctx, int *rounds, float ms[4]);
 
 /* ---- whole decoder: the CPU front-end the path is fed by (container + Huffman on the host) ------
  * Mirrors Decoder / ZuneJpegOptions / ImageInfo (src/decoder.rs:60,178,452,652; src/options.rs:6-40):

@@ -44,4 +44,4 @@ for name, data in (("no restart markers", files_bench.make_jpeg(size, 0, restart
         rounds, ms = ms_best
         print(f"{size}x{size} {name} ({len(data) / 1e6:.2f} MB) sub {sub:3d}: same={same} status={g.gpu_status()} rounds={rounds} | "
               f"prepare {tp * 1e3:.2f} ms | device: upload+rounds {ms[0]:.3f} scan+write {ms[1]:.3f} pixels+download {ms[2]:.3f} ms | "
-              f"finish_pixels {best * 1e3:.2f} ms | CPU-entropy decode_buffer {tc * 1e3:.1f} ms", flush=True)
+              f"finish_pixels {best * 1e3:.2f} ms (host submission {ms[3]:.3f}) | CPU-entropy decode_buffer {tc * 1e3:.1f} ms", flush=True)

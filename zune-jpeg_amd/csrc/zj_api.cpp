@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <string>
@@ -52,6 +53,8 @@ struct zj_ctx {
     void* hplanes = nullptr; size_t hplanes_cap = 0;
     uint32_t* h_ctl = nullptr;    // pinned
     int huff_rounds = 0;          // synchronisation rounds of the last scan
+    int huff_recent = 0;          // the most rounds a scan of the last few needed (decays): how many to launch ahead
+    float huff_submit_ms = 0;     // host time of the last scan's submission (everything up to the final synchronisation)
     float huff_ms[3] = {0, 0, 0}; // with ZJ_HUFF_TIME: upload + sync rounds | scan + write + cut | pixel kernel (+ download) of the last scan
 };
 
@@ -582,6 +585,7 @@ int zj_decode_scan(zj_ctx* c, const zj_frame_desc* d, const void* blob, size_t b
     a.plane[2] = (int16_t*)((uint8_t*)c->hplanes + yb + cbytes);
     a.round = 0;
     const bool timing = getenv("ZJ_HUFF_TIME") != nullptr;
+    const auto t_submit0 = std::chrono::steady_clock::now();
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     if (timing) { for (auto& e : ev) ZJ_HIP(c, hipEventCreate(&e)); ZJ_HIP(c, hipEventRecord(ev[0], s)); }
     ZJ_HIP(c, hipMemcpyAsync(base, blob, blob_bytes, hipMemcpyHostToDevice, s));
@@ -595,6 +599,8 @@ int zj_decode_scan(zj_ctx* c, const zj_frame_desc* d, const void* blob, size_t b
     // last round still changed something: more rounds (looking after each group), then the rest again.
     const uint32_t sub_bytes = h->sub_bytes >= 16 && h->sub_bytes <= (uint32_t)HUFF_SUB_MAX ? h->sub_bytes : (uint32_t)HUFF_SUB_MAX;
     int planned = (int)(1536 / sub_bytes) + 2;
+    // files of one source need about the same number: two more than the recent maximum, never more than the default
+    if (c->huff_recent > 0 && c->huff_recent + 2 < planned) planned = c->huff_recent + 2;
     if (const char* e = getenv("ZJ_HUFF_ROUNDS")) { const int v = atoi(e); if (v >= 1) planned = v; }
     const int max_rounds = h->round_budget >= 1 && h->round_budget <= (uint32_t)HUFF_MAX_ROUNDS ? (int)h->round_budget : HUFF_MAX_ROUNDS;
     if (planned > max_rounds) planned = max_rounds;
@@ -631,6 +637,7 @@ int zj_decode_scan(zj_ctx* c, const zj_frame_desc* d, const void* blob, size_t b
         if (!out_on_device) ZJ_HIP(c, hipMemcpyAsync(out, d_out, pl.out_len, hipMemcpyDeviceToHost, s));
         ZJ_HIP(c, hipMemcpyAsync(c->h_ctl, a.ctl, ctl_words * 4, hipMemcpyDeviceToHost, s));
         if (timing && pass == 0) ZJ_HIP(c, hipEventRecord(ev[3], s));
+        if (pass == 0) c->huff_submit_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_submit0).count();
         ZJ_HIP(c, hipStreamSynchronize(s));
         for (int r = 1; r <= round; r++)
             if (c->h_ctl[HUFF_CTL_ROUND0 + r] == 0) { synced = true; c->huff_rounds = r; break; }
@@ -639,15 +646,17 @@ int zj_decode_scan(zj_ctx* c, const zj_frame_desc* d, const void* blob, size_t b
         for (int k = 0; k < 3; k++) ZJ_HIP(c, hipEventElapsedTime(&c->huff_ms[k], ev[k], ev[k + 1]));
         for (auto& e : ev) (void)hipEventDestroy(e);
     }
+    // (rounds in units of this scan's sub-sequence size; a context is normally fed one kind of file)
+    c->huff_recent = c->huff_rounds >= c->huff_recent ? c->huff_rounds : c->huff_recent - 1;
     if (status_bits) *status_bits = c->h_ctl[HUFF_CTL_STATUS];
     return c->h_ctl[HUFF_CTL_STATUS] ? ZJ_RETRY_CPU : ZJ_OK;
 }
 
-int zj_scan_stats(const zj_ctx* c, int* rounds, float ms[3])
+int zj_scan_stats(const zj_ctx* c, int* rounds, float ms[4])
 {
     if (!c) return ZJ_ERR_ARG;
     if (rounds) *rounds = c->huff_rounds;
-    if (ms) for (int k = 0; k < 3; k++) ms[k] = c->huff_ms[k];
+    if (ms) { for (int k = 0; k < 3; k++) ms[k] = c->huff_ms[k]; ms[3] = c->huff_submit_ms; }
     return ZJ_OK;
 }
 

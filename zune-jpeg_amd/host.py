@@ -472,10 +472,11 @@ class Context:
         _check(lib().zj_sync(self._h), "zj_sync", self._h)
 
     def scan_stats(self):
-        """(synchronisation rounds, [ms upload + rounds, ms prefix sums + write pass, ms pixel kernel + download]) of the
-        last scan the GPU entropy stage decoded on this context; the times need ZJ_HUFF_TIME in the environment."""
+        """(synchronisation rounds, [ms upload + rounds, ms prefix sums + write pass, ms pixel kernel + download, host ms
+        spent submitting]) of the last scan the GPU entropy stage decoded on this context; the device times need
+        ZJ_HUFF_TIME in the environment."""
         r = C.c_int(0)
-        ms = (C.c_float * 3)()
+        ms = (C.c_float * 4)()
         _check(lib().zj_scan_stats(self._h, C.byref(r), ms), "zj_scan_stats", self._h)
         return r.value, [float(x) for x in ms]
 
