@@ -200,6 +200,9 @@ int zj_decode_planes_to_device(zj_ctx *ctx, const zj_frame_desc *d, const int16_
  * *status_bits (optional) when the device hands the scan back. */
 int zj_decode_scan(zj_ctx *ctx, const zj_frame_desc *d, const void *blob, size_t blob_bytes, uint8_t *out,
                    int out_on_device, unsigned *status_bits);
+/* diagnostics: the coefficient planes the last zj_decode_scan on ctx left in HBM, copied to host buffers of zj_plane_len
+ * elements each (NULL: skipped); len[3] (optional) receives the lengths */
+int zj_scan_planes(zj_ctx *ctx, int16_t *y, int16_t *cb, int16_t *cr, size_t len[3]);
 /* of the last zj_decode_scan on ctx: synchronisation rounds; ms[3] = host milliseconds spent submitting (everything in
  * front of the final synchronisation); with ZJ_HUFF_TIME set in the environment, ms[0..2] = device milliseconds of
  * upload + rounds | prefix sums + write pass | pixel kernel (+ download) */

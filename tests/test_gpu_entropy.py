@@ -73,9 +73,26 @@ def test_output_colorspaces(zj, ctx, cs):
     assert g.gpu_status() == 0
 
 
+@pytest.mark.parametrize("mode", ["none", "h", "v", "hv"])
+@pytest.mark.parametrize("restart", [0, 5])
+def test_planes_on_the_device_equal_the_encoder_s_coefficients(zj, ctx, synth, mode, restart):
+    """Ground truth that owes nothing to the CPU walker: tools/jpeg_enc.py writes exactly the planes it is given."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import jpeg_enc
+    hs, vs = {"none": (1, 1), "h": (2, 1), "v": (1, 2), "hv": (2, 2)}[mode]
+    w, h = 120, 88
+    planes = jpeg_enc.small_planes(w, h, hs, vs, 3, seed=w + hs + vs)
+    data = jpeg_enc.encode_baseline(planes, synth.quant_tables(85), w, h, hs, vs, 3, restart=restart)
+    g, _ = decoders(zj, ctx, sub=64)
+    desc, _ = g.prepare(data)
+    out, rc, st = ctx.decode_scan(desc, g.scan_blob())
+    assert rc == 0 and st == 0
+    for c, p in enumerate(ctx.scan_planes()):
+        assert np.array_equal(p, planes[c]), (mode, restart, c)
+
+
 def test_planes_on_the_device_equal_the_cpu_walker(zj, ctx):
-    """zj_decode_scan with YCbCr output at quality 100 is a weak view of the planes; compare the pixels of every
-    colourspace instead, and the prepared scan through the low-level entry."""
     data = pil_jpeg(1024, 768, quality=93, seed=8)
     g, c = decoders(zj, ctx)
     desc, info = g.prepare(data)
@@ -84,6 +101,9 @@ def test_planes_on_the_device_equal_the_cpu_walker(zj, ctx):
     out, rc, st = ctx.decode_scan(desc, blob)
     assert rc == 0 and st == 0
     assert np.array_equal(out, c.decode_buffer(data))
+    _, want, _ = zj.Decoder().decode_coefficients(data)
+    for a, b in zip(ctx.scan_planes(), want):
+        assert np.array_equal(a, b)
     rounds, _ = ctx.scan_stats()
     assert 1 <= rounds <= 32
 

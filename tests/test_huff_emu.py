@@ -25,7 +25,7 @@ def zj():
     return importlib.import_module("zune-jpeg_amd")
 
 
-def gpu_vs_cpu(zj, data, sub=None, expect_status=0):
+def gpu_vs_cpu(zj, data, sub=None, expect_status=0, truth=None):
     """prepare + emulate; returns (stats, status).  Asserts equal planes when the device keeps the scan."""
     old = os.environ.get("ZJ_HUFF_SUB")
     if sub:
@@ -50,6 +50,9 @@ def gpu_vs_cpu(zj, data, sub=None, expect_status=0):
     if status == 0:
         for c, (a, b) in enumerate(zip(got, want)):
             assert np.array_equal(a, b), (c, st, np.nonzero(a != b)[0][:8])
+        if truth is not None:  # the encoder's coefficients: ground truth that owes nothing to the CPU walker
+            for c, (a, b) in enumerate(zip(got, truth)):
+                assert np.array_equal(a, b), (c, st)
     return st, status
 
 
@@ -83,7 +86,7 @@ def test_encoder_round_trip(zj, synth, mode, wh, restart):
         st, status = gpu_vs_cpu(zj, data, sub=128, expect_status=None)
         assert status in (0, 32)
         return
-    st, _ = gpu_vs_cpu(zj, data, sub=64 if restart == 0 else 16)
+    st, _ = gpu_vs_cpu(zj, data, sub=64 if restart == 0 else 16, truth=planes)
     assert st["nsub"] > 1
 
 

@@ -53,6 +53,7 @@ struct zj_ctx {
     void* hplanes = nullptr; size_t hplanes_cap = 0;
     uint32_t* h_ctl = nullptr;    // pinned
     int huff_rounds = 0;          // synchronisation rounds of the last scan
+    size_t huff_plane_off[3] = {0, 0, 0}, huff_plane_len[3] = {0, 0, 0}; // the last scan's planes inside hplanes (bytes / int16 elements)
     int huff_recent = 0;          // the most rounds a scan of the last few needed (decays): how many to launch ahead
     float huff_submit_ms = 0;     // host time of the last scan's submission (everything up to the final synchronisation)
     float huff_ms[3] = {0, 0, 0}; // with ZJ_HUFF_TIME: upload + sync rounds | scan + write + cut | pixel kernel (+ download) of the last scan
@@ -584,6 +585,8 @@ int zj_decode_scan(zj_ctx* c, const zj_frame_desc* d, const void* blob, size_t b
     a.plane[1] = (int16_t*)((uint8_t*)c->hplanes + yb);
     a.plane[2] = (int16_t*)((uint8_t*)c->hplanes + yb + cbytes);
     a.round = 0;
+    c->huff_plane_off[0] = 0; c->huff_plane_off[1] = yb; c->huff_plane_off[2] = yb + cbytes;
+    c->huff_plane_len[0] = ylen; c->huff_plane_len[1] = c->huff_plane_len[2] = clen;
     const bool timing = getenv("ZJ_HUFF_TIME") != nullptr;
     const auto t_submit0 = std::chrono::steady_clock::now();
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -650,6 +653,20 @@ int zj_decode_scan(zj_ctx* c, const zj_frame_desc* d, const void* blob, size_t b
     c->huff_recent = c->huff_rounds >= c->huff_recent ? c->huff_rounds : c->huff_recent - 1;
     if (status_bits) *status_bits = c->h_ctl[HUFF_CTL_STATUS];
     return c->h_ctl[HUFF_CTL_STATUS] ? ZJ_RETRY_CPU : ZJ_OK;
+}
+
+int zj_scan_planes(zj_ctx* c, int16_t* y, int16_t* cb, int16_t* cr, size_t len[3])
+{
+    if (!c || !c->hplanes || !c->huff_plane_len[0]) return ZJ_ERR_ARG;
+    ZJ_HIP(c, hipSetDevice(c->device));
+    int16_t* dst[3] = {y, cb, cr};
+    for (int k = 0; k < 3; k++) {
+        if (len) len[k] = c->huff_plane_len[k];
+        if (dst[k] && c->huff_plane_len[k])
+            ZJ_HIP(c, hipMemcpyAsync(dst[k], (const uint8_t*)c->hplanes + c->huff_plane_off[k], c->huff_plane_len[k] * 2, hipMemcpyDeviceToHost, c->stream));
+    }
+    ZJ_HIP(c, hipStreamSynchronize(c->stream));
+    return ZJ_OK;
 }
 
 int zj_scan_stats(const zj_ctx* c, int* rounds, float ms[4])

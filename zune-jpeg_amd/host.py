@@ -143,7 +143,7 @@ ABI = [  # every symbol include/zjhip.h declares
     "zj_num_components", "zj_decode_planes", "zj_decode_planes_batch", "zj_decode_planes_device",
     "zj_time_decode_device", "zj_alloc_pinned", "zj_free_pinned", "zj_set_thread_device", "zj_device_alloc",
     "zj_device_free", "zj_memcpy_h2d", "zj_memcpy_d2h", "zj_sync", "zj_device_memset",
-    "zj_decode_planes_to_device", "zj_decode_scan", "zj_scan_stats", "zj_decoder_prepare",
+    "zj_decode_planes_to_device", "zj_decode_scan", "zj_scan_stats", "zj_scan_planes", "zj_decoder_prepare",
     "zj_decoder_finish_pixels_device", "zj_decoder_scan_blob", "zj_decoder_gpu_status", "zj_pool_decode_files_device",
     "zj_decoder_new", "zj_decoder_free", "zj_decoder_error", "zj_decoder_read_headers",
     "zj_decoder_decode_coefficients", "zj_decoder_finish_pixels", "zj_decoder_decode_buffer",
@@ -254,6 +254,7 @@ def lib():
     L.zj_decode_scan.argtypes = [vp, C.POINTER(FrameDesc), vp, sz, vp, C.c_int, C.POINTER(C.c_uint)]
     L.zj_decode_planes_to_device.argtypes = [vp, C.POINTER(FrameDesc), i16p, i16p, i16p, vp]
     L.zj_scan_stats.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_float)]
+    L.zj_scan_planes.argtypes = [vp, vp, vp, vp, C.POINTER(sz)]
     L.zj_device_memset.argtypes = [vp, vp, C.c_int, sz]
     L.zj_pool_create.restype = vp
     L.zj_pool_create.argtypes = [C.c_int, C.c_int, C.POINTER(Options), C.POINTER(C.c_int)]
@@ -479,6 +480,15 @@ class Context:
         ms = (C.c_float * 4)()
         _check(lib().zj_scan_stats(self._h, C.byref(r), ms), "zj_scan_stats", self._h)
         return r.value, [float(x) for x in ms]
+
+    def scan_planes(self):
+        """The coefficient planes the last decode_scan / device-entropy decode on this context left in HBM (copies)."""
+        lens = (C.c_size_t * 3)()
+        _check(lib().zj_scan_planes(self._h, None, None, None, lens), "zj_scan_planes", self._h)
+        planes = [np.zeros(max(int(n), 1), np.int16) for n in lens]
+        _check(lib().zj_scan_planes(self._h, _ptr(planes[0]), _ptr(planes[1]) if lens[1] else None,
+                                    _ptr(planes[2]) if lens[2] else None, lens), "zj_scan_planes", self._h)
+        return [p[: int(n)] for p, n in zip(planes, lens) if n]
 
     def decode_scan(self, desc, blob, out=None, device_out=None):
         """zj_decode_scan: a prepared scan -> pixels (host array, or a device pointer with device_out).  Returns
