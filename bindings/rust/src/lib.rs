@@ -110,6 +110,12 @@ extern "C" {
                                     out_len: *mut usize) -> c_int;
     pub fn zj_decoder_finish_pixels_device(d: *mut zj_decoder, ctx: *mut zj_ctx, d_out: *mut u8, out_cap: usize,
                                            out_len: *mut usize) -> c_int;
+    pub fn zj_decode_scans(ctx: *mut zj_ctx, n: usize, descs: *const zj_frame_desc, blobs: *const *const c_void,
+                           blob_bytes: *const usize, outs: *const *mut u8, outs_on_device: c_int, rcs: *mut c_int,
+                           status_bits: *mut u32) -> c_int;
+    pub fn zj_decoder_finish_pixels_batch(ds: *const *mut zj_decoder, n: usize, ctx: *mut zj_ctx, outs: *const *mut u8,
+                                          out_caps: *const usize, out_lens: *mut usize, outs_on_device: c_int,
+                                          rcs: *mut c_int) -> c_int;
     pub fn zj_decode_scan(ctx: *mut zj_ctx, d: *const zj_frame_desc, blob: *const c_void, blob_bytes: usize,
                           out: *mut u8, out_on_device: c_int, status_bits: *mut u32) -> c_int;
     pub fn zj_decoder_decode_buffer(d: *mut zj_decoder, ctx: *mut zj_ctx, buf: *const u8, len: usize, out: *mut u8,

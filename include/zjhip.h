@@ -200,6 +200,12 @@ int zj_decode_planes_to_device(zj_ctx *ctx, const zj_frame_desc *d, const int16_
  * *status_bits (optional) when the device hands the scan back. */
 int zj_decode_scan(zj_ctx *ctx, const zj_frame_desc *d, const void *blob, size_t blob_bytes, uint8_t *out,
                    int out_on_device, unsigned *status_bits);
+/* The same for up to ZJ_SCAN_BATCH_MAX prepared scans of any geometry at once: every phase of the entropy stage is ONE
+ * launch over all of them (a single file leaves most of the GPU idle), then a pixel kernel each.  rcs[k] = ZJ_OK,
+ * ZJ_RETRY_CPU or a zj_status of scan k; status_bits[k] optional.  The return value reports failures of the call itself. */
+#define ZJ_SCAN_BATCH_MAX 16
+int zj_decode_scans(zj_ctx *ctx, size_t n, const zj_frame_desc *descs, const void *const *blobs, const size_t *blob_bytes,
+                    uint8_t *const *outs, int outs_on_device, int *rcs, unsigned *status_bits);
 /* diagnostics: the coefficient planes the last zj_decode_scan on ctx left in HBM, copied to host buffers of zj_plane_len
  * elements each (NULL: skipped); len[3] (optional) receives the lengths */
 int zj_scan_planes(zj_ctx *ctx, int16_t *y, int16_t *cb, int16_t *cr, size_t len[3]);
@@ -255,6 +261,10 @@ int zj_decoder_prepare(zj_decoder *d, const uint8_t *buf, size_t len, zj_frame_d
 int zj_decoder_finish_pixels(zj_decoder *d, zj_ctx *ctx, uint8_t *out, size_t out_cap, size_t *out_len);
 /* the same with the pixels left in HBM (d_out: device pointer on ctx's device, 16-byte aligned) for consumers on the GPU */
 int zj_decoder_finish_pixels_device(zj_decoder *d, zj_ctx *ctx, uint8_t *d_out, size_t out_cap, size_t *out_len);
+/* stage 2 of n decoders on one context: the scans left for the device are decoded together (zj_decode_scans), the rest
+ * one by one; rcs[k] is what zj_decoder_finish_pixels[_device] would have returned for decoder k */
+int zj_decoder_finish_pixels_batch(zj_decoder *const *ds, size_t n, zj_ctx *ctx, uint8_t *const *outs,
+                                   const size_t *out_caps, size_t *out_lens /*[n] or NULL*/, int outs_on_device, int *rcs);
 /* diagnostics: the prepared scan of the last zj_decoder_prepare (ZJ_ERR_ARG: none); the status bits (csrc/zj_huff.h
  * HUFF_ST_*) with which the device handed the last scan back to the CPU (0: it did not) */
 int zj_decoder_scan_blob(const zj_decoder *d, const void **blob, size_t *len);

@@ -232,3 +232,10 @@ extern "C" int zje_huff_decode(const uint8_t* blob, int16_t* y, int16_t* cb, int
 }
 
 
+
+// int16 elements of component c's plane as the scan's header states them
+extern "C" size_t zje_huff_plane_len(const uint8_t* blob, int c)
+{
+    const HuffScan* g = huff_hdr(blob);
+    return c >= 0 && c < (int)g->ncomp ? (size_t)g->comp[c].bw * g->comp[c].bh * 64 : 0;
+}

@@ -17,6 +17,7 @@ size_t zj_out_len(const zj_frame_desc* d)
 int zj_decode_planes(zj_ctx*, const zj_frame_desc*, const int16_t*, const int16_t*, const int16_t*, uint8_t*) { return ZJ_ERR_NO_DEVICE; }
 int zj_decode_planes_to_device(zj_ctx*, const zj_frame_desc*, const int16_t*, const int16_t*, const int16_t*, uint8_t*) { return ZJ_ERR_NO_DEVICE; }
 int zj_decode_scan(zj_ctx*, const zj_frame_desc*, const void*, size_t, uint8_t*, int, unsigned*) { return ZJ_ERR_NO_DEVICE; }
+int zj_decode_scans(zj_ctx*, size_t, const zj_frame_desc*, const void* const*, const size_t*, uint8_t* const*, int, int*, unsigned*) { return ZJ_ERR_NO_DEVICE; }
 int zj_device_memset(zj_ctx*, void*, int, size_t) { return ZJ_ERR_NO_DEVICE; }
 const char* zj_strerror(int) { return "stub"; }
 const char* zj_last_error(const zj_ctx*) { return ""; }

@@ -220,3 +220,52 @@ def test_pool_leaves_pixels_in_hbm(zj, ctx):
     finally:
         for p in ptrs:
             ctx.device_free(p)
+
+
+def test_batch_of_scans_in_one_go(zj, ctx):
+    """zj_decoder_finish_pixels_batch: device scans of different geometry together (one launch per phase), a progressive
+    file and a damaged one (handed back) among them; every result equals the file's own decode."""
+    from PIL import Image
+    import io
+    files = [pil_jpeg(400 + 40 * k, 300 + 8 * k, quality=70 + 3 * k, seed=40 + k, subsampling=k % 3) for k in range(9)]
+    files.append(pil_jpeg(320, 240, quality=80, gray=True, seed=3))
+    b = io.BytesIO()
+    Image.fromarray(np.random.default_rng(5).integers(0, 256, (200, 300, 3), dtype=np.uint8)).save(b, "JPEG", quality=80, progressive=True)
+    files.append(b.getvalue())
+    bad = bytearray(files[2])
+    bad[len(bad) // 2] ^= 0x55
+    files.append(bytes(bad))
+    want = []
+    for f in files:
+        try:
+            want.append(zj.Decoder(None, ctx).decode_buffer(f))
+        except zj.DecodeError as e:
+            want.append(e.status)
+    decs = []
+    for f in files:
+        o = zj.ZuneJpegOptions()
+        o.entropy = zj.ENTROPY_GPU_ALWAYS
+        d = zj.Decoder(o, ctx)
+        d.prepare(f)
+        decs.append(d)
+    outs, rcs = zj.finish_pixels_batch(decs, ctx)
+    for k, (o, rc, w) in enumerate(zip(outs, rcs, want)):
+        if isinstance(w, int):
+            assert rc == w, k
+        else:
+            assert rc == 0 and np.array_equal(o, w), k
+    # and with the pixels left in HBM
+    ptrs = [(ctx.device_alloc(o.size + 64), o.size) for o in outs]
+    try:
+        for d, f in zip(decs, files):
+            d.prepare(f)
+        lens, rcs = zj.finish_pixels_batch(decs, ctx, device_ptrs=ptrs)
+        for k, (p, w) in enumerate(zip(ptrs, want)):
+            if isinstance(w, int):
+                continue
+            got = np.zeros(w.size, np.uint8)
+            ctx.d2h(got, p[0])
+            assert rcs[k] == 0 and lens[k] == w.size and np.array_equal(got, w), k
+    finally:
+        for p, _ in ptrs:
+            ctx.device_free(p)

@@ -56,6 +56,8 @@ def main():
     L.zj_decoder_scan_blob.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     E = C.CDLL(EMU)
     E.zje_huff_decode.argtypes = [C.c_void_p] * 6
+    E.zje_huff_plane_len.restype = C.c_size_t
+    E.zje_huff_plane_len.argtypes = [C.c_void_p, C.c_int]
 
     class Opt(C.Structure):
         _fields_ = [(n, C.c_int32) for n in ("out_colorspace", "strict_mode", "max_width", "max_height", "max_scans", "num_threads", "pinned_planes", "flags", "out_layout", "entropy")]
@@ -106,8 +108,7 @@ def main():
                 st = C.c_uint32(0)
                 # planes of exactly the size the scan's header states (HuffScan.comp[i].bw * bh * 64, zj_huff.h), so
                 # that a store past a plane is a heap overflow the sanitizer sees
-                hdr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(46,))
-                planes = [np.zeros(max(64, int(hdr[34 + 4 * c + 2]) * int(hdr[34 + 4 * c + 3]) * 64), np.int16) for c in range(3)]
+                planes = [np.zeros(max(64, int(E.zje_huff_plane_len(p, c))), np.int16) for c in range(3)]
                 E.zje_huff_decode(p, planes[0].ctypes.data, planes[1].ctypes.data, planes[2].ctypes.data, C.byref(st), None)
                 emu_runs += 1
                 emu_kept += st.value == 0

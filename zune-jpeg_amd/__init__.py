@@ -11,5 +11,5 @@ from .host import (  # noqa: F401
     BACKEND_AVX2, BACKEND_HIP, BACKEND_SCALAR, FLAG_CLAMP_DC, FLAG_CORRECTED, FLAG_EDGE_REPLICATE, FLAG_PLAIN_TAIL, LAYOUT_CHW, LAYOUT_HWC, ColorSpace, Component, Context, DecodeError, Decoder, FrameDesc,
     ENTROPY_CPU, ENTROPY_GPU, ENTROPY_GPU_ALWAYS, HUFF_ST, RETRY_CPU, ImageInfo, Pool, ZjError,
     ZuneJpegOptions, abi_symbols, choose_idct_func, choose_upsample_func,
-    choose_ycbcr_to_rgb_convert_func, device_count, lib, lib_path, num_components,
+    choose_ycbcr_to_rgb_convert_func, device_count, finish_pixels_batch, lib, lib_path, num_components,
 )

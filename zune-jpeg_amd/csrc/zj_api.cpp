@@ -49,11 +49,15 @@ struct zj_ctx {
     int debug = 0;                // ablation switches, diagnostics only (results are WRONG when set)
     int variant = 0;              // kernel variant: 0 packed generation (default), 1 wide generation (round 1), 2 packed with direct stores
     // GPU entropy stage (zj_decode_scan): blob + working set, the three planes (contiguous), control words read back
-    void* hbuf = nullptr; size_t hbuf_cap = 0;
-    void* hplanes = nullptr; size_t hplanes_cap = 0;
-    uint32_t* h_ctl = nullptr;    // pinned
+    // one slot per scan of a batch (zj_decode_scans): blob + working set | planes | pixels on their way to host memory
+    struct HuffSlot { void* buf = nullptr; size_t cap = 0; void* planes = nullptr; size_t pcap = 0; void* out = nullptr; size_t ocap = 0; };
+    HuffSlot hslot[ZJ_SCAN_BATCH_MAX];
+    uint32_t* h_ctl = nullptr;    // pinned: HUFF_CTL_WORDS per slot
+    HuffArgs* h_args = nullptr;   // pinned staging of the kernels' argument array
+    HuffArgs* d_args = nullptr;
     int huff_rounds = 0;          // synchronisation rounds of the last scan
-    size_t huff_plane_off[3] = {0, 0, 0}, huff_plane_len[3] = {0, 0, 0}; // the last scan's planes inside hplanes (bytes / int16 elements)
+    int huff_plane_slot = 0;
+    size_t huff_plane_off[3] = {0, 0, 0}, huff_plane_len[3] = {0, 0, 0}; // the last call's first scan: its planes inside the slot (bytes / int16 elements)
     int huff_recent = 0;          // the most rounds a scan of the last few needed (decays): how many to launch ahead
     float huff_submit_ms = 0;     // host time of the last scan's submission (everything up to the final synchronisation)
     float huff_ms[3] = {0, 0, 0}; // with ZJ_HUFF_TIME: upload + sync rounds | scan + write + cut | pixel kernel (+ download) of the last scan
@@ -165,9 +169,14 @@ void zj_ctx_destroy(zj_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < N_SCRATCH; i++)
         if (c->scratch[i]) (void)hipFree(c->scratch[i]);
-    if (c->hbuf) (void)hipFree(c->hbuf);
-    if (c->hplanes) (void)hipFree(c->hplanes);
+    for (auto& sl : c->hslot) {
+        if (sl.buf) (void)hipFree(sl.buf);
+        if (sl.planes) (void)hipFree(sl.planes);
+        if (sl.out) (void)hipFree(sl.out);
+    }
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+    if (c->h_args) (void)hipHostFree(c->h_args);
+    if (c->d_args) (void)hipFree(c->d_args);
     for (hipStream_t st : {c->s_up, c->s_run, c->s_down})
         if (st) (void)hipStreamSynchronize(st);
     for (PipeSlot& sl : c->slots) {
@@ -542,36 +551,53 @@ static int ensure_buf(zj_ctx* c, void** p, size_t* cap, size_t bytes)
     return ZJ_OK;
 }
 
-int zj_decode_scan(zj_ctx* c, const zj_frame_desc* d, const void* blob, size_t blob_bytes, uint8_t* out, int out_on_device,
-                   unsigned* status_bits)
+namespace {
+struct ScanJob {
+    const zj_frame_desc* d = nullptr;
+    const HuffScan* h = nullptr;
+    const void* blob = nullptr;
+    size_t blob_bytes = 0, nsub = 0, yb = 0, cbytes = 0, ylen = 0, clen = 0;
+    bool chroma = false;
+    Plan pl;
+    HuffArgs a;            // device pointers of the slot
+    uint8_t* out = nullptr;    // the caller's
+    uint8_t* d_out = nullptr;  // where the pixel kernel writes
+    uint32_t* h_ctl = nullptr; // this slot's control words on the host
+    int slot = 0, max_rounds = 0, planned = 0, rounds = 0;
+    int rc = ZJ_OK;        // ZJ_OK while the job is alive
+    bool synced = false;
+};
+size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// validates one scan, sizes its slot, fills the working-set pointers
+int scan_setup(zj_ctx* c, ScanJob& j, int slot, const zj_frame_desc* d, const void* blob, size_t blob_bytes, uint8_t* out, int out_on_device)
 {
-    if (status_bits) *status_bits = 0;
-    if (!c || !d || !blob || !out || blob_bytes < sizeof(HuffScan)) return ZJ_ERR_ARG;
+    if (!d || !blob || !out || blob_bytes < sizeof(HuffScan)) return ZJ_ERR_ARG;
     const HuffScan* h = (const HuffScan*)blob;
     if (h->magic != HUFF_MAGIC || h->blob_bytes != blob_bytes || h->nsub == 0 || h->ncomp != d->in_components) return ZJ_ERR_ARG;
-    Plan pl;
-    int rc = make_plan(d, pl);
+    int rc = make_plan(d, j.pl);
     if (rc) return rc;
-    const bool chroma = h->ncomp == 3;
-    const size_t ylen = zj_plane_len(d, 0), clen = chroma ? zj_plane_len(d, 1) : 0;
-    if (ylen != (size_t)h->comp[0].bw * h->comp[0].bh * 64) return ZJ_ERR_ARG;
-    if (chroma && (clen != (size_t)h->comp[1].bw * h->comp[1].bh * 64 || clen != (size_t)h->comp[2].bw * h->comp[2].bh * 64)) return ZJ_ERR_ARG;
+    j.d = d; j.h = h; j.blob = blob; j.blob_bytes = blob_bytes; j.out = out; j.slot = slot;
+    j.chroma = h->ncomp == 3;
+    j.ylen = zj_plane_len(d, 0);
+    j.clen = j.chroma ? zj_plane_len(d, 1) : 0;
+    if (j.ylen != (size_t)h->comp[0].bw * h->comp[0].bh * 64) return ZJ_ERR_ARG;
+    if (j.chroma && (j.clen != (size_t)h->comp[1].bw * h->comp[1].bh * 64 || j.clen != (size_t)h->comp[2].bw * h->comp[2].bh * 64)) return ZJ_ERR_ARG;
     if (out_on_device && ((uintptr_t)out & 15)) return ZJ_ERR_ARG;
-    ZJ_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    const size_t nsub = h->nsub;
-    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t o_exit = up(blob_bytes), o_aux = o_exit + up(nsub * 8), o_base = o_aux + up(nsub * 16),
-                 o_chg = o_base + up(nsub * 16), o_rel = o_chg + up(nsub * 2), o_ctl = o_rel + up(nsub), ctl_words = HUFF_CTL_WORDS,
-                 nscan = (nsub + HUFF_SCAN_WG - 1) / HUFF_SCAN_WG, o_agg = o_ctl + up(ctl_words * 4),
-                 o_pre = o_agg + up(nscan * sizeof(HuffAgg)), total = o_pre + up(nscan * sizeof(HuffAgg));
-    if ((rc = ensure_buf(c, &c->hbuf, &c->hbuf_cap, total))) return rc;
-    const size_t yb = up(ylen * 2), cbytes = up(clen * 2);
-    if ((rc = ensure_buf(c, &c->hplanes, &c->hplanes_cap, yb + 2 * cbytes))) return rc;
-    if (!c->h_ctl) ZJ_HIP(c, hipHostMalloc((void**)&c->h_ctl, ctl_words * 4, hipHostMallocPortable));
-    if (!out_on_device && (rc = ensure_scratch(c, 3, pl.out_len))) return rc;
-    uint8_t* base = (uint8_t*)c->hbuf;
-    HuffArgs a;
+    j.nsub = h->nsub;
+    const size_t nsub = j.nsub, nscan = (nsub + HUFF_SCAN_WG - 1) / HUFF_SCAN_WG;
+    const size_t o_exit = up256(blob_bytes), o_aux = o_exit + up256(nsub * 8), o_base = o_aux + up256(nsub * 16),
+                 o_chg = o_base + up256(nsub * 16), o_rel = o_chg + up256(nsub * 2), o_ctl = o_rel + up256(nsub),
+                 o_agg = o_ctl + up256((size_t)HUFF_CTL_WORDS * 4), o_pre = o_agg + up256(nscan * sizeof(HuffAgg)),
+                 total = o_pre + up256(nscan * sizeof(HuffAgg));
+    zj_ctx::HuffSlot& sl = c->hslot[slot];
+    if ((rc = ensure_buf(c, &sl.buf, &sl.cap, total))) return rc;
+    j.yb = up256(j.ylen * 2);
+    j.cbytes = up256(j.clen * 2);
+    if ((rc = ensure_buf(c, &sl.planes, &sl.pcap, j.yb + 2 * j.cbytes))) return rc;
+    if (!out_on_device && (rc = ensure_buf(c, &sl.out, &sl.ocap, j.pl.out_len))) return rc;
+    uint8_t* base = (uint8_t*)sl.buf;
+    HuffArgs& a = j.a;
     a.blob = base;
     a.exit = (unsigned long long*)(base + o_exit);
     a.aux = (HuffI4*)(base + o_aux);
@@ -581,89 +607,166 @@ int zj_decode_scan(zj_ctx* c, const zj_frame_desc* d, const void* blob, size_t b
     a.ctl = (uint32_t*)(base + o_ctl);
     a.wgagg = (HuffAgg*)(base + o_agg);
     a.wgpre = (HuffAgg*)(base + o_pre);
-    a.plane[0] = (int16_t*)c->hplanes;
-    a.plane[1] = (int16_t*)((uint8_t*)c->hplanes + yb);
-    a.plane[2] = (int16_t*)((uint8_t*)c->hplanes + yb + cbytes);
+    a.plane[0] = (int16_t*)sl.planes;
+    a.plane[1] = (int16_t*)((uint8_t*)sl.planes + j.yb);
+    a.plane[2] = (int16_t*)((uint8_t*)sl.planes + j.yb + j.cbytes);
     a.round = 0;
-    c->huff_plane_off[0] = 0; c->huff_plane_off[1] = yb; c->huff_plane_off[2] = yb + cbytes;
-    c->huff_plane_len[0] = ylen; c->huff_plane_len[1] = c->huff_plane_len[2] = clen;
+    j.d_out = out_on_device ? out : (uint8_t*)sl.out;
+    j.h_ctl = c->h_ctl + (size_t)slot * HUFF_CTL_WORDS;
+    const uint32_t sub_bytes = h->sub_bytes >= 16 && h->sub_bytes <= (uint32_t)HUFF_SUB_MAX ? h->sub_bytes : (uint32_t)HUFF_SUB_MAX;
+    j.max_rounds = h->round_budget >= 1 && h->round_budget <= (uint32_t)HUFF_MAX_ROUNDS ? (int)h->round_budget : HUFF_MAX_ROUNDS;
+    // Rounds launched ahead: a wrong guess falls into step within ~1 KB of 4:2:0 data, i.e. after 1024 / sub_bytes
+    // rounds; files of one source need about the same number: two more than the context's recent maximum
+    j.planned = (int)(1536 / sub_bytes) + 2;
+    if (c->huff_recent > 0 && c->huff_recent + 2 < j.planned) j.planned = c->huff_recent + 2;
+    if (const char* e = getenv("ZJ_HUFF_ROUNDS")) { const int v = atoi(e); if (v >= 1) j.planned = v; }
+    if (j.planned > j.max_rounds) j.planned = j.max_rounds;
+    return ZJ_OK;
+}
+
+int scan_clear(zj_ctx* c, ScanJob& j, hipStream_t s, bool all_ctl)
+{
+    ZJ_HIP(c, hipMemsetAsync(j.a.ctl, 0, (all_ctl ? (size_t)HUFF_CTL_WORDS : (size_t)HUFF_CTL_ROUND0) * 4, s));
+    ZJ_HIP(c, hipMemsetAsync(j.a.ctl + HUFF_CTL_SEEN, 0xff, 4, s));
+    ZJ_HIP(c, hipMemsetAsync(c->hslot[j.slot].planes, 0, j.yb + 2 * j.cbytes, s)); // the write pass stores non-zero coefficients only
+    return ZJ_OK;
+}
+
+// pixel kernel over the slot's planes, the pixels and the control words on their way back
+int scan_pixels(zj_ctx* c, ScanJob& j, hipStream_t s, int out_on_device)
+{
+    int rc = decode_device_impl(c, j.d, j.pl, 1, j.a.plane[0], j.chroma ? j.a.plane[1] : nullptr, j.chroma ? j.a.plane[2] : nullptr, j.d_out, s, 1);
+    if (rc) return rc;
+    if (!out_on_device) ZJ_HIP(c, hipMemcpyAsync(j.out, j.d_out, j.pl.out_len, hipMemcpyDeviceToHost, s));
+    ZJ_HIP(c, hipMemcpyAsync(j.h_ctl, j.a.ctl, (size_t)HUFF_CTL_WORDS * 4, hipMemcpyDeviceToHost, s));
+    return ZJ_OK;
+}
+
+bool scan_check(ScanJob& j, int launched)
+{
+    for (int r = 1; r <= launched; r++)
+        if (j.h_ctl[HUFF_CTL_ROUND0 + r] == 0) { j.synced = true; j.rounds = r; return true; }
+    j.rounds = launched;
+    return false;
+}
+} // namespace
+
+// The scans of up to ZJ_SCAN_BATCH_MAX files as ONE launch per phase (blockIdx.y = file): a file's entropy kernels are
+// latency-bound at under half a wave per SIMD, several at once cost hardly more than one.
+//   Synchronisation rounds are launched ahead and turn into no-ops once one of them changed nothing; a look at the
+// counters costs a stream synchronisation, so it happens once, after the pixels.  A scan whose last planned round still
+// changed something gets more rounds on its own (looking after each group), has what its premature write pass
+// scattered cleared, and runs the rest again.
+int zj_decode_scans(zj_ctx* c, size_t n, const zj_frame_desc* descs, const void* const* blobs, const size_t* blob_bytes,
+                    uint8_t* const* outs, int outs_on_device, int* rcs, unsigned* status_bits)
+{
+    if (!c || !n || n > (size_t)ZJ_SCAN_BATCH_MAX || !descs || !blobs || !blob_bytes || !outs || !rcs) return ZJ_ERR_ARG;
+    ZJ_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    if (!c->h_ctl) ZJ_HIP(c, hipHostMalloc((void**)&c->h_ctl, (size_t)ZJ_SCAN_BATCH_MAX * HUFF_CTL_WORDS * 4, hipHostMallocPortable));
+    if (!c->h_args) ZJ_HIP(c, hipHostMalloc((void**)&c->h_args, (size_t)ZJ_SCAN_BATCH_MAX * sizeof(HuffArgs), hipHostMallocPortable));
+    if (!c->d_args) ZJ_HIP(c, hipMalloc((void**)&c->d_args, (size_t)ZJ_SCAN_BATCH_MAX * sizeof(HuffArgs)));
     const bool timing = getenv("ZJ_HUFF_TIME") != nullptr;
     const auto t_submit0 = std::chrono::steady_clock::now();
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     if (timing) { for (auto& e : ev) ZJ_HIP(c, hipEventCreate(&e)); ZJ_HIP(c, hipEventRecord(ev[0], s)); }
-    ZJ_HIP(c, hipMemcpyAsync(base, blob, blob_bytes, hipMemcpyHostToDevice, s));
-    ZJ_HIP(c, hipMemsetAsync(a.ctl, 0, ctl_words * 4, s));
-    ZJ_HIP(c, hipMemsetAsync(a.ctl + HUFF_CTL_SEEN, 0xff, 4, s));
-    ZJ_HIP(c, hipMemsetAsync(c->hplanes, 0, yb + 2 * cbytes, s)); // the write pass stores non-zero coefficients only
-    // Synchronisation rounds.  A wrong guess of a sub-sequence's entry state falls into step with the true parse
-    // within ~1 KB of 4:2:0 data, i.e. after 1024 / sub_bytes rounds; rounds are cheap to launch and no-ops once one
-    // of them changed nothing, a look at the counters costs a stream synchronisation.  So: launch what is normally
-    // enough, go on with the prefix sums, the write pass and the pixel kernel, and look once at the end.  Only if the
-    // last round still changed something: more rounds (looking after each group), then the rest again.
-    const uint32_t sub_bytes = h->sub_bytes >= 16 && h->sub_bytes <= (uint32_t)HUFF_SUB_MAX ? h->sub_bytes : (uint32_t)HUFF_SUB_MAX;
-    int planned = (int)(1536 / sub_bytes) + 2;
-    // files of one source need about the same number: two more than the recent maximum, never more than the default
-    if (c->huff_recent > 0 && c->huff_recent + 2 < planned) planned = c->huff_recent + 2;
-    if (const char* e = getenv("ZJ_HUFF_ROUNDS")) { const int v = atoi(e); if (v >= 1) planned = v; }
-    const int max_rounds = h->round_budget >= 1 && h->round_budget <= (uint32_t)HUFF_MAX_ROUNDS ? (int)h->round_budget : HUFF_MAX_ROUNDS;
-    if (planned > max_rounds) planned = max_rounds;
-    uint8_t* d_out = out_on_device ? out : (uint8_t*)c->scratch[3];
-    int round = 0;
-    bool synced = false;
-    ZJ_HIP(c, launch_huff_sync(a, (uint32_t)nsub, s));
-    for (int pass = 0; !synced; pass++) {
-        if (pass == 0) {
-            while (round < planned) { a.round = ++round; ZJ_HIP(c, launch_huff_sync(a, (uint32_t)nsub, s)); }
-        } else {
-            if (round >= max_rounds) { c->huff_rounds = round; if (status_bits) *status_bits = HUFF_ST_NO_SYNC; return ZJ_RETRY_CPU; }
-            // (the planes may hold coefficients scattered from a wrong parse; the counters of the finish kernels restart)
-            int group = 16;
-            while (!synced && round < max_rounds) {
-                const int first = round + 1;
-                for (int k = 0; k < group && round < max_rounds; k++) { a.round = ++round; ZJ_HIP(c, launch_huff_sync(a, (uint32_t)nsub, s)); }
-                ZJ_HIP(c, hipMemcpyAsync(c->h_ctl, a.ctl, ctl_words * 4, hipMemcpyDeviceToHost, s));
-                ZJ_HIP(c, hipStreamSynchronize(s));
-                for (int r = first; r <= round; r++)
-                    if (c->h_ctl[HUFF_CTL_ROUND0 + r] == 0) { synced = true; break; }
-                group *= 2;
-            }
-            if (!synced) continue; // -> NO_SYNC above
-            ZJ_HIP(c, hipMemsetAsync(a.ctl, 0, HUFF_CTL_ROUND0 * 4, s));
-            ZJ_HIP(c, hipMemsetAsync(a.ctl + HUFF_CTL_SEEN, 0xff, 4, s));
-            ZJ_HIP(c, hipMemsetAsync(c->hplanes, 0, yb + 2 * cbytes, s));
-        }
-        if (timing && pass == 0) ZJ_HIP(c, hipEventRecord(ev[1], s));
-        ZJ_HIP(c, launch_huff_finish(a, (uint32_t)nsub, s));
-        if (timing && pass == 0) ZJ_HIP(c, hipEventRecord(ev[2], s));
-        rc = decode_device_impl(c, d, pl, 1, a.plane[0], chroma ? a.plane[1] : nullptr, chroma ? a.plane[2] : nullptr, d_out, s, 1);
-        if (rc) return rc;
-        if (!out_on_device) ZJ_HIP(c, hipMemcpyAsync(out, d_out, pl.out_len, hipMemcpyDeviceToHost, s));
-        ZJ_HIP(c, hipMemcpyAsync(c->h_ctl, a.ctl, ctl_words * 4, hipMemcpyDeviceToHost, s));
-        if (timing && pass == 0) ZJ_HIP(c, hipEventRecord(ev[3], s));
-        if (pass == 0) c->huff_submit_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_submit0).count();
-        ZJ_HIP(c, hipStreamSynchronize(s));
-        for (int r = 1; r <= round; r++)
-            if (c->h_ctl[HUFF_CTL_ROUND0 + r] == 0) { synced = true; c->huff_rounds = r; break; }
+    std::vector<ScanJob> jobs(n);
+    int live[ZJ_SCAN_BATCH_MAX], nlive = 0; // jobs that passed validation, packed: the kernels' argument array
+    uint32_t max_nsub = 0;
+    int planned = 1;
+    for (size_t k = 0; k < n; k++) {
+        if (status_bits) status_bits[k] = 0;
+        rcs[k] = jobs[k].rc = scan_setup(c, jobs[k], (int)k, &descs[k], blobs[k], blob_bytes[k], outs[k], outs_on_device);
+        if (jobs[k].rc) continue;
+        live[nlive] = (int)k;
+        c->h_args[nlive++] = jobs[k].a;
+        if (jobs[k].nsub > max_nsub) max_nsub = (uint32_t)jobs[k].nsub;
+        if (jobs[k].planned > planned) planned = jobs[k].planned;
     }
+    if (!nlive) return ZJ_OK;
+    ZJ_HIP(c, hipMemcpyAsync(c->d_args, c->h_args, (size_t)nlive * sizeof(HuffArgs), hipMemcpyHostToDevice, s));
+    for (int q = 0; q < nlive; q++) {
+        ScanJob& j = jobs[(size_t)live[q]];
+        ZJ_HIP(c, hipMemcpyAsync((void*)j.a.blob, j.blob, j.blob_bytes, hipMemcpyHostToDevice, s));
+        int rc = scan_clear(c, j, s, true);
+        if (rc) return rc;
+    }
+    for (int round = 0; round <= planned; round++) ZJ_HIP(c, launch_huff_sync(c->d_args, nlive, max_nsub, round, s));
+    if (timing) ZJ_HIP(c, hipEventRecord(ev[1], s));
+    ZJ_HIP(c, launch_huff_finish(c->d_args, nlive, max_nsub, s));
+    if (timing) ZJ_HIP(c, hipEventRecord(ev[2], s));
+    for (int q = 0; q < nlive; q++) {
+        int rc = scan_pixels(c, jobs[(size_t)live[q]], s, outs_on_device);
+        if (rc) return rc;
+    }
+    if (timing) ZJ_HIP(c, hipEventRecord(ev[3], s));
+    c->huff_submit_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_submit0).count();
+    ZJ_HIP(c, hipStreamSynchronize(s));
     if (timing) {
         for (int k = 0; k < 3; k++) ZJ_HIP(c, hipEventElapsedTime(&c->huff_ms[k], ev[k], ev[k + 1]));
         for (auto& e : ev) (void)hipEventDestroy(e);
     }
-    // (rounds in units of this scan's sub-sequence size; a context is normally fed one kind of file)
-    c->huff_recent = c->huff_rounds >= c->huff_recent ? c->huff_rounds : c->huff_recent - 1;
-    if (status_bits) *status_bits = c->h_ctl[HUFF_CTL_STATUS];
-    return c->h_ctl[HUFF_CTL_STATUS] ? ZJ_RETRY_CPU : ZJ_OK;
+    int most = 0;
+    for (int q = 0; q < nlive; q++) {
+        ScanJob& j = jobs[(size_t)live[q]];
+        if (!scan_check(j, planned)) {
+            // the slow way, this scan alone: its working set is entry q of the argument array
+            int round = planned, group = 16;
+            while (!j.synced && round < j.max_rounds) {
+                const int first = round + 1;
+                for (int k = 0; k < group && round < j.max_rounds; k++) ZJ_HIP(c, launch_huff_sync(c->d_args + q, 1, (uint32_t)j.nsub, ++round, s));
+                ZJ_HIP(c, hipMemcpyAsync(j.h_ctl, j.a.ctl, (size_t)HUFF_CTL_WORDS * 4, hipMemcpyDeviceToHost, s));
+                ZJ_HIP(c, hipStreamSynchronize(s));
+                for (int r = first; r <= round; r++)
+                    if (j.h_ctl[HUFF_CTL_ROUND0 + r] == 0) { j.synced = true; j.rounds = r; break; }
+                group *= 2;
+            }
+            if (!j.synced) { // the CPU walker is the faster way out
+                j.rounds = round;
+                rcs[live[q]] = ZJ_RETRY_CPU;
+                if (status_bits) status_bits[live[q]] = HUFF_ST_NO_SYNC;
+                if (j.rounds > most) most = j.rounds;
+                continue;
+            }
+            int rc = scan_clear(c, j, s, false); // (the planes may hold coefficients scattered from a wrong parse)
+            if (rc) return rc;
+            ZJ_HIP(c, launch_huff_finish(c->d_args + q, 1, (uint32_t)j.nsub, s));
+            if ((rc = scan_pixels(c, j, s, outs_on_device))) return rc;
+            ZJ_HIP(c, hipStreamSynchronize(s));
+        }
+        if (j.rounds > most) most = j.rounds;
+        if (status_bits) status_bits[live[q]] = j.h_ctl[HUFF_CTL_STATUS];
+        rcs[live[q]] = j.h_ctl[HUFF_CTL_STATUS] ? ZJ_RETRY_CPU : ZJ_OK;
+    }
+    c->huff_rounds = most;
+    // (rounds in units of the scans' sub-sequence size; a context is normally fed one kind of file)
+    c->huff_recent = most >= c->huff_recent ? most : c->huff_recent - 1;
+    const ScanJob& j0 = jobs[(size_t)live[0]]; // zj_scan_planes looks at the first scan of the last call
+    c->huff_plane_slot = j0.slot;
+    c->huff_plane_off[0] = 0; c->huff_plane_off[1] = j0.yb; c->huff_plane_off[2] = j0.yb + j0.cbytes;
+    c->huff_plane_len[0] = j0.ylen; c->huff_plane_len[1] = c->huff_plane_len[2] = j0.clen;
+    return ZJ_OK;
+}
+
+int zj_decode_scan(zj_ctx* c, const zj_frame_desc* d, const void* blob, size_t blob_bytes, uint8_t* out, int out_on_device,
+                   unsigned* status_bits)
+{
+    if (status_bits) *status_bits = 0;
+    if (!c || !d) return ZJ_ERR_ARG;
+    int rc1 = ZJ_OK;
+    const int rc = zj_decode_scans(c, 1, d, &blob, &blob_bytes, &out, out_on_device, &rc1, status_bits);
+    return rc ? rc : rc1;
 }
 
 int zj_scan_planes(zj_ctx* c, int16_t* y, int16_t* cb, int16_t* cr, size_t len[3])
 {
-    if (!c || !c->hplanes || !c->huff_plane_len[0]) return ZJ_ERR_ARG;
+    if (!c || !c->hslot[c->huff_plane_slot].planes || !c->huff_plane_len[0]) return ZJ_ERR_ARG;
     ZJ_HIP(c, hipSetDevice(c->device));
     int16_t* dst[3] = {y, cb, cr};
     for (int k = 0; k < 3; k++) {
         if (len) len[k] = c->huff_plane_len[k];
         if (dst[k] && c->huff_plane_len[k])
-            ZJ_HIP(c, hipMemcpyAsync(dst[k], (const uint8_t*)c->hplanes + c->huff_plane_off[k], c->huff_plane_len[k] * 2, hipMemcpyDeviceToHost, c->stream));
+            ZJ_HIP(c, hipMemcpyAsync(dst[k], (const uint8_t*)c->hslot[c->huff_plane_slot].planes + c->huff_plane_off[k], c->huff_plane_len[k] * 2, hipMemcpyDeviceToHost, c->stream));
     }
     ZJ_HIP(c, hipStreamSynchronize(c->stream));
     return ZJ_OK;

@@ -9,12 +9,17 @@
 
 namespace zj {
 
-__global__ __launch_bounds__(HUFF_WG) void zj_huff_sync_kernel(HuffArgs a)
+// Every kernel takes the working sets of a BATCH of scans (blockIdx.y picks one): the scans of several files run as one
+// launch each, sized for the largest; workgroups past a scan's end leave at once.
+__global__ __launch_bounds__(HUFF_WG) void zj_huff_sync_kernel(const HuffArgs* args, int round)
 {
     __shared__ HuffLds L;
+    HuffArgs a = args[blockIdx.y];
+    a.round = round;
     const uint32_t i = blockIdx.x * HUFF_WG + threadIdx.x;
     const HuffScan* g = huff_hdr(a.blob);
     const uint32_t nsub = g->nsub;
+    if (blockIdx.x * HUFF_WG >= nsub) return;
     // the rounds are launched ahead of any look at their outcome: once a round changed nothing, the rest are no-ops
     // (they leave the flags alone: the rounds after them return here as well)
     if (a.round >= 2 && a.ctl[HUFF_CTL_ROUND0 + a.round - 1] == 0) return;
@@ -28,19 +33,24 @@ __global__ __launch_bounds__(HUFF_WG) void zj_huff_sync_kernel(HuffArgs a)
     huff_sync_thread(a, L, i);
 }
 
-__global__ __launch_bounds__(HUFF_WG) void zj_huff_write_kernel(HuffArgs a)
+__global__ __launch_bounds__(HUFF_WG) void zj_huff_write_kernel(const HuffArgs* args)
 {
     __shared__ HuffLds L;
+    const HuffArgs a = args[blockIdx.y];
+    if (blockIdx.x * HUFF_WG >= huff_hdr(a.blob)->nsub) return;
     huff_stage<HUFF_WG>(a.blob, (int)blockIdx.x, (int)threadIdx.x, true, L);
     __syncthreads();
     huff_write_thread(a, L, blockIdx.x * HUFF_WG + threadIdx.x);
 }
 
-__global__ __launch_bounds__(HUFF_SCAN_WG) void zj_huff_scan_kernel(HuffArgs a)
+__global__ __launch_bounds__(HUFF_SCAN_WG) void zj_huff_scan_kernel(const HuffArgs* args)
 {
     // Hillis-Steele over the workgroup's 1024 elements, double-buffered in LDS
     __shared__ HuffAgg buf[2][HUFF_SCAN_WG];
     __shared__ uint32_t ticket;
+    const HuffArgs a = args[blockIdx.y];
+    const uint32_t nwg = (huff_hdr(a.blob)->nsub + HUFF_SCAN_WG - 1) / HUFF_SCAN_WG; // of THIS scan
+    if (blockIdx.x >= nwg) return;
     const uint32_t t = threadIdx.x, i = blockIdx.x * HUFF_SCAN_WG + t;
     buf[0][t] = huff_scan_element(a, i);
     __syncthreads();
@@ -59,29 +69,30 @@ __global__ __launch_bounds__(HUFF_SCAN_WG) void zj_huff_scan_kernel(HuffArgs a)
         ticket = atomicAdd(&a.ctl[HUFF_CTL_TICKET], 1u);
     }
     __syncthreads();
-    if (ticket == gridDim.x - 1 && t == 0) { // the last workgroup to finish: every total is visible
+    if (ticket == nwg - 1 && t == 0) { // the last workgroup to finish: every total is visible
         __threadfence();
-        huff_scan_totals(a, gridDim.x);
+        huff_scan_totals(a, nwg);
     }
 }
 
-__global__ __launch_bounds__(256) void zj_huff_cut_kernel(HuffArgs a)
+__global__ __launch_bounds__(256) void zj_huff_cut_kernel(const HuffArgs* args)
 {
+    const HuffArgs a = args[blockIdx.y];
     uint32_t first = 0;
     const uint32_t pieces = huff_cut_plan(a, &first);
     for (uint32_t p = threadIdx.x; p < pieces; p += 256) huff_cut_clear(a, first, p);
 }
 
-hipError_t launch_huff_sync(const HuffArgs& a, uint32_t nsub, hipStream_t s)
+hipError_t launch_huff_sync(const HuffArgs* d_args, int njobs, uint32_t max_nsub, int round, hipStream_t s)
 {
-    hipLaunchKernelGGL(zj_huff_sync_kernel, dim3((nsub + HUFF_WG - 1) / HUFF_WG), dim3(HUFF_WG), 0, s, a);
+    hipLaunchKernelGGL(zj_huff_sync_kernel, dim3((max_nsub + HUFF_WG - 1) / HUFF_WG, njobs), dim3(HUFF_WG), 0, s, d_args, round);
     return hipGetLastError();
 }
-hipError_t launch_huff_finish(const HuffArgs& a, uint32_t nsub, hipStream_t s)
+hipError_t launch_huff_finish(const HuffArgs* d_args, int njobs, uint32_t max_nsub, hipStream_t s)
 {
-    hipLaunchKernelGGL(zj_huff_scan_kernel, dim3((nsub + HUFF_SCAN_WG - 1) / HUFF_SCAN_WG), dim3(HUFF_SCAN_WG), 0, s, a);
-    hipLaunchKernelGGL(zj_huff_write_kernel, dim3((nsub + HUFF_WG - 1) / HUFF_WG), dim3(HUFF_WG), 0, s, a);
-    hipLaunchKernelGGL(zj_huff_cut_kernel, dim3(1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(zj_huff_scan_kernel, dim3((max_nsub + HUFF_SCAN_WG - 1) / HUFF_SCAN_WG, njobs), dim3(HUFF_SCAN_WG), 0, s, d_args);
+    hipLaunchKernelGGL(zj_huff_write_kernel, dim3((max_nsub + HUFF_WG - 1) / HUFF_WG, njobs), dim3(HUFF_WG), 0, s, d_args);
+    hipLaunchKernelGGL(zj_huff_cut_kernel, dim3(1, njobs), dim3(256), 0, s, d_args);
     return hipGetLastError();
 }
 

@@ -1310,6 +1310,55 @@ int zj_decoder_finish_pixels(zj_decoder* d, zj_ctx* ctx, uint8_t* out, size_t ou
     return finish_impl(d, ctx, out, out_cap, out_len, 0);
 }
 
+// Stage 2 of several decoders on one context.  Those whose zj_decoder_prepare left a scan for the device go through
+// zj_decode_scans together (one launch per phase for all of them); what the device hands back, and every decoder that
+// holds CPU-decoded planes, is finished one by one.
+int zj_decoder_finish_pixels_batch(zj_decoder* const* ds, size_t n, zj_ctx* ctx, uint8_t* const* outs, const size_t* out_caps,
+                                   size_t* out_lens, int outs_on_device, int* rcs)
+{
+    if (!ds || !n || !ctx || !outs || !out_caps || !rcs) return ZJ_ERR_ARG;
+    std::vector<char> done(n, 0);
+    for (size_t base = 0; base < n;) {
+        // the next chunk of device scans
+        size_t idx[ZJ_SCAN_BATCH_MAX], m = 0, k = base;
+        zj_frame_desc fds[ZJ_SCAN_BATCH_MAX];
+        const void* blobs[ZJ_SCAN_BATCH_MAX];
+        size_t lens[ZJ_SCAN_BATCH_MAX];
+        uint8_t* o[ZJ_SCAN_BATCH_MAX];
+        for (; k < n && m < (size_t)ZJ_SCAN_BATCH_MAX; k++) {
+            zj_decoder* d = ds[k];
+            if (!d || !outs[k] || !d->seen_sof || d->err_code || !d->scan_ready) continue;
+            fill_info(d, nullptr, &fds[m]);
+            if (fds[m].in_components == 1 && fds[m].out_colorspace != ZJ_CS_GRAYSCALE) continue; // all-zero output: finish_impl
+            const size_t need = zj_out_len(&fds[m]);
+            if (out_caps[k] < need) continue;                                                      // finish_impl reports it
+            if (out_lens) out_lens[k] = need;
+            blobs[m] = d->blob_store.p; lens[m] = d->blob_len; o[m] = outs[k]; idx[m++] = k;
+        }
+        base = k;
+        if (m < 2) continue; // a single scan: finish_impl below does the same
+        int sub_rc[ZJ_SCAN_BATCH_MAX];
+        unsigned st[ZJ_SCAN_BATCH_MAX];
+        const int rc = zj_decode_scans(ctx, m, fds, blobs, lens, o, outs_on_device, sub_rc, st);
+        if (rc) continue; // the call itself failed: one by one below, where the error gets its text
+        for (size_t q = 0; q < m; q++) {
+            zj_decoder* d = ds[idx[q]];
+            d->gpu_status = st[q];
+            if (sub_rc[q] == ZJ_OK) { rcs[idx[q]] = ZJ_OK; done[idx[q]] = 1; }
+            else if (sub_rc[q] == ZJ_RETRY_CPU) {
+                // the CPU walker decodes the file; finish_impl then sees planes, not a scan
+                const uint8_t* src = d->src;
+                const size_t src_len = d->src_len;
+                const int rc2 = decode_all(d, src, src_len, false, false);
+                if (rc2) { rcs[idx[q]] = rc2; done[idx[q]] = 1; }
+            }
+        }
+    }
+    for (size_t k = 0; k < n; k++)
+        if (!done[k]) rcs[k] = ds[k] ? finish_impl(ds[k], ctx, outs[k], out_caps[k], out_lens ? &out_lens[k] : nullptr, outs_on_device) : (int)ZJ_ERR_ARG;
+    return ZJ_OK;
+}
+
 int zj_decoder_finish_pixels_device(zj_decoder* d, zj_ctx* ctx, uint8_t* d_out, size_t out_cap, size_t* out_len)
 {
     return finish_impl(d, ctx, d_out, out_cap, out_len, 1);

@@ -71,6 +71,7 @@ struct zj_pool {
     std::string last_error;
     int n_workers = 0;
     int device = 0;                      // every thread of the pool binds to it
+    int device_batch = 4;                // files a submitter takes at once when the pixels stay on the device (ZJ_POOL_BATCH)
     // accumulated over the pool's life (under mu): seconds inside the entropy stage / the GPU stage, files
     double entropy_s = 0, gpu_s = 0;
     size_t files_done = 0;
@@ -129,22 +130,37 @@ struct zj_pool {
         for (;;) {
             cv_ready.wait(lk, [&] { return stop || (!ready.empty() && (index < GPU_SUBMITTERS || (batch && batch->on_device))); });
             if (stop) return;
-            const Job j = ready.front();
-            ready.pop_front();
             Batch& b = *batch;
+            // Pixels that stay on the device: take what is ready, up to a batch -- the device entropy stage runs the scans of
+            // several files as one launch per phase (zj_decode_scans).  Host outputs: one file at a time, the 48 MB
+            // downloads of three submitters are what fills PCIe.
+            Job jobs[ZJ_SCAN_BATCH_MAX];
+            size_t nj = 0;
+            const size_t want = b.on_device ? (size_t)device_batch : 1;
+            while (nj < want && !ready.empty()) { jobs[nj++] = ready.front(); ready.pop_front(); }
             lk.unlock();
-            size_t olen = 0;
+            zj_decoder* decs[ZJ_SCAN_BATCH_MAX];
+            uint8_t* outs[ZJ_SCAN_BATCH_MAX];
+            size_t caps[ZJ_SCAN_BATCH_MAX], olens[ZJ_SCAN_BATCH_MAX];
+            int rcs[ZJ_SCAN_BATCH_MAX];
+            for (size_t q = 0; q < nj; q++) { decs[q] = jobs[q].dec; outs[q] = b.outs[jobs[q].index]; caps[q] = b.caps[jobs[q].index]; olens[q] = 0; rcs[q] = 0; }
             const double t0 = now();
-            const int rc = b.on_device ? zj_decoder_finish_pixels_device(j.dec, ctx, b.outs[j.index], b.caps[j.index], &olen)
-                                       : zj_decoder_finish_pixels(j.dec, ctx, b.outs[j.index], b.caps[j.index], &olen);
+            if (nj == 1) rcs[0] = b.on_device ? zj_decoder_finish_pixels_device(decs[0], ctx, outs[0], caps[0], &olens[0])
+                                              : zj_decoder_finish_pixels(decs[0], ctx, outs[0], caps[0], &olens[0]);
+            else {
+                const int rc = zj_decoder_finish_pixels_batch(decs, nj, ctx, outs, caps, olens, b.on_device ? 1 : 0, rcs);
+                if (rc) for (size_t q = 0; q < nj; q++) rcs[q] = rc;
+            }
             const double dt = now() - t0;
             lk.lock();
             gpu_s += dt;
-            files_done++;
-            finish(b, j.index, rc, rc ? zj_decoder_error(j.dec) : nullptr, olen, nullptr);
-            free_dec.push_back(j.dec);
+            files_done += nj;
+            for (size_t q = 0; q < nj; q++) {
+                finish(b, jobs[q].index, rcs[q], rcs[q] ? zj_decoder_error(jobs[q].dec) : nullptr, olens[q], nullptr);
+                free_dec.push_back(jobs[q].dec);
+            }
             if (b.done == b.n) cv_done.notify_all();
-            cv_work.notify_one();
+            if (nj > 1) cv_work.notify_all(); else cv_work.notify_one();
         }
     }
 };
@@ -181,6 +197,7 @@ zj_pool* zj_pool_create(int device, int threads, const zj_options* opt, int* sta
     p->n_workers = threads;
     p->device = device;
     *status = ZJ_OK;
+    if (const char* e = getenv("ZJ_POOL_BATCH")) { const int v = atoi(e); if (v >= 1 && v <= ZJ_SCAN_BATCH_MAX) p->device_batch = v; }
     int submitters = o.entropy ? GPU_SUBMITTERS_DEVICE_ENTROPY : GPU_SUBMITTERS;
     if (const char* e = getenv("ZJ_POOL_SUBMITTERS")) { const int v = atoi(e); if (v >= 1 && v <= 64) submitters = v; }
     for (int g = 0; g < submitters && *status == ZJ_OK; g++) {
@@ -191,7 +208,8 @@ zj_pool* zj_pool_create(int device, int threads, const zj_options* opt, int* sta
         p->ctxs.push_back(c);
     }
     // plane sets: one per entropy worker plus what the submitters hold plus one in the queue each
-    for (int k = 0; k < threads + 2 * submitters && *status == ZJ_OK; k++) {
+    // (with the device entropy stage a plane set is a few MB of prepared scan, and a submitter may hold a batch of them)
+    for (int k = 0; k < threads + (o.entropy ? submitters * p->device_batch : 2 * submitters) && *status == ZJ_OK; k++) {
         zj_decoder* d = zj_decoder_new(&o);
         if (!d) { *status = ZJ_ERR_NOMEM; break; }
         p->decoders.push_back(d);

@@ -143,7 +143,7 @@ ABI = [  # every symbol include/zjhip.h declares
     "zj_num_components", "zj_decode_planes", "zj_decode_planes_batch", "zj_decode_planes_device",
     "zj_time_decode_device", "zj_alloc_pinned", "zj_free_pinned", "zj_set_thread_device", "zj_device_alloc",
     "zj_device_free", "zj_memcpy_h2d", "zj_memcpy_d2h", "zj_sync", "zj_device_memset",
-    "zj_decode_planes_to_device", "zj_decode_scan", "zj_scan_stats", "zj_scan_planes", "zj_decoder_prepare",
+    "zj_decode_planes_to_device", "zj_decode_scan", "zj_decode_scans", "zj_decoder_finish_pixels_batch", "zj_scan_stats", "zj_scan_planes", "zj_decoder_prepare",
     "zj_decoder_finish_pixels_device", "zj_decoder_scan_blob", "zj_decoder_gpu_status", "zj_pool_decode_files_device",
     "zj_decoder_new", "zj_decoder_free", "zj_decoder_error", "zj_decoder_read_headers",
     "zj_decoder_decode_coefficients", "zj_decoder_finish_pixels", "zj_decoder_decode_buffer",
@@ -255,6 +255,8 @@ def lib():
     L.zj_decode_planes_to_device.argtypes = [vp, C.POINTER(FrameDesc), i16p, i16p, i16p, vp]
     L.zj_scan_stats.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_float)]
     L.zj_scan_planes.argtypes = [vp, vp, vp, vp, C.POINTER(sz)]
+    L.zj_decode_scans.argtypes = [vp, sz, vp, vp, vp, vp, C.c_int, vp, vp]
+    L.zj_decoder_finish_pixels_batch.argtypes = [vp, sz, vp, vp, vp, vp, C.c_int, vp]
     L.zj_device_memset.argtypes = [vp, vp, C.c_int, sz]
     L.zj_pool_create.restype = vp
     L.zj_pool_create.argtypes = [C.c_int, C.c_int, C.POINTER(Options), C.POINTER(C.c_int)]
@@ -649,6 +651,33 @@ class Decoder:
             self._raise(rc)
         self._info = info
         return out[: n.value]
+
+
+def finish_pixels_batch(decoders, ctx, outs=None, device_ptrs=None):
+    """zj_decoder_finish_pixels_batch over Decoder objects that went through prepare(): the scans left for the device are
+    decoded together.  outs: list of uint8 arrays (allocated when None and no device_ptrs); device_ptrs: list of
+    (pointer, capacity) to leave the pixels in HBM.  Returns (outs or lengths, list of return codes)."""
+    n = len(decoders)
+    dptr = (C.c_void_p * n)(*[d._d for d in decoders])
+    if device_ptrs is None and outs is None:
+        outs = []
+        for d in decoders:
+            i = d._info
+            nc = 1 if i.components == 1 else ColorSpace(d._out_cs).num_components()
+            outs.append(np.zeros(int(i.width) * int(i.height) * nc, np.uint8))
+    if device_ptrs is not None:
+        optr = (C.c_void_p * n)(*[p for p, _ in device_ptrs])
+        caps = (C.c_size_t * n)(*[cap for _, cap in device_ptrs])
+    else:
+        optr = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        caps = (C.c_size_t * n)(*[o.size for o in outs])
+    lens = (C.c_size_t * n)()
+    rcs = (C.c_int * n)()
+    _check(lib().zj_decoder_finish_pixels_batch(dptr, n, ctx.handle, optr, caps, lens, 1 if device_ptrs is not None else 0, rcs),
+           "zj_decoder_finish_pixels_batch", ctx.handle)
+    if device_ptrs is not None:
+        return list(lens), list(rcs)
+    return [o[: lens[k]] for k, o in enumerate(outs)], list(rcs)
 
 
 class Pool:
