@@ -657,10 +657,28 @@ bool scan_check(ScanJob& j, int launched)
 // counters costs a stream synchronisation, so it happens once, after the pixels.  A scan whose last planned round still
 // changed something gets more rounds on its own (looking after each group), has what its premature write pass
 // scattered cleared, and runs the rest again.
+static int decode_scans_impl(zj_ctx* c, size_t n, const zj_frame_desc* descs, const void* const* blobs, const size_t* blob_bytes,
+                             uint8_t* const* outs, int outs_on_device, int* rcs, unsigned* status_bits);
+
 int zj_decode_scans(zj_ctx* c, size_t n, const zj_frame_desc* descs, const void* const* blobs, const size_t* blob_bytes,
                     uint8_t* const* outs, int outs_on_device, int* rcs, unsigned* status_bits)
 {
     if (!c || !n || n > (size_t)ZJ_SCAN_BATCH_MAX || !descs || !blobs || !blob_bytes || !outs || !rcs) return ZJ_ERR_ARG;
+    const int rc = decode_scans_impl(c, n, descs, blobs, blob_bytes, outs, outs_on_device, rcs, status_bits);
+    if (rc) {
+        // an error half way leaves copies and kernels in flight that read the caller's blobs and write its outputs:
+        // drain them before the caller may free or reuse its buffers (the first error stays in last_error)
+        const std::string keep = c->last_error;
+        (void)hipStreamSynchronize(c->stream);
+        c->last_error = keep;
+        for (size_t k = 0; k < n; k++) if (rcs[k] == ZJ_OK) rcs[k] = rc;
+    }
+    return rc;
+}
+
+static int decode_scans_impl(zj_ctx* c, size_t n, const zj_frame_desc* descs, const void* const* blobs, const size_t* blob_bytes,
+                             uint8_t* const* outs, int outs_on_device, int* rcs, unsigned* status_bits)
+{
     ZJ_HIP(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     if (!c->h_ctl) ZJ_HIP(c, hipHostMalloc((void**)&c->h_ctl, (size_t)ZJ_SCAN_BATCH_MAX * HUFF_CTL_WORDS * 4, hipHostMallocPortable));
