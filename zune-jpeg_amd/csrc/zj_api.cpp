@@ -53,8 +53,7 @@ struct zj_ctx {
     struct HuffSlot { void* buf = nullptr; size_t cap = 0; void* planes = nullptr; size_t pcap = 0; void* out = nullptr; size_t ocap = 0; };
     HuffSlot hslot[ZJ_SCAN_BATCH_MAX];
     uint32_t* h_ctl = nullptr;    // pinned: HUFF_CTL_WORDS per slot
-    HuffArgs* h_args = nullptr;   // pinned staging of the kernels' argument array
-    HuffArgs* d_args = nullptr;
+
     int huff_rounds = 0;          // synchronisation rounds of the last scan
     int huff_plane_slot = 0;
     size_t huff_plane_off[3] = {0, 0, 0}, huff_plane_len[3] = {0, 0, 0}; // the last call's first scan: its planes inside the slot (bytes / int16 elements)
@@ -175,8 +174,7 @@ void zj_ctx_destroy(zj_ctx* c)
         if (sl.out) (void)hipFree(sl.out);
     }
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
-    if (c->h_args) (void)hipHostFree(c->h_args);
-    if (c->d_args) (void)hipFree(c->d_args);
+
     for (hipStream_t st : {c->s_up, c->s_run, c->s_down})
         if (st) (void)hipStreamSynchronize(st);
     for (PipeSlot& sl : c->slots) {
@@ -682,8 +680,8 @@ static int decode_scans_impl(zj_ctx* c, size_t n, const zj_frame_desc* descs, co
     ZJ_HIP(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     if (!c->h_ctl) ZJ_HIP(c, hipHostMalloc((void**)&c->h_ctl, (size_t)ZJ_SCAN_BATCH_MAX * HUFF_CTL_WORDS * 4, hipHostMallocPortable));
-    if (!c->h_args) ZJ_HIP(c, hipHostMalloc((void**)&c->h_args, (size_t)ZJ_SCAN_BATCH_MAX * sizeof(HuffArgs), hipHostMallocPortable));
-    if (!c->d_args) ZJ_HIP(c, hipMalloc((void**)&c->d_args, (size_t)ZJ_SCAN_BATCH_MAX * sizeof(HuffArgs)));
+    static_assert(ZJ_SCAN_BATCH_MAX == HUFF_BATCH_MAX, "include/zjhip.h and zj_huff.h disagree");
+    HuffBatch batch;
     const bool timing = getenv("ZJ_HUFF_TIME") != nullptr;
     const auto t_submit0 = std::chrono::steady_clock::now();
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -697,21 +695,20 @@ static int decode_scans_impl(zj_ctx* c, size_t n, const zj_frame_desc* descs, co
         rcs[k] = jobs[k].rc = scan_setup(c, jobs[k], (int)k, &descs[k], blobs[k], blob_bytes[k], outs[k], outs_on_device);
         if (jobs[k].rc) continue;
         live[nlive] = (int)k;
-        c->h_args[nlive++] = jobs[k].a;
+        batch.a[nlive++] = jobs[k].a;
         if (jobs[k].nsub > max_nsub) max_nsub = (uint32_t)jobs[k].nsub;
         if (jobs[k].planned > planned) planned = jobs[k].planned;
     }
     if (!nlive) return ZJ_OK;
-    ZJ_HIP(c, hipMemcpyAsync(c->d_args, c->h_args, (size_t)nlive * sizeof(HuffArgs), hipMemcpyHostToDevice, s));
     for (int q = 0; q < nlive; q++) {
         ScanJob& j = jobs[(size_t)live[q]];
         ZJ_HIP(c, hipMemcpyAsync((void*)j.a.blob, j.blob, j.blob_bytes, hipMemcpyHostToDevice, s));
         int rc = scan_clear(c, j, s, true);
         if (rc) return rc;
     }
-    for (int round = 0; round <= planned; round++) ZJ_HIP(c, launch_huff_sync(c->d_args, nlive, max_nsub, round, s));
+    for (int round = 0; round <= planned; round++) ZJ_HIP(c, launch_huff_sync(batch, nlive, max_nsub, round, s));
     if (timing) ZJ_HIP(c, hipEventRecord(ev[1], s));
-    ZJ_HIP(c, launch_huff_finish(c->d_args, nlive, max_nsub, s));
+    ZJ_HIP(c, launch_huff_finish(batch, nlive, max_nsub, s));
     if (timing) ZJ_HIP(c, hipEventRecord(ev[2], s));
     for (int q = 0; q < nlive; q++) {
         int rc = scan_pixels(c, jobs[(size_t)live[q]], s, outs_on_device);
@@ -728,11 +725,13 @@ static int decode_scans_impl(zj_ctx* c, size_t n, const zj_frame_desc* descs, co
     for (int q = 0; q < nlive; q++) {
         ScanJob& j = jobs[(size_t)live[q]];
         if (!scan_check(j, planned)) {
-            // the slow way, this scan alone: its working set is entry q of the argument array
+            // the slow way, this scan alone
+            HuffBatch one;
+            one.a[0] = j.a;
             int round = planned, group = 16;
             while (!j.synced && round < j.max_rounds) {
                 const int first = round + 1;
-                for (int k = 0; k < group && round < j.max_rounds; k++) ZJ_HIP(c, launch_huff_sync(c->d_args + q, 1, (uint32_t)j.nsub, ++round, s));
+                for (int k = 0; k < group && round < j.max_rounds; k++) ZJ_HIP(c, launch_huff_sync(one, 1, (uint32_t)j.nsub, ++round, s));
                 ZJ_HIP(c, hipMemcpyAsync(j.h_ctl, j.a.ctl, (size_t)HUFF_CTL_WORDS * 4, hipMemcpyDeviceToHost, s));
                 ZJ_HIP(c, hipStreamSynchronize(s));
                 for (int r = first; r <= round; r++)
@@ -748,7 +747,7 @@ static int decode_scans_impl(zj_ctx* c, size_t n, const zj_frame_desc* descs, co
             }
             int rc = scan_clear(c, j, s, false); // (the planes may hold coefficients scattered from a wrong parse)
             if (rc) return rc;
-            ZJ_HIP(c, launch_huff_finish(c->d_args + q, 1, (uint32_t)j.nsub, s));
+            ZJ_HIP(c, launch_huff_finish(one, 1, (uint32_t)j.nsub, s));
             if ((rc = scan_pixels(c, j, s, outs_on_device))) return rc;
             ZJ_HIP(c, hipStreamSynchronize(s));
         }

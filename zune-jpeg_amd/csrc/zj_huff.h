@@ -44,7 +44,7 @@ constexpr uint32_t HUFF_FIRST = 0x80000000u, HUFF_LAST = 0x40000000u, HUFF_SEG_M
 constexpr uint32_t HUFF_ST_BAD_CODE = 1, HUFF_ST_RUN_OVER = 2, HUFF_ST_EXHAUSTED = 4, HUFF_ST_CUT_EARLY = 8,
                    HUFF_ST_PHASE = 16, HUFF_ST_NO_SYNC = 32;
 
-// table entry (u16): 0 = no such code.  Bit 15 set: low byte = second-level table number, indexed by the 16 - L1 bits
+// table entry (u16): 16 (16 bits consumed, zig-zag advance 0) = no such code.  Bit 15 set: low byte = second-level table number, indexed by the 16 - L1 bits
 // that follow the first L1.  Bit 15 clear: everything the symbol does to the parse --
 //   bits 0-4   bits consumed: code length + magnitude bits (1..31)
 //   bits 5-10  advance of the zig-zag index: DC symbols 1; AC run/size run + 1; ZRL 16; EOB (any run with size 0) 63
@@ -97,5 +97,10 @@ struct HuffArgs {
     int16_t* plane[3];
     int round;
 };
+
+// the working sets of the scans of one launch, passed BY VALUE in the kernel arguments (blockIdx.y picks one): read
+// through a pointer instead, the same kernels ran the first full round 2.3x slower (152 vs 63 us)
+constexpr int HUFF_BATCH_MAX = 16;
+struct HuffBatch { HuffArgs a[HUFF_BATCH_MAX]; };
 
 } // namespace zj

@@ -11,10 +11,10 @@ namespace zj {
 
 // Every kernel takes the working sets of a BATCH of scans (blockIdx.y picks one): the scans of several files run as one
 // launch each, sized for the largest; workgroups past a scan's end leave at once.
-__global__ __launch_bounds__(HUFF_WG) void zj_huff_sync_kernel(const HuffArgs* args, int round)
+__global__ __launch_bounds__(HUFF_WG) void zj_huff_sync_kernel(const HuffBatch args, int round)
 {
     __shared__ HuffLds L;
-    HuffArgs a = args[blockIdx.y];
+    HuffArgs a = args.a[blockIdx.y];
     a.round = round;
     const uint32_t i = blockIdx.x * HUFF_WG + threadIdx.x;
     const HuffScan* g = huff_hdr(a.blob);
@@ -33,22 +33,22 @@ __global__ __launch_bounds__(HUFF_WG) void zj_huff_sync_kernel(const HuffArgs* a
     huff_sync_thread(a, L, i);
 }
 
-__global__ __launch_bounds__(HUFF_WG) void zj_huff_write_kernel(const HuffArgs* args)
+__global__ __launch_bounds__(HUFF_WG) void zj_huff_write_kernel(const HuffBatch args)
 {
     __shared__ HuffLds L;
-    const HuffArgs a = args[blockIdx.y];
+    const HuffArgs a = args.a[blockIdx.y];
     if (blockIdx.x * HUFF_WG >= huff_hdr(a.blob)->nsub) return;
     huff_stage<HUFF_WG>(a.blob, (int)blockIdx.x, (int)threadIdx.x, true, L);
     __syncthreads();
     huff_write_thread(a, L, blockIdx.x * HUFF_WG + threadIdx.x);
 }
 
-__global__ __launch_bounds__(HUFF_SCAN_WG) void zj_huff_scan_kernel(const HuffArgs* args)
+__global__ __launch_bounds__(HUFF_SCAN_WG) void zj_huff_scan_kernel(const HuffBatch args)
 {
     // Hillis-Steele over the workgroup's 1024 elements, double-buffered in LDS
     __shared__ HuffAgg buf[2][HUFF_SCAN_WG];
     __shared__ uint32_t ticket;
-    const HuffArgs a = args[blockIdx.y];
+    const HuffArgs a = args.a[blockIdx.y];
     const uint32_t nwg = (huff_hdr(a.blob)->nsub + HUFF_SCAN_WG - 1) / HUFF_SCAN_WG; // of THIS scan
     if (blockIdx.x >= nwg) return;
     const uint32_t t = threadIdx.x, i = blockIdx.x * HUFF_SCAN_WG + t;
@@ -75,24 +75,24 @@ __global__ __launch_bounds__(HUFF_SCAN_WG) void zj_huff_scan_kernel(const HuffAr
     }
 }
 
-__global__ __launch_bounds__(256) void zj_huff_cut_kernel(const HuffArgs* args)
+__global__ __launch_bounds__(256) void zj_huff_cut_kernel(const HuffBatch args)
 {
-    const HuffArgs a = args[blockIdx.y];
+    const HuffArgs a = args.a[blockIdx.y];
     uint32_t first = 0;
     const uint32_t pieces = huff_cut_plan(a, &first);
     for (uint32_t p = threadIdx.x; p < pieces; p += 256) huff_cut_clear(a, first, p);
 }
 
-hipError_t launch_huff_sync(const HuffArgs* d_args, int njobs, uint32_t max_nsub, int round, hipStream_t s)
+hipError_t launch_huff_sync(const HuffBatch& b, int njobs, uint32_t max_nsub, int round, hipStream_t s)
 {
-    hipLaunchKernelGGL(zj_huff_sync_kernel, dim3((max_nsub + HUFF_WG - 1) / HUFF_WG, njobs), dim3(HUFF_WG), 0, s, d_args, round);
+    hipLaunchKernelGGL(zj_huff_sync_kernel, dim3((max_nsub + HUFF_WG - 1) / HUFF_WG, njobs), dim3(HUFF_WG), 0, s, b, round);
     return hipGetLastError();
 }
-hipError_t launch_huff_finish(const HuffArgs* d_args, int njobs, uint32_t max_nsub, hipStream_t s)
+hipError_t launch_huff_finish(const HuffBatch& b, int njobs, uint32_t max_nsub, hipStream_t s)
 {
-    hipLaunchKernelGGL(zj_huff_scan_kernel, dim3((max_nsub + HUFF_SCAN_WG - 1) / HUFF_SCAN_WG, njobs), dim3(HUFF_SCAN_WG), 0, s, d_args);
-    hipLaunchKernelGGL(zj_huff_write_kernel, dim3((max_nsub + HUFF_WG - 1) / HUFF_WG, njobs), dim3(HUFF_WG), 0, s, d_args);
-    hipLaunchKernelGGL(zj_huff_cut_kernel, dim3(1, njobs), dim3(256), 0, s, d_args);
+    hipLaunchKernelGGL(zj_huff_scan_kernel, dim3((max_nsub + HUFF_SCAN_WG - 1) / HUFF_SCAN_WG, njobs), dim3(HUFF_SCAN_WG), 0, s, b);
+    hipLaunchKernelGGL(zj_huff_write_kernel, dim3((max_nsub + HUFF_WG - 1) / HUFF_WG, njobs), dim3(HUFF_WG), 0, s, b);
+    hipLaunchKernelGGL(zj_huff_cut_kernel, dim3(1, njobs), dim3(256), 0, s, b);
     return hipGetLastError();
 }
 

@@ -170,11 +170,13 @@ ZJ_DEV HuffState huff_run(const HuffLds& L, HuffState s, uint32_t limit, bool la
     uint32_t status = 0;
     if (j >= h.bpm) j = 0; // (only a corrupted exit word could say so)
     // per component: table offsets; per block of the MCU: its component (2 bits each) -- registers, not LDS, because
-    // every iteration of a wave has some lane at a block boundary
+    // every iteration of a wave has some lane at a block boundary.  m0..m2: all-ones for the current block's component
+    // (the DC difference is added to that component's sum, masked adds instead of selects)
     const uint32_t cmask = h.comp_of_blk;
     const uint32_t dc0 = h.dc_off[0], dc1 = h.dc_off[1], dc2 = h.dc_off[2], ac0 = h.ac_off[0], ac1 = h.ac_off[1], ac2 = h.ac_off[2];
     uint32_t comp = (cmask >> (2 * j)) & 3u;
     uint32_t dcb = comp == 0 ? dc0 : comp == 1 ? dc1 : dc2, acb = comp == 0 ? ac0 : comp == 1 ? ac1 : ac2;
+    int32_t m0 = comp == 0 ? -1 : 0, m1 = comp == 1 ? -1 : 0, m2 = comp == 2 ? -1 : 0;
     int16_t* dst = nullptr;
     if (WRITE) dst = huff_block_ptr(h, *w, h.blk[j]);
     for (;;) {
@@ -189,22 +191,25 @@ ZJ_DEV HuffState huff_run(const HuffLds& L, HuffState s, uint32_t limit, bool la
         const uint32_t l1 = is_dc ? (uint32_t)HUFF_L1_DC : (uint32_t)HUFF_L1_AC;
         uint32_t e = L.T[tb + (win >> (32u - l1))];
         if (e & 0x8000u) e = L.T[tb + (1u << l1) + ((e & 0xffu) << (16u - l1)) + ((win >> 16) & ((1u << (16u - l1)) - 1u))];
-        uint32_t total = e & 31u, zadv = (e >> 5) & 63u;
-        if (total == 0) { total = 16; zadv = 1; e = 0; if (WRITE) status |= HUFF_ST_BAD_CODE; } // no such code: any fixed step
+        // (no such code: the entry says 16 bits, zig-zag advance 0 -- a fixed step for a guess gone wrong, a status for
+        // the write pass)
+        const uint32_t total = e & 31u, zadv = (e >> 5) & 63u;
+        if (WRITE && zadv == 0) status |= HUFF_ST_BAD_CODE;
         const uint32_t sym_start = pos;
         if (is_dc || WRITE) {
-            const uint32_t sz = (e >> 11) & 15u, len = total - sz;
-            const uint32_t bits = sz ? (win << len) >> (32u - sz) : 0u;
-            const int32_t val = sz ? (int32_t)bits - ((bits >> (sz - 1)) ? 0 : (int32_t)((1u << sz) - 1u)) : 0; // EXTEND
+            // magnitude bits and EXTEND (T.81 F.2.2.1) without a branch on the size: t holds the bits left-aligned
+            const uint32_t sz = (e >> 11) & 15u;
+            const uint32_t t = win << (total - sz);
+            const uint32_t bits = (t >> 1) >> (31u - sz);                                   // sz == 0: 0
+            const int32_t val = (int32_t)bits + ((int32_t)~((int32_t)t >> 31) & (1 - (int32_t)(1u << sz))); // top bit 0: negative
             if (is_dc) {
-                d0 += comp == 0 ? val : 0;
-                d1 += comp == 1 ? val : 0;
-                d2 += comp == 2 ? val : 0;
+                const int32_t dv = sz ? val : 0; // (sz == 0: t's top bit belongs to the next symbol)
+                d0 += dv & m0; d1 += dv & m1; d2 += dv & m2;
                 if (WRITE) {
-                    p0 = (int32_t)((uint32_t)p0 + (uint32_t)(comp == 0 ? val : 0));
-                    p1 = (int32_t)((uint32_t)p1 + (uint32_t)(comp == 1 ? val : 0));
-                    p2 = (int32_t)((uint32_t)p2 + (uint32_t)(comp == 2 ? val : 0));
-                    dst[0] = (int16_t)(comp == 0 ? p0 : comp == 1 ? p1 : p2); // bitstream.rs:330
+                    p0 = (int32_t)((uint32_t)p0 + (uint32_t)(dv & m0));
+                    p1 = (int32_t)((uint32_t)p1 + (uint32_t)(dv & m1));
+                    p2 = (int32_t)((uint32_t)p2 + (uint32_t)(dv & m2));
+                    dst[0] = (int16_t)((p0 & m0) | (p1 & m1) | (p2 & m2)); // bitstream.rs:330
                 }
             } else if (WRITE && sz) {
                 const uint32_t zz = z + zadv - 1;
@@ -244,6 +249,7 @@ ZJ_DEV HuffState huff_run(const HuffLds& L, HuffState s, uint32_t limit, bool la
             comp = (cmask >> (2 * j)) & 3u;
             dcb = comp == 0 ? dc0 : comp == 1 ? dc1 : dc2;
             acb = comp == 0 ? ac0 : comp == 1 ? ac1 : ac2;
+            m0 = comp == 0 ? -1 : 0; m1 = comp == 1 ? -1 : 0; m2 = comp == 2 ? -1 : 0;
             if (WRITE && w->blk < w->blk_end) dst = huff_block_ptr(h, *w, h.blk[j]);
         }
     }

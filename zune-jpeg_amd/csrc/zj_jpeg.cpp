@@ -922,8 +922,9 @@ int scan_progressive(zj_decoder* d, BitReader& br)
 int gpu_table(const Huff& h, bool ac, uint16_t* out, int room)
 {
     const int B = ac ? zj::HUFF_L1_AC : zj::HUFF_L1_DC, L1 = 1 << B, L2 = 1 << (16 - B);
+    constexpr uint16_t NONE = 16; // "no such code": 16 bits consumed, zig-zag advance 0 (zj_huff.h)
     if (room < L1) return -1;
-    memset(out, 0, L1 * sizeof(uint16_t));
+    for (int q = 0; q < L1; q++) out[q] = NONE;
     uint32_t code = 0;
     int k = 0, links = 0;
     for (int l = 1; l <= 16; l++) {
@@ -931,15 +932,15 @@ int gpu_table(const Huff& h, bool ac, uint16_t* out, int room)
             // entry: bits consumed | zig-zag advance << 5 | magnitude bits << 11 (zj_huff.h)
             const int sym = h.vals[k], sz = ac ? (sym & 15) : sym, run = ac ? sym >> 4 : 0;
             const int zadv = !ac ? 1 : sz ? run + 1 : run == 15 ? 16 : 63;
-            const uint16_t e = (sz > 15 || l + sz > 31) ? 0 : (uint16_t)((l + sz) | (zadv << 5) | (sz << 11));
+            const uint16_t e = (sz > 15 || l + sz > 31) ? NONE : (uint16_t)((l + sz) | (zadv << 5) | (sz << 11));
             if (l <= B) {
                 const uint32_t base = code << (B - l);
                 for (uint32_t q = 0; q < (1u << (B - l)); q++) out[base + q] = e;
             } else {
                 const uint32_t prefix = code >> (l - B);
-                if (!out[prefix]) {
+                if (out[prefix] == NONE) {
                     if (links == 255 || L1 + (links + 1) * L2 > room) return -1;
-                    memset(out + L1 + links * L2, 0, L2 * sizeof(uint16_t));
+                    for (int q = 0; q < L2; q++) out[L1 + links * L2 + q] = NONE;
                     out[prefix] = (uint16_t)(0x8000 | links++);
                 }
                 const uint32_t sub = (uint32_t)L1 + ((out[prefix] & 0xffu) << (16 - B));

@@ -24,8 +24,8 @@ hipError_t launch_labmem(int i, const void* in, void* out, long long bytes, hipS
 int lab_count();
 const char* lab_name(int i);
 hipError_t launch_lab(int i, const int32_t qt[3][64], int* out, int blocks, int iters, hipStream_t s);
-// d_args: device array of njobs working sets; max_nsub: the largest scan's sub-sequence count
-hipError_t launch_huff_sync(const HuffArgs* d_args, int njobs, uint32_t max_nsub, int round, hipStream_t s); // one synchronisation round
-hipError_t launch_huff_finish(const HuffArgs* d_args, int njobs, uint32_t max_nsub, hipStream_t s);         // prefix sums, write pass, EOI cut
+// b: the working sets of njobs scans; max_nsub: the largest scan's sub-sequence count
+hipError_t launch_huff_sync(const HuffBatch& b, int njobs, uint32_t max_nsub, int round, hipStream_t s); // one synchronisation round
+hipError_t launch_huff_finish(const HuffBatch& b, int njobs, uint32_t max_nsub, hipStream_t s);         // prefix sums, write pass, EOI cut
 hipError_t launch_ub_clock(unsigned long long* out, int blocks, int iters, hipStream_t s);
 } // namespace zj
