@@ -164,47 +164,59 @@ extern "C" int zje_guard_limit(void) { return GUARD_LIMIT; }
 // ---- the GPU entropy stage (zj_huff_device.h), thread by thread -----------------------------------------------------
 #include "../../zune-jpeg_amd/csrc/zj_huff_device.h"
 
-// planes must be zero-filled by the caller (the product clears them with hipMemsetAsync).  stats: [0] rounds run,
+// planes: three separate buffers here, so the caller zero-fills them (on the device round 0 clears the one allocation that
+// holds all three, huff_clear_planes).  stats: [0] rounds run,
 // [1] sub-sequences, [2] sub-sequence decodes over all sync rounds, [3] first-seen MCU of the EOI rule
 extern "C" int zje_huff_decode(const uint8_t* blob, int16_t* y, int16_t* cb, int16_t* cr, uint32_t* status, uint32_t* stats)
 {
     const HuffScan* g = huff_hdr(blob);
     if (g->magic != HUFF_MAGIC) return ZJ_ERR_ARG;
     const uint32_t nsub = g->nsub;
-    std::vector<unsigned long long> exitv(nsub);
+    std::vector<unsigned long long> exitv(nsub), exit_before(nsub);
     std::vector<HuffI4> aux(nsub), base(nsub);
-    std::vector<uint8_t> changed(2 * (size_t)nsub), rel(nsub);
+    std::vector<uint32_t> list(2 * (size_t)nsub);
+    std::vector<uint8_t> rel(nsub);
     std::vector<uint32_t> ctl(HUFF_CTL_WORDS, 0);
     ctl[HUFF_CTL_SEEN] = 0xffffffffu;
     const uint32_t nscan = (nsub + HUFF_SCAN_WG - 1) / HUFF_SCAN_WG;
     std::vector<HuffAgg> wgagg(nscan), wgpre(nscan);
     HuffArgs a;
-    a.blob = blob; a.exit = exitv.data(); a.aux = aux.data(); a.base = base.data(); a.changed = changed.data(); a.rel = rel.data();
+    a.blob = blob; a.exit = exitv.data(); a.exit_rd = exit_before.data(); a.aux = aux.data(); a.base = base.data();
+    a.list = list.data(); a.rel = rel.data();
     a.wgagg = wgagg.data(); a.wgpre = wgpre.data();
     a.ctl = ctl.data(); a.plane[0] = y; a.plane[1] = cb; a.plane[2] = cr; a.round = 0;
+    a.zero_base = nullptr; a.zero_pieces = 0;
+    a.spread = getenv("ZJE_SPREAD") ? atoi(getenv("ZJE_SPREAD")) : 3; // lanes per work-list entry in the sparse rounds
     std::vector<HuffLds> lds(1);
     HuffLds& L = lds[0];
-    const uint32_t nwg = (nsub + HUFF_WG - 1) / HUFF_WG;
     uint32_t work = 0;
     int round = 0;
     for (;; round++) {
         if (round > HUFF_MAX_ROUNDS) { ctl[0] |= HUFF_ST_NO_SYNC; break; }
         a.round = round;
-        // the device runs all threads of a round at once: nobody sees an exit state of the SAME round.  Descending
-        // order gives exactly that here (thread i reads exit[i - 1] before thread i - 1 rewrites it).
-        for (uint32_t wg = nwg; wg-- > 0;) {
-            bool any = false;
-            for (int tid = 0; tid < HUFF_WG; tid++) any |= huff_sync_needed(a, wg * HUFF_WG + tid, nsub, huff_subs(blob));
-            if (!any) { for (int tid = 0; tid < HUFF_WG; tid++) if (wg * HUFF_WG + tid < nsub) changed[(size_t)(round & 1) * nsub + wg * HUFF_WG + tid] = 0; continue; }
+        if (round >= 2 && ctl[HUFF_CTL_ROUND0 + round - 1] == 0) break; // (the device's no-op rounds)
+        // the device runs all threads of a round at once: nobody sees an exit state of the SAME round -- the round reads
+        // its predecessors' states from a copy taken before it
+        exit_before = exitv;
+        a.exit_rd = exit_before.data();
+        uint32_t todo = nsub;
+        if (round >= 2) { const uint32_t entries = ctl[HUFF_CTL_ROUND0 + round - 1]; todo = entries * huff_spread(a, nsub, entries); }
+        for (uint32_t wg = 0; wg * HUFF_WG < todo; wg++) {
+            uint32_t pick[HUFF_WG];
             memset((void*)&L, 0x7B, sizeof L);
-            for (int tid = 0; tid < HUFF_WG; tid++) huff_stage<HUFF_WG>(blob, (int)wg, tid, huff_sync_needed(a, wg * HUFF_WG + tid, nsub, huff_subs(blob)), L);
-            for (int tid = HUFF_WG; tid-- > 0;) {
-                if (huff_sync_needed(a, wg * HUFF_WG + tid, nsub, huff_subs(blob))) work++;
-                huff_sync_thread(a, L, wg * HUFF_WG + tid);
+            for (int tid = 0; tid < HUFF_WG; tid++) {
+                pick[tid] = huff_sync_pick(a, wg * HUFF_WG + tid, nsub, huff_subs(blob));
+                huff_stage<HUFF_WG>(blob, tid, pick[tid] < nsub, pick[tid], L);
+            }
+            for (int tid = 0; tid < HUFF_WG; tid++) {
+                if (pick[tid] < nsub) work++;
+                huff_sync_thread(a, L, (uint32_t)tid, pick[tid]);
             }
         }
         if (round >= 1 && ctl[HUFF_CTL_ROUND0 + round] == 0) break;
     }
+    const uint32_t nwg = (nsub + HUFF_WG - 1) / HUFF_WG;
+    a.exit_rd = exitv.data();
     if (!(ctl[0] & HUFF_ST_NO_SYNC)) {
         for (uint32_t w = 0; w < nscan; w++) { // a prefix-sum workgroup: the scan the device does in log steps
             HuffAgg run = huff_scan_identity();
@@ -219,8 +231,8 @@ extern "C" int zje_huff_decode(const uint8_t* blob, int16_t* y, int16_t* cb, int
         huff_scan_totals(a, nscan);
         for (uint32_t wg = 0; wg < nwg; wg++) {
             memset((void*)&L, 0x7B, sizeof L);
-            for (int tid = 0; tid < HUFF_WG; tid++) huff_stage<HUFF_WG>(blob, (int)wg, tid, true, L);
-            for (int tid = 0; tid < HUFF_WG; tid++) huff_write_thread(a, L, wg * HUFF_WG + tid);
+            for (int tid = 0; tid < HUFF_WG; tid++) huff_stage<HUFF_WG>(blob, tid, wg * HUFF_WG + tid < nsub, wg * HUFF_WG + tid, L);
+            for (int tid = 0; tid < HUFF_WG; tid++) huff_write_thread(a, L, (uint32_t)tid, wg * HUFF_WG + tid);
         }
         uint32_t first = 0;
         const uint32_t pieces = huff_cut_plan(a, &first);

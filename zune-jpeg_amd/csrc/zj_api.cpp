@@ -585,7 +585,7 @@ int scan_setup(zj_ctx* c, ScanJob& j, int slot, const zj_frame_desc* d, const vo
     j.nsub = h->nsub;
     const size_t nsub = j.nsub, nscan = (nsub + HUFF_SCAN_WG - 1) / HUFF_SCAN_WG;
     const size_t o_exit = up256(blob_bytes), o_aux = o_exit + up256(nsub * 8), o_base = o_aux + up256(nsub * 16),
-                 o_chg = o_base + up256(nsub * 16), o_rel = o_chg + up256(nsub * 2), o_ctl = o_rel + up256(nsub),
+                 o_lst = o_base + up256(nsub * 16), o_rel = o_lst + up256(nsub * 8), o_ctl = o_rel + up256(nsub),
                  o_agg = o_ctl + up256((size_t)HUFF_CTL_WORDS * 4), o_pre = o_agg + up256(nscan * sizeof(HuffAgg)),
                  total = o_pre + up256(nscan * sizeof(HuffAgg));
     zj_ctx::HuffSlot& sl = c->hslot[slot];
@@ -600,7 +600,8 @@ int scan_setup(zj_ctx* c, ScanJob& j, int slot, const zj_frame_desc* d, const vo
     a.exit = (unsigned long long*)(base + o_exit);
     a.aux = (HuffI4*)(base + o_aux);
     a.base = (HuffI4*)(base + o_base);
-    a.changed = base + o_chg;
+    a.exit_rd = a.exit;
+    a.list = (uint32_t*)(base + o_lst);
     a.rel = base + o_rel;
     a.ctl = (uint32_t*)(base + o_ctl);
     a.wgagg = (HuffAgg*)(base + o_agg);
@@ -609,6 +610,9 @@ int scan_setup(zj_ctx* c, ScanJob& j, int slot, const zj_frame_desc* d, const vo
     a.plane[1] = (int16_t*)((uint8_t*)sl.planes + j.yb);
     a.plane[2] = (int16_t*)((uint8_t*)sl.planes + j.yb + j.cbytes);
     a.round = 0;
+    a.spread = 1;
+    a.zero_base = (uint8_t*)sl.planes;
+    a.zero_pieces = (uint32_t)((j.yb + 2 * j.cbytes) / 16);
     j.d_out = out_on_device ? out : (uint8_t*)sl.out;
     j.h_ctl = c->h_ctl + (size_t)slot * HUFF_CTL_WORDS;
     const uint32_t sub_bytes = h->sub_bytes >= 16 && h->sub_bytes <= (uint32_t)HUFF_SUB_MAX ? h->sub_bytes : (uint32_t)HUFF_SUB_MAX;
@@ -622,11 +626,12 @@ int scan_setup(zj_ctx* c, ScanJob& j, int slot, const zj_frame_desc* d, const vo
     return ZJ_OK;
 }
 
-int scan_clear(zj_ctx* c, ScanJob& j, hipStream_t s, bool all_ctl)
+// first: before round 0 (which clears the planes itself); otherwise: before the write pass runs a second time
+int scan_clear(zj_ctx* c, ScanJob& j, hipStream_t s, bool first)
 {
-    ZJ_HIP(c, hipMemsetAsync(j.a.ctl, 0, (all_ctl ? (size_t)HUFF_CTL_WORDS : (size_t)HUFF_CTL_ROUND0) * 4, s));
+    ZJ_HIP(c, hipMemsetAsync(j.a.ctl, 0, (first ? (size_t)HUFF_CTL_WORDS : (size_t)HUFF_CTL_ROUND0) * 4, s));
     ZJ_HIP(c, hipMemsetAsync(j.a.ctl + HUFF_CTL_SEEN, 0xff, 4, s));
-    ZJ_HIP(c, hipMemsetAsync(c->hslot[j.slot].planes, 0, j.yb + 2 * j.cbytes, s)); // the write pass stores non-zero coefficients only
+    if (!first) ZJ_HIP(c, hipMemsetAsync(c->hslot[j.slot].planes, 0, j.yb + 2 * j.cbytes, s)); // coefficients of a wrong parse
     return ZJ_OK;
 }
 
@@ -700,6 +705,11 @@ static int decode_scans_impl(zj_ctx* c, size_t n, const zj_frame_desc* descs, co
         if (jobs[k].planned > planned) planned = jobs[k].planned;
     }
     if (!nlive) return ZJ_OK;
+    {   // alone on the GPU a scan's sparse rounds spread out (one entry per wave), in a batch they pack (HuffArgs::spread)
+        int spread = nlive == 1 ? 64 : nlive == 2 ? 16 : nlive <= 4 ? 4 : 1;
+        if (const char* e = getenv("ZJ_HUFF_SPREAD")) { const int v = atoi(e); if (v >= 1 && v <= 64) spread = v; }
+        for (int q = 0; q < nlive; q++) batch.a[q].spread = spread;
+    }
     for (int q = 0; q < nlive; q++) {
         ScanJob& j = jobs[(size_t)live[q]];
         ZJ_HIP(c, hipMemcpyAsync((void*)j.a.blob, j.blob, j.blob_bytes, hipMemcpyHostToDevice, s));
@@ -728,6 +738,7 @@ static int decode_scans_impl(zj_ctx* c, size_t n, const zj_frame_desc* descs, co
             // the slow way, this scan alone
             HuffBatch one;
             one.a[0] = j.a;
+            one.a[0].spread = 64;
             int round = planned, group = 16;
             while (!j.synced && round < j.max_rounds) {
                 const int first = round + 1;

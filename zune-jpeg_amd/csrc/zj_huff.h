@@ -7,9 +7,10 @@
 //
 //   round 0      every thread decodes its sub-sequence as if a block began at its first bit, and records where -- and in
 //                which state (block of the MCU, zig-zag index) -- it crossed into the next sub-sequence;
-//   round r      a thread whose predecessor's exit state changed in round r-1 decodes again from that state; a wrong
-//                guess usually falls into step with the true parse within a few hundred bits, so the set of threads
-//                that still change shrinks quickly; the rounds end when no exit state changed.  At that fixed point
+//   round r      a sub-sequence whose predecessor's exit state changed in round r-1 is decoded again from that state (a
+//                thread of round r-1 that changes its exit state puts its successor on round r's work list); a wrong
+//                guess usually falls into step with the true parse within a few hundred bits, so the list
+//                shrinks quickly; the rounds end when no exit state changed.  At that fixed point
 //                exit[i] = F_i(exit[i-1]) for every i, and exit[first of a segment] started from the known state, so the
 //                chain IS the serial parse;
 //   scan         exclusive prefix sums over the blocks each sub-sequence completed and the DC differences it saw give
@@ -31,7 +32,8 @@ constexpr int HUFF_WG = 256;        // sub-sequences (threads) per workgroup: at
 constexpr int HUFF_L1_DC = 9;       // first-level window of a DC table (12 categories: longer codes are rare)
 constexpr int HUFF_L1_AC = 11;      // ... of an AC table: a lane that meets a longer code sends its whole wave through
                                     // the second lookup, so "longer" has to be rare per WAVE (64 symbols), not per symbol
-constexpr int HUFF_TAB_BUDGET = 9216; // u16 entries all tables of a scan may take together (18 KB of LDS): a table is
+constexpr int HUFF_TAB_BUDGET = 7424; // u16 entries all tables of a scan may take together (14.5 KB of LDS: with the 37 KB
+                                      // of stream words three workgroups fit a CU; two AC + two DC tables need 5120): a table is
                                       // 2^L1 + 2^(16 - L1) x (distinct L1-bit prefixes of its codes longer than L1 bits)
 constexpr int HUFF_MAX_TABS = 6;    // distinct (class, id) tables of a 3-component scan
 constexpr int HUFF_MAX_BPM = 10;    // blocks per MCU (T.81 B.2.3)
@@ -86,16 +88,25 @@ constexpr int HUFF_CTL_STATUS = 0, HUFF_CTL_SEEN = 1, HUFF_CTL_TICKET = 2, HUFF_
 struct HuffArgs {
     const uint8_t* blob;       // device copy of the blob
     unsigned long long* exit;  // [nsub] packed exit state of every sub-sequence
+    const unsigned long long* exit_rd; // where a round reads its predecessors' exit states: the same array (the emulation
+                               // points it at a copy taken before the round -- on the device all threads of a round run at once)
     HuffI4* aux;               // [nsub] blocks completed, DC difference sums per component
     HuffI4* base;              // [nsub] first block index, DC predictors (after the scan kernel)
-    uint8_t* changed;          // [2][nsub] exit state changed in the round of that parity
+    uint32_t* list;            // [2][nsub] from round 2 on: the sub-sequences a round has to decode again (those whose
+                               // predecessor's exit state changed in the round before), compact, so that the waves of a
+                               // sparse round are full; parity = round & 1, length = the change counter of the round before
     uint8_t* rel;              // [nsub] base[i] is relative to its prefix-sum workgroup (add wgpre)
     HuffAgg* wgagg;            // [ceil(nsub / HUFF_SCAN_WG)] totals of the prefix-sum workgroups
     HuffAgg* wgpre;            // the same, exclusive prefix
     uint32_t* ctl;             // HUFF_CTL_*: status bits, first MCU at which the reference has seen EOI, ticket of the
                                // prefix-sum workgroups, changes of round r at [HUFF_CTL_ROUND0 + r]
     int16_t* plane[3];
+    uint8_t* zero_base;        // round 0 also clears the planes (the write pass stores non-zero coefficients only): the
+    uint32_t zero_pieces;      // stores ride along with a latency-bound parse instead of a 50 MB fill of their own; 16-byte pieces
     int round;
+    int spread;                // from round 2 on: work-list entry e is decoded by thread e * S, S = min(spread, nsub / entries):
+                               // a wave with one active lane runs a symbol in 125 ns, a full one in 350 (every lane drags
+                               // the others through its side paths) -- alone on the GPU a scan spreads out, in a batch it packs
 };
 
 // the working sets of the scans of one launch, passed BY VALUE in the kernel arguments (blockIdx.y picks one): read

@@ -1,7 +1,7 @@
 // zj_huff.hip -- kernels of the GPU entropy stage (zj_huff.h: algorithm; zj_huff_device.h: the per-thread code).
-// gfx950: one sub-sequence per lane, 256 per workgroup; every lane that has work stages its own stream bytes in LDS
-// (<= 32 KB per workgroup, bank-skewed), the workgroup stages the decoding tables (<= 18 KB); after that a lane touches
-// global memory only to publish its exit state or to scatter coefficients.
+// gfx950: one sub-sequence per lane, 256 per workgroup; every lane that has work stages its own 144 stream bytes in a
+// private stretch of LDS (37 KB per workgroup, odd stride), the workgroup stages the decoding tables (<= 18 KB); after
+// that a lane touches global memory only to publish its exit state or to scatter coefficients.
 #include <hip/hip_runtime.h>
 
 #include "zj_huff_device.h"
@@ -16,31 +16,30 @@ __global__ __launch_bounds__(HUFF_WG) void zj_huff_sync_kernel(const HuffBatch a
     __shared__ HuffLds L;
     HuffArgs a = args.a[blockIdx.y];
     a.round = round;
-    const uint32_t i = blockIdx.x * HUFF_WG + threadIdx.x;
     const HuffScan* g = huff_hdr(a.blob);
     const uint32_t nsub = g->nsub;
-    if (blockIdx.x * HUFF_WG >= nsub) return;
     // the rounds are launched ahead of any look at their outcome: once a round changed nothing, the rest are no-ops
-    // (they leave the flags alone: the rounds after them return here as well)
-    if (a.round >= 2 && a.ctl[HUFF_CTL_ROUND0 + a.round - 1] == 0) return;
-    const bool need = huff_sync_needed(a, i, nsub, huff_subs(a.blob));
-    if (!__syncthreads_or(need ? 1 : 0)) { // nobody's entry state moved: no staging either
-        if (i < nsub) a.changed[(size_t)(a.round & 1) * nsub + i] = 0;
-        return;
-    }
-    huff_stage<HUFF_WG>(a.blob, (int)blockIdx.x, (int)threadIdx.x, need, L);
+    if (round >= 2 && a.ctl[HUFF_CTL_ROUND0 + round - 1] == 0) return;
+    // rounds 0 and 1 decode (nearly) every sub-sequence in place; later rounds the entries of their work list
+    uint32_t work = nsub;
+    if (round >= 2) { const uint32_t entries = a.ctl[HUFF_CTL_ROUND0 + round - 1]; work = entries * huff_spread(a, nsub, entries); }
+    if (blockIdx.x * HUFF_WG >= work) return;
+    const uint32_t i = huff_sync_pick(a, blockIdx.x * HUFF_WG + threadIdx.x, nsub, huff_subs(a.blob));
+    if (round == 0) huff_clear_planes(a, blockIdx.x * HUFF_WG + threadIdx.x, ((nsub + HUFF_WG - 1) / HUFF_WG) * HUFF_WG);
+    huff_stage<HUFF_WG>(a.blob, (int)threadIdx.x, i < nsub, i, L);
     __syncthreads();
-    huff_sync_thread(a, L, i);
+    huff_sync_thread(a, L, threadIdx.x, i);
 }
 
 __global__ __launch_bounds__(HUFF_WG) void zj_huff_write_kernel(const HuffBatch args)
 {
     __shared__ HuffLds L;
     const HuffArgs a = args.a[blockIdx.y];
-    if (blockIdx.x * HUFF_WG >= huff_hdr(a.blob)->nsub) return;
-    huff_stage<HUFF_WG>(a.blob, (int)blockIdx.x, (int)threadIdx.x, true, L);
+    const uint32_t nsub = huff_hdr(a.blob)->nsub, i = blockIdx.x * HUFF_WG + threadIdx.x;
+    if (blockIdx.x * HUFF_WG >= nsub) return;
+    huff_stage<HUFF_WG>(a.blob, (int)threadIdx.x, i < nsub, i, L);
     __syncthreads();
-    huff_write_thread(a, L, blockIdx.x * HUFF_WG + threadIdx.x);
+    huff_write_thread(a, L, threadIdx.x, i);
 }
 
 __global__ __launch_bounds__(HUFF_SCAN_WG) void zj_huff_scan_kernel(const HuffBatch args)

@@ -24,29 +24,29 @@
 namespace zj {
 
 // ---- LDS image of a workgroup --------------------------------------------------------------------------------------
-constexpr int HUFF_W_WORDS = HUFF_WG * HUFF_SUB_MAX / 4 + 8;     // stream words staged: 256 sub-sequences + the overrun of the last
-constexpr int HUFF_W_SLOTS = HUFF_W_WORDS + HUFF_W_WORDS / 32 + 1;
+constexpr int HUFF_LANE_DATA = HUFF_SUB_MAX / 4 + 4;   // stream words a thread stages: its sub-sequence + 16 bytes (a symbol
+                                                       // that begins before the limit may end up to 31 bits after it)
+constexpr int HUFF_LANE_WORDS = HUFF_LANE_DATA + 1;    // odd stride: lanes reading "their word k" hit different banks
 struct HuffLds {
-    uint32_t W[HUFF_W_SLOTS];                 // big-endian stream words; word k lives in slot k + k/32, so that lanes
-                                              // 32 words (one sub-sequence) apart hit different banks
+    uint32_t W[HUFF_WG * HUFF_LANE_WORDS];    // big-endian stream words, a private stretch per thread (a sparse round's
+                                              // threads decode sub-sequences from all over the scan)
     alignas(16) uint16_t T[HUFF_TAB_BUDGET];  // decoding tables
     HuffScan hdr;
     uint8_t unz[64];                          // zig-zag index -> natural position
-    uint32_t w0, nwords;                      // first stream word staged, count
-    int any;                                  // some thread of the workgroup has work this round
 };
-ZJ_DEV uint32_t huff_slot(uint32_t k) { return k + (k >> 5); }
 struct alignas(16) HuffU4 { uint32_t x, y, z, w; };
 
 #if defined(ZJ_EMU)
 ZJ_DEV void huff_or(uint32_t* p, uint32_t v) { *p |= v; }
 ZJ_DEV void huff_min(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
 ZJ_DEV void huff_add(uint32_t* p, uint32_t v) { *p += v; }
+ZJ_DEV uint32_t huff_add_return(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p += v; return o; }
 ZJ_DEV uint32_t huff_bswap(uint32_t v) { return __builtin_bswap32(v); }
 #else
 ZJ_DEV void huff_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
 ZJ_DEV void huff_min(uint32_t* p, uint32_t v) { atomicMin(p, v); }
 ZJ_DEV void huff_add(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
+ZJ_DEV uint32_t huff_add_return(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 ZJ_DEV uint32_t huff_bswap(uint32_t v) { return __builtin_bswap32(v); }
 #endif
 
@@ -64,38 +64,29 @@ ZJ_DEV uint32_t huff_unzigzag(int k)
     return t[k];
 }
 
-// Staging by the NT threads of workgroup `wg`.  Cooperative: header, decoding tables, zig-zag table.  Per thread: the
-// stream words of ITS sub-sequence (+ 16 bytes: a symbol that begins before the limit may end up to 31 bits after it),
-// and only if `mine` says the thread will decode -- in the later rounds few do.  16-byte loads, all issued before the
-// first LDS write.  A barrier must follow.
+// Staging.  Cooperative (NT threads): header, decoding tables, zig-zag table.  Per thread: the stream words of the
+// sub-sequence `sub_index` it is about to decode, if any (16-byte loads, all issued before the first LDS write).
+// A barrier must follow.
 template <int NT>
-ZJ_DEV void huff_stage(const uint8_t* blob, int wg, int tid, bool mine, HuffLds& L)
+ZJ_DEV void huff_stage(const uint8_t* blob, int tid, bool mine, uint32_t sub_index, HuffLds& L)
 {
     const HuffScan* g = huff_hdr(blob);
-    const HuffSub* subs = huff_subs(blob);
-    const uint32_t nsub = g->nsub;
-    const uint32_t f = (uint32_t)wg * HUFF_WG;
-    const uint32_t b0 = subs[f].start;
-    const uint32_t nwords_all = (g->stream_bytes - b0) / 4; // what the stream holds from the workgroup's first byte on
-    const uint32_t nwords = nwords_all < (uint32_t)HUFF_W_WORDS ? nwords_all : (uint32_t)HUFF_W_WORDS;
-    const HuffU4* src = (const HuffU4*)(blob + g->off_stream + b0);
-    if (mine && f + (uint32_t)tid < nsub) {
-        const uint32_t q0 = (subs[f + (uint32_t)tid].start - b0) / 16; // first 16-byte piece of the sub-sequence
-        constexpr int PIECES = HUFF_SUB_MAX / 16 + 1;
+    if (mine) {
+        const uint32_t b0 = huff_subs(blob)[sub_index].start;          // 16-byte aligned
+        const uint32_t pieces_left = (g->stream_bytes - b0) / 16;       // the stream ends with >= 32 zero bytes
+        const HuffU4* src = (const HuffU4*)(blob + g->off_stream + b0);
+        constexpr int PIECES = HUFF_LANE_DATA / 4;
         HuffU4 v[PIECES];
 #pragma unroll
         for (int q = 0; q < PIECES; q++) {
             v[q].x = v[q].y = v[q].z = v[q].w = 0;
-            if ((q0 + q) * 4 + 3 < nwords) v[q] = src[q0 + q];
+            if ((uint32_t)q < pieces_left) v[q] = src[q];
         }
+        uint32_t* dst = L.W + (uint32_t)tid * HUFF_LANE_WORDS;
 #pragma unroll
         for (int q = 0; q < PIECES; q++) {
-            const uint32_t k = (q0 + q) * 4;
-            if (k + 3 < nwords) {
-                const uint32_t sl = huff_slot(k); // the four words of a piece share their 32-word group: contiguous slots
-                L.W[sl] = huff_bswap(v[q].x); L.W[sl + 1] = huff_bswap(v[q].y);
-                L.W[sl + 2] = huff_bswap(v[q].z); L.W[sl + 3] = huff_bswap(v[q].w);
-            }
+            dst[4 * q] = huff_bswap(v[q].x); dst[4 * q + 1] = huff_bswap(v[q].y);
+            dst[4 * q + 2] = huff_bswap(v[q].z); dst[4 * q + 3] = huff_bswap(v[q].w);
         }
     }
     const HuffU4* tsrc = (const HuffU4*)(blob + g->off_tab);
@@ -106,7 +97,6 @@ ZJ_DEV void huff_stage(const uint8_t* blob, int wg, int tid, bool mine, HuffLds&
     uint32_t* hdst = (uint32_t*)&L.hdr;
     for (uint32_t k = (uint32_t)tid; k < sizeof(HuffScan) / 4; k += NT) hdst[k] = hsrc[k];
     if (tid < 64) L.unz[tid] = (uint8_t)huff_unzigzag(tid);
-    if (tid == 0) { L.w0 = b0 / 4; L.nwords = nwords & ~3u; }
 }
 
 // ---- the parse -------------------------------------------------------------------------------------------------------
@@ -151,17 +141,19 @@ ZJ_DEV uint32_t huff_window(uint32_t hi, uint32_t lo, uint32_t off)
 // advance of the zig-zag index (DC: 1, run + 1, ZRL: 16, EOB: 63) -- so a sync round needs the magnitude bits of DC
 // symbols only.  The bit window is 32 bits rebuilt per symbol from two cached stream words (a code is at most 16
 // bits, its magnitude at most 15); a third word is always in flight from LDS.
+// `start_bits`: first bit of the sub-sequence whose words thread `tid` has staged.
 template <bool WRITE>
-ZJ_DEV HuffState huff_run(const HuffLds& L, HuffState s, uint32_t limit, bool last_sub, HuffI4& aux, HuffWrite* w)
+ZJ_DEV HuffState huff_run(const HuffLds& L, uint32_t tid, uint32_t start_bits, HuffState s, uint32_t limit, bool last_sub, HuffI4& aux, HuffWrite* w)
 {
     const HuffScan& h = L.hdr;
-    const uint32_t nwords = L.nwords;
-    const uint32_t rel = s.pos - L.w0 * 32u;
+    const uint32_t* Wl = L.W + tid * HUFF_LANE_WORDS;
+    constexpr uint32_t nwords = HUFF_LANE_DATA;
+    const uint32_t rel = s.pos - start_bits;
     uint32_t k = rel >> 5, off = rel & 31;
     if (off == 0) { off = 32; k -= 1; } // (k may wrap for the very first bit: the word is never looked at)
-    uint32_t hi = k < nwords ? L.W[huff_slot(k)] : 0u;
-    uint32_t lo = k + 1 < nwords ? L.W[huff_slot(k + 1)] : 0u;
-    uint32_t nx = k + 2 < nwords ? L.W[huff_slot(k + 2)] : 0u;
+    uint32_t hi = k < nwords ? Wl[k] : 0u;
+    uint32_t lo = k + 1 < nwords ? Wl[k + 1] : 0u;
+    uint32_t nx = k + 2 < nwords ? Wl[k + 2] : 0u;
     k += 3;
     uint32_t pos = s.pos, j = s.j, z = s.z;
     int32_t n = 0, d0 = 0, d1 = 0, d2 = 0; // blocks completed, DC differences per component
@@ -224,7 +216,7 @@ ZJ_DEV HuffState huff_run(const HuffLds& L, HuffState s, uint32_t limit, bool la
             off -= 32;
             hi = lo;
             lo = nx;
-            nx = k < nwords ? L.W[huff_slot(k)] : 0u;
+            nx = k < nwords ? Wl[k] : 0u;
             k++;
         }
         if (z >= 64) { // the block is complete
@@ -267,39 +259,57 @@ ZJ_DEV uint32_t huff_limit(const uint8_t* blob, const HuffSub* subs, uint32_t i,
     return subs[i + 1].start * 8u;
 }
 
-// does sub-sequence i have work in round `round`?
-ZJ_DEV bool huff_sync_needed(const HuffArgs& a, uint32_t i, uint32_t nsub, const HuffSub* subs)
+// lanes per work-list entry (see HuffArgs::spread); entries > 0
+ZJ_DEV uint32_t huff_spread(const HuffArgs& a, uint32_t nsub, uint32_t entries)
 {
-    if (i >= nsub) return false;
-    if (a.round == 0) return true;
-    if (subs[i].seg & HUFF_FIRST) return false; // its entry state is known, round 0 was final
-    return a.changed[(size_t)((a.round - 1) & 1) * nsub + i - 1] != 0;
+    uint32_t S = nsub / entries;
+    if (S > (uint32_t)a.spread) S = (uint32_t)a.spread;
+    return S ? S : 1u;
 }
 
-// one thread of a synchronisation round (after staging)
-ZJ_DEV void huff_sync_thread(const HuffArgs& a, const HuffLds& L, uint32_t i)
+// which sub-sequence does thread t of a synchronisation round decode?  Rounds 0 and 1: its own (round 1: unless it begins
+// a restart segment -- its entry state is known, round 0 was final).  From round 2 on: entry t of the round's work list.
+// nsub: no work.
+ZJ_DEV uint32_t huff_sync_pick(const HuffArgs& a, uint32_t t, uint32_t nsub, const HuffSub* subs)
+{
+    if (a.round <= 1) return (t < nsub && (a.round == 0 || !(subs[t].seg & HUFF_FIRST))) ? t : nsub;
+    const uint32_t entries = a.ctl[HUFF_CTL_ROUND0 + a.round - 1], S = huff_spread(a, nsub, entries), e = t / S;
+    return (e * S == t && e < entries) ? a.list[(size_t)(a.round & 1) * nsub + e] : nsub;
+}
+
+// round 0, thread t of nthreads: its share of the planes' clearing, coalesced (piece p by thread p mod nthreads)
+ZJ_DEV void huff_clear_planes(const HuffArgs& a, uint32_t t, uint32_t nthreads)
+{
+    HuffU4 zero;
+    zero.x = zero.y = zero.z = zero.w = 0;
+    for (uint32_t p = t; p < a.zero_pieces; p += nthreads) ((HuffU4*)a.zero_base)[p] = zero;
+}
+
+// one thread of a synchronisation round, decoding sub-sequence i (after staging)
+ZJ_DEV void huff_sync_thread(const HuffArgs& a, const HuffLds& L, uint32_t tid, uint32_t i)
 {
     const uint32_t nsub = L.hdr.nsub;
     if (i >= nsub) return;
     const HuffSub* subs = huff_subs(a.blob);
-    uint8_t* ch = a.changed + (size_t)(a.round & 1) * nsub;
-    if (!huff_sync_needed(a, i, nsub, subs)) { ch[i] = 0; return; }
     const HuffSub sub = subs[i];
     HuffState s;
     if (a.round == 0) { s.pos = sub.start * 8u; s.j = 0; s.z = 0; }
-    else s = huff_unpack(a.exit[i - 1]);
+    else s = huff_unpack(a.exit_rd[i - 1]);
     HuffI4 aux;
-    const HuffState o = huff_run<false>(L, s, huff_limit(a.blob, subs, i, sub), false, aux, nullptr);
+    const HuffState o = huff_run<false>(L, tid, sub.start * 8u, s, huff_limit(a.blob, subs, i, sub), false, aux, nullptr);
     const unsigned long long packed = huff_pack(o);
     const bool differs = a.round == 0 || packed != a.exit[i];
     a.exit[i] = packed;
     a.aux[i] = aux;
-    ch[i] = differs ? 1 : 0;
-    if (differs && a.round) huff_add(&a.ctl[HUFF_CTL_ROUND0 + a.round], 1u);
+    // a changed exit state puts the successor on the next round's list (round 0 changes everything: round 1 needs no list)
+    if (differs && a.round && i + 1 < nsub && !(subs[i + 1].seg & HUFF_FIRST)) {
+        const uint32_t at = huff_add_return(&a.ctl[HUFF_CTL_ROUND0 + a.round], 1u);
+        a.list[(size_t)((a.round + 1) & 1) * nsub + at] = i + 1;
+    }
 }
 
 // one thread of the write pass (after staging)
-ZJ_DEV void huff_write_thread(const HuffArgs& a, const HuffLds& L, uint32_t i)
+ZJ_DEV void huff_write_thread(const HuffArgs& a, const HuffLds& L, uint32_t tid, uint32_t i)
 {
     const HuffScan& h = L.hdr;
     if (i >= h.nsub) return;
@@ -333,7 +343,7 @@ ZJ_DEV void huff_write_thread(const HuffArgs& a, const HuffLds& L, uint32_t i)
     w.eoi_seg = h.is_eoi && k + 1 == h.nseg;
     w.ctl = a.ctl;
     HuffI4 aux;
-    (void)huff_run<true>(L, s, huff_limit(a.blob, subs, i, sub), (sub.seg & HUFF_LAST) != 0, aux, &w);
+    (void)huff_run<true>(L, tid, sub.start * 8u, s, huff_limit(a.blob, subs, i, sub), (sub.seg & HUFF_LAST) != 0, aux, &w);
 }
 
 // ---- prefix sums: first block and DC predictors of every sub-sequence ----------------------------------------------
