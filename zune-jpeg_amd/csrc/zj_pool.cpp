@@ -32,9 +32,10 @@ extern "C" int zj_set_pipeline(zj_ctx* c, int on);
 
 namespace {
 // Three submitters keep both PCIe directions and the kernel queue busy when planes go up and pixels come down.  With
-// the entropy stage on the device a file is a dozen short, latency-bound kernels (zj_huff.hip) and almost no upload:
-// more files in flight fill the GPU better.
-constexpr int GPU_SUBMITTERS = 3, GPU_SUBMITTERS_DEVICE_ENTROPY = 8;
+// the entropy stage on the device and the pixels left there, a submitter takes up to eight ready files at once (their
+// scans run as one launch per phase, zj_decode_scans): three submitters x 8 files measured best (4 900 files/s; eight
+// submitters x 4: 3 600).
+constexpr int GPU_SUBMITTERS = 3;
 }
 
 struct zj_pool {
@@ -71,7 +72,7 @@ struct zj_pool {
     std::string last_error;
     int n_workers = 0;
     int device = 0;                      // every thread of the pool binds to it
-    int device_batch = 4;                // files a submitter takes at once when the pixels stay on the device (ZJ_POOL_BATCH)
+    int device_batch = 8;                // files a submitter takes at once when the pixels stay on the device (ZJ_POOL_BATCH)
     // accumulated over the pool's life (under mu): seconds inside the entropy stage / the GPU stage, files
     double entropy_s = 0, gpu_s = 0;
     size_t files_done = 0;
@@ -116,19 +117,17 @@ struct zj_pool {
             } else {
                 if (b.infos) b.infos[i] = info;
                 ready.push_back(Job{i, dec});
-                // (all submitters: those beyond the first three ignore batches with host outputs)
-                cv_ready.notify_all();
+                cv_ready.notify_one();
             }
         }
     }
 
-    // submitters beyond the first three only work on batches whose pixels stay on the device: with 48 MB per file
-    // coming down PCIe, more than three in flight only contend (measured: 1040 -> 900 files/s)
     void gpu_loop(zj_ctx* ctx, int index)
     {
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
-            cv_ready.wait(lk, [&] { return stop || (!ready.empty() && (index < GPU_SUBMITTERS || (batch && batch->on_device))); });
+            (void)index;
+            cv_ready.wait(lk, [&] { return stop || !ready.empty(); });
             if (stop) return;
             Batch& b = *batch;
             // Pixels that stay on the device: take what is ready, up to a batch -- the device entropy stage runs the scans of
@@ -198,7 +197,7 @@ zj_pool* zj_pool_create(int device, int threads, const zj_options* opt, int* sta
     p->device = device;
     *status = ZJ_OK;
     if (const char* e = getenv("ZJ_POOL_BATCH")) { const int v = atoi(e); if (v >= 1 && v <= ZJ_SCAN_BATCH_MAX) p->device_batch = v; }
-    int submitters = o.entropy ? GPU_SUBMITTERS_DEVICE_ENTROPY : GPU_SUBMITTERS;
+    int submitters = GPU_SUBMITTERS;
     if (const char* e = getenv("ZJ_POOL_SUBMITTERS")) { const int v = atoi(e); if (v >= 1 && v <= 64) submitters = v; }
     for (int g = 0; g < submitters && *status == ZJ_OK; g++) {
         int st = ZJ_OK;
