@@ -177,7 +177,6 @@ extern "C" int zje_huff_decode(const uint8_t* blob, int16_t* y, int16_t* cb, int
     std::vector<uint32_t> list(2 * (size_t)nsub);
     std::vector<uint8_t> rel(nsub);
     std::vector<uint32_t> ctl(HUFF_CTL_WORDS, 0);
-    ctl[HUFF_CTL_SEEN] = 0xffffffffu;
     const uint32_t nscan = (nsub + HUFF_SCAN_WG - 1) / HUFF_SCAN_WG;
     std::vector<HuffAgg> wgagg(nscan), wgpre(nscan);
     HuffArgs a;
@@ -239,7 +238,7 @@ extern "C" int zje_huff_decode(const uint8_t* blob, int16_t* y, int16_t* cb, int
         for (uint32_t p = 0; p < pieces; p++) huff_cut_clear(a, first, p);
     }
     if (status) *status = ctl[0];
-    if (stats) { stats[0] = (uint32_t)round; stats[1] = nsub; stats[2] = work; stats[3] = ctl[HUFF_CTL_SEEN]; }
+    if (stats) { stats[0] = (uint32_t)round; stats[1] = nsub; stats[2] = work; stats[3] = ~ctl[HUFF_CTL_SEEN]; }
     return ZJ_OK;
 }
 

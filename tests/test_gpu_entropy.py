@@ -269,3 +269,35 @@ def test_batch_of_scans_in_one_go(zj, ctx):
     finally:
         for p, _ in ptrs:
             ctx.device_free(p)
+
+
+def test_scans_of_one_geometry_share_a_pixel_launch(zj, ctx):
+    """Same size, same tables: the batch runs them through the pixel kernel as frames of one launch (planes at the arena's
+    stride; device outputs equally spaced, like the images of one tensor).  A different file in the middle splits the run."""
+    files = [pil_jpeg(640, 480, quality=88, seed=60 + k) for k in range(7)]
+    files.insert(3, pil_jpeg(656, 480, quality=88, seed=99))
+    want = [zj.Decoder(None, ctx).decode_buffer(f) for f in files]
+    decs = []
+    for f in files:
+        o = zj.ZuneJpegOptions()
+        o.entropy = zj.ENTROPY_GPU_ALWAYS
+        d = zj.Decoder(o, ctx)
+        d.prepare(f)
+        decs.append(d)
+    outs, rcs = zj.finish_pixels_batch(decs, ctx)
+    assert not any(rcs)
+    for o, w in zip(outs, want):
+        assert np.array_equal(o, w)
+    step = 656 * 480 * 3
+    base = ctx.device_alloc(step * len(files) + 64)
+    try:
+        for d, f in zip(decs, files):
+            d.prepare(f)
+        lens, rcs = zj.finish_pixels_batch(decs, ctx, device_ptrs=[(base + k * step, step) for k in range(len(files))])
+        assert not any(rcs)
+        for k, w in enumerate(want):
+            got = np.zeros(w.size, np.uint8)
+            ctx.d2h(got, base + k * step)
+            assert lens[k] == w.size and np.array_equal(got, w), k
+    finally:
+        ctx.device_free(base)

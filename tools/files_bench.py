@@ -96,7 +96,8 @@ def main():
     # device buffer (ctypes releases the GIL inside the library)
     import threading
     NB = 32
-    dptr = [ctx.device_alloc(S * S * 3) for _ in range(NB)]
+    dbase = ctx.device_alloc(S * S * 3 * NB)  # one allocation, images equally spaced (as in a tensor)
+    dptr = [dbase + k * S * S * 3 for k in range(NB)]
     for workers in (1, 4, 16):
         po = zj.ZuneJpegOptions()
         po.entropy = ENT
@@ -110,8 +111,7 @@ def main():
                 pool.decode_files_device(fl, dptr, [S * S * 3] * NB)
             dt = time.perf_counter() - t0
             print(f"zj_pool into HBM, {workers:3d} workers: {NB * reps} files in {dt*1e3:8.1f} ms  {NB*reps/dt:8.1f} files/s  {NB*reps*mp/dt:9.1f} MP/s")
-    for p in dptr:
-        ctx.device_free(p)
+    ctx.device_free(dbase)
     for T in (1, 2, 4, 8, 16):
         per = max(8, args.files // T)
         def work(k, res):

@@ -15,7 +15,8 @@ S, NB = 4096, 32
 blobs = [files_bench.make_jpeg(S, s, 0) for s in range(4)]
 files = [blobs[i % 4] for i in range(NB)]
 ctx = zj.Context()
-dptr = [ctx.device_alloc(S * S * 3) for _ in range(NB)]
+base = ctx.device_alloc(S * S * 3 * NB)  # one allocation, images equally spaced (as in a tensor)
+dptr = [base + k * S * S * 3 for k in range(NB)]
 o = zj.ZuneJpegOptions()
 o.entropy = zj.ENTROPY_GPU
 res = []

@@ -50,8 +50,13 @@ struct zj_ctx {
     int variant = 0;              // kernel variant: 0 packed generation (default), 1 wide generation (round 1), 2 packed with direct stores
     // GPU entropy stage (zj_decode_scan): blob + working set, the three planes (contiguous), control words read back
     // one slot per scan of a batch (zj_decode_scans): blob + working set | planes | pixels on their way to host memory
-    struct HuffSlot { void* buf = nullptr; size_t cap = 0; void* planes = nullptr; size_t pcap = 0; void* out = nullptr; size_t ocap = 0; };
+    struct HuffSlot { void* buf = nullptr; size_t cap = 0; void* planes = nullptr; void* out = nullptr; };
     HuffSlot hslot[ZJ_SCAN_BATCH_MAX];
+    // planes and staged pixels of the slots live in two arenas at a uniform stride, so that scans of one geometry can go
+    // through the pixel kernel as frames of ONE launch (zj_decode_scans)
+    void* harena = nullptr; size_t harena_stride = 0; int harena_slots = 0;
+    void* hout = nullptr; size_t hout_stride = 0; int hout_slots = 0;
+    uint32_t* d_ctl = nullptr;    // the slots' control words, contiguous: one clear, one copy back per call
     uint32_t* h_ctl = nullptr;    // pinned: HUFF_CTL_WORDS per slot
 
     int huff_rounds = 0;          // synchronisation rounds of the last scan
@@ -168,11 +173,11 @@ void zj_ctx_destroy(zj_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < N_SCRATCH; i++)
         if (c->scratch[i]) (void)hipFree(c->scratch[i]);
-    for (auto& sl : c->hslot) {
+    for (auto& sl : c->hslot)
         if (sl.buf) (void)hipFree(sl.buf);
-        if (sl.planes) (void)hipFree(sl.planes);
-        if (sl.out) (void)hipFree(sl.out);
-    }
+    if (c->harena) (void)hipFree(c->harena);
+    if (c->hout) (void)hipFree(c->hout);
+    if (c->d_ctl) (void)hipFree(c->d_ctl);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
 
     for (hipStream_t st : {c->s_up, c->s_run, c->s_down})
@@ -288,19 +293,24 @@ int zj_sync(zj_ctx* c)
 }
 
 /* ---- frame / batch level -------------------------------------------------------------------- */
+// plane_stride (int16 elements) / out_stride (bytes): distance between the frames' planes / pixels when they are not packed
+// back to back (0: they are)
 static int decode_device_impl(zj_ctx* c, const zj_frame_desc* d, const Plan& pl, size_t nframes,
                               const int16_t* d_y, const int16_t* d_cb, const int16_t* d_cr,
-                              uint8_t* d_out, hipStream_t s, int zero_fill)
+                              uint8_t* d_out, hipStream_t s, int zero_fill, long long plane_stride = 0, long long out_stride = 0)
 {
     Params p; // carries the quantisation tables by value: nothing to stage, nothing to order across streams
     fill_params(d, pl, nframes, d_y, d_cb, d_cr, d_out, zero_fill, p);
     p.debug = c->debug;
+    if (plane_stride) p.y_frame_stride = p.c_frame_stride = plane_stride;
+    if (out_stride) p.out_frame_stride = out_stride;
+    const size_t ostride = out_stride ? (size_t)out_stride : pl.out_len;
     if (zero_fill) {
         // rows below the last complete strip are never written by the reference (Q6): zeros
         size_t off[3], len[3];
         const int nr = uncovered_ranges(d, pl, off, len);
         for (size_t f = 0; f < nframes; f++)
-            for (int r = 0; r < nr; r++) ZJ_HIP(c, hipMemsetAsync(d_out + f * pl.out_len + off[r], 0, len[r], s));
+            for (int r = 0; r < nr; r++) ZJ_HIP(c, hipMemsetAsync(d_out + f * ostride + off[r], 0, len[r], s));
     }
     ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->variant, pl.fast ? 1 : 0, p, s));
     return ZJ_OK;
@@ -567,6 +577,23 @@ struct ScanJob {
 };
 size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// the arenas hold `slots` slots of `plane_bytes` / `out_bytes` each
+int scan_arenas(zj_ctx* c, int slots, size_t plane_bytes, size_t out_bytes)
+{
+    auto grow = [&](void** p, size_t* stride, int* have, size_t need) -> int {
+        if (need <= *stride && slots <= *have) return ZJ_OK;
+        if (*p) { ZJ_HIP(c, hipStreamSynchronize(c->stream)); ZJ_HIP(c, hipFree(*p)); *p = nullptr; }
+        const size_t st = need > *stride ? up256(need + need / 8) : *stride;
+        const int n = slots > *have ? slots : *have;
+        ZJ_HIP(c, hipMalloc(p, st * (size_t)n));
+        *stride = st; *have = n;
+        return ZJ_OK;
+    };
+    int rc = grow(&c->harena, &c->harena_stride, &c->harena_slots, plane_bytes);
+    if (rc) return rc;
+    return out_bytes ? grow(&c->hout, &c->hout_stride, &c->hout_slots, out_bytes) : (int)ZJ_OK;
+}
+
 // validates one scan, sizes its slot, fills the working-set pointers
 int scan_setup(zj_ctx* c, ScanJob& j, int slot, const zj_frame_desc* d, const void* blob, size_t blob_bytes, uint8_t* out, int out_on_device)
 {
@@ -585,15 +612,15 @@ int scan_setup(zj_ctx* c, ScanJob& j, int slot, const zj_frame_desc* d, const vo
     j.nsub = h->nsub;
     const size_t nsub = j.nsub, nscan = (nsub + HUFF_SCAN_WG - 1) / HUFF_SCAN_WG;
     const size_t o_exit = up256(blob_bytes), o_aux = o_exit + up256(nsub * 8), o_base = o_aux + up256(nsub * 16),
-                 o_lst = o_base + up256(nsub * 16), o_rel = o_lst + up256(nsub * 8), o_ctl = o_rel + up256(nsub),
-                 o_agg = o_ctl + up256((size_t)HUFF_CTL_WORDS * 4), o_pre = o_agg + up256(nscan * sizeof(HuffAgg)),
+                 o_lst = o_base + up256(nsub * 16), o_rel = o_lst + up256(nsub * 8),
+                 o_agg = o_rel + up256(nsub), o_pre = o_agg + up256(nscan * sizeof(HuffAgg)),
                  total = o_pre + up256(nscan * sizeof(HuffAgg));
     zj_ctx::HuffSlot& sl = c->hslot[slot];
     if ((rc = ensure_buf(c, &sl.buf, &sl.cap, total))) return rc;
     j.yb = up256(j.ylen * 2);
     j.cbytes = up256(j.clen * 2);
-    if ((rc = ensure_buf(c, &sl.planes, &sl.pcap, j.yb + 2 * j.cbytes))) return rc;
-    if (!out_on_device && (rc = ensure_buf(c, &sl.out, &sl.ocap, j.pl.out_len))) return rc;
+    sl.planes = (uint8_t*)c->harena + (size_t)slot * c->harena_stride; // (the caller has sized the arenas for this call)
+    sl.out = out_on_device ? nullptr : (uint8_t*)c->hout + (size_t)slot * c->hout_stride;
     uint8_t* base = (uint8_t*)sl.buf;
     HuffArgs& a = j.a;
     a.blob = base;
@@ -603,7 +630,7 @@ int scan_setup(zj_ctx* c, ScanJob& j, int slot, const zj_frame_desc* d, const vo
     a.exit_rd = a.exit;
     a.list = (uint32_t*)(base + o_lst);
     a.rel = base + o_rel;
-    a.ctl = (uint32_t*)(base + o_ctl);
+    a.ctl = c->d_ctl + (size_t)slot * HUFF_CTL_WORDS;
     a.wgagg = (HuffAgg*)(base + o_agg);
     a.wgpre = (HuffAgg*)(base + o_pre);
     a.plane[0] = (int16_t*)sl.planes;
@@ -626,12 +653,12 @@ int scan_setup(zj_ctx* c, ScanJob& j, int slot, const zj_frame_desc* d, const vo
     return ZJ_OK;
 }
 
-// first: before round 0 (which clears the planes itself); otherwise: before the write pass runs a second time
-int scan_clear(zj_ctx* c, ScanJob& j, hipStream_t s, bool first)
+// before the write pass runs a second time: status, first-seen MCU and the prefix sums' ticket start over, and the planes
+// hold coefficients of a wrong parse
+int scan_clear_again(zj_ctx* c, ScanJob& j, hipStream_t s)
 {
-    ZJ_HIP(c, hipMemsetAsync(j.a.ctl, 0, (first ? (size_t)HUFF_CTL_WORDS : (size_t)HUFF_CTL_ROUND0) * 4, s));
-    ZJ_HIP(c, hipMemsetAsync(j.a.ctl + HUFF_CTL_SEEN, 0xff, 4, s));
-    if (!first) ZJ_HIP(c, hipMemsetAsync(c->hslot[j.slot].planes, 0, j.yb + 2 * j.cbytes, s)); // coefficients of a wrong parse
+    ZJ_HIP(c, hipMemsetAsync(j.a.ctl, 0, (size_t)HUFF_CTL_ROUND0 * 4, s));
+    ZJ_HIP(c, hipMemsetAsync(c->hslot[j.slot].planes, 0, j.yb + 2 * j.cbytes, s));
     return ZJ_OK;
 }
 
@@ -685,12 +712,26 @@ static int decode_scans_impl(zj_ctx* c, size_t n, const zj_frame_desc* descs, co
     ZJ_HIP(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     if (!c->h_ctl) ZJ_HIP(c, hipHostMalloc((void**)&c->h_ctl, (size_t)ZJ_SCAN_BATCH_MAX * HUFF_CTL_WORDS * 4, hipHostMallocPortable));
+    if (!c->d_ctl) ZJ_HIP(c, hipMalloc((void**)&c->d_ctl, (size_t)ZJ_SCAN_BATCH_MAX * HUFF_CTL_WORDS * 4));
     static_assert(ZJ_SCAN_BATCH_MAX == HUFF_BATCH_MAX, "include/zjhip.h and zj_huff.h disagree");
     HuffBatch batch;
     const bool timing = getenv("ZJ_HUFF_TIME") != nullptr;
     const auto t_submit0 = std::chrono::steady_clock::now();
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     if (timing) { for (auto& e : ev) ZJ_HIP(c, hipEventCreate(&e)); ZJ_HIP(c, hipEventRecord(ev[0], s)); }
+    {   // size the arenas for the largest scan of the call (a scan that fails validation below asks for nothing)
+        size_t pmax = 0, omax = 0;
+        for (size_t k = 0; k < n; k++) {
+            if (!blobs[k] || blob_bytes[k] < sizeof(HuffScan)) continue;
+            const HuffScan* h = (const HuffScan*)blobs[k];
+            Plan pl;
+            if (h->magic != HUFF_MAGIC || make_plan(&descs[k], pl)) continue;
+            const size_t pb = up256(zj_plane_len(&descs[k], 0) * 2) + 2 * up256((h->ncomp == 3 ? zj_plane_len(&descs[k], 1) : 0) * 2);
+            if (pb > pmax) pmax = pb;
+            if (!outs_on_device && pl.out_len > omax) omax = pl.out_len;
+        }
+        if (pmax) { const int rc = scan_arenas(c, (int)n, pmax, omax); if (rc) return rc; }
+    }
     std::vector<ScanJob> jobs(n);
     int live[ZJ_SCAN_BATCH_MAX], nlive = 0; // jobs that passed validation, packed: the kernels' argument array
     uint32_t max_nsub = 0;
@@ -710,20 +751,43 @@ static int decode_scans_impl(zj_ctx* c, size_t n, const zj_frame_desc* descs, co
         if (const char* e = getenv("ZJ_HUFF_SPREAD")) { const int v = atoi(e); if (v >= 1 && v <= 64) spread = v; }
         for (int q = 0; q < nlive; q++) batch.a[q].spread = spread;
     }
+    ZJ_HIP(c, hipMemsetAsync(c->d_ctl, 0, n * (size_t)HUFF_CTL_WORDS * 4, s)); // (the planes: round 0 clears them on the side)
     for (int q = 0; q < nlive; q++) {
         ScanJob& j = jobs[(size_t)live[q]];
         ZJ_HIP(c, hipMemcpyAsync((void*)j.a.blob, j.blob, j.blob_bytes, hipMemcpyHostToDevice, s));
-        int rc = scan_clear(c, j, s, true);
-        if (rc) return rc;
     }
     for (int round = 0; round <= planned; round++) ZJ_HIP(c, launch_huff_sync(batch, nlive, max_nsub, round, s));
     if (timing) ZJ_HIP(c, hipEventRecord(ev[1], s));
     ZJ_HIP(c, launch_huff_finish(batch, nlive, max_nsub, s));
     if (timing) ZJ_HIP(c, hipEventRecord(ev[2], s));
-    for (int q = 0; q < nlive; q++) {
-        int rc = scan_pixels(c, jobs[(size_t)live[q]], s, outs_on_device);
+    // Pixel kernel: consecutive scans of one geometry and one set of tables go through it as the frames of ONE launch --
+    // their planes sit at the arena's stride; their pixels too (host outputs: the staging arena; device outputs: if the
+    // caller's pointers are equally spaced, e.g. the images of one tensor)
+    for (int q = 0; q < nlive;) {
+        ScanJob& j0 = jobs[(size_t)live[q]];
+        int run = 1;
+        long long ostride = outs_on_device ? 0 : (long long)c->hout_stride;
+        while (q + run < nlive) {
+            const ScanJob& jn = jobs[(size_t)live[q + run]];
+            if (jn.slot != j0.slot + run || memcmp(jn.d, j0.d, sizeof(zj_frame_desc)) != 0) break;
+            if (outs_on_device) {
+                const long long step = (long long)(jn.d_out - jobs[(size_t)live[q + run - 1]].d_out);
+                if (run == 1) { if (step < (long long)j0.pl.out_len || (step & 15)) break; ostride = step; }
+                else if (step != ostride) break;
+            }
+            run++;
+        }
+        int rc = decode_device_impl(c, j0.d, j0.pl, (size_t)run, j0.a.plane[0], j0.chroma ? j0.a.plane[1] : nullptr,
+                                    j0.chroma ? j0.a.plane[2] : nullptr, j0.d_out, s, 1,
+                                    run > 1 ? (long long)(c->harena_stride / 2) : 0, run > 1 ? ostride : 0);
         if (rc) return rc;
+        q += run;
     }
+    for (int q = 0; q < nlive && !outs_on_device; q++) {
+        ScanJob& j = jobs[(size_t)live[q]];
+        ZJ_HIP(c, hipMemcpyAsync(j.out, j.d_out, j.pl.out_len, hipMemcpyDeviceToHost, s));
+    }
+    ZJ_HIP(c, hipMemcpyAsync(c->h_ctl, c->d_ctl, n * (size_t)HUFF_CTL_WORDS * 4, hipMemcpyDeviceToHost, s)); // every slot's control words
     if (timing) ZJ_HIP(c, hipEventRecord(ev[3], s));
     c->huff_submit_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_submit0).count();
     ZJ_HIP(c, hipStreamSynchronize(s));
@@ -756,7 +820,7 @@ static int decode_scans_impl(zj_ctx* c, size_t n, const zj_frame_desc* descs, co
                 if (j.rounds > most) most = j.rounds;
                 continue;
             }
-            int rc = scan_clear(c, j, s, false); // (the planes may hold coefficients scattered from a wrong parse)
+            int rc = scan_clear_again(c, j, s);
             if (rc) return rc;
             ZJ_HIP(c, launch_huff_finish(one, 1, (uint32_t)j.nsub, s));
             if ((rc = scan_pixels(c, j, s, outs_on_device))) return rc;

@@ -98,7 +98,7 @@ struct HuffArgs {
     uint8_t* rel;              // [nsub] base[i] is relative to its prefix-sum workgroup (add wgpre)
     HuffAgg* wgagg;            // [ceil(nsub / HUFF_SCAN_WG)] totals of the prefix-sum workgroups
     HuffAgg* wgpre;            // the same, exclusive prefix
-    uint32_t* ctl;             // HUFF_CTL_*: status bits, first MCU at which the reference has seen EOI, ticket of the
+    uint32_t* ctl;             // HUFF_CTL_*: status bits, complement of the first MCU at which the reference has seen EOI, ticket of the
                                // prefix-sum workgroups, changes of round r at [HUFF_CTL_ROUND0 + r]
     int16_t* plane[3];
     uint8_t* zero_base;        // round 0 also clears the planes (the write pass stores non-zero coefficients only): the

@@ -38,13 +38,13 @@ struct alignas(16) HuffU4 { uint32_t x, y, z, w; };
 
 #if defined(ZJ_EMU)
 ZJ_DEV void huff_or(uint32_t* p, uint32_t v) { *p |= v; }
-ZJ_DEV void huff_min(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
+ZJ_DEV void huff_max(uint32_t* p, uint32_t v) { if (v > *p) *p = v; }
 ZJ_DEV void huff_add(uint32_t* p, uint32_t v) { *p += v; }
 ZJ_DEV uint32_t huff_add_return(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p += v; return o; }
 ZJ_DEV uint32_t huff_bswap(uint32_t v) { return __builtin_bswap32(v); }
 #else
 ZJ_DEV void huff_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
-ZJ_DEV void huff_min(uint32_t* p, uint32_t v) { atomicMin(p, v); }
+ZJ_DEV void huff_max(uint32_t* p, uint32_t v) { atomicMax(p, v); }
 ZJ_DEV void huff_add(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
 ZJ_DEV uint32_t huff_add_return(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 ZJ_DEV uint32_t huff_bswap(uint32_t v) { return __builtin_bswap32(v); }
@@ -232,7 +232,7 @@ ZJ_DEV HuffState huff_run(const HuffLds& L, uint32_t tid, uint32_t start_bits, H
                         // MCU's last symbol (zj_jpeg.cpp eoi_cut_after_mcu); C grows with the MCU index, so the first MCU
                         // that satisfies it is the minimum
                         const uint32_t c_last = sym_start - w->seg_start_bits;
-                        if (4u * (c_last / 32u + 2u) > w->eoi_d) huff_min(&w->ctl[HUFF_CTL_SEEN], w->mcu);
+                        if (4u * (c_last / 32u + 2u) > w->eoi_d) huff_max(&w->ctl[HUFF_CTL_SEEN], ~w->mcu); // (the complement: all control words start at 0)
                     }
                     w->mcu++;
                     if (++w->mx == h.mcu_x) { w->mx = 0; w->my++; }
@@ -399,14 +399,14 @@ ZJ_DEV void huff_scan_totals(const HuffArgs& a, uint32_t nwg)
 }
 
 // ---- the reference's early exit at EOI ---------------------------------------------------------------------------------
-// ctl[1] = first MCU after which the reference leaves its row loop (or >= total_mcus: none).  The MCUs that follow it
+// ~ctl[HUFF_CTL_SEEN] = first MCU after which the reference leaves its row loop (or >= total_mcus: none).  The MCUs that follow it
 // in the same row loop keep the zeros of the reference's fresh buffers.  The cut has to fall into the LAST row loop
 // (anything earlier shifts later MCUs, zj_jpeg.cpp scan_baseline: left to the CPU walker).  Returns the number of
 // 16-byte pieces to clear and fills first/count; `piece` p of them is cleared by huff_cut_clear.
 ZJ_DEV uint32_t huff_cut_plan(const HuffArgs& a, uint32_t* first_mcu)
 {
     const HuffScan* g = huff_hdr(a.blob);
-    const uint32_t fs = a.ctl[HUFF_CTL_SEEN];
+    const uint32_t fs = ~a.ctl[HUFF_CTL_SEEN];
     if (fs >= g->total_mcus || fs + 1 >= g->total_mcus) return 0;
     if (fs / g->rowlen != (g->total_mcus - 1) / g->rowlen) { huff_or(&a.ctl[HUFF_CTL_STATUS], HUFF_ST_CUT_EARLY); return 0; }
     *first_mcu = fs + 1;
