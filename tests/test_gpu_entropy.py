@@ -92,6 +92,18 @@ def test_planes_on_the_device_equal_the_encoder_s_coefficients(zj, ctx, synth, m
         assert np.array_equal(p, planes[c]), (mode, restart, c)
 
 
+@pytest.mark.parametrize("name", ["hv", "hv_rst", "none", "h_rst", "gray"])
+def test_entropy_golden_fixtures(zj, ctx, name):
+    """tests/golden/entropy_*.npz (tools/make_golden.py): the planes the device leaves in HBM are the encoder's."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", f"entropy_{name}.npz"))
+    g, _ = decoders(zj, ctx, sub=32)
+    desc, _ = g.prepare(z["jpeg"].tobytes())
+    out, rc, st = ctx.decode_scan(desc, g.scan_blob())
+    assert rc == 0 and st == 0
+    for p, c in zip(ctx.scan_planes(), ("y", "cb", "cr")):
+        assert np.array_equal(p, z[c]), (name, c)
+
+
 def test_planes_on_the_device_equal_the_cpu_walker(zj, ctx):
     data = pil_jpeg(1024, 768, quality=93, seed=8)
     g, c = decoders(zj, ctx)

@@ -12,6 +12,9 @@ Fixtures (all tiny):
   frame_hv_rgb_96x80.npz   a 3-strip 4:2:0 frame whose height is not a multiple of the strip
   adversarial_hv_rgb.npz   full-range coefficients / tables (wrap-around paths, Q1/Q7)
   idct_blocks.npz          256 random blocks + expected pixel blocks (incl. DC-only, wrap)
+  entropy_<name>.npz       a small baseline JPEG written by tools/jpeg_enc.py from seeded coefficient planes (jpeg: the
+                           file's bytes; y/cb/cr: exactly the planes the encoder was given -- ground truth for BOTH entropy
+                           decoders, the CPU walker and the device stage; width, height, h_max, v_max, restart)
   ext_<mode>_<kind>.npz    the output EXTENSIONS (no reference output exists): kind plain (ZJ_FLAG_PLAIN_TAIL),
                            rgba (ZJ_CS_RGBA), chw (ZJ_LAYOUT_CHW); fields flags / out_layout say how to ask for them
 """
@@ -72,6 +75,16 @@ def main():
     qt = rng.integers(1, 256, size=64).astype(np.int32)
     np.savez_compressed(os.path.join(OUT, "idct_blocks.npz"), blocks=blocks, qt=qt,
                         expected=onp.idct_blocks(blocks, qt))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import jpeg_enc
+    for name, (hs, vs, ncomp, w, h, restart) in {"hv": (2, 2, 3, 72, 56, 0), "hv_rst": (2, 2, 3, 72, 56, 2), "none": (1, 1, 3, 40, 24, 0),
+                                                 "h_rst": (2, 1, 3, 50, 30, 1), "gray": (1, 1, 1, 64, 40, 0)}.items():
+        planes = jpeg_enc.small_planes(w, h, hs, vs, ncomp, seed=700 + w + restart)
+        data = jpeg_enc.encode_baseline(planes, synth.quant_tables(85), w, h, hs, vs, ncomp, restart=restart)
+        extra = {c: planes[i] for i, c in enumerate(("y", "cb", "cr")[:ncomp])}
+        np.savez_compressed(os.path.join(OUT, f"entropy_{name}.npz"), jpeg=np.frombuffer(data, np.uint8), width=w, height=h,
+                            h_max=hs, v_max=vs, components=ncomp, restart=restart, **extra)
+        total += len(data)
     print("wrote fixtures to", OUT, "expected bytes:", total)
 
 
