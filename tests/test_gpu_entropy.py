@@ -313,3 +313,24 @@ def test_scans_of_one_geometry_share_a_pixel_launch(zj, ctx):
             assert lens[k] == w.size and np.array_equal(got, w), k
     finally:
         ctx.device_free(base)
+
+
+def test_files_to_a_torch_tensor(zj, ctx):
+    """FileBatchDecoder.to_tensor: 20 files (more than one batch) of one size -> [N, H, W, 3] uint8 on the GPU; a
+    progressive file among them takes the CPU walker, same bytes."""
+    import io
+    import torch
+    from PIL import Image
+    files = [pil_jpeg(512, 384, quality=85, seed=70 + k) for k in range(19)]
+    b = io.BytesIO()
+    Image.fromarray(np.random.default_rng(9).integers(0, 256, (384, 512, 3), dtype=np.uint8)).save(b, "JPEG", quality=85, progressive=True)
+    files.insert(7, b.getvalue())
+    fb = zj.FileBatchDecoder(ctx)
+    try:
+        t = fb.to_tensor(files)
+        assert tuple(t.shape) == (20, 384, 512, 3) and t.dtype == torch.uint8 and t.is_cuda
+        got = t.cpu().numpy()
+        for k, f in enumerate(files):
+            assert np.array_equal(got[k].reshape(-1), zj.Decoder(None, ctx).decode_buffer(f)), k
+    finally:
+        fb.close()

@@ -83,6 +83,7 @@ class FrameDesc(C.Structure):  # zj_frame_desc
 
 
 ENTROPY_CPU, ENTROPY_GPU, ENTROPY_GPU_ALWAYS = 0, 1, 2
+ZJ_SCAN_BATCH_MAX = 16
 RETRY_CPU = 1  # zj_decode_scan: the device hands the scan back
 # csrc/zj_huff.h HUFF_ST_*
 HUFF_ST = {1: "bad code", 2: "run past 63", 4: "bits exhausted", 8: "EOI cut before the last row loop", 16: "phase",
@@ -678,6 +679,61 @@ def finish_pixels_batch(decoders, ctx, outs=None, device_ptrs=None):
     if device_ptrs is not None:
         return list(lens), list(rcs)
     return [o[: lens[k]] for k, o in enumerate(outs)], list(rcs)
+
+
+class FileBatchDecoder:
+    """JPEG files -> pixels left in HBM, e.g. a uint8 CUDA tensor [N, H, W, C] for PyTorch-ROCm consumers.
+    Keeps `capacity` decoders (their prepared scans live in pinned memory) and one context; every call prepares the files
+    on the CPU (headers + byte-level preparation) and finishes them in batches through zj_decoder_finish_pixels_batch:
+    the entropy stage of a batch is one launch per phase, and images of one size that land equally spaced -- the rows of
+    a tensor do -- share one pixel-kernel launch.  Progressive files and whatever the device hands back take the CPU
+    walker; the bytes are the same."""
+
+    def __init__(self, ctx=None, options=None, capacity=ZJ_SCAN_BATCH_MAX):
+        if options is None:
+            options = ZuneJpegOptions()
+            options.entropy = ENTROPY_GPU
+            options.pinned_planes = True
+        self._ctx = ctx if ctx is not None else Context()
+        self._out_cs = int(options.out_colorspace)
+        self._layout = int(options.out_layout)
+        self._decs = [Decoder(options, self._ctx) for _ in range(max(1, min(int(capacity), ZJ_SCAN_BATCH_MAX)))]
+
+    def close(self):
+        for d in self._decs:
+            d.close()
+        self._decs = []
+
+    def decode(self, files, device_ptrs):
+        """files[k] -> device_ptrs[k] = (pointer, capacity).  Returns (lengths, infos); raises DecodeError on the first failure."""
+        lens, infos = [], []
+        for base in range(0, len(files), len(self._decs)):
+            chunk = files[base:base + len(self._decs)]
+            for d, f in zip(self._decs, chunk):
+                infos.append(d.prepare(f)[1])
+            ln, rcs = finish_pixels_batch(self._decs[:len(chunk)], self._ctx, device_ptrs=device_ptrs[base:base + len(chunk)])
+            for d, rc in zip(self._decs, rcs):
+                if rc:
+                    d._raise(rc)
+            lens += ln
+        return lens, infos
+
+    def to_tensor(self, files, device="cuda:0"):
+        """Files of ONE size -> uint8 tensor [N, H, W, C] ([N, C, H, W] with LAYOUT_CHW) on `device`."""
+        import torch
+        info = self._decs[0].read_headers(files[0])
+        nc = 1 if info.components == 1 else ColorSpace(self._out_cs).num_components()
+        h, w = int(info.height), int(info.width)
+        shape = (len(files), nc, h, w) if self._layout == LAYOUT_CHW else (len(files), h, w, nc)
+        t = torch.empty(shape, dtype=torch.uint8, device=device)
+        step = h * w * nc
+        if step % 16:
+            raise ZjError(ERR_ARG, "to_tensor: width * height * components must be a multiple of 16 (rows of the tensor are the outputs)")
+        lens, infos = self.decode(files, [(t.data_ptr() + k * step, step) for k in range(len(files))])
+        for i in infos:
+            if (int(i.width), int(i.height)) != (w, h):
+                raise ZjError(ERR_ARG, "to_tensor: files of different sizes")
+        return t
 
 
 class Pool:
