@@ -174,7 +174,7 @@ extern "C" int zje_huff_decode(const uint8_t* blob, int16_t* y, int16_t* cb, int
     const uint32_t nsub = g->nsub;
     std::vector<unsigned long long> exitv(nsub), exit_before(nsub);
     std::vector<HuffI4> aux(nsub), base(nsub);
-    std::vector<uint32_t> list(2 * (size_t)nsub);
+    std::vector<uint32_t> list(2 * (size_t)HUFF_LIST_FACTOR * nsub);
     std::vector<uint8_t> rel(nsub);
     std::vector<uint32_t> ctl(HUFF_CTL_WORDS, 0);
     const uint32_t nscan = (nsub + HUFF_SCAN_WG - 1) / HUFF_SCAN_WG;
@@ -193,13 +193,19 @@ extern "C" int zje_huff_decode(const uint8_t* blob, int16_t* y, int16_t* cb, int
     for (;; round++) {
         if (round > HUFF_MAX_ROUNDS) { ctl[0] |= HUFF_ST_NO_SYNC; break; }
         a.round = round;
+        if (g->nper && huff_periodic_before(round)) // the periodic-run rule in front of this round
+            for (uint32_t i = 0; i < nsub; i++) huff_periodic_thread(a, i, round);
         if (round >= 2 && ctl[HUFF_CTL_ROUND0 + round - 1] == 0) break; // (the device's no-op rounds)
         // the device runs all threads of a round at once: nobody sees an exit state of the SAME round -- the round reads
         // its predecessors' states from a copy taken before it
         exit_before = exitv;
         a.exit_rd = exit_before.data();
         uint32_t todo = nsub;
-        if (round >= 2) { const uint32_t entries = ctl[HUFF_CTL_ROUND0 + round - 1]; todo = entries * huff_spread(a, nsub, entries); }
+        if (round >= 2) {
+            uint32_t entries = ctl[HUFF_CTL_ROUND0 + round - 1];
+            if (entries > HUFF_LIST_FACTOR * nsub) entries = HUFF_LIST_FACTOR * nsub;
+            todo = entries * huff_spread(a, nsub, entries);
+        }
         for (uint32_t wg = 0; wg * HUFF_WG < todo; wg++) {
             uint32_t pick[HUFF_WG];
             memset((void*)&L, 0x7B, sizeof L);

@@ -612,7 +612,7 @@ int scan_setup(zj_ctx* c, ScanJob& j, int slot, const zj_frame_desc* d, const vo
     j.nsub = h->nsub;
     const size_t nsub = j.nsub, nscan = (nsub + HUFF_SCAN_WG - 1) / HUFF_SCAN_WG;
     const size_t o_exit = up256(blob_bytes), o_aux = o_exit + up256(nsub * 8), o_base = o_aux + up256(nsub * 16),
-                 o_lst = o_base + up256(nsub * 16), o_rel = o_lst + up256(nsub * 8),
+                 o_lst = o_base + up256(nsub * 16), o_rel = o_lst + up256(nsub * 8 * HUFF_LIST_FACTOR),
                  o_agg = o_rel + up256(nsub), o_pre = o_agg + up256(nscan * sizeof(HuffAgg)),
                  total = o_pre + up256(nscan * sizeof(HuffAgg));
     zj_ctx::HuffSlot& sl = c->hslot[slot];
@@ -756,7 +756,9 @@ static int decode_scans_impl(zj_ctx* c, size_t n, const zj_frame_desc* descs, co
         ScanJob& j = jobs[(size_t)live[q]];
         ZJ_HIP(c, hipMemcpyAsync((void*)j.a.blob, j.blob, j.blob_bytes, hipMemcpyHostToDevice, s));
     }
-    for (int round = 0; round <= planned; round++) ZJ_HIP(c, launch_huff_sync(batch, nlive, max_nsub, round, s));
+    bool periodic = false; // some scan has periodic runs (flat areas): the rule of zj_huff.h runs between the rounds
+    for (int q = 0; q < nlive; q++) periodic = periodic || jobs[(size_t)live[q]].h->nper != 0;
+    for (int round = 0; round <= planned; round++) ZJ_HIP(c, launch_huff_sync(batch, nlive, max_nsub, round, periodic, s));
     if (timing) ZJ_HIP(c, hipEventRecord(ev[1], s));
     ZJ_HIP(c, launch_huff_finish(batch, nlive, max_nsub, s));
     if (timing) ZJ_HIP(c, hipEventRecord(ev[2], s));
@@ -806,7 +808,7 @@ static int decode_scans_impl(zj_ctx* c, size_t n, const zj_frame_desc* descs, co
             int round = planned, group = 16;
             while (!j.synced && round < j.max_rounds) {
                 const int first = round + 1;
-                for (int k = 0; k < group && round < j.max_rounds; k++) ZJ_HIP(c, launch_huff_sync(one, 1, (uint32_t)j.nsub, ++round, s));
+                for (int k = 0; k < group && round < j.max_rounds; k++) ZJ_HIP(c, launch_huff_sync(one, 1, (uint32_t)j.nsub, ++round, j.h->nper != 0, s));
                 ZJ_HIP(c, hipMemcpyAsync(j.h_ctl, j.a.ctl, (size_t)HUFF_CTL_WORDS * 4, hipMemcpyDeviceToHost, s));
                 ZJ_HIP(c, hipStreamSynchronize(s));
                 for (int r = first; r <= round; r++)

@@ -69,11 +69,27 @@ struct HuffScan { // header of the blob; every off_* is a byte offset from the h
     uint32_t off_tab, off_sub, off_seg, off_stream, stream_bytes; // stream_bytes: multiple of 16, >= 32 zero bytes at the end
     uint32_t sub_bytes;        // nominal sub-sequence size (the last one of a segment is shorter)
     uint32_t round_budget;     // synchronisation rounds worth spending before the CPU walker is the faster way out
+    uint32_t off_per, nper;    // periodic runs (below): per-sub-sequence words, how many are non-zero
     uint32_t comp_of_blk;      // 2 bits per block of the MCU: its component
     uint16_t dc_off[4], ac_off[4]; // per component: entry offset of its decoding tables
     HuffBlk blk[HUFF_MAX_BPM];
     HuffComp comp[3];
 };
+
+// Periodic runs.  A flat area is a run of identical tiny blocks: a periodic bit stream in which a decoder that is out of
+// step settles into a cycle of its own and never meets the true parse, so the true state would advance one sub-sequence
+// per round.  But where sub-sequence i holds the same bytes as sub-sequence i - q (q <= 8: the period in bits need not
+// divide the sub-sequence size), the same entry state relative to its start gives the same exit state: once the second
+// period of a run closes on itself (exit[a+q-1] = exit[a-1] shifted by q sub-sequences, a = second period), every later
+// sub-sequence of the run is a shifted copy of its counterpart in that period.  The host finds the runs (memcmp against
+// the previous eight sub-sequences); the periodic pass (huff_periodic_thread) applies the rule between rounds and puts
+// what it changed on the next round's work list, where it is verified by decoding like everything else.
+//   word i: 0, or (q << 28) | r0 for a sub-sequence the rule may predict: r0 = first sub-sequence of the run, i >= r0 + 2q
+// the periodic pass runs in front of every second round (a run's second period has to be right before the rule can fire:
+// ~2q rounds after the state in front of the run is; the pass itself is a few microseconds)
+constexpr bool huff_periodic_before(int round) { return round >= 2 && (round & 1) == 0; }
+constexpr uint32_t HUFF_LIST_FACTOR = 3; // a work list holds up to 3 x nsub entries
+constexpr uint32_t HUFF_PER_QSHIFT = 28, HUFF_PER_MASK = (1u << 28) - 1, HUFF_PER_MAXQ = 8;
 
 struct alignas(16) HuffI4 { int32_t x, y, z, w; };
 // prefix sums (blocks completed, DC difference sums per component): a running value; `reset`: it is absolute because a
@@ -92,7 +108,7 @@ struct HuffArgs {
                                // points it at a copy taken before the round -- on the device all threads of a round run at once)
     HuffI4* aux;               // [nsub] blocks completed, DC difference sums per component
     HuffI4* base;              // [nsub] first block index, DC predictors (after the scan kernel)
-    uint32_t* list;            // [2][nsub] from round 2 on: the sub-sequences a round has to decode again (those whose
+    uint32_t* list;            // [2][HUFF_LIST_FACTOR * nsub] from round 2 on: the sub-sequences a round has to decode again (those whose
                                // predecessor's exit state changed in the round before), compact, so that the waves of a
                                // sparse round are full; parity = round & 1, length = the change counter of the round before
     uint8_t* rel;              // [nsub] base[i] is relative to its prefix-sum workgroup (add wgpre)

@@ -22,13 +22,25 @@ __global__ __launch_bounds__(HUFF_WG) void zj_huff_sync_kernel(const HuffBatch a
     if (round >= 2 && a.ctl[HUFF_CTL_ROUND0 + round - 1] == 0) return;
     // rounds 0 and 1 decode (nearly) every sub-sequence in place; later rounds the entries of their work list
     uint32_t work = nsub;
-    if (round >= 2) { const uint32_t entries = a.ctl[HUFF_CTL_ROUND0 + round - 1]; work = entries * huff_spread(a, nsub, entries); }
+    if (round >= 2) {
+        uint32_t entries = a.ctl[HUFF_CTL_ROUND0 + round - 1];
+        if (entries > HUFF_LIST_FACTOR * nsub) entries = HUFF_LIST_FACTOR * nsub;
+        work = entries * huff_spread(a, nsub, entries);
+    }
     if (blockIdx.x * HUFF_WG >= work) return;
     const uint32_t i = huff_sync_pick(a, blockIdx.x * HUFF_WG + threadIdx.x, nsub, huff_subs(a.blob));
     if (round == 0) huff_clear_planes(a, blockIdx.x * HUFF_WG + threadIdx.x, ((nsub + HUFF_WG - 1) / HUFF_WG) * HUFF_WG);
     huff_stage<HUFF_WG>(a.blob, (int)threadIdx.x, i < nsub, i, L);
     __syncthreads();
     huff_sync_thread(a, L, threadIdx.x, i);
+}
+
+// the periodic-run rule between two rounds (zj_huff.h)
+__global__ __launch_bounds__(HUFF_WG) void zj_huff_periodic_kernel(const HuffBatch args, int next_round)
+{
+    const HuffArgs a = args.a[blockIdx.y];
+    if (huff_hdr(a.blob)->nper == 0) return;
+    huff_periodic_thread(a, blockIdx.x * HUFF_WG + threadIdx.x, next_round);
 }
 
 __global__ __launch_bounds__(HUFF_WG) void zj_huff_write_kernel(const HuffBatch args)
@@ -82,9 +94,14 @@ __global__ __launch_bounds__(256) void zj_huff_cut_kernel(const HuffBatch args)
     for (uint32_t p = threadIdx.x; p < pieces; p += 256) huff_cut_clear(a, first, p);
 }
 
-hipError_t launch_huff_sync(const HuffBatch& b, int njobs, uint32_t max_nsub, int round, hipStream_t s)
+// periodic: some scan of the batch has periodic runs -- the rule runs in front of the rounds huff_periodic_before() names
+hipError_t launch_huff_sync(const HuffBatch& b, int njobs, uint32_t max_nsub, int round, bool periodic, hipStream_t s)
 {
-    hipLaunchKernelGGL(zj_huff_sync_kernel, dim3((max_nsub + HUFF_WG - 1) / HUFF_WG, njobs), dim3(HUFF_WG), 0, s, b, round);
+    if (periodic && huff_periodic_before(round))
+        hipLaunchKernelGGL(zj_huff_periodic_kernel, dim3((max_nsub + HUFF_WG - 1) / HUFF_WG, njobs), dim3(HUFF_WG), 0, s, b, round);
+    // from round 2 on a work list may hold up to HUFF_LIST_FACTOR x nsub entries (workgroups past its end leave at once)
+    const uint32_t threads = round >= 2 && periodic ? HUFF_LIST_FACTOR * max_nsub : max_nsub;
+    hipLaunchKernelGGL(zj_huff_sync_kernel, dim3((threads + HUFF_WG - 1) / HUFF_WG, njobs), dim3(HUFF_WG), 0, s, b, round);
     return hipGetLastError();
 }
 hipError_t launch_huff_finish(const HuffBatch& b, int njobs, uint32_t max_nsub, hipStream_t s)

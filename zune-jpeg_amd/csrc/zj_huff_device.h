@@ -262,6 +262,7 @@ ZJ_DEV uint32_t huff_limit(const uint8_t* blob, const HuffSub* subs, uint32_t i,
 // lanes per work-list entry (see HuffArgs::spread); entries > 0
 ZJ_DEV uint32_t huff_spread(const HuffArgs& a, uint32_t nsub, uint32_t entries)
 {
+    if (entries > HUFF_LIST_FACTOR * nsub) entries = HUFF_LIST_FACTOR * nsub; // (the counter ran past the list: status raised)
     uint32_t S = nsub / entries;
     if (S > (uint32_t)a.spread) S = (uint32_t)a.spread;
     return S ? S : 1u;
@@ -273,8 +274,10 @@ ZJ_DEV uint32_t huff_spread(const HuffArgs& a, uint32_t nsub, uint32_t entries)
 ZJ_DEV uint32_t huff_sync_pick(const HuffArgs& a, uint32_t t, uint32_t nsub, const HuffSub* subs)
 {
     if (a.round <= 1) return (t < nsub && (a.round == 0 || !(subs[t].seg & HUFF_FIRST))) ? t : nsub;
-    const uint32_t entries = a.ctl[HUFF_CTL_ROUND0 + a.round - 1], S = huff_spread(a, nsub, entries), e = t / S;
-    return (e * S == t && e < entries) ? a.list[(size_t)(a.round & 1) * nsub + e] : nsub;
+    uint32_t entries = a.ctl[HUFF_CTL_ROUND0 + a.round - 1];
+    if (entries > HUFF_LIST_FACTOR * nsub) entries = HUFF_LIST_FACTOR * nsub;
+    const uint32_t S = huff_spread(a, nsub, entries), e = t / S;
+    return (e * S == t && e < entries) ? a.list[(size_t)(a.round & 1) * HUFF_LIST_FACTOR * nsub + e] : nsub;
 }
 
 // round 0, thread t of nthreads: its share of the planes' clearing, coalesced (piece p by thread p mod nthreads)
@@ -303,8 +306,10 @@ ZJ_DEV void huff_sync_thread(const HuffArgs& a, const HuffLds& L, uint32_t tid, 
     a.aux[i] = aux;
     // a changed exit state puts the successor on the next round's list (round 0 changes everything: round 1 needs no list)
     if (differs && a.round && i + 1 < nsub && !(subs[i + 1].seg & HUFF_FIRST)) {
+        // (the periodic pass may put a sub-sequence on a list a second time: room for that, and a status if it runs out)
         const uint32_t at = huff_add_return(&a.ctl[HUFF_CTL_ROUND0 + a.round], 1u);
-        a.list[(size_t)((a.round + 1) & 1) * nsub + at] = i + 1;
+        if (at < HUFF_LIST_FACTOR * nsub) a.list[(size_t)((a.round + 1) & 1) * HUFF_LIST_FACTOR * nsub + at] = i + 1;
+        else huff_or(&a.ctl[HUFF_CTL_STATUS], HUFF_ST_NO_SYNC);
     }
 }
 
@@ -344,6 +349,40 @@ ZJ_DEV void huff_write_thread(const HuffArgs& a, const HuffLds& L, uint32_t tid,
     w.ctl = a.ctl;
     HuffI4 aux;
     (void)huff_run<true>(L, tid, sub.start * 8u, s, huff_limit(a.blob, subs, i, sub), (sub.seg & HUFF_LAST) != 0, aux, &w);
+}
+
+// ---- periodic runs (zj_huff.h) -----------------------------------------------------------------------------------------
+// One thread per sub-sequence, between two rounds; `next_round` is the round that will verify what this pass changes.
+ZJ_DEV void huff_periodic_thread(const HuffArgs& a, uint32_t i, int next_round)
+{
+    const HuffScan* g = huff_hdr(a.blob);
+    const uint32_t nsub = g->nsub;
+    if (i >= nsub) return;
+    const uint32_t* per = (const uint32_t*)(a.blob + g->off_per);
+    const uint32_t w = per[i];
+    if (!w) return;
+    const uint32_t q = w >> HUFF_PER_QSHIFT, r0 = w & HUFF_PER_MASK, a0 = r0 + q;
+    const uint32_t shift = q * g->sub_bytes * 8u; // bits from one period to the next
+    // does the second period close on itself?
+    const HuffState e1 = huff_unpack(a.exit[a0 - 1]), e2 = huff_unpack(a.exit[a0 + q - 1]);
+    if (e2.pos - e1.pos != shift || e2.j != e1.j || e2.z != e1.z) return;
+    const uint32_t t = a0 + (i - a0) % q; // the counterpart in the second period
+    HuffState p = huff_unpack(a.exit[t]);
+    p.pos += (i - t) * g->sub_bytes * 8u;
+    const unsigned long long packed = huff_pack(p);
+    if (packed == a.exit[i]) return;
+    a.exit[i] = packed;
+    a.aux[i] = a.aux[t];
+    // verified by decoding in the next round; so is the sub-sequence behind the run's last predicted one
+    uint32_t* cnt = &a.ctl[HUFF_CTL_ROUND0 + next_round - 1];
+    uint32_t* list = a.list + (size_t)(next_round & 1) * HUFF_LIST_FACTOR * nsub;
+    const uint32_t cap = HUFF_LIST_FACTOR * nsub;
+    uint32_t at = huff_add_return(cnt, 1u);
+    if (at < cap) list[at] = i; else huff_or(&a.ctl[HUFF_CTL_STATUS], HUFF_ST_NO_SYNC);
+    if (i + 1 < nsub && per[i + 1] != w && !(huff_subs(a.blob)[i + 1].seg & HUFF_FIRST)) {
+        at = huff_add_return(cnt, 1u);
+        if (at < cap) list[at] = i + 1; else huff_or(&a.ctl[HUFF_CTL_STATUS], HUFF_ST_NO_SYNC);
+    }
 }
 
 // ---- prefix sums: first block and DC predictors of every sub-sequence ----------------------------------------------

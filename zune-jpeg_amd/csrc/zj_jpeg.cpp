@@ -1057,7 +1057,8 @@ int prepare_scan(zj_decoder* d, const uint8_t* p, const uint8_t* end)
     auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t off_tab = up16(sizeof(HuffScan));
     const size_t off_sub = up16(off_tab + (size_t)tab_used * 2);
-    const size_t off_seg = up16(off_sub + (max_sub + 1) * sizeof(HuffSub));
+    const size_t off_per = up16(off_sub + (max_sub + 1) * sizeof(HuffSub));
+    const size_t off_seg = up16(off_per + (max_sub + 1) * sizeof(uint32_t));
     const size_t off_stream = up16(off_seg + (size_t)nseg * sizeof(HuffSeg));
     const size_t cap = off_stream + scan_bytes + 16 * (size_t)nseg + 64;
     uint8_t* blob = (uint8_t*)d->blob_store.ensure(cap, d->pinned);
@@ -1089,6 +1090,32 @@ int prepare_scan(zj_decoder* d, const uint8_t* p, const uint8_t* end)
         o = next;
     }
     memset(stream + o, 0, 32);
+    // Periodic runs (zj_huff.h): sub-sequence i holds the bytes of sub-sequence i - q.  Only whole sub-sequences that
+    // are not the last of their segment (the parse of one looks up to 31 bits into the next).
+    uint32_t* per = (uint32_t*)(blob + off_per);
+    memset(per, 0, (nsub + 1) * sizeof(uint32_t));
+    size_t nper = 0;
+    {
+        std::vector<uint8_t> qof(nsub, 0);
+        for (size_t i = 1; i + 1 < nsub; i++) {
+            if ((subs[i].seg & (HUFF_FIRST | HUFF_LAST)) || (subs[i + 1].seg & HUFF_FIRST)) continue;
+            const uint8_t* me = stream + subs[i].start;
+            for (size_t q = 1; q <= HUFF_PER_MAXQ && q <= i; q++) {
+                if ((subs[i - q].seg & HUFF_SEG_MASK) != (subs[i].seg & HUFF_SEG_MASK)) break;
+                const uint8_t* other = stream + subs[i - q].start;
+                if (memcmp(me, other, 8) == 0 && memcmp(me, other, sub) == 0) { qof[i] = (uint8_t)q; break; }
+            }
+        }
+        for (size_t i = 1; i < nsub;) {
+            if (!qof[i]) { i++; continue; }
+            const size_t q = qof[i], s0 = i; // a stretch [s0, e] of consecutive sub-sequences with the same q
+            size_t e = i;
+            while (e + 1 < nsub && qof[e + 1] == q) e++;
+            const size_t r0 = s0 - q; // the run: [r0, e]; predicted: [r0 + 2q, e - 1] (e looks into e + 1, which is not part of it)
+            for (size_t k = r0 + 2 * q; k + 1 <= e; k++) { per[k] = (uint32_t)((q << HUFF_PER_QSHIFT) | r0); nper++; }
+            i = e + 1;
+        }
+    }
     subs[nsub].start = (uint32_t)o; // sentinel
     subs[nsub].seg = 0;
     h.magic = HUFF_MAGIC;
@@ -1099,6 +1126,8 @@ int prepare_scan(zj_decoder* d, const uint8_t* p, const uint8_t* end)
     h.is_eoi = is_eoi ? 1 : 0;
     h.sub_bytes = (uint32_t)sub;
     h.round_budget = (uint32_t)budget;
+    h.off_per = (uint32_t)off_per;
+    h.nper = (uint32_t)nper;
     h.rowlen = (uint32_t)eoi_rowlen(d);
     h.tab_entries = (uint32_t)tab_used;
     h.off_tab = (uint32_t)off_tab; h.off_sub = (uint32_t)off_sub; h.off_seg = (uint32_t)off_seg;

@@ -25,7 +25,7 @@ int lab_count();
 const char* lab_name(int i);
 hipError_t launch_lab(int i, const int32_t qt[3][64], int* out, int blocks, int iters, hipStream_t s);
 // b: the working sets of njobs scans; max_nsub: the largest scan's sub-sequence count
-hipError_t launch_huff_sync(const HuffBatch& b, int njobs, uint32_t max_nsub, int round, hipStream_t s); // one synchronisation round
+hipError_t launch_huff_sync(const HuffBatch& b, int njobs, uint32_t max_nsub, int round, bool periodic, hipStream_t s); // one synchronisation round (+ the periodic-run pass in front of it)
 hipError_t launch_huff_finish(const HuffBatch& b, int njobs, uint32_t max_nsub, hipStream_t s);         // prefix sums, write pass, EOI cut
 hipError_t launch_ub_clock(unsigned long long* out, int blocks, int iters, hipStream_t s);
 } // namespace zj
