@@ -334,3 +334,23 @@ def test_files_to_a_torch_tensor(zj, ctx):
             assert np.array_equal(got[k].reshape(-1), zj.Decoder(None, ctx).decode_buffer(f)), k
     finally:
         fb.close()
+
+
+def test_blown_out_sky_is_bridged_by_the_periodic_run_rule(zj, ctx):
+    """A third of the image is one flat run (hundreds of identical sub-sequences): without the rule of zj_huff.h the true
+    state would cross it one sub-sequence per round and the scan would come back to the CPU."""
+    from PIL import Image
+    import io
+    a = np.full((2048, 2048, 3), 255, np.uint8)
+    small = np.random.default_rng(1).integers(0, 256, (45, 64, 3), dtype=np.uint8)
+    a[700:] = np.asarray(Image.fromarray(small).resize((2048, 1348), Image.BICUBIC))
+    b = io.BytesIO()
+    Image.fromarray(a).save(b, "JPEG", quality=90)
+    data = b.getvalue()
+    o = zj.ZuneJpegOptions()
+    o.entropy = zj.ENTROPY_GPU
+    g = zj.Decoder(o, ctx)
+    got = g.decode_buffer(data)
+    assert g.scan_blob() is not None and g.gpu_status() == 0
+    assert ctx.scan_stats()[0] <= 24
+    assert np.array_equal(got, zj.Decoder(None, ctx).decode_buffer(data))
