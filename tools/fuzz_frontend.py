@@ -71,6 +71,12 @@ def main():
         seeds.append(jpeg_enc.encode_progressive(pl, qts, w, h, hs, vs, 3))
     for name in ("test-baseline.jpg", "test-progressive.jpg"):
         seeds.append(open(os.path.join(ROOT, "tests", "golden", name), "rb").read()[:6000])  # headers + start of data
+    # flat pages: periodic runs, which the device stage bridges with a rule of its own (csrc/zj_huff.h)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_huff_emu import document_like
+    seeds.append(document_like(640, 480))
+    seeds.append(document_like(512, 512, gray=True))
+    seeds.append(document_like(400, 300, subsampling=0))
     rng = np.random.default_rng(7)
     decs = []
     for threads in (1, 3):
