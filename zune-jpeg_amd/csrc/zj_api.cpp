@@ -645,9 +645,10 @@ int scan_setup(zj_ctx* c, ScanJob& j, int slot, const zj_frame_desc* d, const vo
     const uint32_t sub_bytes = h->sub_bytes >= 16 && h->sub_bytes <= (uint32_t)HUFF_SUB_MAX ? h->sub_bytes : (uint32_t)HUFF_SUB_MAX;
     j.max_rounds = h->round_budget >= 1 && h->round_budget <= (uint32_t)HUFF_MAX_ROUNDS ? (int)h->round_budget : HUFF_MAX_ROUNDS;
     // Rounds launched ahead: a wrong guess falls into step within ~1 KB of 4:2:0 data, i.e. after 1024 / sub_bytes
-    // rounds; files of one source need about the same number: two more than the context's recent maximum
+    // rounds; files of one source need about the same number (quality 98 needs 24, a page with flat runs 40): two more
+    // than the context's recent maximum, which decays by one per file
     j.planned = (int)(1536 / sub_bytes) + 2;
-    if (c->huff_recent > 0 && c->huff_recent + 2 < j.planned) j.planned = c->huff_recent + 2;
+    if (c->huff_recent > 0) j.planned = c->huff_recent + 2;
     if (const char* e = getenv("ZJ_HUFF_ROUNDS")) { const int v = atoi(e); if (v >= 1) j.planned = v; }
     if (j.planned > j.max_rounds) j.planned = j.max_rounds;
     return ZJ_OK;
