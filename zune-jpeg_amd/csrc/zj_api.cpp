@@ -799,6 +799,7 @@ static int decode_scans_impl(zj_ctx* c, size_t n, const zj_frame_desc* descs, co
         for (auto& e : ev) (void)hipEventDestroy(e);
     }
     int most = 0;
+    c->huff_rounds = 0;
     for (int q = 0; q < nlive; q++) {
         ScanJob& j = jobs[(size_t)live[q]];
         if (!scan_check(j, planned)) {
@@ -816,11 +817,11 @@ static int decode_scans_impl(zj_ctx* c, size_t n, const zj_frame_desc* descs, co
                     if (j.h_ctl[HUFF_CTL_ROUND0 + r] == 0) { j.synced = true; j.rounds = r; break; }
                 group *= 2;
             }
-            if (!j.synced) { // the CPU walker is the faster way out
+            if (!j.synced) { // the CPU walker is the faster way out (nothing to learn from for the next files)
                 j.rounds = round;
                 rcs[live[q]] = ZJ_RETRY_CPU;
                 if (status_bits) status_bits[live[q]] = HUFF_ST_NO_SYNC;
-                if (j.rounds > most) most = j.rounds;
+                if (j.rounds > c->huff_rounds) c->huff_rounds = j.rounds;
                 continue;
             }
             int rc = scan_clear_again(c, j, s);
@@ -833,9 +834,11 @@ static int decode_scans_impl(zj_ctx* c, size_t n, const zj_frame_desc* descs, co
         if (status_bits) status_bits[live[q]] = j.h_ctl[HUFF_CTL_STATUS];
         rcs[live[q]] = j.h_ctl[HUFF_CTL_STATUS] ? ZJ_RETRY_CPU : ZJ_OK;
     }
-    c->huff_rounds = most;
-    // (rounds in units of the scans' sub-sequence size; a context is normally fed one kind of file)
-    c->huff_recent = most >= c->huff_recent ? most : c->huff_recent - 1;
+    if (most > c->huff_rounds) c->huff_rounds = most;
+    // (rounds in units of the scans' sub-sequence size; a context is normally fed one kind of file; an outlier fades
+    // by a quarter per call)
+    if (most >= c->huff_recent) c->huff_recent = most;
+    else { const int faded = c->huff_recent - (c->huff_recent / 4 > 1 ? c->huff_recent / 4 : 1); c->huff_recent = faded > most ? faded : most; }
     const ScanJob& j0 = jobs[(size_t)live[0]]; // zj_scan_planes looks at the first scan of the last call
     c->huff_plane_slot = j0.slot;
     c->huff_plane_off[0] = 0; c->huff_plane_off[1] = j0.yb; c->huff_plane_off[2] = j0.yb + j0.cbytes;
