@@ -70,6 +70,44 @@ def cpu_baseline(planes, qts, budget_s=20.0):
                       f"scalar restatement 1 thread {sc[0]:.0f} MP/s; host has {ncpu} logical CPUs, cgroup quota {eff}"}
 
 
+def from_files(zj, ctx, size=4096, batch=16, reps=4):
+    """Never `value`: whole 4096x4096 4:2:0 q90 JPEG FILES -> RGB left in HBM, Huffman decoding on the device too
+    (zj_decoder_prepare on one host thread, zj_decoder_finish_pixels_batch in batches of 16), and the same
+    files with the CPU walker in front of the pixel kernel.  None if anything is missing (Pillow writes the files)."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import files_bench
+        blobs = [files_bench.make_jpeg(size, s, 0) for s in range(2)]
+        mp = size * size / 1e6
+        out = {}
+        for name, mode in (("gpu_entropy", zj.ENTROPY_GPU), ("cpu_entropy", zj.ENTROPY_CPU)):
+            o = zj.ZuneJpegOptions()
+            o.entropy, o.pinned_planes, o.num_threads = mode, True, 1
+            decs = [zj.Decoder(o, ctx) for _ in range(batch)]
+            base = ctx.device_alloc(size * size * 3 * batch)
+            ptrs = [(base + k * size * size * 3, size * size * 3) for k in range(batch)]
+            n = batch if mode == zj.ENTROPY_GPU else 2
+            best_total, best_prep = 1e9, 1e9
+            for _ in range(reps if mode == zj.ENTROPY_GPU else 1):
+                t0 = time.perf_counter()
+                for k in range(n):
+                    decs[k].prepare(blobs[k % len(blobs)])
+                t1 = time.perf_counter()
+                _, rcs = zj.finish_pixels_batch(decs[:n], ctx, device_ptrs=ptrs[:n])
+                t2 = time.perf_counter()
+                assert not any(rcs)
+                best_total, best_prep = min(best_total, (t2 - t0) / n), min(best_prep, (t1 - t0) / n)
+            out[name] = {"megapixels_per_s": round(mp / best_total, 1), "ms_per_file": round(best_total * 1e3, 3),
+                         "host_ms_per_file": round(best_prep * 1e3, 3)}
+            ctx.device_free(base)
+            for d in decs:
+                d.close()
+        out["what"] = f"{size}x{size} 4:2:0 q90 baseline JPEG files ({len(blobs[0]) / 1e6:.2f} MB) -> RGB in HBM, one host thread, batches of {batch}; host_ms_per_file = container parsing + Huffman (cpu_entropy) or + scan preparation (gpu_entropy)"
+        return out
+    except Exception as e:  # the headline must not depend on this
+        return {"error": repr(e)[:200]}
+
+
 def load_traffic():
     """HBM bytes per launch from the committed rocprofv3 --pmc summary (tools/pmc_summary.py), or None."""
     p = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -243,6 +281,7 @@ def main():
         }
         if not args.no_cpu_baseline and args.workload == "420-rgb" and world == 1:  # host baseline: rank 0 at N=1 only
             res["cpu_baseline"] = cpu_baseline(frames[0][0], qts)
+            res["from_files"] = from_files(zj, ctx)
         print(json.dumps(res), flush=True)
     shard.barrier(world)
     ctx.close()
