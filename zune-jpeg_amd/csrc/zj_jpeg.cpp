@@ -18,6 +18,7 @@
 #include <emmintrin.h> // _mm_stream_si128: the coefficient planes are written once and read by DMA
 
 #include <atomic>
+#include <chrono>
 #include <new>
 #include <string>
 #include <thread>
@@ -953,18 +954,28 @@ int gpu_table(const Huff& h, bool ac, uint16_t* out, int room)
     return L1 + links * L2;
 }
 
-// copies [s, e) without the zero that follows every 0xFF (T.81 B.1.1.5); (size_t)-1: a 0xFF followed by anything else
-size_t unstuff(const uint8_t* s, const uint8_t* e, uint8_t* dst)
+// Copies entropy-coded bytes from s without the zero that follows every 0xFF, up to the first marker (a 0xFF followed by
+// anything but 0x00; fill 0xFF bytes in front of it belong to it) or `end`.  *marker: the marker's first 0xFF, or null.
+// 16 bytes at a time while none of them is 0xFF (seven of eight such groups in coded data); may write up to 15 bytes of
+// garbage behind the length it returns (the caller's buffer has the slack and clears it).
+size_t unstuff_segment(const uint8_t* s, const uint8_t* end, uint8_t* dst, const uint8_t** marker)
 {
     uint8_t* const d0 = dst;
-    while (s < e) {
-        const uint8_t* f = (const uint8_t*)memchr(s, 0xFF, (size_t)(e - s));
-        if (!f) { memcpy(dst, s, (size_t)(e - s)); dst += e - s; break; }
-        const size_t n = (size_t)(f - s) + 1;
-        memcpy(dst, s, n);
-        dst += n;
-        if (f + 1 >= e || f[1] != 0x00) return (size_t)-1;
-        s = f + 2;
+    const __m128i ff = _mm_set1_epi8((char)0xFF);
+    *marker = nullptr;
+    while (s < end) {
+        if (end - s >= 16) {
+            const __m128i v = _mm_loadu_si128((const __m128i*)s);
+            const int m = _mm_movemask_epi8(_mm_cmpeq_epi8(v, ff));
+            _mm_storeu_si128((__m128i*)dst, v);
+            if (!m) { s += 16; dst += 16; continue; }
+            const int k = __builtin_ctz((unsigned)m); // bytes in front of the first 0xFF: already stored
+            s += k; dst += k;
+        } else if (*s != 0xFF) { *dst++ = *s++; continue; }
+        // *s == 0xFF
+        if (s + 1 < end && s[1] == 0x00) { *dst++ = 0xFF; s += 2; continue; }
+        *marker = s;
+        break;
     }
     return (size_t)(dst - d0);
 }
@@ -980,24 +991,16 @@ int prepare_scan(zj_decoder* d, const uint8_t* p, const uint8_t* end)
     for (int i = 0; i < d->ncomp; i++)
         if (!d->dc[d->comps[i].td & 3].present || !d->ac[d->comps[i].ta & 3].present) return why(2);
     const long long total = (long long)d->mcu_x * d->mcu_y;
-    std::vector<const uint8_t*> seg;
     int nseg = 1;
     long long ri = total;
     bool is_eoi = false;
     if (d->restart_interval > 0 && total > d->restart_interval) {
         ri = d->restart_interval;
         nseg = (int)((total + ri - 1) / ri);
-        if (!find_restart_segments(p, end, nseg, seg)) return why(3);
-        is_eoi = seg[(size_t)nseg] + 1 < end && seg[(size_t)nseg][1] == 0xD9;
-    } else {
-        const uint8_t* e = find_scan_end(p, end, &is_eoi);
-        if (!e) return why(4);
-        seg.push_back(p);
-        seg.push_back(e);
     }
-    const size_t scan_bytes = (size_t)(seg[(size_t)nseg] - p);
-    if (d->entropy < 2 && scan_bytes < (size_t)32 << 10) return why(5); // not worth a trip
-    if (scan_bytes > (size_t)200 << 20 || (size_t)nseg > HUFF_SEG_MASK / 2) return why(6); // 32-bit bit positions
+    const size_t file_left = (size_t)(end - p); // the scan's bytes and whatever follows them: an upper bound
+    if (d->entropy < 2 && file_left < (size_t)32 << 10) return why(5); // not worth a trip
+    if (file_left > (size_t)200 << 20 || (size_t)nseg > HUFF_SEG_MASK / 2) return why(6); // 32-bit bit positions
     // the MCU's blocks in scan order, distinct tables
     HuffScan h;
     memset(&h, 0, sizeof h);
@@ -1041,40 +1044,48 @@ int prepare_scan(zj_decoder* d, const uint8_t* p, const uint8_t* end)
         h.comp[i].h = (uint32_t)d->comps[i].h; h.comp[i].v = (uint32_t)d->comps[i].v;
         h.comp[i].bw = (uint32_t)d->comps[i].bw; h.comp[i].bh = (uint32_t)d->comps[i].bh;
     }
-    // Flat areas defeat self-synchronisation: a stream of identical tiny blocks is periodic, a decoder that starts out
-    // of step settles into a cycle of its own and stays there, so the true state only advances one sub-sequence per round
-    // (a scanned page with white margins: 260 rounds for 580 sub-sequences).  Such scans are also the ones the CPU
-    // walker is quickest with (few symbols per block), so they stay there: under 16 bits per block on average.  Mixed
-    // images pass this test and may still crawl; the round budget below is what the CPU walker would need instead.
     const double blocks = (double)total * bpm;
-    if (d->entropy < 2 && (double)scan_bytes * 8.0 < 16.0 * blocks) return why(14);
     const size_t sub = (size_t)d->sub_bytes;
-    const double cpu_us = (double)scan_bytes * 0.008 + blocks * 0.05, round_us = 10.0 + 0.27 * (double)sub;
-    long long budget = d->entropy >= 2 ? HUFF_MAX_ROUNDS : (long long)(cpu_us / round_us);
-    if (budget < 16) budget = 16;
-    if (budget > HUFF_MAX_ROUNDS) budget = HUFF_MAX_ROUNDS;
-    const size_t max_sub = scan_bytes / sub + (size_t)nseg + 1;
+    const size_t max_sub = file_left / sub + (size_t)nseg + 1;
     auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t off_tab = up16(sizeof(HuffScan));
     const size_t off_sub = up16(off_tab + (size_t)tab_used * 2);
     const size_t off_per = up16(off_sub + (max_sub + 1) * sizeof(HuffSub));
     const size_t off_seg = up16(off_per + (max_sub + 1) * sizeof(uint32_t));
     const size_t off_stream = up16(off_seg + (size_t)nseg * sizeof(HuffSeg));
-    const size_t cap = off_stream + scan_bytes + 16 * (size_t)nseg + 64;
+    const size_t cap = off_stream + file_left + 16 * (size_t)nseg + 64;
     uint8_t* blob = (uint8_t*)d->blob_store.ensure(cap, d->pinned);
     if (!blob) return why(8);
     memcpy(blob + off_tab, tabs.data(), (size_t)tab_used * 2);
     HuffSub* subs = (HuffSub*)(blob + off_sub);
     HuffSeg* segs = (HuffSeg*)(blob + off_seg);
     uint8_t* stream = blob + off_stream;
+    const bool dbg = getenv("ZJ_HUFF_DEBUG") != nullptr;
+    const auto tt0 = std::chrono::steady_clock::now();
+    // One pass over the scan: unstuff, stop at every marker.  Exactly the nseg - 1 RSTn of a well-formed scan, in
+    // sequence, then any other marker (or the end of the file); anything else is left to the CPU walker.
     size_t o = 0, nsub = 0;
+    const uint8_t* at = p;
     for (int k = 0; k < nseg; k++) {
-        const uint8_t* s0 = seg[(size_t)k];
-        const uint8_t* s1 = seg[(size_t)k + 1] - (k + 1 < nseg ? 2 : 0); // without the RSTn that follows
-        while (s1 > s0 && s1[-1] == 0xFF) s1--;                          // fill bytes belong to the marker
-        if (s1 < s0) return why(10);
-        const size_t len = unstuff(s0, s1, stream + o);
-        if (len == (size_t)-1) return why(11);
+        const uint8_t* mk = nullptr;
+        const size_t len = unstuff_segment(at, end, stream + o, &mk);
+        if (mk) {
+            const uint8_t* t = mk;
+            while (t + 1 < end && t[1] == 0xFF) t++; // fill bytes
+            const int m = t + 1 < end ? t[1] : 0xD9; // (a lone 0xFF at the very end: like the walker, as if EOI followed)
+            if (m == 0x00) return why(11);           // 0xFF 0xFF 0x00: fill bytes in front of a stuffed byte
+            if (m >= 0xD0 && m <= 0xD7) {
+                if (k + 1 == nseg || m != 0xD0 + (k & 7)) return why(3); // one too many, or out of sequence
+                at = t + 2;
+            } else {
+                if (k + 1 != nseg) return why(3); // the scan ends early
+                is_eoi = m == 0xD9;
+                at = mk;
+            }
+        } else {
+            if (k + 1 != nseg) return why(4);
+            at = end;
+        }
         segs[k].start = (uint32_t)o;
         segs[k].end = (uint32_t)(o + len);
         const size_t first = nsub;
@@ -1090,6 +1101,17 @@ int prepare_scan(zj_decoder* d, const uint8_t* p, const uint8_t* end)
         o = next;
     }
     memset(stream + o, 0, 32);
+    const auto tt1 = std::chrono::steady_clock::now();
+    const size_t scan_bytes = (size_t)(at - p);
+    if (d->entropy < 2 && scan_bytes < (size_t)32 << 10) return why(5); // not worth a trip
+    // Low-entropy scans that are not exactly periodic still crawl (the reference's test-baseline.jpg: 81 rounds for 72 KB);
+    // they are also the ones the CPU walker is quickest with (few symbols per block), so they stay there: under 16 bits
+    // per block on average.  The round budget is what the CPU walker would need instead, in rounds.
+    if (d->entropy < 2 && (double)scan_bytes * 8.0 < 16.0 * blocks) return why(14);
+    const double cpu_us = (double)scan_bytes * 0.008 + blocks * 0.05, round_us = 10.0 + 0.27 * (double)sub;
+    long long budget = d->entropy >= 2 ? HUFF_MAX_ROUNDS : (long long)(cpu_us / round_us);
+    if (budget < 16) budget = 16;
+    if (budget > HUFF_MAX_ROUNDS) budget = HUFF_MAX_ROUNDS;
     // Periodic runs (zj_huff.h): sub-sequence i holds the bytes of sub-sequence i - q.  Only whole sub-sequences that
     // are not the last of their segment (the parse of one looks up to 31 bits into the next).
     uint32_t* per = (uint32_t*)(blob + off_per);
@@ -1097,13 +1119,16 @@ int prepare_scan(zj_decoder* d, const uint8_t* p, const uint8_t* end)
     size_t nper = 0;
     {
         std::vector<uint8_t> qof(nsub, 0);
+        std::vector<uint64_t> head(nsub + 1); // first 8 bytes of every sub-sequence: almost always enough to say no
+        for (size_t i = 0; i < nsub; i++) memcpy(&head[i], stream + subs[i].start, 8);
         for (size_t i = 1; i + 1 < nsub; i++) {
             if ((subs[i].seg & (HUFF_FIRST | HUFF_LAST)) || (subs[i + 1].seg & HUFF_FIRST)) continue;
-            const uint8_t* me = stream + subs[i].start;
-            for (size_t q = 1; q <= HUFF_PER_MAXQ && q <= i; q++) {
+            const uint64_t mine = head[i];
+            const size_t qmax = i < HUFF_PER_MAXQ ? i : HUFF_PER_MAXQ;
+            for (size_t q = 1; q <= qmax; q++) {
+                if (head[i - q] != mine) continue;
                 if ((subs[i - q].seg & HUFF_SEG_MASK) != (subs[i].seg & HUFF_SEG_MASK)) break;
-                const uint8_t* other = stream + subs[i - q].start;
-                if (memcmp(me, other, 8) == 0 && memcmp(me, other, sub) == 0) { qof[i] = (uint8_t)q; break; }
+                if (memcmp(stream + subs[i].start, stream + subs[i - q].start, sub) == 0) { qof[i] = (uint8_t)q; break; }
             }
         }
         for (size_t i = 1; i < nsub;) {
@@ -1116,6 +1141,9 @@ int prepare_scan(zj_decoder* d, const uint8_t* p, const uint8_t* end)
             i = e + 1;
         }
     }
+    if (dbg) fprintf(stderr, "prepare_scan: unstuff + grid %.3f ms, periodic runs %.3f ms (%zu sub-sequences, %zu predicted)\n",
+                     std::chrono::duration<double, std::milli>(tt1 - tt0).count(),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt1).count(), nsub, nper);
     subs[nsub].start = (uint32_t)o; // sentinel
     subs[nsub].seg = 0;
     h.magic = HUFF_MAGIC;
