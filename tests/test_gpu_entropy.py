@@ -354,3 +354,16 @@ def test_blown_out_sky_is_bridged_by_the_periodic_run_rule(zj, ctx):
     assert g.scan_blob() is not None and g.gpu_status() == 0
     assert ctx.scan_stats()[0] <= 24
     assert np.array_equal(got, zj.Decoder(None, ctx).decode_buffer(data))
+
+
+def test_pool_to_a_torch_tensor(zj, ctx):
+    import torch
+    files = [pil_jpeg(512, 384, quality=82, seed=120 + k) for k in range(24)]
+    o = zj.ZuneJpegOptions()
+    o.entropy = zj.ENTROPY_GPU_ALWAYS
+    with zj.Pool(3, o) as pool:
+        t = pool.to_tensor(files)
+    assert tuple(t.shape) == (24, 384, 512, 3) and t.dtype == torch.uint8
+    got = t.cpu().numpy()
+    for k, f in enumerate(files):
+        assert np.array_equal(got[k].reshape(-1), zj.Decoder(None, ctx).decode_buffer(f)), k

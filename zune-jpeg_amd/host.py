@@ -790,6 +790,24 @@ class Pool:
             raise DecodeError(rc, lib().zj_pool_error(self._p).decode(errors="replace"))
         return list(olen), list(infos), list(sts)
 
+    def to_tensor(self, blobs, device="cuda:0", layout=LAYOUT_HWC):
+        """Files of ONE size -> uint8 tensor [N, H, W, C] on `device` (the pool's): the workers prepare, the submitters
+        finish in batches into the rows of the tensor (with a GPU entropy setting nothing but the files crosses PCIe)."""
+        import torch
+        dec = Decoder()
+        info = dec.read_headers(blobs[0])
+        dec.close()
+        nc = 1 if info.components == 1 else ColorSpace(self._out_cs).num_components()
+        h, w = int(info.height), int(info.width)
+        t = torch.empty((len(blobs), nc, h, w) if layout == LAYOUT_CHW else (len(blobs), h, w, nc), dtype=torch.uint8, device=device)
+        step = h * w * nc
+        if step % 16:
+            raise ZjError(ERR_ARG, "to_tensor: width * height * components must be a multiple of 16")
+        lens, infos, sts = self.decode_files_device(blobs, [t.data_ptr() + k * step for k in range(len(blobs))], [step] * len(blobs))
+        if any(int(i.width) != w or int(i.height) != h for i in infos):
+            raise ZjError(ERR_ARG, "to_tensor: files of different sizes")
+        return t
+
     def decode_files(self, blobs, outs=None, raise_on_error=True):
         """blobs: list of bytes-like JPEG files.  Returns (list of uint8 arrays, list of ImageInfo, statuses).
         `outs` may supply preallocated uint8 arrays (e.g. views of pinned memory)."""
