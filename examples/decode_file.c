@@ -1,7 +1,7 @@
 /* decode_file.c -- the C ABI end to end: JPEG file -> RGB (or RGBA / planar) pixels on an MI355X.
  *
  *   cc -I include examples/decode_file.c -L zune-jpeg_amd -lzjhip -Wl,-rpath,$PWD/zune-jpeg_amd -o decode_file
- *   ./decode_file in.jpg out.ppm
+ *   ./decode_file in.jpg out.ppm [gpu]      "gpu": the Huffman stage runs on the device as well (zj_options.entropy)
  *
  * Mirrors `Decoder::new_with_options(...).decode_buffer(&bytes)` of the reference (src/decoder.rs:178). */
 #include <stdio.h>
@@ -12,7 +12,7 @@
 
 int main(int argc, char **argv)
 {
-    if (argc < 3) { fprintf(stderr, "usage: %s in.jpg out.ppm\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s in.jpg out.ppm [gpu]\n", argv[0]); return 2; }
     FILE *f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 1; }
     fseek(f, 0, SEEK_END);
@@ -30,6 +30,8 @@ int main(int argc, char **argv)
     opt.out_colorspace = ZJ_CS_RGB;
     opt.num_threads = 4;                                      /* restart segments decode concurrently */
     opt.pinned_planes = 1;                                    /* coefficient planes are DMA sources */
+    if (argc > 3 && !strcmp(argv[3], "gpu")) opt.entropy = ZJ_ENTROPY_GPU; /* baseline scans of 32 KB and more: Huffman on the
+                                                                 device, same bytes; everything else as before */
     zj_decoder *dec = zj_decoder_new(&opt);
 
     zj_image_info info;

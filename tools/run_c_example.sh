@@ -2,6 +2,8 @@
 cd $GRAFT_REPO_ROOT
 gcc -std=c99 -Wall -I include examples/decode_file.c -L zune-jpeg_amd -lzjhip -Wl,-rpath,$PWD/zune-jpeg_amd -o /tmp/decode_file || exit 1
 /tmp/decode_file tests/golden/test-baseline.jpg /tmp/out.ppm || exit 1
+/tmp/decode_file tests/golden/test-baseline.jpg /tmp/out_gpu.ppm gpu || exit 1
+cmp /tmp/out.ppm /tmp/out_gpu.ppm && echo "the device entropy stage writes the same file"
 python - <<'PY'
 import importlib, numpy as np
 zj = importlib.import_module("zune-jpeg_amd")
