@@ -15,8 +15,11 @@
 //                chain IS the serial parse;
 //   scan         exclusive prefix sums over the blocks each sub-sequence completed and the DC differences it saw give
 //                every thread its first block index and its DC predictors (segmented by restart interval);
-//   write        every thread decodes once more and scatters the coefficients into the zeroed whole-frame planes the
-//                pixel kernel reads (src/mcu_prog.rs:62-79 layout).
+//   write        every thread decodes once more and scatters the coefficients into the whole-frame planes the pixel
+//                kernel reads (src/mcu_prog.rs:62-79 layout; round 0 has cleared them on the side);
+//   cut          the MCUs the reference never decodes because its reader has come across EOI (zj_jpeg.cpp EoiCut) are cleared.
+// Between the rounds a pass copies exit states forward through periodic runs (flat areas, below), where self-synchronisation
+// fails.  Every kernel takes the working sets of up to HUFF_BATCH_MAX scans (blockIdx.y): several files, one launch per phase.
 //
 // Only the host can do the byte-level work cheaply ahead of time: it removes the stuffed zeros (T.81 B.1.1.5), cuts the
 // scan at its RSTn markers into segments (each starts a fresh bit stream with zero predictors, T.81 E.1.4) and lays the
