@@ -201,8 +201,10 @@ int zj_decode_planes_to_device(zj_ctx *ctx, const zj_frame_desc *d, const int16_
 int zj_decode_scan(zj_ctx *ctx, const zj_frame_desc *d, const void *blob, size_t blob_bytes, uint8_t *out,
                    int out_on_device, unsigned *status_bits);
 /* The same for up to ZJ_SCAN_BATCH_MAX prepared scans of any geometry at once: every phase of the entropy stage is ONE
- * launch over all of them (a single file leaves most of the GPU idle), then a pixel kernel each.  rcs[k] = ZJ_OK,
- * ZJ_RETRY_CPU or a zj_status of scan k; status_bits[k] optional.  The return value reports failures of the call itself. */
+ * launch over all of them (a single file leaves most of the GPU idle); consecutive scans of one geometry and one set of
+ * tables whose outputs are equally spaced (host outputs always are, through a staging arena; device outputs when the
+ * caller's pointers are, e.g. the images of one tensor) also share ONE pixel-kernel launch.  rcs[k] = ZJ_OK, ZJ_RETRY_CPU
+ * or a zj_status of scan k; status_bits[k] optional.  The return value reports failures of the call itself. */
 #define ZJ_SCAN_BATCH_MAX 16
 int zj_decode_scans(zj_ctx *ctx, size_t n, const zj_frame_desc *descs, const void *const *blobs, const size_t *blob_bytes,
                     uint8_t *const *outs, int outs_on_device, int *rcs, unsigned *status_bits);
@@ -231,8 +233,9 @@ typedef struct zj_options {      /* zero = reference default */
     uint32_t flags;              /* ZJ_FLAG_* for the pixel path (0 = the reference's bytes), see zj_frame_desc */
     uint32_t out_layout;         /* ZJ_LAYOUT_HWC (0) or ZJ_LAYOUT_CHW */
     int32_t entropy;             /* where baseline Huffman scans are decoded: ZJ_ENTROPY_CPU (0), ZJ_ENTROPY_GPU (scans of
-                                    32 KB and more on the device, the rest and everything the device hands back on the
-                                    CPU), ZJ_ENTROPY_GPU_ALWAYS (every eligible scan).  Progressive files: always CPU */
+                                    32 KB and more and 16 bits per block and more on the device, the rest and everything
+                                    the device hands back on the CPU), ZJ_ENTROPY_GPU_ALWAYS (every eligible scan: for
+                                    tests).  Progressive files: always CPU.  The output bytes do not depend on it */
 } zj_options;
 #define ZJ_ENTROPY_CPU 0
 #define ZJ_ENTROPY_GPU 1
