@@ -49,6 +49,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--mode", choices=["always", "gpu"], default="always", help="always: every eligible scan goes to the device; gpu: ZJ_ENTROPY_GPU's own choice (size, bits per block, round budget)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     ctx = zj.Context()
@@ -78,7 +79,7 @@ def main():
         sub = int(rng.choice([32, 64, 128, 128, 128]))
         os.environ["ZJ_HUFF_SUB"] = str(sub)
         og, oc = zj.ZuneJpegOptions(), zj.ZuneJpegOptions()
-        og.entropy = zj.ENTROPY_GPU_ALWAYS
+        og.entropy = zj.ENTROPY_GPU_ALWAYS if args.mode == "always" else zj.ENTROPY_GPU
         cs = zj.ColorSpace.RGB if rng.integers(0, 3) else zj.ColorSpace.YCbCr
         og.out_colorspace = oc.out_colorspace = cs
         g, c = zj.Decoder(og, ctx), zj.Decoder(oc, ctx)
