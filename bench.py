@@ -4,15 +4,20 @@ bench.py -- BASELINE.json's metric: megapixels/s decoded (dequantize+IDCT -> h2v
 on synthetic 4096x4096 4:2:0 baseline frames, coefficient planes resident in HBM, plus the achieved
 HBM GB/s of the fused kernel against the MI355X roofline and the CPU baseline timed beside it.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames B] [--shard-frames S]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of the hot path (one launch of the fused kernel) over a batch of B frames per GPU.
-B defaults to 16 so one step moves 1.6 GB, far more than the 256 MiB Infinity Cache.  Frames are
-image-sharded across ranks with no data-path collective (weak scaling); RCCL is used only for the
-barrier, the MAX over ranks and the trivial gather of per-rank checksums after the timed region.
-Rank 0 prints ONE JSON line.
+Workload = BASELINE.json configs[4] sharded by image (configs[1] is its N = 1 case): every rank holds a shard of
+S = 128 distinct frames in HBM (global frame i <- synth.make_frame_t(seed 1234, frame_index i), generated on the GPU
+by an integer-only generator; 8 ranks = the 1024 frames of configs[4]).  A "step" = one pass of the hot path = ONE launch
+of the fused kernel over B = 16 consecutive frames of the shard (1.6 GB of HBM traffic, far more than the 256 MiB
+Infinity Cache); successive steps walk the shard.  The same per-GPU work at every N (weak scaling), no data-path
+collective; RCCL is used only for the barrier, the MAX over ranks and the trivial gather of per-frame checksums after
+the timed region, which are compared with the ORACLE's (tests/golden/checksums_seed1234.json).  Rank 0 prints ONE JSON line.
+
+`--gpus N` without a torchrun environment is self-launching: the parent starts the N ranks as child processes BEFORE
+anything touches a GPU, waits, relays rank 0's line and fails if any rank fails.
 """
 import argparse
 import importlib
@@ -109,12 +114,127 @@ def from_files(zj, ctx, size=4096, batch=16, reps=4):
 
 
 def load_traffic():
-    """HBM bytes per launch from the committed rocprofv3 --pmc summary (tools/pmc_summary.py), or None."""
+    """Counters of the committed rocprofv3 --pmc summary (tools/pmc_summary.py), or None."""
     p = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         return json.load(open(p))
     except Exception:
         return None
+
+
+def live_traffic(workload, B, timeout_s=150):
+    """HBM bytes per launch of the fused kernel measured in THIS run: two child runs of this script under
+    `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE in separate passes, as /opt/skills/guides/MI355X_MICROARCH.md
+    prescribes: the two do not fit the TCC's four slots together), a few launches of the same shape each, summarised by
+    tools/pmc_summary.py's rules (KiB units; FETCH_SIZE doubled on gfx950 for wide streaming reads).  The children are
+    started as child processes (never exec'd from this GPU-initialised process).  None if rocprofv3 is unavailable or fails:
+    the caller then falls back to the committed summary and says so."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="zj_pmc_", dir="/tmp")
+    means = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                env.pop(k, None)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--min-untimed", "2",
+                   "--frames", str(B), "--shard-frames", str(B), "--workload", workload, "--child"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection*.csv"), recursive=True):
+                with open(f, newline="") as fh:
+                    for row in csv.DictReader(fh):
+                        if "zj_fused_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                            vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None
+            means[counter] = (sum(vals) / len(vals), len(vals))
+        fetch, write = means["FETCH_SIZE"][0] * 1024, means["WRITE_SIZE"][0] * 1024
+        return {"hbm_bytes_per_launch": int(2 * fetch + write), "fetch_bytes_raw": fetch, "write_bytes": write,
+                "launches": means["FETCH_SIZE"][1],
+                "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, child runs of this bench.py invocation "
+                          f"({means['FETCH_SIZE'][1]} launches of {B} frames each); FETCH_SIZE x2 per MI355X_MICROARCH.md"}
+    except Exception:  # noqa: BLE001 -- the headline must not depend on the profiler
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def load_golden():
+    try:
+        g = json.load(open(os.path.join(ROOT, "tests", "golden", "checksums_seed1234.json")))
+        return g
+    except Exception:
+        return None
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as CHILD processes (this parent never imports torch
+    or touches a GPU), relay rank 0's stdout, fail if any rank fails."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    import threading
+    lines = []
+    t = threading.Thread(target=lambda: lines.extend(procs[0].stdout.read().decode().splitlines()), daemon=True)
+    t.start()
+    rc = 0
+    live = set(range(n))
+    while live and rc == 0:
+        time.sleep(0.2)
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is not None:
+                live.discard(r)
+                if c != 0:
+                    rc = c if c > 0 else 1
+                    print(f"bench.py: rank {r} exited with {c}", file=sys.stderr)
+    for r in live:  # a rank failed: stop the others (exact PIDs)
+        procs[r].terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except Exception:  # noqa: BLE001
+            p.kill()
+    t.join(5)
+    for ln in lines:
+        print(ln, flush=True)
+    if rc == 0 and not any(ln.startswith("{") for ln in lines):
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    sys.exit(rc)
+
+
+WORKLOADS = {  # name: (h_samp, v_samp, output colourspace name, algorithmic bytes per pixel, description)
+    "420-rgb": (2, 2, "RGB", 6.0, "4096x4096 baseline 4:2:0, dequant+IDCT+h2v2+YCbCr->RGB, planes resident in HBM (BASELINE configs[1]; sharded = configs[4])"),
+    "444-rgb": (1, 1, "RGB", 9.0, "configs[2]: 4096x4096 baseline 4:4:4, dequant+IDCT+YCbCr->RGB, planes resident in HBM"),
+    "444-gray": (1, 1, "GRAYSCALE", 3.0, "configs[2]: 4096x4096 4:4:4 -> GRAYSCALE (luma only), planes resident in HBM"),
+    "422-rgb": (2, 1, "RGB", 7.0, "4096x4096 baseline 4:2:2 (h2v1), dequant+IDCT+horizontal upsample+YCbCr->RGB (the reference's benches/decode.rs horizontal case)"),
+    "440-rgb": (1, 2, "RGB", 7.0, "4096x4096 baseline 4:4:0 (h1v2), dequant+IDCT+vertical upsample+YCbCr->RGB (the reference's benches/decode.rs vertical case)"),
+    "420-rgba": (2, 2, "RGBA", 7.0, "extension: 4096x4096 4:2:0 -> RGBA (R G B 255), planes resident in HBM"),
+    "420-chw": (2, 2, "RGB", 6.0, "extension: 4096x4096 4:2:0 -> planar u8 RGB (C x H x W), planes resident in HBM"),
+}
 
 
 def main():
@@ -123,17 +243,28 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=100,
                     help="untimed steps; the first ~70 launches after idle run 5-35%% slow while the clocks settle")
-    ap.add_argument("--frames", type=int, default=16, help="4096x4096 frames per GPU per step")
-    ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic frames generated (tiled to --frames)")
+    ap.add_argument("--min-untimed", type=int, default=100, help="at least this many untimed launches precede the timed region")
+    ap.add_argument("--frames", type=int, default=16, help="4096x4096 frames per launch (= per step) per GPU")
+    ap.add_argument("--shard-frames", type=int, default=128,
+                    help="distinct frames resident per GPU (configs[4]: 1024 frames over 8 GPUs = 128); steps walk the shard")
+    ap.add_argument("--legacy-data", action="store_true",
+                    help="rounds 1-2 input: two numpy-generated frames (synth.make_frame) tiled to one 16-frame batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--single-frame", action="store_true",
-                    help="also time ONE frame per launch (configs[1] read literally); off by default so that a profiler "
-                         "run of this command sees a single launch shape")
-    ap.add_argument("--workload", choices=["420-rgb", "444-rgb", "444-gray", "422-rgb", "440-rgb", "420-rgba", "420-chw"], default="420-rgb",
-                    help="420-rgb = BASELINE.json configs[1] (the headline); 444-* are configs[2]; 422 / 440 the reference's other sampling modes; 420-rgba / 420-chw are "
-                         "the output extensions (4 B/px interleaved, planar u8)")
+    ap.add_argument("--no-single-frame", action="store_true",
+                    help="skip the one-frame-per-launch timing (configs[1] read literally); for profiler runs that should "
+                         "see a single launch shape")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run the rocprofv3 --pmc child passes")
+    ap.add_argument("--child", action="store_true", help="(internal) a profiler child: kernel launches only, no extras")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="420-rgb",
+                    help="420-rgb = BASELINE.json configs[1]/[4] (the headline); 444-* are configs[2]; 422 / 440 the reference's "
+                         "other sampling modes; 420-rgba / 420-chw are the output extensions (4 B/px interleaved, planar u8)")
     ap.add_argument("--variant", choices=["packed", "wide", "packed-direct"], default=None, help="kernel variant (default: library default)")
     args = ap.parse_args()
+    if args.child:
+        args.no_cpu_baseline = args.no_single_frame = args.no_live_traffic = True
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus, sys.argv[1:])  # does not return
 
     import numpy as np
     import torch  # before libzjhip: both bind the same libamdhip64.so.7
@@ -142,10 +273,7 @@ def main():
     shard = importlib.import_module("zune-jpeg_amd.shard")
 
     rank, local_rank, world = shard.env_world()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product path has no CPU fallback")
     # ZJ_BENCH_SAME_GPU=1 is a plumbing test only (tests the multi-rank control flow on a 1-GPU box: every rank uses
@@ -154,78 +282,116 @@ def main():
     gpu_index = 0 if same_gpu else local_rank
     torch.cuda.set_device(gpu_index)
     dev = torch.device("cuda", gpu_index)
-    shard.init_process_group("gloo" if same_gpu else "nccl", rank, world)
+    backend = "gloo" if same_gpu else "nccl"
+    shard.init_process_group(backend, rank, world)
     coll_dev = "cpu" if same_gpu else dev
 
     B = args.frames
+    S = B if args.legacy_data else max(B, args.shard_frames - args.shard_frames % B)
+    nsub = S // B
     ctx = zj.Context(zj.BACKEND_HIP, gpu_index)
     if args.variant:
         ctx.set_variant({"packed": 0, "wide": 1, "packed-direct": 2}[args.variant])
-    # synthetic data, SURVEY.md 8d generator; every rank decodes its own shard of the global batch
-    lo, _ = shard.shard_range(B * world, rank, world)
-    hs, vs, out_cs, bytes_per_px = {"420-rgb": (2, 2, zj.ColorSpace.RGB, 6.0), "444-rgb": (1, 1, zj.ColorSpace.RGB, 9.0),
-                                    "444-gray": (1, 1, zj.ColorSpace.GRAYSCALE, 3.0),
-                                    "422-rgb": (2, 1, zj.ColorSpace.RGB, 7.0), "440-rgb": (1, 2, zj.ColorSpace.RGB, 7.0),
-                                    "420-rgba": (2, 2, zj.ColorSpace.RGBA, 7.0), "420-chw": (2, 2, zj.ColorSpace.RGB, 6.0)}[args.workload]
-    frames = [synth.make_frame(W, H, hs, vs, 3, seed=1234, frame_index=(lo + i) % max(args.distinct, 1))
-              for i in range(min(args.distinct, B))]
-    qts = frames[0][1]
+    hs, vs, cs_name, bytes_per_px, what = WORKLOADS[args.workload]
+    out_cs = getattr(zj.ColorSpace, cs_name)
+    ncomp_out = out_cs.num_components()
+    # every rank decodes its own contiguous shard [lo, lo + S) of the global batch (image-level sharding)
+    lo, hi = shard.shard_range(S * world, rank, world)
+    assert hi - lo == S
+    golden = load_golden() if (args.workload == "420-rgb" and not args.legacy_data) else None
+    plane_elems = [synth.plane_blocks(W, H, hs, vs, c)[0] * synth.plane_blocks(W, H, hs, vs, c)[1] * 64 for c in range(3)]
+    t_gen = time.perf_counter()
+    d_planes = [torch.empty(S * n, dtype=torch.int16, device=dev) for n in plane_elems]
+    if args.legacy_data:
+        frames = [synth.make_frame(W, H, hs, vs, 3, seed=1234, frame_index=i) for i in range(2)]
+        qts = frames[0][1]
+        for c in range(3):
+            d_planes[c].copy_(torch.from_numpy(np.concatenate([frames[i % 2][0][c] for i in range(B)])))
+        first_planes = frames[0][0]
+    else:
+        for j in range(S):
+            _, qts = synth.make_frame_t(W, H, hs, vs, 3, seed=1234, frame_index=(lo + j) % 1024, device=dev,
+                                        out=[d_planes[c][j * plane_elems[c]:(j + 1) * plane_elems[c]] for c in range(3)])
+        first_planes = None
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
     desc = zj.FrameDesc.make(W, H, hs, vs, 3, out_cs, qts, out_layout=zj.LAYOUT_CHW if args.workload == "420-chw" else zj.LAYOUT_HWC)
-    host = [np.concatenate([frames[i % len(frames)][0][c] for i in range(B)]) for c in range(3)]
-    d_planes = [torch.from_numpy(h).to(dev) for h in host]
-    d_out = torch.empty(B * W * H * out_cs.num_components(), dtype=torch.uint8, device=dev)
+    frame_out = W * H * ncomp_out
+    d_out = torch.empty(S * frame_out, dtype=torch.uint8, device=dev)
     # a dedicated stream: launches on the legacy NULL stream serialise against every blocking stream
     # and cost ~30 us each (tools/launch_overhead.py); torch.cuda.synchronize() still covers it
     torch.cuda.synchronize()
     side = torch.cuda.Stream(device=dev)
     stream = side.cuda_stream
-    ptrs = [t.data_ptr() for t in d_planes] + [d_out.data_ptr()]
+    base = [t.data_ptr() for t in d_planes] + [d_out.data_ptr()]
+    stride = [2 * n * B for n in plane_elems] + [frame_out * B]          # bytes per sub-batch of B frames
 
-    def step():
-        ctx.decode_planes_device(desc, B, ptrs[0], ptrs[1], ptrs[2], ptrs[3], stream)
+    def sub(k):
+        return [base[i] + (k % nsub) * stride[i] for i in range(4)]
 
-    # the first ~70 launches after idle run 5-35 % slow while the clocks settle: whatever --warmup says, at least 100
-    # untimed launches precede the timed region (the W warmup steps are part of them)
-    for _ in range(max(args.warmup, 100)):
-        step()
+    subs = [sub(k) for k in range(nsub)]
+
+    def step(k):
+        p = subs[k % nsub]
+        ctx.decode_planes_device(desc, B, p[0], p[1], p[2], p[3], stream)
+
+    # the first ~70 launches after idle run 5-35 % slow while the clocks settle: whatever --warmup says, at least
+    # --min-untimed (100) untimed launches precede the timed region (the W warmup steps are part of them)
+    untimed = max(args.warmup, args.min_untimed, nsub)
+    for k in range(untimed):
+        step(k)
     torch.cuda.synchronize()
     shard.barrier(world)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k)
     torch.cuda.synchronize()
     shard.barrier(world)
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, world, coll_dev)
 
-    # dominant-kernel duration, HIP events recorded on the launch stream (outside the timed region)
-    kiters = max(10, min(args.steps, 50))
-    kernel_ms, kernel_ms_each, kname = ctx.time_decode_device(desc, B, ptrs[0], ptrs[1], ptrs[2], ptrs[3], kiters, stream)
-    # configs[1] read literally is ONE 4096x4096 frame per launch: time that shape too (1664 workgroups = 1.3 waves of
-    # the chip's 1280 workgroup slots, so the tail of every launch is exposed); reported beside the batched figure
+    # dominant-kernel duration, HIP events recorded on the launch stream (outside the timed region); min(steps, 300)
+    # launches so that it averages over the same population as ms_per_step
+    kiters = max(10, min(args.steps, 300))
+    p0 = subs[0]
+    kernel_ms, kernel_ms_each, kname = ctx.time_decode_device(desc, B, p0[0], p0[1], p0[2], p0[3], kiters, stream)
+    # configs[1] read literally is ONE 4096x4096 frame per launch: time that shape too, reported beside the batched figure
     one_ms = one_ms_each = one_ms_4s = None
-    if args.single_frame:
-        one_ms, one_ms_each, _ = ctx.time_decode_device(desc, 1, ptrs[0], ptrs[1], ptrs[2], ptrs[3], 200, stream)
+    if not args.no_single_frame:
+        one_ms, one_ms_each, _ = ctx.time_decode_device(desc, 1, p0[0], p0[1], p0[2], p0[3], 300, stream)
         # the same shape fed the way a frame-at-a-time caller would: launches rotating over four streams, so the tail
         # of one frame overlaps the head of the next (tools/single_frame_streams.py)
         four = [torch.cuda.Stream(device=dev) for _ in range(4)]
-        ysz, csz, osz = d_planes[0].numel() // B * 2, d_planes[1].numel() // B * 2, d_out.numel() // B
+        fstr = [2 * n for n in plane_elems] + [frame_out]
 
         def rot(n):
             for i in range(n):
-                f = i % B
-                ctx.decode_planes_device(desc, 1, ptrs[0] + f * ysz, ptrs[1] + f * csz, ptrs[2] + f * csz, ptrs[3] + f * osz,
-                                         four[i % 4].cuda_stream)
+                f = i % S
+                ctx.decode_planes_device(desc, 1, base[0] + f * fstr[0], base[1] + f * fstr[1], base[2] + f * fstr[2],
+                                         base[3] + f * fstr[3], four[i % 4].cuda_stream)
         rot(200)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         rot(2000)
         torch.cuda.synchronize()
         one_ms_4s = (time.perf_counter() - t1) / 2000 * 1e3
-    # trivial gather: per-rank checksum of frame 0 (all ranks decode the same synthetic seeds modulo shard)
+    # every frame of the shard decoded once more (untimed), then the trivial gather: per-frame checksums, computed on the
+    # GPU, gathered over RCCL and compared with the oracle's (tests/golden/checksums_seed1234.json)
+    for k in range(nsub):
+        step(k)
     torch.cuda.synchronize()
-    first = d_out[: W * H * out_cs.num_components()].cpu().numpy()
-    sums = shard.gather_checksums([shard.frame_checksum(first)], world, coll_dev)
+    sums = []
+    if not args.child:
+        wts = synth.checksum_weights_t(frame_out // 8, dev)
+        sums = [synth.frame_checksum_t(d_out[j * frame_out:(j + 1) * frame_out], wts) for j in range(S)]
+        del wts
+    all_sums = shard.gather_checksums(sums, world, coll_dev)
+    match = None
+    if golden and sums:
+        gl = [int(x, 16) for x in golden["rgb"]]
+        idx = [(r * S + j) % 1024 for r in range(world) for j in range(len(all_sums[r]))]   # global frame -> golden entry
+        if max(idx) < len(gl):
+            match = all(c == gl[i] for c, i in zip((c for r in all_sums for c in r), idx))
 
     if rank == 0:
         mp_total = world * B * args.steps * W * H / 1e6
@@ -234,6 +400,7 @@ def main():
         tr = load_traffic()
         if tr and not (tr.get("workload", "420-rgb") == args.workload and tr.get("frames_per_launch", 16) == B):
             tr = None  # the committed counters describe another launch shape
+        live = None if (args.no_live_traffic or world > 1) else live_traffic(args.workload, B)
         # Second bound, reported beside the HBM one: integer VALU issue.  A wave64 integer instruction occupies
         # its SIMD for 4 cycles (16 lanes per SIMD per clock; profiles/r01_ubench_valu_issue_cost.txt), so the
         # chip retires at most 1024 SIMDs x 2.4 GHz / 4 wave-instructions per second.
@@ -243,7 +410,8 @@ def main():
             ach_wi = tr["sq_insts_valu_per_launch"] / (kernel_ms * 1e-3)
             valu = {"wave_insts_per_launch": tr["sq_insts_valu_per_launch"], "achieved": round(ach_wi / 1e9, 1),
                     "peak": round(peak_wi / 1e9, 1), "unit": "G wave64-instructions/s", "frac": round(ach_wi / peak_wi, 4),
-                    "source": tr.get("sq_source")}
+                    "source": tr.get("sq_source"), "replayed": True}
+        traffic = live["hbm_bytes_per_launch"] if live else (tr or {}).get("hbm_bytes_per_launch")
         res = {
             "metric": "megapixels/sec decoded (IDCT->RGB), 4K 4:2:0 baseline" if args.workload == "420-rgb" else f"megapixels/sec decoded, 4K {args.workload}",
             "value": round(mp_total / elapsed, 1),
@@ -253,21 +421,22 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "i32",  # the IDCT's fixed-point type (i16 coefficients in, packed-i16 colour math, u8 pixels out)
             "data": "synthetic",
-            "config": {"workload": {"420-rgb": "configs[1]: 4096x4096 baseline 4:2:0, dequant+IDCT+h2v2+YCbCr->RGB, planes resident in HBM",
-                                    "444-rgb": "configs[2]: 4096x4096 baseline 4:4:4, dequant+IDCT+YCbCr->RGB, planes resident in HBM",
-                                    "444-gray": "configs[2]: 4096x4096 4:4:4 -> GRAYSCALE (luma only), planes resident in HBM",
-                                    "422-rgb": "4096x4096 baseline 4:2:2 (h2v1), dequant+IDCT+horizontal upsample+YCbCr->RGB (the reference's benches/decode.rs horizontal case)",
-                                    "440-rgb": "4096x4096 baseline 4:4:0 (h1v2), dequant+IDCT+vertical upsample+YCbCr->RGB (the reference's benches/decode.rs vertical case)",
-                                    "420-rgba": "extension: 4096x4096 4:2:0 -> RGBA (R G B 255), planes resident in HBM",
-                                    "420-chw": "extension: 4096x4096 4:2:0 -> planar u8 RGB (C x H x W), planes resident in HBM"}[args.workload],
-                       "frames_per_gpu_per_step": B, "sharding": f"image-level x{world}, no data-path collective",
-                       "distinct_frames": len(frames), "untimed_launches_before_timing": max(args.warmup, 100)},
+            "config": {"workload": what,
+                       "frames_per_gpu_per_step": B, "frames_resident_per_gpu": S, "frames_total": S * world,
+                       "sharding": f"image-level x{world}, rank r holds global frames [r*{S}, (r+1)*{S}), no data-path collective",
+                       "distinct_frames": 2 if args.legacy_data else S * world,
+                       "generator": "synth.make_frame (numpy, rounds 1-2)" if args.legacy_data else
+                                    "synth.make_frame_t(seed 1234, frame_index = global frame), integer-only, generated on the GPU",
+                       "generate_s": round(t_gen, 2), "untimed_launches_before_timing": untimed},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": (tr or {}).get("hbm_bytes_per_launch"),
+                         "traffic": traffic,
+                         "traffic_replayed": (not live) if traffic is not None else None,
+                         "traffic_source": live["source"] if live else (tr or {}).get("source"),
                          "kernel": kname, "kernel_ms": round(kernel_ms, 4), "kernel_ms_single_launch": round(kernel_ms_each, 4),
+                         "kernel_launches_timed": kiters,
                          "algorithmic_bytes_per_launch": int(algo_bytes),
-                         "traffic_source": (tr or {}).get("source"), "valu_issue": valu,
+                         "valu_issue": valu,
                          "single_frame_launch": None if one_ms is None else {
                              "kernel_ms": round(one_ms, 4), "kernel_ms_single_launch": round(one_ms_each, 4),
                              "megapixels_per_s": round(W * H / 1e6 / (one_ms * 1e-3), 1),
@@ -276,11 +445,15 @@ def main():
                              "four_streams_ms_per_frame": round(one_ms_4s, 4),
                              "four_streams_megapixels_per_s": round(W * H / 1e6 / (one_ms_4s * 1e-3), 1),
                              "four_streams_frac": round(W * H * bytes_per_px / (one_ms_4s * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
-            # every rank's first frame is synthetic frame (rank*B) % distinct: identical data when B % distinct == 0
-            "checksums_equal_across_ranks": (len({tuple(s) for s in sums}) == 1) if (world > 1 and B % max(args.distinct, 1) == 0) else None,
+            "rccl_ranks": world if (world > 1 and backend == "nccl") else 0,
+            "collective_backend": None if world == 1 else backend,
+            "frames_checksummed": sum(len(r) for r in all_sums),
+            "checksums_match_golden": match,
         }
         if not args.no_cpu_baseline and args.workload == "420-rgb" and world == 1:  # host baseline: rank 0 at N=1 only
-            res["cpu_baseline"] = cpu_baseline(frames[0][0], qts)
+            if first_planes is None:
+                first_planes = [d_planes[c][:plane_elems[c]].cpu().numpy() for c in range(3)]
+            res["cpu_baseline"] = cpu_baseline(first_planes, qts)
             res["from_files"] = from_files(zj, ctx)
         print(json.dumps(res), flush=True)
     shard.barrier(world)

@@ -37,7 +37,14 @@
 extern "C" {
 #endif
 
-#define ZJ_ABI_VERSION 4
+#define ZJ_ABI_VERSION 5
+
+/* libzjhip.so is built with -fvisibility=hidden: the functions declared here are its whole dynamic symbol table */
+#if defined(__GNUC__) || defined(__clang__)
+#define ZJ_API __attribute__((visibility("default")))
+#else
+#define ZJ_API
+#endif
 
 /* ColorSpace, same order as src/misc.rs:88-106 */
 typedef enum zj_colorspace {
@@ -127,31 +134,31 @@ typedef struct zj_frame_desc {
 typedef struct zj_ctx zj_ctx;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */
-int zj_abi_version(void);
-int zj_device_count(void);                              /* <0: zj_status */
-zj_ctx *zj_ctx_create(int backend, int device, int *status);
-void zj_ctx_destroy(zj_ctx *ctx);
-zj_ctx *zj_default_ctx(void);        /* the calling thread's own lazily created ctx on device 0, for the fn-pointer
+ZJ_API int zj_abi_version(void);
+ZJ_API int zj_device_count(void);                              /* <0: zj_status */
+ZJ_API zj_ctx *zj_ctx_create(int backend, int device, int *status);
+ZJ_API void zj_ctx_destroy(zj_ctx *ctx);
+ZJ_API zj_ctx *zj_default_ctx(void);        /* the calling thread's own lazily created ctx on device 0, for the fn-pointer
                                         shims (the reference calls them from several worker threads at once);
                                         recycled to the next new thread when its thread ends; never destroy it */
-const char *zj_strerror(int status);
-const char *zj_last_error(const zj_ctx *ctx);           /* detail of the last ZJ_ERR_HIP */
+ZJ_API const char *zj_strerror(int status);
+ZJ_API const char *zj_last_error(const zj_ctx *ctx);           /* detail of the last ZJ_ERR_HIP */
 
 /* ---- strip level: pointer-compatible with the reference's fn types (host buffers) ----------- */
 /* IDCTPtr, src/idct/scalar.rs:19 dequantize_and_idct_int(vector, qt_table, stride, samp_factors, v_samp) */
-int zj_idct_strip(zj_ctx *ctx, const int16_t *coeff, size_t n, const int32_t qt[64], size_t stride,
+ZJ_API int zj_idct_strip(zj_ctx *ctx, const int16_t *coeff, size_t n, const int32_t qt[64], size_t stride,
                   size_t samp_factors, size_t v_samp, int16_t *out /* n */);
 /* UpSampler, src/upsampler/scalar.rs:5 / :64 / :148 (input, output_len) */
-int zj_upsample_h(zj_ctx *ctx, const int16_t *in, size_t n, int16_t *out, size_t out_len);
-int zj_upsample_v(zj_ctx *ctx, const int16_t *in, size_t n, int16_t *out, size_t out_len);
-int zj_upsample_hv(zj_ctx *ctx, const int16_t *in, size_t n, int16_t *out, size_t out_len);
+ZJ_API int zj_upsample_h(zj_ctx *ctx, const int16_t *in, size_t n, int16_t *out, size_t out_len);
+ZJ_API int zj_upsample_v(zj_ctx *ctx, const int16_t *in, size_t n, int16_t *out, size_t out_len);
+ZJ_API int zj_upsample_hv(zj_ctx *ctx, const int16_t *in, size_t n, int16_t *out, size_t out_len);
 /* ColorConvert16Ptr, src/color_convert/scalar.rs:52 ycbcr_to_rgb_16_scalar(y, cb, cr, output, pos) */
-int zj_ycbcr_to_rgb16(zj_ctx *ctx, const int16_t y[16], const int16_t cb[16], const int16_t cr[16],
+ZJ_API int zj_ycbcr_to_rgb16(zj_ctx *ctx, const int16_t y[16], const int16_t cb[16], const int16_t cr[16],
                       uint8_t *out, size_t out_len, size_t *pos);
 /* post_process, src/worker.rs:32.  `out` must be zero-filled by the caller exactly as the
  * reference's callers do (src/mcu.rs:222, src/mcu_prog.rs:176): bytes the reference never writes
  * are left untouched. */
-int zj_post_process_strip(zj_ctx *ctx, const int16_t *const coeff[3], const size_t len[3],
+ZJ_API int zj_post_process_strip(zj_ctx *ctx, const int16_t *const coeff[3], const size_t len[3],
                           const zj_component comps[3], int in_cs, int out_cs, uint8_t *out,
                           size_t out_len, size_t width);
 
@@ -161,44 +168,44 @@ typedef int (*zj_idct_fn)(zj_ctx *, const int16_t *, size_t, const int32_t *, si
 typedef int (*zj_upsample_fn)(zj_ctx *, const int16_t *, size_t, int16_t *, size_t);
 typedef int (*zj_color_convert16_fn)(zj_ctx *, const int16_t *, const int16_t *, const int16_t *,
                                      uint8_t *, size_t, size_t *);
-zj_idct_fn zj_choose_idct_func(int backend);                        /* src/idct.rs:40 */
-zj_upsample_fn zj_choose_upsample_func(int backend, int h_max, int v_max); /* decoder.rs:468 */
-zj_color_convert16_fn zj_choose_ycbcr_to_rgb_convert_func(int backend, int out_cs); /* color_convert.rs:61 */
+ZJ_API zj_idct_fn zj_choose_idct_func(int backend);                        /* src/idct.rs:40 */
+ZJ_API zj_upsample_fn zj_choose_upsample_func(int backend, int h_max, int v_max); /* decoder.rs:468 */
+ZJ_API zj_color_convert16_fn zj_choose_ycbcr_to_rgb_convert_func(int backend, int out_cs); /* color_convert.rs:61 */
 
 /* ---- frame / batch level -------------------------------------------------------------------- */
-size_t zj_plane_len(const zj_frame_desc *d, int comp); /* int16 elements; mcu_prog.rs:76 */
-size_t zj_out_len(const zj_frame_desc *d);             /* bytes = width*height*ncomp */
-int zj_num_components(int colorspace);                 /* misc.rs:113 */
+ZJ_API size_t zj_plane_len(const zj_frame_desc *d, int comp); /* int16 elements; mcu_prog.rs:76 */
+ZJ_API size_t zj_out_len(const zj_frame_desc *d);             /* bytes = width*height*ncomp */
+ZJ_API int zj_num_components(int colorspace);                 /* misc.rs:113 */
 
 /* Host buffers; H2D copy, fused kernel(s), D2H copy, synchronous.  Output is fully written
  * (including the bytes the reference leaves at their initial 0). */
-int zj_decode_planes(zj_ctx *ctx, const zj_frame_desc *d, const int16_t *y, const int16_t *cb,
+ZJ_API int zj_decode_planes(zj_ctx *ctx, const zj_frame_desc *d, const int16_t *y, const int16_t *cb,
                      const int16_t *cr, uint8_t *out);
 /* nframes frames of identical geometry, planes and outputs contiguous frame after frame. */
-int zj_decode_planes_batch(zj_ctx *ctx, const zj_frame_desc *d, size_t nframes, const int16_t *y,
+ZJ_API int zj_decode_planes_batch(zj_ctx *ctx, const zj_frame_desc *d, size_t nframes, const int16_t *y,
                            const int16_t *cb, const int16_t *cr, uint8_t *out);
 /* Device-resident variant (kernel-only path used by bench.py): all pointers are device pointers
  * on ctx's device, 16-byte aligned; frames contiguous.  Asynchronous on `stream` (a hipStream_t;
  * NULL = the ctx stream).  The frame's quantisation tables are uploaded on first use per ctx and
  * cached by value. */
-int zj_decode_planes_device(zj_ctx *ctx, const zj_frame_desc *d, size_t nframes,
+ZJ_API int zj_decode_planes_device(zj_ctx *ctx, const zj_frame_desc *d, size_t nframes,
                             const int16_t *d_y, const int16_t *d_cb, const int16_t *d_cr,
                             uint8_t *d_out, void *stream);
 /* Times zj_decode_planes_device with HIP events recorded on the launch stream: *ms_total = `iters`
  * back-to-back launches between one event pair; *ms_each (optional) = mean over `iters` launches
  * each bracketed by its own event pair; *kernel_name = the dominant kernel. */
-int zj_time_decode_device(zj_ctx *ctx, const zj_frame_desc *d, size_t nframes, const int16_t *d_y,
+ZJ_API int zj_time_decode_device(zj_ctx *ctx, const zj_frame_desc *d, size_t nframes, const int16_t *d_y,
                           const int16_t *d_cb, const int16_t *d_cr, uint8_t *d_out, void *stream,
                           int iters, float *ms_total, float *ms_each, const char **kernel_name);
 
 /* Host planes -> pixels that stay in HBM (d_out: device pointer, 16-byte aligned). Synchronous. */
-int zj_decode_planes_to_device(zj_ctx *ctx, const zj_frame_desc *d, const int16_t *y, const int16_t *cb,
+ZJ_API int zj_decode_planes_to_device(zj_ctx *ctx, const zj_frame_desc *d, const int16_t *y, const int16_t *cb,
                                const int16_t *cr, uint8_t *d_out);
 /* A prepared baseline scan (zj_decoder_prepare / zj_decoder_scan_blob; host memory, pinned for an asynchronous upload)
  * -> pixels: upload, Huffman decoding on the device into whole-frame planes in HBM, pixel kernel, and -- unless
  * out_on_device -- the download.  Replaces the MCU walk of src/mcu.rs:231-351.  Synchronous.  ZJ_RETRY_CPU with
  * *status_bits (optional) when the device hands the scan back. */
-int zj_decode_scan(zj_ctx *ctx, const zj_frame_desc *d, const void *blob, size_t blob_bytes, uint8_t *out,
+ZJ_API int zj_decode_scan(zj_ctx *ctx, const zj_frame_desc *d, const void *blob, size_t blob_bytes, uint8_t *out,
                    int out_on_device, unsigned *status_bits);
 /* The same for up to ZJ_SCAN_BATCH_MAX prepared scans of any geometry at once: every phase of the entropy stage is ONE
  * launch over all of them (a single file leaves most of the GPU idle); consecutive scans of one geometry and one set of
@@ -206,15 +213,15 @@ int zj_decode_scan(zj_ctx *ctx, const zj_frame_desc *d, const void *blob, size_t
  * caller's pointers are, e.g. the images of one tensor) also share ONE pixel-kernel launch.  rcs[k] = ZJ_OK, ZJ_RETRY_CPU
  * or a zj_status of scan k; status_bits[k] optional.  The return value reports failures of the call itself. */
 #define ZJ_SCAN_BATCH_MAX 16
-int zj_decode_scans(zj_ctx *ctx, size_t n, const zj_frame_desc *descs, const void *const *blobs, const size_t *blob_bytes,
+ZJ_API int zj_decode_scans(zj_ctx *ctx, size_t n, const zj_frame_desc *descs, const void *const *blobs, const size_t *blob_bytes,
                     uint8_t *const *outs, int outs_on_device, int *rcs, unsigned *status_bits);
 /* diagnostics: the coefficient planes the last zj_decode_scan on ctx left in HBM, copied to host buffers of zj_plane_len
  * elements each (NULL: skipped); len[3] (optional) receives the lengths */
-int zj_scan_planes(zj_ctx *ctx, int16_t *y, int16_t *cb, int16_t *cr, size_t len[3]);
+ZJ_API int zj_scan_planes(zj_ctx *ctx, int16_t *y, int16_t *cb, int16_t *cr, size_t len[3]);
 /* of the last zj_decode_scan on ctx: synchronisation rounds; ms[3] = host milliseconds spent submitting (everything in
  * front of the final synchronisation); with ZJ_HUFF_TIME set in the environment, ms[0..2] = device milliseconds of
  * upload + rounds | prefix sums + write pass | pixel kernel (+ download) */
-int zj_scan_stats(const zj_ctx *ctx, int *rounds, float ms[4]);
+ZJ_API int zj_scan_stats(const zj_ctx *ctx, int *rounds, float ms[4]);
 
 /* ---- whole decoder: the CPU front-end the path is fed by (container + Huffman on the host) ------
  * Mirrors Decoder / ZuneJpegOptions / ImageInfo (src/decoder.rs:60,178,452,652; src/options.rs:6-40):
@@ -246,37 +253,41 @@ typedef struct zj_image_info {   /* ImageInfo, src/decoder.rs:652-668 (+ what th
     uint16_t scans, restart_interval;
 } zj_image_info;
 typedef struct zj_decoder zj_decoder;
-zj_decoder *zj_decoder_new(const zj_options *opt);            /* Decoder::new_with_options */
-void zj_decoder_free(zj_decoder *d);
-const char *zj_decoder_error(const zj_decoder *d);            /* Display text of the last DecodeErrors */
-int zj_decoder_read_headers(zj_decoder *d, const uint8_t *buf, size_t len, zj_image_info *info); /* decoder.rs:452 */
+ZJ_API zj_decoder *zj_decoder_new(const zj_options *opt);            /* Decoder::new_with_options */
+ZJ_API void zj_decoder_free(zj_decoder *d);
+ZJ_API const char *zj_decoder_error(const zj_decoder *d);            /* Display text of the last DecodeErrors */
+ZJ_API int zj_decoder_read_headers(zj_decoder *d, const uint8_t *buf, size_t len, zj_image_info *info); /* decoder.rs:452 */
 /* CPU half only: planes stay owned by the decoder until the next call (mcu_prog.rs:73-79 layout) */
-int zj_decoder_decode_coefficients(zj_decoder *d, const uint8_t *buf, size_t len, zj_frame_desc *desc,
+ZJ_API int zj_decoder_decode_coefficients(zj_decoder *d, const uint8_t *buf, size_t len, zj_frame_desc *desc,
                                    const int16_t **planes /*[3]*/, size_t *plane_len /*[3]*/, zj_image_info *info);
 /* Stage 1 on the CPU, whatever the options say it is: with entropy == ZJ_ENTROPY_CPU the same as
  * zj_decoder_decode_coefficients; with a GPU setting, headers + the byte-level preparation of a baseline scan
  * (stuffing removed, restart segments located, sub-sequence grid: csrc/zj_huff.h), leaving the Huffman decoding itself
  * (src/mcu.rs:231-351, src/bitstream.rs:314-373) to zj_decoder_finish_pixels.  `buf` must then stay valid until the
  * pixels are finished (a scan the device hands back is decoded from it on the CPU). */
-int zj_decoder_prepare(zj_decoder *d, const uint8_t *buf, size_t len, zj_frame_desc *desc, zj_image_info *info);
+ZJ_API int zj_decoder_prepare(zj_decoder *d, const uint8_t *buf, size_t len, zj_frame_desc *desc, zj_image_info *info);
 /* GPU half: the pixel path over the planes the last zj_decoder_decode_coefficients / zj_decoder_prepare left in the
  * decoder; after a zj_decoder_prepare that left a scan for the device: entropy stage + pixel path on the GPU */
-int zj_decoder_finish_pixels(zj_decoder *d, zj_ctx *ctx, uint8_t *out, size_t out_cap, size_t *out_len);
-/* the same with the pixels left in HBM (d_out: device pointer on ctx's device, 16-byte aligned) for consumers on the GPU */
-int zj_decoder_finish_pixels_device(zj_decoder *d, zj_ctx *ctx, uint8_t *d_out, size_t out_cap, size_t *out_len);
+ZJ_API int zj_decoder_finish_pixels(zj_decoder *d, zj_ctx *ctx, uint8_t *out, size_t out_cap, size_t *out_len);
+/* the same with the pixels left in HBM (d_out: device pointer on ctx's device, 16-byte aligned) for consumers on the GPU.
+ * Stream ordering (also zj_decode_planes_device with stream = NULL, zj_decoder_finish_pixels_batch with device outputs and
+ * zj_pool_decode_files_device): the library writes d_out on ITS OWN non-blocking stream and returns once that is complete;
+ * it does NOT order itself after work the caller still has in flight on other streams.  A caller whose allocator recycles
+ * device memory stream-ordered (torch.empty) must synchronise the stream that last used d_out before the call. */
+ZJ_API int zj_decoder_finish_pixels_device(zj_decoder *d, zj_ctx *ctx, uint8_t *d_out, size_t out_cap, size_t *out_len);
 /* stage 2 of n decoders on one context: the scans left for the device are decoded together (zj_decode_scans), the rest
  * one by one; rcs[k] is what zj_decoder_finish_pixels[_device] would have returned for decoder k */
-int zj_decoder_finish_pixels_batch(zj_decoder *const *ds, size_t n, zj_ctx *ctx, uint8_t *const *outs,
+ZJ_API int zj_decoder_finish_pixels_batch(zj_decoder *const *ds, size_t n, zj_ctx *ctx, uint8_t *const *outs,
                                    const size_t *out_caps, size_t *out_lens /*[n] or NULL*/, int outs_on_device, int *rcs);
 /* diagnostics: the prepared scan of the last zj_decoder_prepare (ZJ_ERR_ARG: none); the status bits (csrc/zj_huff.h
  * HUFF_ST_*) with which the device handed the last scan back to the CPU (0: it did not) */
-int zj_decoder_scan_blob(const zj_decoder *d, const void **blob, size_t *len);
-unsigned zj_decoder_gpu_status(const zj_decoder *d);
+ZJ_API int zj_decoder_scan_blob(const zj_decoder *d, const void **blob, size_t *len);
+ZJ_API unsigned zj_decoder_gpu_status(const zj_decoder *d);
 /* Decoder::decode_buffer (decoder.rs:178): width*height*ncomp bytes into `out` */
-int zj_decoder_decode_buffer(zj_decoder *d, zj_ctx *ctx, const uint8_t *buf, size_t len, uint8_t *out,
+ZJ_API int zj_decoder_decode_buffer(zj_decoder *d, zj_ctx *ctx, const uint8_t *buf, size_t len, uint8_t *out,
                              size_t out_cap, size_t *out_len, zj_image_info *info);
 /* restart segments the last baseline scan decoded concurrently (0 = the serial walk was used) */
-int zj_decoder_parallel_segments(const zj_decoder *d);
+ZJ_API int zj_decoder_parallel_segments(const zj_decoder *d);
 
 /* ---- batches of files: `threads` persistent host workers, each with its own entropy
  * decoder, pinned coefficient planes and GPU context on `device`; file i is decoded by whichever worker is
@@ -285,35 +296,42 @@ int zj_decoder_parallel_segments(const zj_decoder *d);
  * src/mcu.rs:135).  outs[i] must hold out_caps[i] >= width*height*ncomp bytes; statuses[i] (optional) gets
  * the zj_status of file i; the return value is the first error seen (ZJ_OK if none), text via zj_pool_error. */
 typedef struct zj_pool zj_pool;
-zj_pool *zj_pool_create(int device, int threads, const zj_options *opt, int *status);
-void zj_pool_destroy(zj_pool *pool);
-int zj_pool_threads(const zj_pool *pool);
-const char *zj_pool_error(const zj_pool *pool);
+ZJ_API zj_pool *zj_pool_create(int device, int threads, const zj_options *opt, int *status);
+ZJ_API void zj_pool_destroy(zj_pool *pool);
+ZJ_API int zj_pool_threads(const zj_pool *pool);
+ZJ_API const char *zj_pool_error(const zj_pool *pool);
 /* accumulated since creation: seconds spent inside the entropy stage and inside the GPU stage (summed over the
  * threads of each stage) and files that reached the GPU stage */
-int zj_pool_stats(zj_pool *pool, double *entropy_seconds, double *gpu_seconds, size_t *files);
-int zj_pool_decode_files(zj_pool *pool, size_t nfiles, const uint8_t *const *bufs, const size_t *lens,
+ZJ_API int zj_pool_stats(zj_pool *pool, double *entropy_seconds, double *gpu_seconds, size_t *files);
+ZJ_API int zj_pool_decode_files(zj_pool *pool, size_t nfiles, const uint8_t *const *bufs, const size_t *lens,
                          uint8_t *const *outs, const size_t *out_caps, size_t *out_lens /*[nfiles] or NULL*/,
                          zj_image_info *infos /*[nfiles] or NULL*/, int *statuses /*[nfiles] or NULL*/);
 
 /* the same with device pointers (on the pool's device, 16-byte aligned) as outputs: the pixels stay in HBM for a
  * consumer on the GPU, nothing crosses PCIe but the compressed files (with a GPU entropy setting) or the planes */
-int zj_pool_decode_files_device(zj_pool *pool, size_t nfiles, const uint8_t *const *bufs, const size_t *lens,
+ZJ_API int zj_pool_decode_files_device(zj_pool *pool, size_t nfiles, const uint8_t *const *bufs, const size_t *lens,
                                 uint8_t *const *d_outs, const size_t *out_caps, size_t *out_lens /*[nfiles] or NULL*/,
                                 zj_image_info *infos /*[nfiles] or NULL*/, int *statuses /*[nfiles] or NULL*/);
 
 /* ---- memory helpers ------------------------------------------------------------------------- */
-void *zj_alloc_pinned(size_t bytes); /* hipHostMalloc, portable (usable as a DMA source/target from every device); NULL on failure */
+ZJ_API void *zj_alloc_pinned(size_t bytes); /* hipHostMalloc, portable (usable as a DMA source/target from every device); NULL on failure */
 /* binds the CALLING thread to `device` (hipSetDevice): host threads that only allocate pinned memory or fill planes for a
  * context on device N call this first, so they neither initialise nor pin against device 0 */
-int zj_set_thread_device(int device);
-void zj_free_pinned(void *p);
-void *zj_device_alloc(zj_ctx *ctx, size_t bytes);
-void zj_device_free(zj_ctx *ctx, void *p);
-int zj_memcpy_h2d(zj_ctx *ctx, void *dst, const void *src, size_t bytes);
-int zj_memcpy_d2h(zj_ctx *ctx, void *dst, const void *src, size_t bytes);
-int zj_device_memset(zj_ctx *ctx, void *d_ptr, int value, size_t bytes);
-int zj_sync(zj_ctx *ctx);
+ZJ_API int zj_set_thread_device(int device);
+ZJ_API void zj_free_pinned(void *p);
+ZJ_API void *zj_device_alloc(zj_ctx *ctx, size_t bytes);
+ZJ_API void zj_device_free(zj_ctx *ctx, void *p);
+ZJ_API int zj_memcpy_h2d(zj_ctx *ctx, void *dst, const void *src, size_t bytes);
+ZJ_API int zj_memcpy_d2h(zj_ctx *ctx, void *dst, const void *src, size_t bytes);
+ZJ_API int zj_device_memset(zj_ctx *ctx, void *d_ptr, int value, size_t bytes);
+ZJ_API int zj_sync(zj_ctx *ctx);
+
+/* ---- tuning knobs (every setting produces the same bytes) ------------------------------------ */
+/* generation of the fused kernel: 0 = packed IDCT + staged stores (default), 1 = wide (24-bit multiplies, per-lane
+ * stores), 2 = packed with direct stores.  Also settable per process with ZJ_VARIANT. */
+ZJ_API int zj_set_variant(zj_ctx *ctx, int variant);
+/* 0 = zj_decode_planes_batch runs upload / kernel / download back to back instead of overlapped on three streams */
+ZJ_API int zj_set_pipeline(zj_ctx *ctx, int on);
 
 #ifdef __cplusplus
 }

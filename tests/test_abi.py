@@ -36,9 +36,22 @@ def test_header_symbols_exported(zj):
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/zjhip.h but not exported"
     assert sorted(zj.abi_symbols()) == declared
+    # ... and NOTHING else: the library is linked with -fvisibility=hidden and a version script, so its dynamic symbol
+    # table is the header (no C++ internals, no kernel handles, no micro-benchmark / lab / ablation hooks)
     out = subprocess.check_output(["nm", "-D", "--defined-only", zj.lib_path()], text=True)
-    exported = set(re.findall(r" T (zj_[a-z0-9_]+)", out))
-    assert set(declared) <= exported
+    exported = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+    assert exported == declared, sorted(set(exported) ^ set(declared))
+
+
+def test_lab_kernels_live_in_their_own_library(zj):
+    """tools/ubench.py and tools/lab.py use libzjlab.so; the product must not carry their kernels."""
+    lab = os.path.join(os.path.dirname(zj.lib_path()), "libzjlab.so")
+    assert os.path.exists(lab)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lab], text=True)
+    assert "zjlab_ubench" in out and "zjlab_lab" in out
+    blob = open(zj.lib_path(), "rb").read()
+    for needle in (b"ubench", b"labmem", b"zj_set_ablation", b"zj_set_pad_lds"):
+        assert needle not in blob, needle
 
 
 def test_no_oracle_in_product_library(zj):
@@ -48,7 +61,7 @@ def test_no_oracle_in_product_library(zj):
 
 def test_host_only_entry_points(zj):
     L = zj.lib()
-    assert L.zj_abi_version() == 4
+    assert L.zj_abi_version() == 5
     assert L.zj_strerror(0) == b"ok"
     assert b"panic" in L.zj_strerror(-5)
     qts = [np.ones(64, np.int32)] * 3

@@ -70,3 +70,21 @@ def test_two_rank_shard_and_gather():
         flat = allsums[0][:3] + allsums[1][:2]
         assert flat == expect            # gathered checksums == single-process decode
     assert len(set(expect)) == nframes
+
+
+def test_bench_self_launch_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` outside torchrun starts its own ranks (the parent never touches a GPU) and must relay a
+    rank's failure as a non-zero exit; without a GPU every rank refuses to run (no CPU fallback)."""
+    import subprocess
+    import sys
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_bench.py")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       capture_output=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert b"needs a GPU" in r.stderr and b"rank" in r.stderr
+    assert not r.stdout.strip()

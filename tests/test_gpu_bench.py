@@ -1,0 +1,41 @@
+"""bench.py's multi-rank path with the REAL library: two self-launched ranks on the one GPU of the box
+(ZJ_BENCH_SAME_GPU=1: both use cuda:0, collectives on gloo), each decoding its own shard with libzjhip; the gathered
+per-frame checksums must equal the oracle's golden ones (tests/golden/checksums_seed1234.json)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_two_self_launched_ranks_decode_their_shards_to_the_golden_checksums():
+    res = _bench("--gpus", "2", "--steps", "4", "--warmup", "1", "--min-untimed", "1", "--shard-frames", "32",
+                 "--no-cpu-baseline", "--no-live-traffic", "--no-single-frame", env_extra={"ZJ_BENCH_SAME_GPU": "1"})
+    assert res["n_gpus"] == 2 and res["frames_checksummed"] == 64 and res["config"]["frames_total"] == 64
+    assert res["checksums_match_golden"] is True
+    assert res["collective_backend"] == "gloo" and res["rccl_ranks"] == 0     # same-GPU plumbing run: no RCCL
+
+
+@pytest.mark.gpu
+def test_single_rank_line_has_the_contract_fields():
+    res = _bench("--steps", "8", "--warmup", "1", "--min-untimed", "1", "--shard-frames", "16", "--no-cpu-baseline",
+                 "--no-live-traffic")
+    assert res["n_gpus"] == 1 and res["checksums_match_golden"] is True and res["frames_checksummed"] == 16
+    rf = res["roofline"]
+    assert rf["bound"] == "hbm" and rf["algorithmic_bytes_per_launch"] == 16 * 4096 * 4096 * 6
+    assert rf["single_frame_launch"]["kernel_ms"] > 0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Times IDCT / colour formulations in isolation (csrc/zj_lab.hip).  cycles = per wave-iteration per
+"""Times IDCT / colour formulations in isolation (csrc/lab/zj_lab.hip; libzjlab.so).  cycles = per wave-iteration per
 SIMD, i.e. the VALU time one wave needs for 64 blocks (IDCT) or 64 x 16 pixels (colour)."""
 import importlib
 import os
@@ -10,20 +10,21 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    zj = importlib.import_module("zune-jpeg_amd")
-    L = zj.lib()
-    ctx = zj.Context()
-    mhz = ctx.ubench_clock_mhz()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import labctx
+    ctx = labctx.Lab()
+    L = ctx.L
+    mhz = ctx.clock_mhz()
     blocks, iters = 4096, 20
     print(f"clock {mhz:.0f} MHz; {'variant':52s} {'ms':>8s} {'cycles/wave-iter/SIMD':>22s}")
-    for v in range(L.zj_lab_count()):
+    for v in range(L.zjlab_lab_count()):
         ms = ctx.lab(v, blocks, iters, 3)
         cyc = ms * 1e-3 * mhz * 1e6 * 1024 / (blocks * 4 * iters)
-        print(f"{'':16s}{L.zj_lab_name(v).decode():52s} {ms:8.3f} {cyc:22.0f}")
+        print(f"{'':16s}{L.zjlab_lab_name(v).decode():52s} {ms:8.3f} {cyc:22.0f}")
     nbytes = 384 * 256 * 8192  # 805 MB in + 805 MB out, the size of one 16-frame launch
-    for v in range(L.zj_labmem_count()):
+    for v in range(L.zjlab_labmem_count()):
         ms = ctx.labmem(v, nbytes, 20)
-        print(f"{'':16s}{L.zj_labmem_name(v).decode():52s} {ms:8.3f} ms {2 * nbytes / ms / 1e6:10.1f} GB/s")
+        print(f"{'':16s}{L.zjlab_labmem_name(v).decode():52s} {ms:8.3f} ms {2 * nbytes / ms / 1e6:10.1f} GB/s")
     ctx.close()
 
 

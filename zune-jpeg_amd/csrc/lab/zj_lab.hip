@@ -3,8 +3,8 @@
 // Not part of the decode path.
 #include <hip/hip_runtime.h>
 
-#include "zj_device.h"
-#include "zj_launch.h"
+#include "../zj_device.h"
+#include "zj_lab_launch.h"
 
 namespace zj {
 

@@ -4,7 +4,7 @@
 // re-select them.  Not part of the decode path.
 #include <hip/hip_runtime.h>
 
-#include "zj_launch.h"
+#include "zj_lab_launch.h"
 
 namespace zj {
 

@@ -46,7 +46,9 @@ struct zj_ctx {
     hipStream_t s_up = nullptr, s_run = nullptr, s_down = nullptr;
     int pipeline = 1;             // 0: one unit per call (no overlap), for A/B timing only
     std::string last_error;
-    int debug = 0;                // ablation switches, diagnostics only (results are WRONG when set)
+#if defined(ZJ_ABLATION)
+    int debug = 0;                // ablation switches, diagnostic build only (results are WRONG when set)
+#endif
     int variant = 0;              // kernel variant: 0 packed generation (default), 1 wide generation (round 1), 2 packed with direct stores
     // GPU entropy stage (zj_decode_scan): blob + working set, the three planes (contiguous), control words read back
     // one slot per scan of a batch (zj_decode_scans): blob + working set | planes | pixels on their way to host memory
@@ -301,7 +303,9 @@ static int decode_device_impl(zj_ctx* c, const zj_frame_desc* d, const Plan& pl,
 {
     Params p; // carries the quantisation tables by value: nothing to stage, nothing to order across streams
     fill_params(d, pl, nframes, d_y, d_cb, d_cr, d_out, zero_fill, p);
+#if defined(ZJ_ABLATION)
     p.debug = c->debug;
+#endif
     if (plane_stride) p.y_frame_stride = p.c_frame_stride = plane_stride;
     if (out_stride) p.out_frame_stride = out_stride;
     const size_t ostride = out_stride ? (size_t)out_stride : pl.out_len;
@@ -477,7 +481,9 @@ static int decode_planes_batch_impl(zj_ctx* c, const zj_frame_desc* d, size_t nf
             Params p;
             fill_params(d, pl, whole ? nfr : 1, (const int16_t*)sl.buf[0], (const int16_t*)sl.buf[1],
                         (const int16_t*)sl.buf[2], (uint8_t*)sl.buf[3], 1, p);
-            p.debug = c->debug;
+        #if defined(ZJ_ABLATION)
+    p.debug = c->debug;
+#endif
             if (!whole) { // strips [s0, s1) of frame f0 as a frame of its own
                 p.n_strips = (int)(s1 - s0);
                 p.height = (int)d->height - (int)s0 * pl.strip_rows;
@@ -1042,81 +1048,14 @@ zj_color_convert16_fn zj_choose_ycbcr_to_rgb_convert_func(int backend, int out_c
 int zj_set_variant(zj_ctx* c, int variant) { if (!c || variant < 0 || variant > 2) return ZJ_ERR_ARG; c->variant = variant; return ZJ_OK; }
 /* 0 = one unit per zj_decode_planes_batch call (no copy/compute overlap); A/B timing only */
 int zj_set_pipeline(zj_ctx* c, int on) { if (!c) return ZJ_ERR_ARG; c->pipeline = on ? 1 : 0; return ZJ_OK; }
-/* occupancy probe (tools/occupancy.py): pad every fused launch with dynamic LDS; query workgroups per CU */
-int zj_set_pad_lds(int bytes) { set_pad_lds(bytes); return ZJ_OK; }
-int zj_fused_occupancy(int pad_lds) { return fused_occupancy_420_rgb(pad_lds); }
-/* ablation for tools/ablate.py: bit 0 skips the IDCT, bit 1 the colour math; output is WRONG when non-zero */
-int zj_set_ablation(zj_ctx* c, int mask) { if (!c) return ZJ_ERR_ARG; c->debug = mask; return ZJ_OK; }
-
-/* micro-benchmark hooks used by tools/ubench.py (not part of the decode path) */
-int zj_ubench_count(void) { return ubench2_count(); }
-const char* zj_ubench_name(int op) { return ubench2_name(op); }
-int zj_ubench(zj_ctx* c, int op, int blocks, int iters, int reps, float* ms)
-{
-    if (!c || !ms) return ZJ_ERR_ARG;
-    ZJ_HIP(c, hipSetDevice(c->device));
-    int rc = ensure_scratch(c, 0, (size_t)blocks * 256 * 4);
-    if (rc) return rc;
-    ZJ_HIP(c, launch_ubench2(op, (int*)c->scratch[0], blocks, iters, 12345, c->stream)); // warm-up
-    ZJ_HIP(c, hipEventRecord(c->ev0, c->stream));
-    for (int r = 0; r < reps; r++) ZJ_HIP(c, launch_ubench2(op, (int*)c->scratch[0], blocks, iters, 12345 + r, c->stream));
-    ZJ_HIP(c, hipEventRecord(c->ev1, c->stream));
-    ZJ_HIP(c, hipEventSynchronize(c->ev1));
-    ZJ_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
-    return ZJ_OK;
-}
-int zj_labmem_count(void) { return labmem_count(); }
-const char* zj_labmem_name(int i) { return labmem_name(i); }
-int zj_labmem(zj_ctx* c, int variant, long long bytes, int reps, float* ms)
-{
-    if (!c || !ms || bytes % (384 * 256) != 0) return ZJ_ERR_ARG;
-    ZJ_HIP(c, hipSetDevice(c->device));
-    int rc;
-    if ((rc = ensure_scratch(c, 0, (size_t)bytes)) || (rc = ensure_scratch(c, 3, (size_t)bytes))) return rc;
-    ZJ_HIP(c, hipMemsetAsync(c->scratch[0], 1, (size_t)bytes, c->stream));
-    for (int r = 0; r < 3; r++) ZJ_HIP(c, launch_labmem(variant, c->scratch[0], c->scratch[3], bytes, c->stream));
-    ZJ_HIP(c, hipEventRecord(c->ev0, c->stream));
-    for (int r = 0; r < reps; r++) ZJ_HIP(c, launch_labmem(variant, c->scratch[0], c->scratch[3], bytes, c->stream));
-    ZJ_HIP(c, hipEventRecord(c->ev1, c->stream));
-    ZJ_HIP(c, hipEventSynchronize(c->ev1));
-    ZJ_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
-    return ZJ_OK;
-}
-int zj_lab_count(void) { return lab_count(); }
-const char* zj_lab_name(int i) { return lab_name(i); }
-int zj_lab(zj_ctx* c, int variant, int blocks, int iters, int reps, float* ms)
-{
-    if (!c || !ms) return ZJ_ERR_ARG;
-    ZJ_HIP(c, hipSetDevice(c->device));
-    int rc = ensure_scratch(c, 0, (size_t)blocks * 256 * 4);
-    if (rc) return rc;
-    int32_t qt3[3][64];
-    for (int k = 0; k < 3; k++) for (int i = 0; i < 64; i++) qt3[k][i] = 1 + ((i * 7 + k * 3) % 29);
-    ZJ_HIP(c, launch_lab(variant, qt3, (int*)c->scratch[0], blocks, iters, c->stream)); // warm-up
-    ZJ_HIP(c, hipEventRecord(c->ev0, c->stream));
-    for (int r = 0; r < reps; r++) ZJ_HIP(c, launch_lab(variant, qt3, (int*)c->scratch[0], blocks, iters, c->stream));
-    ZJ_HIP(c, hipEventRecord(c->ev1, c->stream));
-    ZJ_HIP(c, hipEventSynchronize(c->ev1));
-    ZJ_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
-    return ZJ_OK;
-}
-/* shader clock: cycles counted by s_memtime in one wave over a fixed spin, and the wall ms of it */
-int zj_ubench_clock(zj_ctx* c, int iters, double* cycles, float* ms)
-{
-    if (!c || !cycles || !ms) return ZJ_ERR_ARG;
-    ZJ_HIP(c, hipSetDevice(c->device));
-    int rc = ensure_scratch(c, 0, 4096);
-    if (rc) return rc;
-    ZJ_HIP(c, launch_ub_clock((unsigned long long*)c->scratch[0], 1, iters, c->stream));
-    ZJ_HIP(c, hipEventRecord(c->ev0, c->stream));
-    ZJ_HIP(c, launch_ub_clock((unsigned long long*)c->scratch[0], 1, iters, c->stream));
-    ZJ_HIP(c, hipEventRecord(c->ev1, c->stream));
-    ZJ_HIP(c, hipEventSynchronize(c->ev1));
-    ZJ_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
-    unsigned long long v = 0;
-    ZJ_HIP(c, hipMemcpy(&v, c->scratch[0], 8, hipMemcpyDeviceToHost));
-    *cycles = (double)v;
-    return ZJ_OK;
-}
-
 } // extern "C"
+
+#if defined(ZJ_ABLATION)
+/* diagnostic build only (tools/build_variant.sh ablate "-DZJ_ABLATION"; never in the product library) */
+/* occupancy probe (tools/occupancy.py): pad every fused launch with dynamic LDS; query workgroups per CU */
+extern "C" __attribute__((visibility("default"))) int zj_set_pad_lds(int bytes) { set_pad_lds(bytes); return ZJ_OK; }
+extern "C" __attribute__((visibility("default"))) int zj_fused_occupancy(int pad_lds) { return fused_occupancy_420_rgb(pad_lds); }
+/* ablation for tools/ablate.py: bit 0 skips the IDCT, bit 1 the colour math; output is WRONG when non-zero */
+extern "C" __attribute__((visibility("default"))) int zj_set_ablation(zj_ctx* c, int mask) { if (!c) return ZJ_ERR_ARG; c->debug = mask; return ZJ_OK; }
+#endif
+

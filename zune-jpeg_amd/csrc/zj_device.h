@@ -42,8 +42,10 @@ struct alignas(8) U2 { uint32_t x, y; };
 typedef uint32_t V4 __attribute__((vector_size(16)));    // the same 16 bytes for builtins that want a vector
 #if defined(ZJ_ABLATION)
 #define ZJ_ABL(debug, bit) ((debug) & (bit))
+#define ZJ_PDBG(p) ((p).debug)
 #else
 #define ZJ_ABL(debug, bit) 0  // the ablation switches exist only in the diagnostic build (tools/ablate.py)
+#define ZJ_PDBG(p) 0          // ... and so does Params::debug: nothing of it travels in a product launch
 #endif
 // ZJ_NT (tools/ab_libs.sh): bit 0 = non-temporal pixel stores everywhere, bit 1 = non-temporal coefficient loads,
 // bit 2 = non-temporal stores where a store instruction writes whole, lane-contiguous lines (the staged stores of
@@ -695,7 +697,9 @@ struct Params {
     int nframes;
     int zero_fill;                // 1: also write the bytes the reference leaves 0 (Q5/Q6)
     int total_tiles;
-    int debug;                    // diagnostics only (tools/ablate.py): 1 skip IDCT, 2 skip colour math, 4 no loads, 8 no stores
+#if defined(ZJ_ABLATION)
+    int debug;                    // diagnostic build only (tools/ablate.py): 1 skip IDCT, 2 skip colour math, 4 no loads, 8 no stores
+#endif
     int plain;                    // OUT_RGB only: 1 = the last 16 samples of a row go to their own position (no Q5/Q6)
     long long plane_stride;       // OUT_RGB_CHW: bytes between the R, G and B planes of a frame (width * height)
     int clamp_dc;                 // extension: DC-only shortcut value clamped to 0..255 (Q1 corrected)
@@ -1270,7 +1274,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
         for (int ch = 0; ch < 2; ch++) {
             const char* cp = lds + LL::C_OFF + ch * C::CSZ * 2;
             uint32_t* dst = ch ? crp : cbp;
-            if (ZJ_ABL(p.debug, 16)) { // ablation: no chroma reads from LDS, no filters (output is wrong)
+            if (ZJ_ABL(ZJ_PDBG(p), 16)) { // ablation: no chroma reads from LDS, no filters (output is wrong)
 #pragma unroll
                 for (int k = 0; k < 8; k++) dst[k] = yp[k] + ch;
                 continue;
@@ -1334,7 +1338,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
         ZJ_COLOR_SB();
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            c[k] = (OUT != OUT_YCBCR && !ZJ_ABL(p.debug, 2)) ? ycc_to_rgb_pair(yp[k], cbp[k], crp[k]) : trunc3(yp[k], cbp[k], crp[k]);
+            c[k] = (OUT != OUT_YCBCR && !ZJ_ABL(ZJ_PDBG(p), 2)) ? ycc_to_rgb_pair(yp[k], cbp[k], crp[k]) : trunc3(yp[k], cbp[k], crp[k]);
         if (OUT == OUT_RGBA) {
             // extension: 16 pixels -> 64 bytes at their own position, any width clipped at 4W
             uint32_t q[16];
@@ -1414,7 +1418,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
             continue;
         }
         const U4 s0 = {d[0], d[1], d[2], d[3]}, s1 = {d[4], d[5], d[6], d[7]}, s2 = {d[8], d[9], d[10], d[11]};
-        if (ZJ_ABL(p.debug, 8) && (d[0] ^ d[5] ^ d[11]) != 0x12345u) continue; // ablation: (practically) no HBM writes
+        if (ZJ_ABL(ZJ_PDBG(p), 8) && (d[0] ^ d[5] ^ d[11]) != 0x12345u) continue; // ablation: (practically) no HBM writes
         const int G = px0 >> 4; // 16-pixel group index in the row
         const bool quirk = OUT == OUT_RGB && !p.plain;
         if (TS) {

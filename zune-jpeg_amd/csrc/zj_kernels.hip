@@ -44,11 +44,11 @@ __device__ __forceinline__ void tile_wide(const Params& p, const TileId t, const
     ZJ_SETPRIO(1, 3); // issue the tile's loads ahead of other waves' arithmetic
     const BlockLoc L = locate<C, GEN_WIDE>(p, t, tid, lds);
     U4 raw[8];
-    load_block(L, raw, p.debug); // HBM loads in flight across the barrier below
+    load_block(L, raw, ZJ_PDBG(p)); // HBM loads in flight across the barrier below
     ZJ_SETPRIO(1, 0);
     phase_setup<C, HS, VS, GEN_WIDE>(p, tid, lds);
     __syncthreads();
-    finish_block<C, GEN_WIDE, false>(L, raw, lds, p.debug, p.clamp_dc);
+    finish_block<C, GEN_WIDE, false>(L, raw, lds, ZJ_PDBG(p), p.clamp_dc);
     __syncthreads();
     ZJ_SETPRIO(2, 2); // (off) let a tile's last phase, the one that frees the workgroup slot, go first
     phase_color<C, HS, VS, OUT, GEN_WIDE, FAST>(p, t, tid, lds);
@@ -77,7 +77,7 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAV
         halo_load(H, hs8);
     } else {
         L = locate<C, GEN_PACKED>(p, t, tid, lds);
-        load_block(L, raw, p.debug);
+        load_block(L, raw, ZJ_PDBG(p));
     }
     ZJ_SETPRIO(1, 0);
     phase_setup<C, HS, VS, GEN_PACKED>(p, tid, lds);
@@ -87,7 +87,7 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAV
         ZJ_WAVE_FENCE();
         halo_pass2<C>(H, lds, p.clamp_dc);
     } else {
-        finish_block<C, GEN_PACKED, NEED_Y16>(L, raw, lds, p.debug, p.clamp_dc);
+        finish_block<C, GEN_PACKED, NEED_Y16>(L, raw, lds, ZJ_PDBG(p), p.clamp_dc);
     }
     // The coefficient loads are consumed inside exec-masked regions, so on the paths that skip those regions the
     // compiler still counts them as outstanding and would put `s_waitcnt vmcnt(0)` in front of every later reuse of
@@ -123,7 +123,8 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAV
     }
 }
 
-// occupancy probe of tools/occupancy.py: extra dynamic LDS per workgroup (never set by the product)
+#if defined(ZJ_ABLATION)
+// occupancy probe of tools/occupancy.py (diagnostic build only): extra dynamic LDS per workgroup
 static int g_pad_lds = 0;
 void set_pad_lds(int bytes) { g_pad_lds = bytes < 0 ? 0 : bytes; }
 int fused_occupancy_420_rgb(int pad_lds)
@@ -132,6 +133,9 @@ int fused_occupancy_420_rgb(int pad_lds)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zj_fused_kernel<2, 2, OUT_RGB, GEN_PACKED, true, true>, Cfg<2, 2, OUT_RGB>::NT, (size_t)pad_lds) != hipSuccess) return -1;
     return n;
 }
+#else
+static constexpr int g_pad_lds = 0;
+#endif
 
 // variant: 0 = packed generation (staged stores where they apply), 1 = wide generation (round 1), 2 = packed with
 // direct stores.  All are bit-exact; 1 and 2 exist for A/B measurements and as the parity cross-check.

@@ -7,25 +7,17 @@
 
 namespace zj {
 hipError_t launch_fused(int hs, int vs, int out, int variant, int fast, const Params& p, hipStream_t s);
+#if defined(ZJ_ABLATION)
 void set_pad_lds(int bytes);
 int fused_occupancy_420_rgb(int pad_lds);
+#endif
 const char* fused_kernel_name(int hs, int vs, int out, int variant, int fast, const Params& p);
 hipError_t launch_idct_strip(const int16_t* coeff, const int32_t qt[64], int16_t* out, long long nblocks,
                              long long chunks, long long bpc, long long stride, hipStream_t s);
 hipError_t launch_upsample_h(const int16_t* in, long long n, int16_t* out, long long out_len, long long m, hipStream_t s);
 hipError_t launch_upsample_v(const int16_t* in, long long stride, int16_t* out, long long out_len, hipStream_t s);
 hipError_t launch_rgb16(const int16_t* ycc, uint8_t* out, hipStream_t s);
-int ubench2_count();
-const char* ubench2_name(int op);
-hipError_t launch_ubench2(int op, int* out, int blocks, int iters, int seed, hipStream_t s);
-int labmem_count();
-const char* labmem_name(int i);
-hipError_t launch_labmem(int i, const void* in, void* out, long long bytes, hipStream_t s);
-int lab_count();
-const char* lab_name(int i);
-hipError_t launch_lab(int i, const int32_t qt[3][64], int* out, int blocks, int iters, hipStream_t s);
 // b: the working sets of njobs scans; max_nsub: the largest scan's sub-sequence count
 hipError_t launch_huff_sync(const HuffBatch& b, int njobs, uint32_t max_nsub, int round, bool periodic, hipStream_t s); // one synchronisation round (+ the periodic-run pass in front of it)
 hipError_t launch_huff_finish(const HuffBatch& b, int njobs, uint32_t max_nsub, hipStream_t s);         // prefix sums, write pass, EOI cut
-hipError_t launch_ub_clock(unsigned long long* out, int blocks, int iters, hipStream_t s);
 } // namespace zj

@@ -146,7 +146,9 @@ inline void fill_params(const zj_frame_desc* d, const Plan& pl, size_t nframes, 
     p.mcu_x = pl.mcu_x; p.n_strips = pl.n_strips; p.tiles_per_row = pl.tiles_per_row;
     p.nframes = (int)nframes; p.zero_fill = zero_fill;
     p.total_tiles = (int)nframes * pl.n_strips * pl.tiles_per_row;
+#if defined(ZJ_ABLATION)
     p.debug = 0;
+#endif
     p.plain = pl.plain;
     p.clamp_dc = pl.clamp_dc;
     p.edge_rep = pl.edge_rep;

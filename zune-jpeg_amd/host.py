@@ -150,7 +150,7 @@ ABI = [  # every symbol include/zjhip.h declares
     "zj_decoder_decode_coefficients", "zj_decoder_finish_pixels", "zj_decoder_decode_buffer",
     "zj_decoder_parallel_segments",
     "zj_pool_create", "zj_pool_destroy", "zj_pool_threads", "zj_pool_error", "zj_pool_stats",
-    "zj_pool_decode_files",
+    "zj_pool_decode_files", "zj_set_variant", "zj_set_pipeline",
 ]
 
 
@@ -236,7 +236,6 @@ def lib():
     L.zj_choose_upsample_func.argtypes = [C.c_int, C.c_int, C.c_int]
     L.zj_choose_ycbcr_to_rgb_convert_func.restype = vp
     L.zj_choose_ycbcr_to_rgb_convert_func.argtypes = [C.c_int, C.c_int]
-    L.zj_ubench.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.zj_decoder_new.restype = vp
     L.zj_decoder_new.argtypes = [C.POINTER(Options)]
     L.zj_decoder_free.argtypes = [vp]
@@ -270,16 +269,8 @@ def lib():
     L.zj_pool_decode_files_device.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp]
     L.zj_set_pipeline.argtypes = [vp, C.c_int]
     L.zj_set_variant.argtypes = [vp, C.c_int]
-    L.zj_set_ablation.argtypes = [vp, C.c_int]
-    L.zj_ubench_name.restype = C.c_char_p
-    L.zj_ubench_name.argtypes = [C.c_int]
-    L.zj_labmem.argtypes = [vp, C.c_int, C.c_longlong, C.c_int, C.POINTER(C.c_float)]
-    L.zj_labmem_name.restype = C.c_char_p
-    L.zj_labmem_name.argtypes = [C.c_int]
-    L.zj_lab.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
-    L.zj_lab_name.restype = C.c_char_p
-    L.zj_lab_name.argtypes = [C.c_int]
-    L.zj_ubench_clock.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float)]
+    if hasattr(L, "zj_set_ablation"):  # diagnostic build only (tools/build_variant.sh ablate "-DZJ_ABLATION")
+        L.zj_set_ablation.argtypes = [vp, C.c_int]
     _LIB = L
     return L
 
@@ -453,7 +444,10 @@ class Context:
         _check(lib().zj_set_pipeline(self._h, int(bool(on))), "zj_set_pipeline", self._h)
 
     def set_ablation(self, mask):
-        """Diagnostics only: bit 0 skips the IDCT, bit 1 the colour math (output is wrong when set)."""
+        """Diagnostic build only (ZJ_LIB=libzjhip_ablate.so): bit 0 skips the IDCT, bit 1 the colour math (output is
+        wrong when set).  The product library has no such switch."""
+        if not hasattr(lib(), "zj_set_ablation"):
+            raise ZjError(ERR_ARG, "zj_set_ablation: not in this build (tools/build_variant.sh ablate \"-DZJ_ABLATION\")")
         _check(lib().zj_set_ablation(self._h, int(mask)), "zj_set_ablation", self._h)
 
     def device_alloc(self, nbytes):
@@ -507,26 +501,6 @@ class Context:
         if rc < 0:
             _check(rc, "zj_decode_scan", self._h)
         return out, rc, st.value
-
-    def ubench(self, op, blocks=2048, iters=200, reps=5):
-        ms = C.c_float(0)
-        _check(lib().zj_ubench(self._h, op, blocks, iters, reps, C.byref(ms)), "zj_ubench", self._h)
-        return ms.value / reps
-
-    def lab(self, variant, blocks=4096, iters=20, reps=3):
-        ms = C.c_float(0)
-        _check(lib().zj_lab(self._h, variant, blocks, iters, reps, C.byref(ms)), "zj_lab", self._h)
-        return ms.value / reps
-
-    def labmem(self, variant, nbytes, reps=20):
-        ms = C.c_float(0)
-        _check(lib().zj_labmem(self._h, variant, nbytes, reps, C.byref(ms)), "zj_labmem", self._h)
-        return ms.value / reps
-
-    def ubench_clock_mhz(self, iters=200000):
-        cyc, ms = C.c_double(0), C.c_float(0)
-        _check(lib().zj_ubench_clock(self._h, iters, C.byref(cyc), C.byref(ms)), "zj_ubench_clock", self._h)
-        return cyc.value / (ms.value * 1e3)
 
 
 class DecodeError(ZjError):
@@ -726,6 +700,9 @@ class FileBatchDecoder:
         h, w = int(info.height), int(info.width)
         shape = (len(files), nc, h, w) if self._layout == LAYOUT_CHW else (len(files), h, w, nc)
         t = torch.empty(shape, dtype=torch.uint8, device=device)
+        # torch's caching allocator may hand back a block that work queued on torch's current stream still reads; the
+        # library writes it on ITS OWN stream, so that work has to be over first (completion is the library's business)
+        torch.cuda.current_stream(t.device).synchronize()
         step = h * w * nc
         if step % 16:
             raise ZjError(ERR_ARG, "to_tensor: width * height * components must be a multiple of 16 (rows of the tensor are the outputs)")
@@ -800,6 +777,7 @@ class Pool:
         nc = 1 if info.components == 1 else ColorSpace(self._out_cs).num_components()
         h, w = int(info.height), int(info.width)
         t = torch.empty((len(blobs), nc, h, w) if layout == LAYOUT_CHW else (len(blobs), h, w, nc), dtype=torch.uint8, device=device)
+        torch.cuda.current_stream(t.device).synchronize()   # see FileBatchDecoder.to_tensor: the pool writes on its own streams
         step = h * w * nc
         if step % 16:
             raise ZjError(ERR_ARG, "to_tensor: width * height * components must be a multiple of 16")
