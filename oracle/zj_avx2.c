@@ -216,6 +216,56 @@ int zja_upsample_h(const int16_t *in, size_t n, int16_t *out, size_t out_len)
     return ZJO_OK;
 }
 
+/* ---- upsample_horizontal_sse_u, src/upsampler/sse.rs:24-134, statement by statement --------------
+ * NOT the same function as the scalar arm: its last eight outputs are written "manually" (sse.rs:113-131) and three of
+ * them use other taps than src/upsampler/scalar.rs:5-60 -- out[2n-5] = (3 in[n-3] + in[n-3] + 2) >> 2, out[2n-4] =
+ * (3 in[n-2] + in[n-2] + 2) >> 2, out[2n-3] = (3 in[n-2] + in[n-3] + 2) >> 2 where the scalar arm has taps in[n-2],
+ * in[n-3], in[n-1].  On unit-step ramps both give the same numbers, which is all the reference's own tests
+ * (src/upsampler.rs:126-151) assert; tests/test_oracle.py replays exactly those and shows the difference elsewhere.
+ * i16 arithmetic wraps (release build).  Kept out of the timed baseline: the reference never selects it for (2,2). */
+int zja_upsample_h_sse(const int16_t *in, size_t n, int16_t *out, size_t out_len)
+{
+    memset(out, 0, out_len * sizeof(int16_t));                      /* vec![0; output_len]            sse.rs:27 */
+    if (!(out_len > 8 && n > 5)) return ZJO_ERR_PANIC;              /* assert!                        sse.rs:33 */
+#define W16(x) ((int16_t)(x))
+    out[0] = in[0];                                                 /* sse.rs:41-55 */
+    out[1] = W16(W16(W16(in[0] * 3) + in[1] + 2) >> 2);
+    out[2] = W16(W16(W16(in[1] * 3) + in[0] + 2) >> 2);
+    out[3] = W16(W16(W16(in[1] * 3) + in[2] + 2) >> 2);
+    out[4] = W16(W16(W16(in[2] * 3) + in[1] + 2) >> 2);
+    out[5] = W16(W16(W16(in[2] * 3) + in[3] + 2) >> 2);
+    out[6] = W16(W16(W16(in[3] * 3) + in[2] + 2) >> 2);
+    out[7] = W16(W16(W16(in[3] * 3) + in[4] + 2) >> 2);
+    for (size_t i = 1; i < (n >> 2) - 1; i++) {                     /* sse.rs:69 */
+        const size_t pos = i << 2;
+        __m128i yn = _mm_loadl_epi64((const __m128i *)(in + pos));
+        yn = _mm_unpacklo_epi16(yn, yn);                            /* [a,a,b,b,c,c,d,d] */
+        const __m128i v = _mm_loadl_epi64((const __m128i *)(in + pos - 1));
+        const __m128i y = _mm_loadl_epi64((const __m128i *)(in + pos + 1));
+        const __m128i even = _mm_unpacklo_epi16(v, v), odd = _mm_unpacklo_epi16(y, y);
+        const __m128i nn = _mm_blend_epi16(even, odd, 0xAA);        /* sse.rs:85 */
+        const __m128i an = _mm_add_epi16(_mm_slli_epi16(yn, 1), yn);/* input[x]*3                     sse.rs:95 */
+        const __m128i bn = _mm_add_epi16(nn, _mm_set1_epi16(2));
+        const __m128i cn = _mm_srai_epi16(_mm_add_epi16(an, bn), 2);
+        if (i * 8 + 8 > out_len) return ZJO_ERR_PANIC;              /* out.get_mut(..).unwrap()       sse.rs:105 */
+        _mm_storeu_si128((__m128i *)(out + i * 8), cn);
+    }
+    {                                                               /* sse.rs:112-131 */
+        int16_t *l = out + (out_len - 8);
+        const size_t il = n - 4;
+        l[0] = W16(W16(W16(in[il] * 3) + in[il - 1] + 2) >> 2);
+        l[1] = W16(W16(W16(in[il] * 3) + in[il + 1] + 2) >> 2);
+        l[2] = W16(W16(W16(in[il + 1] * 3) + in[il] + 2) >> 2);
+        l[3] = W16(W16(W16(in[il + 1] * 3) + in[il + 1] + 2) >> 2);
+        l[4] = W16(W16(W16(in[il + 2] * 3) + in[il + 2] + 2) >> 2);
+        l[5] = W16(W16(W16(in[il + 2] * 3) + in[il + 1] + 2) >> 2);
+        l[6] = W16(W16(W16(in[il + 2] * 3) + in[il + 3] + 2) >> 2);
+        l[7] = in[il + 3];
+    }
+#undef W16
+    return ZJO_OK;
+}
+
 /* ---- colour: src/color_convert/avx.rs:81-192 --------------------------------------------------- */
 static inline void ycbcr_to_rgb_avx2_16(const int16_t *y, const int16_t *cb, const int16_t *cr, uint8_t *o)
 {
@@ -235,6 +285,15 @@ static inline void ycbcr_to_rgb_avx2_16(const int16_t *y, const int16_t *cb, con
         o[3 * j + 1] = (uint8_t)ga[j];
         o[3 * j + 2] = (uint8_t)ba[j];
     }
+}
+
+/* ycbcr_to_rgb_avx2 (src/color_convert/avx.rs:81-106) behind the ColorConvert16Ptr contract: 48 bytes at *pos, pos += 48 */
+int zja_ycbcr_to_rgb16(const int16_t y[16], const int16_t cb[16], const int16_t cr[16], uint8_t *out, size_t out_len, size_t *pos)
+{
+    if (*pos + 48 > out_len) return ZJO_ERR_PANIC;                  /* output.get_mut(*pos..*pos + 48).expect  avx.rs:91 */
+    ycbcr_to_rgb_avx2_16(y, cb, cr, out + *pos);
+    *pos += 48;
+    return ZJO_OK;
 }
 
 /* worker.rs:143-251 with the AVX2 16-pixel kernel; width >= 16 only (bench geometry) */

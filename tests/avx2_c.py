@@ -44,6 +44,22 @@ def upsample_hv(inp, out_len):
     return rc, out
 
 
+def upsample_h_sse(inp, out_len):
+    """upsample_horizontal_sse_u (src/upsampler/sse.rs:24)."""
+    inp = np.ascontiguousarray(inp, np.int16)
+    out = np.empty(out_len, np.int16)
+    rc = lib().zja_upsample_h_sse(_p(inp), C.c_size_t(inp.size), _p(out), C.c_size_t(out_len))
+    return rc, out
+
+
+def ycbcr_to_rgb16(y, cb, cr, out, pos):
+    """ycbcr_to_rgb_avx2 (src/color_convert/avx.rs:81); returns (rc, new pos)."""
+    y, cb, cr = (np.ascontiguousarray(a, np.int16) for a in (y, cb, cr))
+    p = C.c_size_t(pos)
+    rc = lib().zja_ycbcr_to_rgb16(_p(y), _p(cb), _p(cr), _p(out), C.c_size_t(out.size), C.byref(p))
+    return rc, p.value
+
+
 def decode_planes_mt(frame, planes, nframes=1, nthreads=4, out=None):
     arrs = [np.ascontiguousarray(p, np.int16) for p in planes]
     if out is None:

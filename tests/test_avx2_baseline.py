@@ -58,3 +58,76 @@ def test_avx2_frame_close_to_scalar(mode, synth):
     d = np.abs(outs[0][1].astype(np.int32) - exp.astype(np.int32))
     assert d.max() <= 4 and np.mean(d != 0) < 0.5
     assert not outs[0][1].reshape(h, 3 * w)[:, -16:].any()  # same Q5/Q6 tail as the scalar worker
+
+
+# ---- the reference's own relational tests, replayed (the only vectors it holds beyond the IDCT KATs) ----
+
+@pytest.mark.parametrize("ramp", [np.arange(0, 128, dtype=np.int16), np.arange(1279, -1, -1, dtype=np.int16)],
+                         ids=["upsample_sse_v1: 0..128", "upsample_sse_v2: (0..1280).rev()"])
+def test_reference_upsample_sse_equals_scalar_on_its_ramps(ramp):
+    """src/upsampler.rs:126-151: upsample_horizontal_sse(v, 2 len) == scalar::upsample_horizontal(v, 2 len) on exactly
+    these two inputs.  Both sides are restatements (oracle/zj_avx2.c zja_upsample_h_sse <- src/upsampler/sse.rs:24-134,
+    oracle/zj_oracle.c zjo_upsample_h <- src/upsampler/scalar.rs:5-60): the reference's assertion pins them to each other."""
+    rc, sse = avx2_c.upsample_h_sse(ramp, 2 * ramp.size)
+    rc2, sc = oc.upsample_h(ramp, 2 * ramp.size)
+    assert rc == 0 and rc2 == 0
+    assert np.array_equal(sse, sc)
+    # ... and to the numpy restatement, and to the closed form of a unit-step ramp's triangle filter
+    import oracle_np as onp
+    assert np.array_equal(onp.upsample_horizontal(ramp, 2 * ramp.size), sc)
+    step = int(ramp[1]) - int(ramp[0])
+    i = np.arange(1, ramp.size - 1)
+    assert np.array_equal(sc[2 * i].astype(np.int64), (4 * ramp[i].astype(np.int64) - step + 2) >> 2)
+    assert np.array_equal(sc[2 * i + 1].astype(np.int64), (4 * ramp[i].astype(np.int64) + step + 2) >> 2)
+
+
+def test_reference_upsample_sse_differs_from_scalar_only_in_three_of_its_last_eight_outputs():
+    """What the ramps cannot show: sse.rs:113-131 writes the last eight outputs with other taps than the scalar arm at
+    positions 2n-5, 2n-4, 2n-3 (oracle/zj_avx2.c header); everywhere else the two arms agree on arbitrary data."""
+    rng = np.random.default_rng(8)
+    seen = set()
+    for n in (8, 12, 64, 1280, 4096):
+        for _ in range(20):
+            v = rng.integers(-300, 600, size=n).astype(np.int16)
+            rc, sse = avx2_c.upsample_h_sse(v, 2 * n)
+            rc2, sc = oc.upsample_h(v, 2 * n)
+            assert rc == 0 and rc2 == 0
+            bad = np.nonzero(sse != sc)[0]
+            assert set(bad - 2 * n) <= {-5, -4, -3}
+            seen |= set(bad - 2 * n)
+            x = v.astype(np.int64)
+            assert sse[2 * n - 5] == (4 * x[n - 3] + 2) >> 2 and sse[2 * n - 4] == (4 * x[n - 2] + 2) >> 2
+            assert sse[2 * n - 3] == (3 * x[n - 2] + x[n - 3] + 2) >> 2
+    assert seen == {-5, -4, -3}
+    # the reference's asserts (sse.rs:33): out.len() > 8 and input.len() > 5
+    assert avx2_c.upsample_h_sse(np.zeros(5, np.int16), 10)[0] == oc.ERR_PANIC
+    assert avx2_c.upsample_h_sse(np.zeros(8, np.int16), 8)[0] == oc.ERR_PANIC
+
+
+def test_restated_avx2_colour_equals_scalar_colour():
+    """ycbcr_to_rgb_avx2 (src/color_convert/avx.rs:81-192) and ycbcr_to_rgb_16_scalar
+    (src/color_convert/scalar.rs:52-89) are the same arithmetic -- sub 128, i16 wrapping products, arithmetic shifts,
+    clamp -- so the two restatements must agree on EVERY i16 triple: 10^6 random ones over the full i16 range, 10^6 over
+    the range the IDCT can emit incl. the unclamped DC-only values (Q1: -3968 ... 4223), and the corners."""
+    rng = np.random.default_rng(9)
+    edge = np.array([-32768, -32767, -4097, -4096, -3968, -129, -128, -1, 0, 1, 127, 128, 255, 256, 4223, 4224, 32767], np.int16)
+    sets = [rng.integers(-32768, 32768, size=(3, 1_000_000 // 16 * 16)).astype(np.int16),
+            rng.integers(-3968, 4224, size=(3, 1_000_000 // 16 * 16)).astype(np.int16),
+            np.stack(np.meshgrid(edge, edge, edge, indexing="ij")).reshape(3, -1)[:, : edge.size ** 3 // 16 * 16].astype(np.int16)]
+    for ycc in sets:
+        n = ycc.shape[1]
+        a, s = np.zeros(3 * n, np.uint8), np.zeros(3 * n, np.uint8)
+        pa = ps = 0
+        for g in range(0, n, 16):
+            rc, pa = avx2_c.ycbcr_to_rgb16(ycc[0, g:g + 16], ycc[1, g:g + 16], ycc[2, g:g + 16], a, pa)
+            assert rc == 0
+        # the scalar arm over the same groups in one C call per 4096 groups would need a loop in C; the wrapper is cheap enough
+        for g in range(0, n, 16):
+            rc, ps = oc.ycbcr_to_rgb16(ycc[0, g:g + 16], ycc[1, g:g + 16], ycc[2, g:g + 16], s, ps)
+            assert rc == 0
+        assert pa == ps == 3 * n
+        assert np.array_equal(a, s)
+    # same panic rule: 48 bytes must fit behind *pos (avx.rs:91 / scalar.rs:60)
+    small = np.zeros(47, np.uint8)
+    z = np.zeros(16, np.int16)
+    assert avx2_c.ycbcr_to_rgb16(z, z, z, small, 0)[0] == oc.ERR_PANIC and oc.ycbcr_to_rgb16(z, z, z, small, 0)[0] == oc.ERR_PANIC

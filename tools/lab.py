@@ -24,7 +24,12 @@ def main():
     nbytes = 384 * 256 * 8192  # 805 MB in + 805 MB out, the size of one 16-frame launch
     for v in range(L.zjlab_labmem_count()):
         ms = ctx.labmem(v, nbytes, 20)
-        print(f"{'':16s}{L.zjlab_labmem_name(v).decode():52s} {ms:8.3f} ms {2 * nbytes / ms / 1e6:10.1f} GB/s")
+        name = L.zjlab_labmem_name(v).decode()
+        moved = nbytes if name.startswith("read only") else 2 * nbytes
+        print(f"{'':16s}{name:68s} {ms:8.3f} ms {moved / ms / 1e6:10.1f} GB/s")
+    L.zjlab_rd_check.argtypes = [__import__("ctypes").c_void_p, __import__("ctypes").c_int, __import__("ctypes").c_int]
+    for mode in (1, 2):
+        print(f"LDS-DMA read path, mode {mode}: blocks differing from the plain loads over 4096 tiles: {L.zjlab_rd_check(ctx.h, mode, 4096)}")
     ctx.close()
 
 

@@ -226,6 +226,112 @@ __global__ __launch_bounds__(256) void lab_stream_persistent(const U4* __restric
     for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < n; c += (long long)gridDim.x * 256) out[c] = in[c];
 }
 
+
+// ---- load-side lab: what does the decoder's READ pattern cost, and what would LDS-DMA change? ----------------------
+// A workgroup reads one "tile" of 192 coefficient blocks (24 KB contiguous here) and stores nothing.
+//   MODE 0  one lane per block, 8 x 16-byte global loads at a 128-byte lane stride (the decoder today: every wave
+//           instruction touches 64 different 128-byte lines, every line is visited by 8 instructions)
+//   MODE 1  waves 0-2: 8 x global_load_lds_dwordx4 each -- one wave instruction moves 1 KB of CONTIGUOUS memory (8 whole
+//           blocks) straight into LDS; the wave waits for its own data, then every lane reads its block's 8 chunks
+//           with ds_read_b128.  The 16-byte chunks of block b sit at slot c ^ ((b >> 1) & 7) of the block's 128 bytes
+//           (the permutation is applied to the SOURCE address, the LDS image of a DMA instruction is lane-linear), which
+//           makes the lane-per-block ds_read_b128 conflict-free in the hardware's lane groups.
+//   MODE 2  the same, all four waves issue 6 DMA instructions each, workgroup barrier before the reads
+// PAD: extra LDS so that 6 workgroups fit a CU, as in the fused kernel (26.4 KB)
+template <int MODE>
+__global__ __launch_bounds__(256, 6) void lab_rd(const U4* __restrict__ in, U4* __restrict__ out, long long ntiles)
+{
+    __shared__ __attribute__((aligned(16))) U4 raw[192 * 8 + 152];
+    long long id = blockIdx.x;
+    if ((ntiles & 7) == 0) id = (id & 7) * (ntiles >> 3) + (id >> 3);
+    const U4* src = in + id * (192 * 8);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    U4 v[8];
+    if (MODE == 0) {
+        if (tid < 192) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = src[tid * 8 + k];
+        }
+        if (tid == 255) raw[0] = v[0]; // keeps the allocation (and the occupancy) of the other modes
+    } else {
+        const int pos = lane & 7, sub = lane >> 3;
+        if (MODE == 1) {
+            if (w < 3) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int blk = 64 * w + 8 * i + sub;
+                    const U4* g = src + blk * 8 + (pos ^ ((blk >> 1) & 7));
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)(raw + (64 * w + 8 * i) * 8), 16, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const int blk = 48 * w + 8 * i + sub;
+                const U4* g = src + blk * 8 + (pos ^ ((blk >> 1) & 7));
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(raw + (48 * w + 8 * i) * 8), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (tid < 192) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = raw[tid * 8 + (k ^ ((tid >> 1) & 7))];
+        }
+    }
+    if (tid < 192) {
+        // MODE 0 and the DMA modes must see the same values: chunk k of block tid
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc += (v[k].x ^ (v[k].y + k)) + (v[k].z ^ v[k].w) * (k + 1);
+        if (acc == 0x9e3779b9u) out[id * 192 + tid].x = acc; // (practically) never: the kernel only reads
+    }
+}
+// the same with the sums written out, so that tools/lab.py can check MODE 1 / 2 against MODE 0 (one u32 per block)
+template <int MODE>
+__global__ __launch_bounds__(256, 6) void lab_rd_check(const U4* __restrict__ in, uint32_t* __restrict__ sums, long long ntiles)
+{
+    __shared__ __attribute__((aligned(16))) U4 raw[192 * 8 + 152];
+    const long long id = blockIdx.x;
+    const U4* src = in + id * (192 * 8);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    U4 v[8];
+    if (MODE == 0) {
+        if (tid < 192) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = src[tid * 8 + k];
+        }
+        if (tid == 255) raw[0] = v[0];
+    } else {
+        const int pos = lane & 7, sub = lane >> 3;
+        const int per = MODE == 1 ? 64 : 48, n = MODE == 1 ? 8 : 6;
+        if (MODE == 2 || w < 3) {
+            for (int i = 0; i < n; i++) {
+                const int blk = per * w + 8 * i + sub;
+                const U4* g = src + blk * 8 + (pos ^ ((blk >> 1) & 7));
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(raw + (per * w + 8 * i) * 8), 16, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid < 192) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = raw[tid * 8 + (k ^ ((tid >> 1) & 7))];
+        }
+    }
+    if (tid < 192) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc += (v[k].x ^ (v[k].y + k)) + (v[k].z ^ v[k].w) * (k + 1);
+        sums[id * 192 + tid] = acc;
+    }
+}
+
 typedef void (*labmem_fn)(const U4*, U4*, long long);
 static const struct { const char* name; labmem_fn fn; } LABMEM[] = {
     {"copy  rd=coalesced      wr=coalesced", lab_mem<0, 0>},
@@ -256,6 +362,9 @@ static const struct { const char* name; labtile_fn fn; int seg; } LABTILE[] = {
     {"32 KB per workgroup as 32 rows x 1024 B", lab_tile32k<1024>, 1024},
     {"32 KB per workgroup as 16 rows x 2048 B", lab_tile32k<2048>, 1024},
     {"32 KB per workgroup as  8 rows x 4096 B", lab_tile32k<4096>, 1024},
+    {"read only: lane per block, 8 x 16 B at 128-B stride (decoder)", lab_rd<0>, 768},
+    {"read only: LDS-DMA 1 KB/instruction, waves 0-2 x 8, ds_read_b128", lab_rd<1>, 768},
+    {"read only: LDS-DMA 1 KB/instruction, 4 waves x 6, barrier", lab_rd<2>, 768},
 };
 int labmem_count() { return (int)(sizeof(LABMEM) / sizeof(LABMEM[0])) + (int)(sizeof(LABTILE) / sizeof(LABTILE[0])); }
 const char* labmem_name(int i) { const int n = (int)(sizeof(LABMEM) / sizeof(LABMEM[0])); return i < n ? LABMEM[i].name : LABTILE[i - n].name; }
@@ -287,6 +396,15 @@ hipError_t launch_labmem(int i, const void* in, void* out, long long bytes, hipS
         return hipGetLastError();
     }
     hipLaunchKernelGGL(LABMEM[i].fn, dim3((unsigned)(T / 256)), dim3(256), 0, s, (const U4*)in, (U4*)out, T);
+    return hipGetLastError();
+}
+
+// MODE 0 / 1 / 2 of lab_rd_check over `ntiles` tiles of 24 KB: one u32 per block into sums (device memory)
+hipError_t launch_lab_rd_check(int mode, const void* in, uint32_t* sums, long long ntiles, hipStream_t s)
+{
+    if (mode == 0) hipLaunchKernelGGL(lab_rd_check<0>, dim3((unsigned)ntiles), dim3(256), 0, s, (const U4*)in, sums, ntiles);
+    else if (mode == 1) hipLaunchKernelGGL(lab_rd_check<1>, dim3((unsigned)ntiles), dim3(256), 0, s, (const U4*)in, sums, ntiles);
+    else hipLaunchKernelGGL(lab_rd_check<2>, dim3((unsigned)ntiles), dim3(256), 0, s, (const U4*)in, sums, ntiles);
     return hipGetLastError();
 }
 

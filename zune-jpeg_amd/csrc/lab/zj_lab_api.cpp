@@ -89,6 +89,29 @@ LAB_API int zjlab_lab(void* h, int variant, int blocks, int iters, int reps, flo
     for (int k = 0; k < 3; k++) for (int i = 0; i < 64; i++) qt3[k][i] = 1 + ((i * 7 + k * 3) % 29);
     return timed(c, reps, ms, [&](int) { return launch_lab(variant, qt3, (int*)c->buf[0], blocks, iters, c->stream); });
 }
+/* LDS-DMA read path of zj_lab.hip against the plain one: returns the number of blocks whose sums differ (0 = equal) */
+LAB_API int zjlab_rd_check(void* h, int mode, int ntiles)
+{
+    LabCtx* c = (LabCtx*)h;
+    const size_t bytes = (size_t)ntiles * 24576, nsum = (size_t)ntiles * 192;
+    if (!c || ntiles <= 0 || ensure(c, 0, bytes) || ensure(c, 1, nsum * 8)) return -1;
+    uint32_t* host = new uint32_t[bytes / 4];
+    uint32_t x = 12345;
+    for (size_t i = 0; i < bytes / 4; i++) { x = x * 1664525u + 1013904223u; host[i] = x; }
+    LAB_HIP(hipMemcpy(c->buf[0], host, bytes, hipMemcpyHostToDevice));
+    delete[] host;
+    uint32_t* d = (uint32_t*)c->buf[1];
+    LAB_HIP(hipMemsetAsync(d, 0, nsum * 8, c->stream));
+    LAB_HIP(launch_lab_rd_check(0, c->buf[0], d, ntiles, c->stream));
+    LAB_HIP(launch_lab_rd_check(mode, c->buf[0], d + nsum, ntiles, c->stream));
+    LAB_HIP(hipStreamSynchronize(c->stream));
+    uint32_t* got = new uint32_t[2 * nsum];
+    LAB_HIP(hipMemcpy(got, d, nsum * 8, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (size_t i = 0; i < nsum; i++) bad += got[i] != got[nsum + i] || got[i] == 0;
+    delete[] got;
+    return bad;
+}
 /* shader clock: cycles counted by s_memtime in one wave over a fixed spin, and the wall ms of it */
 LAB_API int zjlab_clock(void* h, int iters, double* cycles, float* ms)
 {

@@ -14,5 +14,6 @@ hipError_t launch_labmem(int i, const void* in, void* out, long long bytes, hipS
 int lab_count();
 const char* lab_name(int i);
 hipError_t launch_lab(int i, const int32_t qt[3][64], int* out, int blocks, int iters, hipStream_t s);
+hipError_t launch_lab_rd_check(int mode, const void* in, uint32_t* sums, long long ntiles, hipStream_t s);
 hipError_t launch_ub_clock(unsigned long long* out, int blocks, int iters, hipStream_t s);
 } // namespace zj
