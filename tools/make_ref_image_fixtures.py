@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""
+Pins the reference's OWN integration inputs (tests/large_images.rs:39-153, tests/medium_images.rs:40-121,
+tests/random_images.rs:38-99, benches/decode.rs:44-131: every file under tests/inputs, benches/images, test-images).
+Runs in the BUILD container only (reads /root/reference, which does not exist on the GPU box):
+
+  file -> product CPU front-end (zj_decoder_decode_coefficients: markers + Huffman, no GPU) -> coefficient planes
+       -> ORACLE pixel path (oracle/zj_oracle.c) -> RGB and GRAYSCALE bytes
+  sanity: agreement with libjpeg (Pillow) away from the Q5/Q6 tail columns (mean |diff| <= 2 levels)
+  record: tests/golden/ref_images.json -- name, geometry, scans, DRI, SHA-256 of the file, of the planes, of the outputs
+  copy:   the three small / odd files into tests/golden/ref/ as data (the GPU tests decode them to the recorded hashes)
+
+The reference asserts only `Ok` on these files; the hashes freeze what the restated scalar path makes of them.
+"""
+import hashlib
+import importlib
+import io
+import json
+import os
+import shutil
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+REF = "/root/reference"
+DIRS = ["tests/inputs", "benches/images", "test-images"]
+COPY = ["tests/inputs/huffman_third_index.jpg", "tests/inputs/single_qt.jpeg", "tests/inputs/medium_horiz_samp_2500x1786.jpg"]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main():
+    from PIL import Image
+    import oracle_c as oc
+    zj = importlib.import_module("zune-jpeg_amd")
+    out = {"what": "the reference's own test / bench inputs through the product's CPU front-end and the oracle's pixel path",
+           "tool": "tools/make_ref_image_fixtures.py", "files": []}
+    for d in DIRS:
+        for name in sorted(os.listdir(os.path.join(REF, d))):
+            path = os.path.join(REF, d, name)
+            data = open(path, "rb").read()
+            rec = {"file": f"{d}/{name}", "bytes": len(data), "sha256_file": hashlib.sha256(data).hexdigest()}
+            dec = zj.Decoder()
+            try:
+                desc, planes, info = dec.decode_coefficients(data)
+            except zj.DecodeError as e:
+                rec["error"] = str(e)
+                out["files"].append(rec)
+                print(f"{rec['file']:60s} error: {e}")
+                continue
+            w, h, nc = int(info.width), int(info.height), int(info.components)
+            qts = list(np.ctypeslib.as_array(desc.qt))
+            rec.update(width=w, height=h, components=nc, h_max=int(info.h_max), v_max=int(info.v_max),
+                       progressive=int(info.progressive), scans=int(info.scans), restart_interval=int(info.restart_interval),
+                       sha256_planes=sha(np.concatenate(planes)))
+            for cs_name, cs in (("rgb", oc.RGB), ("gray", oc.GRAYSCALE)):
+                rc, px = oc.decode_planes(oc.make_frame(w, h, info.h_max, info.v_max, nc, cs if nc == 3 else oc.GRAYSCALE, qts), planes)
+                assert rc == 0, (name, rc)
+                rec[f"sha256_{cs_name}"] = sha(px)
+                if cs_name == "rgb" and nc == 3:
+                    pil = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"), np.int32)
+                    dlt = np.abs(px.reshape(h, w, 3).astype(np.int32) - pil)[:, : max(w - 32, 16)]   # Q5/Q6 live in the last 16 samples
+                    rec["pillow_mean_abs_diff"] = round(float(dlt.mean()), 3)
+                    rec["pillow_p999_abs_diff"] = int(np.quantile(dlt, 0.999))
+                    assert dlt.mean() <= 2.0, (name, dlt.mean())
+            dec.close()
+            out["files"].append(rec)
+            print(f"{rec['file']:60s} {w}x{h} {info.h_max}x{info.v_max} prog={info.progressive} scans={info.scans} dri={info.restart_interval} "
+                  f"pillow mean|d|={rec.get('pillow_mean_abs_diff')}")
+    gold = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(os.path.join(gold, "ref"), exist_ok=True)
+    for f in COPY:
+        shutil.copyfile(os.path.join(REF, f), os.path.join(gold, "ref", os.path.basename(f)))
+        os.chmod(os.path.join(gold, "ref", os.path.basename(f)), 0o644)
+    json.dump(out, open(os.path.join(gold, "ref_images.json"), "w"), indent=1)
+    print("wrote tests/golden/ref_images.json;", len(out["files"]), "files")
+
+
+if __name__ == "__main__":
+    main()

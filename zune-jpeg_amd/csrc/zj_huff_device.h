@@ -245,6 +245,10 @@ ZJ_DEV HuffState huff_run(const HuffLds& L, uint32_t tid, uint32_t start_bits, H
             if (WRITE && w->blk < w->blk_end) dst = huff_block_ptr(h, *w, h.blk[j]);
         }
     }
+    // A segment that was cut short: its last symbol began inside the segment but ran past its exact end, into the padding
+    // or the next segment's bytes.  The CPU walker's reader feeds zero bits behind a marker (bitstream.rs:150-262), so the
+    // two would disagree about that symbol: hand the scan back (a well-formed segment ends at or before its limit).
+    if (WRITE && last_sub && pos > limit) status |= HUFF_ST_EXHAUSTED;
     aux.x = n; aux.y = d0; aux.z = d1; aux.w = d2;
     if (WRITE && status) huff_or(&w->ctl[HUFF_CTL_STATUS], status);
     HuffState o;
