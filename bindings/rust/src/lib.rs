@@ -2,12 +2,14 @@
 //! names follow the reference crate (`Decoder`, `ZuneJpegOptions`, `ColorSpace`, the three fn-pointer types of
 //! `src/decoder.rs:47,56` and `src/components.rs:14`).
 //!
-//! The C side is `include/zjhip.h` (ABI version 2).  Output bytes equal the reference's *scalar* arms.
+//! The C side is `include/zjhip.h` (ABI version 5, checked at run time by `Decoder::new_with_options`).  Output bytes equal the reference's *scalar* arms.
 #![allow(non_camel_case_types)]
 use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const ZJ_ABI_VERSION: c_int = 4;
+pub const ZJ_ABI_VERSION: c_int = 5;
+pub const ZJ_BACKEND_SCALAR: c_int = 0;
+pub const ZJ_BACKEND_AVX2: c_int = 1;
 pub const ZJ_BACKEND_HIP: c_int = 2;
 pub const ZJ_OK: c_int = 0;
 pub const ZJ_ERR_PANIC: c_int = -5;
@@ -67,6 +69,11 @@ pub struct zj_image_info {           // <-> ImageInfo, src/decoder.rs:652-668
 #[repr(C)] pub struct zj_ctx { _private: [u8; 0] }
 #[repr(C)] pub struct zj_decoder { _private: [u8; 0] }
 #[repr(C)] pub struct zj_pool { _private: [u8; 0] }
+
+/// the C fn-pointer types `zj_choose_*` hand out (`include/zjhip.h`)
+pub type zj_idct_fn = unsafe extern "C" fn(*mut zj_ctx, *const i16, usize, *const i32, usize, usize, usize, *mut i16) -> c_int;
+pub type zj_upsample_fn = unsafe extern "C" fn(*mut zj_ctx, *const i16, usize, *mut i16, usize) -> c_int;
+pub type zj_color_convert16_fn = unsafe extern "C" fn(*mut zj_ctx, *const i16, *const i16, *const i16, *mut u8, usize, *mut usize) -> c_int;
 
 extern "C" {
     pub fn zj_abi_version() -> c_int;
@@ -129,6 +136,29 @@ extern "C" {
     pub fn zj_pool_decode_files_device(pool: *mut zj_pool, nfiles: usize, bufs: *const *const u8, lens: *const usize,
                                        d_outs: *const *mut u8, out_caps: *const usize, out_lens: *mut usize,
                                        infos: *mut zj_image_info, statuses: *mut c_int) -> c_int;
+    pub fn zj_choose_idct_func(backend: c_int) -> Option<zj_idct_fn>;
+    pub fn zj_choose_upsample_func(backend: c_int, h_max: c_int, v_max: c_int) -> Option<zj_upsample_fn>;
+    pub fn zj_choose_ycbcr_to_rgb_convert_func(backend: c_int, out_cs: c_int) -> Option<zj_color_convert16_fn>;
+    pub fn zj_decode_planes_to_device(ctx: *mut zj_ctx, d: *const zj_frame_desc, y: *const i16, cb: *const i16,
+                                      cr: *const i16, d_out: *mut u8) -> c_int;
+    pub fn zj_time_decode_device(ctx: *mut zj_ctx, d: *const zj_frame_desc, nframes: usize, d_y: *const i16,
+                                 d_cb: *const i16, d_cr: *const i16, d_out: *mut u8, stream: *mut c_void, iters: c_int,
+                                 ms_total: *mut f32, ms_each: *mut f32, kernel_name: *mut *const c_char) -> c_int;
+    pub fn zj_decoder_gpu_status(d: *const zj_decoder) -> u32;
+    pub fn zj_decoder_parallel_segments(d: *const zj_decoder) -> c_int;
+    pub fn zj_decoder_scan_blob(d: *const zj_decoder, blob: *mut *const c_void, len: *mut usize) -> c_int;
+    pub fn zj_scan_planes(ctx: *mut zj_ctx, y: *mut i16, cb: *mut i16, cr: *mut i16, len: *mut usize) -> c_int;
+    pub fn zj_scan_stats(ctx: *const zj_ctx, rounds: *mut c_int, ms: *mut f32) -> c_int;
+    pub fn zj_pool_threads(pool: *const zj_pool) -> c_int;
+    pub fn zj_pool_stats(pool: *mut zj_pool, entropy_seconds: *mut f64, gpu_seconds: *mut f64, files: *mut usize) -> c_int;
+    pub fn zj_device_alloc(ctx: *mut zj_ctx, bytes: usize) -> *mut c_void;
+    pub fn zj_device_free(ctx: *mut zj_ctx, p: *mut c_void);
+    pub fn zj_memcpy_h2d(ctx: *mut zj_ctx, dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
+    pub fn zj_memcpy_d2h(ctx: *mut zj_ctx, dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
+    pub fn zj_device_memset(ctx: *mut zj_ctx, d_ptr: *mut c_void, value: c_int, bytes: usize) -> c_int;
+    pub fn zj_sync(ctx: *mut zj_ctx) -> c_int;
+    pub fn zj_set_variant(ctx: *mut zj_ctx, variant: c_int) -> c_int;
+    pub fn zj_set_pipeline(ctx: *mut zj_ctx, on: c_int) -> c_int;
 }
 
 fn check(rc: c_int, what: &str) {
@@ -173,37 +203,114 @@ pub fn ycbcr_to_rgb_hip_16(y: &[i16; 16], cb: &[i16; 16], cr: &[i16; 16], out: &
                                      out.len(), pos as *mut usize) }, "zj_ycbcr_to_rgb16");
 }
 
+/// `IDCTPtr` (`src/decoder.rs:56`), `UpSampler` (`src/components.rs:14`), `ColorConvert16Ptr` (`src/decoder.rs:47`).
+pub type IDCTPtr = fn(&[i16], &Aligned32<[i32; 64]>, usize, usize, usize) -> Vec<i16>;
+pub type UpSampler = fn(&[i16], usize) -> Vec<i16>;
+pub type ColorConvert16Ptr = fn(&[i16; 16], &[i16; 16], &[i16; 16], &mut [u8], &mut usize);
+
+/// Which arm of the reference's dispatch a decoder uses.  `Scalar` and `Simd` are the reference crate's own arms
+/// (`use_unsafe = false / true`) and stay there; this crate implements `Hip`.
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub enum Backend { Scalar, Simd, Hip }
+
+/// `choose_idct_func` (`src/idct.rs:40`) with the hip arm: `None` for the arms that live in the reference crate
+/// (the maintainer's patched `choose_idct_func` falls through to them).
+pub fn choose_idct_func(backend: Backend) -> Option<IDCTPtr> {
+    match backend { Backend::Hip => Some(dequantize_and_idct_hip), _ => None }
+}
+/// `choose_horizontal_samp_function` (`src/upsampler.rs:82`)
+pub fn choose_horizontal_samp_function(backend: Backend) -> Option<UpSampler> {
+    match backend { Backend::Hip => Some(upsample_horizontal_hip), _ => None }
+}
+/// `choose_hv_samp_function` (`src/upsampler.rs:97`)
+pub fn choose_hv_samp_function(backend: Backend) -> Option<UpSampler> {
+    match backend { Backend::Hip => Some(upsample_hv_hip), _ => None }
+}
+/// the (1,2) case of `Decoder::set_upsampling` (`src/decoder.rs:492-501`; the reference has a scalar arm only)
+pub fn choose_v_samp_function(backend: Backend) -> Option<UpSampler> {
+    match backend { Backend::Hip => Some(upsample_vertical_hip), _ => None }
+}
+/// `choose_ycbcr_to_rgb_convert_func` (`src/color_convert.rs:61`): the reference only ever asks for `ColorSpace::RGB`
+pub fn choose_ycbcr_to_rgb_convert_func(type_need: ColorSpace, backend: Backend) -> Option<ColorConvert16Ptr> {
+    match (backend, type_need) { (Backend::Hip, ColorSpace::RGB) => Some(ycbcr_to_rgb_hip_16), _ => None }
+}
+
 /// `DecodeErrors` (`src/errors.rs:16-43`) flattened: the status code of `include/zjhip.h` and the reference's text.
 #[derive(Debug)]
 pub struct DecodeErrors { pub status: i32, pub message: String }
+impl std::fmt::Display for DecodeErrors {
+    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result { write!(f, "{}", self.message) }
+}
+impl std::error::Error for DecodeErrors {}
 
-/// `ZuneJpegOptions` (`src/options.rs`).
+/// `ImageInfo` (`src/decoder.rs:652-668`): the fields the C side reports (`zj_image_info`).
+pub type ImageInfo = zj_image_info;
+
+/// `ZuneJpegOptions` (`src/options.rs:6-160`; defaults `:26-40`: use_unsafe, RGB, 4 threads, 16384 x 16384, 64 scans,
+/// not strict) plus the knobs of this library.
 #[derive(Clone, Copy)]
-pub struct ZuneJpegOptions { raw: zj_options }
+pub struct ZuneJpegOptions { raw: zj_options, use_unsafe: bool, backend: Backend }
 impl Default for ZuneJpegOptions {
-    fn default() -> Self { ZuneJpegOptions { raw: zj_options::default() } }
+    fn default() -> Self {
+        let raw = zj_options { out_colorspace: ColorSpace::RGB as i32, strict_mode: 0, max_width: 1 << 14, max_height: 1 << 14,
+                               max_scans: 64, num_threads: 4, ..zj_options::default() };
+        ZuneJpegOptions { raw, use_unsafe: true, backend: Backend::Hip }
+    }
 }
 impl ZuneJpegOptions {
     pub fn new() -> Self { Self::default() }
+    pub fn get_out_colorspace(&self) -> ColorSpace { colorspace_from(self.raw.out_colorspace) }
     pub fn set_out_colorspace(mut self, cs: ColorSpace) -> Self { self.raw.out_colorspace = cs as i32; self }
-    pub fn set_strict_mode(mut self, yes: bool) -> Self { self.raw.strict_mode = yes as i32; self }
-    pub fn set_num_threads(mut self, n: usize) -> Self { self.raw.num_threads = n as i32; self }
+    /// `options.rs:66-73`: in the reference this selects the SIMD arms; the hip arm ignores it (kept so that callers
+    /// compile unchanged; `Backend::Scalar` / `Backend::Simd` are the reference crate's business)
+    pub fn get_use_unsafe(&self) -> bool { self.use_unsafe }
+    pub fn set_use_unsafe(mut self, choice: bool) -> Self { self.use_unsafe = choice; self }
+    pub fn get_threads(&self) -> u32 { self.raw.num_threads as u32 }
+    pub fn set_num_threads(mut self, count: std::num::NonZeroU32) -> Self { self.raw.num_threads = count.get() as i32; self }
+    pub fn get_max_width(&self) -> u16 { self.raw.max_width as u16 }
     pub fn set_max_width(mut self, w: u16) -> Self { self.raw.max_width = w as i32; self }
+    pub fn get_max_height(&self) -> u16 { self.raw.max_height as u16 }
     pub fn set_max_height(mut self, h: u16) -> Self { self.raw.max_height = h as i32; self }
+    pub fn get_max_scans(&self) -> usize { self.raw.max_scans as usize }
     pub fn set_max_scans(mut self, n: usize) -> Self { self.raw.max_scans = n as i32; self }
-    /// extension: ZJ_FLAG_* (0 = the reference's bytes; ZJ_FLAG_CORRECTED = the non-quirk mode)
+    pub fn get_strict_mode(&self) -> bool { self.raw.strict_mode != 0 }
+    pub fn set_strict_mode(mut self, yes: bool) -> Self { self.raw.strict_mode = yes as i32; self }
+    // ---- this library's knobs --------------------------------------------------------------------------------------
+    pub fn get_backend(&self) -> Backend { self.backend }
+    /// only `Backend::Hip` can be served by this crate; `Decoder::new_with_options` rejects the others
+    pub fn set_backend(mut self, b: Backend) -> Self { self.backend = b; self }
+    /// ZJ_FLAG_* (0 = the reference's bytes; ZJ_FLAG_CORRECTED = the non-quirk mode)
     pub fn set_flags(mut self, flags: u32) -> Self { self.raw.flags = flags; self }
+    /// 0 = Huffman on the CPU (the default), 1 = baseline scans of 32 KB and more on the GPU, 2 = every eligible scan
+    pub fn set_entropy(mut self, mode: i32) -> Self { self.raw.entropy = mode; self }
+    /// ZJ_LAYOUT_HWC (the reference's interleaved bytes) or ZJ_LAYOUT_CHW (planar u8, tensor consumers)
+    pub fn set_out_layout(mut self, layout: u32) -> Self { self.raw.out_layout = layout; self }
+    /// coefficient planes in pinned host memory (faster uploads)
+    pub fn set_pinned_planes(mut self, yes: bool) -> Self { self.raw.pinned_planes = yes as i32; self }
+}
+fn colorspace_from(v: i32) -> ColorSpace {
+    match v { 1 => ColorSpace::GRAYSCALE, 2 => ColorSpace::YCbCr, 3 => ColorSpace::CMYK, 4 => ColorSpace::YCCK,
+              5 => ColorSpace::RGBA, 6 => ColorSpace::RGBX, _ => ColorSpace::RGB }
 }
 
-/// `Decoder` (`src/decoder.rs:60`): CPU entropy decode, GPU pixel path.
-pub struct Decoder { d: *mut zj_decoder, ctx: *mut zj_ctx, info: Option<zj_image_info>, out_cs: ColorSpace }
+/// `Decoder` (`src/decoder.rs:60`): CPU entropy decode (or the device stage, `set_entropy`), GPU pixel path.
+pub struct Decoder { d: *mut zj_decoder, ctx: *mut zj_ctx, info: Option<ImageInfo>, options: ZuneJpegOptions, stale: bool }
 
 impl Decoder {
-    pub fn new() -> Decoder { Decoder::new_with_options(ZuneJpegOptions::default()) }
+    /// `decoder.rs:186`
+    pub fn new() -> Decoder { Decoder::new_with_options(ZuneJpegOptions::new()) }
+    /// `decoder.rs:462`
     pub fn new_with_options(o: ZuneJpegOptions) -> Decoder {
-        let out_cs = match o.raw.out_colorspace { 1 => ColorSpace::GRAYSCALE, 2 => ColorSpace::YCbCr,
-                                                  5 => ColorSpace::RGBA, 6 => ColorSpace::RGBX, _ => ColorSpace::RGB };
-        Decoder { d: unsafe { zj_decoder_new(&o.raw) }, ctx: unsafe { zj_default_ctx() }, info: None, out_cs }
+        assert_eq!(unsafe { zj_abi_version() }, ZJ_ABI_VERSION, "libzjhip.so and this crate disagree about the ABI");
+        assert!(o.backend == Backend::Hip, "this crate serves Backend::Hip; the scalar / SIMD arms are the reference crate's");
+        Decoder { d: unsafe { zj_decoder_new(&o.raw) }, ctx: unsafe { zj_default_ctx() }, info: None, options: o, stale: false }
+    }
+    fn handle(&mut self) -> *mut zj_decoder {
+        if self.stale { // a deprecated setter changed the options: the C decoder is configured at creation
+            unsafe { zj_decoder_free(self.d); self.d = zj_decoder_new(&self.options.raw); }
+            self.stale = false;
+        }
+        self.d
     }
     fn err(&self, rc: c_int) -> DecodeErrors {
         let m = unsafe { CStr::from_ptr(zj_decoder_error(self.d)) }.to_string_lossy().into_owned();
@@ -212,26 +319,52 @@ impl Decoder {
     /// `decoder.rs:452`
     pub fn read_headers(&mut self, buf: &[u8]) -> Result<(), DecodeErrors> {
         let mut info = zj_image_info::default();
-        let rc = unsafe { zj_decoder_read_headers(self.d, buf.as_ptr(), buf.len(), &mut info) };
+        let rc = unsafe { zj_decoder_read_headers(self.handle(), buf.as_ptr(), buf.len(), &mut info) };
         if rc != ZJ_OK { return Err(self.err(rc)); }
         self.info = Some(info);
         Ok(())
     }
     /// `decoder.rs:210`
-    pub fn info(&self) -> Option<zj_image_info> { self.info }
+    pub fn info(&self) -> Option<ImageInfo> { self.info }
+    /// `decoder.rs:561,570`
+    pub fn width(&self) -> u16 { self.info.map_or(0, |i| i.width) }
+    pub fn height(&self) -> u16 { self.info.map_or(0, |i| i.height) }
+    /// `decoder.rs:415`
+    pub fn get_output_colorspace(&self) -> ColorSpace { self.options.get_out_colorspace() }
     /// `decoder.rs:178`
     pub fn decode_buffer(&mut self, buf: &[u8]) -> Result<Vec<u8>, DecodeErrors> {
         self.read_headers(buf)?;
         let i = self.info.unwrap();
-        let nc = if i.components == 1 { 1 } else { self.out_cs.num_components() };
+        let nc = if i.components == 1 { 1 } else { self.options.get_out_colorspace().num_components() };
         let mut out = vec![0u8; i.width as usize * i.height as usize * nc];
         let (mut n, mut info) = (0usize, zj_image_info::default());
-        let rc = unsafe { zj_decoder_decode_buffer(self.d, self.ctx, buf.as_ptr(), buf.len(), out.as_mut_ptr(),
+        let rc = unsafe { zj_decoder_decode_buffer(self.handle(), self.ctx, buf.as_ptr(), buf.len(), out.as_mut_ptr(),
                                                    out.len(), &mut n, &mut info) };
         if rc != ZJ_OK { return Err(self.err(rc)); }
         out.truncate(n);
         self.info = Some(info);
         Ok(out)
+    }
+    /// `decoder.rs:193`
+    pub fn decode_file<P: AsRef<std::path::Path> + Clone>(&mut self, file: P) -> Result<Vec<u8>, DecodeErrors> {
+        let buf = std::fs::read(file).map_err(|e| DecodeErrors { status: -1, message: e.to_string() })?;
+        self.decode_buffer(&buf)
+    }
+    // ---- the reference's deprecated setters (`decoder.rs:535-600`) ---------------------------------------------------
+    pub fn rgba(&mut self) { self.options = self.options.set_out_colorspace(ColorSpace::RGBA); self.stale = true; }
+    pub fn set_limits(&mut self, width: u16, height: u16) {
+        self.options = self.options.set_max_width(width).set_max_height(height);
+        self.stale = true;
+    }
+    pub fn set_output_colorspace(&mut self, colorspace: ColorSpace) {
+        self.options = self.options.set_out_colorspace(colorspace);
+        self.stale = true;
+    }
+    pub fn set_num_threads(&mut self, threads: usize) -> Result<(), DecodeErrors> {
+        match std::num::NonZeroU32::new(threads as u32) {
+            None => Err(DecodeErrors { status: -1, message: "Cannot set zero threads to decode image".into() }),
+            Some(n) => { self.options = self.options.set_num_threads(n); self.stale = true; Ok(()) }
+        }
     }
 }
 impl Drop for Decoder { fn drop(&mut self) { unsafe { zj_decoder_free(self.d) } } }

@@ -380,14 +380,31 @@ def test_full_size_4096(ctx, zj, synth, mode, out_cs):
     assert np.array_equal(_crc_rows(out, w * ncomp), _crc_rows(out2, w * ncomp))
 
 
-def test_full_size_4096_hv_whole_frame_vs_oracle(ctx, zj, synth):
-    """One complete 4096x4096 4:2:0 frame against the oracle (the oracle needs a few seconds)."""
+@pytest.mark.parametrize("mode,out_cs", [("hv", oc.RGB), ("none", oc.RGB), ("none", oc.GRAYSCALE), ("h", oc.RGB), ("v", oc.RGB)])
+def test_full_size_4096_whole_frame_vs_oracle(ctx, zj, synth, mode, out_cs):
+    """Complete 4096x4096 frames against the oracle, every byte: configs[1] (4:2:0 -> RGB), configs[2] (4:4:4 -> RGB and
+    -> GRAYSCALE), and the reference's other two sampling modes (the oracle needs a few seconds per frame)."""
+    hs, vs = MODES[mode]
     w = h = 4096
-    planes, qts = synth.make_frame(w, h, 2, 2, 3, seed=99)
-    rc, exp = oc.decode_planes(oc.make_frame(w, h, 2, 2, 3, oc.RGB, qts), planes)
+    planes, qts = synth.make_frame(w, h, hs, vs, 3, seed=99)
+    rc, exp = oc.decode_planes(oc.make_frame(w, h, hs, vs, 3, out_cs, qts), planes)
     assert rc == 0
-    d = zj.FrameDesc.make(w, h, 2, 2, 3, zj.ColorSpace.RGB, qts)
-    assert_same(ctx.decode_planes(d, planes), exp, "4096 hv")
+    d = zj.FrameDesc.make(w, h, hs, vs, 3, out_cs, qts)
+    assert_same(ctx.decode_planes(d, planes), exp, ("4096", mode, out_cs))
+
+
+def test_integer_generator_on_the_gpu_equals_the_cpu(zj, synth):
+    """bench.py generates its frames on the GPU (synth.make_frame_t): the same integers as on the CPU, and the luma plane
+    of frame 7 carries the checksum recorded beside the oracle's output checksums."""
+    import json
+    import torch
+    g = json.load(open(os.path.join(HERE, "golden", "checksums_seed1234.json")))
+    pg, _ = synth.make_frame_t(4096, 4096, 2, 2, 3, seed=g["seed"], frame_index=7, device="cuda:0")
+    assert f"{synth.frame_checksum_sum(pg[0].cpu().numpy().view('u1')):016x}" == g["y_plane"][7]
+    pc, _ = synth.make_frame_t(1024, 512, 2, 2, 3, seed=5, frame_index=2, device="cpu")
+    pg, _ = synth.make_frame_t(1024, 512, 2, 2, 3, seed=5, frame_index=2, device="cuda:0")
+    for a, b in zip(pc, pg):
+        assert torch.equal(a, b.cpu())
 
 
 # ---- whole decoder: CPU entropy front-end -> GPU pixel path (BASELINE.json configs[0] and [3]) ----------
