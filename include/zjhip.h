@@ -273,7 +273,7 @@ ZJ_API int zj_decoder_finish_pixels(zj_decoder *d, zj_ctx *ctx, uint8_t *out, si
  * Stream ordering (also zj_decode_planes_device with stream = NULL, zj_decoder_finish_pixels_batch with device outputs and
  * zj_pool_decode_files_device): the library writes d_out on ITS OWN non-blocking stream and returns once that is complete;
  * it does NOT order itself after work the caller still has in flight on other streams.  A caller whose allocator recycles
- * device memory stream-ordered (torch.empty) must synchronise the stream that last used d_out before the call. */
+ * device memory stream-ordered (a caching tensor allocator) must synchronise the stream that last used d_out before the call. */
 ZJ_API int zj_decoder_finish_pixels_device(zj_decoder *d, zj_ctx *ctx, uint8_t *d_out, size_t out_cap, size_t *out_len);
 /* stage 2 of n decoders on one context: the scans left for the device are decoded together (zj_decode_scans), the rest
  * one by one; rcs[k] is what zj_decoder_finish_pixels[_device] would have returned for decoder k */

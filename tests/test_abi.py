@@ -119,6 +119,46 @@ def test_rust_shim_declares_every_symbol():
         assert len(c_args) == len(r_args), (name, len(c_args), len(r_args))
     for field in ("flags", "out_layout", "num_threads", "pinned_planes"):
         assert field in rs
+    # both directions: every function of the header is declared in the extern block
+    assert sorted(n for n, _ in decls) == header_functions()
+    want = int(re.search(r"#define ZJ_ABI_VERSION (\d+)", open(os.path.join(root, "include", "zjhip.h")).read()).group(1))
+    assert int(re.search(r"pub const ZJ_ABI_VERSION: c_int = (\d+);", rs).group(1)) == want
+    assert f"ABI version {want}" in rs and "ABI version 2" not in rs
+
+
+def test_rust_shim_facade_mirrors_the_reference_surface():
+    """SURVEY.md Appendix B (src/decoder.rs, src/options.rs, src/idct.rs:40, src/upsampler.rs:82,97,
+    src/color_convert.rs:61): every public item a user of the reference calls exists in the shim's facade."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rs = open(os.path.join(root, "bindings", "rust", "src", "lib.rs")).read()
+
+    def methods(typ):
+        body = rs[rs.index(f"impl {typ} {{"):]
+        depth, end = 0, 0
+        for i, ch in enumerate(body):
+            depth += ch == "{"
+            depth -= ch == "}"
+            if depth == 0 and ch == "}":
+                end = i
+                break
+        return set(re.findall(r"pub fn (\w+)", body[:end]))
+
+    dec = methods("Decoder")
+    assert {"new", "new_with_options", "decode_buffer", "decode_file", "read_headers", "info", "width", "height",
+            "get_output_colorspace", "rgba", "set_limits", "set_output_colorspace", "set_num_threads"} <= dec
+    opt = methods("ZuneJpegOptions")
+    assert {"new", "get_out_colorspace", "set_out_colorspace", "get_use_unsafe", "set_use_unsafe", "get_threads",
+            "set_num_threads", "get_max_width", "set_max_width", "get_max_height", "set_max_height", "get_max_scans",
+            "set_max_scans", "get_strict_mode", "set_strict_mode"} <= opt
+    assert {"set_backend", "set_flags", "set_entropy", "set_out_layout", "set_pinned_planes"} <= opt     # this library's knobs
+    for item in ("pub enum Backend { Scalar, Simd, Hip }", "pub fn choose_idct_func(", "pub fn choose_horizontal_samp_function(",
+                 "pub fn choose_hv_samp_function(", "pub fn choose_ycbcr_to_rgb_convert_func(", "pub type IDCTPtr",
+                 "pub type UpSampler", "pub type ColorConvert16Ptr", "pub enum ColorSpace", "pub struct DecodeErrors",
+                 "pub type ImageInfo"):
+        assert item in rs, item
+    assert "fn num_components" in rs
+    # the reference's defaults (src/options.rs:26-40)
+    assert "max_width: 1 << 14" in rs and "max_scans: 64" in rs and "num_threads: 4" in rs and "use_unsafe: true" in rs
 
 
 def test_graft_entry_build_passes():
