@@ -15,8 +15,10 @@ rule is checked against.  It follows
   src/mcu.rs:139-165         row geometry: (2,1) walks 2*mcu_x MCUs per row and mcu_y/2 rows, (2,2) mcu_y/2 x 2 rows
   src/mcu.rs:230-350         the MCU loop, `todo` / handle_rst (:382-419), and the EOI break
 
-Coefficient VALUES are not modelled (the front-end's values are covered by tests/test_jpeg_frontend.py); only code
-lengths and magnitude-bit counts matter for the walk.
+decoded_mcus_per_row() follows code lengths and magnitude-bit counts only; decode_baseline_planes() (round 3) also forms
+the coefficient VALUES the reference's reader yields -- including the DC symbols it reads short (src/bitstream.rs:278:
+no refill with 16..26 bits left although a DC symbol can be longer), which the front-end reproduces (ref_dc_misread in
+zj_jpeg.cpp) and tests/test_jpeg_frontend.py checks against this model.
 """
 import struct
 
@@ -125,10 +127,36 @@ class _Reader:
         self.buffer, self.bl, self.marker = 0, 0, None
 
 
+_UNZ = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+        35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55,
+        62, 63]
+
+
+def _extend(x, s):  # huff_extend, src/bitstream.rs:683-687
+    return x - (1 << s) + 1 if x < (1 << (s - 1)) else x
+
+
 def decoded_mcus_per_row(jpeg_bytes):
     """For every MCU row of the image (mcu_y rows of mcu_x MCUs, the front-end's geometry): how many leading MCUs the
     reference entropy-decodes.  Rows it never reaches at all (an odd last MCU row under (2,1)/(2,2) sampling) report
     None."""
+    return _walk(jpeg_bytes, False)[0]
+
+
+def decode_baseline_planes(jpeg_bytes):
+    """The coefficient VALUES of the reference's baseline walk as well: (planes, short_reads, rows).  rows is what
+    decoded_mcus_per_row returns (None: an MCU row the walk never reaches, its blocks stay zero here).  planes[c] is component
+    c's whole-image plane [block row][block column][64] int16, natural order, zeros where the walk never went;
+    short_reads counts the DC symbols the reference reads with fewer bits than they have (decode_dc refills only below
+    16 bits, src/bitstream.rs:278: get_bits() then serves zeros for what is missing and the missing bits are parsed
+    again as the next symbol).  Written for well-formed streams: the fast-AC table (src/bitstream.rs:343-350) yields the
+    same values as the general path there, and runs never pass coefficient 63."""
+    rows, planes, short = _walk(jpeg_bytes, True)
+    return planes, short, rows
+
+
+def _walk(jpeg_bytes, values):
+    import numpy as np
     j = _parse(jpeg_bytes)
     hmax = max(c[1] for c in j["comps"])
     vmax = max(c[2] for c in j["comps"])
@@ -148,39 +176,59 @@ def decoded_mcus_per_row(jpeg_bytes):
     s = _Reader(jpeg_bytes, j["start"])
     todo = j["ri"] if j["ri"] else 1 << 62
     loops = []  # MCUs decoded by every pass of the `for j in 0..mcu_width` loop
+    planes, pred, short = None, [0] * ncomp, 0
+    if values:
+        planes = [np.zeros((mcu_y * c[2], mcu_x * c[1], 64), np.int16) for c in j["comps"]]
+    mcu = 0  # MCUs are coded in raster order whatever the loop shape (mcu.rs:145-152 only reshapes the loops)
     for _ in range(height):
         for _ in range(bias):
             n = 0
+            mcu_pass0 = mcu
             for _ in range(width):
-                for cid, h, v in j["comps"]:
+                mx, my = mcu % mcu_x, mcu // mcu_x
+                for ci, (cid, h, v) in enumerate(j["comps"]):
                     td, ta = j["sel"][cid]
-                    for _ in range(h * v):
+                    for b in range(h * v):
                         if s.bl < 16:
                             s.refill()
                         size = s.symbol(tabs[(0, td)])
                         if size:
+                            if values:
+                                if s.bl < size and s.marker is None:
+                                    short += 1
+                                pred[ci] = (pred[ci] + _extend(s.peek(size), size)) & 0xFFFFFFFF  # wrapping_add on i32
                             s.drop(size)
+                        if values:
+                            blk = planes[ci][my * v + b // h, mx * h + b % h]
+                            blk[:] = 0
+                            blk[0] = np.int16(np.uint16(pred[ci] & 0xFFFF))
                         pos = 1
                         while pos < 64:
                             s.refill()
                             rs = s.symbol(tabs[(1, ta)])
                             r, size = rs >> 4, rs & 15
                             if size:
-                                pos += r + 1
+                                pos += r
+                                if values:
+                                    blk[_UNZ[pos & 63]] = _extend(s.peek(size), size)
+                                pos += 1
                                 s.drop(size)
                             elif r != 15:
                                 break
                             else:
                                 pos += 16
                 n += 1
+                mcu += 1
                 todo -= 1
                 if todo == 0:  # handle_rst
                     todo = j["ri"]
                     if s.marker is not None and 0xD0 <= s.marker <= 0xD7:
                         s.reset()
+                        pred = [0] * ncomp  # mcu.rs:401-404
                 if s.marker == 0xD9:
                     break
             loops.append(n)
+            mcu = mcu_pass0 + width  # the MCUs a cut pass never decoded keep their zeros; the next pass starts behind them
     rows = [None] * mcu_y
     if width == 2 * mcu_x:  # one loop pass covers two MCU rows
         for i, n in enumerate(loops):
@@ -189,4 +237,97 @@ def decoded_mcus_per_row(jpeg_bytes):
     else:
         for i, n in enumerate(loops):
             rows[i] = n
-    return rows
+    return rows, ([p.reshape(-1) for p in planes] if values else None), short
+
+
+def decode_progressive_dc_first(jpeg_bytes):
+    """The FIRST scan of a progressive file when it is a DC scan (Ss = 0, Ah = 0), the way the reference reads it: a run of
+    decode_dc calls (src/bitstream.rs:407-415 -> :264-296), each refilling only below 16 bits -- so DC symbols longer than
+    what is left are read short here too, far more often than in baseline scans (nothing but DC symbols moves bits_left).
+    Returns ([per component: 2-D int16 array [block row][block column] of DC coefficients after the point transform],
+    short_reads).  Follows src/mcu_prog.rs:262-430 for the block order (one component: the blocks that cover the image;
+    several: MCU-interleaved)."""
+    import numpy as np
+    buf = jpeg_bytes
+    p, dht, comps, ri = 2, {}, [], 0
+    while True:
+        assert buf[p] == 0xFF
+        m = buf[p + 1]
+        p += 2
+        if m in (0xD8, 0xFF):
+            continue
+        length = struct.unpack(">H", buf[p:p + 2])[0]
+        seg = buf[p + 2:p + length]
+        if m == 0xC4:
+            q = 0
+            while q < len(seg):
+                tc, th = seg[q] >> 4, seg[q] & 15
+                counts = list(seg[q + 1:q + 17])
+                n = sum(counts)
+                dht[(tc, th)] = _canonical(counts, list(seg[q + 17:q + 17 + n]))
+                q += 17 + n
+        elif m == 0xC2:
+            h, w, nc = struct.unpack(">HHB", seg[1:6])
+            comps = [[seg[6 + 3 * i], seg[7 + 3 * i] >> 4, seg[7 + 3 * i] & 15] for i in range(nc)]
+        elif m == 0xDD:
+            ri = struct.unpack(">H", seg)[0]
+        elif m == 0xDA:
+            ns = seg[0]
+            scan = [(seg[1 + 2 * i], seg[2 + 2 * i] >> 4) for i in range(ns)]
+            ss, se, ah, al = seg[1 + 2 * ns], seg[2 + 2 * ns], seg[3 + 2 * ns] >> 4, seg[3 + 2 * ns] & 15
+            assert ss == 0 and se == 0 and ah == 0, "not a DC-first scan"
+            start = p + length
+            break
+        p += length
+    hmax, vmax = max(c[1] for c in comps), max(c[2] for c in comps)
+    if len(comps) == 1:
+        hmax = vmax = 1
+        comps[0][1] = comps[0][2] = 1
+    mcu_x, mcu_y = (w + 8 * hmax - 1) // (8 * hmax), (h + 8 * vmax - 1) // (8 * vmax)
+    by_id = {c[0]: i for i, c in enumerate(comps)}
+    out = [np.zeros((mcu_y * c[2], mcu_x * c[1]), np.int16) for c in comps]
+    s = _Reader(buf, start)
+    pred, short = [0] * len(comps), 0
+    todo = ri if ri else 1 << 62
+
+    def dc(ci, td):
+        nonlocal short
+        if s.bl < 16:
+            s.refill()
+        size = s.symbol(dht[(0, td)])
+        if size:
+            if s.bl < size and s.marker is None:
+                short += 1
+            pred[ci] = (pred[ci] + _extend(s.peek(size), size)) & 0xFFFFFFFF
+            s.drop(size)
+        return np.int16(np.uint16((pred[ci] << al) & 0xFFFF))       # (dc_pred as i16).wrapping_mul(1 << al), :413
+
+    def rst():
+        nonlocal todo, pred
+        todo -= 1
+        if todo == 0:
+            todo = ri
+            if s.marker is not None and 0xD0 <= s.marker <= 0xD7:
+                s.reset()
+                pred = [0] * len(comps)
+
+    if ns == 1:
+        ci = by_id[scan[0][0]]
+        if ci == 0 or (hmax == 1 and vmax == 1):
+            bw, bh = (w + 7) // 8, (h + 7) // 8
+        else:
+            bw, bh = mcu_x, mcu_y
+        for y in range(bh):
+            for x in range(bw):
+                out[ci][y, x] = dc(ci, scan[0][1])
+                rst()
+    else:
+        for my in range(mcu_y):
+            for mx in range(mcu_x):
+                for cid, td in scan:
+                    ci = by_id[cid]
+                    for v in range(comps[ci][2]):
+                        for hh in range(comps[ci][1]):
+                            out[ci][my * comps[ci][2] + v, mx * comps[ci][1] + hh] = dc(ci, td)
+                rst()
+    return out, short

@@ -68,6 +68,7 @@ static void run(const Params& p)
                 halo_pass1<C>(H[hl], s8, lds);
             }
             for (int hl = 0; hl < 64; hl++) halo_pass2<C>(H[hl], lds, p.clamp_dc);
+            for (int hl = 0; hl < 64; hl++) halo_filter<C, HS, VS>(p, t, hl, lds);
         }
         /* __syncthreads() */
         if (NEED_Y16 && *lds_flag<C>(lds) != 0) { // Q1 value outside a byte: the whole tile again, wide

@@ -301,3 +301,107 @@ def test_pinned_plane_option_without_device(zj, synth):
     o.pinned_planes = True
     _, got, _ = zj.Decoder(o).decode_coefficients(data)
     assert all(np.array_equal(g, p) for g, p in zip(got, planes))
+
+
+# ---- the reference's short read of long DC symbols (src/bitstream.rs:278; zj_jpeg.cpp ref_dc_misread) ------------------
+def _walked_blocks_equal(got, planes, rows, mcu_x, hs, vs):
+    """coefficient planes equal on every MCU row the reference walks (rows[my] is not None)"""
+    for c in range(3):
+        h, v = (hs, vs) if c == 0 else (1, 1)
+        g = np.array(got[c], np.int16).reshape(-1, mcu_x * h, 64)
+        p = np.array(planes[c], np.int16).reshape(-1, mcu_x * h, 64)
+        for my, n in enumerate(rows):
+            if n is not None and not np.array_equal(g[my * v:(my + 1) * v], p[my * v:(my + 1) * v]):
+                return False
+    return True
+
+
+def _noisy_jpeg(seed, subsampling, w=64, h=48):
+    """quality 100, blocks of opposite brightness with full-amplitude pixel noise: DC differences of category 10 / 11
+    (18 / 20-bit symbols with the standard tables) behind blocks whose last symbol is long"""
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    base = (rng.integers(0, 2, (h // 8, w // 8, 1)) * 2 - 1) * rng.integers(60, 128, (h // 8, w // 8, 1))
+    a = 128 + base.repeat(8, 0).repeat(8, 1).repeat(3, 2) + (rng.integers(0, 2, (h, w, 3)) * 2 - 1) * rng.integers(0, 127, (h, w, 3))
+    b = io.BytesIO()
+    Image.fromarray(np.clip(a, 0, 255).astype(np.uint8)).save(b, "JPEG", quality=100, subsampling=subsampling)
+    return b.getvalue()
+
+
+def test_reference_reads_long_dc_symbols_short_and_so_does_the_front_end(zj):
+    """decode_dc refills only below 16 bits (src/bitstream.rs:278) although a DC symbol can have 17-27: with 16..26 bits left
+    the reference decodes the code, gets zeros for the magnitude bits it does not hold, and then parses those bits AGAIN
+    as the next symbol -- garbage from there on, but the reference's garbage.  The literal model of its reader
+    (oracle/ref_walk.py decode_baseline_planes) and the front-end must agree coefficient for coefficient on every MCU
+    row the reference walks -- on files where that happens and on files where it does not."""
+    hit = clean = 0
+    for seed in range(60):
+        sub = [0, 2, 1][seed % 3]
+        hs, vs = [(1, 1), (2, 2), (2, 1)][seed % 3]
+        data = _noisy_jpeg(seed, sub)
+        planes, short, rows = ref_walk.decode_baseline_planes(data)
+        o = _opts(zj, 1)
+        try:
+            desc, got, info = zj.Decoder(o).decode_coefficients(data)
+        except zj.DecodeError:
+            assert short > 0, seed      # only a desynchronised stream may end in a bad code
+            continue
+        mcu_x = (64 + 8 * hs - 1) // (8 * hs)
+        assert _walked_blocks_equal(got, planes, rows, mcu_x, hs, vs), (seed, short)
+        hit += short > 0
+        clean += short == 0
+    assert hit >= 1 and clean >= 10, (hit, clean)
+
+
+def _first_scan_only(data):
+    """a progressive file cut behind its first scan (+ EOI): what the front-end holds after that scan alone"""
+    sos = data.index(b"\xff\xda")
+    p = sos + 2 + int.from_bytes(data[sos + 2:sos + 4], "big")
+    while not (data[p] == 0xFF and data[p + 1] not in (0x00, 0xFF) and not 0xD0 <= data[p + 1] <= 0xD7):
+        p += 1
+    return data[:p] + b"\xff\xd9"
+
+
+def test_reference_short_dc_reads_in_progressive_dc_scans(zj):
+    """A progressive DC scan is a run of decode_dc calls and nothing else, so bits_left wanders through 16..47 and every DC
+    symbol longer than 16 bits has a fair chance of being read short (src/bitstream.rs:278, :407-415).  libjpeg writes
+    progressive files with optimised tables, so the long symbols are the RARE categories: mild images with a few
+    black / white blocks.  The DC scan alone, through the front-end and through the literal reader model
+    (oracle/ref_walk.py): the same coefficients, or -- when the desynchronised stream runs into a code that does not
+    exist -- an error from both."""
+    import io
+    from PIL import Image
+    hit = clean = 0
+    for seed in range(60):
+        rng = np.random.default_rng(seed)
+        w, h = 160, 96
+        nb = (h // 8) * (w // 8)
+        vals = rng.integers(100, 156, nb)
+        k = rng.choice(nb, size=3, replace=False)
+        vals[k] = rng.choice([0, 255], size=k.size)
+        a = vals.reshape(h // 8, w // 8, 1).repeat(8, 0).repeat(8, 1).repeat(3, 2).astype(np.uint8)
+        b = io.BytesIO()
+        Image.fromarray(a).save(b, "JPEG", quality=100, subsampling=[0, 2, 1][seed % 3], progressive=True)
+        data = _first_scan_only(b.getvalue())
+        try:
+            want, short = ref_walk.decode_progressive_dc_first(data)
+        except ValueError:          # "bad Huffman code": the reference fails with DecodeErrors::HuffmanDecode
+            want, short = None, 1
+        o = zj.ZuneJpegOptions()
+        o.num_threads = 1
+        try:
+            desc, got, info = zj.Decoder(o).decode_coefficients(data)
+        except zj.DecodeError as e:
+            assert want is None and "Huffman" in str(e), (seed, str(e))
+            hit += 1
+            continue
+        assert want is not None, seed
+        assert info.progressive == 1 and info.scans == 1
+        for c in range(3):
+            g = np.array(got[c], np.int16).reshape(want[c].shape[0], want[c].shape[1], 64)
+            assert np.array_equal(g[:, :, 0], want[c]), (seed, c, short)
+            assert not g[:, :, 1:].any()
+        hit += short > 0
+        clean += short == 0
+    assert hit >= 3 and clean >= 10, (hit, clean)

@@ -571,6 +571,9 @@ template <int HS, int VS, bool CHROMA> struct TileWidth;
 #ifndef ZJ_TWC_HV
 #define ZJ_TWC_HV 16
 #endif
+#ifndef ZJ_NT_MIN_HV
+#define ZJ_NT_MIN_HV 0 // 512-pixel tiles on 512 threads (-DZJ_TWC_HV=32 -DZJ_NT_MIN_HV=512, 3 workgroups per CU): +3.5 % (round 3)
+#endif
 template <> struct TileWidth<2, 2, true> { static constexpr int TWC = ZJ_TWC_HV; };
 // 4:2:2 -> RGB: 8*TWC + 8 blocks.  TWC = 16 (256 pixels x 16 rows; 64 luma | 64 chroma | 8 halo blocks = pure waves, 192
 // threads) is 8 % faster than round 1's 31 (tools/ab_libs_w.sh 422-rgb); 24: +5 %, 32: -14 %, 16 on 256 threads: +4 %.
@@ -628,20 +631,29 @@ struct Cfg {
     static constexpr int NYB = YBR * TWYB;             // luma blocks per tile
     static constexpr int CCOLS = TWC + 2 * HALO;       // chroma block columns incl. halo
     static constexpr int NCB = CBR * CCOLS;            // chroma blocks per tile and component
-    static constexpr int CPITCH = TWC * 8 + (HALO ? 16 : 0); // i16 per chroma LDS row
-    static constexpr int COFF = HALO ? 8 : 0;          // LDS column of chroma column 0
+    // Chroma LDS rows hold the tile's own TWC * 8 samples and nothing else: 256 bytes per row for the 256-pixel tiles, so
+    // the 16 lanes of a ds_read_b128 lane group -- which belong to two different luma rows -- hit 16 different bank quads
+    // whatever chroma rows they read (rounds 1-2 kept the two halo columns inside the row, 288 bytes, and paid a 2-way
+    // conflict on every such read; profiles/r03_lds_conflicts_by_phase.txt).  The halo blocks' single pixel columns live in
+    // a side array [comp][side][chroma row], and -- packed generation -- vertically filtered per output row in
+    // [comp][side][m] (halo_filter), where the colour phase's edge lanes pick them up.
+    static constexpr int CPITCH = TWC * 8;             // i16 per chroma LDS row
+    static constexpr int COFF = 0;                     // LDS column of chroma column 0
     static constexpr int YSZ = SH * TWY;               // luma samples per tile
     static constexpr int CSZ = CROWS * CPITCH;         // chroma samples per tile and component
     static constexpr int NGRP = TWY / 16;              // 16-pixel groups per tile row
     static constexpr int NITEMS = SH * NGRP;
     static constexpr int NBLK = NYB + (CHROMA ? 2 * NCB : 0);        // blocks per tile
     static constexpr int NT_BLK = (NBLK + 63) / 64 * 64;            // one lane per block
-    static constexpr int NT_MIN = (HS == 1 && VS == 1) ? (CHROMA ? ZJ_NT_MIN_444 : ZJ_NT_MIN_GRAY) : ((HS == 2 && VS == 1 && CHROMA) ? ZJ_NT_MIN_H : 0);
+    static constexpr int NT_MIN = (HS == 1 && VS == 1) ? (CHROMA ? ZJ_NT_MIN_444 : ZJ_NT_MIN_GRAY) : ((HS == 2 && VS == 1 && CHROMA) ? ZJ_NT_MIN_H : ((HS == 2 && VS == 2 && CHROMA) ? ZJ_NT_MIN_HV : 0));
     static constexpr int NT = NT_BLK > NT_MIN ? NT_BLK : NT_MIN;     // threads per workgroup
     static constexpr int NW = NT / 64;
     static constexpr int LUT_N = SH + 2;
     static constexpr int LUT_BYTES = ((2 * LUT_N * 2 + 15) / 16) * 16;
-    static constexpr int CBYTES = CHROMA ? 2 * CSZ * 2 : 0;
+    static constexpr int HRAW = (CHROMA && HALO) ? 2 * 2 * CROWS : 0; // i16: halo pixel columns
+    static constexpr int HFIL = (CHROMA && HALO) ? 2 * 2 * SH : 0;    // i16: the same per up-sampled row
+    static constexpr int CBYTES = CHROMA ? (2 * CSZ + HRAW + HFIL) * 2 : 0;
+    static_assert(CBYTES % 16 == 0, "tables stay 16-byte aligned");
     // interleaved outputs leave through staged stores: PPI 16-byte pieces per 16-pixel item (3 or 4 bytes per pixel)
     static constexpr bool TSCAP = OUT == OUT_RGB || OUT == OUT_YCBCR || OUT == OUT_RGBA;
     static constexpr int PPI = OUT == OUT_RGBA ? 4 : 3;
@@ -748,6 +760,16 @@ ZJ_DEV TileId decode_tile(const Params& p, int bid)
 // Block b of a tile: where its 64 coefficients live in HBM and where its pixels go in LDS.
 //   b in [0, NYB): luma; then NCB Cb blocks; then NCB Cr blocks (halo columns first/last per row)
 // ------------------------------------------------------------------------------------------------
+// side arrays of the halo columns (Cfg::HRAW, Cfg::HFIL): comp 1 | 2, side 0 = left of the tile, 1 = right of it
+template <class C, int GEN> ZJ_DEV int16_t* lds_halo_raw(char* lds, int comp, int side, int row)
+{
+    return reinterpret_cast<int16_t*>(lds + C::template L<GEN>::C_OFF + 2 * C::CSZ * 2) + ((comp - 1) * 2 + side) * C::CROWS + row;
+}
+template <class C, int GEN> ZJ_DEV int16_t* lds_halo_fil(char* lds, int comp, int side, int m)
+{
+    return reinterpret_cast<int16_t*>(lds + C::template L<GEN>::C_OFF + (2 * C::CSZ + C::HRAW) * 2) + ((comp - 1) * 2 + side) * C::SH + m;
+}
+
 struct BlockLoc {
     const U4* src;   // 8 x 16 bytes of coefficients
     char* dst;       // LDS address of the block's pixel (0,0) -- or of the single halo column
@@ -795,10 +817,10 @@ ZJ_DEV BlockLoc locate(const Params& p, const TileId t, const int b, char* lds)
     }
     const int cb0 = t.tile * C::TWC;
     const int nvalid = (cbw - cb0) < C::TWC ? (cbw - cb0) : C::TWC;
-    int gcol, lcol;
+    int gcol, lcol = 0;
     if (C::HALO) {
-        if (j == 0) { gcol = cb0 > 0 ? cb0 - 1 : cbw - 1; lcol = C::COFF - 1; L.halo = 1; }
-        else if (j == C::CCOLS - 1) { gcol = cb0 + nvalid < cbw ? cb0 + nvalid : 0; lcol = C::COFF + 8 * nvalid; L.halo = 2; }
+        if (j == 0) { gcol = cb0 > 0 ? cb0 - 1 : cbw - 1; L.halo = 1; }
+        else if (j == C::CCOLS - 1) { gcol = cb0 + nvalid < cbw ? cb0 + nvalid : 0; L.halo = 2; }
         else { if (j - 1 >= nvalid) return L; gcol = cb0 + j - 1; lcol = C::COFF + 8 * (j - 1); }
     } else {
         if (j >= nvalid) return L;
@@ -807,8 +829,13 @@ ZJ_DEV BlockLoc locate(const Params& p, const TileId t, const int b, char* lds)
     const long long blk = (long long)(t.strip * C::CBR + brow) * cbw + gcol;
     const int16_t* plane = (comp == 1 ? p.cb : p.cr) + (long long)t.frame * p.c_frame_stride;
     L.src = reinterpret_cast<const U4*>(plane + blk * 64);
-    L.dst = lds + LL::C_OFF + ((comp - 1) * C::CSZ + (brow * 8) * C::CPITCH + lcol) * 2;
-    L.pitch = C::CPITCH * 2;
+    if (L.halo) { // the one pixel column of a halo block that is ever read: a column of the side array
+        L.dst = reinterpret_cast<char*>(lds_halo_raw<C, GEN>(lds, comp, L.halo - 1, brow * 8));
+        L.pitch = 2;
+    } else {
+        L.dst = lds + LL::C_OFF + ((comp - 1) * C::CSZ + (brow * 8) * C::CPITCH + lcol) * 2;
+        L.pitch = C::CPITCH * 2;
+    }
     L.comp = comp;
     L.valid = true;
     return L;
@@ -926,7 +953,6 @@ struct HaloLane { const int16_t* src; char* dst; int pitch; int comp; int hb; in
 template <class C>
 ZJ_DEV HaloLane halo_locate(const Params& p, const TileId t, const int hl /* 0..63 */, char* lds)
 {
-    using LL = typename C::template L<GEN_PACKED>;
     HaloLane H;
     H.hb = hl >> 3; H.j = hl & 7;
     H.comp = 1 + H.hb / (2 * C::CBR);
@@ -935,12 +961,11 @@ ZJ_DEV HaloLane halo_locate(const Params& p, const TileId t, const int hl /* 0..
     const int nvalid = (cbw - cb0) < C::TWC ? (cbw - cb0) : C::TWC;
     // the neighbour beyond the strip's first / last column is the other end of the row (Q4: one flat array)
     const int gcol = side == 0 ? (cb0 > 0 ? cb0 - 1 : cbw - 1) : (cb0 + nvalid < cbw ? cb0 + nvalid : 0);
-    const int lcol = side == 0 ? C::COFF - 1 : C::COFF + 8 * nvalid;
     const long long blk = (long long)(t.strip * C::CBR + brow) * cbw + gcol;
     const int16_t* plane = (H.comp == 1 ? p.cb : p.cr) + (long long)t.frame * p.c_frame_stride;
     H.src = plane + blk * 64 + H.j;
-    H.dst = lds + LL::C_OFF + ((H.comp - 1) * C::CSZ + (brow * 8) * C::CPITCH + lcol) * 2;
-    H.pitch = C::CPITCH * 2;
+    H.dst = reinterpret_cast<char*>(lds_halo_raw<C, GEN_PACKED>(lds, H.comp, side, brow * 8));
+    H.pitch = 2;
     H.last_col = side == 0; // left halo: the block's LAST pixel column
     return H;
 }
@@ -997,6 +1022,35 @@ ZJ_DEV void halo_pass2(const HaloLane& H, char* lds, const int clamp_dc)
         v = v < 0 ? 0 : (v > 255 ? 255 : v);
     }
     *reinterpret_cast<int16_t*>(H.dst + i * H.pitch) = (int16_t)v;
+}
+
+// The halo sample beside row m of a tile (`side` 0: left of its first chroma sample, 1: right of its last): the chroma
+// rows the vertical schedule gives row m (Q3) -- taken one up-sampled row up (left) / down (right) where the flat-array
+// neighbour wraps to the other end of the strip (Q4; `wrap`: the tile is the first / last of its row).
+template <class C, int HS, int VS, int GEN>
+ZJ_DEV int halo_value(char* lds, const int comp, const int side, const int m, const bool wrap)
+{
+    const int16_t* raw = lds_halo_raw<C, GEN>(lds, comp, side, 0);
+    if (VS == 2) {
+        const int16_t* lut = lds_lut<C, GEN>(lds);
+        const int i = m + 1 + (wrap ? (side == 0 ? -1 : 1) : 0);
+        const int ra = lut[i] / (C::CPITCH * 2), rb = lut[C::LUT_N + i] / (C::CPITCH * 2);
+        return tri1(raw[ra], raw[rb]);
+    }
+    const int r = side == 0 ? (wrap && m > 0 ? m - 1 : m) : (wrap && m < C::SH - 1 ? m + 1 : m);
+    return raw[r];
+}
+// Packed generation, after halo_pass2 (same wave, LDS in order): every halo column filtered for every up-sampled row of
+// the strip, 2 * 2 * SH values, so that the colour phase's edge lanes read one finished sample per side.
+template <class C, int HS, int VS>
+ZJ_DEV void halo_filter(const Params& p, const TileId t, const int hl, char* lds)
+{
+    const int cbw = p.mcu_x, cb0 = t.tile * C::TWC;
+    const bool left_wrap = cb0 == 0, right_wrap = cb0 + C::TWC >= cbw;
+    for (int q = hl; q < C::HFIL; q += 64) {
+        const int comp = 1 + q / (2 * C::SH), side = (q / C::SH) & 1, m = q % C::SH;
+        *lds_halo_fil<C, GEN_PACKED>(lds, comp, side, m) = (int16_t)halo_value<C, HS, VS, GEN_PACKED>(lds, comp, side, m, side == 0 ? left_wrap : right_wrap);
+    }
 }
 
 // GEN_WIDE: the round-1 form.  GEN_PACKED: luma leaves as bytes, chroma as i16; NEED_Y16 = the output does
@@ -1147,6 +1201,30 @@ ZJ_DEV char* piece_addr(char* lds, const int item0, const int wave, const int q)
     return (q < C::INPL ? ybase : xbase) + 16 * q;
 }
 
+// left / right neighbour pairs of a lane's eight chroma samples (phase_color, HS == 2), see there
+template <class C, int VS>
+ZJ_DEV void nb_pair(const uint32_t vm[4], const char* cp, const int oa, const int ob, const int lc, const int g, uint32_t& prev, uint32_t& next)
+{
+#if !defined(ZJ_EMU)
+    if (C::NGRP == 16) {
+        prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vm[3], 0x111, 0xf, 0xf, false); // row_shr:1: lane g-1's (v7, v8)
+        next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vm[0], 0x101, 0xf, 0xf, false); // row_shl:1: lane g+1's (v1, v2)
+        return;
+    }
+#endif
+    // the emulation (lanes run one after the other), and tile widths whose rows are not one DPP row: the same samples
+    // from LDS, wherever they exist (the ends of the row are the caller's)
+    prev = next = 0;
+    if (g > 0) {
+        prev = *reinterpret_cast<const uint32_t*>(cp + oa + lc - 4);
+        if (VS == 2) prev = tri(prev, *reinterpret_cast<const uint32_t*>(cp + ob + lc - 4));
+    }
+    if (g < C::NGRP - 1) {
+        next = *reinterpret_cast<const uint32_t*>(cp + oa + lc + 16);
+        if (VS == 2) next = tri(next, *reinterpret_cast<const uint32_t*>(cp + ob + lc + 16));
+    }
+}
+
 template <class C>
 ZJ_DEV void stage_item(const ItemOut& io, const int tid, char* lds, const int round)
 {
@@ -1244,27 +1322,17 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
         // Only the first / last tile of a row (a workgroup-uniform property) holds the strip's first / last chroma
         // column: every other tile skips the wrap logic and the patches below on a scalar branch.
         bool first = false, last = false;
-        int oa, ob, oal, obl, oar, obr;
+        int oa, ob;
         if (VS == 2) {
             const int16_t* lut = lds_lut<C, GEN>(lds);
             oa = lut[m + 1]; ob = lut[C::LUT_N + m + 1];
         } else {
             oa = ob = m * C::CPITCH * 2;
         }
-        oal = oar = oa; obl = obr = ob;
         if (edge_tile) {
             ZJ_NO_IF_CONVERT();
             first = (g == 0) && left_wrap;                  // chroma column 0 of the strip
             last = (8 * g + 8 == 8 * nvalid) && right_wrap; // last chroma column
-            if (VS == 2) {
-                const int16_t* lut = lds_lut<C, GEN>(lds);
-                const int im = m + 1, il = im - (first ? 1 : 0), ir = im + (last ? 1 : 0);
-                oal = lut[il]; obl = lut[C::LUT_N + il];
-                oar = lut[ir]; obr = lut[C::LUT_N + ir];
-            } else {
-                oal = obl = (first && m > 0 ? m - 1 : m) * C::CPITCH * 2;
-                oar = obr = (last && m < C::SH - 1 ? m + 1 : m) * C::CPITCH * 2;
-            }
         }
         // ZJ_FLAG_EDGE_REPLICATE (extension): the neighbour beyond a row's end is the end sample itself, in every row,
         // so neither the wrap to the previous / next row nor the strip-end special cases apply
@@ -1297,14 +1365,28 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
                 const U4 a = *reinterpret_cast<const U4*>(cp + oa + lc);
                 uint32_t vm[4] = {a.x, a.y, a.z, a.w}; // (v1,v2) (v3,v4) (v5,v6) (v7,v8)
                 // the neighbours come as aligned pairs: (x, v0) left of the group, (v9, x) right of it
-                uint32_t prev = *reinterpret_cast<const uint32_t*>(cp + oal + lc - 4);
-                uint32_t next = *reinterpret_cast<const uint32_t*>(cp + oar + lc + 16);
                 if (VS == 2) {
                     const U4 b = *reinterpret_cast<const U4*>(cp + ob + lc);
                     vm[0] = tri(vm[0], b.x); vm[1] = tri(vm[1], b.y);
                     vm[2] = tri(vm[2], b.z); vm[3] = tri(vm[3], b.w);
-                    prev = tri(prev, *reinterpret_cast<const uint32_t*>(cp + obl + lc - 4));
-                    next = tri(next, *reinterpret_cast<const uint32_t*>(cp + obr + lc + 16));
+                }
+                // The neighbours come as aligned pairs: (x, v0) left of the group, (v9, x) right of it.  Inside the tile's
+                // row they are the neighbouring LANES' filtered samples -- a row of 16 groups is one DPP row of 16 lanes:
+                // two v_mov_dpp where rounds 1-2 had four bank-conflicted 4-byte LDS reads and two more filters -- and at
+                // the two ends of the row the halo columns (finished by halo_filter in the packed generation).
+                uint32_t prev, next;
+                nb_pair<C, VS>(vm, cp, oa, ob, lc, g, prev, next);
+                {
+                    int hvl, hvr;
+                    if (GEN == GEN_PACKED && C::HALO_PURE) {
+                        hvl = *lds_halo_fil<C, GEN>(lds, ch + 1, 0, m);
+                        hvr = *lds_halo_fil<C, GEN>(lds, ch + 1, 1, m);
+                    } else {
+                        hvl = halo_value<C, HS, VS, GEN>(lds, ch + 1, 0, m, left_wrap);
+                        hvr = halo_value<C, HS, VS, GEN>(lds, ch + 1, 1, m, right_wrap);
+                    }
+                    if (g == 0) prev = (uint32_t)hvl << 16;
+                    if (g == nvalid - 1) next = (uint32_t)hvr & 0xffffu;
                 }
                 if (p.edge_rep) { // uniform branch (kernel argument): the default path pays no select for it
                     ZJ_NO_IF_CONVERT();

@@ -109,7 +109,12 @@ struct BitReader {
     uint32_t stuffed = 0;
     int pad = 0;
     int last_sym = 0;
-    void reset() { acc = 0; nbits = 0; marker = 0; istart = p; mpos = nullptr; stuffed = 0; pad = 0; }
+    // the REFERENCE reader's `bits_left` (src/bitstream.rs:117), followed symbol by symbol as long as no marker has come
+    // into its view: refill() adds 32 when it is called with bits_left <= 32 (before every AC symbol) or < 16 (before a DC
+    // symbol, :278).  It exists for one case only, ref_dc_misread() below.
+    int rbl = 0;
+    long long misreads = 0; // DC symbols the reference reads short (ref_dc_misread)
+    void reset() { acc = 0; nbits = 0; marker = 0; istart = p; mpos = nullptr; stuffed = 0; pad = 0; rbl = 0; }
     // bits consumed since istart (zero padding included once the real bits are used up)
     long long consumed() const
     {
@@ -182,6 +187,40 @@ struct BitReader {
 };
 
 inline int32_t extend(int32_t v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; } // T.81 F.2.2.1
+
+// ---- the reference's short read of long DC symbols (src/bitstream.rs:264-296) ---------------------------------------
+// decode_dc refills only when bits_left < 16, but a DC symbol is a code of up to 16 bits PLUS up to 11 (16) magnitude
+// bits.  With 16 <= bits_left < code + magnitude the reference decodes the code, then get_bits() rotates zeros into the
+// magnitude's low end (the buffer holds nothing below bits_left), bits_left saturates at 0 -- and the bits it did not
+// have are never skipped: the next refill continues right behind the last LOADED bit, so the rest of the magnitude is
+// parsed as the next symbol.  Everything after that is garbage, but it is the reference's garbage, and "same bytes as
+// the reference" includes it.  Standard tables reach 18 / 20 bits for |DC difference| >= 512 / 1024; in a baseline
+// scan the case needs the previous block to end in a symbol of 14 bits or more, in a progressive DC scan (nothing but
+// DC symbols, so bits_left wanders through 16..47) it is common once such differences occur.
+// Called after the DC code (`len` bits) has been dropped, with rbl already raised by the < 16 refill: true if the
+// reference reads the `s` magnitude bits short; then *bits is what it gets and the reader has consumed what it had.
+inline bool ref_dc_misread(BitReader& br, int& rbl, const int len, const int s, int32_t* bits)
+{
+    if (len + s <= rbl) return false;
+    // rbl describes the reference only while it has not come across the marker that ends the interval (after that it
+    // holds every remaining bit and serves zeros): it has read (consumed + rbl) / 8 data bytes
+    const uint8_t* m = br.marker ? br.mpos : nullptr;
+    long long st = br.stuffed;
+    if (!m) {
+        for (const uint8_t* q = br.p; q + 1 < br.end; q++)
+            if (q[0] == 0xFF) { if (q[1] == 0x00) { st++; q++; } else { m = q; break; } }
+        if (!m) m = br.end;
+    }
+    const long long data_bits = 8 * ((long long)(m - br.istart) - st);
+    const long long c_code_start = br.consumed() - len;
+    if (c_code_start + rbl > data_bits) return false;
+    const int avail = rbl - len; // 0 <= avail < s (len <= 16 <= rbl)
+    *bits = avail > 0 ? (int32_t)(br.peek(avail) << (s - avail)) : 0;
+    if (avail > 0) br.drop(avail);
+    rbl = 0;
+    br.misreads++;
+    return true;
+}
 
 struct Comp {
     int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
@@ -512,18 +551,30 @@ int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, in
         const int16_t* src; int16_t* dst;
         ~Flush() { for (int i = 0; i < 8; i++) _mm_stream_si128((__m128i*)dst + i, _mm_load_si128((const __m128i*)src + i)); }
     } flush{blk, out};
+    int rbl = br.rbl; // the reference's bits_left (BitReader::rbl), in a register through the block
+    struct KeepRbl { BitReader& b; int& r; ~KeepRbl() { b.rbl = r < 0 ? 0 : r; } } keep{br, rbl};
+    if (br.nbits < 32) br.fill();
+    const int dc_before = br.nbits; // >= 32: decode() does not refill, the difference is the code's length
     int s = br.decode(hd);
     if (s < 0 || s > 16) { *err = "Bad Huffman code in DC"; return ZJ_ERR_HUFFMAN; }
-    int32_t diff = s ? extend(br.get(s), s) : 0;
+    const int dc_len = dc_before - br.nbits;
+    if (rbl < 16) rbl += 32; // bitstream.rs:278
+    int32_t diff = 0, short_bits = 0;
+    if (s) {
+        if (__builtin_expect(dc_len + s > rbl, 0) && ref_dc_misread(br, rbl, dc_len, s, &short_bits)) diff = extend(short_bits, s);
+        else { diff = extend(br.get(s), s); rbl -= dc_len + s; }
+    } else rbl -= dc_len;
     dc_pred = (int32_t)((uint32_t)dc_pred + (uint32_t)diff);
     blk[0] = (int16_t)dc_pred; // bitstream.rs:330
     for (int k = 1; k < 64;) {
         if (br.nbits < 32) br.fill(); // a code (<= 16 bits) and its magnitude bits (<= 15) without another refill
+        if (rbl <= 32) rbl += 32;     // the reference's refill before every AC symbol (bitstream.rs:334)
         const uint32_t look9 = br.peek(9);
         const int16_t fa = ha.fast[look9];
         if (fa) { // short code + small value: run, magnitude and sign from one table entry
             k += (fa >> 4) & 15;
             br.drop(fa & 15);
+            rbl -= fa & 15;
             if (TRACK) br.last_sym = fa & 15;
             blk[kUnZigzag[k & 63]] = (int16_t)(fa >> 8);
             k++;
@@ -531,11 +582,12 @@ int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, in
         }
         int rs;
         const uint16_t e = ha.look[look9];
-        if (e) { br.drop(e >> 8); if (TRACK) br.last_sym = e >> 8; rs = e & 0xff; }
+        if (e) { br.drop(e >> 8); rbl -= e >> 8; if (TRACK) br.last_sym = e >> 8; rs = e & 0xff; }
         else {
             const int before = br.nbits; // >= 32 here: decode() does not refill, the difference is the code's length
             rs = br.decode(ha);
             if (rs < 0) { *err = "Bad Huffman code in AC"; return ZJ_ERR_HUFFMAN; }
+            rbl -= before - br.nbits;
             if (TRACK) br.last_sym = before - br.nbits;
         }
         const int r = rs >> 4, sz = rs & 15;
@@ -543,6 +595,7 @@ int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, in
             k += r;
             const int32_t bits = (int32_t)br.peek(sz);
             br.drop(sz);
+            rbl -= sz;
             if (TRACK) br.last_sym += sz;
             // EXTEND (T.81 F.2.2.1) without a branch: values below 2^(sz-1) are negative
             const int32_t v = bits + ((((bits - (1 << (sz - 1))) >> 31)) & (1 - (1 << sz)));
@@ -786,9 +839,18 @@ int scan_baseline(zj_decoder* d, BitReader& br)
 
 int dc_first(zj_decoder* d, BitReader& br, Comp& cm, int16_t* blk)
 {
+    if (br.nbits < 32) br.fill();
+    const int before = br.nbits;
     int s = br.decode(d->dc[cm.td & 3]);
     if (s < 0 || s > 16) return fail(d, ZJ_ERR_HUFFMAN, "Bad Huffman code in DC");
-    int32_t diff = s ? extend(br.get(s), s) : 0;
+    const int len = before - br.nbits;
+    // a DC scan is nothing but decode_dc calls (bitstream.rs:407-415 -> :264): bits_left is refilled below 16 only
+    if (br.rbl < 16) br.rbl += 32;
+    int32_t diff = 0, short_bits = 0;
+    if (s) {
+        if (len + s > br.rbl && ref_dc_misread(br, br.rbl, len, s, &short_bits)) diff = extend(short_bits, s);
+        else { diff = extend(br.get(s), s); br.rbl -= len + s; }
+    } else br.rbl -= len;
     cm.dc_pred = (int32_t)((uint32_t)cm.dc_pred + (uint32_t)diff);
     blk[0] = (int16_t)((uint16_t)(int16_t)cm.dc_pred * (uint16_t)(1u << d->al)); // bitstream.rs:413
     return ZJ_OK;

@@ -86,6 +86,8 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAV
         halo_pass1<C>(H, hs8, lds);
         ZJ_WAVE_FENCE();
         halo_pass2<C>(H, lds, p.clamp_dc);
+        ZJ_WAVE_FENCE();
+        halo_filter<C, HS, VS>(p, t, tid - C::HALO_T0, lds);
     } else {
         finish_block<C, GEN_PACKED, NEED_Y16>(L, raw, lds, ZJ_PDBG(p), p.clamp_dc);
     }
