@@ -367,3 +367,37 @@ def test_pool_to_a_torch_tensor(zj, ctx):
     got = t.cpu().numpy()
     for k, f in enumerate(files):
         assert np.array_equal(got[k].reshape(-1), zj.Decoder(None, ctx).decode_buffer(f)), k
+
+
+def test_malformed_scan_blobs_are_argument_errors(zj, ctx):
+    """zj_decode_scan takes any blob.  Every header field the kernels index with is bounded on the host, so a
+    stale or corrupted prepared scan comes back as ZJ_ERR_ARG instead of an out-of-bounds access on the device."""
+    import struct
+    data = pil_jpeg(256, 128, quality=90, seed=3)
+    g, _ = decoders(zj, ctx)
+    desc, info = g.prepare(data)
+    blob = g.scan_blob()
+    assert blob is not None
+    out, rc, st = ctx.decode_scan(desc, blob)
+    assert rc == 0 and st == 0
+    # u32 fields of HuffScan (csrc/zj_huff.h): index -> a value that must be refused
+    names = ["magic", "blob_bytes", "nsub", "nseg", "ri_mcus", "bpm", "ncomp", "mcu_x", "mcu_y", "total_mcus", "is_eoi", "rowlen",
+             "tab_entries", "off_tab", "off_sub", "off_seg", "off_stream", "stream_bytes", "sub_bytes", "round_budget", "off_per"]
+    bad = {"nseg": 1 << 20, "bpm": 11, "mcu_x": 0, "total_mcus": 7, "rowlen": 0, "tab_entries": 60000, "off_tab": 8,
+           "off_sub": len(blob) - 16, "off_seg": len(blob), "off_stream": len(blob) - 48, "stream_bytes": 1 << 30,
+           "sub_bytes": 4096, "off_per": len(blob) + 1024, "ri_mcus": 0}
+    for name, val in bad.items():
+        b = blob.copy()
+        struct.pack_into("<I", b, 4 * names.index(name), val)
+        with pytest.raises(zj.ZjError) as e:
+            ctx.decode_scan(desc, b)
+        assert e.value.status == -1, name
+    # a block of the MCU that claims a component the scan does not have
+    b = blob.copy()
+    off_blk = 4 * len(names) + 4 * 2 + 2 * 8   # ... off_per, nper, comp_of_blk, dc_off[4], ac_off[4] -> blk[]
+    b[off_blk] = 7
+    with pytest.raises(zj.ZjError):
+        ctx.decode_scan(desc, b)
+    # and the context still works
+    out2, rc, st = ctx.decode_scan(desc, blob)
+    assert rc == 0 and st == 0 and np.array_equal(out, out2)

@@ -283,3 +283,48 @@ def test_shared_tables_are_left_to_the_cpu_unless_forced(zj, synth):
     big = pil_jpeg(640, 480, quality=92, seed=2)
     d.prepare(big)
     assert d.scan_blob() is not None
+
+
+def test_long_dc_symbols_the_reference_reads_short_are_handed_back(zj):
+    """src/bitstream.rs:278: a DC symbol longer than the reference's reader holds is read short and the stream
+    desynchronises (tests/test_jpeg_frontend.py, zj_jpeg.cpp ref_dc_misread).  Only the CPU walker follows that reader;
+    the device stage must never keep such a scan (it would decode the file CORRECTLY, i.e. differently): whatever it keeps
+    equals the walker's planes, and every file with a short read comes back with HUFF_ST_DC_LONG."""
+    import ref_walk
+    from test_jpeg_frontend import _noisy_jpeg
+    kept = back = short_files = 0
+    for seed in range(60):
+        data = _noisy_jpeg(seed, [0, 2, 1][seed % 3], w=128, h=96)
+        try:
+            _, short, _ = ref_walk.decode_baseline_planes(data)
+        except ValueError:   # the desynchronised stream ran into a code that does not exist: a short read happened
+            short = 1
+        o = zj.ZuneJpegOptions()
+        o.entropy = zj.ENTROPY_GPU_ALWAYS
+        d = zj.Decoder(o)
+        d.prepare(data)
+        blob = d.scan_blob()
+        if blob is None:
+            continue
+        try:
+            _, want, _ = zj.Decoder().decode_coefficients(data)
+        except zj.DecodeError:
+            want = None
+        if want is None:     # the walker fails like the reference (bad code behind the short read): size the planes by hand
+            info = zj.Decoder().read_headers(data)
+            mx, my = -(-info.width // (8 * info.h_max)), -(-info.height // (8 * info.v_max))
+            lens = [mx * my * info.h_max * info.v_max * 64, mx * my * 64, mx * my * 64]
+        else:
+            lens = [p.size for p in want]
+        got, status, st = emu_c.huff_decode(blob, lens)
+        if short:
+            short_files += 1
+            assert status & 64, (seed, status)
+        if status == 0:
+            kept += 1
+            assert want is not None, seed
+            for a, b in zip(got, want):
+                assert np.array_equal(a[: b.size], b), seed
+        else:
+            back += 1
+    assert short_files >= 2 and kept >= 10, (short_files, kept, back)

@@ -587,10 +587,13 @@ size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 int scan_arenas(zj_ctx* c, int slots, size_t plane_bytes, size_t out_bytes)
 {
     auto grow = [&](void** p, size_t* stride, int* have, size_t need) -> int {
-        if (need <= *stride && slots <= *have) return ZJ_OK;
-        if (*p) { ZJ_HIP(c, hipStreamSynchronize(c->stream)); ZJ_HIP(c, hipFree(*p)); *p = nullptr; }
+        if (*p && need <= *stride && slots <= *have) return ZJ_OK;
         const size_t st = need > *stride ? up256(need + need / 8) : *stride;
         const int n = slots > *have ? slots : *have;
+        // nothing is remembered of an arena that is gone: if the hipMalloc below fails, the next call must not pass the
+        // early-out on the strength of the freed arena's size
+        if (*p) { ZJ_HIP(c, hipStreamSynchronize(c->stream)); ZJ_HIP(c, hipFree(*p)); *p = nullptr; }
+        *stride = 0; *have = 0;
         ZJ_HIP(c, hipMalloc(p, st * (size_t)n));
         *stride = st; *have = n;
         return ZJ_OK;
@@ -600,12 +603,54 @@ int scan_arenas(zj_ctx* c, int slots, size_t plane_bytes, size_t out_bytes)
     return out_bytes ? grow(&c->hout, &c->hout_stride, &c->hout_slots, out_bytes) : (int)ZJ_OK;
 }
 
+// A prepared scan is public input (zj_decode_scan / zj_decode_scans take any blob): every field the kernels index with is
+// bounded here, so that a stale or malformed blob is an argument error and not an out-of-bounds access on the device.
+bool scan_header_ok(const HuffScan* h, size_t blob_bytes)
+{
+    auto inside = [&](uint64_t off, uint64_t bytes) { return (off & 15) == 0 && off >= sizeof(HuffScan) && off + bytes <= blob_bytes; };
+    if (h->ncomp != 1 && h->ncomp != 3) return false;
+    if (h->bpm < 1 || h->bpm > (uint32_t)HUFF_MAX_BPM || h->nseg < 1 || h->nseg > h->nsub) return false;
+    if (h->tab_entries == 0 || h->tab_entries > (uint32_t)HUFF_TAB_BUDGET || (h->tab_entries & 1)) return false;
+    if (h->sub_bytes < 16 || h->sub_bytes > (uint32_t)HUFF_SUB_MAX || (h->sub_bytes & 15)) return false;
+    if ((h->stream_bytes & 15) || h->stream_bytes < 32) return false;
+    if (!inside(h->off_tab, (uint64_t)h->tab_entries * 2) || !inside(h->off_sub, ((uint64_t)h->nsub + 1) * sizeof(HuffSub)) ||
+        !inside(h->off_seg, (uint64_t)h->nseg * sizeof(HuffSeg)) || !inside(h->off_per, (uint64_t)h->nsub * 4) ||
+        !inside(h->off_stream, h->stream_bytes)) return false;
+    if (h->mcu_x == 0 || h->mcu_y == 0 || (uint64_t)h->mcu_x * h->mcu_y != h->total_mcus || h->ri_mcus == 0 || h->rowlen == 0) return false;
+    for (uint32_t k = 0; k < h->ncomp; k++) {
+        if (h->comp[k].h < 1 || h->comp[k].h > 2 || h->comp[k].v < 1 || h->comp[k].v > 2) return false;
+        if ((uint64_t)h->dc_off[k] >= h->tab_entries || (uint64_t)h->ac_off[k] >= h->tab_entries) return false;
+    }
+    uint32_t per_comp[3] = {0, 0, 0};
+    for (uint32_t b = 0; b < h->bpm; b++) {
+        const HuffBlk& k = h->blk[b];
+        if (k.comp >= h->ncomp || k.hx >= h->comp[k.comp].h || k.vy >= h->comp[k.comp].v) return false;
+        if (((h->comp_of_blk >> (2 * b)) & 3u) != k.comp) return false;
+        per_comp[k.comp]++;
+    }
+    for (uint32_t k = 0; k < h->ncomp; k++)
+        if (per_comp[k] != h->comp[k].h * h->comp[k].v) return false;
+    // the grid and the segments: ascending, inside the stream
+    const uint8_t* base = (const uint8_t*)h;
+    const HuffSub* subs = (const HuffSub*)(base + h->off_sub);
+    const HuffSeg* segs = (const HuffSeg*)(base + h->off_seg);
+    for (uint32_t i = 0; i < h->nseg; i++)
+        if (segs[i].start > segs[i].end || segs[i].end > h->stream_bytes - 32 || (segs[i].start & 15)) return false;
+    for (uint32_t i = 0; i < h->nsub; i++) {
+        const uint32_t sg = subs[i].seg & HUFF_SEG_MASK;
+        if (sg >= h->nseg || subs[i].start < segs[sg].start || subs[i].start > segs[sg].end) return false;
+        if (i && !(subs[i].seg & HUFF_FIRST) && subs[i].start <= subs[i - 1].start) return false;
+    }
+    return true;
+}
+
 // validates one scan, sizes its slot, fills the working-set pointers
 int scan_setup(zj_ctx* c, ScanJob& j, int slot, const zj_frame_desc* d, const void* blob, size_t blob_bytes, uint8_t* out, int out_on_device)
 {
     if (!d || !blob || !out || blob_bytes < sizeof(HuffScan)) return ZJ_ERR_ARG;
     const HuffScan* h = (const HuffScan*)blob;
     if (h->magic != HUFF_MAGIC || h->blob_bytes != blob_bytes || h->nsub == 0 || h->ncomp != d->in_components) return ZJ_ERR_ARG;
+    if (!scan_header_ok(h, blob_bytes)) return ZJ_ERR_ARG;
     int rc = make_plan(d, j.pl);
     if (rc) return rc;
     j.d = d; j.h = h; j.blob = blob; j.blob_bytes = blob_bytes; j.out = out; j.slot = slot;

@@ -47,7 +47,10 @@ constexpr uint32_t HUFF_FIRST = 0x80000000u, HUFF_LAST = 0x40000000u, HUFF_SEG_M
 // status bits the device raises; any of them sends the file to the CPU walker (zj_jpeg.cpp), which owns the
 // reference-compatible treatment of damaged streams
 constexpr uint32_t HUFF_ST_BAD_CODE = 1, HUFF_ST_RUN_OVER = 2, HUFF_ST_EXHAUSTED = 4, HUFF_ST_CUT_EARLY = 8,
-                   HUFF_ST_PHASE = 16, HUFF_ST_NO_SYNC = 32;
+                   HUFF_ST_PHASE = 16, HUFF_ST_NO_SYNC = 32,
+                   // a DC symbol of more than 16 bits: the reference may read it short (src/bitstream.rs:278; zj_jpeg.cpp
+                   // ref_dc_misread) depending on its reader's state, which only the CPU walker follows
+                   HUFF_ST_DC_LONG = 64;
 
 // table entry (u16): 16 (16 bits consumed, zig-zag advance 0) = no such code.  Bit 15 set: low byte = second-level table number, indexed by the 16 - L1 bits
 // that follow the first L1.  Bit 15 clear: everything the symbol does to the parse --

@@ -171,6 +171,7 @@ ZJ_DEV HuffState huff_run(const HuffLds& L, uint32_t tid, uint32_t start_bits, H
     int32_t m0 = comp == 0 ? -1 : 0, m1 = comp == 1 ? -1 : 0, m2 = comp == 2 ? -1 : 0;
     int16_t* dst = nullptr;
     if (WRITE) dst = huff_block_ptr(h, *w, h.blk[j]);
+    uint32_t prev_start = 0xffffffffu; // (write pass) first bit of the previous symbol; none yet in this sub-sequence
     for (;;) {
         if (WRITE && w->blk >= w->blk_end) break;
         if (pos >= limit) {
@@ -195,6 +196,21 @@ ZJ_DEV HuffState huff_run(const HuffLds& L, uint32_t tid, uint32_t start_bits, H
             const uint32_t bits = (t >> 1) >> (31u - sz);                                   // sz == 0: 0
             const int32_t val = (int32_t)bits + ((int32_t)~((int32_t)t >> 31) & (1 - (int32_t)(1u << sz))); // top bit 0: negative
             if (is_dc) {
+                if (WRITE && total > 16u && sym_start != w->seg_start_bits) {
+                    // Would the reference read this symbol short (src/bitstream.rs:278, zj_jpeg.cpp ref_dc_misread)?  Its
+                    // reader holds 64 - (C mod 32) bits behind the refill of the AC call site at C consumed bits (32 or 64
+                    // when C mod 32 == 0, depending on its history: assume 32), minus the previous block's last symbol,
+                    // plus 32 if that leaves fewer than 16.  The first symbol of a sub-sequence knows no predecessor:
+                    // assume the worst.  Either way the CPU walker, which follows the reader exactly, decides.
+                    bool shortr = true;
+                    if (prev_start != 0xffffffffu) {
+                        const uint32_t r = (prev_start - w->seg_start_bits) & 31u;
+                        int32_t rbl = (int32_t)(r ? 64u - r : 32u) - (int32_t)(sym_start - prev_start);
+                        if (rbl < 16) rbl += 32;
+                        shortr = (int32_t)total > rbl;
+                    }
+                    if (shortr) status |= HUFF_ST_DC_LONG;
+                }
                 const int32_t dv = sz ? val : 0; // (sz == 0: t's top bit belongs to the next symbol)
                 d0 += dv & m0; d1 += dv & m1; d2 += dv & m2;
                 if (WRITE) {
@@ -209,6 +225,7 @@ ZJ_DEV HuffState huff_run(const HuffLds& L, uint32_t tid, uint32_t start_bits, H
                 else status |= HUFF_ST_RUN_OVER;
             }
         }
+        if (WRITE) prev_start = sym_start;
         z += zadv;
         pos += total;
         off += total;
@@ -374,7 +391,10 @@ ZJ_DEV void huff_periodic_thread(const HuffArgs& a, uint32_t i, int next_round)
     HuffState p = huff_unpack(a.exit[t]);
     p.pos += (i - t) * g->sub_bytes * 8u;
     const unsigned long long packed = huff_pack(p);
-    if (packed == a.exit[i]) return;
+    // (the counts travel with the exit state even when the state is already the predicted one: they may stem from a decode
+    // that entered sub-sequence i in another state, and nothing re-decodes i unless its predecessor's exit changes -- under
+    // the closure condition above the counterpart's counts are i's)
+    if (packed == a.exit[i]) { if (t != i) a.aux[i] = a.aux[t]; return; }
     a.exit[i] = packed;
     a.aux[i] = a.aux[t];
     // verified by decoding in the next round; so is the sub-sequence behind the run's last predicted one

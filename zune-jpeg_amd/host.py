@@ -87,7 +87,7 @@ ZJ_SCAN_BATCH_MAX = 16
 RETRY_CPU = 1  # zj_decode_scan: the device hands the scan back
 # csrc/zj_huff.h HUFF_ST_*
 HUFF_ST = {1: "bad code", 2: "run past 63", 4: "bits exhausted", 8: "EOI cut before the last row loop", 16: "phase",
-           32: "no synchronisation"}
+           32: "no synchronisation", 64: "a DC symbol the reference may read short"}
 
 
 class Options(C.Structure):  # zj_options
