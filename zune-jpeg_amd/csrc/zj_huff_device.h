@@ -142,6 +142,20 @@ ZJ_DEV uint32_t huff_window(uint32_t hi, uint32_t lo, uint32_t off)
 // symbols only.  The bit window is 32 bits rebuilt per symbol from two cached stream words (a code is at most 16
 // bits, its magnitude at most 15); a third word is always in flight from LDS.
 // `start_bits`: first bit of the sub-sequence whose words thread `tid` has staged.
+// Would the reference read a DC symbol of `total` (> 16) bits short (src/bitstream.rs:278, zj_jpeg.cpp ref_dc_misread)?
+// c_prev / c_sym: bits consumed since the segment began in front of the previous symbol (the last AC symbol of the block
+// before) and in front of this one.  Behind the refill of the AC call site at c_prev the reference's reader holds
+// 64 - (c_prev mod 32) bits -- 32 or 64 when c_prev mod 32 == 0, depending on its history: assume 32 -- then the previous
+// symbol goes, and decode_dc adds 32 if fewer than 16 are left.  Errs on the side of "yes"; the CPU walker, which follows
+// the reader bit by bit, decides.
+ZJ_DEV bool huff_ref_reads_short(const uint32_t c_prev, const uint32_t c_sym, const uint32_t total)
+{
+    const uint32_t r = c_prev & 31u;
+    int32_t rbl = (int32_t)(r ? 64u - r : 32u) - (int32_t)(c_sym - c_prev);
+    if (rbl < 16) rbl += 32;
+    return (int32_t)total > rbl;
+}
+
 template <bool WRITE>
 ZJ_DEV HuffState huff_run(const HuffLds& L, uint32_t tid, uint32_t start_bits, HuffState s, uint32_t limit, bool last_sub, HuffI4& aux, HuffWrite* w)
 {
@@ -196,21 +210,9 @@ ZJ_DEV HuffState huff_run(const HuffLds& L, uint32_t tid, uint32_t start_bits, H
             const uint32_t bits = (t >> 1) >> (31u - sz);                                   // sz == 0: 0
             const int32_t val = (int32_t)bits + ((int32_t)~((int32_t)t >> 31) & (1 - (int32_t)(1u << sz))); // top bit 0: negative
             if (is_dc) {
-                if (WRITE && total > 16u && sym_start != w->seg_start_bits) {
-                    // Would the reference read this symbol short (src/bitstream.rs:278, zj_jpeg.cpp ref_dc_misread)?  Its
-                    // reader holds 64 - (C mod 32) bits behind the refill of the AC call site at C consumed bits (32 or 64
-                    // when C mod 32 == 0, depending on its history: assume 32), minus the previous block's last symbol,
-                    // plus 32 if that leaves fewer than 16.  The first symbol of a sub-sequence knows no predecessor:
-                    // assume the worst.  Either way the CPU walker, which follows the reader exactly, decides.
-                    bool shortr = true;
-                    if (prev_start != 0xffffffffu) {
-                        const uint32_t r = (prev_start - w->seg_start_bits) & 31u;
-                        int32_t rbl = (int32_t)(r ? 64u - r : 32u) - (int32_t)(sym_start - prev_start);
-                        if (rbl < 16) rbl += 32;
-                        shortr = (int32_t)total > rbl;
-                    }
-                    if (shortr) status |= HUFF_ST_DC_LONG;
-                }
+                // (the first symbol of a sub-sequence knows no predecessor: the lane in front of it looks ahead, below)
+                if (WRITE && total > 16u && prev_start != 0xffffffffu &&
+                    huff_ref_reads_short(prev_start - w->seg_start_bits, sym_start - w->seg_start_bits, total)) status |= HUFF_ST_DC_LONG;
                 const int32_t dv = sz ? val : 0; // (sz == 0: t's top bit belongs to the next symbol)
                 d0 += dv & m0; d1 += dv & m1; d2 += dv & m2;
                 if (WRITE) {
@@ -266,6 +268,15 @@ ZJ_DEV HuffState huff_run(const HuffLds& L, uint32_t tid, uint32_t start_bits, H
     // or the next segment's bytes.  The CPU walker's reader feeds zero bits behind a marker (bitstream.rs:150-262), so the
     // two would disagree about that symbol: hand the scan back (a well-formed segment ends at or before its limit).
     if (WRITE && last_sub && pos > limit) status |= HUFF_ST_EXHAUSTED;
+    // the next sub-sequence begins with a DC symbol whose predecessor is this lane's last symbol: the short-read test for
+    // it happens here (a look at its table entry; the stream words behind the limit are staged, HUFF_LANE_DATA)
+    if (WRITE && !last_sub && z == 0 && pos >= limit && prev_start != 0xffffffffu && w->blk < w->blk_end) {
+        const uint32_t win = huff_window(hi, lo, off);
+        uint32_t e = L.T[dcb + (win >> (32u - (uint32_t)HUFF_L1_DC))];
+        if (e & 0x8000u) e = L.T[dcb + (1u << HUFF_L1_DC) + ((e & 0xffu) << (16u - HUFF_L1_DC)) + ((win >> 16) & ((1u << (16u - HUFF_L1_DC)) - 1u))];
+        const uint32_t total = e & 31u;
+        if (total > 16u && huff_ref_reads_short(prev_start - w->seg_start_bits, pos - w->seg_start_bits, total)) status |= HUFF_ST_DC_LONG;
+    }
     aux.x = n; aux.y = d0; aux.z = d1; aux.w = d2;
     if (WRITE && status) huff_or(&w->ctl[HUFF_CTL_STATUS], status);
     HuffState o;
