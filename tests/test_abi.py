@@ -191,3 +191,31 @@ def test_c_example_builds_and_links():
                            "-Wl,-rpath," + os.path.join(root, "zune-jpeg_amd"), "-o", out])
     assert os.path.exists(out)
     os.remove(out)
+
+
+def test_rust_shim_source_is_at_least_well_formed():
+    """no rustc in this image: the cheapest checks a compiler would make first -- balanced delimiters outside strings and
+    comments, every `fn` with a body or a `;`, no tabs, the crate-level attributes in front of the first item"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rs = open(os.path.join(root, "bindings", "rust", "src", "lib.rs")).read()
+    code = re.sub(r"//[^\n]*", "", rs)                      # line comments (doc comments included)
+    code = re.sub(r'"(?:\\.|[^"\\])*"', '""', code)      # string literals
+    code = re.sub(r"'(?:\\.|[^'\\])'", "' '", code)      # char literals (lifetimes such as '_ stay)
+    stack = []
+    pairs = {")": "(", "]": "[", "}": "{"}
+    for i, ch in enumerate(code):
+        if ch in "([{":
+            stack.append((ch, i))
+        elif ch in ")]}":
+            assert stack and stack[-1][0] == pairs[ch], f"unbalanced {ch!r} near: {code[max(0, i - 60):i + 20]!r}"
+            stack.pop()
+    assert not stack, f"unclosed {stack[-1][0]!r} near: {code[stack[-1][1]:stack[-1][1] + 80]!r}"
+    assert "\t" not in rs
+    assert rs.index("#![allow(non_camel_case_types)]") < rs.index("use std::ffi::CStr;")
+    for m in re.finditer(r"\bfn\s+\w+[^;{]*([;{])", code):
+        assert m.group(1) in ";{"
+    # every extern fn is `pub fn name(args) -> ret;` or `pub fn name(args);`
+    block = code[code.index('extern "" {'):]
+    block = block[:block.index("\n}\n")]
+    for line in re.findall(r"pub fn [^;]*;", block, flags=re.S):
+        assert re.match(r"pub fn zj_\w+\([^)]*\)(\s*->\s*[^;]+)?;", line, flags=re.S), line
