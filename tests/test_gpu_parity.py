@@ -213,7 +213,7 @@ def test_golden_extension_fixtures(ctx, zj, path):
 
 @pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("out_cs", [oc.RGB, oc.GRAYSCALE, oc.YCBCR])
-@pytest.mark.parametrize("wh", [(64, 64), (528, 40), (32, 8), (1040, 33), (1920, 1080)])
+@pytest.mark.parametrize("wh", [(64, 64), (528, 40), (32, 8), (272, 100), (304, 48), (1040, 33), (2080, 16), (1920, 1080)])
 def test_decode_planes_vs_oracle(ctx, zj, synth, mode, out_cs, wh):
     hs, vs = MODES[mode]
     w, h = wh
