@@ -613,8 +613,8 @@ enum { OUT_RGB = 0, OUT_GRAY = 1, OUT_YCBCR = 2, OUT_RGBA = 3, OUT_RGB_CHW = 4 }
 enum { GEN_WIDE = 0, GEN_PACKED = 1 };
 
 // LDS layouts (byte offsets).
-//   GEN_WIDE    Yp[SH][TWY] i16 | Cb[CROWS][CPITCH] i16 | Cr[..] | tables | vertical LUT
-//   GEN_PACKED  Yb[SH][TWY] u8  | Cb[CROWS][CPITCH] i16 | Cr[..] | tables | vertical LUT | flag | store staging
+//   GEN_WIDE    Yp[SH][TWY] i16 | Cb[CROWS][CPITCH] i16 | Cr[..] | halo columns, raw + filtered | tables | vertical LUT
+//   GEN_PACKED  Yb[SH][TWY] u8  | Cb[CROWS][CPITCH] i16 | Cr[..] | halo columns, raw + filtered | tables | vertical LUT | flag | store staging
 // The packed kernel's allocation covers the wide layout too: a tile whose luma cannot be staged as bytes (an
 // unclamped DC-only value outside 0..255, Q1) is redone by the wide code in the same workgroup.
 template <int HS, int VS, int OUT>

@@ -16,7 +16,7 @@
 
 // launch bound, waves per SIMD.  Wide generation: 5 (the 24-bit transform holds 64 x i32 between its passes: 89 VGPRs;
 // 32.4 KB of LDS per workgroup allow 5 as well).  Packed generation: 6 -- its hot path fits 80 VGPRs (the spills the
-// bound causes, 44 bytes, are all inside the wide code it falls back to), a 256-pixel tile needs 26.4 KB of LDS, and six
+// bound causes, 44 bytes, are all inside the wide code it falls back to), a 256-pixel tile needs 25.8 KB of LDS (26.4 before round 3 moved the halo columns out of the chroma rows), and six
 // workgroups per CU measure 1 % faster than five (tools/ab_libs.sh, profiles/r02_*).
 #ifndef ZJ_WAVES_PER_SIMD
 #define ZJ_WAVES_PER_SIMD 5
