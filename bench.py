@@ -37,8 +37,9 @@ BYTES_PER_PX = 6.0               # 3 B coefficients read + 3 B RGB
 
 
 def cpu_baseline(planes, qts, budget_s=20.0):
-    """The reference's x86 path restated (kind "port"): oracle/zj_avx2.c follows src/idct/avx2.rs,
-    src/color_convert/avx.rs and the strip-per-job pool of src/mcu.rs:356 (AVX2, N threads), timed on
+    """The reference's x86 path restated (kind "port"): oracle/zj_avx2.c follows src/idct/avx2.rs, src/upsampler/avx2.rs
+    (upsample_hv_avx, literally since round 3), src/color_convert/avx.rs and the strip-per-job pool of src/mcu.rs:356
+    (AVX2, N threads), timed on
     whole 4096x4096 4:2:0 frames at 4 threads (the reference's default, src/options.rs:33), at the container's
     CPU quota and at twice that (about 20 s of CPU work in total); `value` is the fastest with its thread count in `cores`.  The scalar oracle
     (1 thread) is timed beside it.  Checker/baseline only -- never on the product path."""

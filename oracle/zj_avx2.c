@@ -11,12 +11,12 @@
  *   colour    src/color_convert/avx.rs:81-192  16 pixels per call: sub 128, mullo_epi16, srai, add,
  *             clamp, scalar 3-byte interleave.
  *   worker    src/worker.rs:32-251 row/tail logic (shared semantics with the scalar arm).
- * What is restated in the same vector structure but with the scalar arm's edge rules:
- *   h2v2      src/upsampler/avx2.rs:29-342 fuses the vertical and horizontal triangle filters on 16
- *             input samples per iteration and patches edge samples by copying neighbours; here the two
- *             filters are vectorised (16 x i16 per op, unaligned neighbour loads, unpack interleave)
- *             with the scalar arm's exact first/last-sample rules, so the output equals the oracle's
- *             and can be checked; the instruction mix per sample is the same class (mullo/add/srai/unpack).
+ *   h2v2      src/upsampler/avx2.rs:29-342 upsample_hv_avx, literally (round 3): the fused vertical + horizontal filter on
+ *             16 input samples per iteration, its scalar row tails and its copied edge samples (zja_upsample_hv_avx).
+ *   h (SSE)   src/upsampler/sse.rs:24-134 upsample_horizontal_sse_u, literally (zja_upsample_h_sse; the reference's own
+ *             SSE == scalar tests are replayed on it).
+ * Kept beside them: zja_upsample_v / zja_upsample_h, the two filters vectorised with the SCALAR arm's edge rules (their
+ * output equals the oracle's; rounds 1-2 timed these in place of upsample_hv_avx).
  */
 #include <immintrin.h>
 #include <pthread.h>
@@ -216,6 +216,128 @@ int zja_upsample_h(const int16_t *in, size_t n, int16_t *out, size_t out_len)
     return ZJO_OK;
 }
 
+/* ---- upsample_hv_avx, src/upsampler/avx2.rs:29-342, statement by statement ----------------------------------------
+ * The arm the reference selects for (2,2) sampling when use_unsafe is on (src/upsampler.rs:97-112, via upsample_hv_simd
+ * :15-23: inputs shorter than 500 samples take the scalar arm).  It fuses the vertical and the horizontal triangle filter
+ * over 16 input samples per iteration; the last 16 samples of every input row, and five more outputs per row pair, are
+ * patched "manually".  NOT the scalar arm's function and not a parity target -- restated literally for the timed baseline:
+ *   - the carried neighbours `prev` / `pixel_far` are (3 * (a + b + 2)) >> 2 after the first iteration (method-call
+ *     precedence in :261-267: `3 * (*x).wrapping_add(y).wrapping_add(2)`), not (3a + b + 2) >> 2 as before the loop (:66-67);
+ *   - the scalar tail (:282-304) filters the RAW input rows horizontally -- no vertical filter -- into the last v outputs of
+ *     both output rows, and ends each with the raw sample input[pos] / input[pos + stride];
+ *   - five outputs around the row ends are copies of their neighbours (:331-339).
+ * Everywhere else (the interior of every row) its numbers equal upsample_hv's, which tests/test_avx2_baseline.py checks.
+ * i16 arithmetic wraps (release build); every slice index / get_mut().unwrap() / assert! of the Rust is a ZJO_ERR_PANIC here. */
+static inline __m256i hv_pack_shuffle(__m256i x, int hi_half)      /* pack_shuffle!, :72-81 */
+{
+    const __m256i v = hi_half ? _mm256_permute2x128_si256(x, x, 0x33) : _mm256_permute2x128_si256(x, x, 0x00);
+    const __m256i rwn_hi = _mm256_unpackhi_epi16(v, v), rwn_lo = _mm256_unpacklo_epi16(v, v);
+    return _mm256_permute2x128_si256(rwn_lo, rwn_hi, 0x30);
+}
+static inline int hv_horizontal(__m256i row, int16_t prev, int16_t pixel_far, int16_t *output, size_t out_len, size_t at)
+{                                                                   /* upsample_horizontal!, :83-197 */
+    const __m256i three = _mm256_set1_epi16(3), two = _mm256_set1_epi16(2);
+    __m256i next_arr = _mm256_alignr_epi8(_mm256_permute2x128_si256(row, row, 0x81), row, 2);        /* shuffle(2,0,0,1) */
+    __m256i prev_arr = _mm256_alignr_epi8(row, _mm256_permute2x128_si256(row, row, 0x08), 14);       /* shuffle(0,0,2,0) */
+    prev_arr = _mm256_insert_epi16(prev_arr, prev, 0);
+    next_arr = _mm256_insert_epi16(next_arr, pixel_far, 15);
+    const __m256i near_lo = hv_pack_shuffle(row, 0), near_hi = hv_pack_shuffle(row, 1);
+    const __m256i prev_lo = hv_pack_shuffle(prev_arr, 0), prev_hi = hv_pack_shuffle(prev_arr, 1);
+    const __m256i next_lo = hv_pack_shuffle(next_arr, 0), next_hi = hv_pack_shuffle(next_arr, 1);
+    if (at + 32 > out_len) return ZJO_ERR_PANIC;                    /* output.get_mut(..).unwrap(), :176,:192 */
+    __m256i nn = _mm256_blend_epi16(prev_lo, next_lo, 0xAA);
+    __m256i cn = _mm256_srai_epi16(_mm256_add_epi16(_mm256_mullo_epi16(near_lo, three), _mm256_add_epi16(nn, two)), 2);
+    _mm256_storeu_si256((__m256i *)(output + at), cn);
+    nn = _mm256_blend_epi16(prev_hi, next_hi, 0xAA);
+    cn = _mm256_srai_epi16(_mm256_add_epi16(_mm256_mullo_epi16(near_hi, three), _mm256_add_epi16(nn, two)), 2);
+    _mm256_storeu_si256((__m256i *)(output + at + 16), cn);
+    return ZJO_OK;
+}
+int zja_upsample_hv_avx(const int16_t *input, size_t n, int16_t *output, size_t output_len)
+{
+#define W16(x) ((int16_t)(x))
+    memset(output, 0, output_len * sizeof(int16_t));               /* vec![0; output_len], :55 */
+    size_t stride = 0, pos = 0, output_position = 0;
+    int modify_stride = 1;
+    if (n <= 16) return ZJO_ERR_PANIC;                             /* input[pos + 16], :67 */
+    int16_t prev = W16(W16(W16(3 * input[0]) + input[stride] + 2) >> 2);                              /* :66 */
+    int16_t pixel_far = W16(W16(W16(3 * input[pos + 16]) + input[pos + stride + 16] + 2) >> 2);       /* :67 */
+    const __m256i three = _mm256_set1_epi16(3), two = _mm256_set1_epi16(2);
+    const size_t len = output_len / 16;                             /* :216 */
+    const size_t end = (n >> 7) ? (n >> 7) - 1 : 0;                 /* saturating_sub, :217 */
+    const size_t v = output_len / 16 > end * 32 ? output_len / 16 - end * 32 : 0;                     /* :219 */
+    for (int j = 0; j < 8; j++) {
+        for (size_t it = 0; it < end; it++) {
+            if (pos > n || pos + stride > n) return ZJO_ERR_PANIC;  /* input[pos..], input[pos + stride..], :232-233 */
+            if (pos + 16 > n || pos + stride + 16 > n) return ZJO_ERR_PANIC; /* (the unchecked 32-byte loads must stay inside) */
+            const __m256i load_near = _mm256_loadu_si256((const __m256i *)(input + pos));
+            const __m256i load_far = _mm256_loadu_si256((const __m256i *)(input + pos + stride));
+            /* upsample_vertical!, :200-213 */
+            const __m256i row_near = _mm256_srai_epi16(_mm256_add_epi16(_mm256_mullo_epi16(load_near, three), _mm256_add_epi16(load_far, two)), 2);
+            const __m256i row_far = _mm256_srai_epi16(_mm256_add_epi16(_mm256_add_epi16(load_near, two), _mm256_mullo_epi16(load_far, three)), 2);
+            int rc = hv_horizontal(row_near, prev, pixel_far, output, output_len, output_position);            /* :248 */
+            if (rc == ZJO_OK) rc = hv_horizontal(row_far, prev, pixel_far, output, output_len, output_position + len); /* :250 */
+            if (rc) return rc;
+            output_position += 32;
+            pos += 16;
+            if (n < pos + stride + 16) return ZJO_ERR_PANIC;        /* assert!, :259 */
+            {                                                       /* :261-267: 3 * (a + b + 2), see the header */
+                const int16_t a = pos < n ? input[pos] : 0, b = pos + stride < n ? input[pos + stride] : 0;
+                prev = W16(W16(3 * W16(W16(a + b) + 2)) >> 2);
+                const int16_t c = pos + 16 < n ? input[pos + 16] : 0, d = pos + stride + 16 < n ? input[pos + stride + 16] : 0;
+                pixel_far = W16(W16(3 * W16(W16(c + d) + 2)) >> 2);
+            }
+        }
+        /* the part of the row the vector loop leaves: scalar, :274-304 */
+        if (output_position + v > output_len) return ZJO_ERR_PANIC;  /* split_at_mut */
+        if (v == 0) return ZJO_ERR_PANIC;                            /* unwritten.last_mut().unwrap() */
+        const size_t blen = output_len - (output_position + v);
+        if (len > blen || len < v) return ZJO_ERR_PANIC;             /* b[len - v..len] */
+        int16_t *unwritten = output + output_position;               /* a[c..], c = a.len() - v */
+        int16_t *unwritten_stride = output + output_position + v + (len - v);
+        if (pos < v / 2 + 2 || pos > n) return ZJO_ERR_PANIC;        /* input[pos - v/2 - 2..pos] */
+        {
+            const int16_t *w = input + pos - v / 2 - 2;
+            for (size_t k = 0; k + 1 < v; k += 2) { /* windows(3) over v/2 + 2 samples: v/2 windows; chunks_exact_mut(2): v/2 */
+                const int16_t sample = W16(W16(3 * w[k / 2 + 1]) + 2);
+                unwritten[k] = W16(W16(sample + w[k / 2]) >> 2);
+                unwritten[k + 1] = W16(W16(sample + w[k / 2 + 2]) >> 2);
+            }
+        }
+        if (pos >= n) return ZJO_ERR_PANIC;                          /* input[pos] */
+        unwritten[v - 1] = input[pos];
+        if (pos + stride < v / 2 + 2 || pos + stride > n) return ZJO_ERR_PANIC;
+        {
+            const int16_t *w = input + pos - v / 2 + stride - 2;
+            for (size_t k = 0; k + 1 < v; k += 2) {
+                const int16_t sample = W16(W16(3 * w[k / 2 + 1]) + 2);
+                unwritten_stride[k] = W16(W16(sample + w[k / 2]) >> 2);
+                unwritten_stride[k + 1] = W16(W16(sample + w[k / 2 + 2]) >> 2);
+            }
+        }
+        if (pos + stride >= n) return ZJO_ERR_PANIC;                 /* input[pos + stride] */
+        unwritten_stride[v - 1] = input[pos + stride];
+        output_position += len + v;
+        pos += v / 2;
+        if (modify_stride) { stride = n / 8; modify_stride = 0; }   /* :312-317 */
+        if (j == 6) stride = 0;                                      /* :318-326 */
+        if (output_position > output_len || output_position < len + 4) return ZJO_ERR_PANIC;
+        output[output_position - len] = output[output_position - len + 1];       /* :331 (index + 1 may be == output_len) */
+        output[output_position - len - 2] = output[output_position - len - 4];
+        output[output_position - len - 1] = output[output_position - len - 3];
+        output[output_position - 2] = output[output_position - 4];
+        output[output_position - 1] = output[output_position - 3];
+    }
+#undef W16
+    return ZJO_OK;
+}
+/* upsample_hv_simd, src/upsampler/avx2.rs:15-23 */
+int zja_upsample_hv_simd(const int16_t *input, size_t n, int16_t *output, size_t output_len)
+{
+    if (n < 500) return zjo_upsample_hv(input, n, output, output_len);
+    return zja_upsample_hv_avx(input, n, output, output_len);
+}
+
 /* ---- upsample_horizontal_sse_u, src/upsampler/sse.rs:24-134, statement by statement --------------
  * NOT the same function as the scalar arm: its last eight outputs are written "manually" (sse.rs:113-131) and three of
  * them use other taps than src/upsampler/scalar.rs:5-60 -- out[2n-5] = (3 in[n-3] + in[n-3] + 2) >> 2, out[2n-4] =
@@ -353,9 +475,8 @@ static int post_process_avx2(scratch_t *sc, const int16_t *const coeff[3], const
     size_t ylen = len[0];
     const int16_t *ch[3] = {sc->unp[0], sc->unp[1], sc->unp[2]};
     if (rc == ZJO_OK && hs == 2 && vs == 2) {
-        for (int i = 1; i < 3 && rc == ZJO_OK; i++) {
-            rc = zja_upsample_v(sc->unp[i], len[i], sc->mid, len[i] * 2);
-            if (rc == ZJO_OK) rc = zja_upsample_h(sc->mid, len[i] * 2, sc->up[i - 1], ylen);
+        for (int i = 1; i < 3 && rc == ZJO_OK; i++) { /* the arm choose_hv_samp_function picks, src/upsampler.rs:97-112 */
+            rc = zja_upsample_hv_simd(sc->unp[i], len[i], sc->up[i - 1], ylen);
             ch[i] = sc->up[i - 1];
         }
     } else if (rc == ZJO_OK && !(hs == 1 && vs == 1)) {

@@ -44,6 +44,15 @@ def upsample_hv(inp, out_len):
     return rc, out
 
 
+def upsample_hv_avx(inp, out_len, simd_entry=False):
+    """upsample_hv_avx (src/upsampler/avx2.rs:29) or, with simd_entry, upsample_hv_simd (:15: scalar below 500 samples)."""
+    inp = np.ascontiguousarray(inp, np.int16)
+    out = np.empty(out_len, np.int16)
+    fn = lib().zja_upsample_hv_simd if simd_entry else lib().zja_upsample_hv_avx
+    rc = fn(_p(inp), C.c_size_t(inp.size), _p(out), C.c_size_t(out_len))
+    return rc, out
+
+
 def upsample_h_sse(inp, out_len):
     """upsample_horizontal_sse_u (src/upsampler/sse.rs:24)."""
     inp = np.ascontiguousarray(inp, np.int16)

@@ -55,7 +55,17 @@ def test_avx2_frame_close_to_scalar(mode, synth):
     outs = [avx2_c.decode_planes_mt(f, planes, 1, t) for t in (1, 4)]
     assert rc == 0 and all(r == 0 for r, _ in outs)
     assert np.array_equal(outs[0][1], outs[1][1])  # thread count does not change the result
-    d = np.abs(outs[0][1].astype(np.int32) - exp.astype(np.int32))
+    d = np.abs(outs[0][1].astype(np.int32) - exp.astype(np.int32)).reshape(h, w, 3)
+    if mode == (2, 2):
+        # the reference's AVX2 h2v2 arm (upsample_hv_avx, restated literally) mis-weights the neighbour taps it carries
+        # between its 16-sample iterations and filters its row tails differently (test_reference_hv_avx_arm below):
+        # pixel columns 0, 32k - 1, 32k and the last 48 (32 + the Q5 shift) are its own
+        keep = np.ones(w, bool)
+        keep[0] = False
+        keep[31::32] = False
+        keep[32::32] = False
+        keep[-48:] = False
+        d = d[:, keep]
     assert d.max() <= 4 and np.mean(d != 0) < 0.5
     assert not outs[0][1].reshape(h, 3 * w)[:, -16:].any()  # same Q5/Q6 tail as the scalar worker
 
@@ -131,3 +141,33 @@ def test_restated_avx2_colour_equals_scalar_colour():
     small = np.zeros(47, np.uint8)
     z = np.zeros(16, np.int16)
     assert avx2_c.ycbcr_to_rgb16(z, z, z, small, 0)[0] == oc.ERR_PANIC and oc.ycbcr_to_rgb16(z, z, z, small, 0)[0] == oc.ERR_PANIC
+
+
+def test_reference_hv_avx_arm_equals_scalar_in_the_interior_only():
+    """upsample_hv_avx (src/upsampler/avx2.rs:29-342), restated statement by statement for the timed baseline
+    (oracle/zj_avx2.c zja_upsample_hv_avx).  Not the scalar arm's function: the neighbours it carries from one 16-sample
+    iteration to the next are 3 * (a + b + 2) >> 2 (method-call precedence, :261-267), its row tails filter the raw input
+    rows, five outputs per row pair are copies.  So: equal to upsample_hv wherever neither applies -- every output column
+    except 0, 32k - 1, 32k and the last 32 -- and different there on arbitrary data."""
+    rng = np.random.default_rng(10)
+    for W in (256, 512, 4096):
+        inp = rng.integers(0, 256, size=8 * (W // 2)).astype(np.int16)
+        rc, a = avx2_c.upsample_hv_avx(inp, 16 * W)
+        rc2, s = oc.upsample_hv(inp, 16 * W)
+        assert rc == 0 and rc2 == 0
+        own = np.zeros(W, bool)
+        own[0] = True
+        own[31::32] = True
+        own[32::32] = True
+        own[-32:] = True
+        diff = (a != s).reshape(16, W)
+        assert not diff[:, ~own].any()
+        assert diff[:, own].any(axis=0).sum() > own.sum() // 2      # ... and it really is another function there
+    # upsample_hv_simd (:15-23): fewer than 500 input samples take the scalar arm
+    small = rng.integers(0, 256, size=8 * 32).astype(np.int16)
+    rc, a = avx2_c.upsample_hv_avx(small, 16 * 64, simd_entry=True)
+    rc2, s = oc.upsample_hv(small, 16 * 64)
+    assert rc == 0 and rc2 == 0 and np.array_equal(a, s)
+    # slices the Rust would panic on
+    assert avx2_c.upsample_hv_avx(np.zeros(16, np.int16), 64)[0] == oc.ERR_PANIC
+    assert avx2_c.upsample_hv_avx(np.zeros(1024, np.int16), 1024)[0] == oc.ERR_PANIC    # output too short for the stores
