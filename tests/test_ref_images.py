@@ -77,11 +77,12 @@ def test_reference_tree_files_give_the_recorded_planes(zj, name):
 @pytest.mark.parametrize("name", sorted(LOCAL))
 def test_reference_files_on_the_gpu(zj, name, entropy):
     """decode_buffer through the C ABI -- Huffman on the CPU walker or forced onto the device stage, pixel path on the GPU --
-    to the hashes the oracle recorded, RGB and GRAYSCALE (tests/random_images.rs:38-99, tests/medium_images.rs:82-98)."""
+    to the hashes the oracle recorded -- RGB, GRAYSCALE and YCbCr, the three outputs the reference's integration tests ask
+    for (tests/large_images.rs:39-153, tests/random_images.rs:38-99, tests/medium_images.rs:82-98)."""
     r = REC[name]
     data = open(os.path.join(GOLD, LOCAL[name]), "rb").read()
     ctx = zj.Context(zj.BACKEND_HIP, 0)
-    for cs, key in ((zj.ColorSpace.RGB, "sha256_rgb"), (zj.ColorSpace.GRAYSCALE, "sha256_gray")):
+    for cs, key in ((zj.ColorSpace.RGB, "sha256_rgb"), (zj.ColorSpace.GRAYSCALE, "sha256_gray"), (zj.ColorSpace.YCbCr, "sha256_ycbcr")):
         o = zj.ZuneJpegOptions()
         o.out_colorspace = cs
         o.entropy = zj.ENTROPY_CPU if entropy == "cpu" else zj.ENTROPY_GPU_ALWAYS

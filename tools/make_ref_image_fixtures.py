@@ -58,7 +58,7 @@ def main():
             rec.update(width=w, height=h, components=nc, h_max=int(info.h_max), v_max=int(info.v_max),
                        progressive=int(info.progressive), scans=int(info.scans), restart_interval=int(info.restart_interval),
                        sha256_planes=sha(np.concatenate(planes)))
-            for cs_name, cs in (("rgb", oc.RGB), ("gray", oc.GRAYSCALE)):
+            for cs_name, cs in (("rgb", oc.RGB), ("gray", oc.GRAYSCALE), ("ycbcr", oc.YCBCR)):   # the three outputs tests/large_images.rs asks for
                 rc, px = oc.decode_planes(oc.make_frame(w, h, info.h_max, info.v_max, nc, cs if nc == 3 else oc.GRAYSCALE, qts), planes)
                 assert rc == 0, (name, rc)
                 rec[f"sha256_{cs_name}"] = sha(px)
