@@ -742,12 +742,8 @@ ZJ_DEV void vrows(int m, int& ra, int& rb)
 
 struct TileId { int frame, strip, tile; };
 
-ZJ_DEV TileId decode_tile(const Params& p, int bid)
+ZJ_DEV TileId tile_from_id(const Params& p, const int id)
 {
-    // XCD-aware order: hardware sends workgroup b to XCD b % 8; give each XCD a contiguous run of
-    // tiles so neighbouring tiles (which share halo blocks) meet in the same L2.
-    int id = bid;
-    if ((p.total_tiles & 7) == 0) id = (bid & 7) * (p.total_tiles >> 3) + (bid >> 3);
     TileId t;
     t.tile = id % p.tiles_per_row;
     const int r = id / p.tiles_per_row;
@@ -755,6 +751,10 @@ ZJ_DEV TileId decode_tile(const Params& p, int bid)
     t.frame = r / p.n_strips;
     return t;
 }
+// XCD-aware order: hardware sends workgroup b to XCD b % 8; give each XCD a contiguous run of `n` units
+// so neighbouring tiles (which share halo blocks) meet in the same L2.
+ZJ_DEV int xcd_order(const int bid, const int n) { return (n & 7) == 0 ? (bid & 7) * (n >> 3) + (bid >> 3) : bid; }
+ZJ_DEV TileId decode_tile(const Params& p, int bid) { return tile_from_id(p, xcd_order(bid, p.total_tiles)); }
 
 // ------------------------------------------------------------------------------------------------
 // Block b of a tile: where its 64 coefficients live in HBM and where its pixels go in LDS.
