@@ -7,7 +7,7 @@ i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
-  (cd /tmp && timeout 300 rocprofv3 --pmc $line --output-format csv -d $O/$V/p$i -o pmc -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --variant $V > $O/$V-p$i.log 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --pmc $line --output-format csv -d $O/$V/p$i -o pmc -- python3 $R/bench.py --steps 5 --warmup 2 --child --shard-frames 16 --variant $V > $O/$V-p$i.log 2>&1)
 done <<LIST
 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU
 SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM

@@ -6,7 +6,7 @@ i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
-  (cd /tmp && timeout 300 rocprofv3 --pmc $line --output-format csv -d $O/p$i -o pmc -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --variant $VAR > $O/p$i.log 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --pmc $line --output-format csv -d $O/p$i -o pmc -- python3 $R/bench.py --steps 5 --warmup 2 --child --shard-frames 16 --variant $VAR > $O/p$i.log 2>&1)
 done <<LIST
 SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CU_CYCLES
