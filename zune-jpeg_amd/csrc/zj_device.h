@@ -1558,13 +1558,20 @@ ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid, char* 
     const char* src[PPI];
     uint32_t off[PPI];
     int mm[PPI], cc[PPI];
+    // A round of NT items covers whole tile rows when NT is a multiple of the groups per row: the pieces of round r then
+    // sit NT / NGRP rows below those of round 0, in the same columns -- the division below is written for round 0 only,
+    // so that the unrolled rounds of a tile share it (round 3: -20 VALU instructions per wave and round after the first)
+    constexpr bool WHOLE_ROWS = C::NT % C::NGRP == 0;
+    const int item_q = WHOLE_ROWS ? 64 * w : item0;
+    const int row_shift = WHOLE_ROWS ? round * (C::NT / C::NGRP) : 0;
 #pragma unroll
     for (int j = 0; j < PPI; j++) {
         src[j] = (j == 0 && L < C::INPL ? ybase : xbase) + 16 * (64 * j + L);
-        const int Q = PPI * item0 + 64 * j + L;   // piece index inside the tile
-        mm[j] = (int)(((uint32_t)Q * (uint32_t)C::PPR_MAGIC) >> 20); // Q / PIECES_PER_ROW (3 instructions; checked in Cfg)
-        cc[j] = Q - mm[j] * C::PIECES_PER_ROW;
-        off[j] = (uint32_t)mul24(mm[j], (int32_t)row_bytes) + 16u * (uint32_t)cc[j]; // m < 32, row_bytes < 2^18
+        const int Q = PPI * item_q + 64 * j + L;  // piece index inside the tile (of round 0 when WHOLE_ROWS)
+        const int m0 = (int)(((uint32_t)Q * (uint32_t)C::PPR_MAGIC) >> 20); // Q / PIECES_PER_ROW (3 instructions; checked in Cfg)
+        cc[j] = Q - m0 * C::PIECES_PER_ROW;
+        mm[j] = m0 + row_shift;
+        off[j] = (uint32_t)mul24(m0, (int32_t)row_bytes) + 16u * (uint32_t)cc[j] + (uint32_t)row_shift * row_bytes; // m < 32, row_bytes < 2^18
     }
     // interior tiles (all but the last of a row, all but a clipped last strip), whole rounds: no per-piece test,
     // PPI LDS reads, one wait, PPI stores
