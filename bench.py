@@ -180,6 +180,17 @@ def load_golden():
         return None
 
 
+def golden_match(all_sums, shard_frames, golden):
+    """all_sums[r][j] = checksum of frame j of rank r's shard = global frame r * shard_frames + j (frames beyond the 1024 of
+    configs[4] wrap around): True iff every one equals the oracle's (tests/golden/checksums_seed1234.json), None if the
+    golden file does not reach that far."""
+    gl = [int(x, 16) for x in golden["rgb"]]
+    idx = [(r * shard_frames + j) % 1024 for r in range(len(all_sums)) for j in range(len(all_sums[r]))]
+    if not idx or max(idx) >= len(gl):
+        return None
+    return all(c == gl[i] for c, i in zip((c for r in all_sums for c in r), idx))
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` outside torchrun: start the N ranks as CHILD processes (this parent never imports torch
     or touches a GPU), relay rank 0's stdout, fail if any rank fails."""
@@ -387,12 +398,7 @@ def main():
         sums = [synth.frame_checksum_t(d_out[j * frame_out:(j + 1) * frame_out], wts) for j in range(S)]
         del wts
     all_sums = shard.gather_checksums(sums, world, coll_dev)
-    match = None
-    if golden and sums:
-        gl = [int(x, 16) for x in golden["rgb"]]
-        idx = [(r * S + j) % 1024 for r in range(world) for j in range(len(all_sums[r]))]   # global frame -> golden entry
-        if max(idx) < len(gl):
-            match = all(c == gl[i] for c, i in zip((c for r in all_sums for c in r), idx))
+    match = golden_match(all_sums, S, golden) if (golden and sums) else None
 
     if rank == 0:
         mp_total = world * B * args.steps * W * H / 1e6

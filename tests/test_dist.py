@@ -88,3 +88,28 @@ def test_bench_self_launch_fails_loudly_without_a_gpu():
     assert r.returncode != 0
     assert b"needs a GPU" in r.stderr and b"rank" in r.stderr
     assert not r.stdout.strip()
+
+
+def test_golden_checksum_comparison_has_teeth():
+    """bench.py's checksums_match_golden: the gathered per-frame checksums against tests/golden/checksums_seed1234.json --
+    true for the oracle's own numbers in shard order, false for one flipped bit, one swapped pair of frames or shards
+    handed out in the wrong order."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    g = json.load(open(os.path.join(root, "tests", "golden", "checksums_seed1234.json")))
+    gl = [int(x, 16) for x in g["rgb"]]
+    S, world = 128, 8
+    good = [gl[r * S:(r + 1) * S] for r in range(world)]
+    assert bench.golden_match(good, S, g) is True
+    assert bench.golden_match([gl[:16]], 16, g) is True and bench.golden_match([gl[:16], gl[16:32]], 16, g) is True
+    bad = [list(x) for x in good]
+    bad[5][77] ^= 1
+    assert bench.golden_match(bad, S, g) is False
+    swapped = [list(x) for x in good]
+    swapped[0][3], swapped[0][4] = swapped[0][4], swapped[0][3]
+    assert bench.golden_match(swapped, S, g) is False
+    assert bench.golden_match(good[::-1], S, g) is False
+    assert bench.golden_match([], S, g) is None
