@@ -36,19 +36,21 @@ HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E
 BYTES_PER_PX = 6.0               # 3 B coefficients read + 3 B RGB written per pixel
 
 
-def cpu_baseline(planes, qts, budget_s=20.0):
+def cpu_baseline(frames, qts, budget_s=20.0):
     """The reference's x86 path restated (kind "port"): oracle/zj_avx2.c follows src/idct/avx2.rs, src/upsampler/avx2.rs
     (upsample_hv_avx, literally since round 3), src/color_convert/avx.rs and the strip-per-job pool of src/mcu.rs:356
-    (AVX2, N threads), timed on
-    whole 4096x4096 4:2:0 frames at 4 threads (the reference's default, src/options.rs:33), at the container's
-    CPU quota and at twice that (about 20 s of CPU work in total); `value` is the fastest with its thread count in `cores`.  The scalar oracle
-    (1 thread) is timed beside it.  Checker/baseline only -- never on the product path."""
+    (AVX2, N threads), timed on whole 4096x4096 4:2:0 frames at 4 threads (the reference's default, src/options.rs:33),
+    at the container's CPU quota and at twice that (about 20 s of CPU work in total); `value` is the fastest with its
+    thread count in `cores`.  `frames` = the coefficient planes of >= 8 DISTINCT frames of the GPU's shard, decoded in
+    rotation into as many output buffers (0.8 GB working set: nothing stays in the host's L3 between visits).  The scalar
+    oracle (1 thread) is timed beside it.  Checker/baseline only -- never on the product path."""
     import numpy as np
     import avx2_c
     import oracle_c as oc
     f = oc.make_frame(W, H, 2, 2, 3, oc.RGB, qts)
-    out = np.zeros(W * H * 3, np.uint8)
+    outs = [np.zeros(W * H * 3, np.uint8) for _ in frames]
     ncpu = os.cpu_count() or 1
+    turn = [0]
 
     def run(fn, budget):
         fn()  # warm
@@ -65,15 +67,68 @@ def cpu_baseline(planes, qts, budget_s=20.0):
     tset = sorted({min(t, ncpu) for t in (4, eff, 2 * eff)})
     for t in tset:
         def fn(t=t):
-            rc, _ = avx2_c.decode_planes_mt(f, planes, 1, t, out)
+            k = turn[0] = (turn[0] + 1) % len(frames)
+            rc, _ = avx2_c.decode_planes_mt(f, frames[k], 1, t, outs[k])
             assert rc == 0
         res[t] = run(fn, budget_s * (0.35 if t == 4 else 0.5 / max(len(tset) - 1, 1)))
-    sc = run(lambda: oc.decode_planes(f, planes), budget_s * 0.15)
+
+    def scalar():
+        k = turn[0] = (turn[0] + 1) % len(frames)
+        oc.decode_planes(f, frames[k])
+    sc = run(scalar, budget_s * 0.15)
     best = max(res, key=lambda t: res[t][0])
     detail = "; ".join(f"{t} threads {res[t][0]:.0f} MP/s ({res[t][1]} frames, {res[t][2]:.1f} s)" for t in sorted(res))
     return {"value": round(res[best][0], 1), "unit": "megapixels/s", "cores": best, "kind": "port",
-            "sample": f"restated zune-jpeg AVX2 path (oracle/zj_avx2.c) on 4096x4096 4:2:0 frames: {detail}; "
+            "distinct_frames": len(frames), "l3_resident": False,
+            "sample": f"restated zune-jpeg AVX2 path (oracle/zj_avx2.c) on 4096x4096 4:2:0 frames, {len(frames)} distinct "
+                      f"frames in rotation: {detail}; "
                       f"scalar restatement 1 thread {sc[0]:.0f} MP/s; host has {ncpu} logical CPUs, cgroup quota {eff}"}
+
+
+def e2e_pinned(zj, ctx, desc, d_planes, plane_elems, frame_out, golden_sums=None, nb=8, reps=4):
+    """Never `value`: the boundary as north_star words it -- coefficient planes in PINNED host memory streamed to HBM with
+    hipMemcpyAsync, the fused kernel, the pixels streamed back to pinned host memory (zj_decode_planes_batch: three
+    streams, uploads / kernels / downloads overlapped over units of ~16 MB).  `nb` distinct frames of the shard.  PCIe
+    Gen5 x16 carries ~63 GB/s per direction at best, so this rate is the link's, not the kernel's."""
+    import ctypes as C
+    try:
+        L = zj.lib()
+        sizes = [2 * n * nb for n in plane_elems] + [frame_out * nb]
+        pins = [L.zj_alloc_pinned(sz) for sz in sizes]
+        if not all(pins):
+            return {"error": "zj_alloc_pinned failed"}
+        try:
+            for c in range(3):
+                host = d_planes[c][:nb * plane_elems[c]].cpu().numpy()
+                C.memmove(pins[c], host.ctypes.data, host.nbytes)
+
+            def once():
+                rc = L.zj_decode_planes_batch(ctx.handle, C.byref(desc), nb, pins[0], pins[1], pins[2], pins[3])
+                if rc != 0:
+                    raise RuntimeError(f"zj_decode_planes_batch: {rc}")
+            once()
+            best = 1e9
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                once()
+                best = min(best, time.perf_counter() - t0)
+            import numpy as np
+            got = np.ctypeslib.as_array((C.c_uint8 * frame_out).from_address(pins[3] + (nb - 1) * frame_out))
+            synth = importlib.import_module("zune-jpeg_amd.synth")
+            last_sum = synth.frame_checksum_sum(got)
+        finally:
+            for p_ in pins:
+                L.zj_free_pinned(p_)
+        up = sum(sizes[:3]) / best / 1e9
+        down = sizes[3] / best / 1e9
+        return {"megapixels_per_s": round(nb * W * H / 1e6 / best, 1), "ms_per_frame": round(best / nb * 1e3, 3),
+                "frames": nb, "h2d_gbs": round(up, 1), "d2h_gbs": round(down, 1), "pcie_peak_gbs_per_direction": 63.0,
+                "h2d_frac": round(up / 63.0, 3), "d2h_frac": round(down / 63.0, 3),
+                "last_frame_matches_golden": (last_sum == golden_sums[nb - 1]) if golden_sums else None,
+                "what": f"{nb} distinct 4096x4096 4:2:0 frames: pinned host planes -> hipMemcpyAsync -> fused kernel -> "
+                        f"hipMemcpyAsync -> pinned host RGB (zj_decode_planes_batch, 3 streams), best of {reps} passes"}
+    except Exception as e:  # the headline must not depend on this
+        return {"error": repr(e)[:200]}
 
 
 def from_files(zj, ctx, size=4096, batch=16, reps=4):
@@ -123,7 +178,7 @@ def load_traffic():
         return None
 
 
-def live_traffic(workload, B, timeout_s=150):
+def live_traffic(workload, B, S, timeout_s=200):
     """HBM bytes per launch of the fused kernel measured in THIS run: two child runs of this script under
     `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE in separate passes, as /opt/skills/guides/MI355X_MICROARCH.md
     prescribes: the two do not fit the TCC's four slots together), a few launches of the same shape each, summarised by
@@ -148,7 +203,7 @@ def live_traffic(workload, B, timeout_s=150):
                 env.pop(k, None)
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--min-untimed", "2",
-                   "--frames", str(B), "--shard-frames", str(B), "--workload", workload, "--child"]
+                   "--frames", str(B), "--shard-frames", str(S), "--workload", workload, "--child"]
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
             if r.returncode != 0:
                 return None
@@ -165,7 +220,8 @@ def live_traffic(workload, B, timeout_s=150):
         return {"hbm_bytes_per_launch": int(2 * fetch + write), "fetch_bytes_raw": fetch, "write_bytes": write,
                 "launches": means["FETCH_SIZE"][1],
                 "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, child runs of this bench.py invocation "
-                          f"({means['FETCH_SIZE'][1]} launches of {B} frames each); FETCH_SIZE x2 per MI355X_MICROARCH.md"}
+                          f"({means['FETCH_SIZE'][1]} launches of {B} frames each, walking the same {S}-frame shard as the timed steps); "
+                          f"FETCH_SIZE x2 per MI355X_MICROARCH.md"}
     except Exception:  # noqa: BLE001 -- the headline must not depend on the profiler
         return None
     finally:
@@ -191,28 +247,38 @@ def golden_match(all_sums, shard_frames, golden):
     return all(c == gl[i] for c, i in zip((c for r in all_sums for c in r), idx))
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, rank_timeout=600.0):
     """`python bench.py --gpus N` outside torchrun: start the N ranks as CHILD processes (this parent never imports torch
-    or touches a GPU), relay rank 0's stdout, fail if any rank fails."""
-    import socket
+    or touches a GPU), relay rank 0's stdout, fail if any rank fails -- or if the ranks are not all done `rank_timeout`
+    seconds after the launch (a rank hung in RCCL initialisation must not cost the caller its whole time budget): the
+    children still alive are named on stderr, terminated (exact PIDs; fresh processes, nothing is ever re-exec'd) and the
+    exit code is 124.
+    Rendezvous: no port is probed here (a probe socket closed before the children bind is a race).  Rank 0 binds port 0
+    itself and publishes the kernel's choice through a file the other ranks wait for (shard._store_from_port_file)."""
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    import tempfile
+    import threading
+    tmpdir = tempfile.mkdtemp(prefix="zj_bench_")
+    port_file = os.path.join(tmpdir, "port")
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   MASTER_ADDR="127.0.0.1", ZJ_BENCH_PORT_FILE=port_file)
+        env.pop("MASTER_PORT", None)
+        # The pool's host driver supports only dmabuf IPC: with the legacy mode RCCL's (and torch's) cross-process device
+        # memory sharing fails with `hipIpcGetMemHandle: invalid argument`.  The image exports this variable already; it is
+        # repeated here only so that a caller with a scrubbed environment gets the same ranks.  A/B on one GPU
+        # (profiles/r04_probe_toolchain_rccl.txt): RCCL initialises and runs its collectives with 0, 1 and unset alike --
+        # the setting matters for peer-to-peer mappings only, i.e. from 2 GPUs up.
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    import threading
     lines = []
     t = threading.Thread(target=lambda: lines.extend(procs[0].stdout.read().decode().splitlines()), daemon=True)
     t.start()
     rc = 0
     live = set(range(n))
+    t0 = time.monotonic()
     while live and rc == 0:
         time.sleep(0.2)
         for r in sorted(live):
@@ -222,14 +288,23 @@ def launch_ranks(n, argv):
                 if c != 0:
                     rc = c if c > 0 else 1
                     print(f"bench.py: rank {r} exited with {c}", file=sys.stderr)
-    for r in live:  # a rank failed: stop the others (exact PIDs)
+        if live and rc == 0 and time.monotonic() - t0 > rank_timeout:
+            rc = 124
+            print(f"bench.py: rank(s) {sorted(live)} still running {rank_timeout:.0f} s after the launch (--rank-timeout): "
+                  f"terminating them", file=sys.stderr)
+    for r in live:  # a rank failed or hung: stop the others (exact PIDs)
         procs[r].terminate()
     for p in procs:
         try:
-            p.wait(timeout=30)
+            p.wait(timeout=10)
         except Exception:  # noqa: BLE001
             p.kill()
     t.join(5)
+    try:
+        import shutil
+        shutil.rmtree(tmpdir, ignore_errors=True)
+    except Exception:  # noqa: BLE001
+        pass
     for ln in lines:
         print(ln, flush=True)
     if rc == 0 and not any(ln.startswith("{") for ln in lines):
@@ -267,16 +342,25 @@ def main():
                          "see a single launch shape")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the rocprofv3 --pmc child passes")
     ap.add_argument("--child", action="store_true", help="(internal) a profiler child: kernel launches only, no extras")
+    ap.add_argument("--rank-timeout", type=float, default=600.0,
+                    help="self-launched ranks (--gpus N outside torchrun): seconds after which ranks still running are "
+                         "terminated and the run fails with exit code 124")
+    ap.add_argument("--gather-rgb", action="store_true",
+                    help="after the timed region: every rank's decoded RGB frames gathered to rank 0 (RCCL over xGMI), "
+                         "reported separately as `gather_rgb`, never part of `value` (SURVEY.md 8e, optional)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the pinned-host end-to-end figure (e2e_pinned)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="420-rgb",
                     help="420-rgb = BASELINE.json configs[1]/[4] (the headline); 444-* are configs[2]; 422 / 440 the reference's "
                          "other sampling modes; 420-rgba / 420-chw are the output extensions (4 B/px interleaved, planar u8)")
     ap.add_argument("--variant", choices=["packed", "wide", "packed-direct"], default=None, help="kernel variant (default: library default)")
     args = ap.parse_args()
     if args.child:
-        args.no_cpu_baseline = args.no_single_frame = args.no_live_traffic = True
+        args.no_cpu_baseline = args.no_single_frame = args.no_live_traffic = args.no_e2e = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        launch_ranks(args.gpus, sys.argv[1:])  # does not return
+        launch_ranks(args.gpus, sys.argv[1:], args.rank_timeout)  # does not return
+    if os.environ.get("ZJ_BENCH_TEST_HANG_RANK") in (os.environ.get("RANK", "0"), "all"):
+        time.sleep(1e6)  # test knob (tests/test_dist.py): this rank never reaches the rendezvous
 
     import numpy as np
     import torch  # before libzjhip: both bind the same libamdhip64.so.7
@@ -295,7 +379,12 @@ def main():
     torch.cuda.set_device(gpu_index)
     dev = torch.device("cuda", gpu_index)
     backend = "gloo" if same_gpu else "nccl"
-    shard.init_process_group(backend, rank, world)
+    port_file = os.environ.get("ZJ_BENCH_PORT_FILE")
+    if world == 1 and args.gather_rgb and not port_file and "MASTER_PORT" not in os.environ:
+        import tempfile
+        port_file = os.path.join(tempfile.mkdtemp(prefix="zj_bench_"), "port")  # N = 1 plumbing run of the frame gather
+    shard.init_process_group(backend, rank, world, force=args.gather_rgb and not args.child, port_file=port_file,
+                             timeout_s=args.rank_timeout, device_id=None if same_gpu else dev)
     coll_dev = "cpu" if same_gpu else dev
 
     B = args.frames
@@ -355,32 +444,70 @@ def main():
     torch.cuda.synchronize()
     shard.barrier(world)
     torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     t0 = time.perf_counter()
+    ev[0].record(side)  # HIP events on the launch stream, around exactly the timed region's K launches
     for k in range(args.steps):
         step(k)
+    ev[1].record(side)
     torch.cuda.synchronize()
+    el_local = time.perf_counter() - t0
     shard.barrier(world)
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, world, coll_dev)
+    per_rank_ms = shard.gather_values(el_local / args.steps * 1e3, world, coll_dev)
+    kernel_ms_region = ev[0].elapsed_time(ev[1]) / args.steps
 
-    # dominant-kernel duration, HIP events recorded on the launch stream (outside the timed region); min(steps, 300)
-    # launches so that it averages over the same population as ms_per_step
-    kiters = max(10, min(args.steps, 300))
+    # dominant-kernel duration for the roofline: HIP events on the launch stream over >= 100 launches WALKING THE SHARD
+    # like the timed steps do (whatever --steps says: the driver's --steps 20 would average 20).  When the timed region
+    # itself has >= 100 launches its own event pair is the figure; otherwise a second, untimed run of 104+ launches.
+    kiters = args.steps if (args.steps >= 100 or args.child) else -(-100 // nsub) * nsub
+    if kiters == args.steps:
+        kernel_ms = kernel_ms_region
+    else:
+        ev[2].record(side)
+        for k in range(kiters):
+            step(k)
+        ev[3].record(side)
+        ev[3].synchronize()
+        kernel_ms = ev[2].elapsed_time(ev[3]) / kiters
+    # every launch bracketed by its own event pair (what a profiler reports per dispatch), a few per sub-batch
     p0 = subs[0]
-    kernel_ms, kernel_ms_each, kname = ctx.time_decode_device(desc, B, p0[0], p0[1], p0[2], p0[3], kiters, stream)
+    each, kname = [], None
+    for k in range(1 if args.child else nsub):
+        pk = subs[k]
+        _, e1, kname = ctx.time_decode_device(desc, B, pk[0], pk[1], pk[2], pk[3], 2 if args.child else max(2, -(-48 // nsub)), stream)
+        each.append(e1)
+    kernel_ms_each = sum(each) / len(each)
     # configs[1] read literally is ONE 4096x4096 frame per launch: time that shape too, reported beside the batched figure
     one_ms = one_ms_each = one_ms_4s = None
     if not args.no_single_frame:
-        one_ms, one_ms_each, _ = ctx.time_decode_device(desc, 1, p0[0], p0[1], p0[2], p0[3], 300, stream)
+        fstr = [2 * n for n in plane_elems] + [frame_out]
+
+        def one(i, st):
+            f = i % S  # successive launches walk the shard's frames
+            ctx.decode_planes_device(desc, 1, base[0] + f * fstr[0], base[1] + f * fstr[1], base[2] + f * fstr[2],
+                                     base[3] + f * fstr[3], st)
+        for i in range(50):
+            one(i, stream)
+        ev[2].record(side)
+        for i in range(384):  # ONE caller stream, launches back to back
+            one(i, stream)
+        ev[3].record(side)
+        ev[3].synchronize()
+        one_ms = ev[2].elapsed_time(ev[3]) / 384
+        eachs = []
+        for f in range(0, S, max(1, S // 8)):  # isolated launches (own event pair each) on 8 frames of the shard
+            _, e1, _ = ctx.time_decode_device(desc, 1, base[0] + f * fstr[0], base[1] + f * fstr[1], base[2] + f * fstr[2],
+                                              base[3] + f * fstr[3], 24, stream)
+            eachs.append(e1)
+        one_ms_each = sum(eachs) / len(eachs)
         # the same shape fed the way a frame-at-a-time caller would: launches rotating over four streams, so the tail
         # of one frame overlaps the head of the next (tools/single_frame_streams.py)
         four = [torch.cuda.Stream(device=dev) for _ in range(4)]
-        fstr = [2 * n for n in plane_elems] + [frame_out]
 
         def rot(n):
             for i in range(n):
-                f = i % S
-                ctx.decode_planes_device(desc, 1, base[0] + f * fstr[0], base[1] + f * fstr[1], base[2] + f * fstr[2],
-                                         base[3] + f * fstr[3], four[i % 4].cuda_stream)
+                one(i, four[i % 4].cuda_stream)
         rot(200)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -399,6 +526,28 @@ def main():
         del wts
     all_sums = shard.gather_checksums(sums, world, coll_dev)
     match = golden_match(all_sums, S, golden) if (golden and sums) else None
+    # SURVEY.md 8e, optional: the decoded frames themselves to rank 0 -- the only step that puts real bytes on xGMI.
+    # Measured on its own, after everything else; never part of `value`.
+    gather_rgb = None
+    if args.gather_rgb and not args.child:
+        torch.cuda.empty_cache()
+        try:
+            g_in = d_out if not same_gpu else d_out.cpu()
+            outs, g_s = shard.gather_frames(g_in, rank, world, always=True)
+            g_s = shard.max_over_ranks(g_s, world, coll_dev)
+            ok = None
+            if rank == 0 and outs is not None and golden:
+                # spot check: the LAST frame of the last rank's shard, as it arrived on rank 0
+                last = outs[-1][(S - 1) * frame_out:].to(dev)
+                ok = synth.frame_checksum_t(last) == int(golden["rgb"][((world - 1) * S + S - 1) % 1024], 16)
+            remote = (world - 1) * S * frame_out
+            gather_rgb = {"seconds": round(g_s, 4), "bytes_total": world * S * frame_out, "bytes_remote": remote,
+                          "gbs_remote": round(remote / g_s / 1e9, 1) if (g_s > 0 and remote) else None,
+                          "backend": backend, "last_frame_matches_golden": ok,
+                          "what": f"dist.gather of every rank's {S} decoded RGB frames ({S * frame_out / 1e9:.2f} GB) to rank 0"}
+            del outs
+        except Exception as e:  # noqa: BLE001 -- optional measurement; the headline must not depend on it
+            gather_rgb = {"error": repr(e)[:300]}
 
     if rank == 0:
         mp_total = world * B * args.steps * W * H / 1e6
@@ -407,7 +556,7 @@ def main():
         tr = load_traffic()
         if tr and not (tr.get("workload", "420-rgb") == args.workload and tr.get("frames_per_launch", 16) == B):
             tr = None  # the committed counters describe another launch shape
-        live = None if (args.no_live_traffic or world > 1) else live_traffic(args.workload, B)
+        live = None if (args.no_live_traffic or world > 1) else live_traffic(args.workload, B, S)
         # Second bound, reported beside the HBM one: integer VALU issue.  A wave64 integer instruction occupies
         # its SIMD for 4 cycles (16 lanes per SIMD per clock; profiles/r01_ubench_valu_issue_cost.txt), so the
         # chip retires at most 1024 SIMDs x 2.4 GHz / 4 wave-instructions per second.
@@ -441,7 +590,11 @@ def main():
                          "traffic_replayed": (not live) if traffic is not None else None,
                          "traffic_source": live["source"] if live else (tr or {}).get("source"),
                          "kernel": kname, "kernel_ms": round(kernel_ms, 4), "kernel_ms_single_launch": round(kernel_ms_each, 4),
-                         "kernel_launches_timed": kiters,
+                         "kernel_launches_timed": kiters, "kernel_ms_timed_region": round(kernel_ms_region, 4),
+                         "kernel_timing": f"HIP events on the launch stream; {kiters} launches walking the shard's {nsub} "
+                                          f"sub-batches of {B} frames (>= 100 whatever --steps); kernel_ms_timed_region = "
+                                          f"events around the {args.steps} timed steps; kernel_ms_single_launch = own event "
+                                          f"pair per launch",
                          "algorithmic_bytes_per_launch": int(algo_bytes),
                          "valu_issue": valu,
                          "single_frame_launch": None if one_ms is None else {
@@ -454,19 +607,27 @@ def main():
                              "four_streams_frac": round(W * H * bytes_per_px / (one_ms_4s * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
             "rccl_ranks": world if (world > 1 and backend == "nccl") else 0,
             "collective_backend": None if world == 1 else backend,
+            "per_rank_ms": [round(v, 4) for v in per_rank_ms],
             "frames_checksummed": sum(len(r) for r in all_sums),
             "checksums_match_golden": match,
         }
         if not args.no_cpu_baseline and args.workload == "420-rgb" and world == 1:  # host baseline: rank 0 at N=1 only
-            if first_planes is None:
-                first_planes = [d_planes[c][:plane_elems[c]].cpu().numpy() for c in range(3)]
-            res["cpu_baseline"] = cpu_baseline(first_planes, qts)
+            nf = 2 if args.legacy_data else min(8, S)
+            cpu_frames = [[d_planes[c][j * plane_elems[c]:(j + 1) * plane_elems[c]].cpu().numpy() for c in range(3)]
+                          for j in range(nf)]
+            res["cpu_baseline"] = cpu_baseline(cpu_frames, qts)
+            del cpu_frames
             res["from_files"] = from_files(zj, ctx)
+        if not args.no_e2e and args.workload == "420-rgb" and world == 1:
+            gsums = [int(x, 16) for x in golden["rgb"][lo:lo + 8]] if golden else None
+            res["e2e_pinned"] = e2e_pinned(zj, ctx, desc, d_planes, plane_elems, frame_out, gsums, nb=min(8, S))
+        if gather_rgb is not None:
+            res["gather_rgb"] = gather_rgb
         print(json.dumps(res), flush=True)
     shard.barrier(world)
     ctx.close()
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -25,8 +25,12 @@ def _worker(rank, world, port, nframes, q):
     shard = importlib.import_module("zune-jpeg_amd.shard")
     synth = importlib.import_module("zune-jpeg_amd.synth")
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    shard.init_process_group("gloo", rank, world)
+    if isinstance(port, str):   # a path: the race-free rendezvous of bench.py's self-launcher (rank 0 binds port 0)
+        os.environ.pop("MASTER_PORT", None)
+        shard.init_process_group("gloo", rank, world, port_file=port, timeout_s=60)
+    else:
+        os.environ["MASTER_PORT"] = str(port)
+        shard.init_process_group("gloo", rank, world)
     lo, hi = shard.shard_range(nframes, rank, world)
     sums = []
     for i in range(lo, hi):
@@ -39,10 +43,19 @@ def _worker(rank, world, port, nframes, q):
     total = shard.sum_over_ranks(hi - lo, world)
     pad = sums + [0] * (3 - len(sums))
     allsums = shard.gather_checksums(pad, world)
-    q.put((rank, lo, hi, elapsed, total, allsums))
+    per_rank = shard.gather_values(10.0 + rank, world)
+    import torch
+    frames = torch.full((1000,), 7 + rank, dtype=torch.uint8)
+    outs, secs = shard.gather_frames(frames, rank, world)
+    got = None if outs is None else [int(o[0]) for o in outs]
+    q.put((rank, lo, hi, elapsed, total, allsums, per_rank, got))
 
 
-def test_two_rank_shard_and_gather():
+import pytest
+
+
+@pytest.mark.parametrize("rendezvous", ["port", "port_file"])
+def test_two_rank_shard_and_gather(rendezvous, tmp_path):
     shard = importlib.import_module("zune-jpeg_amd.shard")
     synth = importlib.import_module("zune-jpeg_amd.synth")
     import oracle_c as oc
@@ -51,7 +64,7 @@ def test_two_rank_shard_and_gather():
     nframes, world = 5, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
+    port = _free_port() if rendezvous == "port" else str(tmp_path / "port")
     procs = [ctx.Process(target=_worker, args=(r, world, port, nframes, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -64,7 +77,9 @@ def test_two_rank_shard_and_gather():
         planes, qts = synth.make_frame(64, 32, 2, 2, 3, seed=500, frame_index=i)
         rc, out = oc.decode_planes(oc.make_frame(64, 32, 2, 2, 3, oc.RGB, qts), planes)
         expect.append(shard.frame_checksum(out))
-    for rank, lo, hi, elapsed, total, allsums in res:
+    for rank, lo, hi, elapsed, total, allsums, per_rank, got in res:
+        assert per_rank == [10.0, 11.0]  # per-rank values on every rank (bench.py's per_rank_ms)
+        assert got == ([7, 8] if rank == 0 else None)   # the frame gather lands on rank 0 only
         assert elapsed == 2.0            # MAX over ranks
         assert total == nframes          # every frame decoded exactly once
         flat = allsums[0][:3] + allsums[1][:2]
@@ -77,7 +92,6 @@ def test_bench_self_launch_fails_loudly_without_a_gpu():
     rank's failure as a non-zero exit; without a GPU every rank refuses to run (no CPU fallback)."""
     import subprocess
     import sys
-    import pytest
     import torch
     if torch.cuda.is_available():
         pytest.skip("GPU present: covered by tests/test_gpu_bench.py")
@@ -113,3 +127,20 @@ def test_golden_checksum_comparison_has_teeth():
     assert bench.golden_match(swapped, S, g) is False
     assert bench.golden_match(good[::-1], S, g) is False
     assert bench.golden_match([], S, g) is None
+
+
+def test_bench_self_launch_ends_hung_ranks():
+    """A rank that never reaches the rendezvous (here: every rank, by the test knob) must not cost the caller its whole
+    time budget: after --rank-timeout the launcher names the ranks still alive, terminates them and exits with 124."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["ZJ_BENCH_TEST_HANG_RANK"] = "all"
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--rank-timeout", "3"],
+                       capture_output=True, timeout=120, env=env)
+    assert r.returncode == 124, r.stderr.decode()[-500:]
+    assert time.monotonic() - t0 < 30
+    assert b"rank(s) [0, 1] still running" in r.stderr and not r.stdout.strip()

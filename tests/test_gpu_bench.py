@@ -28,6 +28,22 @@ def test_two_self_launched_ranks_decode_their_shards_to_the_golden_checksums():
     assert res["n_gpus"] == 2 and res["frames_checksummed"] == 64 and res["config"]["frames_total"] == 64
     assert res["checksums_match_golden"] is True
     assert res["collective_backend"] == "gloo" and res["rccl_ranks"] == 0     # same-GPU plumbing run: no RCCL
+    assert len(res["per_rank_ms"]) == 2 and all(v > 0 for v in res["per_rank_ms"])
+    assert max(res["per_rank_ms"]) <= res["ms_per_step"] * 1.001                # the line's time is the MAX over ranks
+
+
+@pytest.mark.gpu
+def test_a_hung_rank_ends_the_self_launched_run_quickly():
+    """Rank 1 never reaches the rendezvous (test knob); rank 0 waits for it inside init_process_group.  The launcher must
+    give up after --rank-timeout, say which ranks were alive, and exit non-zero -- in well under 30 s here."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update({"ZJ_BENCH_SAME_GPU": "1", "ZJ_BENCH_TEST_HANG_RANK": "1"})
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--shard-frames", "16",
+                        "--rank-timeout", "8"], capture_output=True, timeout=300, env=env)
+    assert r.returncode != 0 and time.monotonic() - t0 < 30
+    assert b"still running" in r.stderr and not [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
 
 
 @pytest.mark.gpu
@@ -39,3 +55,8 @@ def test_single_rank_line_has_the_contract_fields():
     assert rf["bound"] == "hbm" and rf["algorithmic_bytes_per_launch"] == 16 * 4096 * 4096 * 6
     assert rf["single_frame_launch"]["kernel_ms"] > 0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["kernel_launches_timed"] >= 100                       # whatever --steps says
+    assert res["per_rank_ms"] == [res["ms_per_step"]] or abs(res["per_rank_ms"][0] - res["ms_per_step"]) < 0.01
+    e = res["e2e_pinned"]
+    assert "error" not in e, e
+    assert e["megapixels_per_s"] > 1000 and e["last_frame_matches_golden"] is True
