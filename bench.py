@@ -384,7 +384,8 @@ def main():
         import tempfile
         port_file = os.path.join(tempfile.mkdtemp(prefix="zj_bench_"), "port")  # N = 1 plumbing run of the frame gather
     shard.init_process_group(backend, rank, world, force=args.gather_rgb and not args.child, port_file=port_file,
-                             timeout_s=args.rank_timeout, device_id=None if same_gpu else dev)
+                             timeout_s=args.rank_timeout + 60,  # the launcher's deadline (rank_timeout) comes first and names the ranks
+                             device_id=None if same_gpu else dev)
     coll_dev = "cpu" if same_gpu else dev
 
     B = args.frames

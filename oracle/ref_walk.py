@@ -66,27 +66,47 @@ def _canonical(counts, vals):
     return table
 
 
+_M64 = (1 << 64) - 1
+
+# statistics of the last walk: DC symbols read short, and how many of those picked up STALE bits (see _Reader.get)
+# "first_marker_block": index (in decode order) of the first block whose decoding began with a marker already in the
+# reader's view, i.e. from which on the reference may serve bits it does not hold (None: never)
+last_stats = {"short": 0, "stale": 0, "first_marker_block": None}
+
+
 class _Reader:
-    """src/bitstream.rs BitStream: `buffer`/`bits_left` bookkeeping and the marker logic of refill()"""
+    """src/bitstream.rs BitStream, LITERALLY: `buffer` (u64, :105), `aligned_buffer` (u64, :109), `bits_left` (u8, :117)
+    and the marker logic of refill().  aligned_buffer is recomputed from `buffer` only by a real refill (:231, :248, :196);
+    between refills drop_bits shifts it (zeros enter at the bottom, :386-390) and get_bits ROTATES it (:394-402): the
+    magnitude bits a get_bits hands out re-enter at the bottom of aligned_buffer and stay there, below the
+    (64 - bits_left after the last refill) zero bits the refill left under the valid data, moving up with every later
+    drop / get.  A read that wants more bits than bits_left holds (the short DC read, :278) is served from there: zeros
+    first, then those stale magnitude bits (round 4; rounds 2-3 modelled zeros only -- right for 98.8 % of the short reads
+    of random streams, wrong when an AC refill at bits_left near 32 left a gap of few zero bits)."""
 
     def __init__(self, buf, pos):
-        self.buf, self.pos, self.buffer, self.bl, self.marker = buf, pos, 0, 0, None
+        self.buf, self.pos, self.buffer, self.aligned, self.bl, self.marker = buf, pos, 0, 0, 0, None
+        self.clean = 64  # model bookkeeping (not reference state): low bits of `aligned` known to be refill zeros
 
     def _byte(self):  # read_u8 (:689-703): zeros past the end
         v = self.buf[self.pos] if self.pos < len(self.buf) else 0
         self.pos += 1
         return v
 
+    def _realign(self):  # self.aligned_buffer = self.buffer << (64 - self.bits_left)
+        self.aligned = (self.buffer << (64 - self.bl)) & _M64
+
     def refill(self):
         if self.bl <= 32 and self.marker is None:
             if self.pos + 4 < len(self.buf) and 0xFF not in self.buf[self.pos:self.pos + 4]:  # :220-236
-                self.buffer = (self.buffer << 32) | int.from_bytes(self.buf[self.pos:self.pos + 4], "big")
+                self.buffer = ((self.buffer << 32) | int.from_bytes(self.buf[self.pos:self.pos + 4], "big")) & _M64
                 self.pos += 4
                 self.bl += 32
+                self._realign()
                 return
             for _ in range(4):  # the refill! macro, :168-213
                 b = self._byte()
-                self.buffer = (self.buffer << 8) | b
+                self.buffer = ((self.buffer << 8) | b) & _M64
                 self.bl += 8
                 if b == 0xFF:
                     n = self._byte()
@@ -96,35 +116,46 @@ class _Reader:
                         if n != 0:
                             self.buffer >>= 8
                             self.bl -= 8
+                            if self.bl != 0:  # :193-197
+                                self._realign()
                             self.marker = n
                             return
-        elif self.marker is not None:  # :254-258: zeros from here on
-            if self.bl < 63:
-                self.buffer <<= 63 - self.bl
+            self._realign()
+        elif self.marker is not None:  # :254-258: bits_left = 63, aligned_buffer stays as it is
             self.bl = 63
 
-    def peek(self, n):
-        if self.bl >= n:
-            return (self.buffer >> (self.bl - n)) & ((1 << n) - 1)
-        return (self.buffer << (n - self.bl)) & ((1 << n) - 1)
+    def peek(self, n):  # peek_bits::<n> (:378-382)
+        return self.aligned >> (64 - n)
 
-    def drop(self, n):  # drop_bits / get_bits: saturating_sub on bits_left, zeros shift in
-        if n > self.bl:
-            self.buffer <<= n - self.bl
-            self.bl = n
-        self.bl -= n
-        self.buffer &= (1 << self.bl) - 1
+    def drop(self, n):  # drop_bits (:386-390)
+        self.bl = max(0, self.bl - n)
+        self.aligned = (self.aligned << n) & _M64
+
+    def get(self, n):  # get_bits (:394-402)
+        self.aligned = ((self.aligned << n) | (self.aligned >> (64 - n))) & _M64
+        self.bl = max(0, self.bl - n)
+        return self.aligned & ((1 << n) - 1)
 
     def symbol(self, table):
+        # decode_huff! (:49-86) resolves a code from the top 16 bits of aligned_buffer; every symbol decode is preceded by
+        # a refill that leaves at least 16 valid bits there (or by the marker's zeros), so for the canonical tables of a
+        # well-formed stream this is the first (length, code) of the prefix-free set found in those bits
         for length in range(1, 17):
             c = self.peek(length)
             if (length, c) in table:
                 self.drop(length)
+                self.last_len = length
                 return table[(length, c)]
         raise ValueError("bad Huffman code")
 
     def reset(self):  # :671-678
-        self.buffer, self.bl, self.marker = 0, 0, None
+        self.buffer, self.aligned, self.bl, self.marker = 0, 0, 0, None
+
+
+def _zero_model_bits(s, size):
+    """what rounds 2-3 assumed a short read yields: the bits held, zeros below"""
+    have = min(s.bl, size)
+    return ((s.aligned >> (64 - have)) << (size - have)) if have else 0
 
 
 _UNZ = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
@@ -176,7 +207,7 @@ def _walk(jpeg_bytes, values):
     s = _Reader(jpeg_bytes, j["start"])
     todo = j["ri"] if j["ri"] else 1 << 62
     loops = []  # MCUs decoded by every pass of the `for j in 0..mcu_width` loop
-    planes, pred, short = None, [0] * ncomp, 0
+    planes, pred, short, stale, nblk, first_marker = None, [0] * ncomp, 0, 0, 0, None
     if values:
         planes = [np.zeros((mcu_y * c[2], mcu_x * c[1], 64), np.int16) for c in j["comps"]]
     mcu = 0  # MCUs are coded in raster order whatever the loop shape (mcu.rs:145-152 only reshapes the loops)
@@ -189,15 +220,20 @@ def _walk(jpeg_bytes, values):
                 for ci, (cid, h, v) in enumerate(j["comps"]):
                     td, ta = j["sel"][cid]
                     for b in range(h * v):
+                        if s.marker is not None and first_marker is None:
+                            first_marker = nblk
+                        nblk += 1
                         if s.bl < 16:
                             s.refill()
                         size = s.symbol(tabs[(0, td)])
                         if size:
-                            if values:
-                                if s.bl < size and s.marker is None:
-                                    short += 1
-                                pred[ci] = (pred[ci] + _extend(s.peek(size), size)) & 0xFFFFFFFF  # wrapping_add on i32
-                            s.drop(size)
+                            is_short = s.bl < size and s.marker is None
+                            zero_bits = _zero_model_bits(s, size) if is_short else None
+                            bits = s.get(size)
+                            if is_short:
+                                short += 1
+                                stale += bits != zero_bits
+                            pred[ci] = (pred[ci] + _extend(bits, size)) & 0xFFFFFFFF  # wrapping_add on i32
                         if values:
                             blk = planes[ci][my * v + b // h, mx * h + b % h]
                             blk[:] = 0
@@ -209,10 +245,17 @@ def _walk(jpeg_bytes, values):
                             r, size = rs >> 4, rs & 15
                             if size:
                                 pos += r
+                                if s.last_len + size <= 9:
+                                    # the fast-AC table (src/huffman.rs:186-243, src/bitstream.rs:339-347) holds every
+                                    # code + magnitude that fits the 9 look-ahead bits: ONE drop_bits for both, zeros
+                                    # enter aligned_buffer; only the general path (:350-362) rotates with get_bits
+                                    bits = s.peek(size)
+                                    s.drop(size)
+                                else:
+                                    bits = s.get(size)
                                 if values:
-                                    blk[_UNZ[pos & 63]] = _extend(s.peek(size), size)
+                                    blk[_UNZ[pos & 63]] = _extend(bits, size)
                                 pos += 1
-                                s.drop(size)
                             elif r != 15:
                                 break
                             else:
@@ -237,6 +280,7 @@ def _walk(jpeg_bytes, values):
     else:
         for i, n in enumerate(loops):
             rows[i] = n
+    last_stats["short"], last_stats["stale"], last_stats["first_marker_block"] = short, stale, first_marker
     return rows, ([p.reshape(-1) for p in planes] if values else None), short
 
 
@@ -288,6 +332,7 @@ def decode_progressive_dc_first(jpeg_bytes):
     out = [np.zeros((mcu_y * c[2], mcu_x * c[1]), np.int16) for c in comps]
     s = _Reader(buf, start)
     pred, short = [0] * len(comps), 0
+    last_stats["stale"] = 0
     todo = ri if ri else 1 << 62
 
     def dc(ci, td):
@@ -296,10 +341,13 @@ def decode_progressive_dc_first(jpeg_bytes):
             s.refill()
         size = s.symbol(dht[(0, td)])
         if size:
-            if s.bl < size and s.marker is None:
+            is_short = s.bl < size and s.marker is None
+            zero_bits = _zero_model_bits(s, size) if is_short else None
+            bits = s.get(size)
+            if is_short:
                 short += 1
-            pred[ci] = (pred[ci] + _extend(s.peek(size), size)) & 0xFFFFFFFF
-            s.drop(size)
+                last_stats["stale"] += bits != zero_bits
+            pred[ci] = (pred[ci] + _extend(bits, size)) & 0xFFFFFFFF
         return np.int16(np.uint16((pred[ci] << al) & 0xFFFF))       # (dc_pred as i16).wrapping_mul(1 << al), :413
 
     def rst():
@@ -330,4 +378,5 @@ def decode_progressive_dc_first(jpeg_bytes):
                         for hh in range(comps[ci][1]):
                             out[ci][my * comps[ci][2] + v, mx * comps[ci][1] + hh] = dc(ci, td)
                 rst()
+    last_stats["short"] = short
     return out, short

@@ -162,6 +162,28 @@ extern "C" void zje_idct_wide(const int16_t* coeff, size_t nblocks, const int32_
 }
 extern "C" int zje_guard_limit(void) { return GUARD_LIMIT; }
 
+// tile_from_id's division by a launch constant (magic_u31 / magic_div): quotients of n[0..count) by d, and the first n
+// of an exhaustive sweep [lo, hi) where it disagrees with `/` (-1: none)
+extern "C" void zje_magic_div(uint32_t d, const uint32_t* n, size_t count, uint32_t* q)
+{
+    const Magic g = magic_u31(d);
+    for (size_t i = 0; i < count; i++) q[i] = magic_div(n[i], g);
+}
+extern "C" long long zje_magic_sweep(uint32_t d, uint32_t lo, uint32_t hi)
+{
+    const Magic g = magic_u31(d);
+    for (uint32_t n = lo; n < hi; n++)
+        if (magic_div(n, g) != n / d) return (long long)n;
+    return -1;
+}
+extern "C" void zje_tile_from_id(int nframes, int n_strips, int tiles_per_row, int id, int out[3])
+{
+    Params p;
+    set_grid(p, nframes, n_strips, tiles_per_row);
+    const TileId t = tile_from_id(p, id);
+    out[0] = t.frame; out[1] = t.strip; out[2] = t.tile;
+}
+
 // ---- the GPU entropy stage (zj_huff_device.h), thread by thread -----------------------------------------------------
 #include "../../zune-jpeg_amd/csrc/zj_huff_device.h"
 

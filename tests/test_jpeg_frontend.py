@@ -354,6 +354,57 @@ def test_reference_reads_long_dc_symbols_short_and_so_does_the_front_end(zj):
     assert hit >= 1 and clean >= 10, (hit, clean)
 
 
+def test_short_dc_read_picks_up_stale_rotated_bits(zj, synth):
+    """the reference's get_bits ROTATES aligned_buffer (src/bitstream.rs:394-402), so the magnitude bits it has
+    handed out since the last real refill lie below the zeros that refill left, and a short DC read that reaches past those
+    zeros is served stale magnitude bits, not zeros.  It takes a refill at bits_left near 32 (a gap of few zeros), a short
+    code right behind it whose magnitude goes through get_bits (code + magnitude > 9 bits: not in the fast-AC table), no
+    further refill, and a DC symbol far longer than what is left: hand-made Huffman tables (tools/jpeg_enc.py
+    canonical_tables) with a 16-bit code for DC category 11 and 2..6-bit codes for (run, size 10) AC symbols build that
+    on purpose.  The front-end must produce the literal reader model's coefficients -- and not the zeros-only ones -- in
+    every block decoded before the end marker comes into the reader's view."""
+    ac_len = {0xFA: 2, 0x0A: 2, 0xFF: 3, 0xEA: 4, 0x0F: 4, 0x00: 5, 0x3A: 5, 0x7A: 6, 0x01: 6, 0xF0: 7}
+    dc_len = {0: 1, 11: 16, 2: 2, 6: 3}
+    tabs = jpeg_enc.canonical_tables(dc_len, ac_len)
+    zz = jpeg_enc.ZIGZAG
+    stale_files = 0
+    for seq in ([0xFA, 0xFA, 0xEA, 0x7A, 0x7A], [0xFA, 0xFA, 0x7A, 0xEA, 0x7A], [0xFA, 0x0A, 0xEA, 0xEA, 0xFF]):
+        nb = 12                                   # one row of 12 blocks: the event in blocks 0/1, real data behind it
+        p = np.zeros((nb, 64), np.int16)
+        p[0, 0] = 40                              # category 6
+        pos = 1
+        for sym in seq:                           # block 0 ends at coefficient 63 without an EOB
+            pos += sym >> 4
+            sz = sym & 15
+            p[0, zz[pos]] = (1 << sz) - 1 if sz < 15 else 32767   # all-ones magnitudes: the stale bits are ones
+            pos += 1
+        p[1, 0] = p[0, 0] + 1500                  # category 11 behind it: 16 + 11 bits, the reader holds 17..23
+        for b in range(2, nb):                    # plain blocks: something real to go on parsing (garbled, but real bits)
+            p[b, 0] = p[b - 1, 0] + (40 if b % 2 else -40)
+            p[b, zz[1]], p[b, zz[2]] = 600, -700
+        data = jpeg_enc.encode_baseline([p.reshape(-1)], [synth.quant_tables(85)[0]], 8 * nb, 8, 1, 1, 1, tables=tabs)
+        try:
+            want, short, rows = ref_walk.decode_baseline_planes(data)
+        except ValueError:
+            want = None
+        st = dict(ref_walk.last_stats)
+        assert st["short"] >= 1 and st["stale"] >= 1, (seq, st)
+        stale_files += 1
+        try:
+            desc, got, info = zj.Decoder(_opts(zj, 1)).decode_coefficients(data)
+        except zj.DecodeError:
+            assert want is None, seq              # only if the literal reader ends in a bad code as well
+            continue
+        assert want is not None, seq
+        g = np.array(got[0], np.int16).reshape(-1, 64)
+        w_ = want[0].reshape(-1, 64)
+        upto = st["first_marker_block"] if st["first_marker_block"] is not None else nb
+        assert upto >= 2, (seq, st)
+        assert np.array_equal(g[:upto], w_[:upto]), (seq, st, [int(x) for x in g[:upto, 0]], [int(x) for x in w_[:upto, 0]])
+        assert int(g[1, 0]) != 40 + 1024          # 1064 = what zeros below the held bits would give (rounds 2-3)
+    assert stale_files == 3
+
+
 def _first_scan_only(data):
     """a progressive file cut behind its first scan (+ EOI): what the front-end holds after that scan alone"""
     sos = data.index(b"\xff\xda")

@@ -58,7 +58,35 @@ def _ac_code(sym):   # 256 symbols: 255 nine-bit codes + one ten-bit code (a cou
     return (sym, 9) if sym < 255 else (510, 10)
 
 
-def _dht_segment():
+def canonical_tables(dc_lengths, ac_lengths):
+    """Custom Huffman tables for encode_baseline(tables=...): {symbol: code length} per class -> canonical codes
+    (T.81 Annex C) and the DHT payload.  The same tables serve every component.  For tests that need particular code
+    lengths (e.g. a 16-bit DC code in front of 11 magnitude bits)."""
+    out = {}
+    for name, lens in (("dc", dc_lengths), ("ac", ac_lengths)):
+        order = sorted(lens, key=lambda sym: (lens[sym], sym))
+        counts = [0] * 16
+        codes, code, prev = {}, 0, 0
+        for sym in order:
+            length = lens[sym]
+            code <<= length - prev
+            prev = length
+            assert code < (1 << length) - 1 or (length == 16 and code < (1 << 16) - 1), "all-ones code / over-subscribed lengths"
+            codes[sym] = (code, length)
+            counts[length - 1] += 1
+            code += 1
+        out[name] = {"codes": codes, "counts": counts, "symbols": order}
+    return out
+
+
+def _dht_segment(tables=None):
+    if tables is not None:
+        seg = bytearray()
+        for cls, name in ((0, "dc"), (1, "ac")):
+            t = tables[name]
+            for idx in (0, 1):
+                seg += bytes([(cls << 4) | idx]) + bytes(t["counts"]) + bytes(t["symbols"])
+        return b"\xff\xc4" + struct.pack(">H", len(seg) + 2) + bytes(seg)
     seg = bytearray()
     for cls, nsym, length in ((0, 16, 5), (1, 256, 9)):
         counts = [0] * 16
@@ -76,7 +104,7 @@ def _geometry(w, h, hs, vs):
     return mcu_x, mcu_y
 
 
-def _headers(w, h, hs, vs, ncomp, qts, progressive, restart):
+def _headers(w, h, hs, vs, ncomp, qts, progressive, restart, tables=None):
     out = bytearray(b"\xff\xd8")
     out += b"\xff\xe0" + struct.pack(">H", 16) + b"JFIF\x00\x01\x01\x00\x00\x01\x00\x01\x00\x00"
     ntab = 1 if ncomp == 1 else 2
@@ -87,7 +115,7 @@ def _headers(w, h, hs, vs, ncomp, qts, progressive, restart):
     for c in range(ncomp):
         samp = (hs << 4) | vs if c == 0 else 0x11
         out += bytes([c + 1, samp, 0 if c == 0 else 1])
-    out += _dht_segment()
+    out += _dht_segment(tables)
     if restart:
         out += b"\xff\xdd" + struct.pack(">HH", 4, restart)
     return out
@@ -141,9 +169,11 @@ def _emit_restart(bw, count):
     bw.out += bytes([0xFF, 0xD0 + (count & 7)])
 
 
-def encode_baseline(planes, qts, w, h, hs=1, vs=1, ncomp=3, restart=0):
+def encode_baseline(planes, qts, w, h, hs=1, vs=1, ncomp=3, restart=0, tables=None):
     P = _Planes(planes, w, h, hs, vs, ncomp)
-    out = _headers(w, h, hs, vs, ncomp, qts, False, restart)
+    out = _headers(w, h, hs, vs, ncomp, qts, False, restart, tables)
+    dc_code = (lambda sym: tables["dc"]["codes"][sym]) if tables else _dc_code
+    ac_code = (lambda sym: tables["ac"]["codes"][sym]) if tables else _ac_code
     out += _sos(list(range(ncomp)), 0, 63, 0, 0)
     bw = BitWriter()
     pred = [0] * ncomp
@@ -158,7 +188,7 @@ def encode_baseline(planes, qts, w, h, hs=1, vs=1, ncomp=3, restart=0):
             diff = int(blk[0]) - pred[c]
             pred[c] = int(blk[0])
             s = _nbits(diff)
-            bw.put(*_dc_code(s))
+            bw.put(*dc_code(s))
             if s:
                 bw.put(diff if diff >= 0 else diff + (1 << s) - 1, s)
             run = 0
@@ -168,14 +198,14 @@ def encode_baseline(planes, qts, w, h, hs=1, vs=1, ncomp=3, restart=0):
                     run += 1
                     continue
                 while run > 15:
-                    bw.put(*_ac_code(0xF0))
+                    bw.put(*ac_code(0xF0))
                     run -= 16
                 s = _nbits(v)
-                bw.put(*_ac_code((run << 4) | s))
+                bw.put(*ac_code((run << 4) | s))
                 bw.put(v if v >= 0 else v + (1 << s) - 1, s)
                 run = 0
             if run:
-                bw.put(*_ac_code(0))
+                bw.put(*ac_code(0))
         n_mcu += 1
     bw.flush()
     return bytes(out) + bytes(bw.out) + b"\xff\xd9"

@@ -50,6 +50,9 @@ struct zj_ctx {
     int debug = 0;                // ablation switches, diagnostic build only (results are WRONG when set)
 #endif
     int variant = 0;              // kernel variant: 0 packed generation (default), 1 wide generation (round 1), 2 packed with direct stores
+    // first-wave stagger of short launches (zj_kernels.hip: stagger_start): workgroup slots of the device, delay per
+    // step, and the largest grid that still gets it
+    int stagger_wgs = 0, stagger_delay = 0, stagger_max_tiles = 0;
     // GPU entropy stage (zj_decode_scan): blob + working set, the three planes (contiguous), control words read back
     // one slot per scan of a batch (zj_decode_scans): blob + working set | planes | pixels on their way to host memory
     struct HuffSlot { void* buf = nullptr; size_t cap = 0; void* planes = nullptr; void* out = nullptr; };
@@ -161,6 +164,14 @@ zj_ctx* zj_ctx_create(int backend, int device, int* status)
     if (!c) { *status = ZJ_ERR_NOMEM; return nullptr; }
     c->device = device;
     if (const char* e = getenv("ZJ_VARIANT")) { int v = atoi(e); if (v >= 0 && v <= 2) c->variant = v; }
+    {
+        hipDeviceProp_t prop;
+        const int cus = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
+        c->stagger_wgs = cus * 6;                     // six workgroups of the fused kernels per CU (LDS, VGPRs)
+        c->stagger_max_tiles = 2 * c->stagger_wgs;
+        c->stagger_delay = 0;
+        if (const char* e = getenv("ZJ_STAGGER")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->stagger_delay = v; }
+    }
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
     if (!ok) { zj_ctx_destroy(c); *status = ZJ_ERR_NO_DEVICE; return nullptr; }
@@ -308,6 +319,7 @@ static int decode_device_impl(zj_ctx* c, const zj_frame_desc* d, const Plan& pl,
 #endif
     if (plane_stride) p.y_frame_stride = p.c_frame_stride = plane_stride;
     if (out_stride) p.out_frame_stride = out_stride;
+    if (c->stagger_delay > 0 && p.total_tiles <= c->stagger_max_tiles) { p.stagger_wgs = c->stagger_wgs; p.stagger_delay = c->stagger_delay; }
     const size_t ostride = out_stride ? (size_t)out_stride : pl.out_len;
     if (zero_fill) {
         // rows below the last complete strip are never written by the reference (Q6): zeros
@@ -485,9 +497,8 @@ static int decode_planes_batch_impl(zj_ctx* c, const zj_frame_desc* d, size_t nf
     p.debug = c->debug;
 #endif
             if (!whole) { // strips [s0, s1) of frame f0 as a frame of its own
-                p.n_strips = (int)(s1 - s0);
                 p.height = (int)d->height - (int)s0 * pl.strip_rows;
-                p.total_tiles = p.n_strips * pl.tiles_per_row;
+                set_grid(p, 1, (int)(s1 - s0), pl.tiles_per_row);
             }
             ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->variant, pl.fast ? 1 : 0, p, c->s_run));
             ZJ_HIP(c, hipEventRecord(sl.run_done, c->s_run));

@@ -709,6 +709,9 @@ struct Params {
     int nframes;
     int zero_fill;                // 1: also write the bytes the reference leaves 0 (Q5/Q6)
     int total_tiles;
+    uint32_t tpr_magic, tpr_shift; // magic_u31(tiles_per_row), magic_u31(n_strips): tile_from_id
+    uint32_t ns_magic, ns_shift;
+    int stagger_wgs, stagger_delay; // first-wave de-synchronisation (zj_kernels.hip: stagger_start); 0 = off
 #if defined(ZJ_ABLATION)
     int debug;                    // diagnostic build only (tools/ablate.py): 1 skip IDCT, 2 skip colour math, 4 no loads, 8 no stores
 #endif
@@ -742,13 +745,40 @@ ZJ_DEV void vrows(int m, int& ra, int& rb)
 
 struct TileId { int frame, strip, tile; };
 
+// Division of a workgroup id by a launch constant (tiles per row, strips per frame) as multiply-high + shift with a
+// host-computed multiplier: 5 scalar instructions where the compiler's expansion of `/` and `%` by a kernel argument is
+// a float-reciprocal sequence of ~35 scalar + 4 vector instructions (v_rcp, v_readfirstlane) -- twice, in every workgroup,
+// in front of the first load (profiles/r04_valu_ledger.txt).  Exact for every 0 <= n < 2^31 and 1 <= d < 2^30:
+// with l = ceil(log2 d) and m = floor(2^(31+l) / d) + 1 the error m*d - 2^(31+l) is in (0, d], so n * error < 2^(31+l).
+struct Magic { uint32_t m, s; };  // m == 0: d == 1
+inline Magic magic_u31(const uint32_t d)
+{
+    Magic g = {0, 0};
+    if (d <= 1) return g;
+    uint32_t l = 0;
+    while ((1ull << l) < d) l++;
+    g.m = (uint32_t)((1ull << (31 + l)) / d) + 1u;
+    g.s = l - 1;
+    return g;
+}
+ZJ_DEV uint32_t magic_div(const uint32_t n, const Magic g)
+{
+#if defined(ZJ_EMU)
+    return g.m ? (uint32_t)(((uint64_t)n * g.m) >> 32) >> g.s : n;
+#else
+    return g.m ? __umulhi(n, g.m) >> g.s : n;
+#endif
+}
+
 ZJ_DEV TileId tile_from_id(const Params& p, const int id)
 {
     TileId t;
-    t.tile = id % p.tiles_per_row;
-    const int r = id / p.tiles_per_row;
-    t.strip = r % p.n_strips;
-    t.frame = r / p.n_strips;
+    const Magic gt = {p.tpr_magic, p.tpr_shift}, gs = {p.ns_magic, p.ns_shift};
+    const uint32_t r = magic_div((uint32_t)id, gt);
+    t.tile = id - (int)r * p.tiles_per_row;
+    const uint32_t f = magic_div(r, gs);
+    t.strip = (int)r - (int)f * p.n_strips;
+    t.frame = (int)f;
     return t;
 }
 // XCD-aware order: hardware sends workgroup b to XCD b % 8; give each XCD a contiguous run of `n` units

@@ -113,8 +113,15 @@ struct BitReader {
     // into its view: refill() adds 32 when it is called with bits_left <= 32 (before every AC symbol) or < 16 (before a DC
     // symbol, :278).  It exists for one case only, ref_dc_misread() below.
     int rbl = 0;
+    // ... and what lies BELOW the valid bits in the reference's aligned_buffer (round 4).  A real refill leaves 64 - rbl0
+    // zero bits there (rbl0 = bits_left right after it); from then on drop_bits shifts zeros in at the bottom and
+    // get_bits ROTATES (src/bitstream.rs:394-402): the magnitude bits it hands out re-enter at the bottom.  rhist is that
+    // history as a shift register (newest at the bottom; a fast-AC symbol is one drop_bits, src/bitstream.rs:339-347): the
+    // low (rbl0 - bits_left) bits of it are what the reference holds under its zero gap.  Only ref_dc_misread() reads it.
+    int rbl0 = 0;
+    uint64_t rhist = 0;
     long long misreads = 0; // DC symbols the reference reads short (ref_dc_misread)
-    void reset() { acc = 0; nbits = 0; marker = 0; istart = p; mpos = nullptr; stuffed = 0; pad = 0; rbl = 0; }
+    void reset() { acc = 0; nbits = 0; marker = 0; istart = p; mpos = nullptr; stuffed = 0; pad = 0; rbl = 0; rbl0 = 0; rhist = 0; }
     // bits consumed since istart (zero padding included once the real bits are used up)
     long long consumed() const
     {
@@ -190,16 +197,22 @@ inline int32_t extend(int32_t v, int s) { return v < (1 << (s - 1)) ? v - (1 << 
 
 // ---- the reference's short read of long DC symbols (src/bitstream.rs:264-296) ---------------------------------------
 // decode_dc refills only when bits_left < 16, but a DC symbol is a code of up to 16 bits PLUS up to 11 (16) magnitude
-// bits.  With 16 <= bits_left < code + magnitude the reference decodes the code, then get_bits() rotates zeros into the
-// magnitude's low end (the buffer holds nothing below bits_left), bits_left saturates at 0 -- and the bits it did not
-// have are never skipped: the next refill continues right behind the last LOADED bit, so the rest of the magnitude is
-// parsed as the next symbol.  Everything after that is garbage, but it is the reference's garbage, and "same bytes as
-// the reference" includes it.  Standard tables reach 18 / 20 bits for |DC difference| >= 512 / 1024; in a baseline
-// scan the case needs the previous block to end in a symbol of 14 bits or more, in a progressive DC scan (nothing but
-// DC symbols, so bits_left wanders through 16..47) it is common once such differences occur.
-// Called after the DC code (`len` bits) has been dropped, with rbl already raised by the < 16 refill: true if the
-// reference reads the `s` magnitude bits short; then *bits is what it gets and the reader has consumed what it had.
-inline bool ref_dc_misread(BitReader& br, int& rbl, const int len, const int s, int32_t* bits)
+// bits.  With 16 <= bits_left < code + magnitude the reference decodes the code, then get_bits() rotates into the
+// magnitude's low end whatever aligned_buffer holds below its bits_left valid bits, bits_left saturates at 0 -- and the
+// bits it did not have are never skipped: the next refill continues right behind the last LOADED bit, so the rest of
+// the magnitude is parsed as the next symbol.  Everything after that is garbage, but it is the reference's garbage, and
+// "same bytes as the reference" includes it.  Standard tables reach 18 / 20 bits for |DC difference| >= 512 / 1024; in a
+// baseline scan the case needs the previous block to end in a symbol of 14 bits or more, in a progressive DC scan
+// (nothing but DC symbols, so bits_left wanders through 16..47) it is common once such differences occur.
+// What lies below the valid bits: the zeros the last real refill left (64 - rbl0 of them), then the history of every
+// drop_bits (zeros) and get_bits (the magnitude bits themselves, rotated in) since that refill -- BitReader::rhist.
+// Mostly the read ends inside the zeros; when the last refill came at bits_left near 32 (a gap of few zeros) and was
+// followed by a short code whose magnitude went through get_bits, it reaches that magnitude's stale bits (ADVICE r3;
+// tests/test_jpeg_frontend.py::test_short_dc_read_picks_up_stale_rotated_bits).
+// Called after the DC code (`len` bits) has been dropped and entered into `hist`, with rbl already raised by the < 16
+// refill: true if the reference reads the `s` magnitude bits short; then *bits is what it gets and the reader has
+// consumed what it had.
+inline bool ref_dc_misread(BitReader& br, int& rbl, const int rbl0, const uint64_t hist, const int len, const int s, int32_t* bits)
 {
     if (len + s <= rbl) return false;
     // rbl describes the reference only while it has not come across the marker that ends the interval (after that it
@@ -215,7 +228,11 @@ inline bool ref_dc_misread(BitReader& br, int& rbl, const int len, const int s, 
     const long long c_code_start = br.consumed() - len;
     if (c_code_start + rbl > data_bits) return false;
     const int avail = rbl - len; // 0 <= avail < s (len <= 16 <= rbl)
-    *bits = avail > 0 ? (int32_t)(br.peek(avail) << (s - avail)) : 0;
+    // the reference's aligned_buffer at this moment: `avail` valid bits, the refill's zeros, the history since the refill
+    const int nhist = rbl0 - avail; // bits consumed since the last real refill (the DC code included): 5 .. 64 - 16
+    uint64_t aligned = nhist > 0 && nhist < 64 ? hist & ((1ull << nhist) - 1) : 0;
+    if (avail > 0) aligned |= (uint64_t)br.peek(avail) << (64 - avail);
+    *bits = (int32_t)(aligned >> (64 - s));
     if (avail > 0) br.drop(avail);
     rbl = 0;
     br.misreads++;
@@ -551,30 +568,34 @@ int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, in
         const int16_t* src; int16_t* dst;
         ~Flush() { for (int i = 0; i < 8; i++) _mm_stream_si128((__m128i*)dst + i, _mm_load_si128((const __m128i*)src + i)); }
     } flush{blk, out};
-    int rbl = br.rbl; // the reference's bits_left (BitReader::rbl), in a register through the block
-    struct KeepRbl { BitReader& b; int& r; ~KeepRbl() { b.rbl = r < 0 ? 0 : r; } } keep{br, rbl};
+    int rbl = br.rbl, rbl0 = br.rbl0; // the reference's bits_left and its history (BitReader::rbl, rbl0, rhist), in
+    uint64_t hist = br.rhist;         // registers through the block
+    struct KeepRbl { BitReader& b; int& r; int& r0; uint64_t& h; ~KeepRbl() { b.rbl = r < 0 ? 0 : r; b.rbl0 = r0; b.rhist = h; } } keep{br, rbl, rbl0, hist};
     if (br.nbits < 32) br.fill();
     const int dc_before = br.nbits; // >= 32: decode() does not refill, the difference is the code's length
     int s = br.decode(hd);
     if (s < 0 || s > 16) { *err = "Bad Huffman code in DC"; return ZJ_ERR_HUFFMAN; }
     const int dc_len = dc_before - br.nbits;
-    if (rbl < 16) rbl += 32; // bitstream.rs:278
+    if (rbl < 16) { rbl += 32; rbl0 = rbl; } // bitstream.rs:278
+    hist <<= dc_len;                          // drop_bits(code)
     int32_t diff = 0, short_bits = 0;
     if (s) {
-        if (__builtin_expect(dc_len + s > rbl, 0) && ref_dc_misread(br, rbl, dc_len, s, &short_bits)) diff = extend(short_bits, s);
-        else { diff = extend(br.get(s), s); rbl -= dc_len + s; }
+        if (__builtin_expect(dc_len + s > rbl, 0) && ref_dc_misread(br, rbl, rbl0, hist, dc_len, s, &short_bits)) diff = extend(short_bits, s);
+        else { const int32_t mag = br.get(s); diff = extend(mag, s); rbl -= dc_len + s; hist = (hist << s) | (uint32_t)mag; } // get_bits rotates
     } else rbl -= dc_len;
     dc_pred = (int32_t)((uint32_t)dc_pred + (uint32_t)diff);
     blk[0] = (int16_t)dc_pred; // bitstream.rs:330
     for (int k = 1; k < 64;) {
         if (br.nbits < 32) br.fill(); // a code (<= 16 bits) and its magnitude bits (<= 15) without another refill
-        if (rbl <= 32) rbl += 32;     // the reference's refill before every AC symbol (bitstream.rs:334)
+        if (rbl <= 32) { rbl += 32; rbl0 = rbl; } // the reference's refill before every AC symbol (bitstream.rs:334)
         const uint32_t look9 = br.peek(9);
         const int16_t fa = ha.fast[look9];
-        if (fa) { // short code + small value: run, magnitude and sign from one table entry
+        if (fa) { // short code + small value: run, magnitude and sign from one table entry -- in the reference too
+                  // (src/huffman.rs:186-243 fills its fast_ac by the same rule: code + magnitude <= 9 bits), ONE drop_bits
             k += (fa >> 4) & 15;
             br.drop(fa & 15);
             rbl -= fa & 15;
+            hist <<= fa & 15;
             if (TRACK) br.last_sym = fa & 15;
             blk[kUnZigzag[k & 63]] = (int16_t)(fa >> 8);
             k++;
@@ -582,12 +603,13 @@ int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, in
         }
         int rs;
         const uint16_t e = ha.look[look9];
-        if (e) { br.drop(e >> 8); rbl -= e >> 8; if (TRACK) br.last_sym = e >> 8; rs = e & 0xff; }
+        if (e) { br.drop(e >> 8); rbl -= e >> 8; hist <<= e >> 8; if (TRACK) br.last_sym = e >> 8; rs = e & 0xff; }
         else {
             const int before = br.nbits; // >= 32 here: decode() does not refill, the difference is the code's length
             rs = br.decode(ha);
             if (rs < 0) { *err = "Bad Huffman code in AC"; return ZJ_ERR_HUFFMAN; }
             rbl -= before - br.nbits;
+            hist <<= before - br.nbits;
             if (TRACK) br.last_sym = before - br.nbits;
         }
         const int r = rs >> 4, sz = rs & 15;
@@ -596,6 +618,7 @@ int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, in
             const int32_t bits = (int32_t)br.peek(sz);
             br.drop(sz);
             rbl -= sz;
+            hist = (hist << sz) | (uint32_t)bits; // the general path reads the magnitude with get_bits: it rotates back in
             if (TRACK) br.last_sym += sz;
             // EXTEND (T.81 F.2.2.1) without a branch: values below 2^(sz-1) are negative
             const int32_t v = bits + ((((bits - (1 << (sz - 1))) >> 31)) & (1 - (1 << sz)));
@@ -845,11 +868,12 @@ int dc_first(zj_decoder* d, BitReader& br, Comp& cm, int16_t* blk)
     if (s < 0 || s > 16) return fail(d, ZJ_ERR_HUFFMAN, "Bad Huffman code in DC");
     const int len = before - br.nbits;
     // a DC scan is nothing but decode_dc calls (bitstream.rs:407-415 -> :264): bits_left is refilled below 16 only
-    if (br.rbl < 16) br.rbl += 32;
+    if (br.rbl < 16) { br.rbl += 32; br.rbl0 = br.rbl; }
+    br.rhist <<= len;
     int32_t diff = 0, short_bits = 0;
     if (s) {
-        if (len + s > br.rbl && ref_dc_misread(br, br.rbl, len, s, &short_bits)) diff = extend(short_bits, s);
-        else { diff = extend(br.get(s), s); br.rbl -= len + s; }
+        if (len + s > br.rbl && ref_dc_misread(br, br.rbl, br.rbl0, br.rhist, len, s, &short_bits)) diff = extend(short_bits, s);
+        else { const int32_t mag = br.get(s); diff = extend(mag, s); br.rbl -= len + s; br.rhist = (br.rhist << s) | (uint32_t)mag; }
     } else br.rbl -= len;
     cm.dc_pred = (int32_t)((uint32_t)cm.dc_pred + (uint32_t)diff);
     blk[0] = (int16_t)((uint16_t)(int16_t)cm.dc_pred * (uint16_t)(1u << d->al)); // bitstream.rs:413

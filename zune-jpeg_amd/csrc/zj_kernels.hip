@@ -54,6 +54,18 @@ __device__ __forceinline__ void tile_wide(const Params& p, const TileId t, const
     phase_color<C, HS, VS, OUT, GEN_WIDE, FAST>(p, t, tid, lds);
 }
 
+// The workgroups of a launch's FIRST wave (one per occupancy slot of the chip) all start in the same cycle and would move
+// through load / transform / colour / store in lock step: memory idles while they compute and the SIMDs idle while they
+// load.  In a long launch that synchrony dissolves after a tile or two; a launch of ONE frame (2048 tiles on 1536 slots)
+// never gets that far (profiles/r03_ab_history.txt: 25 us against 18 us per frame in a batch).  Here the k-th workgroup of
+// every slot group waits k * delay before its first load, so that the six workgroups sharing a CU start a phase apart.
+__device__ __forceinline__ void stagger_start(const Params& p, const int bid)
+{
+    if (p.stagger_delay <= 0 || bid >= p.stagger_wgs) return; // uniform
+    const int k = bid / (p.stagger_wgs / 6);                  // 0..5: the dispatcher fills the CUs round-robin
+    for (int i = 0; i < k * p.stagger_delay; i++) __builtin_amdgcn_s_sleep(8); // ~512 cycles = 0.21 us per step
+}
+
 template <int HS, int VS, int OUT, int GEN, bool FAST, bool TS>
 // launch bounds: see ZJ_WAVES_PER_SIMD / ZJ_WAVES_PER_SIMD_PACKED above
 __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAVES_PER_SIMD_PACKED : ZJ_WAVES_PER_SIMD)) void zj_fused_kernel(const Params p)
@@ -62,6 +74,7 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAV
     __shared__ __attribute__((aligned(16))) char lds[GEN == GEN_PACKED ? C::LDS_PACKED : C::LDS_WIDE];
     const TileId t = decode_tile(p, (int)blockIdx.x);
     const int tid = (int)threadIdx.x;
+    stagger_start(p, (int)blockIdx.x);
     if (GEN == GEN_WIDE) { tile_wide<C, HS, VS, OUT, FAST>(p, t, tid, lds); return; }
     // luma enters arithmetic for the RGB family only; gray / YCbCr outputs keep its low byte (Q7)
     constexpr bool NEED_Y16 = OUT == OUT_RGB || OUT == OUT_RGBA || OUT == OUT_RGB_CHW;

@@ -132,6 +132,16 @@ inline int uncovered_ranges(const zj_frame_desc* d, const Plan& pl, size_t off[3
     return 1;
 }
 
+// the launch grid: nframes x n_strips x tiles_per_row workgroups, and the multipliers tile_from_id divides with
+inline void set_grid(Params& p, int nframes, int n_strips, int tiles_per_row)
+{
+    p.nframes = nframes; p.n_strips = n_strips; p.tiles_per_row = tiles_per_row;
+    p.total_tiles = nframes * n_strips * tiles_per_row;
+    const Magic gt = magic_u31((uint32_t)(tiles_per_row > 0 ? tiles_per_row : 1)), gs = magic_u31((uint32_t)(n_strips > 0 ? n_strips : 1));
+    p.tpr_magic = gt.m; p.tpr_shift = gt.s; p.ns_magic = gs.m; p.ns_shift = gs.s;
+    p.stagger_wgs = p.stagger_delay = 0;
+}
+
 inline void fill_params(const zj_frame_desc* d, const Plan& pl, size_t nframes, const int16_t* y,
                         const int16_t* cb, const int16_t* cr, uint8_t* out, int zero_fill, Params& p)
 {
@@ -143,9 +153,8 @@ inline void fill_params(const zj_frame_desc* d, const Plan& pl, size_t nframes, 
     p.c_frame_stride = (long long)pl.c_len;
     p.out_frame_stride = (long long)pl.out_len;
     p.width = (int)d->width; p.height = (int)d->height;
-    p.mcu_x = pl.mcu_x; p.n_strips = pl.n_strips; p.tiles_per_row = pl.tiles_per_row;
-    p.nframes = (int)nframes; p.zero_fill = zero_fill;
-    p.total_tiles = (int)nframes * pl.n_strips * pl.tiles_per_row;
+    p.mcu_x = pl.mcu_x; p.zero_fill = zero_fill;
+    set_grid(p, (int)nframes, pl.n_strips, pl.tiles_per_row);
 #if defined(ZJ_ABLATION)
     p.debug = 0;
 #endif
