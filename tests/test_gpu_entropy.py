@@ -398,6 +398,31 @@ def test_malformed_scan_blobs_are_argument_errors(zj, ctx):
     b[off_blk] = 7
     with pytest.raises(zj.ZjError):
         ctx.decode_scan(desc, b)
+    # three more inputs the kernels index with.  (1) periodic-run words: a period outside 1..8, or less than two
+    # whole periods in front of the sub-sequence; (2) a plane narrower than the MCU grid writes into it; (3) a first-level
+    # table entry naming a second-level table beyond the tables
+    hdr = struct.unpack_from("<%dI" % len(names), blob, 0)
+    off_per, off_tab, nsub = hdr[names.index("off_per")], hdr[names.index("off_tab")], hdr[names.index("nsub")]
+    assert nsub > 8
+    for word in ((1 << 28) | 5, (9 << 28) | 0, (0 << 28) | 1, (2 << 28) | 3):
+        b = blob.copy()
+        struct.pack_into("<I", b, off_per + 4 * 6, word)          # word of sub-sequence 6
+        with pytest.raises(zj.ZjError) as e:
+            ctx.decode_scan(desc, b)
+        assert e.value.status == -1, hex(word)
+    off_comp = off_blk + 4 * 10                                    # blk[HUFF_MAX_BPM] -> comp[]: h, v, bw, bh
+    for field in (2, 3):
+        b = blob.copy()
+        cur = struct.unpack_from("<I", b, off_comp + 4 * field)[0]
+        struct.pack_into("<I", b, off_comp + 4 * field, cur - 1)
+        with pytest.raises(zj.ZjError) as e:
+            ctx.decode_scan(desc, b)
+        assert e.value.status == -1, field
+    b = blob.copy()
+    struct.pack_into("<H", b, off_tab + 2 * 3, 0x80FF)             # first-level entry 3 of the first table
+    with pytest.raises(zj.ZjError) as e:
+        ctx.decode_scan(desc, b)
+    assert e.value.status == -1
     # and the context still works
     out2, rc, st = ctx.decode_scan(desc, blob)
     assert rc == 0 and st == 0 and np.array_equal(out, out2)

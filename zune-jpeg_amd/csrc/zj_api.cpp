@@ -628,9 +628,23 @@ bool scan_header_ok(const HuffScan* h, size_t blob_bytes)
         !inside(h->off_seg, (uint64_t)h->nseg * sizeof(HuffSeg)) || !inside(h->off_per, (uint64_t)h->nsub * 4) ||
         !inside(h->off_stream, h->stream_bytes)) return false;
     if (h->mcu_x == 0 || h->mcu_y == 0 || (uint64_t)h->mcu_x * h->mcu_y != h->total_mcus || h->ri_mcus == 0 || h->rowlen == 0) return false;
+    const uint16_t* tab = (const uint16_t*)((const uint8_t*)h + h->off_tab);
+    // a decoding table: 2^l1 first-level entries at `base`, then the second-level tables its entries name (bit 15 set:
+    // low byte = table number, 2^(16 - l1) entries each; huff_decode_* index base + 2^l1 + (number << (16 - l1)) + x)
+    auto table_ok = [&](uint32_t base, uint32_t l1) {
+        const uint64_t n1 = 1ull << l1, n2 = 1ull << (16 - l1);
+        if ((uint64_t)base + n1 > h->tab_entries) return false;
+        for (uint64_t q = 0; q < n1; q++) {
+            const uint16_t e = tab[base + q];
+            if ((e & 0x8000u) && (uint64_t)base + n1 + ((uint64_t)(e & 0xffu) + 1) * n2 > h->tab_entries) return false;
+        }
+        return true;
+    };
     for (uint32_t k = 0; k < h->ncomp; k++) {
         if (h->comp[k].h < 1 || h->comp[k].h > 2 || h->comp[k].v < 1 || h->comp[k].v > 2) return false;
-        if ((uint64_t)h->dc_off[k] >= h->tab_entries || (uint64_t)h->ac_off[k] >= h->tab_entries) return false;
+        // huff_block_ptr writes block (my * v + vy, mx * h + hx) of a plane of bw x bh blocks: the plane must hold the grid
+        if ((uint64_t)h->comp[k].bw < (uint64_t)h->mcu_x * h->comp[k].h || (uint64_t)h->comp[k].bh < (uint64_t)h->mcu_y * h->comp[k].v) return false;
+        if (!table_ok(h->dc_off[k], (uint32_t)HUFF_L1_DC) || !table_ok(h->ac_off[k], (uint32_t)HUFF_L1_AC)) return false;
     }
     uint32_t per_comp[3] = {0, 0, 0};
     for (uint32_t b = 0; b < h->bpm; b++) {
@@ -652,6 +666,17 @@ bool scan_header_ok(const HuffScan* h, size_t blob_bytes)
         if (sg >= h->nseg || subs[i].start < segs[sg].start || subs[i].start > segs[sg].end) return false;
         if (i && !(subs[i].seg & HUFF_FIRST) && subs[i].start <= subs[i - 1].start) return false;
     }
+    // periodic-run words (zj_huff.h): huff_periodic_thread reads exit[r0 + q - 1], exit[r0 + 2q - 1] and
+    // exit[r0 + q + (i - r0 - q) % q] for word i = (q << 28) | r0: a period of 1..8 sub-sequences, two whole periods in
+    // front of i, all of it inside i's restart segment
+    const uint32_t* per = (const uint32_t*)(base + h->off_per);
+    for (uint32_t i = 0; i < h->nsub; i++) {
+        const uint32_t w = per[i];
+        if (!w) continue;
+        const uint64_t q = w >> HUFF_PER_QSHIFT, r0 = w & HUFF_PER_MASK;
+        if (q < 1 || q > HUFF_PER_MAXQ || r0 + 2 * q > i) return false;
+        if ((subs[r0].seg & HUFF_SEG_MASK) != (subs[i].seg & HUFF_SEG_MASK)) return false;
+    }
     return true;
 }
 
@@ -668,6 +693,12 @@ int scan_setup(zj_ctx* c, ScanJob& j, int slot, const zj_frame_desc* d, const vo
     j.chroma = h->ncomp == 3;
     j.ylen = zj_plane_len(d, 0);
     j.clen = j.chroma ? zj_plane_len(d, 1) : 0;
+    // the blob's grid is the descriptor's: same MCU counts, sampling factors and plane sizes as the plan the pixel kernel runs
+    if ((int)h->mcu_x != j.pl.mcu_x || (int)h->mcu_y != j.pl.mcu_y || (int)h->comp[0].h != j.pl.hs || (int)h->comp[0].v != j.pl.vs) return ZJ_ERR_ARG;
+    for (uint32_t k = 0; k < h->ncomp; k++) {
+        if (k && (h->comp[k].h != 1 || h->comp[k].v != 1)) return ZJ_ERR_ARG;
+        if (h->comp[k].bw != h->mcu_x * h->comp[k].h || h->comp[k].bh != h->mcu_y * h->comp[k].v) return ZJ_ERR_ARG;
+    }
     if (j.ylen != (size_t)h->comp[0].bw * h->comp[0].bh * 64) return ZJ_ERR_ARG;
     if (j.chroma && (j.clen != (size_t)h->comp[1].bw * h->comp[1].bh * 64 || j.clen != (size_t)h->comp[2].bw * h->comp[2].bh * 64)) return ZJ_ERR_ARG;
     if (out_on_device && ((uintptr_t)out & 15)) return ZJ_ERR_ARG;
