@@ -169,8 +169,8 @@ zj_ctx* zj_ctx_create(int backend, int device, int* status)
         const int cus = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
         c->stagger_wgs = cus * 6;                     // six workgroups of the fused kernels per CU (LDS, VGPRs)
         c->stagger_max_tiles = 2 * c->stagger_wgs;
-        c->stagger_delay = 0;
-        if (const char* e = getenv("ZJ_STAGGER")) { const int v = atoi(e); if (v >= 0 && v <= 64) c->stagger_delay = v; }
+        c->stagger_delay = 16;                        // x 128 cycles per slot group; 0 = off (ZJ_STAGGER: A/B knob)
+        if (const char* e = getenv("ZJ_STAGGER")) { const int v = atoi(e); if (v >= 0 && v < 1024) c->stagger_delay = v; }
     }
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
@@ -319,7 +319,12 @@ static int decode_device_impl(zj_ctx* c, const zj_frame_desc* d, const Plan& pl,
 #endif
     if (plane_stride) p.y_frame_stride = p.c_frame_stride = plane_stride;
     if (out_stride) p.out_frame_stride = out_stride;
-    if (c->stagger_delay > 0 && p.total_tiles <= c->stagger_max_tiles) { p.stagger_wgs = c->stagger_wgs; p.stagger_delay = c->stagger_delay; }
+    // Short launches of the 4:2:0 kernels (at most two waves of workgroups: one frame at a time, BASELINE configs[1] read
+    // literally) start their first wave staggered, see stagger_start in zj_kernels.hip: 27.9 -> 24.3 us per 4096x4096 frame
+    // (profiles/r04_single_frame.txt).  Measured for this tile shape only (six 256-thread workgroups per CU).
+    if (c->stagger_delay > 0 && p.total_tiles <= c->stagger_max_tiles && pl.hs == 2 && pl.vs == 2 && pl.out != OUT_GRAY && c->variant != 1) {
+        p.stagger_wgs = c->stagger_wgs; p.stagger_delay = c->stagger_delay;
+    }
     const size_t ostride = out_stride ? (size_t)out_stride : pl.out_len;
     if (zero_fill) {
         // rows below the last complete strip are never written by the reference (Q6): zeros
@@ -328,6 +333,37 @@ static int decode_device_impl(zj_ctx* c, const zj_frame_desc* d, const Plan& pl,
         for (size_t f = 0; f < nframes; f++)
             for (int r = 0; r < nr; r++) ZJ_HIP(c, hipMemsetAsync(d_out + f * ostride + off[r], 0, len[r], s));
     }
+#if defined(ZJ_ABLATION)
+    // Experiment of round 4, diagnostic build only: ONE frame cut into ZJ_SPLIT strip ranges (strips
+    // are independent, src/mcu.rs:225-226) launched on internal streams that are forked from and joined to the caller's
+    // stream by events.  Measured in profiles/r04_single_frame.txt: the fork / join costs more than the overlap gains.
+    static const int split = [] { const char* e = getenv("ZJ_SPLIT"); const int v = e ? atoi(e) : 0; return v >= 2 && v <= 4 ? v : 0; }();
+    if (split && nframes == 1 && pl.n_strips >= 2 * split) {
+        static hipStream_t in[4] = {nullptr, nullptr, nullptr, nullptr};
+        static hipEvent_t fork = nullptr, join[4];
+        if (!fork) {
+            ZJ_HIP(c, hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+            for (int i = 0; i < 4; i++) { ZJ_HIP(c, hipStreamCreateWithFlags(&in[i], hipStreamNonBlocking)); ZJ_HIP(c, hipEventCreateWithFlags(&join[i], hipEventDisableTiming)); }
+        }
+        ZJ_HIP(c, hipEventRecord(fork, s));
+        const int per = (pl.n_strips + split - 1) / split;
+        for (int r = 0; r < split; r++) {
+            const int s0 = r * per, s1 = (s0 + per < pl.n_strips) ? s0 + per : pl.n_strips;
+            Params q = p;
+            const long long yrow = (long long)pl.mcu_x * pl.hs * 64 * (pl.strip_rows / 8), crow = (long long)pl.mcu_x * 64 * (pl.strip_rows / (8 * pl.vs));
+            q.y = p.y + s0 * yrow; q.cb = p.cb ? p.cb + s0 * crow : nullptr; q.cr = p.cr ? p.cr + s0 * crow : nullptr;
+            q.out = p.out + (size_t)s0 * pl.strip_rows * d->width * pl.ncomp_out;
+            q.height = (int)d->height - s0 * pl.strip_rows;
+            set_grid(q, 1, s1 - s0, pl.tiles_per_row);
+            q.stagger_wgs = p.stagger_wgs; q.stagger_delay = p.stagger_delay;
+            ZJ_HIP(c, hipStreamWaitEvent(in[r], fork, 0));
+            ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->variant, pl.fast ? 1 : 0, q, in[r]));
+            ZJ_HIP(c, hipEventRecord(join[r], in[r]));
+            ZJ_HIP(c, hipStreamWaitEvent(s, join[r], 0));
+        }
+        return ZJ_OK;
+    }
+#endif
     ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->variant, pl.fast ? 1 : 0, p, s));
     return ZJ_OK;
 }

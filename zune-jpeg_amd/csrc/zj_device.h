@@ -541,7 +541,10 @@ ZJ_DEV RGB2 ycc_to_rgb_pair(uint32_t y_, uint32_t cb_, uint32_t cr_)
     const u16x2 y = as_u16x2(y_), cb = as_u16x2(cb_), cr = as_u16x2(cr_);
     RGB2 o;
     o.r = as_u32(y + (u16x2)sar(splat(45) * cr + splat(-5760), 5));
-    o.g = as_u32(y - (u16x2)sar(splat(11) * cb + (splat(23) * cr + splat(-4352)), 5));
+    // two multiply-adds: left alone the compiler forms 23*cr, 11*cb + that, + constant (three instructions; round 4 ledger)
+    uint32_t gt = as_u32(splat(23) * cr + splat(-4352));
+    ZJ_PIN(gt);
+    o.g = as_u32(y - (u16x2)sar(splat(11) * cb + as_u16x2(gt), 5));
     o.b = as_u32(y + (u16x2)sar(splat(113) * cb + splat(-14464), 6));
     return o;
 }
@@ -584,7 +587,13 @@ template <> struct TileWidth<2, 2, true> { static constexpr int TWC = ZJ_TWC_HV;
 #define ZJ_NT_MIN_H 0
 #endif
 template <> struct TileWidth<2, 1, true> { static constexpr int TWC = ZJ_TWC_H; };   // 8*TWC+8 blocks (31: 256, 496 px)
-template <> struct TileWidth<1, 2, true> { static constexpr int TWC = 64; };   // 4*TWC = 256, 512 px
+#ifndef ZJ_TWC_V
+#define ZJ_TWC_V 32 // 256-pixel tiles on 128 threads: +2 % over 512 pixels on 256 (round 4, profiles/r04_workloads.txt); 64 is the round 1-3 shape
+#endif
+#ifndef ZJ_NT_MIN_V
+#define ZJ_NT_MIN_V 0
+#endif
+template <> struct TileWidth<1, 2, true> { static constexpr int TWC = ZJ_TWC_V; };   // 4*TWC = 256 blocks, 512 px
 // 4:4:4 with chroma: 3*TWC blocks.  Round 1 ran TWC = 84 (252 lanes busy, 672 pixels).  TWC = 64 with 256 threads is
 // 15 % faster (tools/ab_libs_w.sh 444-rgb): 192 blocks on three waves (the fourth idles through the IDCT), but 512 pixels
 // x 8 rows = 256 items = exactly one colour round for four waves, and 4096-pixel rows split into whole tiles (672 leaves a
@@ -645,7 +654,7 @@ struct Cfg {
     static constexpr int NITEMS = SH * NGRP;
     static constexpr int NBLK = NYB + (CHROMA ? 2 * NCB : 0);        // blocks per tile
     static constexpr int NT_BLK = (NBLK + 63) / 64 * 64;            // one lane per block
-    static constexpr int NT_MIN = (HS == 1 && VS == 1) ? (CHROMA ? ZJ_NT_MIN_444 : ZJ_NT_MIN_GRAY) : ((HS == 2 && VS == 1 && CHROMA) ? ZJ_NT_MIN_H : ((HS == 2 && VS == 2 && CHROMA) ? ZJ_NT_MIN_HV : 0));
+    static constexpr int NT_MIN = (HS == 1 && VS == 1) ? (CHROMA ? ZJ_NT_MIN_444 : ZJ_NT_MIN_GRAY) : ((HS == 2 && VS == 1 && CHROMA) ? ZJ_NT_MIN_H : ((HS == 2 && VS == 2 && CHROMA) ? ZJ_NT_MIN_HV : ((HS == 1 && VS == 2 && CHROMA) ? ZJ_NT_MIN_V : 0)));
     static constexpr int NT = NT_BLK > NT_MIN ? NT_BLK : NT_MIN;     // threads per workgroup
     static constexpr int NW = NT / 64;
     static constexpr int LUT_N = SH + 2;
@@ -1106,16 +1115,24 @@ ZJ_DEV void finish_block(const BlockLoc& L, const U4 raw[8], char* lds, const in
         }
         return;
     }
+    // With the halo blocks in a wave of their own (HALO_PURE) every block that comes here is a full one, and where a luma
+    // row of bytes is as long as a chroma row of i16 (the 256-pixel tiles of the horizontally sub-sampled modes) the LDS
+    // pitch is ONE compile-time constant: the eight row stores take immediate offsets instead of 64-bit multiply-adds on a
+    // per-lane pitch (round 4 ledger: 4 v_mad_u64_u32 + 3 v_lshl_add per block store)
+    using LLp = typename C::template L<GEN_PACKED>;
+    constexpr bool CONST_PITCH = C::HALO_PURE && C::TWY * LLp::YPX == C::CPITCH * 2;
+    BlockLoc Lc = L;
+    if (CONST_PITCH) { Lc.pitch = C::CPITCH * 2; Lc.halo = 0; }
     int cls = classify_block(w, tab + 32);
     if (ZJ_ABL(debug, 1)) cls = 0;
     if (cls == 0) {
         const uint32_t v = dc_only_value(w[0], (int32_t)(tab[0] & 0xffffu), clamp_dc);
-        if (L.comp != 0) { store_splat(L, v); return; }
+        if (L.comp != 0) { store_splat(Lc, v); return; }
         if (NEED_Y16 && (v & 0xffffu) > 255u) *lds_flag<C>(lds) = 1; // benign race: every writer stores 1
         const uint32_t b = (v & 0xffu) * 0x01010101u;
         const U2 row = {b, b};
 #pragma unroll
-        for (int r = 0; r < 8; r++) *reinterpret_cast<U2*>(L.dst + r * L.pitch) = row;
+        for (int r = 0; r < 8; r++) *reinterpret_cast<U2*>(Lc.dst + r * Lc.pitch) = row;
         return;
     }
     uint32_t b[16];
@@ -1129,11 +1146,11 @@ ZJ_DEV void finish_block(const BlockLoc& L, const U4 raw[8], char* lds, const in
     }
     if (L.comp == 0) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) { const U2 row = {b[2 * r], b[2 * r + 1]}; *reinterpret_cast<U2*>(L.dst + r * L.pitch) = row; }
+        for (int r = 0; r < 8; r++) { const U2 row = {b[2 * r], b[2 * r + 1]}; *reinterpret_cast<U2*>(Lc.dst + r * Lc.pitch) = row; }
     } else {
         U4 px[8];
         bytes_to_rows(b, px);
-        store_block(L, px);
+        store_block(Lc, px);
     }
 }
 

@@ -62,8 +62,11 @@ __device__ __forceinline__ void tile_wide(const Params& p, const TileId t, const
 __device__ __forceinline__ void stagger_start(const Params& p, const int bid)
 {
     if (p.stagger_delay <= 0 || bid >= p.stagger_wgs) return; // uniform
-    const int k = bid / (p.stagger_wgs / 6);                  // 0..5: the dispatcher fills the CUs round-robin
-    for (int i = 0; i < k * p.stagger_delay; i++) __builtin_amdgcn_s_sleep(8); // ~512 cycles = 0.21 us per step
+    int k = bid / (p.stagger_wgs / 6);                        // 0..5: the dispatcher fills the CUs round-robin
+    const int mode = p.stagger_delay >> 8;                    // experiment knob (ZJ_STAGGER = delay + 256 * mode)
+    if (mode == 1) k &= 1; else if (mode == 2) k %= 3; else if (mode == 3) k = 5 - k;
+    const int n = k * (p.stagger_delay & 255);
+    for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(2);  // ~128 cycles = 53 ns per step
 }
 
 template <int HS, int VS, int OUT, int GEN, bool FAST, bool TS>
@@ -94,6 +97,9 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAV
     }
     ZJ_SETPRIO(1, 0);
     phase_setup<C, HS, VS, GEN_PACKED>(p, tid, lds);
+    // cut points of the instruction ledger (diagnostic build only, tools/valu_ledger.sh): the kernel ends here, so that
+    // the hardware's instruction counters of two builds-with-a-cut differ by exactly one phase
+    if (ZJ_ABL(ZJ_PDBG(p), 32)) return;   // ... after tile decode, block addresses, load issue, table staging
     __syncthreads();
     if (halo_wave) {
         halo_pass1<C>(H, hs8, lds);
@@ -110,6 +116,7 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAV
     // for loads and stores) and serialises them.  One explicit wait here (free: the data arrived before the IDCT) tells
     // the wait-count pass that nothing is pending.
     __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0) only
+    if (ZJ_ABL(ZJ_PDBG(p), 64)) return;   // ... after classification, IDCT, LDS staging (block waves) / the halo wave's work
     __syncthreads();
     // a DC-only luma block of this tile decodes outside 0..255 (Q1: the scalar shortcut does not clamp): the byte
     // staging cannot carry it, the whole tile is redone by the wide code (never seen on valid 8-bit JPEG data)
@@ -126,10 +133,12 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAV
         for (int round = 0; round * C::NT < C::NITEMS; round++) {
             ItemOut io;
             phase_color<C, HS, VS, OUT, GEN_PACKED, FAST, true>(p, t, tid, lds, round, &io);
+            if (round == 0 && ZJ_ABL(ZJ_PDBG(p), 128)) { ZJ_USE(io.s0.x ^ io.s0.y ^ io.s0.z ^ io.s0.w ^ io.s1.x ^ io.s1.y ^ io.s1.z ^ io.s1.w ^ io.s2.x ^ io.s2.y ^ io.s2.z ^ io.s2.w); return; } // ... after round 0's filters, colour math, packing
             stage_item<C>(io, tid, lds, round);
             ZJ_WAVE_FENCE();
             color_copyout<C, OUT>(p, t, tid, lds, round);
             ZJ_WAVE_FENCE();
+            if (round == 0 && ZJ_ABL(ZJ_PDBG(p), 256)) return; // ... after round 0's staging and stores
         }
     } else {
         ZJ_SETPRIO(2, 2);
