@@ -6,6 +6,7 @@
 #include <cstddef>
 #include <cstdint>
 
+#include "../zj_plan.h"
 #include "zj_lab_launch.h"
 
 using namespace zj;
@@ -122,4 +123,27 @@ LAB_API int zjlab_clock(void* h, int iters, double* cycles, float* ms)
     LAB_HIP(hipMemcpy(&v, c->buf[0], 8, hipMemcpyDeviceToHost));
     *cycles = (double)v;
     return 0;
+}
+
+/* persistent-workgroup experiment (lab/zj_persist.hip): `reps` launches of the whole batch, device pointers in the product's
+ * plane layout; mode 0 = persistent + LDS-DMA prefetch, 1 = persistent only; groups = workgroups in the grid (0: CUs x
+ * the kernel's occupancy).  *ms = total of the timed launches; returns the grid size used, or < 0. */
+LAB_API int zjlab_persist(void* h, const zj_frame_desc* d, int nframes, const int16_t* y, const int16_t* cb, const int16_t* cr,
+                          uint8_t* out, int groups, int mode, int reps, float* ms)
+{
+    LabCtx* c = (LabCtx*)h;
+    Plan pl;
+    if (!c || !ms || make_plan(d, pl) != ZJ_OK || pl.hs != 2 || pl.vs != 2 || pl.out != OUT_RGB || !pl.fast || nframes < 1) return -1;
+    Params p;
+    fill_params(d, pl, (size_t)nframes, y, cb, cr, out, 1, p);
+    if (!ts_eligible<Cfg<2, 2, OUT_RGB>>(p, OUT_RGB, true)) return -2;
+    if (groups <= 0) {
+        hipDeviceProp_t prop;
+        LAB_HIP(hipGetDeviceProperties(&prop, c->device));
+        const int occ = persist_occupancy(mode);
+        if (occ <= 0) return -3;
+        groups = prop.multiProcessorCount * occ;
+    }
+    if (timed(c, reps, ms, [&](int) { return launch_persist(mode, p, groups, c->stream); })) return -4;
+    return groups;
 }

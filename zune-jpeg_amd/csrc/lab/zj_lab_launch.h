@@ -16,4 +16,7 @@ const char* lab_name(int i);
 hipError_t launch_lab(int i, const int32_t qt[3][64], int* out, int blocks, int iters, hipStream_t s);
 hipError_t launch_lab_rd_check(int mode, const void* in, uint32_t* sums, long long ntiles, hipStream_t s);
 hipError_t launch_ub_clock(unsigned long long* out, int blocks, int iters, hipStream_t s);
+struct Params;
+hipError_t launch_persist(int mode, const Params& p, int groups, hipStream_t s);   // lab/zj_persist.hip
+int persist_occupancy(int mode);
 } // namespace zj

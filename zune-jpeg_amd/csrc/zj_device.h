@@ -197,7 +197,7 @@ ZJ_DEV int uniform(int v)
 #if defined(ZJ_EMU)
 #define ZJ_NO_IF_CONVERT() ((void)0)
 #else
-#define ZJ_NO_IF_CONVERT() asm volatile("") // (no memory clobber: that would force register arrays into scratch)
+#define ZJ_NO_IF_CONVERT() asm volatile("; zj-rare-branch") // (no memory clobber: that would force register arrays into scratch; the comment marks the block for tools/valu_ledger.py)
 #endif
 #if defined(ZJ_EMU) || defined(ZJ_IDCT_NOBARRIER)
 #define ZJ_SCHED_BARRIER() ((void)0)
@@ -1249,13 +1249,16 @@ ZJ_DEV char* piece_addr(char* lds, const int item0, const int wave, const int q)
 }
 
 // left / right neighbour pairs of a lane's eight chroma samples (phase_color, HS == 2), see there
+// `pl`, `nr`: what the first / last lane of a full row gets instead (the halo samples, as aligned pairs): a DPP shift leaves
+// the destination's old value in the lane that has no source, so the row's two end lanes need no select
 template <class C, int VS>
-ZJ_DEV void nb_pair(const uint32_t vm[4], const char* cp, const int oa, const int ob, const int lc, const int g, uint32_t& prev, uint32_t& next)
+ZJ_DEV void nb_pair(const uint32_t vm[4], const char* cp, const int oa, const int ob, const int lc, const int g, uint32_t& prev, uint32_t& next,
+                    const uint32_t pl = 0, const uint32_t nr = 0)
 {
 #if !defined(ZJ_EMU)
     if (C::NGRP == 16) {
-        prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vm[3], 0x111, 0xf, 0xf, false); // row_shr:1: lane g-1's (v7, v8)
-        next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vm[0], 0x101, 0xf, 0xf, false); // row_shl:1: lane g+1's (v1, v2)
+        prev = (uint32_t)__builtin_amdgcn_update_dpp((int)pl, (int)vm[3], 0x111, 0xf, 0xf, false); // row_shr:1: lane g-1's (v7, v8)
+        next = (uint32_t)__builtin_amdgcn_update_dpp((int)nr, (int)vm[0], 0x101, 0xf, 0xf, false); // row_shl:1: lane g+1's (v1, v2)
         return;
     }
 #endif
@@ -1422,7 +1425,6 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
                 // two v_mov_dpp where rounds 1-2 had four bank-conflicted 4-byte LDS reads and two more filters -- and at
                 // the two ends of the row the halo columns (finished by halo_filter in the packed generation).
                 uint32_t prev, next;
-                nb_pair<C, VS>(vm, cp, oa, ob, lc, g, prev, next);
                 {
                     int hvl, hvr;
                     if (GEN == GEN_PACKED && C::HALO_PURE) {
@@ -1432,8 +1434,20 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
                         hvl = halo_value<C, HS, VS, GEN>(lds, ch + 1, 0, m, left_wrap);
                         hvr = halo_value<C, HS, VS, GEN>(lds, ch + 1, 1, m, right_wrap);
                     }
-                    if (g == 0) prev = (uint32_t)hvl << 16;
-                    if (g == nvalid - 1) next = (uint32_t)hvr & 0xffffu;
+                    const uint32_t pl = (uint32_t)hvl << 16, nr = (uint32_t)hvr & 0xffffu;
+                    nb_pair<C, VS>(vm, cp, oa, ob, lc, g, prev, next, pl, nr);
+#if defined(ZJ_EMU)
+                    constexpr bool DPP_ENDS = false;
+#else
+                    constexpr bool DPP_ENDS = C::NGRP == 16; // the DPP shifts have put pl / nr into lanes 0 / 15 of the row
+#endif
+                    if (!DPP_ENDS) {
+                        if (g == 0) prev = pl;
+                        if (g == nvalid - 1) next = nr;
+                    } else if (nvalid != C::NGRP) { // a row's last, narrower tile (workgroup-uniform): its end is not lane 15
+                        ZJ_NO_IF_CONVERT();
+                        if (g == nvalid - 1) next = nr;
+                    }
                 }
                 if (p.edge_rep) { // uniform branch (kernel argument): the default path pays no select for it
                     ZJ_NO_IF_CONVERT();

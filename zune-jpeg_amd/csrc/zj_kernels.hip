@@ -76,7 +76,21 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAV
     using C = Cfg<HS, VS, OUT>;
     __shared__ __attribute__((aligned(16))) char lds[GEN == GEN_PACKED ? C::LDS_PACKED : C::LDS_WIDE];
     const TileId t = decode_tile(p, (int)blockIdx.x);
-    const int tid = (int)threadIdx.x;
+    // Wave ROLES rotate with the workgroup: the hardware places wave i of every 4-wave workgroup on SIMD i, and the roles
+    // are unequal (4:2:0: two luma waves and the chroma wave run a full transform, ~1350 VALU instructions per tile; the
+    // halo wave ~830), so with fixed roles the SIMD of the halo waves idles a third of the time while the other three are
+    // the kernel's bottleneck.  `tid` is the LOGICAL thread number everywhere below (block, item, staging slot): any
+    // rotation of whole waves is equivalent, barriers are workgroup-wide.  ZJ_ROTATE=0: round 1-3 behaviour (A/B).
+#ifndef ZJ_ROTATE
+#define ZJ_ROTATE 1
+#endif
+    int tid = (int)threadIdx.x;
+    if (ZJ_ROTATE && C::NW > 1) {
+        const unsigned b = blockIdx.x;
+        const int rot = (int)((b ^ (b >> 3) ^ (b >> 8)) % (unsigned)C::NW); // co-resident workgroups differ in one of these
+        tid += 64 * rot;
+        if (tid >= C::NT) tid -= C::NT;
+    }
     stagger_start(p, (int)blockIdx.x);
     if (GEN == GEN_WIDE) { tile_wide<C, HS, VS, OUT, FAST>(p, t, tid, lds); return; }
     // luma enters arithmetic for the RGB family only; gray / YCbCr outputs keep its low byte (Q7)
