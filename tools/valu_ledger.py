@@ -134,11 +134,16 @@ def main():
         return None
     bar1 = idx_bar[0]
     halo_end = find(r"halo_filter.*exit")
-    pc0 = find(r"phase_colorINS_3CfgILi2ELi2ELi0EEELi2ELi2ELi0ELi1ELb1ELb1E.*exit")
-    st0 = find(r"stage_item.*exit", pc0)
+    # (LLVM does not always keep phase_color's exit label; then the staging writes are counted with the colour phase)
+    st0 = find(r"stage_item.*exit", halo_end)
+    pc0 = find(r"phase_colorINS_3CfgILi2ELi2ELi0EEELi2ELi2ELi0ELi1ELb1ELb1E.*exit", halo_end)
+    if pc0 is None or pc0 > st0:
+        pc0 = st0
     co0 = find(r"color_copyout.*exit", st0)
+    st1 = find(r"stage_item.*exit", co0 + 1)
     pc1 = find(r"phase_color.*exit", co0 + 1)
-    st1 = find(r"stage_item.*exit", pc1)
+    if pc1 is None or pc1 > st1:
+        pc1 = st1
     co1 = find(r"color_copyout.*exit", st1)
     # the staged-store rounds start where the wide redo path (tile_wide, inlined behind the second barrier) ends: the
     # last block before pc0 that begins with the kernel-argument reloads of phase_color

@@ -76,20 +76,25 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAV
     using C = Cfg<HS, VS, OUT>;
     __shared__ __attribute__((aligned(16))) char lds[GEN == GEN_PACKED ? C::LDS_PACKED : C::LDS_WIDE];
     const TileId t = decode_tile(p, (int)blockIdx.x);
-    // Wave ROLES rotate with the workgroup: the hardware places wave i of every 4-wave workgroup on SIMD i, and the roles
-    // are unequal (4:2:0: two luma waves and the chroma wave run a full transform, ~1350 VALU instructions per tile; the
-    // halo wave ~830), so with fixed roles the SIMD of the halo waves idles a third of the time while the other three are
-    // the kernel's bottleneck.  `tid` is the LOGICAL thread number everywhere below (block, item, staging slot): any
-    // rotation of whole waves is equivalent, barriers are workgroup-wide.  ZJ_ROTATE=0: round 1-3 behaviour (A/B).
+    // Which hardware wave plays which role (4:2:0: two luma waves, the chroma wave, the halo wave -- ~1390 VALU instructions per
+    // tile for the first three, ~900 for the last).  `tid` is the LOGICAL thread number everywhere below (block, item,
+    // staging slot), so any rotation of whole waves is equivalent; barriers are workgroup-wide.  Measured in round 4
+    // (profiles/r04_ab_history.txt): rotating the roles with the workgroup, so that every SIMD sees every role, is 3.7 %
+    // SLOWER than fixed roles (ZJ_ROTATE=1); a constant shift (ZJ_ROLE_SHIFT: which role the first wave plays) is the
+    // other knob.  Default: roles as the threads are numbered.
 #ifndef ZJ_ROTATE
-#define ZJ_ROTATE 1
+#define ZJ_ROTATE 0
+#endif
+#ifndef ZJ_ROLE_SHIFT
+#define ZJ_ROLE_SHIFT 0
 #endif
     int tid = (int)threadIdx.x;
-    if (ZJ_ROTATE && C::NW > 1) {
+    if ((ZJ_ROTATE || ZJ_ROLE_SHIFT) && C::NW > 1) {
         const unsigned b = blockIdx.x;
-        const int rot = (int)((b ^ (b >> 3) ^ (b >> 8)) % (unsigned)C::NW); // co-resident workgroups differ in one of these
+        const int rot = ZJ_ROTATE ? (int)((b ^ (b >> 3) ^ (b >> 8)) % (unsigned)C::NW) : ZJ_ROLE_SHIFT % C::NW;
         tid += 64 * rot;
-        if (tid >= C::NT) tid -= C::NT;
+        if ((C::NT & (C::NT - 1)) == 0) tid &= C::NT - 1; else if (tid >= C::NT) tid -= C::NT;
+        __builtin_assume(tid >= 0 && tid < C::NT); // what the compiler knew of threadIdx.x (it shapes the colour rounds)
     }
     stagger_start(p, (int)blockIdx.x);
     if (GEN == GEN_WIDE) { tile_wide<C, HS, VS, OUT, FAST>(p, t, tid, lds); return; }
