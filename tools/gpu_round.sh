@@ -35,20 +35,20 @@ if has bench; then
 fi
 if has prof; then
   echo "== rocprofv3 --kernel-trace --stats (same command as bench)" | tee -a $O/summary.txt
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o stats -- python3 $R/bench.py --no-cpu-baseline --no-single-frame --no-live-traffic > $O/prof_stats.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o stats -- python3 $R/bench.py --no-cpu-baseline --no-single-frame --no-live-traffic --no-e2e > $O/prof_stats.log 2>&1)
   grep -h '"metric"' $O/prof_stats.log | tail -1 | tee -a $O/summary.txt
   find $O/prof_stats -name "*kernel_stats*.csv" | head -1 | xargs -r head -6 | tee -a $O/summary.txt
 fi
 if has pmc; then
   echo "== rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)" | tee -a $O/summary.txt
-  (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pmc -- python3 $R/bench.py --steps 5 --warmup 1 --min-untimed 5 --shard-frames 16 --no-cpu-baseline --no-single-frame --no-live-traffic > $O/pmc_fetch.log 2>&1)
-  (cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o pmc -- python3 $R/bench.py --steps 5 --warmup 1 --min-untimed 5 --shard-frames 16 --no-cpu-baseline --no-single-frame --no-live-traffic > $O/pmc_write.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pmc -- python3 $R/bench.py --steps 5 --warmup 1 --min-untimed 5 --shard-frames 16 --child > $O/pmc_fetch.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o pmc -- python3 $R/bench.py --steps 5 --warmup 1 --min-untimed 5 --shard-frames 16 --child > $O/pmc_write.log 2>&1)
   python tools/pmc_summary.py $O --out $O/pmc_summary.json --tag $TAG 2>&1 | tail -30 | tee -a $O/summary.txt
 fi
 if has sq; then
   echo "== rocprofv3 --pmc SQ counters" | tee -a $O/summary.txt
-  (cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_sq -o pmc -- python3 $R/bench.py --steps 5 --warmup 1 --min-untimed 5 --shard-frames 16 --no-cpu-baseline --no-single-frame --no-live-traffic > $O/pmc_sq.log 2>&1)
-  (cd /tmp && timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM --output-format csv -d $O/pmc_sq2 -o pmc -- python3 $R/bench.py --steps 5 --warmup 1 --min-untimed 5 --shard-frames 16 --no-cpu-baseline --no-single-frame --no-live-traffic > $O/pmc_sq2.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_sq -o pmc -- python3 $R/bench.py --steps 5 --warmup 1 --min-untimed 5 --shard-frames 16 --child > $O/pmc_sq.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM --output-format csv -d $O/pmc_sq2 -o pmc -- python3 $R/bench.py --steps 5 --warmup 1 --min-untimed 5 --shard-frames 16 --child > $O/pmc_sq2.log 2>&1)
   python tools/pmc_summary.py $O/pmc_sq --tag $TAG-sq 2>&1 | grep -E '"(SQ|GRBM)|mean' | paste - - | tee -a $O/summary.txt
   python tools/pmc_summary.py $O/pmc_sq2 --tag $TAG-sq2 2>&1 | grep -E '"(SQ|GRBM)|mean' | paste - - | tee -a $O/summary.txt
 fi

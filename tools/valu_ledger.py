@@ -155,7 +155,7 @@ def main():
             break
     phases = [
         ("prologue: tile decode, stagger test, block / halo addresses, load issue, table + LUT staging", range(0, bar1 + 1), "all 4 waves (each its own role's path)"),
-        ("classify_block (DC-only test, packed-IDCT guard)", range(classify, classify + 1), "3 block waves"),
+        ("classify_block (DC-only test, packed-IDCT guard)", range(bar1 + 1, classify + 1), "3 block waves"),
         ("packed IDCT (v_dot2_i32_i16)", range(packed, packed + 1), "3 block waves"),
         ("IDCT results -> LDS (luma bytes / chroma i16 rows / DC-only splats)", range(packed + 1, halo_start), "3 block waves"),
         ("halo wave: column pass, row pass, vertical filter of the halo columns", range(halo_start, halo_end + 1), "the halo wave"),
