@@ -479,6 +479,25 @@ def main():
         _, e1, kname = ctx.time_decode_device(desc, B, pk[0], pk[1], pk[2], pk[3], 2 if args.child else max(2, -(-48 // nsub)), stream)
         each.append(e1)
     kernel_ms_each = sum(each) / len(each)
+    # Control for data dependence: the kernel's only data-dependent shortcut is the reference's own DC-only one, and it is
+    # taken lane by lane (a wave transforms as long as any of its 64 blocks needs it).  The same sub-batch with ONE coefficient
+    # (row 1, column 7) set to 1 in every block -- no DC-only block, nothing sparse about any column -- must therefore decode at
+    # the same rate (the output differs, of course).  Reported beside the headline, never as it.
+    dense_ms = None
+    if not args.child:
+        dpl = [d_planes[c][:B * plane_elems[c]].clone() for c in range(3)]
+        for t_ in dpl:
+            t_.view(-1, 64)[:, 15] = 1
+        dp = [t_.data_ptr() for t_ in dpl]
+        for _ in range(20):
+            ctx.decode_planes_device(desc, B, dp[0], dp[1], dp[2], subs[0][3], stream)
+        ev[2].record(side)
+        for _ in range(100):
+            ctx.decode_planes_device(desc, B, dp[0], dp[1], dp[2], subs[0][3], stream)
+        ev[3].record(side)
+        ev[3].synchronize()
+        dense_ms = ev[2].elapsed_time(ev[3]) / 100
+        del dpl
     # configs[1] read literally is ONE 4096x4096 frame per launch: time that shape too, reported beside the batched figure
     one_ms = one_ms_each = one_ms_4s = None
     if not args.no_single_frame:
@@ -597,6 +616,10 @@ def main():
                                           f"events around the {args.steps} timed steps; kernel_ms_single_launch = own event "
                                           f"pair per launch",
                          "algorithmic_bytes_per_launch": int(algo_bytes),
+                         "dense_control": None if dense_ms is None else {
+                             "kernel_ms": round(dense_ms, 4), "frac": round(algo_bytes / (dense_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "what": "the same 16 frames with coefficient (row 1, column 7) of every block set to 1: no DC-only "
+                                     "block, no empty column anywhere; the rate does not depend on the coefficients' sparsity"},
                          "valu_issue": valu,
                          "single_frame_launch": None if one_ms is None else {
                              "kernel_ms": round(one_ms, 4), "kernel_ms_single_launch": round(one_ms_each, 4),

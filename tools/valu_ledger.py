@@ -123,7 +123,9 @@ def main():
     B = blocks_of(kernel_lines(path, a.kernel))
     idx_bar = [i for i, b in enumerate(B) if any(s.split()[0] == "s_barrier" for s in b["ins"])]
     has = lambda b, rx, n=1: sum(bool(re.match(rx, s.split()[0])) for s in b["ins"]) >= n  # noqa: E731
-    packed = next(i for i, b in enumerate(B) if has(b, r"v_dot2", 100))
+    dot_blocks = [i for i, b in enumerate(B) if has(b, r"v_dot2", 100)]
+    packed = dot_blocks[0]                                   # the full form of the packed transform
+    sparse = dot_blocks[1] if len(dot_blocks) > 1 else None  # its sparse form (columns 5..7 empty below the first row)
     wide = [i for i, b in enumerate(B) if has(b, r"v_mad_i32_i24", 100)]
     classify = next(i for i, b in enumerate(B) if has(b, r"v_sad", 16))
 
@@ -132,8 +134,13 @@ def main():
             if re.search(rx, B[i]["comment"]):
                 return i
         return None
-    bar1 = idx_bar[0]
+    bar1 = idx_bar[0]                                        # the block waves' first barrier (their path comes first in the layout)
+    halo_loc = find(r"halo_locate.*exit")
     halo_end = find(r"halo_filter.*exit")
+    # the halo wave's path starts a few scalar blocks in front of halo_locate's exit label: at the block behind the last
+    # block of the block waves' path (the one that carries finish_block's exit label)
+    fb_exit = max(i for i in range(packed, halo_loc) if "finish_block" in B[i]["comment"])
+    halo_start = fb_exit + 1
     # (LLVM does not always keep phase_color's exit label; then the staging writes are counted with the colour phase)
     st0 = find(r"stage_item.*exit", halo_end)
     pc0 = find(r"phase_colorINS_3CfgILi2ELi2ELi0EEELi2ELi2ELi0ELi1ELb1ELb1E.*exit", halo_end)
@@ -148,17 +155,18 @@ def main():
     # the staged-store rounds start where the wide redo path (tile_wide, inlined behind the second barrier) ends: the
     # last block before pc0 that begins with the kernel-argument reloads of phase_color
     ts0 = max(i for i in range(wide[-1] if wide else packed, pc0) if any(s.startswith("s_load_dwordx4") for s in B[i]["ins"]) and not B[i]["cold"])
-    halo_start = find(r"Flow", packed + 1)
-    for i in range(packed + 1, halo_end):
-        if has(B[i], r"v_mad_i32_i24", 20) and not has(B[i], r"v_mad_i32_i24", 100):
-            halo_start = i
-            break
+    after_full = sparse if sparse is not None else halo_start
     phases = [
-        ("prologue: tile decode, stagger test, block / halo addresses, load issue, table + LUT staging", range(0, bar1 + 1), "all 4 waves (each its own role's path)"),
-        ("classify_block (DC-only test, packed-IDCT guard)", range(bar1 + 1, classify + 1), "3 block waves"),
-        ("packed IDCT (v_dot2_i32_i16)", range(packed, packed + 1), "3 block waves"),
-        ("IDCT results -> LDS (luma bytes / chroma i16 rows / DC-only splats)", range(packed + 1, halo_start), "3 block waves"),
-        ("halo wave: column pass, row pass, vertical filter of the halo columns", range(halo_start, halo_end + 1), "the halo wave"),
+        ("tile decode, stagger test; block waves: addresses, load issue, table + LUT staging (to their first barrier)", range(0, bar1 + 1), "3 block waves (the halo wave runs the first ~20 blocks of it: tile decode)"),
+        ("classify_block (DC-only test, packed-IDCT guard) + the test for the sparse form", range(bar1 + 1, packed), "3 block waves"),
+        ("packed IDCT, FULL form (v_dot2_i32_i16)", range(packed, packed + 1), "block waves with a block that has anything below row 0 in columns 5..7"),
+        ("  its results -> LDS (luma bytes / chroma i16 rows)", range(packed + 1, after_full), "the same"),
+    ]
+    if sparse is not None:
+        phases += [("packed IDCT, SPARSE form (three column transforms of pass 1 skipped)", range(sparse, sparse + 1), "block waves where no block has"),
+                   ("  its results -> LDS, DC-only splats", range(sparse + 1, halo_start), "the same")]
+    phases += [
+        ("halo wave: addresses, loads, table staging, column pass, row pass, vertical filter of the halo columns", range(halo_start, halo_end + 1), "the halo wave"),
         ("colour round 0: luma unpack, vertical + horizontal chroma filters, YCbCr->RGB, clamp + interleave", range(ts0, pc0), "all 4 waves"),
         ("round 0 staging (ds_write) ", range(pc0, st0), "all 4 waves"),
         ("round 0 copy-out (addresses, ds_read, global_store)", range(st0, co0), "all 4 waves"),
@@ -167,19 +175,22 @@ def main():
         ("round 1 copy-out", range(st1, co1), "all 4 waves"),
     ]
     covered = set()
-    print(f"{'phase':98s} {'VALU':>5s} {'SALU':>5s} {'LDS':>4s} {'VMEM':>4s} {'nop':>4s} {'wait':>4s} | cold (edge tiles, not executed by interior tiles): VALU SALU")
+    print(f"{'phase':112s} {'VALU':>5s} {'SALU':>5s} {'LDS':>4s} {'VMEM':>4s} {'nop':>4s} {'wait':>4s} | cold (edge tiles, not executed by interior tiles): VALU SALU")
     for name, rng, who in phases:
         hot = [B[i] for i in rng if not B[i]["cold"] and i not in wide]
         cold = [B[i] for i in rng if B[i]["cold"]]
         covered.update(rng)
         v, s, l, m, nop, w, _ = totals(count(hot))
         cv, cs, *_ = totals(count(cold))
-        print(f"{name:98s} {v:5d} {s:5d} {l:4d} {m:4d} {nop:4d} {w:4d} | {cv:4d} {cs:4d}   [{who}]")
+        print(f"{name:112s} {v:5d} {s:5d} {l:4d} {m:4d} {nop:4d} {w:4d} | {cv:4d} {cs:4d}   [{who}]")
     rest = [B[i] for i in range(len(B)) if i not in covered]
     v, s, l, m, nop, w, sc = totals(count(rest))
-    print(f"{'not on the hot path: wide IDCT fall-back, tile_wide redo (Q1), generic tails':98s} {v:5d} {s:5d} {l:4d} {m:4d} {nop:4d} {w:4d} | scratch instructions {sc}")
+    print(f"{'not on the hot path: wide IDCT fall-back, tile_wide redo (Q1), generic tails':112s} {v:5d} {s:5d} {l:4d} {m:4d} {nop:4d} {w:4d} | scratch instructions {sc}")
     print()
-    for name, rng in (("packed IDCT", range(packed, packed + 1)), ("classify_block", range(classify, classify + 1)), ("colour round 0 (hot blocks)", range(ts0, pc0))):
+    kinds = [("packed IDCT, full form", range(packed, packed + 1)), ("classify_block", range(classify, classify + 1)), ("colour round 0 (hot blocks)", range(ts0, pc0))]
+    if sparse is not None:
+        kinds.insert(1, ("packed IDCT, sparse form", range(sparse, sparse + 1)))
+    for name, rng in kinds:
         c = count([B[i] for i in rng if not B[i]["cold"]])
         items = ", ".join(f"{k[2:]} {n}" for k, n in sorted(c.items(), key=lambda kv: -kv[1]) if k.startswith("V:"))
         print(f"{name}: {items}")

@@ -199,6 +199,11 @@ ZJ_DEV int uniform(int v)
 #else
 #define ZJ_NO_IF_CONVERT() asm volatile("; zj-rare-branch") // (no memory clobber: that would force register arrays into scratch; the comment marks the block for tools/valu_ledger.py)
 #endif
+#if defined(ZJ_EMU)
+#define ZJ_BRANCH_TAG(text) ((void)0)
+#else
+#define ZJ_BRANCH_TAG(text) asm volatile(text)
+#endif
 #if defined(ZJ_EMU) || defined(ZJ_IDCT_NOBARRIER)
 #define ZJ_SCHED_BARRIER() ((void)0)
 #else
@@ -477,6 +482,10 @@ ZJ_DEV void idct_block_packed(const U4 raw[8], const uint32_t* qp, uint32_t out[
     for (int i = 0; i < 32; i++) D[i] = as_u32(as_u16x2(w[i]) * as_u16x2(qp[i]));
     // pass 1: columns (scalar.rs:79-167), bias 512, >> 10.  Two columns per group, chosen so that their results
     // pair up as pass 2 wants them: T[i][g] = (tmp[i][CA[g]], tmp[i][CB[g]]) = p04, p26, p13, p57 of row i.
+    // (Round 4 tried a sparse form of this pass -- a column with nothing below its first row yields 4 * s0 in every row,
+    // exactly; columns 5..7 qualify in every wave of q90 data -- behind a wave-uniform test: as a second instantiation it
+    // gained 1.3 % on 4:2:0 and cost 18 % on dense input (the full form lost its register allocation), as branches inside
+    // this body it gained nothing; profiles/r04_ab_history.txt.  The kernel sits on its memory floor by then.)
     uint32_t T[8][4];
 #pragma unroll
     for (int g = 0; g < 4; g++) {
@@ -1135,22 +1144,30 @@ ZJ_DEV void finish_block(const BlockLoc& L, const U4 raw[8], char* lds, const in
         for (int r = 0; r < 8; r++) *reinterpret_cast<U2*>(Lc.dst + r * Lc.pitch) = row;
         return;
     }
-    uint32_t b[16];
+    // the block's pixels (16 dwords of bytes) to LDS: luma rows of bytes, chroma rows of i16
+    auto emit = [&](const uint32_t* b) {
+        if (L.comp == 0) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) { const U2 row = {b[2 * r], b[2 * r + 1]}; *reinterpret_cast<U2*>(Lc.dst + r * Lc.pitch) = row; }
+        } else {
+            U4 px[8];
+            bytes_to_rows(b, px);
+            store_block(Lc, px);
+        }
+    };
     if (cls == 1) {
+        uint32_t b[16];
         idct_block_packed(raw, tab, b);
-    } else {
+        emit(b);
+        return;
+    }
+    {
         ZJ_NO_IF_CONVERT();
+        uint32_t b[16];
         U4 px[8];
         idct_block(raw, reinterpret_cast<const uint16_t*>(tab), px);
         rows_to_bytes(px, b);
-    }
-    if (L.comp == 0) {
-#pragma unroll
-        for (int r = 0; r < 8; r++) { const U2 row = {b[2 * r], b[2 * r + 1]}; *reinterpret_cast<U2*>(Lc.dst + r * Lc.pitch) = row; }
-    } else {
-        U4 px[8];
-        bytes_to_rows(b, px);
-        store_block(Lc, px);
+        emit(b);
     }
 }
 

@@ -103,30 +103,34 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAV
     ZJ_SETPRIO(1, 3);
     // the wave of the halo blocks works with one lane per block column (zj_device.h: halo_*); a wave-uniform split
     const bool halo_wave = C::HALO_PURE && (__builtin_amdgcn_readfirstlane(tid) >> 6) == C::HALO_T0 / 64;
-    BlockLoc L;
-    HaloLane H;
-    U4 raw[8];
-    int32_t hs8[8];
+    // The halo wave and the block waves run DISJOINT code from their first load to the second barrier (both sides execute
+    // the same two barriers).  Written as two consecutive `if (halo_wave)` the compiler keeps the halo wave's twelve
+    // registers (its eight coefficients, its addresses) live THROUGH the block waves' transform -- it cannot know that the
+    // two conditions exclude that path -- and the packed IDCT has 68 registers instead of 80 (round 4, seen as spills the
+    // moment the transform got a second form).
     if (halo_wave) {
-        H = halo_locate<C>(p, t, tid - C::HALO_T0, lds);
+        HaloLane H = halo_locate<C>(p, t, tid - C::HALO_T0, lds);
+        int32_t hs8[8];
         halo_load(H, hs8);
-    } else {
-        L = locate<C, GEN_PACKED>(p, t, tid, lds);
-        load_block(L, raw, ZJ_PDBG(p));
-    }
-    ZJ_SETPRIO(1, 0);
-    phase_setup<C, HS, VS, GEN_PACKED>(p, tid, lds);
-    // cut points of the instruction ledger (diagnostic build only, tools/valu_ledger.sh): the kernel ends here, so that
-    // the hardware's instruction counters of two builds-with-a-cut differ by exactly one phase
-    if (ZJ_ABL(ZJ_PDBG(p), 32)) return;   // ... after tile decode, block addresses, load issue, table staging
-    __syncthreads();
-    if (halo_wave) {
+        ZJ_SETPRIO(1, 0);
+        phase_setup<C, HS, VS, GEN_PACKED>(p, tid, lds);
+        // cut points of the instruction ledger (diagnostic build only, tools/valu_ledger.sh): the kernel ends here, so that
+        // the hardware's instruction counters of two builds-with-a-cut differ by exactly one phase
+        if (ZJ_ABL(ZJ_PDBG(p), 32)) return;   // ... after tile decode, block addresses, load issue, table staging
+        __syncthreads();
         halo_pass1<C>(H, hs8, lds);
         ZJ_WAVE_FENCE();
         halo_pass2<C>(H, lds, p.clamp_dc);
         ZJ_WAVE_FENCE();
         halo_filter<C, HS, VS>(p, t, tid - C::HALO_T0, lds);
     } else {
+        const BlockLoc L = locate<C, GEN_PACKED>(p, t, tid, lds);
+        U4 raw[8];
+        load_block(L, raw, ZJ_PDBG(p));
+        ZJ_SETPRIO(1, 0);
+        phase_setup<C, HS, VS, GEN_PACKED>(p, tid, lds);
+        if (ZJ_ABL(ZJ_PDBG(p), 32)) return;
+        __syncthreads();
         finish_block<C, GEN_PACKED, NEED_Y16>(L, raw, lds, ZJ_PDBG(p), p.clamp_dc);
     }
     // The coefficient loads are consumed inside exec-masked regions, so on the paths that skip those regions the
