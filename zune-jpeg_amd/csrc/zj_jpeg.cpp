@@ -212,7 +212,10 @@ inline int32_t extend(int32_t v, int s) { return v < (1 << (s - 1)) ? v - (1 << 
 // Called after the DC code (`len` bits) has been dropped and entered into `hist`, with rbl already raised by the < 16
 // refill: true if the reference reads the `s` magnitude bits short; then *bits is what it gets and the reader has
 // consumed what it had.
-inline bool ref_dc_misread(BitReader& br, int& rbl, const int rbl0, const uint64_t hist, const int len, const int s, int32_t* bits)
+// need_hist (non-null from a caller that does not track rbl0 / the history -- the default: tracking costs the Huffman loop
+// 9-13 %): a short read is only REPORTED; the caller then decodes the image again with tracking on.
+inline bool ref_dc_misread(BitReader& br, int& rbl, const int rbl0, const uint64_t hist, const int len, const int s, int32_t* bits,
+                           bool* need_hist = nullptr)
 {
     if (len + s <= rbl) return false;
     // rbl describes the reference only while it has not come across the marker that ends the interval (after that it
@@ -228,6 +231,7 @@ inline bool ref_dc_misread(BitReader& br, int& rbl, const int rbl0, const uint64
     const long long c_code_start = br.consumed() - len;
     if (c_code_start + rbl > data_bits) return false;
     const int avail = rbl - len; // 0 <= avail < s (len <= 16 <= rbl)
+    if (need_hist) { *need_hist = true; return true; } // (a caller without the history: it discards this decode and starts over)
     // the reference's aligned_buffer at this moment: `avail` valid bits, the refill's zeros, the history since the refill
     const int nhist = rbl0 - avail; // bits consumed since the last real refill (the DC code included): 5 .. 64 - 16
     uint64_t aligned = nhist > 0 && nhist < 64 ? hist & ((1ull << nhist) - 1) : 0;
@@ -314,6 +318,8 @@ struct zj_decoder {
     int restart_interval = 0;
     int seen_sof = 0, scans = 0;
     bool coef_valid = false; // the planes hold the coefficients of a complete, successful decode_all
+    long long hist_retries = 0; // images decoded a second time for it (tests)
+    bool track_hist = false; // second pass of decode_all: the Huffman loop keeps the reference reader's bit history (BitReader::rhist)
     uint16_t qt[4][64];
     bool qt_present[4] = {false, false, false, false};
     Huff dc[4], ac[4];
@@ -554,7 +560,10 @@ inline int16_t* block_at(Comp& cm, int bx, int by) { return cm.coef + ((size_t)b
 // run on several threads
 // TRACK: also record the bit length of the block's last symbol (BitReader::last_sym) -- needed only near the end of
 // the scan, where reference_saw_eoi() looks at it; the hot instantiation carries no bookkeeping
-template <bool TRACK>
+// HIST: also keep the history register of the reference's aligned_buffer (BitReader::rhist).  Off in the first decode of an
+// image; a short DC read that would need it returns ZJ_INT_NEED_HIST and decode_all starts over with it on.
+constexpr int ZJ_INT_NEED_HIST = 1000; // internal status, never leaves this file
+template <bool TRACK, bool HIST>
 int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, int32_t& dc_pred, int16_t* out, const char** err)
 {
     const Huff& hd = d->dc[cm.td & 3];
@@ -568,26 +577,29 @@ int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, in
         const int16_t* src; int16_t* dst;
         ~Flush() { for (int i = 0; i < 8; i++) _mm_stream_si128((__m128i*)dst + i, _mm_load_si128((const __m128i*)src + i)); }
     } flush{blk, out};
-    int rbl = br.rbl, rbl0 = br.rbl0; // the reference's bits_left and its history (BitReader::rbl, rbl0, rhist), in
-    uint64_t hist = br.rhist;         // registers through the block
-    struct KeepRbl { BitReader& b; int& r; int& r0; uint64_t& h; ~KeepRbl() { b.rbl = r < 0 ? 0 : r; b.rbl0 = r0; b.rhist = h; } } keep{br, rbl, rbl0, hist};
+    int rbl = br.rbl, rbl0 = HIST ? br.rbl0 : 0; // the reference's bits_left and (HIST) its history (BitReader::rbl, rbl0, rhist),
+    uint64_t hist = HIST ? br.rhist : 0;         // in registers through the block
+    struct KeepRbl { BitReader& b; int& r; int& r0; uint64_t& h; ~KeepRbl() { b.rbl = r < 0 ? 0 : r; if (HIST) { b.rbl0 = r0; b.rhist = h; } } } keep{br, rbl, rbl0, hist};
     if (br.nbits < 32) br.fill();
     const int dc_before = br.nbits; // >= 32: decode() does not refill, the difference is the code's length
     int s = br.decode(hd);
     if (s < 0 || s > 16) { *err = "Bad Huffman code in DC"; return ZJ_ERR_HUFFMAN; }
     const int dc_len = dc_before - br.nbits;
-    if (rbl < 16) { rbl += 32; rbl0 = rbl; } // bitstream.rs:278
-    hist <<= dc_len;                          // drop_bits(code)
+    if (rbl < 16) { rbl += 32; if (HIST) rbl0 = rbl; } // bitstream.rs:278
+    if (HIST) hist <<= dc_len;                // drop_bits(code)
     int32_t diff = 0, short_bits = 0;
     if (s) {
-        if (__builtin_expect(dc_len + s > rbl, 0) && ref_dc_misread(br, rbl, rbl0, hist, dc_len, s, &short_bits)) diff = extend(short_bits, s);
-        else { const int32_t mag = br.get(s); diff = extend(mag, s); rbl -= dc_len + s; hist = (hist << s) | (uint32_t)mag; } // get_bits rotates
+        bool need_hist = false;
+        if (__builtin_expect(dc_len + s > rbl, 0) && ref_dc_misread(br, rbl, rbl0, hist, dc_len, s, &short_bits, HIST ? nullptr : &need_hist)) {
+            if (need_hist) { *err = "short DC read reaches the reader's history"; return ZJ_INT_NEED_HIST; }
+            diff = extend(short_bits, s);
+        } else { const int32_t mag = br.get(s); diff = extend(mag, s); rbl -= dc_len + s; if (HIST) hist = (hist << s) | (uint32_t)mag; } // get_bits rotates
     } else rbl -= dc_len;
     dc_pred = (int32_t)((uint32_t)dc_pred + (uint32_t)diff);
     blk[0] = (int16_t)dc_pred; // bitstream.rs:330
     for (int k = 1; k < 64;) {
         if (br.nbits < 32) br.fill(); // a code (<= 16 bits) and its magnitude bits (<= 15) without another refill
-        if (rbl <= 32) { rbl += 32; rbl0 = rbl; } // the reference's refill before every AC symbol (bitstream.rs:334)
+        if (rbl <= 32) { rbl += 32; if (HIST) rbl0 = rbl; } // the reference's refill before every AC symbol (bitstream.rs:334)
         const uint32_t look9 = br.peek(9);
         const int16_t fa = ha.fast[look9];
         if (fa) { // short code + small value: run, magnitude and sign from one table entry -- in the reference too
@@ -595,7 +607,7 @@ int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, in
             k += (fa >> 4) & 15;
             br.drop(fa & 15);
             rbl -= fa & 15;
-            hist <<= fa & 15;
+            if (HIST) hist <<= fa & 15;
             if (TRACK) br.last_sym = fa & 15;
             blk[kUnZigzag[k & 63]] = (int16_t)(fa >> 8);
             k++;
@@ -603,13 +615,13 @@ int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, in
         }
         int rs;
         const uint16_t e = ha.look[look9];
-        if (e) { br.drop(e >> 8); rbl -= e >> 8; hist <<= e >> 8; if (TRACK) br.last_sym = e >> 8; rs = e & 0xff; }
+        if (e) { br.drop(e >> 8); rbl -= e >> 8; if (HIST) hist <<= e >> 8; if (TRACK) br.last_sym = e >> 8; rs = e & 0xff; }
         else {
             const int before = br.nbits; // >= 32 here: decode() does not refill, the difference is the code's length
             rs = br.decode(ha);
             if (rs < 0) { *err = "Bad Huffman code in AC"; return ZJ_ERR_HUFFMAN; }
             rbl -= before - br.nbits;
-            hist <<= before - br.nbits;
+            if (HIST) hist <<= before - br.nbits;
             if (TRACK) br.last_sym = before - br.nbits;
         }
         const int r = rs >> 4, sz = rs & 15;
@@ -618,7 +630,7 @@ int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, in
             const int32_t bits = (int32_t)br.peek(sz);
             br.drop(sz);
             rbl -= sz;
-            hist = (hist << sz) | (uint32_t)bits; // the general path reads the magnitude with get_bits: it rotates back in
+            if (HIST) hist = (hist << sz) | (uint32_t)bits; // the general path reads the magnitude with get_bits: it rotates back in
             if (TRACK) br.last_sym += sz;
             // EXTEND (T.81 F.2.2.1) without a branch: values below 2^(sz-1) are negative
             const int32_t v = bits + ((((bits - (1 << (sz - 1))) >> 31)) & (1 - (1 << sz)));
@@ -767,8 +779,9 @@ int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p,
             for (int v = 0; v < cm.v; v++)
                 for (int h = 0; h < cm.h; h++) {
                     int16_t* blk = block_at(cm, mx * cm.h + h, my * cm.v + v);
-                    int rc = near_end ? decode_block_baseline<true>(d, br, cm, pred[d->order[ci]], blk, err)
-                                      : decode_block_baseline<false>(d, br, cm, pred[d->order[ci]], blk, err);
+                    int rc = d->track_hist ? decode_block_baseline<true, true>(d, br, cm, pred[d->order[ci]], blk, err)
+                           : near_end ? decode_block_baseline<true, false>(d, br, cm, pred[d->order[ci]], blk, err)
+                                      : decode_block_baseline<false, false>(d, br, cm, pred[d->order[ci]], blk, err);
                     if (rc) return rc;
                 }
         }
@@ -843,8 +856,9 @@ int scan_baseline(zj_decoder* d, BitReader& br)
                     for (int h = 0; h < cm.h; h++) {
                         const char* err = nullptr;
                         int16_t* blk = block_at(cm, mx * cm.h + h, my * cm.v + v);
-                        int rc = near_end ? decode_block_baseline<true>(d, br, cm, cm.dc_pred, blk, &err)
-                                          : decode_block_baseline<false>(d, br, cm, cm.dc_pred, blk, &err);
+                        int rc = d->track_hist ? decode_block_baseline<true, true>(d, br, cm, cm.dc_pred, blk, &err)
+                               : near_end ? decode_block_baseline<true, false>(d, br, cm, cm.dc_pred, blk, &err)
+                                          : decode_block_baseline<false, false>(d, br, cm, cm.dc_pred, blk, &err);
                         if (rc) { clear_from(my, mx); return fail(d, rc, err); }
                     }
             }
@@ -1266,7 +1280,25 @@ int next_marker(BitReader& br)
 
 // for_device: a baseline scan the GPU entropy stage can take is only PREPARED (prepare_scan: scan_ready instead of
 // coef_valid); everything else is decoded here as always
+int decode_all_once(zj_decoder* d, const uint8_t* buf, size_t len, bool headers_only, bool for_device);
+
+// The image is decoded WITHOUT the reference reader's bit history first (round 4: the history costs the Huffman loop 9-13 %,
+// and only a short DC read ever looks at it -- 78 in 1 500 quality-100 noise files, none in ordinary images); the first
+// block with a short read returns ZJ_INT_NEED_HIST and the whole image is decoded again with the history on.
 int decode_all(zj_decoder* d, const uint8_t* buf, size_t len, bool headers_only, bool for_device = false)
+{
+    d->track_hist = false;
+    int rc = decode_all_once(d, buf, len, headers_only, for_device);
+    if (rc == ZJ_INT_NEED_HIST) {
+        d->track_hist = true;
+        d->hist_retries++;
+        rc = decode_all_once(d, buf, len, headers_only, false);
+        d->track_hist = false;
+    }
+    return rc;
+}
+
+int decode_all_once(zj_decoder* d, const uint8_t* buf, size_t len, bool headers_only, bool for_device)
 {
     d->err.clear(); d->err_code = 0; d->seen_sof = 0; d->scans = 0; d->restart_interval = 0;
     d->coef_valid = false; d->scan_ready = false; d->src = nullptr; d->src_len = 0;
