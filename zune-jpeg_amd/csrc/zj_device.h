@@ -801,7 +801,10 @@ ZJ_DEV TileId tile_from_id(const Params& p, const int id)
 }
 // XCD-aware order: hardware sends workgroup b to XCD b % 8; give each XCD a contiguous run of `n` units
 // so neighbouring tiles (which share halo blocks) meet in the same L2.
-ZJ_DEV int xcd_order(const int bid, const int n) { return (n & 7) == 0 ? (bid & 7) * (n >> 3) + (bid >> 3) : bid; }
+#ifndef ZJ_XCD_ORDER
+#define ZJ_XCD_ORDER 1 // 0: workgroup b decodes tile b (A/B knob, round 4)
+#endif
+ZJ_DEV int xcd_order(const int bid, const int n) { return (ZJ_XCD_ORDER && (n & 7) == 0) ? (bid & 7) * (n >> 3) + (bid >> 3) : bid; }
 ZJ_DEV TileId decode_tile(const Params& p, int bid) { return tile_from_id(p, xcd_order(bid, p.total_tiles)); }
 
 // ------------------------------------------------------------------------------------------------
