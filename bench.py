@@ -349,6 +349,8 @@ def main():
                     help="after the timed region: every rank's decoded RGB frames gathered to rank 0 (RCCL over xGMI), "
                          "reported separately as `gather_rgb`, never part of `value` (SURVEY.md 8e, optional)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the pinned-host end-to-end figure (e2e_pinned)")
+    ap.add_argument("--no-prewarm", action="store_true", help="do not settle the clocks with another kernel before the first launch")
+    ap.add_argument("--no-dense-control", action="store_true", help="skip roofline.dense_control (profiler runs that should see only the shard's launches)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="420-rgb",
                     help="420-rgb = BASELINE.json configs[1]/[4] (the headline); 444-* are configs[2]; 422 / 440 the reference's "
                          "other sampling modes; 420-rgba / 420-chw are the output extensions (4 B/px interleaved, planar u8)")
@@ -437,8 +439,18 @@ def main():
         p = subs[k % nsub]
         ctx.decode_planes_device(desc, B, p[0], p[1], p[2], p[3], stream)
 
-    # the first ~70 launches after idle run 5-35 % slow while the clocks settle: whatever --warmup says, at least
-    # --min-untimed (100) untimed launches precede the timed region (the W warmup steps are part of them)
+    # The first ~70 launches after idle run 5-35 % slow while the clocks settle.  Two measures: (1) half a second of another
+    # kernel (a torch elementwise pass over the output buffer, which the decode overwrites anyway) brings the clocks up BEFORE
+    # the first fused launch, so that a profiler's average over ALL launches of the fused kernel (rocprofv3 --stats,
+    # profiles/*kernel_stats.csv) describes the same steady state as the HIP events do; (2) whatever --warmup says, at least
+    # --min-untimed (100) untimed launches precede the timed region (the W warmup steps are part of them).
+    if not args.no_prewarm:
+        t_pw = time.perf_counter()
+        with torch.cuda.stream(side):
+            while time.perf_counter() - t_pw < 0.5:
+                for _ in range(8):
+                    d_out[:B * frame_out].add_(1)
+                side.synchronize()
     untimed = max(args.warmup, args.min_untimed, nsub)
     for k in range(untimed):
         step(k)
@@ -484,7 +496,7 @@ def main():
     # (row 1, column 7) set to 1 in every block -- no DC-only block, nothing sparse about any column -- must therefore decode at
     # the same rate (the output differs, of course).  Reported beside the headline, never as it.
     dense_ms = None
-    if not args.child:
+    if not args.child and not args.no_dense_control:
         dpl = [d_planes[c][:B * plane_elems[c]].clone() for c in range(3)]
         for t_ in dpl:
             t_.view(-1, 64)[:, 15] = 1
