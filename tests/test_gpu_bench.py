@@ -56,6 +56,8 @@ def test_single_rank_line_has_the_contract_fields():
     assert rf["single_frame_launch"]["kernel_ms"] > 0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert rf["kernel_launches_timed"] >= 100                       # whatever --steps says
+    dc = rf["dense_control"]                                        # no sparsity shortcut: a dense input decodes at the same rate
+    assert dc["kernel_ms"] > 0 and abs(dc["kernel_ms"] - rf["kernel_ms"]) < 0.1 * rf["kernel_ms"], (dc, rf["kernel_ms"])
     assert res["per_rank_ms"] == [res["ms_per_step"]] or abs(res["per_rank_ms"][0] - res["ms_per_step"]) < 0.01
     e = res["e2e_pinned"]
     assert "error" not in e, e
