@@ -2,12 +2,13 @@
 //! names follow the reference crate (`Decoder`, `ZuneJpegOptions`, `ColorSpace`, the three fn-pointer types of
 //! `src/decoder.rs:47,56` and `src/components.rs:14`).
 //!
-//! The C side is `include/zjhip.h` (ABI version 5, checked at run time by `Decoder::new_with_options`).  Output bytes equal the reference's *scalar* arms.
+//! The C side is `include/zjhip.h` (ABI version 6, checked at run time by `Decoder::new_with_options`).  Output bytes equal the reference's *scalar* arms.
 #![allow(non_camel_case_types)]
 use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const ZJ_ABI_VERSION: c_int = 5;
+pub const ZJ_ABI_VERSION: c_int = 6;
+pub const ZJ_SCATTER_MAX: usize = 32;
 pub const ZJ_BACKEND_SCALAR: c_int = 0;
 pub const ZJ_BACKEND_AVX2: c_int = 1;
 pub const ZJ_BACKEND_HIP: c_int = 2;
@@ -69,6 +70,7 @@ pub struct zj_image_info {           // <-> ImageInfo, src/decoder.rs:652-668
 #[repr(C)] pub struct zj_ctx { _private: [u8; 0] }
 #[repr(C)] pub struct zj_decoder { _private: [u8; 0] }
 #[repr(C)] pub struct zj_pool { _private: [u8; 0] }
+#[repr(C)] pub struct zj_multi { _private: [u8; 0] }
 
 /// the C fn-pointer types `zj_choose_*` hand out (`include/zjhip.h`)
 pub type zj_idct_fn = unsafe extern "C" fn(*mut zj_ctx, *const i16, usize, *const i32, usize, usize, usize, *mut i16) -> c_int;
@@ -159,6 +161,34 @@ extern "C" {
     pub fn zj_sync(ctx: *mut zj_ctx) -> c_int;
     pub fn zj_set_variant(ctx: *mut zj_ctx, variant: c_int) -> c_int;
     pub fn zj_set_pipeline(ctx: *mut zj_ctx, on: c_int) -> c_int;
+    pub fn zj_decode_frames(ctx: *mut zj_ctx, d: *const zj_frame_desc, nframes: usize, y: *const *const i16,
+                            cb: *const *const i16, cr: *const *const i16, out: *const *mut u8) -> c_int;
+    pub fn zj_decode_planes_device_strided(ctx: *mut zj_ctx, d: *const zj_frame_desc, nframes: usize, d_y: *const i16,
+                                           d_cb: *const i16, d_cr: *const i16, d_out: *mut u8, y_stride: usize,
+                                           c_stride: usize, out_stride: usize, stream: *mut c_void) -> c_int;
+    pub fn zj_decode_frames_device(ctx: *mut zj_ctx, d: *const zj_frame_desc, nframes: usize, d_y: *const *const i16,
+                                   d_cb: *const *const i16, d_cr: *const *const i16, d_out: *const *mut u8,
+                                   stream: *mut c_void) -> c_int;
+    pub fn zj_pointer_device(p: *const c_void) -> c_int;
+    pub fn zj_pool_create_multi(devices: *const c_int, ndev: c_int, threads_per_device: c_int, opt: *const zj_options,
+                                status: *mut c_int) -> *mut zj_pool;
+    pub fn zj_pool_devices(pool: *const zj_pool) -> c_int;
+    pub fn zj_pool_device_stats(pool: *mut zj_pool, slot: c_int, device: *mut c_int, gpu_seconds: *mut f64,
+                                files: *mut usize) -> c_int;
+    pub fn zj_shard_range(nframes: usize, slot: c_int, nslots: c_int, lo: *mut usize, hi: *mut usize);
+    pub fn zj_multi_create(devices: *const c_int, ndev: c_int, status: *mut c_int) -> *mut zj_multi;
+    pub fn zj_multi_destroy(m: *mut zj_multi);
+    pub fn zj_multi_devices(m: *const zj_multi) -> c_int;
+    pub fn zj_multi_ctx(m: *mut zj_multi, slot: c_int) -> *mut zj_ctx;
+    pub fn zj_multi_slot_stats(m: *mut zj_multi, slot: c_int, device: *mut c_int, frames: *mut usize) -> c_int;
+    pub fn zj_multi_decode_planes_batch(m: *mut zj_multi, d: *const zj_frame_desc, nframes: usize, y: *const i16,
+                                        cb: *const i16, cr: *const i16, out: *mut u8, statuses: *mut c_int) -> c_int;
+    pub fn zj_multi_decode_frames(m: *mut zj_multi, d: *const zj_frame_desc, nframes: usize, y: *const *const i16,
+                                  cb: *const *const i16, cr: *const *const i16, out: *const *mut u8,
+                                  statuses: *mut c_int) -> c_int;
+    pub fn zj_multi_decode_frames_device(m: *mut zj_multi, d: *const zj_frame_desc, nframes: usize, d_y: *const *const i16,
+                                         d_cb: *const *const i16, d_cr: *const *const i16, d_out: *const *mut u8,
+                                         statuses: *mut c_int) -> c_int;
 }
 
 fn check(rc: c_int, what: &str) {
@@ -201,6 +231,25 @@ upsampler!(upsample_hv_hip, zj_upsample_hv);
 pub fn ycbcr_to_rgb_hip_16(y: &[i16; 16], cb: &[i16; 16], cr: &[i16; 16], out: &mut [u8], pos: &mut usize) {
     check(unsafe { zj_ycbcr_to_rgb16(zj_default_ctx(), y.as_ptr(), cb.as_ptr(), cr.as_ptr(), out.as_mut_ptr(),
                                      out.len(), pos as *mut usize) }, "zj_ycbcr_to_rgb16");
+}
+
+/// Frames the caller owns as independent `Vec`s -- the shape the reference's own callers have (a fresh `Vec` per strip,
+/// `src/mcu.rs:238-250`; one `Vec<u8>` per decode, `src/decoder.rs:178`) -- decoded together: one pipelined pass over the
+/// GPU instead of one launch per frame (`zj_decode_frames`).  `frames[f]` = `[y, cb, cr]` coefficient planes of frame `f`.
+pub fn decode_frames(d: &zj_frame_desc, frames: &[[&[i16]; 3]]) -> Vec<Vec<u8>> {
+    let n_out = unsafe { zj_out_len(d) };
+    let mut outs: Vec<Vec<u8>> = frames.iter().map(|_| vec![0u8; n_out]).collect();
+    let y: Vec<*const i16> = frames.iter().map(|f| f[0].as_ptr()).collect();
+    let cb: Vec<*const i16> = frames.iter().map(|f| f[1].as_ptr()).collect();
+    let cr: Vec<*const i16> = frames.iter().map(|f| f[2].as_ptr()).collect();
+    let o: Vec<*mut u8> = outs.iter_mut().map(|v| v.as_mut_ptr()).collect();
+    for f in frames {
+        assert!(f[0].len() >= unsafe { zj_plane_len(d, 0) }, "luma plane too short");
+        if d.in_components == 3 { assert!(f[1].len() >= unsafe { zj_plane_len(d, 1) } && f[2].len() >= unsafe { zj_plane_len(d, 2) }, "chroma plane too short"); }
+    }
+    check(unsafe { zj_decode_frames(zj_default_ctx(), d, frames.len(), y.as_ptr(), cb.as_ptr(), cr.as_ptr(), o.as_ptr()) },
+          "zj_decode_frames");
+    outs
 }
 
 /// `IDCTPtr` (`src/decoder.rs:56`), `UpSampler` (`src/components.rs:14`), `ColorConvert16Ptr` (`src/decoder.rs:47`).

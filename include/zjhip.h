@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ZJ_ABI_VERSION 5
+#define ZJ_ABI_VERSION 6
 
 /* libzjhip.so is built with -fvisibility=hidden: the functions declared here are its whole dynamic symbol table */
 #if defined(__GNUC__) || defined(__clang__)
@@ -184,13 +184,33 @@ ZJ_API int zj_decode_planes(zj_ctx *ctx, const zj_frame_desc *d, const int16_t *
 /* nframes frames of identical geometry, planes and outputs contiguous frame after frame. */
 ZJ_API int zj_decode_planes_batch(zj_ctx *ctx, const zj_frame_desc *d, size_t nframes, const int16_t *y,
                            const int16_t *cb, const int16_t *cr, uint8_t *out);
+/* The same for frames that are INDEPENDENT allocations, the way the reference's callers own them (a fresh Vec per strip,
+ * src/mcu.rs:238-250; one Vec<u8> per decode, src/decoder.rs:178): y[f] / cb[f] / cr[f] / out[f] are frame f's host
+ * buffers (cb / cr may be NULL for ZJ_CS_GRAYSCALE output).  Same pipeline, one copy per frame and plane. */
+ZJ_API int zj_decode_frames(zj_ctx *ctx, const zj_frame_desc *d, size_t nframes, const int16_t *const *y,
+                     const int16_t *const *cb, const int16_t *const *cr, uint8_t *const *out);
 /* Device-resident variant (kernel-only path used by bench.py): all pointers are device pointers
  * on ctx's device, 16-byte aligned; frames contiguous.  Asynchronous on `stream` (a hipStream_t;
- * NULL = the ctx stream).  The frame's quantisation tables are uploaded on first use per ctx and
- * cached by value. */
+ * NULL = the ctx stream).  The frame's quantisation tables travel by value in the kernel arguments:
+ * nothing is uploaded, cached or ordered against other streams. */
 ZJ_API int zj_decode_planes_device(zj_ctx *ctx, const zj_frame_desc *d, size_t nframes,
                             const int16_t *d_y, const int16_t *d_cb, const int16_t *d_cr,
                             uint8_t *d_out, void *stream);
+/* Frames at a uniform distance instead of back to back (the images of one tensor with padding, the slots of an arena):
+ * y_stride / c_stride in int16 elements (multiples of 8), out_stride in bytes (a multiple of 16); 0 = packed.  ONE launch. */
+ZJ_API int zj_decode_planes_device_strided(zj_ctx *ctx, const zj_frame_desc *d, size_t nframes, const int16_t *d_y,
+                                    const int16_t *d_cb, const int16_t *d_cr, uint8_t *d_out, size_t y_stride,
+                                    size_t c_stride, size_t out_stride, void *stream);
+/* Scattered batch: nframes frames of ONE geometry whose planes and pixels are independent device allocations, in any
+ * order.  d_y / d_cb / d_cr / d_out are HOST arrays of nframes device pointers (each 16-byte aligned; d_cb / d_cr may be
+ * NULL for ZJ_CS_GRAYSCALE output); they are read during the call -- the addresses travel in the kernel arguments, up to
+ * ZJ_SCATTER_MAX frames per launch, nothing is staged and nothing has to outlive the call.  Frames that turn out to be
+ * equally spaced share one launch whatever their number.  A caller with two or more frames in hand should use this (or a
+ * contiguous batch) instead of one launch per frame: a launch of one 4096x4096 frame is 1.3 waves of workgroups and runs
+ * at 0.49-0.54 of the HBM peak, a launch of 16 at 0.70.  Asynchronous on `stream`. */
+#define ZJ_SCATTER_MAX 32
+ZJ_API int zj_decode_frames_device(zj_ctx *ctx, const zj_frame_desc *d, size_t nframes, const int16_t *const *d_y,
+                            const int16_t *const *d_cb, const int16_t *const *d_cr, uint8_t *const *d_out, void *stream);
 /* Times zj_decode_planes_device with HIP events recorded on the launch stream: *ms_total = `iters`
  * back-to-back launches between one event pair; *ms_each (optional) = mean over `iters` launches
  * each bracketed by its own event pair; *kernel_name = the dominant kernel. */
@@ -208,9 +228,8 @@ ZJ_API int zj_decode_planes_to_device(zj_ctx *ctx, const zj_frame_desc *d, const
 ZJ_API int zj_decode_scan(zj_ctx *ctx, const zj_frame_desc *d, const void *blob, size_t blob_bytes, uint8_t *out,
                    int out_on_device, unsigned *status_bits);
 /* The same for up to ZJ_SCAN_BATCH_MAX prepared scans of any geometry at once: every phase of the entropy stage is ONE
- * launch over all of them (a single file leaves most of the GPU idle); consecutive scans of one geometry and one set of
- * tables whose outputs are equally spaced (host outputs always are, through a staging arena; device outputs when the
- * caller's pointers are, e.g. the images of one tensor) also share ONE pixel-kernel launch.  rcs[k] = ZJ_OK, ZJ_RETRY_CPU
+ * launch over all of them (a single file leaves most of the GPU idle); the scans of one geometry and one set of tables
+ * also share ONE pixel-kernel launch, wherever their outputs lie (zj_decode_frames_device's scattered form).  rcs[k] = ZJ_OK, ZJ_RETRY_CPU
  * or a zj_status of scan k; status_bits[k] optional.  The return value reports failures of the call itself. */
 #define ZJ_SCAN_BATCH_MAX 16
 ZJ_API int zj_decode_scans(zj_ctx *ctx, size_t n, const zj_frame_desc *descs, const void *const *blobs, const size_t *blob_bytes,
@@ -297,6 +316,17 @@ ZJ_API int zj_decoder_parallel_segments(const zj_decoder *d);
  * the zj_status of file i; the return value is the first error seen (ZJ_OK if none), text via zj_pool_error. */
 typedef struct zj_pool zj_pool;
 ZJ_API zj_pool *zj_pool_create(int device, int threads, const zj_options *opt, int *status);
+/* Image-level sharding across the GPUs of one node, inside the library (north_star): one pool over `ndev`
+ * device slots (devices[k] = HIP device of slot k; a device may fill several slots), threads_per_device entropy workers
+ * per slot.  Every slot has its own submitters and contexts; workers and pinned plane sets are shared.  Files whose
+ * pixels go to host memory are taken by whichever slot is free (dealt by readiness, so a slow GPU does not hold up a
+ * fixed share); with zj_pool_decode_files_device each file goes to the slot(s) of the device that owns its output pointer
+ * (zj_pointer_device), so a caller shards by allocating output i on device i * ndev / nfiles.  Results are in the caller's
+ * order either way.  The 8-GPU node: devices = {0,...,7}. */
+ZJ_API zj_pool *zj_pool_create_multi(const int *devices, int ndev, int threads_per_device, const zj_options *opt, int *status);
+ZJ_API int zj_pool_devices(const zj_pool *pool);              /* device slots */
+/* of one slot, accumulated since creation: its HIP device, seconds inside its GPU stage, files it finished */
+ZJ_API int zj_pool_device_stats(zj_pool *pool, int slot, int *device, double *gpu_seconds, size_t *files);
 ZJ_API void zj_pool_destroy(zj_pool *pool);
 ZJ_API int zj_pool_threads(const zj_pool *pool);
 ZJ_API const char *zj_pool_error(const zj_pool *pool);
@@ -313,11 +343,37 @@ ZJ_API int zj_pool_decode_files_device(zj_pool *pool, size_t nfiles, const uint8
                                 uint8_t *const *d_outs, const size_t *out_caps, size_t *out_lens /*[nfiles] or NULL*/,
                                 zj_image_info *infos /*[nfiles] or NULL*/, int *statuses /*[nfiles] or NULL*/);
 
+/* ---- image-level sharding of plane batches across the GPUs of one node ------------------------------
+ * Frames are independent, so N frames over D device slots are D contiguous shards (zj_shard_range: sizes differ by at
+ * most one; the same rule as bench.py's ranks) and no collective.  A zj_multi owns one context and one persistent host
+ * thread per slot ("one host thread per GPU"); a call runs every slot's shard at once through that slot's three-stream
+ * pipeline and returns when all are done.  statuses[slot] (optional) = that shard's zj_status; the return value is the
+ * first error.  devices[k] may repeat (two slots on one GPU).  The 8-GPU node: devices = {0,...,7}. */
+typedef struct zj_multi zj_multi;
+ZJ_API void zj_shard_range(size_t nframes, int slot, int nslots, size_t *lo, size_t *hi); /* [lo, hi) of slot */
+ZJ_API zj_multi *zj_multi_create(const int *devices, int ndev, int *status);
+ZJ_API void zj_multi_destroy(zj_multi *m);
+ZJ_API int zj_multi_devices(const zj_multi *m);
+ZJ_API zj_ctx *zj_multi_ctx(zj_multi *m, int slot);            /* slot's context (owned by m), e.g. for zj_device_alloc */
+ZJ_API int zj_multi_slot_stats(zj_multi *m, int slot, int *device, size_t *frames); /* frames decoded since creation */
+/* zj_decode_planes_batch / zj_decode_frames, sharded: host planes (pinned: zj_alloc_pinned) -> host pixels */
+ZJ_API int zj_multi_decode_planes_batch(zj_multi *m, const zj_frame_desc *d, size_t nframes, const int16_t *y,
+                                 const int16_t *cb, const int16_t *cr, uint8_t *out, int *statuses /*[slots] or NULL*/);
+ZJ_API int zj_multi_decode_frames(zj_multi *m, const zj_frame_desc *d, size_t nframes, const int16_t *const *y,
+                           const int16_t *const *cb, const int16_t *const *cr, uint8_t *const *out, int *statuses);
+/* zj_decode_frames_device, sharded: frame f's pointers must live on the device of the slot whose shard holds f;
+ * returns once every shard is complete */
+ZJ_API int zj_multi_decode_frames_device(zj_multi *m, const zj_frame_desc *d, size_t nframes, const int16_t *const *d_y,
+                                  const int16_t *const *d_cb, const int16_t *const *d_cr, uint8_t *const *d_out,
+                                  int *statuses);
+
 /* ---- memory helpers ------------------------------------------------------------------------- */
 ZJ_API void *zj_alloc_pinned(size_t bytes); /* hipHostMalloc, portable (usable as a DMA source/target from every device); NULL on failure */
 /* binds the CALLING thread to `device` (hipSetDevice): host threads that only allocate pinned memory or fill planes for a
  * context on device N call this first, so they neither initialise nor pin against device 0 */
 ZJ_API int zj_set_thread_device(int device);
+/* the HIP device that owns device pointer p (>= 0), ZJ_ERR_ARG for host memory or an unknown pointer */
+ZJ_API int zj_pointer_device(const void *p);
 ZJ_API void zj_free_pinned(void *p);
 ZJ_API void *zj_device_alloc(zj_ctx *ctx, size_t bytes);
 ZJ_API void zj_device_free(zj_ctx *ctx, void *p);

@@ -100,6 +100,19 @@ extern "C" int zje_threads_per_group(const zj_frame_desc* d)
     return rc ? rc : pl.nt;
 }
 
+static int dispatch(const Plan& pl, const Params& p)
+{
+#define ZJ_CASE(H, V, O) if (pl.hs == H && pl.vs == V && pl.out == O) { if (pl.fast) run<H, V, O, true>(p); else run<H, V, O, false>(p); return ZJ_OK; }
+    ZJ_CASE(1, 1, OUT_RGB) ZJ_CASE(1, 1, OUT_GRAY) ZJ_CASE(1, 1, OUT_YCBCR)
+    ZJ_CASE(2, 1, OUT_RGB) ZJ_CASE(2, 1, OUT_GRAY) ZJ_CASE(2, 1, OUT_YCBCR)
+    ZJ_CASE(1, 2, OUT_RGB) ZJ_CASE(1, 2, OUT_GRAY) ZJ_CASE(1, 2, OUT_YCBCR)
+    ZJ_CASE(2, 2, OUT_RGB) ZJ_CASE(2, 2, OUT_GRAY) ZJ_CASE(2, 2, OUT_YCBCR)
+    ZJ_CASE(1, 1, OUT_RGBA) ZJ_CASE(2, 1, OUT_RGBA) ZJ_CASE(1, 2, OUT_RGBA) ZJ_CASE(2, 2, OUT_RGBA)
+    ZJ_CASE(1, 1, OUT_RGB_CHW) ZJ_CASE(2, 1, OUT_RGB_CHW) ZJ_CASE(1, 2, OUT_RGB_CHW) ZJ_CASE(2, 2, OUT_RGB_CHW)
+#undef ZJ_CASE
+    return ZJ_ERR_UNSUPPORTED;
+}
+
 extern "C" int zje_decode_planes(const zj_frame_desc* d, size_t nframes, const int16_t* y,
                                  const int16_t* cb, const int16_t* cr, uint8_t* out, int zero_fill)
 {
@@ -115,15 +128,31 @@ extern "C" int zje_decode_planes(const zj_frame_desc* d, size_t nframes, const i
         for (size_t f = 0; f < nframes; f++)
             for (int r = 0; r < nr; r++) memset(out + f * pl.out_len + off[r], 0, len[r]);
     }
-#define ZJ_CASE(H, V, O) if (pl.hs == H && pl.vs == V && pl.out == O) { if (pl.fast) run<H, V, O, true>(p); else run<H, V, O, false>(p); return ZJ_OK; }
-    ZJ_CASE(1, 1, OUT_RGB) ZJ_CASE(1, 1, OUT_GRAY) ZJ_CASE(1, 1, OUT_YCBCR)
-    ZJ_CASE(2, 1, OUT_RGB) ZJ_CASE(2, 1, OUT_GRAY) ZJ_CASE(2, 1, OUT_YCBCR)
-    ZJ_CASE(1, 2, OUT_RGB) ZJ_CASE(1, 2, OUT_GRAY) ZJ_CASE(1, 2, OUT_YCBCR)
-    ZJ_CASE(2, 2, OUT_RGB) ZJ_CASE(2, 2, OUT_GRAY) ZJ_CASE(2, 2, OUT_YCBCR)
-    ZJ_CASE(1, 1, OUT_RGBA) ZJ_CASE(2, 1, OUT_RGBA) ZJ_CASE(1, 2, OUT_RGBA) ZJ_CASE(2, 2, OUT_RGBA)
-    ZJ_CASE(1, 1, OUT_RGB_CHW) ZJ_CASE(2, 1, OUT_RGB_CHW) ZJ_CASE(1, 2, OUT_RGB_CHW) ZJ_CASE(2, 2, OUT_RGB_CHW)
-#undef ZJ_CASE
-    return ZJ_ERR_UNSUPPORTED;
+    return dispatch(pl, p);
+}
+
+// the scattered form (zj_decode_frames_device): per-frame pointers through the launch's table, in launches of at most
+// SCATTER_MAX frames, exactly as decode_frames_device_impl of zj_api.cpp cuts them
+extern "C" int zje_decode_frames(const zj_frame_desc* d, size_t nframes, const int16_t* const* y, const int16_t* const* cb,
+                                 const int16_t* const* cr, uint8_t* const* out, int zero_fill)
+{
+    Plan pl;
+    int rc = make_plan(d, pl);
+    if (rc) return rc;
+    g_cls[0] = g_cls[1] = g_cls[2] = g_redo = 0;
+    const bool chroma = pl.out != OUT_GRAY;
+    size_t off[3], len[3];
+    const int nr = zero_fill ? uncovered_ranges(d, pl, off, len) : 0;
+    for (size_t f0 = 0; f0 < nframes; f0 += SCATTER_MAX) {
+        const int n = (int)(nframes - f0 < (size_t)SCATTER_MAX ? nframes - f0 : (size_t)SCATTER_MAX);
+        Params p;
+        fill_params(d, pl, (size_t)n, nullptr, nullptr, nullptr, nullptr, zero_fill, p);
+        set_scatter(p, y, chroma ? cb : nullptr, chroma ? cr : nullptr, out, f0, n);
+        for (int f = 0; f < n; f++)
+            for (int r = 0; r < nr; r++) memset(out[f0 + f] + off[r], 0, len[r]);
+        if ((rc = dispatch(pl, p))) return rc;
+    }
+    return ZJ_OK;
 }
 
 // ---- block level: the two transforms and the guard on their own (tests/test_packed_idct.py) -------------------

@@ -111,3 +111,23 @@ def huff_decode(blob, plane_lens):
     if rc:
         raise RuntimeError(f"zje_huff_decode: {rc}")
     return planes[: len(plane_lens)], int(status.value), dict(rounds=stats[0], nsub=stats[1], decodes=stats[2], first_seen=stats[3])
+
+
+def decode_frames(frame, frames_planes, order=None, zero_fill=1, poison=0xAA, flags=0, out_layout=0):
+    """The scattered form: frames_planes[f] = the planes of frame f, each an allocation of its own; the launch table is
+    filled in `order` (a permutation; default: reversed) so that table index != allocation order.  Returns (rc, [out per
+    frame])."""
+    n = len(frames_planes)
+    order = list(range(n))[::-1] if order is None else list(order)
+    d = FrameDesc()
+    for name in ("width", "height", "h_max", "v_max", "in_components", "out_colorspace"):
+        setattr(d, name, getattr(frame, name))
+    C.memmove(d.qt, frame.qt, 3 * 64 * 4)
+    d.flags, d.out_layout = flags, out_layout
+    ncomp = {0: 3, 1: 1, 2: 3, 5: 4, 6: 4}[d.out_colorspace]
+    arrs = [[np.ascontiguousarray(p, np.int16) for p in pl] + [np.zeros(8, np.int16)] * (3 - len(pl)) for pl in frames_planes]
+    outs = [np.full(d.width * d.height * ncomp, poison, np.uint8) for _ in range(n)]
+    tab = [(C.c_void_p * n)(*[arrs[f][c].ctypes.data for f in order]) for c in range(3)]
+    otab = (C.c_void_p * n)(*[outs[f].ctypes.data for f in order])
+    rc = lib().zje_decode_frames(C.byref(d), C.c_size_t(n), tab[0], tab[1], tab[2], otab, C.c_int(zero_fill))
+    return rc, outs

@@ -61,7 +61,7 @@ def test_no_oracle_in_product_library(zj):
 
 def test_host_only_entry_points(zj):
     L = zj.lib()
-    assert L.zj_abi_version() == 5
+    assert L.zj_abi_version() == 6
     assert L.zj_strerror(0) == b"ok"
     assert b"panic" in L.zj_strerror(-5)
     qts = [np.ones(64, np.int32)] * 3
@@ -124,6 +124,76 @@ def test_rust_shim_declares_every_symbol():
     want = int(re.search(r"#define ZJ_ABI_VERSION (\d+)", open(os.path.join(root, "include", "zjhip.h")).read()).group(1))
     assert int(re.search(r"pub const ZJ_ABI_VERSION: c_int = (\d+);", rs).group(1)) == want
     assert f"ABI version {want}" in rs and "ABI version 2" not in rs
+
+
+def _abi_texts():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return (open(os.path.join(root, "include", "zjhip.h")).read(),
+            open(os.path.join(root, "bindings", "rust", "src", "lib.rs")).read())
+
+
+def test_rust_shim_types_match_the_header():
+    """No rustc anywhere on this pool, so the one thing a compiler + bindgen would prove is checked here by hand: every
+    extern fn's return and argument TYPES (pointer depth and constness included: `*const *mut u8` <-> `uint8_t *const *`,
+    `usize` <-> `size_t`, `c_int` <-> `int`), the three fn-pointer typedefs and the field order / types / array shapes of
+    the four #[repr(C)] structs agree with include/zjhip.h (tests/abi_types.py).  Surface: src/decoder.rs:47,56,
+    src/components.rs:14 of the reference."""
+    import abi_types
+    hdr, rs = _abi_texts()
+    assert len(abi_types.c_prototypes(hdr)) == len(header_functions()) >= 70
+    assert set(abi_types.c_structs(hdr)) == {"zj_component", "zj_frame_desc", "zj_options", "zj_image_info"}
+    assert set(abi_types.c_fn_typedefs(hdr)) == {"zj_idct_fn", "zj_upsample_fn", "zj_color_convert16_fn"}
+    assert abi_types.compare(hdr, rs) == []
+
+
+@pytest.mark.parametrize("side,old,new,expect", [
+    ("h", "const int16_t *coeff, size_t n, const int32_t qt[64]", "const int16_t *coeff, int n, const int32_t qt[64]", "zj_idct_strip: parameter 2"),
+    ("h", "ZJ_API size_t zj_out_len(", "ZJ_API int zj_out_len(", "zj_out_len: return type"),
+    ("h", "uint32_t flags;          /* 0 = the reference", "int32_t flags;          /* 0 = the reference", "struct zj_frame_desc"),
+    ("h", "const int16_t *const *d_cb, const int16_t *const *d_cr, uint8_t *const *d_out, void *stream);",
+          "const int16_t *const *d_cb, const int16_t **d_cr, uint8_t *const *d_out, void *stream);", "zj_decode_frames_device: parameter 5"),
+    ("r", "pub scans: u16, pub restart_interval: u16", "pub scans: u32, pub restart_interval: u16", "struct zj_image_info"),
+    ("r", "pub fn zj_plane_len(d: *const zj_frame_desc, comp: c_int) -> usize;", "pub fn zj_plane_len(d: *mut zj_frame_desc, comp: c_int) -> usize;", "zj_plane_len: parameter 0"),
+    ("r", "pub quantization_table: [i32; 64],", "pub quantization_table: [i32; 32],", "struct zj_component"),
+    ("r", "fn(*mut zj_ctx, *const i16, usize, *mut i16, usize) -> c_int;", "fn(*mut zj_ctx, *const i16, usize, *mut i16, u32) -> c_int;", "fn type zj_upsample_fn"),
+    ("r", "pub max_scans: i32, pub num_threads: i32,", "pub num_threads: i32, pub max_scans: i32,", "struct zj_options"),
+])
+def test_rust_shim_type_check_notices_a_changed_type(side, old, new, expect):
+    """the check above fails when ONE type, on either side, is changed"""
+    import abi_types
+    hdr, rs = _abi_texts()
+    src = hdr if side == "h" else rs
+    assert src.count(old) == 1, old
+    mutated = src.replace(old, new)
+    bad = abi_types.compare(mutated if side == "h" else hdr, mutated if side == "r" else rs)
+    assert len(bad) == 1 and bad[0].startswith(expect), bad
+
+
+def test_shard_range_matches_the_python_harness(zj):
+    """zj_shard_range (the library's dealer) and shard.shard_range (bench.py's ranks) are the same rule"""
+    shard = importlib.import_module("zune-jpeg_amd.shard")
+    for n in (0, 1, 7, 8, 128, 1000, 1024, 1025):
+        for w in (1, 2, 3, 8):
+            got = [zj.shard_range(n, r, w) for r in range(w)]
+            assert got == [shard.shard_range(n, r, w) for r in range(w)]
+            assert got[0][0] == 0 and got[-1][1] == n and all(a[1] == b[0] for a, b in zip(got, got[1:]))
+    assert zj.shard_range(10, 5, 4) == (0, 0) and zj.shard_range(10, -1, 4) == (0, 0)
+
+
+def test_multi_device_entry_points_fail_loudly_without_gpu(zj):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(zj.ZjError) as e:
+        zj.Multi([0, 0])
+    assert e.value.status == -6
+    with pytest.raises(zj.ZjError) as e:
+        zj.Pool(threads=1, devices=[0, 0])
+    assert e.value.status == -6
+    st = C.c_int(0)
+    assert not zj.lib().zj_pool_create_multi(None, 2, 1, None, C.byref(st)) and st.value == -1
+    assert not zj.lib().zj_multi_create(None, 0, C.byref(st)) and st.value == -1
+    assert zj.pointer_device(None) == -1
 
 
 def test_rust_shim_facade_mirrors_the_reference_surface():

@@ -191,3 +191,41 @@ def test_emulated_corrected_mode_flags(mode, flags, out_cs, layout, wh, compact,
         assert rce == 0
         bad = np.nonzero(out != exp)[0]
         assert bad.size == 0, (mode, flags, out_cs, layout, wh, adversarial, bad[:8])
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("out_cs", [oc.RGB, oc.GRAYSCALE, oc.YCBCR])
+@pytest.mark.parametrize("wh,n", [((64, 64), 5), ((272, 40), 3), ((37, 50), 4)])
+def test_emulated_scattered_frames_match_oracle(mode, out_cs, wh, n, synth):
+    """zj_decode_frames_device's form: every frame an allocation of its own, the launch's pointer table filled in an
+    order that is not the allocation order (Params::fptr, set_scatter)."""
+    hs, vs = MODES[mode]
+    w, h = wh
+    frames = [synth.make_frame(w, h, hs, vs, 3, seed=77, frame_index=i) for i in range(n)]
+    f = oc.make_frame(w, h, hs, vs, 3, out_cs, frames[0][1])
+    order = [(3 * i + 1) % n for i in range(n)] if n % 3 else list(range(n))[::-1]
+    rc, outs = emu_c.decode_frames(f, [fr[0] for fr in frames], order=order)
+    orc = oc.decode_planes(f, frames[0][0])[0]
+    if orc != 0:  # a geometry on which the reference panics (padded width, GRAYSCALE): the same verdict, nothing decoded
+        assert rc == -5
+        return
+    assert rc == 0
+    for i, fr in enumerate(frames):
+        rc, exp = oc.decode_planes(f, fr[0])
+        assert rc == 0
+        assert np.array_equal(outs[i], exp), (mode, out_cs, wh, i)
+
+
+def test_emulated_scattered_more_frames_than_one_table(synth):
+    """More frames than a launch's table holds (SCATTER_MAX = 32): cut into launches, every frame still lands where its
+    own pointer says; zero_fill = 0 leaves the never-written bytes alone in every frame."""
+    w, h, n = 32, 16, 70
+    frames = [synth.make_frame(w, h, 2, 1, 3, seed=3, frame_index=i % 7) for i in range(n)]
+    f = oc.make_frame(w, h, 2, 1, 3, oc.RGB, frames[0][1])
+    rc, outs = emu_c.decode_frames(f, [fr[0] for fr in frames], zero_fill=0, poison=0x33)
+    assert rc == 0
+    exps = [oc.decode_planes(f, frames[i][0])[1].reshape(h, 3 * w) for i in range(7)]
+    for i in range(n):
+        got = outs[i].reshape(h, 3 * w)
+        assert np.array_equal(got[:, :3 * w - 16], exps[i % 7][:, :3 * w - 16]), i
+        assert (got[:, 3 * w - 16:] == 0x33).all()

@@ -17,6 +17,7 @@
 #include "zj_plan.h"
 
 using namespace zj;
+static_assert(SCATTER_MAX == ZJ_SCATTER_MAX, "include/zjhip.h and zj_device.h disagree");
 
 namespace {
 constexpr int N_SCRATCH = 4;
@@ -50,9 +51,9 @@ struct zj_ctx {
     int debug = 0;                // ablation switches, diagnostic build only (results are WRONG when set)
 #endif
     int variant = 0;              // kernel variant: 0 packed generation (default), 1 wide generation (round 1), 2 packed with direct stores
-    // first-wave stagger of short launches (zj_kernels.hip: stagger_start): workgroup slots of the device, delay per
-    // step, and the largest grid that still gets it
-    int stagger_wgs = 0, stagger_delay = 0, stagger_max_tiles = 0;
+    // first-wave stagger of short launches (zj_kernels.hip: stagger_start, launch_params below): CUs of the device, delay
+    // per step
+    int cus = 256, stagger_delay = 0;
     // GPU entropy stage (zj_decode_scan): blob + working set, the three planes (contiguous), control words read back
     // one slot per scan of a batch (zj_decode_scans): blob + working set | planes | pixels on their way to host memory
     struct HuffSlot { void* buf = nullptr; size_t cap = 0; void* planes = nullptr; void* out = nullptr; };
@@ -166,11 +167,9 @@ zj_ctx* zj_ctx_create(int backend, int device, int* status)
     if (const char* e = getenv("ZJ_VARIANT")) { int v = atoi(e); if (v >= 0 && v <= 2) c->variant = v; }
     {
         hipDeviceProp_t prop;
-        const int cus = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
-        c->stagger_wgs = cus * 6;                     // six workgroups of the fused kernels per CU (LDS, VGPRs)
-        c->stagger_max_tiles = 2 * c->stagger_wgs;
-        c->stagger_delay = 16;                        // x 128 cycles per slot group; 0 = off (ZJ_STAGGER: A/B knob)
-        if (const char* e = getenv("ZJ_STAGGER")) { const int v = atoi(e); if (v >= 0 && v < 1024) c->stagger_delay = v; }
+        c->cus = hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        c->stagger_delay = 16;                        // x 128 cycles per slot group; 0 = off (ZJ_STAGGER: the escape hatch)
+        if (const char* e = getenv("ZJ_STAGGER")) { const int v = atoi(e); if (v >= 0 && v < 256) c->stagger_delay = v; }
     }
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
@@ -273,6 +272,15 @@ int zj_set_thread_device(int device)
     return hipSetDevice(device) == hipSuccess ? ZJ_OK : ZJ_ERR_HIP;
 }
 void zj_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
+int zj_pointer_device(const void* p)
+{
+    if (!p) return ZJ_ERR_ARG;
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return ZJ_ERR_ARG; }
+    if (a.type != hipMemoryTypeDevice) return ZJ_ERR_ARG;
+    return a.device;
+}
 void* zj_device_alloc(zj_ctx* c, size_t bytes)
 {
     if (!c || hipSetDevice(c->device) != hipSuccess) return nullptr;
@@ -305,26 +313,43 @@ int zj_sync(zj_ctx* c)
     return ZJ_OK;
 }
 
-/* ---- frame / batch level -------------------------------------------------------------------- */
-// plane_stride (int16 elements) / out_stride (bytes): distance between the frames' planes / pixels when they are not packed
-// back to back (0: they are)
-static int decode_device_impl(zj_ctx* c, const zj_frame_desc* d, const Plan& pl, size_t nframes,
-                              const int16_t* d_y, const int16_t* d_cb, const int16_t* d_cr,
-                              uint8_t* d_out, hipStream_t s, int zero_fill, long long plane_stride = 0, long long out_stride = 0)
+// The launch itself, shared by the contiguous / strided form and the scattered form.
+static int launch_params(zj_ctx* c, const Plan& pl, Params& p, hipStream_t s)
 {
-    Params p; // carries the quantisation tables by value: nothing to stage, nothing to order across streams
-    fill_params(d, pl, nframes, d_y, d_cb, d_cr, d_out, zero_fill, p);
 #if defined(ZJ_ABLATION)
     p.debug = c->debug;
 #endif
-    if (plane_stride) p.y_frame_stride = p.c_frame_stride = plane_stride;
-    if (out_stride) p.out_frame_stride = out_stride;
-    // Short launches of the 4:2:0 kernels (at most two waves of workgroups: one frame at a time, BASELINE configs[1] read
-    // literally) start their first wave staggered, see stagger_start in zj_kernels.hip: 27.9 -> 24.3 us per 4096x4096 frame
-    // (profiles/r04_single_frame.txt).  Measured for this tile shape only (six 256-thread workgroups per CU).
-    if (c->stagger_delay > 0 && p.total_tiles <= c->stagger_max_tiles && pl.hs == 2 && pl.vs == 2 && pl.out != OUT_GRAY && c->variant != 1) {
-        p.stagger_wgs = c->stagger_wgs; p.stagger_delay = c->stagger_delay;
+    // Short launches of the 4:2:0 kernels (between one and two waves of workgroups: one 4096x4096 frame at a time, BASELINE
+    // configs[1] read literally) start their first wave staggered, see stagger_start in zj_kernels.hip: 27.9 -> 24.3 us per
+    // frame (profiles/r04_single_frame.txt).  That is the only regime it was measured in, so it is the only one that gets
+    // it: a grid smaller than one wave of workgroups, or longer than two, starts as the hardware dispatches it.  The slots
+    // per CU are the occupancy of the instantiation that is launched, not a constant.
+    if (c->stagger_delay > 0 && pl.hs == 2 && pl.vs == 2 && pl.out != OUT_GRAY && c->variant != 1) {
+        const int slots = fused_slots_per_cu(pl.hs, pl.vs, pl.out, c->variant, pl.fast ? 1 : 0, p);
+        const int wgs = c->cus * slots;
+        if (slots >= 2 && p.total_tiles > wgs && p.total_tiles <= 2 * wgs) {
+            p.stagger_wgs = wgs; p.stagger_delay = c->stagger_delay;
+            const Magic g = magic_u31((uint32_t)c->cus);
+            p.stagger_magic = g.m; p.stagger_shift = g.s;
+        }
     }
+    ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->variant, pl.fast ? 1 : 0, p, s));
+    return ZJ_OK;
+}
+
+/* ---- frame / batch level -------------------------------------------------------------------- */
+// y_stride / c_stride (int16 elements) / out_stride (bytes): distance between the frames' planes / pixels when they are
+// not packed back to back (0: they are)
+static int decode_device_impl(zj_ctx* c, const zj_frame_desc* d, const Plan& pl, size_t nframes,
+                              const int16_t* d_y, const int16_t* d_cb, const int16_t* d_cr,
+                              uint8_t* d_out, hipStream_t s, int zero_fill, long long y_stride = 0, long long c_stride = 0,
+                              long long out_stride = 0)
+{
+    Params p; // carries the quantisation tables by value: nothing to stage, nothing to order across streams
+    fill_params(d, pl, nframes, d_y, d_cb, d_cr, d_out, zero_fill, p);
+    if (y_stride) p.y_frame_stride = y_stride;
+    if (c_stride) p.c_frame_stride = c_stride;
+    if (out_stride) p.out_frame_stride = out_stride;
     const size_t ostride = out_stride ? (size_t)out_stride : pl.out_len;
     if (zero_fill) {
         // rows below the last complete strip are never written by the reference (Q6): zeros
@@ -355,16 +380,45 @@ static int decode_device_impl(zj_ctx* c, const zj_frame_desc* d, const Plan& pl,
             q.out = p.out + (size_t)s0 * pl.strip_rows * d->width * pl.ncomp_out;
             q.height = (int)d->height - s0 * pl.strip_rows;
             set_grid(q, 1, s1 - s0, pl.tiles_per_row);
-            q.stagger_wgs = p.stagger_wgs; q.stagger_delay = p.stagger_delay;
             ZJ_HIP(c, hipStreamWaitEvent(in[r], fork, 0));
-            ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->variant, pl.fast ? 1 : 0, q, in[r]));
+            { const int rc = launch_params(c, pl, q, in[r]); if (rc) return rc; }
             ZJ_HIP(c, hipEventRecord(join[r], in[r]));
             ZJ_HIP(c, hipStreamWaitEvent(s, join[r], 0));
         }
         return ZJ_OK;
     }
 #endif
-    ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->variant, pl.fast ? 1 : 0, p, s));
+    return launch_params(c, pl, p, s);
+}
+
+// Frames that are independent allocations (device pointers in HOST arrays, read during the call): launches of up to
+// SCATTER_MAX frames whose addresses travel in the kernel arguments.  Frames that turn out to be equally spaced -- the
+// images of one tensor, the slots of an arena -- take the strided form instead: one launch whatever their number.
+static int decode_frames_device_impl(zj_ctx* c, const zj_frame_desc* d, const Plan& pl, size_t nframes, const int16_t* const* y,
+                                     const int16_t* const* cb, const int16_t* const* cr, uint8_t* const* out, hipStream_t s,
+                                     int zero_fill)
+{
+    const bool chroma = pl.out != OUT_GRAY;
+    if (nframes == 1) return decode_device_impl(c, d, pl, 1, y[0], chroma ? cb[0] : nullptr, chroma ? cr[0] : nullptr, out[0], s, zero_fill);
+    {
+        const long long ys = y[1] - y[0], cs = chroma ? cb[1] - cb[0] : 0, os = out[1] - out[0];
+        bool uniform = ys >= (long long)pl.y_len && os >= (long long)pl.out_len && (!chroma || (cs >= (long long)pl.c_len && cr[1] - cr[0] == cs));
+        for (size_t f = 2; f < nframes && uniform; f++)
+            uniform = y[f] - y[f - 1] == ys && out[f] - out[f - 1] == os && (!chroma || (cb[f] - cb[f - 1] == cs && cr[f] - cr[f - 1] == cs));
+        if (uniform) return decode_device_impl(c, d, pl, nframes, y[0], chroma ? cb[0] : nullptr, chroma ? cr[0] : nullptr, out[0], s, zero_fill, ys, cs, os);
+    }
+    size_t off[3], len[3];
+    const int nr = zero_fill ? uncovered_ranges(d, pl, off, len) : 0;
+    for (size_t f0 = 0; f0 < nframes; f0 += SCATTER_MAX) {
+        const int n = (int)(nframes - f0 < (size_t)SCATTER_MAX ? nframes - f0 : (size_t)SCATTER_MAX);
+        Params p;
+        fill_params(d, pl, (size_t)n, nullptr, nullptr, nullptr, nullptr, zero_fill, p);
+        set_scatter(p, y, chroma ? cb : nullptr, chroma ? cr : nullptr, out, f0, n);
+        for (int f = 0; f < n; f++)
+            for (int r = 0; r < nr; r++) ZJ_HIP(c, hipMemsetAsync(out[f0 + f] + off[r], 0, len[r], s));
+        const int rc = launch_params(c, pl, p, s);
+        if (rc) return rc;
+    }
     return ZJ_OK;
 }
 
@@ -391,6 +445,39 @@ int zj_decode_planes_device(zj_ctx* c, const zj_frame_desc* d, size_t nframes, c
     ZJ_HIP(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     return decode_device_impl(c, d, pl, nframes, d_y, d_cb, d_cr, d_out, s, 1);
+}
+
+int zj_decode_planes_device_strided(zj_ctx* c, const zj_frame_desc* d, size_t nframes, const int16_t* d_y, const int16_t* d_cb,
+                                    const int16_t* d_cr, uint8_t* d_out, size_t y_stride, size_t c_stride, size_t out_stride,
+                                    void* stream)
+{
+    Plan pl;
+    int rc = check_frame_args(c, d, nframes, d_y, d_cb, d_cr, d_out, pl);
+    if (rc) return rc;
+    if (((uintptr_t)d_y | (uintptr_t)d_cb | (uintptr_t)d_cr | (uintptr_t)d_out) & 15) return ZJ_ERR_ARG;
+    // 0 = packed; otherwise at least a frame, and every frame as aligned as the first
+    if ((y_stride && (y_stride < pl.y_len || (y_stride & 7))) || (c_stride && (c_stride < pl.c_len || (c_stride & 7))) ||
+        (out_stride && (out_stride < pl.out_len || (out_stride & 15)))) return ZJ_ERR_ARG;
+    if ((y_stride | c_stride | out_stride) >> 62) return ZJ_ERR_ARG;
+    ZJ_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return decode_device_impl(c, d, pl, nframes, d_y, d_cb, d_cr, d_out, s, 1, (long long)y_stride, (long long)c_stride, (long long)out_stride);
+}
+
+int zj_decode_frames_device(zj_ctx* c, const zj_frame_desc* d, size_t nframes, const int16_t* const* d_y,
+                            const int16_t* const* d_cb, const int16_t* const* d_cr, uint8_t* const* d_out, void* stream)
+{
+    Plan pl;
+    int rc = check_frame_args(c, d, nframes, d_y, d_cb, d_cr, d_out, pl);
+    if (rc) return rc;
+    const bool chroma = pl.out != OUT_GRAY;
+    for (size_t f = 0; f < nframes; f++) {
+        if (!d_y[f] || !d_out[f] || (chroma && (!d_cb[f] || !d_cr[f]))) return ZJ_ERR_ARG;
+        if (((uintptr_t)d_y[f] | (uintptr_t)d_out[f] | (chroma ? (uintptr_t)d_cb[f] | (uintptr_t)d_cr[f] : 0)) & 15) return ZJ_ERR_ARG;
+    }
+    ZJ_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return decode_frames_device_impl(c, d, pl, nframes, d_y, d_cb, d_cr, d_out, s, 1);
 }
 
 int zj_time_decode_device(zj_ctx* c, const zj_frame_desc* d, size_t nframes, const int16_t* d_y,
@@ -435,15 +522,27 @@ int zj_time_decode_device(zj_ctx* c, const zj_frame_desc* d, size_t nframes, con
     return ZJ_OK;
 }
 
-static int decode_planes_batch_impl(zj_ctx* c, const zj_frame_desc* d, size_t nframes, const int16_t* y,
-                                    const int16_t* cb, const int16_t* cr, uint8_t* out);
+namespace {
+// the host frames of a batch: packed back to back behind one base pointer per plane (zj_decode_planes_batch), or
+// independent allocations named by pointer arrays (zj_decode_frames)
+struct HostFrames {
+    const int16_t* y = nullptr; const int16_t* cb = nullptr; const int16_t* cr = nullptr; uint8_t* out = nullptr;
+    const int16_t* const* ys = nullptr; const int16_t* const* cbs = nullptr; const int16_t* const* crs = nullptr; uint8_t* const* outs = nullptr;
+    size_t y_len = 0, c_len = 0, out_len = 0;
+    bool packed() const { return ys == nullptr; }
+    const int16_t* Y(size_t f) const { return ys ? ys[f] : y + f * y_len; }
+    const int16_t* Cb(size_t f) const { return cbs ? cbs[f] : (cb ? cb + f * c_len : nullptr); }
+    const int16_t* Cr(size_t f) const { return crs ? crs[f] : (cr ? cr + f * c_len : nullptr); }
+    uint8_t* Out(size_t f) const { return outs ? outs[f] : out + f * out_len; }
+};
+}
 
-int zj_decode_planes_batch(zj_ctx* c, const zj_frame_desc* d, size_t nframes, const int16_t* y,
-                           const int16_t* cb, const int16_t* cr, uint8_t* out)
+static int decode_planes_batch_impl(zj_ctx* c, const zj_frame_desc* d, const Plan& pl, size_t nframes, const HostFrames& hf);
+
+// drains what an error half way left in flight on the three streams before the caller may free or reuse its buffers
+// (the first error stays in last_error)
+static int batch_guard(zj_ctx* c, int rc)
 {
-    const int rc = decode_planes_batch_impl(c, d, nframes, y, cb, cr, out);
-    // an error half way leaves copies and kernels in flight on the three streams: drain them before the caller
-    // may free or reuse its buffers (the first error stays in last_error)
     if (rc && c && c->s_up) {
         const std::string keep = c->last_error;
         (void)pipe_sync(c);
@@ -452,17 +551,43 @@ int zj_decode_planes_batch(zj_ctx* c, const zj_frame_desc* d, size_t nframes, co
     return rc;
 }
 
-static int decode_planes_batch_impl(zj_ctx* c, const zj_frame_desc* d, size_t nframes, const int16_t* y,
-                                    const int16_t* cb, const int16_t* cr, uint8_t* out)
+int zj_decode_planes_batch(zj_ctx* c, const zj_frame_desc* d, size_t nframes, const int16_t* y,
+                           const int16_t* cb, const int16_t* cr, uint8_t* out)
+{
+    Plan pl;
+    const int rc = check_frame_args(c, d, nframes, y, cb, cr, out, pl);
+    if (rc) return rc;
+    HostFrames hf;
+    hf.y = y; hf.cb = cb; hf.cr = cr; hf.out = out;
+    hf.y_len = pl.y_len; hf.c_len = pl.c_len; hf.out_len = pl.out_len;
+    return batch_guard(c, decode_planes_batch_impl(c, d, pl, nframes, hf));
+}
+
+int zj_decode_frames(zj_ctx* c, const zj_frame_desc* d, size_t nframes, const int16_t* const* y, const int16_t* const* cb,
+                     const int16_t* const* cr, uint8_t* const* out)
+{
+    Plan pl;
+    int rc = check_frame_args(c, d, nframes, y, cb, cr, out, pl);
+    if (rc) return rc;
+    const bool chroma = pl.out != OUT_GRAY;
+    for (size_t f = 0; f < nframes; f++)
+        if (!y[f] || !out[f] || (chroma && (!cb[f] || !cr[f]))) return ZJ_ERR_ARG;
+    HostFrames hf;
+    hf.ys = y; hf.cbs = chroma ? cb : nullptr; hf.crs = chroma ? cr : nullptr; hf.outs = out;
+    hf.y_len = pl.y_len; hf.c_len = pl.c_len; hf.out_len = pl.out_len;
+    return batch_guard(c, decode_planes_batch_impl(c, d, pl, nframes, hf));
+}
+
+static int decode_planes_batch_impl(zj_ctx* c, const zj_frame_desc* d, const Plan& pl, size_t nframes, const HostFrames& hf)
 {
     // Host planes -> host pixels.  The batch is cut into units of about 16 MB of coefficients (ZJ_UNIT_MB) --
     // several whole frames, or a strip range of one large frame (strips are independent: no filter tap
     // crosses a strip, Q3/Q4).  Uploads, kernels and downloads run on a stream each, chained by events over
     // N_SLOTS buffer sets, so the upload of one unit, the kernel of the previous and the download of the one
     // before overlap (PCIe is full duplex).  Pinned host buffers (zj_alloc_pinned) make the copies asynchronous.
-    Plan pl;
-    int rc = check_frame_args(c, d, nframes, y, cb, cr, out, pl);
-    if (rc) return rc;
+    //   Frames that are independent allocations (zj_decode_frames) differ only in the copies: one per frame and plane
+    // where packed frames take one per unit and plane; on the device a unit is packed either way.
+    int rc;
     ZJ_HIP(c, hipSetDevice(c->device));
     const bool chroma = pl.out != OUT_GRAY;
     const int mrps = pl.hs == 2 ? 2 : 1;                                     // MCU rows per strip
@@ -476,7 +601,7 @@ static int decode_planes_batch_impl(zj_ctx* c, const zj_frame_desc* d, size_t nf
         size_t off[3], len[3];
         const int nr = uncovered_ranges(d, pl, off, len);
         for (size_t f = 0; f < nframes; f++)
-            for (int r = 0; r < nr; r++) memset(out + f * pl.out_len + off[r], 0, len[r]);
+            for (int r = 0; r < nr; r++) memset(hf.Out(f) + off[r], 0, len[r]);
     }
     if (pl.n_strips == 0) return ZJ_OK;
 
@@ -516,11 +641,21 @@ static int decode_planes_batch_impl(zj_ctx* c, const zj_frame_desc* d, size_t nf
             if ((rc = ensure_slot(c, sl, 3, whole ? nfr * pl.out_len : (s1 - s0) * ostrip))) return rc;
             // up: the slot's planes are free once the kernel of its previous unit has run
             if (sl.used) ZJ_HIP(c, hipStreamWaitEvent(c->s_up, sl.run_done, 0));
-            const size_t yoff = f0 * pl.y_len + (whole ? 0 : s0 * ystrip), coff = f0 * pl.c_len + (whole ? 0 : s0 * cstrip);
-            ZJ_HIP(c, hipMemcpyAsync(sl.buf[0], y + yoff, yel * 2, hipMemcpyHostToDevice, c->s_up));
-            if (chroma) {
-                ZJ_HIP(c, hipMemcpyAsync(sl.buf[1], cb + coff, cel * 2, hipMemcpyHostToDevice, c->s_up));
-                ZJ_HIP(c, hipMemcpyAsync(sl.buf[2], cr + coff, cel * 2, hipMemcpyHostToDevice, c->s_up));
+            if (!whole || hf.packed()) {
+                const size_t yo = whole ? 0 : s0 * ystrip, co = whole ? 0 : s0 * cstrip;
+                ZJ_HIP(c, hipMemcpyAsync(sl.buf[0], hf.Y(f0) + yo, yel * 2, hipMemcpyHostToDevice, c->s_up));
+                if (chroma) {
+                    ZJ_HIP(c, hipMemcpyAsync(sl.buf[1], hf.Cb(f0) + co, cel * 2, hipMemcpyHostToDevice, c->s_up));
+                    ZJ_HIP(c, hipMemcpyAsync(sl.buf[2], hf.Cr(f0) + co, cel * 2, hipMemcpyHostToDevice, c->s_up));
+                }
+            } else {
+                for (size_t f = 0; f < nfr; f++) {
+                    ZJ_HIP(c, hipMemcpyAsync((int16_t*)sl.buf[0] + f * pl.y_len, hf.Y(f0 + f), pl.y_len * 2, hipMemcpyHostToDevice, c->s_up));
+                    if (chroma) {
+                        ZJ_HIP(c, hipMemcpyAsync((int16_t*)sl.buf[1] + f * pl.c_len, hf.Cb(f0 + f), pl.c_len * 2, hipMemcpyHostToDevice, c->s_up));
+                        ZJ_HIP(c, hipMemcpyAsync((int16_t*)sl.buf[2] + f * pl.c_len, hf.Cr(f0 + f), pl.c_len * 2, hipMemcpyHostToDevice, c->s_up));
+                    }
+                }
             }
             ZJ_HIP(c, hipEventRecord(sl.up_done, c->s_up));
             // run: after this unit's upload and after the slot's previous download has drained its pixels
@@ -529,30 +664,27 @@ static int decode_planes_batch_impl(zj_ctx* c, const zj_frame_desc* d, size_t nf
             Params p;
             fill_params(d, pl, whole ? nfr : 1, (const int16_t*)sl.buf[0], (const int16_t*)sl.buf[1],
                         (const int16_t*)sl.buf[2], (uint8_t*)sl.buf[3], 1, p);
-        #if defined(ZJ_ABLATION)
-    p.debug = c->debug;
-#endif
             if (!whole) { // strips [s0, s1) of frame f0 as a frame of its own
                 p.height = (int)d->height - (int)s0 * pl.strip_rows;
                 set_grid(p, 1, (int)(s1 - s0), pl.tiles_per_row);
             }
-            ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->variant, pl.fast ? 1 : 0, p, c->s_run));
+            if ((rc = launch_params(c, pl, p, c->s_run))) return rc;
             ZJ_HIP(c, hipEventRecord(sl.run_done, c->s_run));
             // down
             ZJ_HIP(c, hipStreamWaitEvent(c->s_down, sl.run_done, 0));
             if (planar) { // the covered rows of every plane of every frame
                 for (size_t f = 0; f < nfr; f++)
                     for (size_t pc = 0; pc < 3; pc++) {
-                        const size_t po = f * pl.out_len + pc * (size_t)d->width * d->height;
-                        ZJ_HIP(c, hipMemcpyAsync(out + f0 * pl.out_len + po, (uint8_t*)sl.buf[3] + po, covered * d->width,
+                        const size_t po = pc * (size_t)d->width * d->height;
+                        ZJ_HIP(c, hipMemcpyAsync(hf.Out(f0 + f) + po, (uint8_t*)sl.buf[3] + f * pl.out_len + po, covered * d->width,
                                                  hipMemcpyDeviceToHost, c->s_down));
                     }
-            } else if (whole && covered_bytes < pl.out_len) { // skip the never-written rows of every frame
+            } else if (whole && (covered_bytes < pl.out_len || !hf.packed())) { // frame by frame, without the never-written rows
                 for (size_t f = 0; f < nfr; f++)
-                    ZJ_HIP(c, hipMemcpyAsync(out + (f0 + f) * pl.out_len, (uint8_t*)sl.buf[3] + f * pl.out_len, covered_bytes,
+                    ZJ_HIP(c, hipMemcpyAsync(hf.Out(f0 + f), (uint8_t*)sl.buf[3] + f * pl.out_len, covered_bytes,
                                              hipMemcpyDeviceToHost, c->s_down));
             } else {
-                ZJ_HIP(c, hipMemcpyAsync(out + f0 * pl.out_len + (whole ? 0 : s0 * ostrip), sl.buf[3], obytes,
+                ZJ_HIP(c, hipMemcpyAsync(hf.Out(f0) + (whole ? 0 : s0 * ostrip), sl.buf[3], obytes,
                                          hipMemcpyDeviceToHost, c->s_down));
             }
             ZJ_HIP(c, hipEventRecord(sl.down_done, c->s_down));
@@ -892,28 +1024,27 @@ static int decode_scans_impl(zj_ctx* c, size_t n, const zj_frame_desc* descs, co
     if (timing) ZJ_HIP(c, hipEventRecord(ev[1], s));
     ZJ_HIP(c, launch_huff_finish(batch, nlive, max_nsub, s));
     if (timing) ZJ_HIP(c, hipEventRecord(ev[2], s));
-    // Pixel kernel: consecutive scans of one geometry and one set of tables go through it as the frames of ONE launch --
-    // their planes sit at the arena's stride; their pixels too (host outputs: the staging arena; device outputs: if the
-    // caller's pointers are equally spaced, e.g. the images of one tensor)
-    for (int q = 0; q < nlive;) {
-        ScanJob& j0 = jobs[(size_t)live[q]];
-        int run = 1;
-        long long ostride = outs_on_device ? 0 : (long long)c->hout_stride;
-        while (q + run < nlive) {
-            const ScanJob& jn = jobs[(size_t)live[q + run]];
-            if (jn.slot != j0.slot + run || memcmp(jn.d, j0.d, sizeof(zj_frame_desc)) != 0) break;
-            if (outs_on_device) {
-                const long long step = (long long)(jn.d_out - jobs[(size_t)live[q + run - 1]].d_out);
-                if (run == 1) { if (step < (long long)j0.pl.out_len || (step & 15)) break; ostride = step; }
-                else if (step != ostride) break;
+    // Pixel kernel: the scans of one geometry and one set of tables go through it as the frames of ONE launch, wherever
+    // their planes (arena slots) and their pixels (the staging arena, or whatever the caller's pointers are) happen to lie:
+    // equally spaced frames take the strided form, anything else the scattered form (decode_frames_device_impl)
+    {
+        bool launched[ZJ_SCAN_BATCH_MAX] = {};
+        for (int q = 0; q < nlive; q++) {
+            if (launched[q]) continue;
+            const ScanJob& j0 = jobs[(size_t)live[q]];
+            const int16_t* fy[ZJ_SCAN_BATCH_MAX]; const int16_t* fcb[ZJ_SCAN_BATCH_MAX]; const int16_t* fcr[ZJ_SCAN_BATCH_MAX];
+            uint8_t* fo[ZJ_SCAN_BATCH_MAX];
+            size_t run = 0;
+            for (int r = q; r < nlive; r++) {
+                const ScanJob& jn = jobs[(size_t)live[r]];
+                if (launched[r] || memcmp(jn.d, j0.d, sizeof(zj_frame_desc)) != 0) continue;
+                fy[run] = jn.a.plane[0]; fcb[run] = jn.a.plane[1]; fcr[run] = jn.a.plane[2]; fo[run] = jn.d_out;
+                launched[r] = true;
+                run++;
             }
-            run++;
+            const int rc = decode_frames_device_impl(c, j0.d, j0.pl, run, fy, fcb, fcr, fo, s, 1);
+            if (rc) return rc;
         }
-        int rc = decode_device_impl(c, j0.d, j0.pl, (size_t)run, j0.a.plane[0], j0.chroma ? j0.a.plane[1] : nullptr,
-                                    j0.chroma ? j0.a.plane[2] : nullptr, j0.d_out, s, 1,
-                                    run > 1 ? (long long)(c->harena_stride / 2) : 0, run > 1 ? ostride : 0);
-        if (rc) return rc;
-        q += run;
     }
     for (int q = 0; q < nlive && !outs_on_device; q++) {
         ScanJob& j = jobs[(size_t)live[q]];

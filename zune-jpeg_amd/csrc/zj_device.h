@@ -712,6 +712,8 @@ struct Cfg {
     static_assert(NT <= 512 && NBLK <= NT, "one lane per block, at most 8 waves");
 };
 
+constexpr int SCATTER_MAX = 32;            // frames of one scattered launch (4 x 32 pointers = 1 KB of kernel arguments)
+
 struct Params {
     const int16_t* y;
     const int16_t* cb;
@@ -730,6 +732,7 @@ struct Params {
     uint32_t tpr_magic, tpr_shift; // magic_u31(tiles_per_row), magic_u31(n_strips): tile_from_id
     uint32_t ns_magic, ns_shift;
     int stagger_wgs, stagger_delay; // first-wave de-synchronisation (zj_kernels.hip: stagger_start); 0 = off
+    uint32_t stagger_magic, stagger_shift; // magic_u31(CUs of the device): a workgroup's slot group = id / CUs
 #if defined(ZJ_ABLATION)
     int debug;                    // diagnostic build only (tools/ablate.py): 1 skip IDCT, 2 skip colour math, 4 no loads, 8 no stores
 #endif
@@ -738,7 +741,25 @@ struct Params {
     int clamp_dc;                 // extension: DC-only shortcut value clamped to 0..255 (Q1 corrected)
     int edge_rep;                 // extension: horizontal chroma filter per row with replicated edges (Q4 corrected)
     uint32_t tab[3 * TAB_DW];     // the three quantisation tables + guard constants (build_table), by value
+    // Scattered batch (zj_decode_frames_device): the frames of one launch are independent allocations, the way the
+    // reference's callers own them (a fresh Vec per strip, src/mcu.rs:238-250; a Vec<u8> per decode, src/decoder.rs:178).
+    // Their addresses travel by value like the tables -- nothing to stage, nothing to keep alive -- and a workgroup reads
+    // the four of its frame with scalar loads indexed by the (uniform) frame number.
+    int scatter;                  // 0: frame f at base + f * stride; 1: at fptr[.][f]
+    uint64_t fptr[4][SCATTER_MAX]; // y | cb | cr | out
 };
+
+// where frame `f` of the launch lives (f is workgroup-uniform: scalar loads from the kernel arguments)
+ZJ_DEV const int16_t* frame_plane(const Params& p, const int comp, const int f)
+{
+    if (p.scatter) return reinterpret_cast<const int16_t*>(p.fptr[comp][f]);
+    return comp == 0 ? p.y + (long long)f * p.y_frame_stride : (comp == 1 ? p.cb : p.cr) + (long long)f * p.c_frame_stride;
+}
+ZJ_DEV uint8_t* frame_pixels(const Params& p, const int f)
+{
+    if (p.scatter) return reinterpret_cast<uint8_t*>(p.fptr[3][f]);
+    return p.out + (long long)f * p.out_frame_stride;
+}
 
 // vertical schedule of upsample_vertical (upsampler/scalar.rs:84-144): pair k -> (near, far)
 ZJ_DEV void vsched(int k, int& n, int& f) { n = k; f = (k == 0) ? 0 : (k < 7 ? k + 1 : 7); }
@@ -843,7 +864,7 @@ ZJ_DEV BlockLoc locate(const Params& p, const TileId t, const int b, char* lds)
         const int gcol = t.tile * C::TWYB + bcol;
         if (gcol >= ybw) return L;
         const long long blk = (long long)(t.strip * C::YBR + brow) * ybw + gcol;
-        L.src = reinterpret_cast<const U4*>(p.y + (long long)t.frame * p.y_frame_stride + blk * 64);
+        L.src = reinterpret_cast<const U4*>(frame_plane(p, 0, t.frame) + blk * 64);
         L.dst = lds + ((brow * 8) * C::TWY + bcol * 8) * LL::YPX;
         L.valid = true;
         return L;
@@ -878,7 +899,7 @@ ZJ_DEV BlockLoc locate(const Params& p, const TileId t, const int b, char* lds)
         gcol = cb0 + j; lcol = 8 * j;
     }
     const long long blk = (long long)(t.strip * C::CBR + brow) * cbw + gcol;
-    const int16_t* plane = (comp == 1 ? p.cb : p.cr) + (long long)t.frame * p.c_frame_stride;
+    const int16_t* plane = frame_plane(p, comp, t.frame);
     L.src = reinterpret_cast<const U4*>(plane + blk * 64);
     if (L.halo) { // the one pixel column of a halo block that is ever read: a column of the side array
         L.dst = reinterpret_cast<char*>(lds_halo_raw<C, GEN>(lds, comp, L.halo - 1, brow * 8));
@@ -1013,7 +1034,7 @@ ZJ_DEV HaloLane halo_locate(const Params& p, const TileId t, const int hl /* 0..
     // the neighbour beyond the strip's first / last column is the other end of the row (Q4: one flat array)
     const int gcol = side == 0 ? (cb0 > 0 ? cb0 - 1 : cbw - 1) : (cb0 + nvalid < cbw ? cb0 + nvalid : 0);
     const long long blk = (long long)(t.strip * C::CBR + brow) * cbw + gcol;
-    const int16_t* plane = (H.comp == 1 ? p.cb : p.cr) + (long long)t.frame * p.c_frame_stride;
+    const int16_t* plane = frame_plane(p, H.comp, t.frame);
     H.src = plane + blk * 64 + H.j;
     H.dst = reinterpret_cast<char*>(lds_halo_raw<C, GEN_PACKED>(lds, H.comp, side, brow * 8));
     H.pitch = 2;
@@ -1333,7 +1354,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
     const int x0 = t.tile * C::TWY;
     const int ncomp = OUT == OUT_GRAY ? 1 : (OUT == OUT_RGBA ? 4 : 3);
     const long long row_bytes = OUT == OUT_RGB_CHW ? (long long)W : (long long)W * ncomp; // CHW: one plane's row
-    uint8_t* const frame_out = p.out + (long long)t.frame * p.out_frame_stride;
+    uint8_t* const frame_out = frame_pixels(p, t.frame);
     const int elements = P / 16 - 1; // worker.rs:171 (P >= 32 on this path)
     if (TS) io->kind = 0;
 
@@ -1626,7 +1647,7 @@ ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid, char* 
     const int nvg = (P - x0) / 16 < C::NGRP ? (P - x0) / 16 : C::NGRP; // valid 16-pixel groups of this tile
     const uint32_t row_bytes = (uint32_t)(PPI == 4 ? 4 : 3) * (uint32_t)p.width;
     // everything up to here is uniform: a scalar base address, 32-bit per-lane offsets below
-    uint8_t* const tile_out = p.out + (long long)t.frame * p.out_frame_stride + (long long)t.strip * C::SH * row_bytes + (long long)(PPI == 4 ? 4 : 3) * x0;
+    uint8_t* const tile_out = frame_pixels(p, t.frame) + (long long)t.strip * C::SH * row_bytes + (long long)(PPI == 4 ? 4 : 3) * x0;
     const int w = uniform(tid >> 6), L = tid & 63;
     const int item0 = 64 * w + round * C::NT;  // first item of this wave's round
     if (item0 >= C::NITEMS) return;            // (the last round of a tile is partly empty)

@@ -58,14 +58,15 @@ __device__ __forceinline__ void tile_wide(const Params& p, const TileId t, const
 // through load / transform / colour / store in lock step: memory idles while they compute and the SIMDs idle while they
 // load.  In a long launch that synchrony dissolves after a tile or two; a launch of ONE frame (2048 tiles on 1536 slots)
 // never gets that far (profiles/r03_ab_history.txt: 25 us against 18 us per frame in a batch).  Here the k-th workgroup of
-// every slot group waits k * delay before its first load, so that the six workgroups sharing a CU start a phase apart.
+// every slot group waits k * delay before its first load, so that the workgroups sharing a CU start a phase apart.  The
+// host turns it on for launches of one to two waves of workgroups only (zj_api.cpp: launch_params) and passes the slot
+// count of the launched instantiation (stagger_wgs = CUs x workgroups per CU) and the divisor as a multiplier.
 __device__ __forceinline__ void stagger_start(const Params& p, const int bid)
 {
     if (p.stagger_delay <= 0 || bid >= p.stagger_wgs) return; // uniform
-    int k = bid / (p.stagger_wgs / 6);                        // 0..5: the dispatcher fills the CUs round-robin
-    const int mode = p.stagger_delay >> 8;                    // experiment knob (ZJ_STAGGER = delay + 256 * mode)
-    if (mode == 1) k &= 1; else if (mode == 2) k %= 3; else if (mode == 3) k = 5 - k;
-    const int n = k * (p.stagger_delay & 255);
+    const Magic g = {p.stagger_magic, p.stagger_shift};
+    const int k = (int)magic_div((uint32_t)bid, g);           // 0 .. slots per CU - 1: the dispatcher fills the CUs round-robin
+    const int n = k * p.stagger_delay;
     for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(2);  // ~128 cycles = 53 ns per step
 }
 
@@ -222,6 +223,37 @@ hipError_t launch_fused(int hs, int vs, int out, int variant, int fast, const Pa
     ZJ_CASE(1, 1, OUT_RGB_CHW) ZJ_CASE(2, 1, OUT_RGB_CHW) ZJ_CASE(1, 2, OUT_RGB_CHW) ZJ_CASE(2, 2, OUT_RGB_CHW)
 #undef ZJ_CASE
     return hipErrorInvalidValue;
+}
+
+// workgroups of the instantiation launch_fused() picks that fit one CU (occupancy query, once per instantiation)
+template <int HS, int VS, int OUT>
+static int slots_t(const Params& p, int variant, int fast)
+{
+    using C = Cfg<HS, VS, OUT>;
+    int gen; bool ts;
+    pick(variant, OUT, fast != 0, ts_eligible<C>(p, OUT, fast != 0), gen, ts);
+    constexpr bool TSC = C::TSCAP;
+    static int cache[6] = {0, 0, 0, 0, 0, 0}; // 0 = not asked yet, -1 = the query failed
+    const int which = gen == GEN_WIDE ? (fast ? 0 : 1) : (!fast ? 2 : ((ts && TSC) ? 3 : 4));
+    if (cache[which] == 0) {
+        int n = 0;
+        hipError_t e;
+        if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zj_fused_kernel<HS, VS, OUT, GEN_WIDE, true, false>, C::NT, 0);
+        else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zj_fused_kernel<HS, VS, OUT, GEN_WIDE, false, false>, C::NT, 0);
+        else if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zj_fused_kernel<HS, VS, OUT, GEN_PACKED, false, false>, C::NT, 0);
+        else if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zj_fused_kernel<HS, VS, OUT, GEN_PACKED, true, TSC>, C::NT, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zj_fused_kernel<HS, VS, OUT, GEN_PACKED, true, false>, C::NT, 0);
+        cache[which] = (e == hipSuccess && n > 0) ? n : -1;
+    }
+    return cache[which] > 0 ? cache[which] : 0;
+}
+
+int fused_slots_per_cu(int hs, int vs, int out, int variant, int fast, const Params& p)
+{
+#define ZJ_CASE(H, V, O) if (hs == H && vs == V && out == O) return slots_t<H, V, O>(p, variant, fast);
+    ZJ_CASE(2, 2, OUT_RGB) ZJ_CASE(2, 2, OUT_YCBCR) ZJ_CASE(2, 2, OUT_RGBA) ZJ_CASE(2, 2, OUT_RGB_CHW) // (the shapes that stagger)
+#undef ZJ_CASE
+    return 0;
 }
 
 template <int HS, int VS, int OUT>

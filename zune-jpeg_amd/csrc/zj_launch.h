@@ -11,6 +11,7 @@ hipError_t launch_fused(int hs, int vs, int out, int variant, int fast, const Pa
 void set_pad_lds(int bytes);
 int fused_occupancy_420_rgb(int pad_lds);
 #endif
+int fused_slots_per_cu(int hs, int vs, int out, int variant, int fast, const Params& p); // 0: unknown
 const char* fused_kernel_name(int hs, int vs, int out, int variant, int fast, const Params& p);
 hipError_t launch_idct_strip(const int16_t* coeff, const int32_t qt[64], int16_t* out, long long nblocks,
                              long long chunks, long long bpc, long long stride, hipStream_t s);

@@ -139,7 +139,7 @@ inline void set_grid(Params& p, int nframes, int n_strips, int tiles_per_row)
     p.total_tiles = nframes * n_strips * tiles_per_row;
     const Magic gt = magic_u31((uint32_t)(tiles_per_row > 0 ? tiles_per_row : 1)), gs = magic_u31((uint32_t)(n_strips > 0 ? n_strips : 1));
     p.tpr_magic = gt.m; p.tpr_shift = gt.s; p.ns_magic = gs.m; p.ns_shift = gs.s;
-    p.stagger_wgs = p.stagger_delay = 0;
+    p.stagger_wgs = p.stagger_delay = 0; p.stagger_magic = p.stagger_shift = 0;
 }
 
 inline void fill_params(const zj_frame_desc* d, const Plan& pl, size_t nframes, const int16_t* y,
@@ -162,6 +162,21 @@ inline void fill_params(const zj_frame_desc* d, const Plan& pl, size_t nframes, 
     p.clamp_dc = pl.clamp_dc;
     p.edge_rep = pl.edge_rep;
     p.plane_stride = (long long)d->width * d->height;
+    p.scatter = 0;
+}
+
+// frames [f0, f0 + n) of a scattered batch: their addresses into the launch's table (n <= SCATTER_MAX)
+inline void set_scatter(Params& p, const int16_t* const* y, const int16_t* const* cb, const int16_t* const* cr,
+                        uint8_t* const* out, size_t f0, int n)
+{
+    p.scatter = 1;
+    for (int f = 0; f < SCATTER_MAX; f++) {
+        const bool in = f < n;
+        p.fptr[0][f] = in ? (uint64_t)(uintptr_t)y[f0 + f] : 0;
+        p.fptr[1][f] = in && cb ? (uint64_t)(uintptr_t)cb[f0 + f] : 0;
+        p.fptr[2][f] = in && cr ? (uint64_t)(uintptr_t)cr[f0 + f] : 0;
+        p.fptr[3][f] = in ? (uint64_t)(uintptr_t)out[f0 + f] : 0;
+    }
 }
 
 } // namespace zj

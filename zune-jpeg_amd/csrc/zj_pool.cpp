@@ -11,6 +11,13 @@
 // The reference creates a scoped_threadpool per decode for its post_process strips (src/mcu.rs:135); this
 // pool lives across calls because streams, pinned planes and device buffers are worth keeping.
 //
+// Several devices (zj_pool_create_multi): image-level sharding inside the library (north_star: "independent frames across
+// the 8 GPUs of one node"; SURVEY.md 8e: one host thread per GPU).  Every device slot gets its own submitters and contexts;
+// the entropy workers and the plane sets (pinned, portable: any device can DMA them) are shared.  A file whose pixels
+// go to host memory is taken by whichever slot has a submitter free (dealt by readiness, not by index, so a slow GPU does
+// not hold up its share); a file whose pixels stay in HBM goes to the slot(s) of the device that owns its output
+// pointer.  Results land in the caller's order because every file carries its own output pointer.
+//
 // Only the C ABI of the library is used (include/zjhip.h, plus the zj_set_pipeline knob).
 #include <stdint.h>
 #include <stdlib.h>
@@ -54,24 +61,32 @@ struct zj_pool {
         int first_error = 0;
     };
     struct Job { size_t index; zj_decoder* dec; };
+    struct Slot {                        // one device of the pool (the same device may fill several slots)
+        int device = 0;
+        std::deque<Job> ready;           // prepared files whose output lives on this slot's device
+        std::condition_variable cv;      // this slot's submitters
+        double gpu_s = 0;                // under mu
+        size_t files = 0;
+    };
 
     std::vector<std::thread> threads;
     std::vector<zj_decoder*> decoders;   // all plane sets
     std::vector<zj_ctx*> ctxs;           // one per submitter
+    std::deque<Slot> slots;              // (a deque: condition variables do not move)
     std::mutex mu;
     // one condition per kind of waiter, so that a finished file wakes one submitter or one worker and not all 20+
     // threads of the pool (with the device entropy stage a file is ~1 ms of work: the wake-ups showed)
     std::condition_variable cv_work;     // entropy workers: a batch has files left and a plane set is free
-    std::condition_variable cv_ready;    // submitters: a prepared file waits
+                                         // (submitters wait on their slot's condition: a prepared file waits)
     std::condition_variable cv_done;     // the caller: the batch is complete
     std::vector<zj_decoder*> free_dec;
-    std::deque<Job> ready;               // entropy-decoded, waiting for the GPU
+    std::deque<Job> ready;               // entropy-decoded, waiting for the GPU, output in host memory: any slot
     Batch* batch = nullptr;
     bool stop = false;
     std::mutex call_mu;                  // serialises zj_pool_decode_files callers
     std::string last_error;
     int n_workers = 0;
-    int device = 0;                      // every thread of the pool binds to it
+    std::vector<int> out_slot;           // per file of a device-output batch: the slot its output pointer belongs to
     int device_batch = 8;                // files a submitter takes at once when the pixels stay on the device (ZJ_POOL_BATCH)
     // accumulated over the pool's life (under mu): seconds inside the entropy stage / the GPU stage, files
     double entropy_s = 0, gpu_s = 0;
@@ -87,10 +102,15 @@ struct zj_pool {
         b.done++;
     }
 
-    void entropy_loop()
+    void wake_submitters()
+    {   // a file any slot may take: one submitter of every slot looks (those that find nothing go back to sleep)
+        for (Slot& sl : slots) sl.cv.notify_one();
+    }
+
+    void entropy_loop(int device)
     {
-        // the planes this thread fills are pinned (zj_alloc_pinned) and DMA'd by the submitters' contexts on `device`:
-        // bind the thread there, so a pool on device N never touches device 0
+        // the planes this thread fills are pinned (zj_alloc_pinned) and DMA'd by the submitters' contexts:
+        // bind the thread to one of the pool's devices, so a pool on device N never touches device 0
         (void)zj_set_thread_device(device);
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
@@ -116,18 +136,19 @@ struct zj_pool {
                 cv_work.notify_one();
             } else {
                 if (b.infos) b.infos[i] = info;
-                ready.push_back(Job{i, dec});
-                cv_ready.notify_one();
+                if (b.on_device) { Slot& sl = slots[(size_t)out_slot[i]]; sl.ready.push_back(Job{i, dec}); sl.cv.notify_one(); }
+                else { ready.push_back(Job{i, dec}); wake_submitters(); }
             }
         }
     }
 
-    void gpu_loop(zj_ctx* ctx, int index)
+    void gpu_loop(zj_ctx* ctx, int slot_index)
     {
+        Slot& me = slots[(size_t)slot_index];
+        (void)zj_set_thread_device(me.device);
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
-            (void)index;
-            cv_ready.wait(lk, [&] { return stop || !ready.empty(); });
+            me.cv.wait(lk, [&] { return stop || !ready.empty() || !me.ready.empty(); });
             if (stop) return;
             Batch& b = *batch;
             // Pixels that stay on the device: take what is ready, up to a batch -- the device entropy stage runs the scans of
@@ -136,6 +157,7 @@ struct zj_pool {
             Job jobs[ZJ_SCAN_BATCH_MAX];
             size_t nj = 0;
             const size_t want = b.on_device ? (size_t)device_batch : 1;
+            while (nj < want && !me.ready.empty()) { jobs[nj++] = me.ready.front(); me.ready.pop_front(); }
             while (nj < want && !ready.empty()) { jobs[nj++] = ready.front(); ready.pop_front(); }
             lk.unlock();
             zj_decoder* decs[ZJ_SCAN_BATCH_MAX];
@@ -154,6 +176,8 @@ struct zj_pool {
             lk.lock();
             gpu_s += dt;
             files_done += nj;
+            me.gpu_s += dt;
+            me.files += nj;
             for (size_t q = 0; q < nj; q++) {
                 finish(b, jobs[q].index, rcs[q], rcs[q] ? zj_decoder_error(jobs[q].dec) : nullptr, olens[q], nullptr);
                 free_dec.push_back(jobs[q].dec);
@@ -174,18 +198,22 @@ void zj_pool_destroy(zj_pool* p)
         p->stop = true;
     }
     p->cv_work.notify_all();
-    p->cv_ready.notify_all();
+    for (auto& sl : p->slots) sl.cv.notify_all();
     for (auto& th : p->threads) if (th.joinable()) th.join();
     for (zj_decoder* d : p->decoders) zj_decoder_free(d);
     for (zj_ctx* c : p->ctxs) zj_ctx_destroy(c);
     delete p;
 }
 
-zj_pool* zj_pool_create(int device, int threads, const zj_options* opt, int* status)
+zj_pool* zj_pool_create_multi(const int* devices, int ndev, int threads_per_device, const zj_options* opt, int* status)
 {
     int dummy;
     if (!status) status = &dummy;
-    if (threads <= 0 || threads > 1024) { *status = ZJ_ERR_ARG; return nullptr; }
+    if (!devices || ndev <= 0 || ndev > 64 || threads_per_device <= 0 || (long long)threads_per_device * ndev > 1024) { *status = ZJ_ERR_ARG; return nullptr; }
+    const int ngpu = zj_device_count();
+    if (ngpu <= 0) { *status = ZJ_ERR_NO_DEVICE; return nullptr; }
+    for (int k = 0; k < ndev; k++)
+        if (devices[k] < 0 || devices[k] >= ngpu) { *status = ZJ_ERR_NO_DEVICE; return nullptr; }
     zj_pool* p = new (std::nothrow) zj_pool();
     if (!p) { *status = ZJ_ERR_NOMEM; return nullptr; }
     zj_options o;
@@ -193,31 +221,55 @@ zj_pool* zj_pool_create(int device, int threads, const zj_options* opt, int* sta
     if (opt) o = *opt;
     o.pinned_planes = getenv("ZJ_POOL_HEAP_PLANES") ? 0 : 1; // planes are DMA sources (the env knob is for A/B timing)
     if (o.num_threads <= 0) o.num_threads = 1; // the pool is the parallelism; > 1 adds restart-segment threads per file
+    const int threads = threads_per_device * ndev;
     p->n_workers = threads;
-    p->device = device;
+    for (int k = 0; k < ndev; k++) { p->slots.emplace_back(); p->slots.back().device = devices[k]; }
     *status = ZJ_OK;
     if (const char* e = getenv("ZJ_POOL_BATCH")) { const int v = atoi(e); if (v >= 1 && v <= ZJ_SCAN_BATCH_MAX) p->device_batch = v; }
     int submitters = GPU_SUBMITTERS;
     if (const char* e = getenv("ZJ_POOL_SUBMITTERS")) { const int v = atoi(e); if (v >= 1 && v <= 64) submitters = v; }
-    for (int g = 0; g < submitters && *status == ZJ_OK; g++) {
-        int st = ZJ_OK;
-        zj_ctx* c = zj_ctx_create(ZJ_BACKEND_HIP, device, &st);
-        if (!c) { *status = st ? st : ZJ_ERR_NOMEM; break; }
-        zj_set_pipeline(c, 0); // one unit per file: the overlap comes from the other submitters
-        p->ctxs.push_back(c);
-    }
+    std::vector<int> ctx_slot;
+    for (int k = 0; k < ndev && *status == ZJ_OK; k++)
+        for (int g = 0; g < submitters && *status == ZJ_OK; g++) {
+            int st = ZJ_OK;
+            zj_ctx* c = zj_ctx_create(ZJ_BACKEND_HIP, devices[k], &st);
+            if (!c) { *status = st ? st : ZJ_ERR_NOMEM; break; }
+            zj_set_pipeline(c, 0); // one unit per file: the overlap comes from the other submitters
+            p->ctxs.push_back(c);
+            ctx_slot.push_back(k);
+        }
     // plane sets: one per entropy worker plus what the submitters hold plus one in the queue each
     // (with the device entropy stage a plane set is a few MB of prepared scan, and a submitter may hold a batch of them)
-    for (int k = 0; k < threads + (o.entropy ? submitters * p->device_batch : 2 * submitters) && *status == ZJ_OK; k++) {
+    const int all_submitters = submitters * ndev;
+    (void)zj_set_thread_device(devices[0]); // the pinned planes are allocated from here: not against device 0 unless it is the pool's
+    for (int k = 0; k < threads + (o.entropy ? all_submitters * p->device_batch : 2 * all_submitters) && *status == ZJ_OK; k++) {
         zj_decoder* d = zj_decoder_new(&o);
         if (!d) { *status = ZJ_ERR_NOMEM; break; }
         p->decoders.push_back(d);
         p->free_dec.push_back(d);
     }
     if (*status != ZJ_OK) { zj_pool_destroy(p); return nullptr; }
-    for (int t = 0; t < threads; t++) p->threads.emplace_back([p] { p->entropy_loop(); });
-    for (size_t g = 0; g < p->ctxs.size(); g++) { zj_ctx* c = p->ctxs[g]; p->threads.emplace_back([p, c, g] { p->gpu_loop(c, (int)g); }); }
+    for (int t = 0; t < threads; t++) { const int dev = devices[t % ndev]; p->threads.emplace_back([p, dev] { p->entropy_loop(dev); }); }
+    for (size_t g = 0; g < p->ctxs.size(); g++) { zj_ctx* c = p->ctxs[g]; const int k = ctx_slot[g]; p->threads.emplace_back([p, c, k] { p->gpu_loop(c, k); }); }
     return p;
+}
+
+zj_pool* zj_pool_create(int device, int threads, const zj_options* opt, int* status)
+{
+    return zj_pool_create_multi(&device, 1, threads, opt, status);
+}
+
+int zj_pool_devices(const zj_pool* p) { return p ? (int)p->slots.size() : 0; }
+
+int zj_pool_device_stats(zj_pool* p, int slot, int* device, double* gpu_seconds, size_t* files)
+{
+    if (!p || slot < 0 || slot >= (int)p->slots.size()) return ZJ_ERR_ARG;
+    std::lock_guard<std::mutex> lk(p->mu);
+    const zj_pool::Slot& sl = p->slots[(size_t)slot];
+    if (device) *device = sl.device;
+    if (gpu_seconds) *gpu_seconds = sl.gpu_s;
+    if (files) *files = sl.files;
+    return ZJ_OK;
 }
 
 int zj_pool_threads(const zj_pool* p) { return p ? p->n_workers : 0; }
@@ -259,6 +311,22 @@ static int pool_decode(zj_pool* p, size_t nfiles, const uint8_t* const* bufs, co
     for (size_t i = 0; i < nfiles; i++)
         if (!bufs[i] || !outs[i]) return ZJ_ERR_ARG;
     std::lock_guard<std::mutex> call(p->call_mu);
+    if (on_device) {
+        // every output goes to the slot(s) of the device that owns it; the files of one device rotate over its slots
+        const size_t ns = p->slots.size();
+        std::vector<size_t> turn(ns, 0); // indexed by the first slot of a device
+        p->out_slot.assign(nfiles, 0);
+        for (size_t i = 0; i < nfiles && ns > 1; i++) {
+            const int dev = zj_pointer_device(outs[i]);
+            size_t first = ns, cand = 0;
+            for (size_t k = 0; k < ns; k++)
+                if (p->slots[k].device == dev) { if (first == ns) first = k; cand++; }
+            if (!cand) { p->last_error = "file " + std::to_string(i) + ": the output pointer is not on a device of this pool"; return ZJ_ERR_ARG; }
+            size_t nth = turn[first]++ % cand;
+            for (size_t k = first; k < ns; k++)
+                if (p->slots[k].device == dev && nth-- == 0) { p->out_slot[i] = (int)k; break; }
+        }
+    }
     zj_pool::Batch b;
     b.n = nfiles; b.bufs = bufs; b.lens = lens; b.outs = outs; b.caps = out_caps;
     b.out_lens = out_lens; b.infos = infos; b.statuses = statuses; b.on_device = on_device;

@@ -151,7 +151,12 @@ ABI = [  # every symbol include/zjhip.h declares
     "zj_decoder_parallel_segments",
     "zj_pool_create", "zj_pool_destroy", "zj_pool_threads", "zj_pool_error", "zj_pool_stats",
     "zj_pool_decode_files", "zj_set_variant", "zj_set_pipeline",
+    "zj_decode_frames", "zj_decode_planes_device_strided", "zj_decode_frames_device", "zj_pointer_device",
+    "zj_pool_create_multi", "zj_pool_devices", "zj_pool_device_stats",
+    "zj_shard_range", "zj_multi_create", "zj_multi_destroy", "zj_multi_devices", "zj_multi_ctx", "zj_multi_slot_stats",
+    "zj_multi_decode_planes_batch", "zj_multi_decode_frames", "zj_multi_decode_frames_device",
 ]
+SCATTER_MAX = 32  # ZJ_SCATTER_MAX: frames per launch of the scattered form
 
 
 def abi_symbols():
@@ -269,6 +274,26 @@ def lib():
     L.zj_pool_decode_files_device.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp]
     L.zj_set_pipeline.argtypes = [vp, C.c_int]
     L.zj_set_variant.argtypes = [vp, C.c_int]
+    L.zj_decode_frames.argtypes = [vp, C.POINTER(FrameDesc), sz, vp, vp, vp, vp]
+    L.zj_decode_planes_device_strided.argtypes = [vp, C.POINTER(FrameDesc), sz, vp, vp, vp, vp, sz, sz, sz, vp]
+    L.zj_decode_frames_device.argtypes = [vp, C.POINTER(FrameDesc), sz, vp, vp, vp, vp, vp]
+    L.zj_pointer_device.argtypes = [vp]
+    L.zj_pool_create_multi.restype = vp
+    L.zj_pool_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(Options), C.POINTER(C.c_int)]
+    L.zj_pool_devices.argtypes = [vp]
+    L.zj_pool_device_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(sz)]
+    L.zj_shard_range.restype = None
+    L.zj_shard_range.argtypes = [sz, C.c_int, C.c_int, C.POINTER(sz), C.POINTER(sz)]
+    L.zj_multi_create.restype = vp
+    L.zj_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
+    L.zj_multi_destroy.argtypes = [vp]
+    L.zj_multi_devices.argtypes = [vp]
+    L.zj_multi_ctx.restype = vp
+    L.zj_multi_ctx.argtypes = [vp, C.c_int]
+    L.zj_multi_slot_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(sz)]
+    L.zj_multi_decode_planes_batch.argtypes = [vp, C.POINTER(FrameDesc), sz, i16p, i16p, i16p, u8p, C.POINTER(C.c_int)]
+    L.zj_multi_decode_frames.argtypes = [vp, C.POINTER(FrameDesc), sz, vp, vp, vp, vp, C.POINTER(C.c_int)]
+    L.zj_multi_decode_frames_device.argtypes = [vp, C.POINTER(FrameDesc), sz, vp, vp, vp, vp, C.POINTER(C.c_int)]
     if hasattr(L, "zj_set_ablation"):  # diagnostic build only (tools/build_variant.sh ablate "-DZJ_ABLATION")
         L.zj_set_ablation.argtypes = [vp, C.c_int]
     _LIB = L
@@ -406,6 +431,32 @@ class Context:
         """Device pointers (ints), asynchronous on `stream` (int handle or None = ctx stream)."""
         _check(lib().zj_decode_planes_device(self._h, C.byref(desc), nframes, d_y, d_cb, d_cr, d_out, stream),
                "zj_decode_planes_device", self._h)
+
+    def decode_planes_device_strided(self, desc, nframes, d_y, d_cb, d_cr, d_out, y_stride=0, c_stride=0, out_stride=0, stream=None):
+        """Frames at a uniform distance (int16 elements for the planes, bytes for the pixels; 0 = packed): ONE launch."""
+        _check(lib().zj_decode_planes_device_strided(self._h, C.byref(desc), nframes, d_y, d_cb, d_cr, d_out, y_stride, c_stride,
+                                                     out_stride, stream), "zj_decode_planes_device_strided", self._h)
+
+    def decode_frames_device(self, desc, d_y, d_cb, d_cr, d_out, stream=None):
+        """Scattered batch: lists of device pointers (ints), one entry per frame, any order, independent allocations.
+        d_cb / d_cr may be None for GRAYSCALE output.  Asynchronous on `stream`."""
+        n = len(d_y)
+        arr = lambda v: (C.c_void_p * n)(*v) if v is not None else None
+        _check(lib().zj_decode_frames_device(self._h, C.byref(desc), n, arr(d_y), arr(d_cb), arr(d_cr), arr(d_out), stream),
+               "zj_decode_frames_device", self._h)
+
+    def decode_frames(self, desc, frames_planes, outs=None):
+        """Host frames that are independent allocations (zj_decode_frames): frames_planes[f] = [y, cb, cr] arrays of frame
+        f.  Returns the list of per-frame uint8 arrays."""
+        n = len(frames_planes)
+        arrs = [[_i16(p) for p in pl] for pl in frames_planes]
+        nc = max(len(a) for a in arrs)
+        if outs is None:
+            outs = [np.empty(lib().zj_out_len(C.byref(desc)), np.uint8) for _ in range(n)]
+        tab = [(C.c_void_p * n)(*[a[c].ctypes.data for a in arrs]) if c < nc else None for c in range(3)]
+        otab = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        _check(lib().zj_decode_frames(self._h, C.byref(desc), n, tab[0], tab[1], tab[2], otab), "zj_decode_frames", self._h)
+        return outs
 
     def decode_to_tensor(self, desc, y, cb=None, cr=None, out=None):
         """Device-resident in, device-resident out, for PyTorch-ROCm consumers: y / cb / cr are int16
@@ -713,16 +764,110 @@ class FileBatchDecoder:
         return t
 
 
-class Pool:
-    """zj_pool: persistent host workers (entropy decoder + GPU context each) for batches of JPEG files."""
+def pointer_device(p):
+    """HIP device that owns device pointer p, or a negative zj_status (host memory, unknown pointer)."""
+    return lib().zj_pointer_device(p)
 
-    def __init__(self, threads=4, options=None, device=0):
+
+def shard_range(nframes, slot, nslots):
+    """zj_shard_range: contiguous shard [lo, hi) of `slot` (the rule of shard.shard_range, in the library)."""
+    lo, hi = C.c_size_t(0), C.c_size_t(0)
+    lib().zj_shard_range(nframes, slot, nslots, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+class Multi:
+    """zj_multi: image-level sharding of plane batches over device slots (one context + one host thread per slot)."""
+
+    def __init__(self, devices):
+        devs = (C.c_int * len(devices))(*devices)
+        st = C.c_int(0)
+        self._m = lib().zj_multi_create(devs, len(devices), C.byref(st))
+        if not self._m:
+            raise ZjError(st.value, "zj_multi_create")
+        self.nslots = len(devices)
+
+    def close(self):
+        if getattr(self, "_m", None):
+            lib().zj_multi_destroy(self._m)
+            self._m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def slot_stats(self):
+        """[(device, frames decoded)] per slot"""
+        res = []
+        for k in range(self.nslots):
+            d, n = C.c_int(0), C.c_size_t(0)
+            lib().zj_multi_slot_stats(self._m, k, C.byref(d), C.byref(n))
+            res.append((d.value, n.value))
+        return res
+
+    def decode_planes(self, desc, planes, nframes):
+        """Packed host frames -> packed host pixels, sharded over the slots."""
+        arrs = [_i16(p) for p in planes]
+        while len(arrs) < 3:
+            arrs.append(np.zeros(8, np.int16))
+        out = np.empty(nframes * lib().zj_out_len(C.byref(desc)), np.uint8)
+        sts = (C.c_int * self.nslots)()
+        rc = lib().zj_multi_decode_planes_batch(self._m, C.byref(desc), nframes, _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]),
+                                                _ptr(out), sts)
+        if rc:
+            raise ZjError(rc, f"zj_multi_decode_planes_batch (per slot: {list(sts)})")
+        return out
+
+    def decode_frames(self, desc, frames_planes):
+        """Host frames that are independent allocations, sharded over the slots; returns the per-frame arrays."""
+        n = len(frames_planes)
+        arrs = [[_i16(p) for p in pl] for pl in frames_planes]
+        nc = max(len(a) for a in arrs)
+        outs = [np.empty(lib().zj_out_len(C.byref(desc)), np.uint8) for _ in range(n)]
+        tab = [(C.c_void_p * n)(*[a[c].ctypes.data for a in arrs]) if c < nc else None for c in range(3)]
+        otab = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        sts = (C.c_int * self.nslots)()
+        rc = lib().zj_multi_decode_frames(self._m, C.byref(desc), n, tab[0], tab[1], tab[2], otab, sts)
+        if rc:
+            raise ZjError(rc, f"zj_multi_decode_frames (per slot: {list(sts)})")
+        return outs
+
+    def decode_frames_device(self, desc, d_y, d_cb, d_cr, d_out):
+        """Device pointers per frame (frame f on the device of the slot whose shard holds f); returns when all are done."""
+        n = len(d_y)
+        arr = lambda v: (C.c_void_p * n)(*v) if v is not None else None
+        sts = (C.c_int * self.nslots)()
+        rc = lib().zj_multi_decode_frames_device(self._m, C.byref(desc), n, arr(d_y), arr(d_cb), arr(d_cr), arr(d_out), sts)
+        if rc:
+            raise ZjError(rc, f"zj_multi_decode_frames_device (per slot: {list(sts)})")
+
+
+class Pool:
+    """zj_pool: persistent host workers (entropy decoder + GPU context each) for batches of JPEG files.  `devices` (a
+    list) makes it a multi-device pool (zj_pool_create_multi): `threads` entropy workers per device slot."""
+
+    def __init__(self, threads=4, options=None, device=0, devices=None):
         o = options.to_c() if options is not None else Options()
         st = C.c_int(0)
-        self._p = lib().zj_pool_create(int(device), int(threads), C.byref(o), C.byref(st))
+        if devices is not None:
+            devs = (C.c_int * len(devices))(*devices)
+            self._p = lib().zj_pool_create_multi(devs, len(devices), int(threads), C.byref(o), C.byref(st))
+        else:
+            self._p = lib().zj_pool_create(int(device), int(threads), C.byref(o), C.byref(st))
         if not self._p:
             raise ZjError(st.value, "zj_pool_create")
         self._out_cs = int(o.out_colorspace)
+
+    def device_stats(self):
+        """[(device, GPU-stage seconds, files)] per device slot"""
+        res = []
+        for k in range(lib().zj_pool_devices(self._p)):
+            d, s_, n = C.c_int(0), C.c_double(0), C.c_size_t(0)
+            lib().zj_pool_device_stats(self._p, k, C.byref(d), C.byref(s_), C.byref(n))
+            res.append((d.value, s_.value, n.value))
+        return res
 
     def close(self):
         if getattr(self, "_p", None):
