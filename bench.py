@@ -16,6 +16,10 @@ Infinity Cache); successive steps walk the shard.  The same per-GPU work at ever
 collective; RCCL is used only for the barrier, the MAX over ranks and the trivial gather of per-frame checksums after
 the timed region, which are compared with the ORACLE's (tests/golden/checksums_seed1234.json).  Rank 0 prints ONE JSON line.
 
+`--as-rank R/N` (one process, one GPU): the shard, the frame indices and the golden offsets of rank R of an N-rank run --
+global frames [R*S, (R+1)*S) -- with world-size-1 collectives; eight such runs (R = 0..7) decode all 1024 frames of
+configs[4] on one GPU (tools/virtual_ranks.py, tests/test_gpu_bench.py).
+
 `--gpus N` without a torchrun environment is self-launching: the parent starts the N ranks as child processes BEFORE
 anything touches a GPU, waits, relays rank 0's line and fails if any rank fails.
 """
@@ -85,7 +89,64 @@ def cpu_baseline(frames, qts, budget_s=20.0):
                       f"scalar restatement 1 thread {sc[0]:.0f} MP/s; host has {ncpu} logical CPUs, cgroup quota {eff}"}
 
 
-def e2e_pinned(zj, ctx, desc, d_planes, plane_elems, frame_out, golden_sums=None, nb=8, reps=4):
+def pcie_probe(zj, device, nbytes=256 << 20, reps=3):
+    """This host's PCIe ceilings, measured now through the library's own copy path: pinned (zj_alloc_pinned) <-> device
+    copies of 256 MB, one direction at a time and both at once (two host threads, a context and a stream each; ctypes
+    releases the GIL).  GB/s per direction.  The duplex figure, not the link's nominal 63 GB/s, is what e2e_pinned can
+    reach."""
+    import threading
+    L = zj.lib()
+    ctxs, pins, devs = [], [], []
+    try:
+        for _ in range(2):
+            c = zj.Context(zj.BACKEND_HIP, device)
+            ctxs.append(c)
+            pins.append(L.zj_alloc_pinned(nbytes))
+            devs.append(c.device_alloc(nbytes))
+        if not all(pins):
+            return {"error": "zj_alloc_pinned failed"}
+
+        def copy(i, up, out):
+            t0 = time.perf_counter()
+            rc = (L.zj_memcpy_h2d(ctxs[i].handle, devs[i], pins[i], nbytes) if up else
+                  L.zj_memcpy_d2h(ctxs[i].handle, pins[i], devs[i], nbytes))
+            out[i] = (time.perf_counter() - t0) if rc == 0 else None
+
+        def run(up, down):
+            best = None
+            for _ in range(reps + 1):
+                out = [0.0, 0.0]
+                th = []
+                if up:
+                    th.append(threading.Thread(target=copy, args=(0, True, out)))
+                if down:
+                    th.append(threading.Thread(target=copy, args=(1, False, out)))
+                t0 = time.perf_counter()
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                wall = time.perf_counter() - t0
+                if None in out:
+                    return None
+                best = wall if best is None else min(best, wall)
+            return round(nbytes / best / 1e9, 1)
+        return {"h2d_alone_gbs": run(True, False), "d2h_alone_gbs": run(False, True),
+                "duplex_gbs_per_direction": run(True, True), "bytes_per_copy": nbytes,
+                "how": "zj_memcpy_h2d / zj_memcpy_d2h on pinned buffers, two host threads with a context each for the duplex figure"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:200]}
+    finally:
+        for c, p_, d_ in zip(ctxs, pins, devs):
+            if d_:
+                c.device_free(d_)
+            if p_:
+                L.zj_free_pinned(p_)
+        for c in ctxs:
+            c.close()
+
+
+def e2e_pinned(zj, ctx, desc, d_planes, plane_elems, frame_out, golden_sums=None, nb=8, reps=4, probe=None):
     """Never `value`: the boundary as north_star words it -- coefficient planes in PINNED host memory streamed to HBM with
     hipMemcpyAsync, the fused kernel, the pixels streamed back to pinned host memory (zj_decode_planes_batch: three
     streams, uploads / kernels / downloads overlapped over units of ~16 MB).  `nb` distinct frames of the shard.  PCIe
@@ -121,9 +182,13 @@ def e2e_pinned(zj, ctx, desc, d_planes, plane_elems, frame_out, golden_sums=None
                 L.zj_free_pinned(p_)
         up = sum(sizes[:3]) / best / 1e9
         down = sizes[3] / best / 1e9
+        duplex = (probe or {}).get("duplex_gbs_per_direction")
         return {"megapixels_per_s": round(nb * W * H / 1e6 / best, 1), "ms_per_frame": round(best / nb * 1e3, 3),
                 "frames": nb, "h2d_gbs": round(up, 1), "d2h_gbs": round(down, 1), "pcie_peak_gbs_per_direction": 63.0,
                 "h2d_frac": round(up / 63.0, 3), "d2h_frac": round(down / 63.0, 3),
+                # the yardstick that applies: both directions busy at once on THIS host, measured in this run
+                "pcie_probe": probe,
+                "frac_of_duplex_ceiling": round(min(up, down) / duplex, 3) if duplex else None,
                 "last_frame_matches_golden": (last_sum == golden_sums[nb - 1]) if golden_sums else None,
                 "what": f"{nb} distinct 4096x4096 4:2:0 frames: pinned host planes -> hipMemcpyAsync -> fused kernel -> "
                         f"hipMemcpyAsync -> pinned host RGB (zj_decode_planes_batch, 3 streams), best of {reps} passes"}
@@ -179,12 +244,13 @@ def load_traffic():
 
 
 def live_traffic(workload, B, S, timeout_s=200):
-    """HBM bytes per launch of the fused kernel measured in THIS run: two child runs of this script under
-    `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE in separate passes, as /opt/skills/guides/MI355X_MICROARCH.md
-    prescribes: the two do not fit the TCC's four slots together), a few launches of the same shape each, summarised by
-    tools/pmc_summary.py's rules (KiB units; FETCH_SIZE doubled on gfx950 for wide streaming reads).  The children are
-    started as child processes (never exec'd from this GPU-initialised process).  None if rocprofv3 is unavailable or fails:
-    the caller then falls back to the committed summary and says so."""
+    """HBM bytes and VALU instructions per launch of the fused kernel measured in THIS run: three child runs of this script
+    under `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE and SQ_INSTS_VALU in separate passes, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes: the TCC counters do not fit its four slots together), a few launches
+    of the same shape each, summarised by tools/pmc_summary.py's rules (KiB units; FETCH_SIZE doubled on gfx950 for wide
+    streaming reads).  The children are started as child processes (never exec'd from this GPU-initialised process).
+    Always returns a dict: `hbm_bytes_per_launch` / `sq_insts_valu_per_launch` when the passes worked, `dropped` = why not
+    otherwise (the caller then falls back to the committed summary and says so)."""
     import csv
     import glob
     import shutil
@@ -192,11 +258,11 @@ def live_traffic(workload, B, S, timeout_s=200):
     import tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None
+        return {"dropped": "rocprofv3 not found"}
     tmp = tempfile.mkdtemp(prefix="zj_pmc_", dir="/tmp")
-    means = {}
+    means, why = {}, {}
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
             d = os.path.join(tmp, counter)
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
@@ -204,9 +270,14 @@ def live_traffic(workload, B, S, timeout_s=200):
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--min-untimed", "2",
                    "--frames", str(B), "--shard-frames", str(S), "--workload", workload, "--child"]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                why[counter] = f"child pass exceeded {timeout_s} s"
+                continue
             if r.returncode != 0:
-                return None
+                why[counter] = f"child pass exited with {r.returncode}"
+                continue
             vals = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection*.csv"), recursive=True):
                 with open(f, newline="") as fh:
@@ -214,18 +285,118 @@ def live_traffic(workload, B, S, timeout_s=200):
                         if "zj_fused_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
                             vals.append(float(row["Counter_Value"]))
             if not vals:
-                return None
+                why[counter] = "no rows for the fused kernel in the counter CSV"
+                continue
             means[counter] = (sum(vals) / len(vals), len(vals))
-        fetch, write = means["FETCH_SIZE"][0] * 1024, means["WRITE_SIZE"][0] * 1024
-        return {"hbm_bytes_per_launch": int(2 * fetch + write), "fetch_bytes_raw": fetch, "write_bytes": write,
-                "launches": means["FETCH_SIZE"][1],
-                "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, child runs of this bench.py invocation "
-                          f"({means['FETCH_SIZE'][1]} launches of {B} frames each, walking the same {S}-frame shard as the timed steps); "
-                          f"FETCH_SIZE x2 per MI355X_MICROARCH.md"}
-    except Exception:  # noqa: BLE001 -- the headline must not depend on the profiler
-        return None
+        out = {}
+        if "FETCH_SIZE" in means and "WRITE_SIZE" in means:
+            fetch, write = means["FETCH_SIZE"][0] * 1024, means["WRITE_SIZE"][0] * 1024
+            out.update({"hbm_bytes_per_launch": int(2 * fetch + write), "fetch_bytes_raw": fetch, "write_bytes": write,
+                        "launches": means["FETCH_SIZE"][1],
+                        "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, child runs of this bench.py invocation "
+                                  f"({means['FETCH_SIZE'][1]} launches of {B} frames each, walking the same {S}-frame shard as the timed steps); "
+                                  f"FETCH_SIZE x2 per MI355X_MICROARCH.md"})
+        if "SQ_INSTS_VALU" in means:
+            out["sq_insts_valu_per_launch"] = int(means["SQ_INSTS_VALU"][0])
+            out["sq_source"] = (f"rocprofv3 --pmc SQ_INSTS_VALU, its own pass, child run of this bench.py invocation "
+                                f"({means['SQ_INSTS_VALU'][1]} launches)")
+        if why:
+            out["dropped"] = "; ".join(f"{k}: {v}" for k, v in why.items())
+        return out
+    except Exception as e:  # noqa: BLE001 -- the headline must not depend on the profiler
+        return {"dropped": repr(e)[:200]}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def other_workloads(zj, synth, ctx, dev, side, names=("444-rgb", "444-gray", "422-rgb", "440-rgb"), B=16, iters=100):
+    """Never `value`: BASELINE configs[2] (4:4:4 -> RGB, -> GRAYSCALE; benches/decode.rs:44-131, decode_grayscale.rs:12-58)
+    and the reference's two other sampling modes, each timed like the headline's kernel: 16 resident 4096x4096 frames per
+    launch, HIP events on the launch stream around `iters` launches, against each workload's own algorithmic bytes per
+    pixel.  The wide kernel generation decodes frame 0 once more and must give the same bytes."""
+    import torch
+    out = {}
+    for name in names:
+        try:
+            hs, vs, cs_name, bpp, what = WORKLOADS[name]
+            cs = getattr(zj.ColorSpace, cs_name)
+            pe = [synth.plane_blocks(W, H, hs, vs, c)[0] * synth.plane_blocks(W, H, hs, vs, c)[1] * 64 for c in range(3)]
+            pl = [torch.empty(B * n, dtype=torch.int16, device=dev) for n in pe]
+            for j in range(B):
+                _, qts = synth.make_frame_t(W, H, hs, vs, 3, seed=1234, frame_index=j, device=dev,
+                                            out=[pl[c][j * pe[c]:(j + 1) * pe[c]] for c in range(3)])
+            desc = zj.FrameDesc.make(W, H, hs, vs, 3, cs, qts)
+            fo = W * H * cs.num_components()
+            o = torch.empty(B * fo, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            ptr = [t.data_ptr() for t in pl] + [o.data_ptr()]
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            for _ in range(20):
+                ctx.decode_planes_device(desc, B, ptr[0], ptr[1], ptr[2], ptr[3], side.cuda_stream)
+            ev[0].record(side)
+            for _ in range(iters):
+                ctx.decode_planes_device(desc, B, ptr[0], ptr[1], ptr[2], ptr[3], side.cuda_stream)
+            ev[1].record(side)
+            ev[1].synchronize()
+            ms = ev[0].elapsed_time(ev[1]) / iters
+            _, _, kname = ctx.time_decode_device(desc, B, ptr[0], ptr[1], ptr[2], ptr[3], 1, side.cuda_stream)
+            first = o[:fo].clone()
+            ctx.set_variant(1)
+            try:
+                ctx.decode_planes_device(desc, 1, ptr[0], ptr[1], ptr[2], ptr[3], side.cuda_stream)
+                side.synchronize()
+            finally:
+                ctx.set_variant(0)
+            gbs = B * W * H * bpp / (ms * 1e-3) / 1e9
+            out[name] = {"kernel_ms": round(ms, 4), "megapixels_per_s": round(B * W * H / 1e6 / (ms * 1e-3), 1),
+                         "bytes_per_px": bpp, "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "kernel": kname,
+                         "matches_wide_variant": bool(torch.equal(first, o[:fo])), "what": what}
+            del pl, o, first
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001 -- the headline must not depend on this
+            out[name] = {"error": repr(e)[:200]}
+    return out
+
+
+def reference_files(zj, ctx, reps=5):
+    """Never `value`: BASELINE configs[0] / configs[3] -- the reference's own 1920x1080 test images (copies under
+    tests/golden/) through Decoder: entropy stage on ONE host thread (baseline: the MCU walk of src/mcu.rs:231-351;
+    progressive: the 10-scan coefficient accumulation of src/mcu_prog.rs:49) into pinned planes, then the pixel path on the
+    GPU (upload, fused kernel, download).  The output must hash to what tests/golden/ref_images.json records."""
+    import hashlib
+    import numpy as np
+    out = {}
+    try:
+        rec = {r["file"]: r for r in json.load(open(os.path.join(ROOT, "tests", "golden", "ref_images.json")))["files"]}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:200]}
+    for name in ("test-baseline.jpg", "test-progressive.jpg"):
+        try:
+            data = open(os.path.join(ROOT, "tests", "golden", name), "rb").read()
+            r = rec["test-images/" + name]
+            o = zj.ZuneJpegOptions()
+            o.num_threads, o.pinned_planes = 1, True
+            dec = zj.Decoder(o, ctx)
+            host = gpu = 1e9
+            px = None
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                dec.prepare(data)
+                t1 = time.perf_counter()
+                px = dec.finish_pixels(px)
+                t2 = time.perf_counter()
+                host, gpu = min(host, t1 - t0), min(gpu, t2 - t1)
+            dec.close()
+            mp = r["width"] * r["height"] / 1e6
+            out[name] = {"host_entropy_ms": round(host * 1e3, 3), "gpu_pixels_ms": round(gpu * 1e3, 3),
+                         "megapixels_per_s": round(mp / (host + gpu), 1), "scans": r["scans"], "progressive": bool(r["progressive"]),
+                         "width": r["width"], "height": r["height"],
+                         "sha256_matches_golden": hashlib.sha256(np.ascontiguousarray(px).tobytes()).hexdigest() == r["sha256_rgb"]}
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": repr(e)[:200]}
+    out["what"] = ("the reference's test-images/*.jpg (1920x1080 4:4:4): Huffman / progressive accumulation on one host thread into "
+                   "pinned planes (host_entropy_ms), then upload + fused kernel + download (gpu_pixels_ms); best of 5")
+    return out
 
 
 def load_golden():
@@ -236,12 +407,12 @@ def load_golden():
         return None
 
 
-def golden_match(all_sums, shard_frames, golden):
-    """all_sums[r][j] = checksum of frame j of rank r's shard = global frame r * shard_frames + j (frames beyond the 1024 of
-    configs[4] wrap around): True iff every one equals the oracle's (tests/golden/checksums_seed1234.json), None if the
-    golden file does not reach that far."""
+def golden_match(all_sums, shard_frames, golden, first_rank=0):
+    """all_sums[r][j] = checksum of frame j of rank (first_rank + r)'s shard = global frame (first_rank + r) * shard_frames + j
+    (frames beyond the 1024 of configs[4] wrap around): True iff every one equals the oracle's
+    (tests/golden/checksums_seed1234.json), None if the golden file does not reach that far."""
     gl = [int(x, 16) for x in golden["rgb"]]
-    idx = [(r * shard_frames + j) % 1024 for r in range(len(all_sums)) for j in range(len(all_sums[r]))]
+    idx = [((first_rank + r) * shard_frames + j) % 1024 for r in range(len(all_sums)) for j in range(len(all_sums[r]))]
     if not idx or max(idx) >= len(gl):
         return None
     return all(c == gl[i] for c, i in zip((c for r in all_sums for c in r), idx))
@@ -355,9 +526,25 @@ def main():
                     help="420-rgb = BASELINE.json configs[1]/[4] (the headline); 444-* are configs[2]; 422 / 440 the reference's "
                          "other sampling modes; 420-rgba / 420-chw are the output extensions (4 B/px interleaved, planar u8)")
     ap.add_argument("--variant", choices=["packed", "wide", "packed-direct"], default=None, help="kernel variant (default: library default)")
+    ap.add_argument("--as-rank", default=None, metavar="R/N",
+                    help="one process on one GPU playing rank R of an N-rank run: its shard [R*S, (R+1)*S), its golden offsets; "
+                         "collectives at world size 1 (virtual ranks: everything about configs[4] one GPU can prove)")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip other_workloads / reference_files / scattered_batch")
     args = ap.parse_args()
     if args.child:
         args.no_cpu_baseline = args.no_single_frame = args.no_live_traffic = args.no_e2e = True
+        # a profiler child serialises every dispatch: nothing but the shard's launches (no pre-warm passes, no control)
+        args.no_prewarm = args.no_dense_control = args.no_other_workloads = True
+    virt = None
+    if args.as_rank:
+        try:
+            vr, vn = (int(x) for x in args.as_rank.split("/"))
+            assert 0 <= vr < vn <= 1024
+        except Exception:  # noqa: BLE001
+            sys.exit("--as-rank wants R/N with 0 <= R < N")
+        if args.gpus != 1 or "WORLD_SIZE" in os.environ and os.environ["WORLD_SIZE"] != "1":
+            sys.exit("--as-rank is a single-process mode")
+        virt = (vr, vn)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus, sys.argv[1:], args.rank_timeout)  # does not return
@@ -400,7 +587,7 @@ def main():
     out_cs = getattr(zj.ColorSpace, cs_name)
     ncomp_out = out_cs.num_components()
     # every rank decodes its own contiguous shard [lo, lo + S) of the global batch (image-level sharding)
-    lo, hi = shard.shard_range(S * world, rank, world)
+    lo, hi = shard.shard_range(S * virt[1], virt[0], virt[1]) if virt else shard.shard_range(S * world, rank, world)
     assert hi - lo == S
     golden = load_golden() if (args.workload == "420-rgb" and not args.legacy_data) else None
     plane_elems = [synth.plane_blocks(W, H, hs, vs, c)[0] * synth.plane_blocks(W, H, hs, vs, c)[1] * 64 for c in range(3)]
@@ -491,10 +678,13 @@ def main():
         _, e1, kname = ctx.time_decode_device(desc, B, pk[0], pk[1], pk[2], pk[3], 2 if args.child else max(2, -(-48 // nsub)), stream)
         each.append(e1)
     kernel_ms_each = sum(each) / len(each)
+    # every rank's own figure: the roofline fraction below is the SLOWEST rank's, not rank 0's
+    per_rank_kernel_ms = shard.gather_values(kernel_ms, world, coll_dev)
+    kernel_ms_rank0, kernel_ms = kernel_ms, max(per_rank_kernel_ms)
     # Control for data dependence: the kernel's only data-dependent shortcut is the reference's own DC-only one, and it is
     # taken lane by lane (a wave transforms as long as any of its 64 blocks needs it).  The same sub-batch with ONE coefficient
     # (row 1, column 7) set to 1 in every block -- no DC-only block, nothing sparse about any column -- must therefore decode at
-    # the same rate (the output differs, of course).  Reported beside the headline, never as it.
+    # nearly the same rate (measured: within 3 %; the output differs, of course).  Reported beside the headline, never as it.
     dense_ms = None
     if not args.child and not args.no_dense_control:
         dpl = [d_planes[c][:B * plane_elems[c]].clone() for c in range(3)]
@@ -546,18 +736,54 @@ def main():
         rot(2000)
         torch.cuda.synchronize()
         one_ms_4s = (time.perf_counter() - t1) / 2000 * 1e3
+    # The scattered form (zj_decode_frames_device): 16 NON-adjacent frames of the shard, each named by its own four
+    # pointers, in ONE launch -- what a caller who owns its frames as independent allocations gets (the reference's callers
+    # do: src/mcu.rs:238-250, src/decoder.rs:178).  Eight different irregular frame sets in rotation; every frame is
+    # decoded to its own place in d_out, so the checksums below also cover this path's bytes.
+    scat_ms = None
+    if not args.child and not args.no_other_workloads and S >= 2 * B:
+        fstr = [2 * n for n in plane_elems] + [frame_out]
+        rng = np.random.default_rng(5)
+        sets = []
+        for _ in range(8):
+            idx = [int(v) for v in rng.permutation(S)[:B]]
+            sets.append([[base[i] + f * fstr[i] for f in idx] for i in range(4)])
+        for k in range(24):
+            q = sets[k % 8]
+            ctx.decode_frames_device(desc, q[0], q[1], q[2], q[3], stream)
+        ev[2].record(side)
+        for k in range(104):
+            q = sets[k % 8]
+            ctx.decode_frames_device(desc, q[0], q[1], q[2], q[3], stream)
+        ev[3].record(side)
+        ev[3].synchronize()
+        scat_ms = ev[2].elapsed_time(ev[3]) / 104
     # every frame of the shard decoded once more (untimed), then the trivial gather: per-frame checksums, computed on the
     # GPU, gathered over RCCL and compared with the oracle's (tests/golden/checksums_seed1234.json)
     for k in range(nsub):
         step(k)
     torch.cuda.synchronize()
     sums = []
+    scat_same = None
     if not args.child:
         wts = synth.checksum_weights_t(frame_out // 8, dev)
         sums = [synth.frame_checksum_t(d_out[j * frame_out:(j + 1) * frame_out], wts) for j in range(S)]
+        if scat_ms is not None:
+            # ... and once more through the scattered form, over a cleared output: frames [k*B, (k+1)*B) in reversed order
+            # (two of them swapped: not equally spaced, so the strided shortcut cannot take it), one launch per sub-batch
+            d_out.zero_()
+            torch.cuda.synchronize()  # (zero_ ran on torch's stream, the launches go to `stream`)
+            fstr = [2 * n for n in plane_elems] + [frame_out]
+            for k in range(nsub):
+                idx = list(range(k * B, (k + 1) * B))[::-1]
+                idx[0], idx[3 % B] = idx[3 % B], idx[0]
+                q = [[base[i] + f * fstr[i] for f in idx] for i in range(4)]
+                ctx.decode_frames_device(desc, q[0], q[1], q[2], q[3], stream)
+            torch.cuda.synchronize()
+            scat_same = sums == [synth.frame_checksum_t(d_out[j * frame_out:(j + 1) * frame_out], wts) for j in range(S)]
         del wts
     all_sums = shard.gather_checksums(sums, world, coll_dev)
-    match = golden_match(all_sums, S, golden) if (golden and sums) else None
+    match = golden_match(all_sums, S, golden, first_rank=virt[0] if virt else 0) if (golden and sums) else None
     # SURVEY.md 8e, optional: the decoded frames themselves to rank 0 -- the only step that puts real bytes on xGMI.
     # Measured on its own, after everything else; never part of `value`.
     gather_rgb = None
@@ -588,18 +814,20 @@ def main():
         tr = load_traffic()
         if tr and not (tr.get("workload", "420-rgb") == args.workload and tr.get("frames_per_launch", 16) == B):
             tr = None  # the committed counters describe another launch shape
-        live = None if (args.no_live_traffic or world > 1) else live_traffic(args.workload, B, S)
+        live = {} if (args.no_live_traffic or world > 1) else live_traffic(args.workload, B, S)
+        live_hbm = live if live.get("hbm_bytes_per_launch") else None
         # Second bound, reported beside the HBM one: integer VALU issue.  A wave64 integer instruction occupies
         # its SIMD for 4 cycles (16 lanes per SIMD per clock; profiles/r01_ubench_valu_issue_cost.txt), so the
         # chip retires at most 1024 SIMDs x 2.4 GHz / 4 wave-instructions per second.
         valu = None
-        if tr and tr.get("sq_insts_valu_per_launch"):
+        sq = live if live.get("sq_insts_valu_per_launch") else tr
+        if sq and sq.get("sq_insts_valu_per_launch"):
             peak_wi = 1024 * 2.4e9 / 4.0
-            ach_wi = tr["sq_insts_valu_per_launch"] / (kernel_ms * 1e-3)
-            valu = {"wave_insts_per_launch": tr["sq_insts_valu_per_launch"], "achieved": round(ach_wi / 1e9, 1),
+            ach_wi = sq["sq_insts_valu_per_launch"] / (kernel_ms * 1e-3)
+            valu = {"wave_insts_per_launch": sq["sq_insts_valu_per_launch"], "achieved": round(ach_wi / 1e9, 1),
                     "peak": round(peak_wi / 1e9, 1), "unit": "G wave64-instructions/s", "frac": round(ach_wi / peak_wi, 4),
-                    "source": tr.get("sq_source"), "replayed": True}
-        traffic = live["hbm_bytes_per_launch"] if live else (tr or {}).get("hbm_bytes_per_launch")
+                    "source": sq.get("sq_source"), "replayed": sq is not live}
+        traffic = live_hbm["hbm_bytes_per_launch"] if live_hbm else (tr or {}).get("hbm_bytes_per_launch")
         res = {
             "metric": "megapixels/sec decoded (IDCT->RGB), 4K 4:2:0 baseline" if args.workload == "420-rgb" else f"megapixels/sec decoded, 4K {args.workload}",
             "value": round(mp_total / elapsed, 1),
@@ -619,19 +847,24 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic,
-                         "traffic_replayed": (not live) if traffic is not None else None,
-                         "traffic_source": live["source"] if live else (tr or {}).get("source"),
-                         "kernel": kname, "kernel_ms": round(kernel_ms, 4), "kernel_ms_single_launch": round(kernel_ms_each, 4),
+                         "traffic_replayed": (not live_hbm) if traffic is not None else None,
+                         "traffic_source": live_hbm["source"] if live_hbm else (tr or {}).get("source"),
+                         "live_counters_dropped": live.get("dropped") or ("N > 1: the counter passes run at N = 1 only" if world > 1 else
+                                                                          ("--no-live-traffic" if args.no_live_traffic else None)),
+                         "kernel": kname, "kernel_ms": round(kernel_ms, 4), "kernel_ms_rank0": round(kernel_ms_rank0, 4),
+                         "per_rank_kernel_ms": [round(v, 4) for v in per_rank_kernel_ms],
+                         "kernel_ms_single_launch": round(kernel_ms_each, 4),
                          "kernel_launches_timed": kiters, "kernel_ms_timed_region": round(kernel_ms_region, 4),
                          "kernel_timing": f"HIP events on the launch stream; {kiters} launches walking the shard's {nsub} "
                                           f"sub-batches of {B} frames (>= 100 whatever --steps); kernel_ms_timed_region = "
                                           f"events around the {args.steps} timed steps; kernel_ms_single_launch = own event "
-                                          f"pair per launch",
+                                          f"pair per launch; kernel_ms (and frac) = the slowest rank's, per_rank_kernel_ms = every rank's",
                          "algorithmic_bytes_per_launch": int(algo_bytes),
                          "dense_control": None if dense_ms is None else {
                              "kernel_ms": round(dense_ms, 4), "frac": round(algo_bytes / (dense_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "vs_kernel_ms": round(dense_ms / kernel_ms_rank0, 4),
                              "what": "the same 16 frames with coefficient (row 1, column 7) of every block set to 1: no DC-only "
-                                     "block, no empty column anywhere; the rate does not depend on the coefficients' sparsity"},
+                                     "block, no empty column anywhere; the rate stays within 3 % of the shard's (vs_kernel_ms)"},
                          "valu_issue": valu,
                          "single_frame_launch": None if one_ms is None else {
                              "kernel_ms": round(one_ms, 4), "kernel_ms_single_launch": round(one_ms_each, 4),
@@ -640,26 +873,42 @@ def main():
                              "frac": round(W * H * bytes_per_px / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              "four_streams_ms_per_frame": round(one_ms_4s, 4),
                              "four_streams_megapixels_per_s": round(W * H / 1e6 / (one_ms_4s * 1e-3), 1),
-                             "four_streams_frac": round(W * H * bytes_per_px / (one_ms_4s * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
+                             "four_streams_frac": round(W * H * bytes_per_px / (one_ms_4s * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                         "scattered_batch": None if scat_ms is None else {
+                             "kernel_ms": round(scat_ms, 4), "vs_kernel_ms": round(scat_ms / kernel_ms_rank0, 4),
+                             "frac": round(algo_bytes / (scat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "same_checksums_as_contiguous": scat_same,
+                             "what": f"zj_decode_frames_device: {B} non-adjacent frames of the shard per launch, each named by its own "
+                                     f"four pointers (by value in the kernel arguments); 104 launches over 8 irregular frame sets"}},
             "rccl_ranks": world if (world > 1 and backend == "nccl") else 0,
             "collective_backend": None if world == 1 else backend,
             "per_rank_ms": [round(v, 4) for v in per_rank_ms],
+            "as_rank": None if not virt else {"rank": virt[0], "of": virt[1], "global_frames": [lo, hi]},
             "frames_checksummed": sum(len(r) for r in all_sums),
             "checksums_match_golden": match,
         }
-        if not args.no_cpu_baseline and args.workload == "420-rgb" and world == 1:  # host baseline: rank 0 at N=1 only
+        if not args.no_cpu_baseline and args.workload == "420-rgb":
+            # host baseline, rank 0, "in the same run" at every N (north_star): ~20 s of CPU work at N = 1, ~8 s at N > 1,
+            # where the other ranks sleep on the store meanwhile (shard.wait_for_rank0: no spinning on the host cores being timed)
             nf = 2 if args.legacy_data else min(8, S)
             cpu_frames = [[d_planes[c][j * plane_elems[c]:(j + 1) * plane_elems[c]].cpu().numpy() for c in range(3)]
                           for j in range(nf)]
-            res["cpu_baseline"] = cpu_baseline(cpu_frames, qts)
+            res["cpu_baseline"] = cpu_baseline(cpu_frames, qts, budget_s=20.0 if world == 1 else 8.0)
             del cpu_frames
-            res["from_files"] = from_files(zj, ctx)
-        if not args.no_e2e and args.workload == "420-rgb" and world == 1:
+            if world == 1 and not virt:
+                res["from_files"] = from_files(zj, ctx)
+        if not args.no_other_workloads and args.workload == "420-rgb" and world == 1 and not virt:
+            res["other_workloads"] = other_workloads(zj, synth, ctx, dev, side)
+            res["reference_files"] = reference_files(zj, ctx)
+        if not args.no_e2e and args.workload == "420-rgb" and world == 1 and not virt:
             gsums = [int(x, 16) for x in golden["rgb"][lo:lo + 8]] if golden else None
-            res["e2e_pinned"] = e2e_pinned(zj, ctx, desc, d_planes, plane_elems, frame_out, gsums, nb=min(8, S))
+            res["e2e_pinned"] = e2e_pinned(zj, ctx, desc, d_planes, plane_elems, frame_out, gsums, nb=min(8, S), probe=pcie_probe(zj, gpu_index))
         if gather_rgb is not None:
             res["gather_rgb"] = gather_rgb
         print(json.dumps(res), flush=True)
+        shard.signal_from_rank0("zj_bench_rank0_done", world)
+    else:
+        shard.wait_for_rank0("zj_bench_rank0_done", world, timeout_s=args.rank_timeout)
     shard.barrier(world)
     ctx.close()
     import torch.distributed as dist

@@ -100,9 +100,22 @@ extern "C" int zje_threads_per_group(const zj_frame_desc* d)
     return rc ? rc : pl.nt;
 }
 
+static int dispatch1(const Plan& pl, const Params& p, bool fast);
+
+// as launch_params of zj_api.cpp: a ragged width is two launches (split_ragged)
 static int dispatch(const Plan& pl, const Params& p)
 {
-#define ZJ_CASE(H, V, O) if (pl.hs == H && pl.vs == V && pl.out == O) { if (pl.fast) run<H, V, O, true>(p); else run<H, V, O, false>(p); return ZJ_OK; }
+    Params in, edge;
+    if (split_ragged(pl, p, in, edge)) {
+        const int rc = dispatch1(pl, in, true);
+        return rc ? rc : dispatch1(pl, edge, false);
+    }
+    return dispatch1(pl, p, pl.fast);
+}
+
+static int dispatch1(const Plan& pl, const Params& p, bool fast)
+{
+#define ZJ_CASE(H, V, O) if (pl.hs == H && pl.vs == V && pl.out == O) { if (fast) run<H, V, O, true>(p); else run<H, V, O, false>(p); return ZJ_OK; }
     ZJ_CASE(1, 1, OUT_RGB) ZJ_CASE(1, 1, OUT_GRAY) ZJ_CASE(1, 1, OUT_YCBCR)
     ZJ_CASE(2, 1, OUT_RGB) ZJ_CASE(2, 1, OUT_GRAY) ZJ_CASE(2, 1, OUT_YCBCR)
     ZJ_CASE(1, 2, OUT_RGB) ZJ_CASE(1, 2, OUT_GRAY) ZJ_CASE(1, 2, OUT_YCBCR)

@@ -48,7 +48,17 @@ def _worker(rank, world, port, nframes, q):
     frames = torch.full((1000,), 7 + rank, dtype=torch.uint8)
     outs, secs = shard.gather_frames(frames, rank, world)
     got = None if outs is None else [int(o[0]) for o in outs]
-    q.put((rank, lo, hi, elapsed, total, allsums, per_rank, got))
+    # bench.py's host-only leg at N > 1: rank 0 works (the CPU baseline), the others park on the store, not in a collective
+    import time
+    t0 = time.monotonic()
+    if rank == 0:
+        time.sleep(1.0)
+        shard.signal_from_rank0("zj_test_done", world)
+    else:
+        shard.wait_for_rank0("zj_test_done", world, timeout_s=30)
+    parked = time.monotonic() - t0
+    shard.barrier(world)
+    q.put((rank, lo, hi, elapsed, total, allsums, per_rank, got, parked))
 
 
 import pytest
@@ -77,7 +87,8 @@ def test_two_rank_shard_and_gather(rendezvous, tmp_path):
         planes, qts = synth.make_frame(64, 32, 2, 2, 3, seed=500, frame_index=i)
         rc, out = oc.decode_planes(oc.make_frame(64, 32, 2, 2, 3, oc.RGB, qts), planes)
         expect.append(shard.frame_checksum(out))
-    for rank, lo, hi, elapsed, total, allsums, per_rank, got in res:
+    for rank, lo, hi, elapsed, total, allsums, per_rank, got, parked in res:
+        assert 0.5 < parked < 20         # rank 1 waited for rank 0's signal (about a second), neither returned early nor timed out
         assert per_rank == [10.0, 11.0]  # per-rank values on every rank (bench.py's per_rank_ms)
         assert got == ([7, 8] if rank == 0 else None)   # the frame gather lands on rank 0 only
         assert elapsed == 2.0            # MAX over ranks
@@ -127,6 +138,11 @@ def test_golden_checksum_comparison_has_teeth():
     assert bench.golden_match(swapped, S, g) is False
     assert bench.golden_match(good[::-1], S, g) is False
     assert bench.golden_match([], S, g) is None
+    # virtual ranks (bench.py --as-rank R/8): one shard checked at rank R's offsets into the golden list
+    for r in (0, 3, 7):
+        assert bench.golden_match([good[r]], S, g, first_rank=r) is True
+        assert bench.golden_match([good[r]], S, g, first_rank=(r + 1) % 8) is False
+    assert bench.golden_match([good[6], good[7]], S, g, first_rank=6) is True
 
 
 def test_bench_self_launch_ends_hung_ranks():

@@ -229,3 +229,41 @@ def test_emulated_scattered_more_frames_than_one_table(synth):
         got = outs[i].reshape(h, 3 * w)
         assert np.array_equal(got[:, :3 * w - 16], exps[i % 7][:, :3 * w - 16]), i
         assert (got[:, 3 * w - 16:] == 0x33).all()
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("w", [65, 255, 257, 289, 303, 304, 305, 311, 312, 313, 319, 321, 511, 513, 535, 560, 561, 569, 575, 577, 767, 769,
+                               1023, 1025, 1079, 1081, 2500, 2501, 2503])
+def test_emulated_ragged_width_split_into_fast_interior_and_generic_edge(mode, w, synth):
+    """A ragged width runs as two launches (zj_plan.h: split_ragged): the leading tile columns on the aligned fast path --
+    rows starting at any byte --, the row ends on the generic store path.  Widths on both sides of every boundary of the
+    split (tile widths 256 / 512 pixels, the 48-pixel margin in front of the early-written tail, P % 16 == 8), every
+    output kind, both the reference's bytes (zero_fill) and the strip-level contract (never-written bytes untouched)."""
+    hs, vs = MODES[mode]
+    h = 8 * vs * (2 if hs == 2 else 1) + 3   # one strip and a clipped second one
+    planes, qts = synth.make_frame(w, h, hs, vs, 3, seed=w)
+    for out_cs in (oc.RGB, oc.GRAYSCALE, oc.YCBCR):
+        f = oc.make_frame(w, h, hs, vs, 3, out_cs, qts)
+        rc, exp = oc.decode_planes(f, planes)
+        rce, out = emu_c.decode_planes(f, planes)
+        if rc != 0:
+            assert rce == -5
+            continue
+        assert rce == 0
+        bad = np.nonzero(out != exp)[0]
+        assert bad.size == 0, (mode, w, out_cs, bad[:8], bad.size)
+        if out_cs == oc.RGB:  # zero_fill = 0: whatever the reference never writes keeps the caller's bytes
+            rce, raw = emu_c.decode_planes(f, planes, zero_fill=0, poison=0x5C)
+            rce2, raw2 = emu_c.decode_planes(f, planes, zero_fill=0, poison=0xA3)
+            assert rce == 0 and rce2 == 0
+            never = raw != raw2                      # bytes that kept the poison
+            assert np.array_equal(raw[~never], exp[~never]) and not exp[never].any()
+    # the extensions take the same split: plain placement, RGBA, planar
+    for out_cs, flags, layout in ((oc.RGB, 1, 0), (oc.RGBA, 0, 0), (oc.RGB, 0, 1)):
+        f = oc.make_frame(w, h, hs, vs, 3, out_cs, qts)
+        rc, exp = oc.decode_planes(f, planes, plain=True)
+        assert rc == 0
+        if layout == 1:
+            exp = np.ascontiguousarray(exp.reshape(h, w, 3).transpose(2, 0, 1)).reshape(-1)
+        rce, out = emu_c.decode_planes(f, planes, flags=flags, out_layout=layout)
+        assert rce == 0 and np.array_equal(out, exp), (mode, w, out_cs, flags, layout)

@@ -30,6 +30,33 @@ def test_two_self_launched_ranks_decode_their_shards_to_the_golden_checksums():
     assert res["collective_backend"] == "gloo" and res["rccl_ranks"] == 0     # same-GPU plumbing run: no RCCL
     assert len(res["per_rank_ms"]) == 2 and all(v > 0 for v in res["per_rank_ms"])
     assert max(res["per_rank_ms"]) <= res["ms_per_step"] * 1.001                # the line's time is the MAX over ranks
+    rf = res["roofline"]
+    assert len(rf["per_rank_kernel_ms"]) == 2 and rf["kernel_ms"] == max(rf["per_rank_kernel_ms"])  # the slowest rank's
+    assert rf["live_counters_dropped"] and rf["scattered_batch"]["same_checksums_as_contiguous"] is True
+
+
+@pytest.mark.gpu
+def test_two_ranks_carry_the_cpu_baseline_in_the_same_run():
+    """north_star: the AVX2 figure "in the same run" at every N -- rank 0 times it after the gather while the other ranks
+    sleep on the store (the driver's command shape, shortened)."""
+    res = _bench("--gpus", "2", "--steps", "4", "--warmup", "1", "--min-untimed", "1", "--shard-frames", "16",
+                 "--no-live-traffic", "--no-single-frame", "--no-dense-control", env_extra={"ZJ_BENCH_SAME_GPU": "1"})
+    cb = res["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 100 and cb["cores"] >= 1 and "4 threads" in cb["sample"]
+    assert res["checksums_match_golden"] is True and res["n_gpus"] == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("r", range(8))
+def test_virtual_rank_decodes_its_shard_of_configs4_to_the_golden_checksums(r):
+    """--as-rank R/8: rank R's shard of the 1024-frame batch (global frames [128 R, 128 R + 128)), its frame indices and
+    golden offsets, on the box's one GPU.  R = 0..7 together: every frame of configs[4] decoded on hardware."""
+    res = _bench("--as-rank", f"{r}/8", "--steps", "8", "--warmup", "1", "--min-untimed", "1", "--no-cpu-baseline",
+                 "--no-live-traffic", "--no-single-frame", "--no-e2e", "--no-dense-control")
+    assert res["as_rank"] == {"rank": r, "of": 8, "global_frames": [128 * r, 128 * r + 128]}
+    assert res["frames_checksummed"] == 128 and res["checksums_match_golden"] is True
+    assert res["roofline"]["scattered_batch"]["same_checksums_as_contiguous"] is True
+    assert res["n_gpus"] == 1 and "other_workloads" not in res
 
 
 @pytest.mark.gpu
@@ -62,3 +89,16 @@ def test_single_rank_line_has_the_contract_fields():
     e = res["e2e_pinned"]
     assert "error" not in e, e
     assert e["megapixels_per_s"] > 1000 and e["last_frame_matches_golden"] is True
+    assert e["pcie_probe"]["duplex_gbs_per_direction"] > 5 and 0 < e["frac_of_duplex_ceiling"] < 1.5
+    assert rf["scattered_batch"] is None                              # a 16-frame shard has no 16 non-adjacent frames
+    # configs[2] / configs[3] in the driver's line
+    ow = res["other_workloads"]
+    for name, bpp in (("444-rgb", 9.0), ("444-gray", 3.0), ("422-rgb", 7.0), ("440-rgb", 7.0)):
+        assert "error" not in ow[name], ow[name]
+        assert ow[name]["bytes_per_px"] == bpp and ow[name]["kernel_ms"] > 0 and ow[name]["matches_wide_variant"] is True
+        assert abs(ow[name]["frac"] - 16 * 4096 * 4096 * bpp / (ow[name]["kernel_ms"] * 1e-3) / 1e9 / 8000.0) < 2e-3
+    rfiles = res["reference_files"]
+    for name, prog in (("test-baseline.jpg", False), ("test-progressive.jpg", True)):
+        assert "error" not in rfiles[name], rfiles[name]
+        assert rfiles[name]["sha256_matches_golden"] is True and rfiles[name]["progressive"] is prog
+        assert rfiles[name]["host_entropy_ms"] > 0 and rfiles[name]["gpu_pixels_ms"] > 0

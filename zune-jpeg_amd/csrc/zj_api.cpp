@@ -333,6 +333,12 @@ static int launch_params(zj_ctx* c, const Plan& pl, Params& p, hipStream_t s)
             p.stagger_magic = g.m; p.stagger_shift = g.s;
         }
     }
+    Params in, edge;
+    if (split_ragged(pl, p, in, edge)) { // a ragged width: leading tile columns on the fast path, the row ends on the generic one
+        ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->variant, 1, in, s));
+        ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->variant, 0, edge, s));
+        return ZJ_OK;
+    }
     ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->variant, pl.fast ? 1 : 0, p, s));
     return ZJ_OK;
 }
@@ -491,9 +497,10 @@ int zj_time_decode_device(zj_ctx* c, const zj_frame_desc* d, size_t nframes, con
     ZJ_HIP(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     if (kernel_name) {
-        Params p;
+        Params p, in, edge;
         fill_params(d, pl, nframes, d_y, d_cb, d_cr, d_out, 1, p);
-        *kernel_name = fused_kernel_name(pl.hs, pl.vs, pl.out, c->variant, pl.fast ? 1 : 0, p);
+        const bool split = split_ragged(pl, p, in, edge); // a ragged width: the launch over the leading tile columns dominates
+        *kernel_name = fused_kernel_name(pl.hs, pl.vs, pl.out, c->variant, (pl.fast || split) ? 1 : 0, split ? in : p);
     }
     // (1) `iters` back-to-back launches between one event pair
     ZJ_HIP(c, hipEventRecord(c->ev0, s));

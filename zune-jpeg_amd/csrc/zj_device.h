@@ -37,6 +37,14 @@ namespace zj {
 typedef uint16_t u16x2 __attribute__((vector_size(4)));  // packed pair, wrap-around + - *
 typedef int16_t s16x2 __attribute__((vector_size(4)));   // packed pair, arithmetic >>, min/max
 
+// an address held as an integer -> a pointer the compiler knows to be in GLOBAL memory (address space 1), so that what is
+// loaded / stored through it stays global_load / global_store (scalar base + 32-bit lane offset) instead of flat_*
+#if defined(ZJ_EMU)
+#define ZJ_GLOBAL_PTR(T, v) (reinterpret_cast<T*>(v))
+#else
+#define ZJ_GLOBAL_PTR(T, v) ((T*)(__attribute__((address_space(1))) T*)(v))
+#endif
+
 struct alignas(16) U4 { uint32_t x, y, z, w; };
 struct alignas(8) U2 { uint32_t x, y; };
 typedef uint32_t V4 __attribute__((vector_size(16)));    // the same 16 bytes for builtins that want a vector
@@ -602,7 +610,7 @@ template <> struct TileWidth<2, 1, true> { static constexpr int TWC = ZJ_TWC_H; 
 #ifndef ZJ_NT_MIN_V
 #define ZJ_NT_MIN_V 0
 #endif
-template <> struct TileWidth<1, 2, true> { static constexpr int TWC = ZJ_TWC_V; };   // 4*TWC = 256 blocks, 512 px
+template <> struct TileWidth<1, 2, true> { static constexpr int TWC = ZJ_TWC_V; };   // 4*TWC = 128 blocks, 256 px (128 threads)
 // 4:4:4 with chroma: 3*TWC blocks.  Round 1 ran TWC = 84 (252 lanes busy, 672 pixels).  TWC = 64 with 256 threads is
 // 15 % faster (tools/ab_libs_w.sh 444-rgb): 192 blocks on three waves (the fourth idles through the IDCT), but 512 pixels
 // x 8 rows = 256 items = exactly one colour round for four waves, and 4096-pixel rows split into whole tiles (672 leaves a
@@ -725,7 +733,8 @@ struct Params {
     int width, height;            // pixels
     int mcu_x;                    // MCUs per row (headers.rs:317)
     int n_strips;
-    int tiles_per_row;
+    int tiles_per_row;            // tile columns of THIS launch (a ragged width is two launches, see tile0)
+    int tile0;                    // first tile column of this launch
     int nframes;
     int zero_fill;                // 1: also write the bytes the reference leaves 0 (Q5/Q6)
     int total_tiles;
@@ -744,22 +753,10 @@ struct Params {
     // Scattered batch (zj_decode_frames_device): the frames of one launch are independent allocations, the way the
     // reference's callers own them (a fresh Vec per strip, src/mcu.rs:238-250; a Vec<u8> per decode, src/decoder.rs:178).
     // Their addresses travel by value like the tables -- nothing to stage, nothing to keep alive -- and a workgroup reads
-    // the four of its frame with scalar loads indexed by the (uniform) frame number.
-    int scatter;                  // 0: frame f at base + f * stride; 1: at fptr[.][f]
-    uint64_t fptr[4][SCATTER_MAX]; // y | cb | cr | out
+    // the four of its frame with ONE scalar load (32 bytes, one cache line) indexed by the (uniform) frame number.  A
+    // launch is scattered when its base pointer `y` is null: the flag costs the contiguous form no extra load.
+    uint64_t fptr[SCATTER_MAX][4]; // per frame: y | cb | cr | out
 };
-
-// where frame `f` of the launch lives (f is workgroup-uniform: scalar loads from the kernel arguments)
-ZJ_DEV const int16_t* frame_plane(const Params& p, const int comp, const int f)
-{
-    if (p.scatter) return reinterpret_cast<const int16_t*>(p.fptr[comp][f]);
-    return comp == 0 ? p.y + (long long)f * p.y_frame_stride : (comp == 1 ? p.cb : p.cr) + (long long)f * p.c_frame_stride;
-}
-ZJ_DEV uint8_t* frame_pixels(const Params& p, const int f)
-{
-    if (p.scatter) return reinterpret_cast<uint8_t*>(p.fptr[3][f]);
-    return p.out + (long long)f * p.out_frame_stride;
-}
 
 // vertical schedule of upsample_vertical (upsampler/scalar.rs:84-144): pair k -> (near, far)
 ZJ_DEV void vsched(int k, int& n, int& f) { n = k; f = (k == 0) ? 0 : (k < 7 ? k + 1 : 7); }
@@ -782,7 +779,12 @@ ZJ_DEV void vrows(int m, int& ra, int& rb)
     }
 }
 
-struct TileId { int frame, strip, tile; };
+// a workgroup's tile, and where its frame lives (all workgroup-uniform: the compiler keeps them in scalar registers)
+struct TileId {
+    int frame, strip, tile;
+    const int16_t* y; const int16_t* cb; const int16_t* cr; // the frame's planes
+    uint8_t* out;                                           // the frame's pixels
+};
 
 // Division of a workgroup id by a launch constant (tiles per row, strips per frame) as multiply-high + shift with a
 // host-computed multiplier: 5 scalar instructions where the compiler's expansion of `/` and `%` by a kernel argument is
@@ -814,7 +816,7 @@ ZJ_DEV TileId tile_from_id(const Params& p, const int id)
     TileId t;
     const Magic gt = {p.tpr_magic, p.tpr_shift}, gs = {p.ns_magic, p.ns_shift};
     const uint32_t r = magic_div((uint32_t)id, gt);
-    t.tile = id - (int)r * p.tiles_per_row;
+    t.tile = id - (int)r * p.tiles_per_row + p.tile0;
     const uint32_t f = magic_div(r, gs);
     t.strip = (int)r - (int)f * p.n_strips;
     t.frame = (int)f;
@@ -826,7 +828,28 @@ ZJ_DEV TileId tile_from_id(const Params& p, const int id)
 #define ZJ_XCD_ORDER 1 // 0: workgroup b decodes tile b (A/B knob, round 4)
 #endif
 ZJ_DEV int xcd_order(const int bid, const int n) { return (ZJ_XCD_ORDER && (n & 7) == 0) ? (bid & 7) * (n >> 3) + (bid >> 3) : bid; }
-ZJ_DEV TileId decode_tile(const Params& p, int bid) { return tile_from_id(p, xcd_order(bid, p.total_tiles)); }
+ZJ_DEV TileId decode_tile(const Params& p, int bid)
+{
+    TileId t = tile_from_id(p, xcd_order(bid, p.total_tiles));
+    // One scalar branch per workgroup; everything after it sees four scalar pointers, whichever form the launch has --
+    // the per-lane code selects between t.cb and t.cr exactly as it selected between p.cb and p.cr before the table existed
+    // (an index into the table by a per-lane component number would be a vector load from the kernel arguments).
+    if (p.y == nullptr) {
+        // (an integer turned into a pointer is a FLAT pointer to the compiler: every load and store of the kernel became a
+        // flat_* instruction with a 64-bit per-lane address, +1.9 % kernel time, until the table's entries were declared
+        // what they are -- addresses in global memory)
+        t.y = ZJ_GLOBAL_PTR(const int16_t, p.fptr[t.frame][0]);
+        t.cb = ZJ_GLOBAL_PTR(const int16_t, p.fptr[t.frame][1]);
+        t.cr = ZJ_GLOBAL_PTR(const int16_t, p.fptr[t.frame][2]);
+        t.out = ZJ_GLOBAL_PTR(uint8_t, p.fptr[t.frame][3]);
+    } else {
+        t.y = p.y + (long long)t.frame * p.y_frame_stride;
+        t.cb = p.cb + (long long)t.frame * p.c_frame_stride;
+        t.cr = p.cr + (long long)t.frame * p.c_frame_stride;
+        t.out = p.out + (long long)t.frame * p.out_frame_stride;
+    }
+    return t;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Block b of a tile: where its 64 coefficients live in HBM and where its pixels go in LDS.
@@ -864,7 +887,7 @@ ZJ_DEV BlockLoc locate(const Params& p, const TileId t, const int b, char* lds)
         const int gcol = t.tile * C::TWYB + bcol;
         if (gcol >= ybw) return L;
         const long long blk = (long long)(t.strip * C::YBR + brow) * ybw + gcol;
-        L.src = reinterpret_cast<const U4*>(frame_plane(p, 0, t.frame) + blk * 64);
+        L.src = reinterpret_cast<const U4*>(t.y + blk * 64);
         L.dst = lds + ((brow * 8) * C::TWY + bcol * 8) * LL::YPX;
         L.valid = true;
         return L;
@@ -899,7 +922,7 @@ ZJ_DEV BlockLoc locate(const Params& p, const TileId t, const int b, char* lds)
         gcol = cb0 + j; lcol = 8 * j;
     }
     const long long blk = (long long)(t.strip * C::CBR + brow) * cbw + gcol;
-    const int16_t* plane = frame_plane(p, comp, t.frame);
+    const int16_t* plane = comp == 1 ? t.cb : t.cr;
     L.src = reinterpret_cast<const U4*>(plane + blk * 64);
     if (L.halo) { // the one pixel column of a halo block that is ever read: a column of the side array
         L.dst = reinterpret_cast<char*>(lds_halo_raw<C, GEN>(lds, comp, L.halo - 1, brow * 8));
@@ -1034,7 +1057,7 @@ ZJ_DEV HaloLane halo_locate(const Params& p, const TileId t, const int hl /* 0..
     // the neighbour beyond the strip's first / last column is the other end of the row (Q4: one flat array)
     const int gcol = side == 0 ? (cb0 > 0 ? cb0 - 1 : cbw - 1) : (cb0 + nvalid < cbw ? cb0 + nvalid : 0);
     const long long blk = (long long)(t.strip * C::CBR + brow) * cbw + gcol;
-    const int16_t* plane = frame_plane(p, H.comp, t.frame);
+    const int16_t* plane = H.comp == 1 ? t.cb : t.cr;
     H.src = plane + blk * 64 + H.j;
     H.dst = reinterpret_cast<char*>(lds_halo_raw<C, GEN_PACKED>(lds, H.comp, side, brow * 8));
     H.pitch = 2;
@@ -1203,7 +1226,11 @@ ZJ_DEV void store16(uint8_t* p, const U4& v, const bool staged = false)
 #if !defined(ZJ_EMU)
     if ((ZJ_NT & 1) || ((ZJ_NT & 4) && staged)) { const V4 t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<V4*>(p)); return; }
 #endif
+#if defined(ZJ_EMU)
+    __builtin_memcpy(p, &v, 16); // rows of a ragged width start at any byte (the GPU's global stores take any alignment)
+#else
     *reinterpret_cast<U4*>(p) = v;
+#endif
 }
 
 // 4 pixels -> 12 bytes from UNCLAMPED i16 pairs.  EO arrangement: (e) holds px 0,2  (o) px 1,3.
@@ -1354,7 +1381,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
     const int x0 = t.tile * C::TWY;
     const int ncomp = OUT == OUT_GRAY ? 1 : (OUT == OUT_RGBA ? 4 : 3);
     const long long row_bytes = OUT == OUT_RGB_CHW ? (long long)W : (long long)W * ncomp; // CHW: one plane's row
-    uint8_t* const frame_out = frame_pixels(p, t.frame);
+    uint8_t* const frame_out = t.out;
     const int elements = P / 16 - 1; // worker.rs:171 (P >= 32 on this path)
     if (TS) io->kind = 0;
 
@@ -1647,7 +1674,7 @@ ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid, char* 
     const int nvg = (P - x0) / 16 < C::NGRP ? (P - x0) / 16 : C::NGRP; // valid 16-pixel groups of this tile
     const uint32_t row_bytes = (uint32_t)(PPI == 4 ? 4 : 3) * (uint32_t)p.width;
     // everything up to here is uniform: a scalar base address, 32-bit per-lane offsets below
-    uint8_t* const tile_out = frame_pixels(p, t.frame) + (long long)t.strip * C::SH * row_bytes + (long long)(PPI == 4 ? 4 : 3) * x0;
+    uint8_t* const tile_out = t.out + (long long)t.strip * C::SH * row_bytes + (long long)(PPI == 4 ? 4 : 3) * x0;
     const int w = uniform(tid >> 6), L = tid & 63;
     const int item0 = 64 * w + round * C::NT;  // first item of this wave's round
     if (item0 >= C::NITEMS) return;            // (the last round of a tile is partly empty)
@@ -1703,6 +1730,7 @@ inline bool ts_eligible(const Params& p, const int out, const bool fast)
     if (out != OUT_RGB || p.plain) return true;
     const int P = p.mcu_x * 8 * (C::TWYB / C::TWC);
     const int tiles = (P + C::TWY - 1) / C::TWY;
+    if (p.tile0 + p.tiles_per_row < tiles) return true; // a launch over leading tile columns only: no row end in it
     const int nvg_last = (P - (tiles - 1) * C::TWY) / 16;
     if (nvg_last < 2) return false;
     for (int m = 0; m < C::SH; m++)

@@ -233,8 +233,11 @@ inline bool ref_dc_misread(BitReader& br, int& rbl, const int rbl0, const uint64
     const int avail = rbl - len; // 0 <= avail < s (len <= 16 <= rbl)
     if (need_hist) { *need_hist = true; return true; } // (a caller without the history: it discards this decode and starts over)
     // the reference's aligned_buffer at this moment: `avail` valid bits, the refill's zeros, the history since the refill
-    const int nhist = rbl0 - avail; // bits consumed since the last real refill (the DC code included): 5 .. 64 - 16
-    uint64_t aligned = nhist > 0 && nhist < 64 ? hist & ((1ull << nhist) - 1) : 0;
+    // bits consumed since the last real refill (the DC code included): up to 64 -- an AC refill at bits_left == 32 gives
+    // rbl0 == 64, and a long last AC symbol plus a 16-bit DC code can use all of it: then the whole register
+    // is history
+    const int nhist = rbl0 - avail;
+    uint64_t aligned = nhist >= 64 ? hist : (nhist > 0 ? hist & ((1ull << nhist) - 1) : 0);
     if (avail > 0) aligned |= (uint64_t)br.peek(avail) << (64 - avail);
     *bits = (int32_t)(aligned >> (64 - s));
     if (avail > 0) br.drop(avail);

@@ -84,6 +84,36 @@ def init_process_group(backend, rank, world, force=False, port_file=None, timeou
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
 
 
+def _default_store():
+    try:
+        import torch.distributed as dist
+        return dist.distributed_c10d._get_default_store()
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def signal_from_rank0(tag, world):
+    """Rank 0 has finished a host-only leg (bench.py's cpu_baseline at N > 1): release the ranks parked in wait_for_rank0."""
+    if world > 1:
+        st = _default_store()
+        if st is not None:
+            st.set(tag, "1")
+
+
+def wait_for_rank0(tag, world, timeout_s=600):
+    """Park this rank WITHOUT spinning until rank 0 signals `tag`: a blocking wait on the rendezvous store's socket.  A
+    collective barrier would do the waiting inside a stream synchronisation, which polls a host core per rank -- on the
+    very cores rank 0 is timing the CPU baseline on.  Falls through (the barrier that follows still synchronises) when
+    there is no store."""
+    if world > 1:
+        st = _default_store()
+        if st is not None:
+            try:
+                st.wait([tag], datetime.timedelta(seconds=timeout_s))
+            except Exception:  # noqa: BLE001 -- timeout: let the barrier's own timeout name the problem
+                pass
+
+
 def barrier(world, always=False):
     if world > 1 or always:
         import torch.distributed as dist
