@@ -89,61 +89,40 @@ def cpu_baseline(frames, qts, budget_s=20.0):
                       f"scalar restatement 1 thread {sc[0]:.0f} MP/s; host has {ncpu} logical CPUs, cgroup quota {eff}"}
 
 
-def pcie_probe(zj, device, nbytes=256 << 20, reps=3):
-    """This host's PCIe ceilings, measured now through the library's own copy path: pinned (zj_alloc_pinned) <-> device
-    copies of 256 MB, one direction at a time and both at once (two host threads, a context and a stream each; ctypes
-    releases the GIL).  GB/s per direction.  The duplex figure, not the link's nominal 63 GB/s, is what e2e_pinned can
-    reach."""
-    import threading
-    L = zj.lib()
-    ctxs, pins, devs = [], [], []
+def pcie_probe(dev, nbytes=48 << 20, copies=16):
+    """This host's PCIe ceilings, measured now: pinned <-> device copies the size of one frame's pixels (48 MiB), `copies`
+    of them queued back to back from ONE host thread -- one direction at a time, then both directions on a stream each (the
+    way zj_decode_planes_batch drives its upload and download streams; tools/pcie_probe.py, profiles/r01_pcie_probe.txt).
+    GB/s per direction.  The duplex figure, not the link's nominal 63 GB/s, is the yardstick for e2e_pinned.  (Two host
+    threads that each wait for their own copy, or copies of hundreds of MB, serialise the two directions on this host.)"""
+    import torch
     try:
-        for _ in range(2):
-            c = zj.Context(zj.BACKEND_HIP, device)
-            ctxs.append(c)
-            pins.append(L.zj_alloc_pinned(nbytes))
-            devs.append(c.device_alloc(nbytes))
-        if not all(pins):
-            return {"error": "zj_alloc_pinned failed"}
-
-        def copy(i, up, out):
-            t0 = time.perf_counter()
-            rc = (L.zj_memcpy_h2d(ctxs[i].handle, devs[i], pins[i], nbytes) if up else
-                  L.zj_memcpy_d2h(ctxs[i].handle, pins[i], devs[i], nbytes))
-            out[i] = (time.perf_counter() - t0) if rc == 0 else None
+        h_up = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        h_dn = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        d_up = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        d_dn = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
 
         def run(up, down):
-            best = None
-            for _ in range(reps + 1):
-                out = [0.0, 0.0]
-                th = []
-                if up:
-                    th.append(threading.Thread(target=copy, args=(0, True, out)))
-                if down:
-                    th.append(threading.Thread(target=copy, args=(1, False, out)))
+            best = 1e9
+            for _ in range(3):
+                torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
-                for t in th:
-                    t.start()
-                for t in th:
-                    t.join()
-                wall = time.perf_counter() - t0
-                if None in out:
-                    return None
-                best = wall if best is None else min(best, wall)
-            return round(nbytes / best / 1e9, 1)
+                for _ in range(copies):
+                    if up:
+                        with torch.cuda.stream(s1):
+                            d_up.copy_(h_up, non_blocking=True)
+                    if down:
+                        with torch.cuda.stream(s2):
+                            h_dn.copy_(d_dn, non_blocking=True)
+                torch.cuda.synchronize(dev)
+                best = min(best, time.perf_counter() - t0)
+            return round(copies * nbytes / best / 1e9, 1)
         return {"h2d_alone_gbs": run(True, False), "d2h_alone_gbs": run(False, True),
-                "duplex_gbs_per_direction": run(True, True), "bytes_per_copy": nbytes,
-                "how": "zj_memcpy_h2d / zj_memcpy_d2h on pinned buffers, two host threads with a context each for the duplex figure"}
+                "duplex_gbs_per_direction": run(True, True), "bytes_per_copy": nbytes, "copies": copies,
+                "how": "pinned <-> device copies queued back to back from one thread, a stream per direction"}
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)[:200]}
-    finally:
-        for c, p_, d_ in zip(ctxs, pins, devs):
-            if d_:
-                c.device_free(d_)
-            if p_:
-                L.zj_free_pinned(p_)
-        for c in ctxs:
-            c.close()
 
 
 def e2e_pinned(zj, ctx, desc, d_planes, plane_elems, frame_out, golden_sums=None, nb=8, reps=4, probe=None):
@@ -309,16 +288,20 @@ def live_traffic(workload, B, S, timeout_s=200):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def other_workloads(zj, synth, ctx, dev, side, names=("444-rgb", "444-gray", "422-rgb", "440-rgb"), B=16, iters=100):
+def other_workloads(zj, synth, ctx, dev, side, names=("444-rgb", "444-gray", "422-rgb", "440-rgb", "420-rgb-2500x1786"), B=16, iters=100):
     """Never `value`: BASELINE configs[2] (4:4:4 -> RGB, -> GRAYSCALE; benches/decode.rs:44-131, decode_grayscale.rs:12-58)
     and the reference's two other sampling modes, each timed like the headline's kernel: 16 resident 4096x4096 frames per
     launch, HIP events on the launch stream around `iters` launches, against each workload's own algorithmic bytes per
-    pixel.  The wide kernel generation decodes frame 0 once more and must give the same bytes."""
+    pixel; and the reference's medium image size, a ragged width (60 frames per launch: the same pixels per launch).
+    The wide kernel generation decodes frame 0 once more and must give the same bytes."""
     import torch
     out = {}
+    B16 = B
     for name in names:
         try:
-            hs, vs, cs_name, bpp, what = WORKLOADS[name]
+            hs, vs, cs_name, bpp, what = WORKLOADS[name][:5]
+            W, H = workload_dims(name)
+            B = max(1, round(B16 * 4096 * 4096 / (W * H)))
             cs = getattr(zj.ColorSpace, cs_name)
             pe = [synth.plane_blocks(W, H, hs, vs, c)[0] * synth.plane_blocks(W, H, hs, vs, c)[1] * 64 for c in range(3)]
             pl = [torch.empty(B * n, dtype=torch.int16, device=dev) for n in pe]
@@ -349,7 +332,7 @@ def other_workloads(zj, synth, ctx, dev, side, names=("444-rgb", "444-gray", "42
                 ctx.set_variant(0)
             gbs = B * W * H * bpp / (ms * 1e-3) / 1e9
             out[name] = {"kernel_ms": round(ms, 4), "megapixels_per_s": round(B * W * H / 1e6 / (ms * 1e-3), 1),
-                         "bytes_per_px": bpp, "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "kernel": kname,
+                         "frames_per_launch": B, "width": W, "height": H, "bytes_per_px": bpp, "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "kernel": kname,
                          "matches_wide_variant": bool(torch.equal(first, o[:fo])), "what": what}
             del pl, o, first
             torch.cuda.empty_cache()
@@ -492,10 +475,20 @@ WORKLOADS = {  # name: (h_samp, v_samp, output colourspace name, algorithmic byt
     "440-rgb": (1, 2, "RGB", 7.0, "4096x4096 baseline 4:4:0 (h1v2), dequant+IDCT+vertical upsample+YCbCr->RGB (the reference's benches/decode.rs vertical case)"),
     "420-rgba": (2, 2, "RGBA", 7.0, "extension: 4096x4096 4:2:0 -> RGBA (R G B 255), planes resident in HBM"),
     "420-chw": (2, 2, "RGB", 6.0, "extension: 4096x4096 4:2:0 -> planar u8 RGB (C x H x W), planes resident in HBM"),
+    # a ragged width (not a multiple of 16): the size of the reference's own medium test images (tests/medium_images.rs);
+    # rows start at any byte, the row ends follow the reference's any-width rules (worker.rs:143-251)
+    "420-rgb-2500x1786": (2, 2, "RGB", 6.0, "2500x1786 baseline 4:2:0 -> RGB (the reference's medium image size, a ragged width), planes resident in HBM", (2500, 1786)),
+    "444-rgb-2500x1786": (1, 1, "RGB", 9.0, "2500x1786 baseline 4:4:4 -> RGB (ragged width), planes resident in HBM", (2500, 1786)),
 }
 
 
+def workload_dims(name):
+    wl = WORKLOADS[name]
+    return wl[5] if len(wl) > 5 else (4096, 4096)
+
+
 def main():
+    global W, H  # the frame size follows --workload (4096 x 4096 unless the workload names another)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
@@ -583,7 +576,8 @@ def main():
     ctx = zj.Context(zj.BACKEND_HIP, gpu_index)
     if args.variant:
         ctx.set_variant({"packed": 0, "wide": 1, "packed-direct": 2}[args.variant])
-    hs, vs, cs_name, bytes_per_px, what = WORKLOADS[args.workload]
+    hs, vs, cs_name, bytes_per_px, what = WORKLOADS[args.workload][:5]
+    W, H = workload_dims(args.workload)
     out_cs = getattr(zj.ColorSpace, cs_name)
     ncomp_out = out_cs.num_components()
     # every rank decodes its own contiguous shard [lo, lo + S) of the global batch (image-level sharding)
@@ -740,7 +734,7 @@ def main():
     # pointers, in ONE launch -- what a caller who owns its frames as independent allocations gets (the reference's callers
     # do: src/mcu.rs:238-250, src/decoder.rs:178).  Eight different irregular frame sets in rotation; every frame is
     # decoded to its own place in d_out, so the checksums below also cover this path's bytes.
-    scat_ms = None
+    scat_ms = scat_adj_ms = None
     if not args.child and not args.no_other_workloads and S >= 2 * B:
         fstr = [2 * n for n in plane_elems] + [frame_out]
         rng = np.random.default_rng(5)
@@ -758,6 +752,21 @@ def main():
         ev[3].record(side)
         ev[3].synchronize()
         scat_ms = ev[2].elapsed_time(ev[3]) / 104
+        # control: the SAME frames a contiguous step decodes (sub-batch k), named one by one in a shuffled order -- what the
+        # pointer table itself costs, apart from where in HBM the frames lie
+        adj = []
+        for k in range(nsub):
+            idx = [k * B + int(v) for v in rng.permutation(B)]
+            adj.append([[base[i] + f * fstr[i] for f in idx] for i in range(4)])
+        for k in range(nsub):
+            ctx.decode_frames_device(desc, adj[k][0], adj[k][1], adj[k][2], adj[k][3], stream)
+        ev[2].record(side)
+        for k in range(104):
+            q = adj[k % nsub]
+            ctx.decode_frames_device(desc, q[0], q[1], q[2], q[3], stream)
+        ev[3].record(side)
+        ev[3].synchronize()
+        scat_adj_ms = ev[2].elapsed_time(ev[3]) / 104
     # every frame of the shard decoded once more (untimed), then the trivial gather: per-frame checksums, computed on the
     # GPU, gathered over RCCL and compared with the oracle's (tests/golden/checksums_seed1234.json)
     for k in range(nsub):
@@ -878,8 +887,10 @@ def main():
                              "kernel_ms": round(scat_ms, 4), "vs_kernel_ms": round(scat_ms / kernel_ms_rank0, 4),
                              "frac": round(algo_bytes / (scat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              "same_checksums_as_contiguous": scat_same,
+                             "adjacent_frames_kernel_ms": round(scat_adj_ms, 4), "adjacent_frames_vs_kernel_ms": round(scat_adj_ms / kernel_ms_rank0, 4),
                              "what": f"zj_decode_frames_device: {B} non-adjacent frames of the shard per launch, each named by its own "
-                                     f"four pointers (by value in the kernel arguments); 104 launches over 8 irregular frame sets"}},
+                                     f"four pointers (by value in the kernel arguments); 104 launches over 8 irregular frame sets; adjacent_frames_* = "
+                                     f"the frames of a contiguous step, named one by one in shuffled order (the table's own cost)"}},
             "rccl_ranks": world if (world > 1 and backend == "nccl") else 0,
             "collective_backend": None if world == 1 else backend,
             "per_rank_ms": [round(v, 4) for v in per_rank_ms],
@@ -902,7 +913,7 @@ def main():
             res["reference_files"] = reference_files(zj, ctx)
         if not args.no_e2e and args.workload == "420-rgb" and world == 1 and not virt:
             gsums = [int(x, 16) for x in golden["rgb"][lo:lo + 8]] if golden else None
-            res["e2e_pinned"] = e2e_pinned(zj, ctx, desc, d_planes, plane_elems, frame_out, gsums, nb=min(8, S), probe=pcie_probe(zj, gpu_index))
+            res["e2e_pinned"] = e2e_pinned(zj, ctx, desc, d_planes, plane_elems, frame_out, gsums, nb=min(8, S), probe=pcie_probe(dev))
         if gather_rgb is not None:
             res["gather_rgb"] = gather_rgb
         print(json.dumps(res), flush=True)

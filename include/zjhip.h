@@ -190,7 +190,8 @@ ZJ_API int zj_decode_planes_batch(zj_ctx *ctx, const zj_frame_desc *d, size_t nf
 ZJ_API int zj_decode_frames(zj_ctx *ctx, const zj_frame_desc *d, size_t nframes, const int16_t *const *y,
                      const int16_t *const *cb, const int16_t *const *cr, uint8_t *const *out);
 /* Device-resident variant (kernel-only path used by bench.py): all pointers are device pointers
- * on ctx's device, 16-byte aligned; frames contiguous.  Asynchronous on `stream` (a hipStream_t;
+ * on ctx's device, 16-byte aligned (the pixels of a frame whose width is not a multiple of 16 may start at any byte:
+ * its rows do anyway); frames contiguous.  Asynchronous on `stream` (a hipStream_t;
  * NULL = the ctx stream).  The frame's quantisation tables travel by value in the kernel arguments:
  * nothing is uploaded, cached or ordered against other streams. */
 ZJ_API int zj_decode_planes_device(zj_ctx *ctx, const zj_frame_desc *d, size_t nframes,

@@ -20,7 +20,7 @@ extern "C" void zje_set_variant(int v) { g_variant = v; }
 static long long g_cls[3] = {0, 0, 0}, g_redo = 0;
 extern "C" void zje_stats(long long out[4]) { out[0] = g_cls[0]; out[1] = g_cls[1]; out[2] = g_cls[2]; out[3] = g_redo; }
 
-template <class C, int HS, int VS, int OUT, bool FAST>
+template <class C, int HS, int VS, int OUT, bool FAST, bool RAG = false>
 static void tile_wide(const Params& p, const TileId t, char* lds)
 {
     for (int tid = 0; tid < C::NT; tid++) phase_setup<C, HS, VS, GEN_WIDE>(p, tid, lds);
@@ -32,10 +32,10 @@ static void tile_wide(const Params& p, const TileId t, char* lds)
         finish_block<C, GEN_WIDE, false>(L, raw, lds, 0, p.clamp_dc);
     }
     /* __syncthreads() */
-    for (int tid = 0; tid < C::NT; tid++) phase_color<C, HS, VS, OUT, GEN_WIDE, FAST>(p, t, tid, lds);
+    for (int tid = 0; tid < C::NT; tid++) phase_color<C, HS, VS, OUT, GEN_WIDE, FAST, false, RAG>(p, t, tid, lds);
 }
 
-template <int HS, int VS, int OUT, bool FAST>
+template <int HS, int VS, int OUT, bool FAST, bool RAG = false>
 static void run(const Params& p)
 {
     using C = Cfg<HS, VS, OUT>;
@@ -44,11 +44,11 @@ static void run(const Params& p)
     std::vector<char> lds_store(C::LDS_PACKED + 32);
     // 16-byte aligned like a real LDS allocation
     char* lds = (char*)(((uintptr_t)lds_store.data() + 15) & ~(uintptr_t)15);
-    const bool ts = CAN_TS && g_variant == 0 && ts_eligible<C>(p, OUT, FAST);
+    const bool ts = CAN_TS && g_variant == 0 && ts_eligible<C>(p, OUT, FAST, RAG);
     for (int bid = 0; bid < p.total_tiles; bid++) {
         memset(lds, 0x7B, C::LDS_PACKED); // poison: unwritten LDS must not matter
         const TileId t = decode_tile(p, bid);
-        if (g_variant == 1) { tile_wide<C, HS, VS, OUT, FAST>(p, t, lds); continue; }
+        if (g_variant == 1) { tile_wide<C, HS, VS, OUT, FAST, RAG>(p, t, lds); continue; }
         for (int tid = 0; tid < C::NT; tid++) phase_setup<C, HS, VS, GEN_PACKED>(p, tid, lds);
         /* __syncthreads() */
         const int nblock_lanes = C::HALO_PURE ? C::HALO_T0 : C::NT;
@@ -74,7 +74,7 @@ static void run(const Params& p)
         if (NEED_Y16 && *lds_flag<C>(lds) != 0) { // Q1 value outside a byte: the whole tile again, wide
             g_redo++;
             memset(lds, 0x7B, C::LDS_PACKED);
-            tile_wide<C, HS, VS, OUT, FAST>(p, t, lds);
+            tile_wide<C, HS, VS, OUT, FAST, RAG>(p, t, lds);
             continue;
         }
         if (ts) {
@@ -83,12 +83,12 @@ static void run(const Params& p)
             for (int round = 0; round * C::NT < C::NITEMS; round++)
                 for (int w = 0; w < C::NW; w++) {
                     ItemOut io[64];
-                    for (int l = 0; l < 64; l++) phase_color<C, HS, VS, OUT, GEN_PACKED, FAST, CAN_TS>(p, t, 64 * w + l, lds, round, &io[l]);
+                    for (int l = 0; l < 64; l++) phase_color<C, HS, VS, OUT, GEN_PACKED, FAST, CAN_TS, RAG>(p, t, 64 * w + l, lds, round, &io[l]);
                     for (int l = 0; l < 64; l++) stage_item<C>(io[l], 64 * w + l, lds, round);
-                    for (int l = 0; l < 64; l++) color_copyout<C, OUT>(p, t, 64 * w + l, lds, round);
+                    for (int l = 0; l < 64; l++) color_copyout<C, OUT, RAG>(p, t, 64 * w + l, lds, round);
                 }
         } else {
-            for (int tid = 0; tid < C::NT; tid++) phase_color<C, HS, VS, OUT, GEN_PACKED, FAST>(p, t, tid, lds);
+            for (int tid = 0; tid < C::NT; tid++) phase_color<C, HS, VS, OUT, GEN_PACKED, FAST, false, RAG>(p, t, tid, lds);
         }
     }
 }
@@ -100,22 +100,12 @@ extern "C" int zje_threads_per_group(const zj_frame_desc* d)
     return rc ? rc : pl.nt;
 }
 
-static int dispatch1(const Plan& pl, const Params& p, bool fast);
-
-// as launch_params of zj_api.cpp: a ragged width is two launches (split_ragged)
+// as launch_params of zj_api.cpp: zj_plan.h's launch_mode picks generic / aligned / ragged (the wide generation,
+// variant 1, has no ragged form)
 static int dispatch(const Plan& pl, const Params& p)
 {
-    Params in, edge;
-    if (split_ragged(pl, p, in, edge)) {
-        const int rc = dispatch1(pl, in, true);
-        return rc ? rc : dispatch1(pl, edge, false);
-    }
-    return dispatch1(pl, p, pl.fast);
-}
-
-static int dispatch1(const Plan& pl, const Params& p, bool fast)
-{
-#define ZJ_CASE(H, V, O) if (pl.hs == H && pl.vs == V && pl.out == O) { if (fast) run<H, V, O, true>(p); else run<H, V, O, false>(p); return ZJ_OK; }
+    const int mode = launch_mode(pl, g_variant);
+#define ZJ_CASE(H, V, O) if (pl.hs == H && pl.vs == V && pl.out == O) { if (mode == 2) run<H, V, O, true, true>(p); else if (mode == 1) run<H, V, O, true>(p); else run<H, V, O, false>(p); return ZJ_OK; }
     ZJ_CASE(1, 1, OUT_RGB) ZJ_CASE(1, 1, OUT_GRAY) ZJ_CASE(1, 1, OUT_YCBCR)
     ZJ_CASE(2, 1, OUT_RGB) ZJ_CASE(2, 1, OUT_GRAY) ZJ_CASE(2, 1, OUT_YCBCR)
     ZJ_CASE(1, 2, OUT_RGB) ZJ_CASE(1, 2, OUT_GRAY) ZJ_CASE(1, 2, OUT_YCBCR)

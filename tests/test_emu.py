@@ -232,20 +232,25 @@ def test_emulated_scattered_more_frames_than_one_table(synth):
 
 
 @pytest.mark.parametrize("mode", list(MODES))
-@pytest.mark.parametrize("w", [65, 255, 257, 289, 303, 304, 305, 311, 312, 313, 319, 321, 511, 513, 535, 560, 561, 569, 575, 577, 767, 769,
-                               1023, 1025, 1079, 1081, 2500, 2501, 2503])
+@pytest.mark.parametrize("w", [65, 255, 257, 289, 302, 303, 304, 305, 311, 312, 313, 319, 321, 511, 513, 535, 560, 561, 569, 570, 575, 577, 767, 769,
+                               1023, 1025, 1079, 1081, 1082, 2500, 2501, 2502, 2503])
 def test_emulated_ragged_width_split_into_fast_interior_and_generic_edge(mode, w, synth):
-    """A ragged width runs as two launches (zj_plan.h: split_ragged): the leading tile columns on the aligned fast path --
-    rows starting at any byte --, the row ends on the generic store path.  Widths on both sides of every boundary of the
-    split (tile widths 256 / 512 pixels, the 48-pixel margin in front of the early-written tail, P % 16 == 8), every
-    output kind, both the reference's bytes (zero_fill) and the strip-level contract (never-written bytes untouched)."""
+    """A ragged width runs the RAG kernels (zj_device.h: phase_color): every ordinary 16-pixel group of a row on the fast
+    path -- rows starting at any byte --, the groups at the row's end on the generic store path, in one launch.  Widths on
+    both sides of every boundary (tile widths 256 / 512 pixels, the 48-pixel margin in front of the early-written tail,
+    P % 16 == 8), every output kind, every kernel variant, both the reference's bytes (zero_fill) and the strip-level
+    contract (never-written bytes untouched)."""
     hs, vs = MODES[mode]
     h = 8 * vs * (2 if hs == 2 else 1) + 3   # one strip and a clipped second one
     planes, qts = synth.make_frame(w, h, hs, vs, 3, seed=w)
     for out_cs in (oc.RGB, oc.GRAYSCALE, oc.YCBCR):
         f = oc.make_frame(w, h, hs, vs, 3, out_cs, qts)
         rc, exp = oc.decode_planes(f, planes)
-        rce, out = emu_c.decode_planes(f, planes)
+        for variant in (2, 1, 0):  # direct stores with the ragged split, the wide generation (generic kernels), staged stores
+            emu_c.set_variant(variant)
+            rce, out = emu_c.decode_planes(f, planes)
+            if rc == 0:
+                assert rce == 0 and np.array_equal(out, exp), (mode, w, out_cs, variant)
         if rc != 0:
             assert rce == -5
             continue

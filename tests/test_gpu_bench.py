@@ -89,7 +89,7 @@ def test_single_rank_line_has_the_contract_fields():
     e = res["e2e_pinned"]
     assert "error" not in e, e
     assert e["megapixels_per_s"] > 1000 and e["last_frame_matches_golden"] is True
-    assert e["pcie_probe"]["duplex_gbs_per_direction"] > 5 and 0 < e["frac_of_duplex_ceiling"] < 1.5
+    assert e["pcie_probe"]["duplex_gbs_per_direction"] > 5 and 0 < e["frac_of_duplex_ceiling"] < 1.25, e
     assert rf["scattered_batch"] is None                              # a 16-frame shard has no 16 non-adjacent frames
     # configs[2] / configs[3] in the driver's line
     ow = res["other_workloads"]

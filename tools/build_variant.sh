@@ -12,6 +12,6 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno
 /opt/rocm/bin/hipcc $FLAGS $2 -c zj_kernels.hip -o /tmp/zj_kernels_$1.o
 # zj_api.cpp sees the tile geometry through zj_plan.h: recompile it under the same flags
 /opt/rocm/bin/hipcc $FLAGS $2 -x hip -c zj_api.cpp -o /tmp/zj_api_$1.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o ../libzjhip_$1.so /tmp/zj_kernels_$1.o zj_huff.o /tmp/zj_api_$1.o zj_jpeg.o zj_pool.o \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o ../libzjhip_$1.so /tmp/zj_kernels_$1.o zj_huff.o /tmp/zj_api_$1.o zj_jpeg.o zj_pool.o zj_multi.o \
   -Wl,-soname,libzjhip_$1.so -Wl,--exclude-libs,ALL -Wl,--version-script=zjhip.map
 echo built libzjhip_$1.so

@@ -20,6 +20,12 @@ names = {0: "RGB", 1: "GRAY", 2: "YCBCR", 3: "RGBA", 4: "CHW"}
 print(f"{'kernel <HS,VS,OUT,GEN,FAST,TS>':40s} VGPR scratch LDS   waves/SIMD")
 for k, v in sorted(rows.items()):
     m = re.search(r"zj_fused_kernelILi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)E", k)
+    r = re.search(r"zj_fused_ragged_kernelILi(\d)ELi(\d)ELi(\d)ELb(\d)E", k)
+    if r:  # the ragged family: packed generation, fast path + generic stores at the row ends
+        hs, vs, o, t = map(int, r.groups())
+        print(f"<{hs},{vs},{names[o]:5s},packed,rag ,{'staged' if t else 'direct'}>".ljust(40),
+              f"{v.get('VGPRs', -1):4d} {v.get('ScratchSize', -1):7d} {v.get('LDS', -1):6d} {v.get('Occupancy', -1):4d}")
+        continue
     if not m:
         continue
     hs, vs, o, g, f, t = map(int, m.groups())

@@ -18,11 +18,11 @@ def main():
     dev = torch.device("cuda", 0)
     ctx = zj.Context(zj.BACKEND_HIP, 0)
     side = torch.cuda.Stream(device=dev)
-    B = 32
+    B = int(os.environ.get("ZJ_RAGGED_B", "32"))
     sizes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(2500, 1786), (2512, 1786), (4090, 4096), (4096, 4096)]
     for (w, h) in sizes:
         for name, (hs, vs), bpp in (("420", (2, 2), 6.0), ("444", (1, 1), 9.0), ("422", (2, 1), 7.0)):
-            nb = B if w * h < 8e6 else 16
+            nb = B if w * h < 8e6 else (32 if w * h < 12e6 else 16)
             pe = [synth.plane_blocks(w, h, hs, vs, c)[0] * synth.plane_blocks(w, h, hs, vs, c)[1] * 64 for c in range(3)]
             pl = [torch.empty(nb * n, dtype=torch.int16, device=dev) for n in pe]
             for j in range(nb):

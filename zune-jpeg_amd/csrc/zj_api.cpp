@@ -325,7 +325,7 @@ static int launch_params(zj_ctx* c, const Plan& pl, Params& p, hipStream_t s)
     // it: a grid smaller than one wave of workgroups, or longer than two, starts as the hardware dispatches it.  The slots
     // per CU are the occupancy of the instantiation that is launched, not a constant.
     if (c->stagger_delay > 0 && pl.hs == 2 && pl.vs == 2 && pl.out != OUT_GRAY && c->variant != 1) {
-        const int slots = fused_slots_per_cu(pl.hs, pl.vs, pl.out, c->variant, pl.fast ? 1 : 0, p);
+        const int slots = pl.fast ? fused_slots_per_cu(pl.hs, pl.vs, pl.out, c->variant, 1, p) : 0;
         const int wgs = c->cus * slots;
         if (slots >= 2 && p.total_tiles > wgs && p.total_tiles <= 2 * wgs) {
             p.stagger_wgs = wgs; p.stagger_delay = c->stagger_delay;
@@ -333,13 +333,7 @@ static int launch_params(zj_ctx* c, const Plan& pl, Params& p, hipStream_t s)
             p.stagger_magic = g.m; p.stagger_shift = g.s;
         }
     }
-    Params in, edge;
-    if (split_ragged(pl, p, in, edge)) { // a ragged width: leading tile columns on the fast path, the row ends on the generic one
-        ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->variant, 1, in, s));
-        ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->variant, 0, edge, s));
-        return ZJ_OK;
-    }
-    ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->variant, pl.fast ? 1 : 0, p, s));
+    ZJ_HIP(c, launch_fused(pl.hs, pl.vs, pl.out, c->variant, launch_mode(pl, c->variant), p, s));
     return ZJ_OK;
 }
 
@@ -447,7 +441,9 @@ int zj_decode_planes_device(zj_ctx* c, const zj_frame_desc* d, size_t nframes, c
     Plan pl;
     int rc = check_frame_args(c, d, nframes, d_y, d_cb, d_cr, d_out, pl);
     if (rc) return rc;
-    if (((uintptr_t)d_y | (uintptr_t)d_cb | (uintptr_t)d_cr | (uintptr_t)d_out) & 15) return ZJ_ERR_ARG;
+    // planes: 16-byte aligned; pixels: 16-byte aligned when the rows are (width % 16 == 0) -- the rows of a ragged width
+    // start at any byte anyway, and so may its frames (packed frames of 2500 x 1786 x 3 bytes are 8 bytes apart from it)
+    if (((uintptr_t)d_y | (uintptr_t)d_cb | (uintptr_t)d_cr | (pl.fast ? (uintptr_t)d_out : 0)) & 15) return ZJ_ERR_ARG;
     ZJ_HIP(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     return decode_device_impl(c, d, pl, nframes, d_y, d_cb, d_cr, d_out, s, 1);
@@ -460,10 +456,10 @@ int zj_decode_planes_device_strided(zj_ctx* c, const zj_frame_desc* d, size_t nf
     Plan pl;
     int rc = check_frame_args(c, d, nframes, d_y, d_cb, d_cr, d_out, pl);
     if (rc) return rc;
-    if (((uintptr_t)d_y | (uintptr_t)d_cb | (uintptr_t)d_cr | (uintptr_t)d_out) & 15) return ZJ_ERR_ARG;
+    if (((uintptr_t)d_y | (uintptr_t)d_cb | (uintptr_t)d_cr | (pl.fast ? (uintptr_t)d_out : 0)) & 15) return ZJ_ERR_ARG;
     // 0 = packed; otherwise at least a frame, and every frame as aligned as the first
     if ((y_stride && (y_stride < pl.y_len || (y_stride & 7))) || (c_stride && (c_stride < pl.c_len || (c_stride & 7))) ||
-        (out_stride && (out_stride < pl.out_len || (out_stride & 15)))) return ZJ_ERR_ARG;
+        (out_stride && (out_stride < pl.out_len || (pl.fast && (out_stride & 15))))) return ZJ_ERR_ARG;
     if ((y_stride | c_stride | out_stride) >> 62) return ZJ_ERR_ARG;
     ZJ_HIP(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
@@ -479,7 +475,7 @@ int zj_decode_frames_device(zj_ctx* c, const zj_frame_desc* d, size_t nframes, c
     const bool chroma = pl.out != OUT_GRAY;
     for (size_t f = 0; f < nframes; f++) {
         if (!d_y[f] || !d_out[f] || (chroma && (!d_cb[f] || !d_cr[f]))) return ZJ_ERR_ARG;
-        if (((uintptr_t)d_y[f] | (uintptr_t)d_out[f] | (chroma ? (uintptr_t)d_cb[f] | (uintptr_t)d_cr[f] : 0)) & 15) return ZJ_ERR_ARG;
+        if (((uintptr_t)d_y[f] | (pl.fast ? (uintptr_t)d_out[f] : 0) | (chroma ? (uintptr_t)d_cb[f] | (uintptr_t)d_cr[f] : 0)) & 15) return ZJ_ERR_ARG;
     }
     ZJ_HIP(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
@@ -497,10 +493,9 @@ int zj_time_decode_device(zj_ctx* c, const zj_frame_desc* d, size_t nframes, con
     ZJ_HIP(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     if (kernel_name) {
-        Params p, in, edge;
+        Params p;
         fill_params(d, pl, nframes, d_y, d_cb, d_cr, d_out, 1, p);
-        const bool split = split_ragged(pl, p, in, edge); // a ragged width: the launch over the leading tile columns dominates
-        *kernel_name = fused_kernel_name(pl.hs, pl.vs, pl.out, c->variant, (pl.fast || split) ? 1 : 0, split ? in : p);
+        *kernel_name = fused_kernel_name(pl.hs, pl.vs, pl.out, c->variant, launch_mode(pl, c->variant), p);
     }
     // (1) `iters` back-to-back launches between one event pair
     ZJ_HIP(c, hipEventRecord(c->ev0, s));

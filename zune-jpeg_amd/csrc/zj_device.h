@@ -147,6 +147,15 @@ ZJ_DEV uint32_t pack_sar(int32_t a, int32_t b)
 }
 
 // v_perm_b32: bytes {s0[3..0] -> 7..4, s1[3..0] -> 3..0}; selector byte i picks result byte i.
+// v_alignbyte_b32: bytes [s, s + 4) of the 8-byte value hi:lo (s = 0..3)
+ZJ_DEV uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t s)
+{
+#if defined(ZJ_EMU)
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (s & 3u)));
+#else
+    return __builtin_amdgcn_alignbyte(hi, lo, s);
+#endif
+}
 ZJ_DEV uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel)
 {
 #if defined(ZJ_EMU)
@@ -733,8 +742,8 @@ struct Params {
     int width, height;            // pixels
     int mcu_x;                    // MCUs per row (headers.rs:317)
     int n_strips;
-    int tiles_per_row;            // tile columns of THIS launch (a ragged width is two launches, see tile0)
-    int tile0;                    // first tile column of this launch
+    int tiles_per_row;
+    int regular_px;               // ragged widths (RAG instantiations): pixels of a row made of ordinary 16-pixel groups
     int nframes;
     int zero_fill;                // 1: also write the bytes the reference leaves 0 (Q5/Q6)
     int total_tiles;
@@ -816,7 +825,7 @@ ZJ_DEV TileId tile_from_id(const Params& p, const int id)
     TileId t;
     const Magic gt = {p.tpr_magic, p.tpr_shift}, gs = {p.ns_magic, p.ns_shift};
     const uint32_t r = magic_div((uint32_t)id, gt);
-    t.tile = id - (int)r * p.tiles_per_row + p.tile0;
+    t.tile = id - (int)r * p.tiles_per_row;
     const uint32_t f = magic_div(r, gs);
     t.strip = (int)r - (int)f * p.n_strips;
     t.frame = (int)f;
@@ -1297,6 +1306,38 @@ ZJ_DEV void store_clip(uint8_t* orow, long long off, const uint32_t* w, int ndw,
     }
 }
 
+// One 8-pixel unit `u` of a row's 3-byte interleaved output (24 bytes in w6) by the reference's rules for ANY width
+// (worker.rs:143-251 in full); `P` is the padded row length:
+//   width < 16, YCbCr, plain : natural layout, clipped at 3W                      (:176-198)
+//   u < 2*elements           : main groups at 24u                                  (:201-214)
+//   the last two units       : the "last 16 samples", written at p' (Q5)           (:221-246)
+//   units in between         : never converted (P % 16 == 8)
+// main bytes inside [p', p'+48) belong to the tail, so every byte of the row has exactly one writer.
+template <int OUT>
+ZJ_DEV void store_unit_generic(const Params& p, uint8_t* orow, const int P, const int u, const uint32_t* w6)
+{
+    const int W = p.width;
+    const long long stride = 3ll * W;
+    const int units = P >> 3;
+    if (u >= units) return;
+    long long elems = P / 16 - 1; if (elems < 0) elems = 0;
+    const long long position = 48 * elems;
+    long long diff = 64 - (stride - position); if (diff < 0) diff = 0;
+    const long long pp = position > diff ? position - diff : 0; // p'
+    if (OUT == OUT_YCBCR || W < 16 || p.plain) {
+        store_clip(orow, 24ll * u, w6, 6, stride, 0, 0);
+    } else if (u >= units - 2) {
+        const long long off = pp + 24ll * (u - (units - 2));
+        store_clip(orow, off, w6, 6, off + 24, 0, 0);
+        if (u == units - 1 && p.zero_fill) { // bytes the reference never writes (Q6)
+            const long long z0 = position > pp + 48 ? position : pp + 48;
+            for (long long o = z0; o < stride; o++) orow[o] = 0;
+        }
+    } else if (u < 2 * elems) {
+        store_clip(orow, 24ll * u, w6, 6, stride, pp, pp + 48);
+    }
+}
+
 // What a lane hands to the staged-store half of a round (TS): its item's 48 output bytes and where they go.
 //   kind 0: nothing (no item)   1: pieces PPI*L ... PPI*L + PPI-1   2: (RGB) as 1 without the third piece
 //        3: the row's last group under the early-tail quirk (Q5): pieces 3L-1, 3L, 3L+1, then zeros in 3L+2 (Q6)
@@ -1367,7 +1408,12 @@ ZJ_DEV void stage_item(const ItemOut& io, const int tid, char* lds, const int ro
 // TS (staged stores, GEN_PACKED, FAST RGB / YCbCr only): processes ONE round (item = tid + round * NT) and, instead
 // of storing its 48 bytes at a 48-byte lane stride, returns them in *io for stage_item; color_copyout then stores
 // 16-byte pieces that are contiguous across the lanes of a wave.
-template <class C, int HS, int VS, int OUT, int GEN, bool FAST = true, bool TS = false>
+// RAG (ragged width, FAST instantiations only): the row is irregular only at its end -- the last two 8-pixel units are
+// written early (Q5), what lies between them and the padded width is never converted, everything is clipped at 3W
+// (worker.rs:143-251).  16-pixel groups below Params::regular_px are ordinary ones (48 bytes at 48 * G, all inside the row):
+// they take the fast stores, from rows that may start at any byte; the few groups beyond take the generic store path, by
+// the lanes that hold them, in the same workgroup.
+template <class C, int HS, int VS, int OUT, int GEN, bool FAST = true, bool TS = false, bool RAG = false>
 ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* lds, const int round = 0, ItemOut* io = nullptr)
 {
     using LL = typename C::template L<GEN>;
@@ -1390,6 +1436,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
         const int px0 = x0 + 16 * g;      // first pixel of the group in the padded row
         const int row = t.strip * C::SH + m;
         if (px0 >= P || row >= p.height) continue;
+        const bool irregular = RAG && px0 >= p.regular_px; // a group at the row's end: generic stores (RAG only)
         uint8_t* const orow = frame_out + (long long)row * row_bytes;
         // ---- luma: yp[] = packed i16 pairs in the arrangement the chroma code produces -----------------
         //   HS == 2: [0..3] = (Y[4k], Y[4k+2]), [4..7] = (Y[4k+1], Y[4k+3]);  HS == 1: natural pairs (Y[2k], Y[2k+1])
@@ -1398,7 +1445,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
             const U4 yv = *reinterpret_cast<const U4*>(lds + 16 * item);
             if (OUT == OUT_GRAY) {
                 // ycbcr_to_grayscale (color_convert/scalar.rs:91-114): `as u8` truncation (Q7) == the staged byte
-                if (FAST) store16(orow + px0, yv, true); // W % 16 == 0; lane-contiguous whole lines: streaming stores (+3.7 %)
+                if (FAST && !irregular) store16(orow + px0, yv, true); // lane-contiguous whole lines: streaming stores (+3.7 %)
                 else { const uint32_t ow4[4] = {yv.x, yv.y, yv.z, yv.w}; store_clip(orow, px0, ow4, 4, W, 0, 0); }
                 continue;
             }
@@ -1416,7 +1463,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
                 U4 o;
                 o.x = perm(yw[1], yw[0], 0x06040200u); o.y = perm(yw[3], yw[2], 0x06040200u);
                 o.z = perm(yw[5], yw[4], 0x06040200u); o.w = perm(yw[7], yw[6], 0x06040200u);
-                if (FAST) store16(orow + px0, o);
+                if (FAST && !irregular) store16(orow + px0, o);
                 else { const uint32_t ow4[4] = {o.x, o.y, o.z, o.w}; store_clip(orow, px0, ow4, 4, W, 0, 0); }
                 continue;
             }
@@ -1558,11 +1605,11 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
                 if (HS == 2) pack_rgba4(c[k], c[4 + k], q[4 * k], q[4 * k + 2], q[4 * k + 1], q[4 * k + 3]);
                 else pack_rgba4(c[2 * k], c[2 * k + 1], q[4 * k], q[4 * k + 1], q[4 * k + 2], q[4 * k + 3]);
             }
-            if (TS) {
+            if (TS) { // (RAG: an irregular group is staged like any other; color_copyout stores its units clipped)
                 io->s0 = U4{q[0], q[1], q[2], q[3]}; io->s1 = U4{q[4], q[5], q[6], q[7]};
                 io->s2 = U4{q[8], q[9], q[10], q[11]}; io->s3 = U4{q[12], q[13], q[14], q[15]};
                 io->kind = 1;
-            } else if (FAST) {
+            } else if (FAST && !irregular) {
                 uint8_t* o = orow + 4ll * px0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) { const U4 v = {q[4 * k], q[4 * k + 1], q[4 * k + 2], q[4 * k + 3]}; store16(o + 16 * k, v); }
@@ -1584,7 +1631,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
                     q[k] = pl == 0 ? pack_plane4<HS == 2>(a.r, b.r) : (pl == 1 ? pack_plane4<HS == 2>(a.g, b.g) : pack_plane4<HS == 2>(a.b, b.b));
                 }
                 uint8_t* prow = orow + (long long)pl * p.plane_stride;
-                if (FAST) { const U4 v = {q[0], q[1], q[2], q[3]}; store16(prow + px0, v); }
+                if (FAST && !irregular) { const U4 v = {q[0], q[1], q[2], q[3]}; store16(prow + px0, v); }
                 else store_clip(prow, px0, q, 4, W, 0, 0);
             }
             continue;
@@ -1595,43 +1642,15 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
             if (HS == 2) pack_rgb4_eo(c[k], c[4 + k], d[3 * k], d[3 * k + 1], d[3 * k + 2]);
             else pack_rgb4_nat(c[2 * k], c[2 * k + 1], d[3 * k], d[3 * k + 1], d[3 * k + 2]);
         }
-        if (!FAST) {
-            // Any width (worker.rs:143-251 in full): per 8-pixel unit u of the padded row
-            //   width < 16            : natural layout, clipped at 3W                      (:176-198)
-            //   u < 2*elements        : main groups at 24u                                  (:201-214)
-            //   the last two units    : the "last 16 samples", written at p' (Q5)           (:221-246)
-            //   units in between      : never converted (P % 16 == 8)
-            // main bytes inside [p', p'+48) belong to the tail (it is written last).
-            const long long stride = 3ll * W;
-            const int units = P >> 3;
-            long long elems = P / 16 - 1; if (elems < 0) elems = 0;
-            const long long position = 48 * elems;
-            long long diff = 64 - (stride - position); if (diff < 0) diff = 0;
-            const long long pp = position > diff ? position - diff : 0; // p'
+        if (!FAST || (irregular && !TS)) { // (TS: an irregular group is staged like any other; color_copyout stores its units)
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int u = (px0 >> 3) + h;
-                if (u >= units) continue;
-                const uint32_t* w6 = d + 6 * h;
-                if (OUT == OUT_YCBCR || W < 16 || p.plain) {
-                    store_clip(orow, 24ll * u, w6, 6, stride, 0, 0);
-                } else if (u >= units - 2) {
-                    const long long off = pp + 24ll * (u - (units - 2));
-                    store_clip(orow, off, w6, 6, off + 24, 0, 0);
-                    if (u == units - 1 && p.zero_fill) { // bytes the reference never writes (Q6)
-                        const long long z0 = position > pp + 48 ? position : pp + 48;
-                        for (long long o = z0; o < stride; o++) orow[o] = 0;
-                    }
-                } else if (u < 2 * elems) {
-                    store_clip(orow, 24ll * u, w6, 6, stride, pp, pp + 48);
-                }
-            }
+            for (int h = 0; h < 2; h++) store_unit_generic<OUT>(p, orow, P, (px0 >> 3) + h, d + 6 * h);
             continue;
         }
         const U4 s0 = {d[0], d[1], d[2], d[3]}, s1 = {d[4], d[5], d[6], d[7]}, s2 = {d[8], d[9], d[10], d[11]};
         if (ZJ_ABL(ZJ_PDBG(p), 8) && (d[0] ^ d[5] ^ d[11]) != 0x12345u) continue; // ablation: (practically) no HBM writes
         const int G = px0 >> 4; // 16-pixel group index in the row
-        const bool quirk = OUT == OUT_RGB && !p.plain;
+        const bool quirk = OUT == OUT_RGB && !p.plain && !RAG; // (RAG: the tail groups went the generic way above)
         if (TS) {
             // The early RGB tail (Q5) is a shift by one piece: the last group of a row starts in the third slot of the
             // group before it, and the row's last piece is zero (Q6) or never stored (color_copyout)
@@ -1664,14 +1683,15 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
 // Second half of a staged-store round: lane L of a wave stores pieces 64*j + L (j = 0 .. PPI-1) of the 64*PPI pieces
 // its wave staged, i.e. every store instruction writes 1024 contiguous bytes of the tile's rows (row segments of
 // PIECES_PER_ROW pieces), instead of 64 pieces 48 (64) bytes apart.
-template <class C, int OUT>
+template <class C, int OUT, bool RAG = false>
 ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid, char* lds, const int round)
 {
     using LL = typename C::template L<GEN_PACKED>;
     constexpr int PPI = C::PPI;
-    const int P = p.mcu_x * 8 * (C::TWYB / C::TWC);
+    const int P = RAG ? p.regular_px : p.mcu_x * 8 * (C::TWYB / C::TWC); // RAG: only the ordinary groups were staged
     const int x0 = t.tile * C::TWY;
-    const int nvg = (P - x0) / 16 < C::NGRP ? (P - x0) / 16 : C::NGRP; // valid 16-pixel groups of this tile
+    const int left = P - x0 > 0 ? (P - x0) / 16 : 0;
+    const int nvg = left < C::NGRP ? left : C::NGRP; // valid 16-pixel groups of this tile
     const uint32_t row_bytes = (uint32_t)(PPI == 4 ? 4 : 3) * (uint32_t)p.width;
     // everything up to here is uniform: a scalar base address, 32-bit per-lane offsets below
     uint8_t* const tile_out = t.out + (long long)t.strip * C::SH * row_bytes + (long long)(PPI == 4 ? 4 : 3) * x0;
@@ -1679,7 +1699,7 @@ ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid, char* 
     const int item0 = 64 * w + round * C::NT;  // first item of this wave's round
     if (item0 >= C::NITEMS) return;            // (the last round of a tile is partly empty)
     // the piece the reference never writes: the last one of a row, in the tile that holds the row's end
-    const bool row_end_here = x0 + 16 * nvg == P;
+    const bool row_end_here = !RAG && x0 + 16 * nvg == P;
     const int never = (OUT == OUT_RGB && !p.plain && !p.zero_fill && row_end_here) ? 3 * nvg - 1 : -1;
     const int rows_left = p.height - t.strip * C::SH; // > 0
     const char* const ybase = lds + 16 * item0;
@@ -1705,6 +1725,44 @@ ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid, char* 
     // interior tiles (all but the last of a row, all but a clipped last strip), whole rounds: no per-piece test,
     // PPI LDS reads, one wait, PPI stores
     const bool plain_round = nvg == C::NGRP && rows_left >= C::SH && never < 0 && item0 + 64 <= C::NITEMS;
+    // Rows that are not dword-aligned (ragged widths with width % 4 != 0, or a frame that starts at an odd address): a
+    // 16-byte store per lane at an address that is not a multiple of 4 costs the memory pipeline dearly (+22 % kernel time
+    // at 4090 pixels, where every second row is off by 2; dword-aligned but not 16-byte-aligned rows cost 3 %).  Such rows
+    // are copied out SHIFTED: lane q stores bytes [16q + d, 16q + d + 16) of its row segment, d = the row's distance to the
+    // next dword boundary, assembled from its own piece and the first dword of the next one with v_alignbyte_b32 -- every
+    // 16-byte store is dword-aligned; the first d bytes of a row segment and the short last piece go out as bytes / dwords
+    // from the two lanes at its ends.
+    if (RAG) {
+        const uint32_t a0 = (uint32_t)reinterpret_cast<uintptr_t>(tile_out) & 3u, rho = row_bytes & 3u;
+        if ((a0 | rho) != 0) { // workgroup-uniform
+            ZJ_NO_IF_CONVERT();
+#pragma unroll
+            for (int j = 0; j < PPI; j++) {
+                const bool ok = plain_round || (PPI * item0 + 64 * j + L < PPI * C::NITEMS && cc[j] < PPI * nvg && mm[j] < rows_left);
+                const bool last = cc[j] == PPI * nvg - 1;   // the row segment's last ordinary piece: nothing of the next one
+                const uint32_t delta = (4u - ((a0 + (uint32_t)mm[j] * rho) & 3u)) & 3u;
+                const U4 v = *reinterpret_cast<const U4*>(src[j]);
+                const int qn = 64 * j + L + 1;              // the next piece of the wave's round (same row unless `last`)
+                const char* const src2 = last ? src[j] : (qn < C::INPL ? ybase : xbase) + 16 * qn;
+                const uint32_t nx = *reinterpret_cast<const uint32_t*>(src2);
+                U4 o;
+                o.x = alignbyte(v.y, v.x, delta); o.y = alignbyte(v.z, v.y, delta);
+                o.z = alignbyte(v.w, v.z, delta); o.w = alignbyte(nx, v.w, delta);
+                uint8_t* const dst = tile_out + off[j];
+                if (ok) {
+                    if (!last) store16(dst + delta, o, true);
+                    else {
+                        uint32_t* const d32 = reinterpret_cast<uint32_t*>(dst + delta);
+                        d32[0] = o.x; d32[1] = o.y; d32[2] = o.z;
+                        if (delta == 0) d32[3] = o.w;
+                        else for (uint32_t b = 0; b < 4u - delta; b++) dst[delta + 12 + b] = (uint8_t)(o.w >> (8 * b));
+                    }
+                    if (cc[j] == 0) for (uint32_t b = 0; b < delta; b++) dst[b] = (uint8_t)(v.x >> (8 * b));
+                }
+            }
+            goto ragged_tail;
+        }
+    }
     if (plain_round) {
         U4 v[PPI];
 #pragma unroll
@@ -1719,18 +1777,40 @@ ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid, char* 
         const bool ok = PPI * item0 + 64 * j + L < PPI * C::NITEMS && cc[j] < PPI * nvg && mm[j] < rows_left && cc[j] != never;
         if (ok) store16(tile_out + off[j], *reinterpret_cast<const U4*>(src[j]), true);
     }
+ragged_tail:
+    if (RAG && nvg < C::NGRP) {
+        // The row's end lies in this tile (workgroup-uniform): its groups beyond regular_px were staged like the others and
+        // are stored here, one lane per (row, 8-pixel unit), by the generic rules -- early tail, gap, clip at the row's end.
+        // At most four groups of a row are irregular (56 pixels), so eight units per row cover them.
+        constexpr int RPR = 64 / C::NGRP > 0 ? 64 / C::NGRP : 1;  // tile rows of a wave's round (NGRP <= 64)
+        const int Pfull = p.mcu_x * 8 * (C::TWYB / C::TWC);
+        const int r = L >> 3, k = L & 7;
+        const int u = (p.regular_px >> 3) + k;                    // unit index in the padded row
+        const int g = (8 * u - x0) >> 4;                          // its group inside the tile
+        const int item = r * C::NGRP + g;                         // ... inside the wave's round
+        static_assert(!RAG || (64 % C::NGRP == 0 && C::NT % C::NGRP == 0), "a wave's round covers whole tile rows");
+        const int m = item0 / C::NGRP + r;                        // tile row
+        if (r < RPR && 8 * u >= x0 && g < C::NGRP && 8 * u < Pfull && item0 + item < C::NITEMS && m < rows_left) {
+            const char* const sp = (PPI * item < C::INPL ? ybase : xbase) + 16 * PPI * item + (PPI * 4) * 2 * (u & 1);
+            uint32_t wv[2 * PPI];
+#pragma unroll
+            for (int i = 0; i < 2 * PPI; i++) wv[i] = *reinterpret_cast<const uint32_t*>(sp + 4 * i);
+            uint8_t* const orow = t.out + (long long)(t.strip * C::SH + m) * row_bytes;
+            if (PPI == 4) store_clip(orow, 32ll * u, wv, 8, 4ll * p.width, 0, 0);
+            else store_unit_generic<OUT>(p, orow, Pfull, u, wv);
+        }
+    }
 }
 
 // Are staged stores usable for this launch?  The early-tail shift writes into the piece before the lane's own, so
 // the row's last group must never sit in lane 0 of a wave, and both tail groups must be in one tile.
 template <class C>
-inline bool ts_eligible(const Params& p, const int out, const bool fast)
+inline bool ts_eligible(const Params& p, const int out, const bool fast, const bool rag = false)
 {
     if (!fast || !(out == OUT_RGB || out == OUT_YCBCR || out == OUT_RGBA)) return false;
-    if (out != OUT_RGB || p.plain) return true;
+    if (out != OUT_RGB || p.plain || rag) return true; // (rag: the early tail never goes through the staging)
     const int P = p.mcu_x * 8 * (C::TWYB / C::TWC);
     const int tiles = (P + C::TWY - 1) / C::TWY;
-    if (p.tile0 + p.tiles_per_row < tiles) return true; // a launch over leading tile columns only: no row end in it
     const int nvg_last = (P - (tiles - 1) * C::TWY) / 16;
     if (nvg_last < 2) return false;
     for (int m = 0; m < C::SH; m++)

@@ -38,7 +38,7 @@ namespace zj {
 #define ZJ_SETPRIO(bit, level) do { if (ZJ_PRIO & (bit)) __builtin_amdgcn_s_setprio(level); } while (0)
 
 // the round-1 pipeline for one tile: int16 staging, 24-bit IDCT, 48-byte-per-lane stores
-template <class C, int HS, int VS, int OUT, bool FAST>
+template <class C, int HS, int VS, int OUT, bool FAST, bool RAG = false>
 __device__ __forceinline__ void tile_wide(const Params& p, const TileId t, const int tid, char* lds)
 {
     ZJ_SETPRIO(1, 3); // issue the tile's loads ahead of other waves' arithmetic
@@ -51,7 +51,7 @@ __device__ __forceinline__ void tile_wide(const Params& p, const TileId t, const
     finish_block<C, GEN_WIDE, false>(L, raw, lds, ZJ_PDBG(p), p.clamp_dc);
     __syncthreads();
     ZJ_SETPRIO(2, 2); // (off) let a tile's last phase, the one that frees the workgroup slot, go first
-    phase_color<C, HS, VS, OUT, GEN_WIDE, FAST>(p, t, tid, lds);
+    phase_color<C, HS, VS, OUT, GEN_WIDE, FAST, false, RAG>(p, t, tid, lds);
 }
 
 // The workgroups of a launch's FIRST wave (one per occupancy slot of the chip) all start in the same cycle and would move
@@ -70,12 +70,32 @@ __device__ __forceinline__ void stagger_start(const Params& p, const int bid)
     for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(2);  // ~128 cycles = 53 ns per step
 }
 
-template <int HS, int VS, int OUT, int GEN, bool FAST, bool TS>
-// launch bounds: see ZJ_WAVES_PER_SIMD / ZJ_WAVES_PER_SIMD_PACKED above
-__global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAVES_PER_SIMD_PACKED : ZJ_WAVES_PER_SIMD)) void zj_fused_kernel(const Params p)
+// What precedes a workgroup's first load is on its critical path: the workgroup holds one of the CU's six slots while it
+// waits, so throughput = slots / workgroup lifetime (round 4: the division by a kernel argument).  Left to itself the
+// compiler loads each kernel argument where it is first used -- total_tiles, then the multipliers, then a shift, then the
+// base pointers, then the strides: five to six scalar-cache round trips in a row before the first coefficient load can
+// issue.  The empty asm below makes the first 128 bytes of the arguments (everything the tile decode, the addresses and
+// the stagger need) operands at the kernel's entry, so their loads are issued together -- merged into a few wide s_load --
+// and waited for once; later uses find the values in registers (invariant loads, the same SSA values).
+#ifndef ZJ_PIN_ARGS
+#define ZJ_PIN_ARGS 1 // 0: A/B knob (tools/build_variant.sh nopin "-DZJ_PIN_ARGS=0")
+#endif
+__device__ __forceinline__ void pin_head(const Params& p)
+{
+    if (!ZJ_PIN_ARGS) return;
+    asm volatile("; kernel arguments 0x00-0x7f are resident"
+                 :: "s"(p.y), "s"(p.cb), "s"(p.cr), "s"(p.out), "s"(p.y_frame_stride), "s"(p.c_frame_stride), "s"(p.out_frame_stride),
+                    "s"(p.width), "s"(p.height), "s"(p.mcu_x), "s"(p.n_strips), "s"(p.tiles_per_row), "s"(p.regular_px), "s"(p.zero_fill),
+                    "s"(p.total_tiles), "s"(p.tpr_magic), "s"(p.tpr_shift), "s"(p.ns_magic), "s"(p.ns_shift), "s"(p.stagger_wgs),
+                    "s"(p.stagger_delay), "s"(p.stagger_magic), "s"(p.stagger_shift), "s"(p.plain));
+}
+
+// the body of both kernel families: zj_fused_kernel (RAG = false) and zj_fused_ragged_kernel (GEN_PACKED, FAST, RAG)
+template <int HS, int VS, int OUT, int GEN, bool FAST, bool TS, bool RAG>
+__device__ __forceinline__ void fused_body(const Params& p, char* lds)
 {
     using C = Cfg<HS, VS, OUT>;
-    __shared__ __attribute__((aligned(16))) char lds[GEN == GEN_PACKED ? C::LDS_PACKED : C::LDS_WIDE];
+    pin_head(p);
     const TileId t = decode_tile(p, (int)blockIdx.x);
     // Which hardware wave plays which role (4:2:0: two luma waves, the chroma wave, the halo wave -- ~1390 VALU instructions per
     // tile for the first three, ~900 for the last).  `tid` is the LOGICAL thread number everywhere below (block, item,
@@ -98,7 +118,7 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAV
         __builtin_assume(tid >= 0 && tid < C::NT); // what the compiler knew of threadIdx.x (it shapes the colour rounds)
     }
     stagger_start(p, (int)blockIdx.x);
-    if (GEN == GEN_WIDE) { tile_wide<C, HS, VS, OUT, FAST>(p, t, tid, lds); return; }
+    if (GEN == GEN_WIDE) { tile_wide<C, HS, VS, OUT, FAST, RAG>(p, t, tid, lds); return; }
     // luma enters arithmetic for the RGB family only; gray / YCbCr outputs keep its low byte (Q7)
     constexpr bool NEED_Y16 = OUT == OUT_RGB || OUT == OUT_RGBA || OUT == OUT_RGB_CHW;
     ZJ_SETPRIO(1, 3);
@@ -147,7 +167,7 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAV
     const bool redo = NEED_Y16 && __builtin_amdgcn_readfirstlane((int)*lds_flag<C>(lds)) != 0;
     if (redo) {
         __syncthreads(); // everyone has read the flag before the wide layout overwrites it
-        tile_wide<C, HS, VS, OUT, FAST>(p, t, tid, lds);
+        tile_wide<C, HS, VS, OUT, FAST, RAG>(p, t, tid, lds);
     } else if (TS) {
         // each wave stages its 64 items of a round in LDS, then stores them as contiguous pieces; LDS operations
         // of one wave execute in order, so no barrier is needed between the halves or between rounds
@@ -156,19 +176,39 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAV
 #pragma unroll
         for (int round = 0; round * C::NT < C::NITEMS; round++) {
             ItemOut io;
-            phase_color<C, HS, VS, OUT, GEN_PACKED, FAST, true>(p, t, tid, lds, round, &io);
+            phase_color<C, HS, VS, OUT, GEN_PACKED, FAST, true, RAG>(p, t, tid, lds, round, &io);
             if (round == 0 && ZJ_ABL(ZJ_PDBG(p), 128)) { ZJ_USE(io.s0.x ^ io.s0.y ^ io.s0.z ^ io.s0.w ^ io.s1.x ^ io.s1.y ^ io.s1.z ^ io.s1.w ^ io.s2.x ^ io.s2.y ^ io.s2.z ^ io.s2.w); return; } // ... after round 0's filters, colour math, packing
             stage_item<C>(io, tid, lds, round);
             ZJ_WAVE_FENCE();
-            color_copyout<C, OUT>(p, t, tid, lds, round);
+            color_copyout<C, OUT, RAG>(p, t, tid, lds, round);
             ZJ_WAVE_FENCE();
             if (round == 0 && ZJ_ABL(ZJ_PDBG(p), 256)) return; // ... after round 0's staging and stores
         }
     } else {
         ZJ_SETPRIO(2, 2);
         __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0), free here; see above
-        phase_color<C, HS, VS, OUT, GEN_PACKED, FAST>(p, t, tid, lds);
+        phase_color<C, HS, VS, OUT, GEN_PACKED, FAST, false, RAG>(p, t, tid, lds);
     }
+}
+
+template <int HS, int VS, int OUT, int GEN, bool FAST, bool TS>
+// launch bounds: see ZJ_WAVES_PER_SIMD / ZJ_WAVES_PER_SIMD_PACKED above
+__global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAVES_PER_SIMD_PACKED : ZJ_WAVES_PER_SIMD)) void zj_fused_kernel(const Params p)
+{
+    using C = Cfg<HS, VS, OUT>;
+    __shared__ __attribute__((aligned(16))) char lds[GEN == GEN_PACKED ? C::LDS_PACKED : C::LDS_WIDE];
+    fused_body<HS, VS, OUT, GEN, FAST, TS, false>(p, lds);
+}
+
+// Ragged widths (width % 16 != 0, width >= 64; the reference's medium images are 2500 wide): the packed generation's fast
+// path for every ordinary 16-pixel group of a row, the generic stores for the few groups at the row's end -- one launch,
+// one kernel (zj_device.h: phase_color, RAG).  A family of its own so that the aligned kernels above keep their code.
+template <int HS, int VS, int OUT, bool TS>
+__global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), ZJ_WAVES_PER_SIMD_PACKED) void zj_fused_ragged_kernel(const Params p)
+{
+    using C = Cfg<HS, VS, OUT>;
+    __shared__ __attribute__((aligned(16))) char lds[C::LDS_PACKED];
+    fused_body<HS, VS, OUT, GEN_PACKED, true, TS, true>(p, lds);
 }
 
 #if defined(ZJ_ABLATION)
@@ -187,6 +227,7 @@ static constexpr int g_pad_lds = 0;
 
 // variant: 0 = packed generation (staged stores where they apply), 1 = wide generation (round 1), 2 = packed with
 // direct stores.  All are bit-exact; 1 and 2 exist for A/B measurements and as the parity cross-check.
+// `fast` is zj_plan.h's launch_mode: 0 generic stores, 1 aligned fast path, 2 ragged fast path (packed generation only)
 static void pick(int variant, int out, bool fast, bool ts_ok, int& gen, bool& ts)
 {
     gen = variant == 1 ? GEN_WIDE : GEN_PACKED;
@@ -200,9 +241,15 @@ static hipError_t launch_fused_t(const Params& p, int variant, int fast, hipStre
     if (p.total_tiles <= 0) return hipSuccess;
     const dim3 grid((unsigned)p.total_tiles), block(C::NT);
     int gen; bool ts;
-    pick(variant, OUT, fast != 0, ts_eligible<C>(p, OUT, fast != 0), gen, ts);
+    pick(variant, OUT, fast != 0, ts_eligible<C>(p, OUT, fast != 0, fast == 2), gen, ts);
     const size_t dyn = (size_t)g_pad_lds;
     constexpr bool TSC = C::TSCAP; // staged stores exist for the 3-byte interleaved outputs only
+    if (fast == 2 && gen == GEN_PACKED) {
+        if (ts && TSC) hipLaunchKernelGGL((zj_fused_ragged_kernel<HS, VS, OUT, TSC>), grid, block, dyn, s, p);
+        else hipLaunchKernelGGL((zj_fused_ragged_kernel<HS, VS, OUT, false>), grid, block, dyn, s, p);
+        return hipGetLastError();
+    }
+    if (fast == 2) fast = 0; // (the wide generation has no ragged form)
     if (gen == GEN_WIDE) {
         if (fast) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, GEN_WIDE, true, false>), grid, block, dyn, s, p);
         else hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, GEN_WIDE, false, false>), grid, block, dyn, s, p);
@@ -272,8 +319,9 @@ const char* fused_kernel_name(int hs, int vs, int out, int variant, int fast, co
     ZJ_CASE(1, 1, OUT_RGBA) ZJ_CASE(2, 1, OUT_RGBA) ZJ_CASE(1, 2, OUT_RGBA) ZJ_CASE(2, 2, OUT_RGBA)
 #undef ZJ_CASE
     int gen; bool ts;
-    pick(variant, out, fast != 0, ok, gen, ts);
-    snprintf(b, 112, "void zj::zj_fused_kernel<%d, %d, %d, %d, %s, %s>(zj::Params)", hs, vs, out, gen, fast ? "true" : "false", ts ? "true" : "false");
+    pick(variant, out, fast != 0, ok || (fast == 2 && (out == OUT_RGB || out == OUT_YCBCR || out == OUT_RGBA)), gen, ts);
+    if (fast == 2 && gen == GEN_PACKED) snprintf(b, 112, "void zj::zj_fused_ragged_kernel<%d, %d, %d, %s>(zj::Params)", hs, vs, out, ts ? "true" : "false");
+    else snprintf(b, 112, "void zj::zj_fused_kernel<%d, %d, %d, %d, %s, %s>(zj::Params)", hs, vs, out, gen, (fast == 1) ? "true" : "false", ts ? "true" : "false");
     return b;
 }
 

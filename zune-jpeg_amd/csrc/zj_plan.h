@@ -28,8 +28,7 @@ struct Plan {
     size_t out_len;      // bytes per frame
     int ncomp_out;
     bool fast;           // aligned fast path (W % 16 == 0, W >= 32)
-    int twy;             // pixels per tile column
-    int interior_tiles;  // !fast: leading tile columns that hold nothing but regular 16-pixel groups (see make_plan)
+    int regular_px;      // !fast: pixels of a row made of ordinary 16-pixel groups; 0: the generic kernels (see make_plan)
     int rows_covered;    // n_strips * strip_rows; rows below stay 0 in the reference (Q6)
 };
 
@@ -48,10 +47,10 @@ inline void plan_geo(Plan& pl, bool chroma)
 {
     if (chroma) {
         using C = Cfg<HS, VS, OUT_RGB>;
-        pl.strip_rows = C::SH; pl.tiles_per_row = (pl.mcu_x + C::TWC - 1) / C::TWC; pl.nt = C::NT; pl.twy = C::TWY;
+        pl.strip_rows = C::SH; pl.tiles_per_row = (pl.mcu_x + C::TWC - 1) / C::TWC; pl.nt = C::NT;
     } else {
         using C = Cfg<HS, VS, OUT_GRAY>;
-        pl.strip_rows = C::SH; pl.tiles_per_row = (pl.mcu_x + C::TWC - 1) / C::TWC; pl.nt = C::NT; pl.twy = C::TWY;
+        pl.strip_rows = C::SH; pl.tiles_per_row = (pl.mcu_x + C::TWC - 1) / C::TWC; pl.nt = C::NT;
     }
 }
 
@@ -112,16 +111,13 @@ inline int make_plan(const zj_frame_desc* d, Plan& pl)
     // at the END of its rows: the last two 8-pixel units are written early (Q5), what lies between them and the padded
     // width is never converted, the row is clipped at 3W (worker.rs:143-251).  The tail region starts at most 61 bytes
     // below 48 * elements (elements = P/16 - 1, worker.rs:171), so every 16-pixel group G <= elements - 3 is an ordinary
-    // one: 48 bytes at 48 * G, all inside the row.  Tile columns made of such groups only run the aligned fast path (the
-    // staged, lane-contiguous stores; a row may start at any byte, global stores take any alignment); the remaining one or
-    // two columns of a row take the generic store path in a second launch (Params::tile0).
-    pl.interior_tiles = 0;
+    // one: 48 bytes at 48 * G, all inside the row.  Those groups take the aligned fast path (the staged, lane-contiguous
+    // stores; a row may start at any byte, global stores take any alignment); the few groups beyond them take the generic
+    // stores, by the lanes that hold them, in the same launch (the RAG instantiations, zj_device.h: phase_color).
+    pl.regular_px = 0;
     if (!pl.fast && d->width >= 64) {
         const int P = pl.mcu_x * 8 * pl.hs, elements = P / 16 - 1;
-        const int regular_px = 16 * (elements - 2); // groups 0 .. elements - 3
-        int n = regular_px > 0 ? regular_px / pl.twy : 0;
-        if (n > pl.tiles_per_row - 1) n = pl.tiles_per_row - 1;
-        pl.interior_tiles = n > 0 ? n : 0;
+        if (elements > 2) pl.regular_px = 16 * (elements - 2); // groups 0 .. elements - 3
     }
     if (pl.out == OUT_GRAY && pl.n_strips > 0) {
         // ycbcr_to_grayscale re-derives the row count as len/width (color_convert/scalar.rs:97-99);
@@ -152,7 +148,7 @@ inline int uncovered_ranges(const zj_frame_desc* d, const Plan& pl, size_t off[3
 // the launch grid: nframes x n_strips x tiles_per_row workgroups, and the multipliers tile_from_id divides with
 inline void set_grid(Params& p, int nframes, int n_strips, int tiles_per_row)
 {
-    p.nframes = nframes; p.n_strips = n_strips; p.tiles_per_row = tiles_per_row; p.tile0 = 0;
+    p.nframes = nframes; p.n_strips = n_strips; p.tiles_per_row = tiles_per_row;
     p.total_tiles = nframes * n_strips * tiles_per_row;
     const Magic gt = magic_u31((uint32_t)(tiles_per_row > 0 ? tiles_per_row : 1)), gs = magic_u31((uint32_t)(n_strips > 0 ? n_strips : 1));
     p.tpr_magic = gt.m; p.tpr_shift = gt.s; p.ns_magic = gs.m; p.ns_shift = gs.s;
@@ -179,19 +175,12 @@ inline void fill_params(const zj_frame_desc* d, const Plan& pl, size_t nframes, 
     p.clamp_dc = pl.clamp_dc;
     p.edge_rep = pl.edge_rep;
     p.plane_stride = (long long)d->width * d->height;
+    p.regular_px = pl.regular_px;
 }
 
-// A ragged width as two launches: the leading `interior_tiles` tile columns of every row on the aligned fast path, the
-// rest on the generic one (make_plan).  Both keep the frames / strips of `p`.  Returns false when the plan has no split.
-inline bool split_ragged(const Plan& pl, const Params& p, Params& interior, Params& edge)
-{
-    if (pl.fast || pl.interior_tiles <= 0 || p.tiles_per_row != pl.tiles_per_row) return false;
-    interior = p; edge = p;
-    set_grid(interior, p.nframes, p.n_strips, pl.interior_tiles);
-    set_grid(edge, p.nframes, p.n_strips, pl.tiles_per_row - pl.interior_tiles);
-    edge.tile0 = pl.interior_tiles;
-    return true;
-}
+// which family of fused kernels a plan launches: 0 generic stores (any width), 1 aligned fast path, 2 ragged fast path
+// (RAG).  The wide generation (variant 1) has no RAG form: its ragged frames take the generic kernels.
+inline int launch_mode(const Plan& pl, int variant) { return pl.fast ? 1 : ((pl.regular_px > 0 && variant != 1) ? 2 : 0); }
 
 // frames [f0, f0 + n) of a scattered batch: their addresses into the launch's table (n <= SCATTER_MAX)
 inline void set_scatter(Params& p, const int16_t* const* y, const int16_t* const* cb, const int16_t* const* cr,
