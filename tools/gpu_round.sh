@@ -35,7 +35,7 @@ if has bench; then
 fi
 if has prof; then
   echo "== rocprofv3 --kernel-trace --stats (same command as bench)" | tee -a $O/summary.txt
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o stats -- python3 $R/bench.py --no-cpu-baseline --no-single-frame --no-live-traffic --no-e2e --no-dense-control > $O/prof_stats.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o stats -- python3 $R/bench.py --no-cpu-baseline --no-single-frame --no-live-traffic --no-e2e --no-dense-control --no-other-workloads > $O/prof_stats.log 2>&1)
   grep -h '"metric"' $O/prof_stats.log | tail -1 | tee -a $O/summary.txt
   find $O/prof_stats -name "*kernel_stats*.csv" | head -1 | xargs -r head -6 | tee -a $O/summary.txt
 fi
