@@ -252,6 +252,49 @@ pub fn decode_frames(d: &zj_frame_desc, frames: &[[&[i16]; 3]]) -> Vec<Vec<u8>> 
     outs
 }
 
+/// Image-level sharding over the GPUs of one node (`zj_multi_*`): frames are independent (the reference's own unit of
+/// independence is the strip, `src/mcu.rs:225-226,356-368`), so N frames over D devices are D contiguous shards and no
+/// collective; one context and one host thread per device slot, all slots at once.
+pub struct Multi { m: *mut zj_multi }
+unsafe impl Send for Multi {}
+impl Multi {
+    /// `devices[k]` = HIP device of slot k (a device may fill several slots); the 8-GPU node: `&[0, 1, 2, 3, 4, 5, 6, 7]`
+    pub fn new(devices: &[c_int]) -> Result<Multi, DecodeErrors> {
+        let mut st: c_int = 0;
+        let m = unsafe { zj_multi_create(devices.as_ptr(), devices.len() as c_int, &mut st) };
+        if m.is_null() {
+            let msg = unsafe { CStr::from_ptr(zj_strerror(st)) }.to_string_lossy().into_owned();
+            return Err(DecodeErrors { status: st, message: msg });
+        }
+        Ok(Multi { m })
+    }
+    pub fn slots(&self) -> usize { unsafe { zj_multi_devices(self.m) as usize } }
+    /// frames `[lo, hi)` that slot `slot` of `nslots` decodes out of `nframes` (`zj_shard_range`)
+    pub fn shard_range(nframes: usize, slot: usize, nslots: usize) -> (usize, usize) {
+        let (mut lo, mut hi) = (0usize, 0usize);
+        unsafe { zj_shard_range(nframes, slot as c_int, nslots as c_int, &mut lo, &mut hi) };
+        (lo, hi)
+    }
+    /// `frames[f]` = `[y, cb, cr]` coefficient planes of frame `f`, each an allocation of its own; returns the frames' pixels
+    pub fn decode_frames(&self, d: &zj_frame_desc, frames: &[[&[i16]; 3]]) -> Result<Vec<Vec<u8>>, DecodeErrors> {
+        let n_out = unsafe { zj_out_len(d) };
+        let mut outs: Vec<Vec<u8>> = frames.iter().map(|_| vec![0u8; n_out]).collect();
+        let y: Vec<*const i16> = frames.iter().map(|f| f[0].as_ptr()).collect();
+        let cb: Vec<*const i16> = frames.iter().map(|f| f[1].as_ptr()).collect();
+        let cr: Vec<*const i16> = frames.iter().map(|f| f[2].as_ptr()).collect();
+        let o: Vec<*mut u8> = outs.iter_mut().map(|v| v.as_mut_ptr()).collect();
+        let mut statuses = vec![0 as c_int; self.slots()];
+        let rc = unsafe { zj_multi_decode_frames(self.m, d, frames.len(), y.as_ptr(), cb.as_ptr(), cr.as_ptr(), o.as_ptr(),
+                                                 statuses.as_mut_ptr()) };
+        if rc != ZJ_OK {
+            let msg = unsafe { CStr::from_ptr(zj_strerror(rc)) }.to_string_lossy().into_owned();
+            return Err(DecodeErrors { status: rc, message: format!("{} (per slot: {:?})", msg, statuses) });
+        }
+        Ok(outs)
+    }
+}
+impl Drop for Multi { fn drop(&mut self) { unsafe { zj_multi_destroy(self.m) } } }
+
 /// `IDCTPtr` (`src/decoder.rs:56`), `UpSampler` (`src/components.rs:14`), `ColorConvert16Ptr` (`src/decoder.rs:47`).
 pub type IDCTPtr = fn(&[i16], &Aligned32<[i32; 64]>, usize, usize, usize) -> Vec<i16>;
 pub type UpSampler = fn(&[i16], usize) -> Vec<i16>;
