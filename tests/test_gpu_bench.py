@@ -102,3 +102,28 @@ def test_single_rank_line_has_the_contract_fields():
         assert "error" not in rfiles[name], rfiles[name]
         assert rfiles[name]["sha256_matches_golden"] is True and rfiles[name]["progressive"] is prog
         assert rfiles[name]["host_entropy_ms"] > 0 and rfiles[name]["gpu_pixels_ms"] > 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_under_torchrun_the_drivers_launch_shape():
+    """The driver starts N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...`: env:// rendezvous instead of the self-launcher's port file.  Two ranks on the
+    box's one GPU (ZJ_BENCH_SAME_GPU=1, gloo): the line, the golden checksums, the CPU baseline in the same run (rank 0 times
+    it while rank 1 is parked on torchrun's own store)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["ZJ_BENCH_SAME_GPU"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--min-untimed", "1", "--shard-frames", "16", "--no-live-traffic", "--no-single-frame", "--no-dense-control"],
+                       capture_output=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["frames_checksummed"] == 32 and res["checksums_match_golden"] is True
+    assert res["cpu_baseline"]["value"] > 100 and len(res["roofline"]["per_rank_kernel_ms"]) == 2
