@@ -50,12 +50,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--devices", default=None, help="comma-separated device slots for a multi-device pool (zj_pool_create_multi), e.g. 0,0")
+    ap.add_argument("--entropy", choices=["gpu", "cpu"], default="gpu")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     ctx = zj.Context()
     o = zj.ZuneJpegOptions()
-    o.entropy = zj.ENTROPY_GPU_ALWAYS
-    pool = zj.Pool(4, o)
+    o.entropy = zj.ENTROPY_GPU_ALWAYS if args.entropy == "gpu" else zj.ENTROPY_CPU
+    pool = zj.Pool(4, o) if not args.devices else zj.Pool(2, o, devices=[int(v) for v in args.devices.split(",")])
     ref = zj.Decoder(None, ctx)
     nfiles = nbatches = bad = 0
     t_end = time.time() + args.seconds
