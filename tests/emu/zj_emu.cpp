@@ -82,10 +82,10 @@ static void run(const Params& p)
             // all lanes copy out -- the GPU runs these back to back inside each wave, lanes in lockstep
             for (int round = 0; round * C::NT < C::NITEMS; round++)
                 for (int w = 0; w < C::NW; w++) {
-                    ItemOut io[64];
-                    for (int l = 0; l < 64; l++) phase_color<C, HS, VS, OUT, GEN_PACKED, FAST, CAN_TS, RAG>(p, t, 64 * w + l, lds, round, &io[l]);
-                    for (int l = 0; l < 64; l++) stage_item<C>(io[l], 64 * w + l, lds, round);
-                    for (int l = 0; l < 64; l++) color_copyout<C, OUT, RAG>(p, t, 64 * w + l, lds, round);
+                    ItemOut io[64];  // hardware wave w plays the logical threads round_tid gives it; its staging bytes are its own
+                    for (int l = 0; l < 64; l++) phase_color<C, HS, VS, OUT, GEN_PACKED, FAST, CAN_TS, RAG>(p, t, round_tid<C>(64 * w + l, round), lds, round, &io[l]);
+                    for (int l = 0; l < 64; l++) stage_item<C>(io[l], round_tid<C>(64 * w + l, round), lds, round, w);
+                    for (int l = 0; l < 64; l++) color_copyout<C, OUT, RAG>(p, t, round_tid<C>(64 * w + l, round), lds, round, w);
                 }
         } else {
             for (int tid = 0; tid < C::NT; tid++) phase_color<C, HS, VS, OUT, GEN_PACKED, FAST, false, RAG>(p, t, tid, lds);

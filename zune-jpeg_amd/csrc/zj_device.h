@@ -62,6 +62,10 @@ typedef uint32_t V4 __attribute__((vector_size(16)));    // the same 16 bytes fo
 #ifndef ZJ_NT
 #define ZJ_NT 4
 #endif
+// 1: a colour round that does not fill the workgroup is served by its last wave (Cfg::ROUND_ROT); 0: by its first (A/B knob)
+#ifndef ZJ_ROUND_ROT
+#define ZJ_ROUND_ROT 1
+#endif
 
 ZJ_DEV uint32_t as_u32(u16x2 v) { uint32_t r; __builtin_memcpy(&r, &v, 4); return r; }
 ZJ_DEV uint32_t as_u32(s16x2 v) { uint32_t r; __builtin_memcpy(&r, &v, 4); return r; }
@@ -683,6 +687,12 @@ struct Cfg {
     static constexpr int NT_MIN = (HS == 1 && VS == 1) ? (CHROMA ? ZJ_NT_MIN_444 : ZJ_NT_MIN_GRAY) : ((HS == 2 && VS == 1 && CHROMA) ? ZJ_NT_MIN_H : ((HS == 2 && VS == 2 && CHROMA) ? ZJ_NT_MIN_HV : ((HS == 1 && VS == 2 && CHROMA) ? ZJ_NT_MIN_V : 0)));
     static constexpr int NT = NT_BLK > NT_MIN ? NT_BLK : NT_MIN;     // threads per workgroup
     static constexpr int NW = NT / 64;
+    // Colour rounds that do not fill the workgroup (4:2:2: 256 items on 192 threads -- round 1 is one wave's worth) go to the
+    // LAST wave instead of the first: the first waves carry the block transforms (~640 instructions per lane), the last one
+    // the halo columns (~190), so the extra round lands where the workgroup's critical path is shortest.  ROUND_ROT = waves
+    // by which the logical thread numbering is rotated per round (kernel: round_tid); 0 where the rounds are full.
+    static constexpr int ROUND_ROT = (ZJ_ROUND_ROT && NITEMS % NT != 0 && NITEMS % NT <= 64 && NW > 1) ? 1 : 0;
+
     static constexpr int LUT_N = SH + 2;
     static constexpr int LUT_BYTES = ((2 * LUT_N * 2 + 15) / 16) * 16;
     static constexpr int HRAW = (CHROMA && HALO) ? 2 * 2 * CROWS : 0; // i16: halo pixel columns
@@ -1343,6 +1353,16 @@ ZJ_DEV void store_unit_generic(const Params& p, uint8_t* orow, const int P, cons
 //        3: the row's last group under the early-tail quirk (Q5): pieces 3L-1, 3L, 3L+1, then zeros in 3L+2 (Q6)
 struct ItemOut { U4 s0, s1, s2, s3; int kind; };
 
+// The LOGICAL thread number a hardware thread plays in colour round `round` (see Cfg::ROUND_ROT): item = logical tid +
+// round * NT everywhere in the colour phase; the staging area of a wave is the HARDWARE wave's (two hardware waves may be
+// copying out different rounds at the same time: no barrier separates the rounds).
+template <class C> ZJ_DEV int round_tid(const int tid, const int round)
+{
+    if (C::ROUND_ROT == 0) return tid;
+    const int t = tid + 64 * C::ROUND_ROT * round;
+    return t >= C::NT ? t - C::NT * (t / C::NT) : t;
+}
+
 // LDS address of piece q (0 .. 64*PPI-1) of a wave's round.  The first INPL pieces (whole items: lanes 0..20 for the
 // 48-byte items, 0..15 for the 64-byte ones) reuse the luma bytes the wave's 64 items have just consumed (16 bytes each,
 // contiguous because consecutive items are consecutive 16-pixel groups); the others live in the wave's XSTAGE bytes of
@@ -1385,11 +1405,12 @@ ZJ_DEV void nb_pair(const uint32_t vm[4], const char* cp, const int oa, const in
 }
 
 template <class C>
-ZJ_DEV void stage_item(const ItemOut& io, const int tid, char* lds, const int round)
+ZJ_DEV void stage_item(const ItemOut& io, const int tid /* logical */, char* lds, const int round, const int hw_wave = -1)
 {
     if (io.kind == 0) return;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int item0 = 64 * wave + round * C::NT;
+    const int lwave = tid >> 6, lane = tid & 63;
+    const int item0 = 64 * lwave + round * C::NT;
+    const int wave = hw_wave < 0 ? lwave : hw_wave; // whose staging bytes
     if (C::PPI == 3 && io.kind == 3) { // rare: one lane per row of the tile that holds the row's end
         const U4 z = {0, 0, 0, 0};
         *reinterpret_cast<U4*>(piece_addr<C>(lds, item0, wave, 3 * lane - 1)) = io.s0; // launcher: lane > 0 here
@@ -1684,7 +1705,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
 // its wave staged, i.e. every store instruction writes 1024 contiguous bytes of the tile's rows (row segments of
 // PIECES_PER_ROW pieces), instead of 64 pieces 48 (64) bytes apart.
 template <class C, int OUT, bool RAG = false>
-ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid, char* lds, const int round)
+ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid /* logical */, char* lds, const int round, const int hw_wave = -1)
 {
     using LL = typename C::template L<GEN_PACKED>;
     constexpr int PPI = C::PPI;
@@ -1703,7 +1724,7 @@ ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid, char* 
     const int never = (OUT == OUT_RGB && !p.plain && !p.zero_fill && row_end_here) ? 3 * nvg - 1 : -1;
     const int rows_left = p.height - t.strip * C::SH; // > 0
     const char* const ybase = lds + 16 * item0;
-    const char* const xbase = lds + LL::X_OFF + C::XSTAGE * w - 16 * C::INPL;
+    const char* const xbase = lds + LL::X_OFF + C::XSTAGE * (hw_wave < 0 ? w : hw_wave) - 16 * C::INPL;
     const char* src[PPI];
     uint32_t off[PPI];
     int mm[PPI], cc[PPI];
