@@ -403,6 +403,35 @@ def test_short_dc_read_picks_up_stale_rotated_bits(zj, synth):
         assert np.array_equal(g[:upto], w_[:upto]), (seq, st, [int(x) for x in g[:upto, 0]], [int(x) for x in w_[:upto, 0]])
         assert int(g[1, 0]) != 40 + 1024          # 1064 = what zeros below the held bits would give (rounds 2-3)
     assert stale_files == 3
+    # the WHOLE 64-bit register is history.  An AC refill at bits_left == 32 makes it 64; symbols worth 29 bits
+    # follow without another refill, then a 4 + 15-bit symbol that lands on coefficient 63 (bits_left 35 -> 16), then the
+    # 16-bit DC code of category 11 (no refill: 16 bits are held): the 11 magnitude bits are read with NOTHING left, all of
+    # them from the rotated history (ref_dc_misread: nhist == 64).  Sequences found by a search over this table's symbols;
+    # block 1's difference is chosen so that the literal reader's parse survives to the end of the scan.
+    seq = [0xFA, 0xFA, 0xFA, 0x0A, 0x0A, 0x0A, 0x0A, 0x0A, 0x0A, 0x0A, 0x01, 0x3A, 0x01, 0x01, 0x0F]
+    for diff, dc1 in ((1556, -1984), (-1529, -763)):
+        nb = 12
+        p = np.zeros((nb, 64), np.int16)
+        pos = 1                                   # block 0: DC 0 (category 0), then the sequence up to coefficient 63
+        for sym in seq:
+            pos += sym >> 4
+            sz = sym & 15
+            p[0, zz[pos]] = (1 << sz) - 1 if sz < 15 else 32767
+            pos += 1
+        assert pos == 64
+        p[1, 0] = diff
+        for b in range(2, nb):
+            p[b, 0] = p[b - 1, 0] + (40 if b % 2 else -40)
+            p[b, zz[1]], p[b, zz[2]] = 600, -700
+        data = jpeg_enc.encode_baseline([p.reshape(-1)], [synth.quant_tables(85)[0]], 8 * nb, 8, 1, 1, 1, tables=tabs)
+        want, short, rows = ref_walk.decode_baseline_planes(data)
+        st = dict(ref_walk.last_stats)
+        assert st["short"] >= 1 and st["stale"] >= 1 and st["first_marker_block"] is None, st
+        desc, got, info = zj.Decoder(_opts(zj, 1)).decode_coefficients(data)
+        g = np.array(got[0], np.int16).reshape(-1, 64)
+        w_ = want[0].reshape(-1, 64)
+        assert np.array_equal(g, w_), (diff, [int(x) for x in g[:, 0]], [int(x) for x in w_[:, 0]])
+        assert int(g[1, 0]) == dc1 and dc1 != -2047   # -2047 = zeros for all eleven bits: what the mask gave at nhist == 64
 
 
 def _first_scan_only(data):
