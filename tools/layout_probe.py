@@ -56,7 +56,6 @@ def main():
             base = [a.data_ptr() + pads[i] for i, a in enumerate(arenas)]
             base = [(b + 255) & ~255 for b in base]
             for c in range(3):
-                view = torch.empty(0)
                 for j in range(S):
                     off = base[c] - arenas[c].data_ptr() + j * pe[c] * 2
                     arenas[c][off:off + pe[c] * 2].view(torch.int16).copy_(frames[j][c])

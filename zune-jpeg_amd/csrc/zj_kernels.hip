@@ -176,7 +176,8 @@ __device__ __forceinline__ void fused_body(const Params& p, char* lds)
 #pragma unroll
         for (int round = 0; round * C::NT < C::NITEMS; round++) {
             ItemOut io;
-            const int hw = uniform(tid >> 6), ltid = round_tid<C>(tid, round); // (ltid == tid except for 4:2:2's partly filled round)
+            // (only 4:2:2 has a partly filled round: everywhere else the logical numbering is the hardware's, hw = -1 says so)
+            const int hw = C::ROUND_ROT ? uniform(tid >> 6) : -1, ltid = round_tid<C>(tid, round);
             phase_color<C, HS, VS, OUT, GEN_PACKED, FAST, true, RAG>(p, t, ltid, lds, round, &io);
             if (round == 0 && ZJ_ABL(ZJ_PDBG(p), 128)) { ZJ_USE(io.s0.x ^ io.s0.y ^ io.s0.z ^ io.s0.w ^ io.s1.x ^ io.s1.y ^ io.s1.z ^ io.s1.w ^ io.s2.x ^ io.s2.y ^ io.s2.z ^ io.s2.w); return; } // ... after round 0's filters, colour math, packing
             stage_item<C>(io, ltid, lds, round, hw);
