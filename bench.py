@@ -742,7 +742,8 @@ def main():
         for _ in range(8):
             idx = [int(v) for v in rng.permutation(S)[:B]]
             sets.append([[base[i] + f * fstr[i] for f in idx] for i in range(4)])
-        for k in range(24):
+        # (the one-frame launches above leave the clocks low: the same >= 100 untimed launches as in front of the timed region)
+        for k in range(max(args.min_untimed, 24)):
             q = sets[k % 8]
             ctx.decode_frames_device(desc, q[0], q[1], q[2], q[3], stream)
         ev[2].record(side)

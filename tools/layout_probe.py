@@ -6,6 +6,7 @@ launch, 4096 x 4096 4:2:0 -> RGB, under several placements of the same data:
   skewed     the same with the four tensors' bases skewed by odd multiples of 1 MiB + 4 KiB
   per-frame  frame f's y | cb | cr | out adjacent (one arena, scattered launch)
   spread     the 16 frames of a step 8 frames apart in the planar shard (scattered launch)
+  random / random-sorted / adjacent-shuffled   16 frames picked at random (in random or ascending order), the frames of a step shuffled
 """
 import importlib
 import os
@@ -73,6 +74,15 @@ def main():
                     ctx.decode_frames_device(d, [base[0] + f * pe[0] * 2 for f in idx], [base[1] + f * pe[1] * 2 for f in idx],
                                              [base[2] + f * pe[2] * 2 for f in idx], [base[3] + f * fo for f in idx], side.cuda_stream)
                 res.setdefault("spread", []).append(timed(spread, side))
+                rng = np.random.default_rng(5)
+                picks = [[int(v) for v in rng.permutation(S)[:B]] for _ in range(8)]
+                for label, sets in (("random", picks), ("random-sorted", [sorted(p_) for p_ in picks]),
+                                    ("adjacent-shuffled", [[q * B + int(v) for v in rng.permutation(B)] for q in range(nsub)])):
+                    def scat(k, base=base, sets=sets):
+                        idx = sets[k % len(sets)]
+                        ctx.decode_frames_device(d, [base[0] + f * pe[0] * 2 for f in idx], [base[1] + f * pe[1] * 2 for f in idx],
+                                                 [base[2] + f * pe[2] * 2 for f in idx], [base[3] + f * fo for f in idx], side.cuda_stream)
+                    res.setdefault(label, []).append(timed(scat, side))
             del arenas
             torch.cuda.empty_cache()
         # per-frame
