@@ -314,7 +314,7 @@ def other_workloads(zj, synth, ctx, dev, side, names=("444-rgb", "444-gray", "42
             torch.cuda.synchronize()
             ptr = [t.data_ptr() for t in pl] + [o.data_ptr()]
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-            for _ in range(20):
+            for _ in range(120):  # (the CPU baseline left the GPU idle for seconds: the first ~70 launches after idle run slow)
                 ctx.decode_planes_device(desc, B, ptr[0], ptr[1], ptr[2], ptr[3], side.cuda_stream)
             ev[0].record(side)
             for _ in range(iters):
