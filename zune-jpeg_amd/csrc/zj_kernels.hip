@@ -77,6 +77,9 @@ __device__ __forceinline__ void stagger_start(const Params& p, const int bid)
 // issue.  The empty asm below makes the first 128 bytes of the arguments (everything the tile decode, the addresses and
 // the stagger need) operands at the kernel's entry, so their loads are issued together -- merged into a few wide s_load --
 // and waited for once; later uses find the values in registers (invariant loads, the same SSA values).
+#ifndef ZJ_ASSUME_NO_HALO
+#define ZJ_ASSUME_NO_HALO 1 // 0: A/B knob for the __builtin_assume in front of the block waves' `locate`
+#endif
 #ifndef ZJ_PIN_ARGS
 #define ZJ_PIN_ARGS 1 // 0: A/B knob (tools/build_variant.sh nopin "-DZJ_PIN_ARGS=0")
 #endif
@@ -145,6 +148,9 @@ __device__ __forceinline__ void fused_body(const Params& p, char* lds)
         ZJ_WAVE_FENCE();
         halo_filter<C, HS, VS>(p, t, tid - C::HALO_T0, lds);
     } else {
+        // (with the halo blocks in a wave of their own no block wave ever holds one: telling the compiler prunes the halo
+        // cases out of `locate`, which sits in front of the chroma wave's first load)
+        if (ZJ_ASSUME_NO_HALO && C::HALO_PURE && C::NT == C::HALO_T0 + 64) __builtin_assume(tid < C::HALO_T0);
         const BlockLoc L = locate<C, GEN_PACKED>(p, t, tid, lds);
         U4 raw[8];
         load_block(L, raw, ZJ_PDBG(p));
