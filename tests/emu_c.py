@@ -1,5 +1,6 @@
 """ctypes binding of the CPU emulation of the HIP workgroup phases (tests/emu).  TEST ONLY."""
 import ctypes as C
+import fcntl
 import os
 import subprocess
 
@@ -19,9 +20,18 @@ def lib():
                 os.path.join(ROOT, "zune-jpeg_amd", "csrc", "zj_plan.h"),
                 os.path.join(ROOT, "zune-jpeg_amd", "csrc", "zj_huff.h"),
                 os.path.join(ROOT, "zune-jpeg_amd", "csrc", "zj_huff_device.h")]
-        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-            subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fno-strict-aliasing",
-                                   "-Wall", "-Wno-unknown-pragmas", "-o", so, srcs[0]])
+        def stale():
+            return not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+        if stale():
+            # pytest-xdist workers import this together: one of them builds (to a name of its own, renamed when whole),
+            # the others wait at the lock and find the library fresh
+            with open(so + ".lock", "w") as lk:
+                fcntl.flock(lk, fcntl.LOCK_EX)
+                if stale():
+                    tmp = f"{so}.{os.getpid()}.tmp"
+                    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fno-strict-aliasing",
+                                           "-Wall", "-Wno-unknown-pragmas", "-o", tmp, srcs[0]])
+                    os.replace(tmp, so)
         _LIB = C.CDLL(so)
     return _LIB
 

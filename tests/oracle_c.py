@@ -1,5 +1,6 @@
 """ctypes binding of the C oracle (oracle/libzjoracle.so).  TEST INFRASTRUCTURE ONLY."""
 import ctypes as C
+import fcntl
 import os
 import subprocess
 
@@ -27,8 +28,13 @@ class Frame(C.Structure):
 def build(force=False):
     so = os.path.join(ORACLE_DIR, "libzjoracle.so")
     src = os.path.join(ORACLE_DIR, "zj_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, so])
+    def stale():
+        return not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src)
+    if force or stale():
+        with open(so + ".lock", "w") as lk:          # pytest-xdist workers: one builds, the others wait and find it fresh
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if force or stale():
+                subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, so])
     return so
 
 
