@@ -862,10 +862,11 @@ ZJ_DEV TileId decode_tile(const Params& p, int bid)
         t.cr = ZJ_GLOBAL_PTR(const int16_t, p.fptr[t.frame][2]);
         t.out = ZJ_GLOBAL_PTR(uint8_t, p.fptr[t.frame][3]);
     } else {
-        t.y = p.y + (long long)t.frame * p.y_frame_stride;
-        t.cb = p.cb + (long long)t.frame * p.c_frame_stride;
-        t.cr = p.cr + (long long)t.frame * p.c_frame_stride;
-        t.out = p.out + (long long)t.frame * p.out_frame_stride;
+        const unsigned long long f = (unsigned)t.frame;   // (never negative: spares the scalar unit the sign terms of a 32 x 64 product)
+        t.y = p.y + f * (unsigned long long)p.y_frame_stride;
+        t.cb = p.cb + f * (unsigned long long)p.c_frame_stride;
+        t.cr = p.cr + f * (unsigned long long)p.c_frame_stride;
+        t.out = p.out + f * (unsigned long long)p.out_frame_stride;
     }
     return t;
 }
