@@ -1,0 +1,104 @@
+// Store-pattern probe (tools only, never in the product): what does a row pitch that is not a multiple of 128 bytes
+// cost the fused kernel's copy-out, and does a lane rotation that keeps every 8-lane group inside one 128-byte line
+// recover it?  Each workgroup writes one 256 x 32 pixel RGB tile the way color_copyout does: a wave's store instruction
+// covers 64 consecutive 16-byte pieces of the tile's 768-byte row segments.  No loads, no arithmetic: the store path alone.
+//   usage: zj_store_probe [frames]        build: hipcc --offload-arch=gfx950 -O3 -o tools/store_probe <this file>
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+// MODE 0: natural lane order; 1: lanes rotated so that every 8-lane group lies in one 128-byte line; 2: ... 4-lane group in 64 bytes;
+// 3: natural order, the pieces at a row segment's two ends (the sectors shared with the neighbouring tiles) stored
+//    write-back, everything else non-temporal (NT must be true)
+// XCD: workgroup -> tile as the product does it (zj_device.h: xcd_order): each XCD takes a contiguous run of tiles, so the
+//    tiles on both sides of a seam meet in ONE L2
+template <int MODE, bool NT, bool XCD>
+__global__ __launch_bounds__(256) void probe(unsigned char* out, int tiles_per_row, int strips, unsigned pitch, long long frame_bytes)
+{
+    int bid = blockIdx.x;
+    if (XCD && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int per_frame = tiles_per_row * strips;
+    const int frame = bid / per_frame, rem = bid % per_frame;
+    const int strip = rem / tiles_per_row, tile = rem % tiles_per_row;
+    unsigned char* const tile_out = out + frame * frame_bytes + (long long)strip * 32 * pitch + 768ll * tile;
+    const int w = threadIdx.x >> 6, L = threadIdx.x & 63;
+    const unsigned a0 = (unsigned)((unsigned long long)tile_out >> 4);
+    const unsigned rho = pitch >> 4;
+    const u4 v = {(unsigned)bid, (unsigned)threadIdx.x, 0x01020304u, 0x05060708u};
+#pragma unroll
+    for (int round = 0; round < 2; round++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int Q = 3 * (64 * w + 256 * round) + 64 * j + L;
+            const int m = Q / 48;
+            int cc = Q - 48 * m;
+            if (MODE == 1 || MODE == 2) {
+                const unsigned s = (a0 + (unsigned)m * rho) & (MODE == 1 ? 7u : 3u);
+                cc -= (int)s;
+                if (cc < 0) cc += 48;
+            }
+            u4* const dst = reinterpret_cast<u4*>(tile_out + (unsigned)m * pitch + 16u * (unsigned)cc);
+            if (MODE == 3) {
+                // (written as two plain C++ stores the compiler merges the arms into one store WITHOUT the nt bit)
+                if (cc == 0 || cc == 47) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(v) : "memory");
+                else asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(dst), "v"(v) : "memory");
+            } else if (MODE == 4 || MODE == 5) {
+                // every piece of a sector (4: 64 bytes, 5: a 128-byte line) that the row segment shares with a neighbouring tile
+                // is stored write-back, so that the L2 can put the two halves together; the sectors the tile owns stream out
+                const unsigned long long G = MODE == 4 ? 64 : 128;
+                const unsigned long long seg = (unsigned long long)(tile_out + (unsigned)m * pitch), a = (unsigned long long)dst;
+                const unsigned long long sec = a & ~(G - 1);
+                if (sec < seg || sec + G > seg + 768) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(v) : "memory");
+                else asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(dst), "v"(v) : "memory");
+            } else if (NT) __builtin_nontemporal_store(v, dst); else *dst = v;
+        }
+    }
+}
+
+template <int MODE, bool NT, bool XCD>
+static float run(unsigned char* buf, int W, int H, int frames, size_t offset)
+{
+    const int tiles = W / 256, strips = H / 32;
+    const unsigned pitch = 3u * W;
+    const long long fb = (long long)pitch * H;
+    hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    for (int i = 0; i < 20; i++) probe<MODE, NT, XCD><<<tiles * strips * frames, 256>>>(buf + offset, tiles, strips, pitch, fb);
+    CHECK(hipEventRecord(a));
+    const int reps = 50;
+    for (int i = 0; i < reps; i++) probe<MODE, NT, XCD><<<tiles * strips * frames, 256>>>(buf + offset, tiles, strips, pitch, fb);
+    CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+    float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+    CHECK(hipEventDestroy(a)); CHECK(hipEventDestroy(b));
+    return ms / reps;
+}
+
+int main(int argc, char** argv)
+{
+    const int frames = argc > 1 ? atoi(argv[1]) : 16;
+    unsigned char* buf; CHECK(hipMalloc(&buf, (size_t)frames * 3 * 4352 * 4096 + 4096));
+    CHECK(hipMemset(buf, 0, (size_t)frames * 3 * 4352 * 4096 + 4096));
+    // the tile grid covers floor(W / 256) tiles per row: the widths differ in PITCH only (the bytes beyond the last tile are not written)
+    const int widths[] = {4096, 4096 + 16, 4096 + 32, 4096 + 48, 4096 + 64, 4096 + 80, 4096 + 128, 4096 - 16 + 256};
+    printf("%-30s %9s %9s | %9s %9s %9s %9s %9s %9s   (GB/s written; pure stores, %d frames of W x 4096, tiles 256 x 32)\n", "pitch",
+           "wb", "NT", "xcd: wb", "xcd: NT", "rot128,NT", "ends wb", "64B mix", "128B mix", frames);
+    for (int W : widths) {
+        const int Wt = W / 256 * 256;   // pixels written per row
+        const double bytes = (double)frames * 4096 * 3 * Wt;
+        float t[8];
+        t[0] = run<0, false, false>(buf, W, 4096, frames, 0); t[1] = run<0, true, false>(buf, W, 4096, frames, 0);
+        t[2] = run<0, false, true>(buf, W, 4096, frames, 0);  t[3] = run<0, true, true>(buf, W, 4096, frames, 0);
+        t[4] = run<1, true, true>(buf, W, 4096, frames, 0);   t[5] = run<3, true, true>(buf, W, 4096, frames, 0);
+        t[6] = run<4, true, true>(buf, W, 4096, frames, 0);   t[7] = run<5, true, true>(buf, W, 4096, frames, 0);
+        char name[64]; snprintf(name, sizeof name, "3 x %d = %u (%% 128 = %u)", W, 3u * W, 3u * W % 128u);
+        printf("%-30s", name);
+        for (int i = 0; i < 8; i++) printf(" %9.0f%s", bytes / (t[i] * 1e-3) / 1e9, i == 1 ? " |" : "");
+        printf("\n");
+    }
+    CHECK(hipFree(buf));
+    return 0;
+}
