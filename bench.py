@@ -288,11 +288,13 @@ def live_traffic(workload, B, S, timeout_s=200):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def other_workloads(zj, synth, ctx, dev, side, names=("444-rgb", "444-gray", "422-rgb", "440-rgb", "420-rgb-2500x1786"), B=16, iters=100):
+def other_workloads(zj, synth, ctx, dev, side, names=("444-rgb", "444-gray", "422-rgb", "440-rgb", "420-rgb-2500x1786", "420-rgb-2500x1786-pitch128"), B=16, iters=100):
     """Never `value`: BASELINE configs[2] (4:4:4 -> RGB, -> GRAYSCALE; benches/decode.rs:44-131, decode_grayscale.rs:12-58)
     and the reference's two other sampling modes, each timed like the headline's kernel: 16 resident 4096x4096 frames per
     launch, HIP events on the launch stream around `iters` launches, against each workload's own algorithmic bytes per
-    pixel; and the reference's medium image size, a ragged width (60 frames per launch: the same pixels per launch).
+    pixel; and the reference's medium image size, a ragged width (60 frames per launch: the same pixels per launch), in the
+    reference's tight layout and with its rows laid out at a pitch that is a multiple of 128 bytes (zj_frame_desc.out_pitch:
+    a layout for outputs that stay in HBM; its rows must equal the tight layout's).
     The wide kernel generation decodes frame 0 once more and must give the same bytes."""
     import torch
     out = {}
@@ -308,8 +310,11 @@ def other_workloads(zj, synth, ctx, dev, side, names=("444-rgb", "444-gray", "42
             for j in range(B):
                 _, qts = synth.make_frame_t(W, H, hs, vs, 3, seed=1234, frame_index=j, device=dev,
                                             out=[pl[c][j * pe[c]:(j + 1) * pe[c]] for c in range(3)])
-            desc = zj.FrameDesc.make(W, H, hs, vs, 3, cs, qts)
-            fo = W * H * cs.num_components()
+            row = W * cs.num_components()
+            align = WORKLOADS[name][6] if len(WORKLOADS[name]) > 6 else 0
+            pitch = (row + align - 1) // align * align if align else 0
+            desc = zj.FrameDesc.make(W, H, hs, vs, 3, cs, qts, out_pitch=pitch)
+            fo = (pitch or row) * H
             o = torch.empty(B * fo, dtype=torch.uint8, device=dev)
             torch.cuda.synchronize()
             ptr = [t.data_ptr() for t in pl] + [o.data_ptr()]
@@ -330,10 +335,19 @@ def other_workloads(zj, synth, ctx, dev, side, names=("444-rgb", "444-gray", "42
                 side.synchronize()
             finally:
                 ctx.set_variant(0)
+            tight_ok = None
+            if pitch:  # the padded layout's rows are the tight layout's rows
+                t = torch.empty(row * H, dtype=torch.uint8, device=dev)
+                ctx.decode_planes_device(zj.FrameDesc.make(W, H, hs, vs, 3, cs, qts), 1, ptr[0], ptr[1], ptr[2], t.data_ptr(), side.cuda_stream)
+                side.synchronize()
+                tight_ok = bool(torch.equal(first.view(H, pitch)[:, :row], t.view(H, row)))
+                del t
             gbs = B * W * H * bpp / (ms * 1e-3) / 1e9
             out[name] = {"kernel_ms": round(ms, 4), "megapixels_per_s": round(B * W * H / 1e6 / (ms * 1e-3), 1),
                          "frames_per_launch": B, "width": W, "height": H, "bytes_per_px": bpp, "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "kernel": kname,
                          "matches_wide_variant": bool(torch.equal(first, o[:fo])), "what": what}
+            if pitch:
+                out[name].update({"out_pitch": pitch, "rows_match_tight_layout": tight_ok})
             del pl, o, first
             torch.cuda.empty_cache()
         except Exception as e:  # noqa: BLE001 -- the headline must not depend on this
@@ -479,6 +493,9 @@ WORKLOADS = {  # name: (h_samp, v_samp, output colourspace name, algorithmic byt
     # rows start at any byte, the row ends follow the reference's any-width rules (worker.rs:143-251)
     "420-rgb-2500x1786": (2, 2, "RGB", 6.0, "2500x1786 baseline 4:2:0 -> RGB (the reference's medium image size, a ragged width), planes resident in HBM", (2500, 1786)),
     "444-rgb-2500x1786": (1, 1, "RGB", 9.0, "2500x1786 baseline 4:4:4 -> RGB (ragged width), planes resident in HBM", (2500, 1786)),
+    # the same frames with their rows at a pitch of 7552 bytes (zj_frame_desc.out_pitch, a multiple of 128): every tile's row
+    # segment on whole cache lines; an extension for outputs that stay in HBM, the reference's layout is the tight one
+    "420-rgb-2500x1786-pitch128": (2, 2, "RGB", 6.0, "2500x1786 baseline 4:2:0 -> RGB, output rows at a pitch of 7552 bytes (multiple of 128; extension), planes resident in HBM", (2500, 1786), 128),
 }
 
 
@@ -600,8 +617,13 @@ def main():
         first_planes = None
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
-    desc = zj.FrameDesc.make(W, H, hs, vs, 3, out_cs, qts, out_layout=zj.LAYOUT_CHW if args.workload == "420-chw" else zj.LAYOUT_HWC)
-    frame_out = W * H * ncomp_out
+    wl_align = WORKLOADS[args.workload][6] if len(WORKLOADS[args.workload]) > 6 else 0
+    out_pitch = (W * ncomp_out + wl_align - 1) // wl_align * wl_align if wl_align else 0   # zj_frame_desc.out_pitch (0 = tight rows)
+    desc = zj.FrameDesc.make(W, H, hs, vs, 3, out_cs, qts, out_layout=zj.LAYOUT_CHW if args.workload == "420-chw" else zj.LAYOUT_HWC,
+                             out_pitch=out_pitch)
+    frame_out = out_pitch * H if out_pitch else W * H * ncomp_out
+    if out_pitch:
+        args.no_e2e = True   # host outputs are tight (the pipeline refuses a padded pitch)
     d_out = torch.empty(S * frame_out, dtype=torch.uint8, device=dev)
     # a dedicated stream: launches on the legacy NULL stream serialise against every blocking stream
     # and cost ~30 us each (tools/launch_overhead.py); torch.cuda.synchronize() still covers it

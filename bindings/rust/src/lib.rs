@@ -2,12 +2,12 @@
 //! names follow the reference crate (`Decoder`, `ZuneJpegOptions`, `ColorSpace`, the three fn-pointer types of
 //! `src/decoder.rs:47,56` and `src/components.rs:14`).
 //!
-//! The C side is `include/zjhip.h` (ABI version 6, checked at run time by `Decoder::new_with_options`).  Output bytes equal the reference's *scalar* arms.
+//! The C side is `include/zjhip.h` (ABI version 7, checked at run time by `Decoder::new_with_options`).  Output bytes equal the reference's *scalar* arms.
 #![allow(non_camel_case_types)]
 use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const ZJ_ABI_VERSION: c_int = 6;
+pub const ZJ_ABI_VERSION: c_int = 7;
 pub const ZJ_SCATTER_MAX: usize = 32;
 pub const ZJ_BACKEND_SCALAR: c_int = 0;
 pub const ZJ_BACKEND_AVX2: c_int = 1;
@@ -48,6 +48,7 @@ pub struct zj_frame_desc {
     pub in_components: u32, pub out_colorspace: i32,
     pub qt: [[i32; 64]; 3],
     pub flags: u32, pub out_layout: u32,
+    pub out_pitch: u32,             // bytes between output rows, 0 = tight (device outputs only)
 }
 
 #[repr(C)]

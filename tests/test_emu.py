@@ -272,3 +272,41 @@ def test_emulated_ragged_width_split_into_fast_interior_and_generic_edge(mode, w
             exp = np.ascontiguousarray(exp.reshape(h, w, 3).transpose(2, 0, 1)).reshape(-1)
         rce, out = emu_c.decode_planes(f, planes, flags=flags, out_layout=layout)
         assert rce == 0 and np.array_equal(out, exp), (mode, w, out_cs, flags, layout)
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("w", [32, 64, 250, 272, 303, 528, 1000, 1040, 2500])
+def test_emulated_out_pitch_rows_are_the_tight_rows(mode, w, synth):
+    """zj_frame_desc.out_pitch (rows laid out wider than they are, for outputs that stay in HBM): every row of the padded
+    layout holds the bytes of the tight layout's row, the bytes between a row's end and the next row's start keep the
+    caller's, in every output kind and kernel variant; pitches that are multiples of 128 / 16 / (ragged widths) of nothing;
+    the arguments make_plan refuses."""
+    hs, vs = MODES[mode]
+    h = 8 * vs * (2 if hs == 2 else 1) + 3   # one strip and a clipped second one
+    planes, qts = synth.make_frame(w, h, hs, vs, 3, seed=w + 7)
+    for out_cs, flags, layout, ncomp in ((oc.RGB, 0, 0, 3), (oc.GRAYSCALE, 0, 0, 1), (oc.YCBCR, 0, 0, 3), (oc.RGB, 1, 0, 3),
+                                         (oc.RGBA, 0, 0, 4), (oc.RGB, 0, 1, 3)):
+        f = oc.make_frame(w, h, hs, vs, 3, out_cs, qts)
+        row = w if layout == 1 else w * ncomp
+        planes_out = 3 if layout == 1 else 1
+        pitches = [(row + 127) // 128 * 128, (row + 15) // 16 * 16 + 16] + ([row + 5] if w % 16 else [])
+        for variant in (0, 2, 1):
+            emu_c.set_variant(variant)
+            for zf in (0, 1):
+                rc, tight = emu_c.decode_planes(f, planes, zero_fill=zf, poison=0x5C, flags=flags, out_layout=layout)
+                if rc != 0:
+                    assert rc == -5
+                    continue
+                for pitch in pitches:
+                    rc, out = emu_c.decode_planes(f, planes, zero_fill=zf, poison=0x5C, flags=flags, out_layout=layout, out_pitch=pitch)
+                    assert rc == 0 and out.size == pitch * h * planes_out, (mode, w, out_cs, layout, variant, pitch)
+                    o = out.reshape(planes_out * h, pitch)
+                    assert np.array_equal(o[:, :row], tight.reshape(planes_out * h, row)), (mode, w, out_cs, flags, layout, variant, zf, pitch)
+                    if zf == 0:
+                        assert (o[:, row:] == 0x5C).all(), (mode, w, out_cs, layout, variant, pitch)
+    emu_c.set_variant(0)
+    f = oc.make_frame(w, h, hs, vs, 3, oc.RGB, qts)
+    assert emu_c.decode_planes(f, planes, out_pitch=3 * w - 1)[0] == -1          # shorter than a row
+    if w % 16 == 0:
+        assert emu_c.decode_planes(f, planes, out_pitch=3 * w + 8)[0] == -1      # aligned kernels: 16-byte rows
+    assert emu_c.decode_planes(f, planes, out_pitch=(1 << 20) + 16)[0] == -1

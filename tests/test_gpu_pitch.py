@@ -1,0 +1,151 @@
+"""GPU parity for zj_frame_desc.out_pitch (rows laid out wider than they are, for outputs that stay in HBM): every call
+through the C ABI of libzjhip.so, every row against the oracle's row (the tight layout is the reference's,
+/root/reference/src/mcu.rs:375-379), the bytes between a row's end and the next row's start against the fill the test put
+there.  A pitch that is a multiple of 128 bytes is what the layout exists for (DESIGN.md 4.0 "row pitch"); any other is
+legal too."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+import oracle_c as oc
+
+pytestmark = pytest.mark.gpu
+MODES = {"none": (1, 1), "h": (2, 1), "v": (1, 2), "hv": (2, 2)}
+
+
+@pytest.fixture(scope="module")
+def zj():
+    return importlib.import_module("zune-jpeg_amd")
+
+
+@pytest.fixture(scope="module", params=[0, 1, 2], ids=["packed", "wide", "packed-direct"])
+def ctx(zj, request):
+    c = zj.Context(zj.BACKEND_HIP, 0)
+    c.set_variant(request.param)
+    yield c
+    c.close()
+
+
+def expected(synth, w, h, hs, vs, out_cs, flags, layout, qts, planes):
+    """the tight bytes, as rows: (planes * h, row_bytes)"""
+    f = oc.make_frame(w, h, hs, vs, 3, out_cs, qts)
+    ext = flags != 0 or layout == 1 or out_cs in (oc.RGBA,)
+    rc, exp = oc.decode_planes(f, planes, plain=True) if ext else oc.decode_planes(f, planes)
+    if rc != 0:
+        return rc, None
+    ncomp = {oc.RGB: 3, oc.GRAYSCALE: 1, oc.YCBCR: 3, oc.RGBA: 4}[out_cs]
+    if layout == 1:
+        return 0, np.ascontiguousarray(exp.reshape(h, w, 3).transpose(2, 0, 1)).reshape(3 * h, w)
+    return 0, exp.reshape(h, w * ncomp)
+
+
+def run_device(zj, ctx, d, planes, n=1, fill=0xAA):
+    out_len = zj.lib().zj_out_len(C.byref(d))
+    bufs = [ctx.device_alloc(max(p.nbytes, 16)) for p in planes] + [ctx.device_alloc(n * out_len)]
+    try:
+        for b, p in zip(bufs, planes):
+            ctx.h2d(b, p)
+        zj.lib().zj_device_memset(ctx.handle, bufs[3], fill, n * out_len)
+        ctx.decode_planes_device(d, n, bufs[0], bufs[1], bufs[2], bufs[3])
+        ctx.sync()
+        got = np.empty(n * out_len, np.uint8)
+        ctx.d2h(got, bufs[3])
+        return got
+    finally:
+        for b in bufs:
+            ctx.device_free(b)
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("kind", ["rgb", "gray", "ycbcr", "plain", "rgba", "chw"])
+@pytest.mark.parametrize("wh", [(272, 100), (64, 64), (1040, 33), (2500, 70), (303, 40), (37, 50)])
+def test_padded_rows_on_the_device_vs_oracle(ctx, zj, synth, mode, kind, wh):
+    hs, vs = MODES[mode]
+    w, h = wh
+    out_cs, flags, layout, ncomp = {"rgb": (oc.RGB, 0, 0, 3), "gray": (oc.GRAYSCALE, 0, 0, 1), "ycbcr": (oc.YCBCR, 0, 0, 3),
+                                    "plain": (oc.RGB, 1, 0, 3), "rgba": (oc.RGBA, 0, 0, 4), "chw": (oc.RGB, 0, 1, 3)}[kind]
+    planes, qts = synth.make_frame(w, h, hs, vs, 3, seed=w + h)
+    rc, exp = expected(synth, w, h, hs, vs, out_cs, flags, layout, qts, planes)
+    row = w if layout == 1 else w * ncomp
+    for pitch in ((row + 127) // 128 * 128, (row + 15) // 16 * 16 + 16):
+        d = zj.FrameDesc.make(w, h, hs, vs, 3, out_cs, qts, flags=flags, out_layout=layout, out_pitch=pitch)
+        if rc != 0:
+            with pytest.raises(zj.ZjError) as e:
+                run_device(zj, ctx, d, planes)
+            assert e.value.status == -5
+            return
+        assert zj.lib().zj_out_len(C.byref(d)) == pitch * h * (3 if layout == 1 else 1)
+        got = run_device(zj, ctx, d, planes).reshape(-1, pitch)
+        bad = np.nonzero(got[:, :row] != exp)
+        assert bad[0].size == 0, (mode, kind, wh, pitch, bad[0][:5], bad[1][:5])
+        # the padding: untouched, except in rows the strips never reach (zeroed whole with the row, Q6)
+        pad = got[:, row:]
+        rows_touched = (pad != 0xAA).any(axis=1)
+        assert not pad[~rows_touched].size or (pad[~rows_touched] == 0xAA).all()
+        assert (pad[rows_touched] == 0).all() and not exp[rows_touched].any(), (mode, kind, wh, pitch)
+
+
+def test_padded_rows_batches_scattered_strided_and_multi(zj, synth):
+    """the other device entry points take the same descriptor: a contiguous batch (frame stride = out_pitch * height), a
+    scattered batch, a strided one, two device slots -- all equal to the one-frame result"""
+    ctx = zj.Context(zj.BACKEND_HIP, 0)
+    w, h, n = 2500, 40, 5
+    frames = [synth.make_frame(w, h, 2, 2, 3, seed=9, frame_index=i) for i in range(n)]
+    qts = frames[0][1]
+    pitch = (3 * w + 127) // 128 * 128
+    d = zj.FrameDesc.make(w, h, 2, 2, 3, zj.ColorSpace.RGB, qts, out_pitch=pitch)
+    out_len = zj.lib().zj_out_len(C.byref(d))
+    assert out_len == pitch * h
+    f = oc.make_frame(w, h, 2, 2, 3, oc.RGB, qts)
+    want = []
+    for fr in frames:
+        e = np.full((h, pitch), 0x5C, np.uint8)
+        e[:, :3 * w] = oc.decode_planes(f, fr[0])[1].reshape(h, 3 * w)
+        e[32:] = 0   # rows below the last complete strip (Q6) are zeroed whole, padding included
+        want.append(e.reshape(-1))
+    cat = [np.concatenate([fr[0][c] for fr in frames]) for c in range(3)]
+    bufs = [ctx.device_alloc(p.nbytes) for p in cat] + [ctx.device_alloc(n * (out_len + 4096))]
+    try:
+        for b, p in zip(bufs, cat):
+            ctx.h2d(b, p)
+        ylen, clen = frames[0][0][0].size, frames[0][0][1].size
+        for which in ("batch", "scattered", "strided", "multi"):
+            stride = out_len if which in ("batch", "multi") else out_len + 4096
+            zj.lib().zj_device_memset(ctx.handle, bufs[3], 0x5C, n * (out_len + 4096))
+            if which == "batch":
+                ctx.decode_planes_device(d, n, bufs[0], bufs[1], bufs[2], bufs[3])
+            elif which == "strided":
+                ctx.decode_planes_device_strided(d, n, bufs[0], bufs[1], bufs[2], bufs[3], ylen, clen, stride)
+            elif which == "scattered":
+                order = [3, 0, 4, 1, 2]
+                ctx.decode_frames_device(d, [bufs[0] + 2 * i * ylen for i in order], [bufs[1] + 2 * i * clen for i in order],
+                                         [bufs[2] + 2 * i * clen for i in order], [bufs[3] + i * stride for i in order])
+            else:
+                m = zj.Multi([0, 0])
+                try:
+                    m.decode_frames_device(d, [bufs[0] + 2 * i * ylen for i in range(n)], [bufs[1] + 2 * i * clen for i in range(n)],
+                                           [bufs[2] + 2 * i * clen for i in range(n)], [bufs[3] + i * stride for i in range(n)])
+                finally:
+                    m.close()
+            ctx.sync()
+            got = np.empty(n * (out_len + 4096), np.uint8)
+            ctx.d2h(got, bufs[3])
+            for i in range(n):
+                assert np.array_equal(got[i * stride:i * stride + out_len], want[i]), (which, i)
+        # host outputs are tight: a padded pitch is refused there, and so are pitches no kernel can serve
+        with pytest.raises(zj.ZjError) as e:
+            ctx.decode_planes(d, frames[0][0])
+        assert e.value.status == -2
+        for bad in (3 * w - 1, (1 << 20) + 128):
+            with pytest.raises(zj.ZjError) as e:
+                ctx.decode_planes_device(zj.FrameDesc.make(w, h, 2, 2, 3, zj.ColorSpace.RGB, qts, out_pitch=bad), 1, bufs[0], bufs[1], bufs[2], bufs[3])
+            assert e.value.status == -1
+        with pytest.raises(zj.ZjError) as e:   # aligned widths: rows of the aligned kernels start on 16-byte boundaries
+            ctx.decode_planes_device(zj.FrameDesc.make(2496, h, 2, 2, 3, zj.ColorSpace.RGB, qts, out_pitch=3 * 2496 + 8), 1, bufs[0], bufs[1], bufs[2], bufs[3])
+        assert e.value.status == -1
+    finally:
+        for b in bufs:
+            ctx.device_free(b)
+        ctx.close()

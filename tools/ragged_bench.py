@@ -19,6 +19,7 @@ def main():
     ctx = zj.Context(zj.BACKEND_HIP, 0)
     side = torch.cuda.Stream(device=dev)
     B = int(os.environ.get("ZJ_RAGGED_B", "32"))
+    PITCH = int(os.environ.get("ZJ_RAGGED_PITCH", "0"))  # e.g. 128: output rows at the next multiple of 128 bytes
     sizes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(2500, 1786), (2512, 1786), (4090, 4096), (4096, 4096)]
     for (w, h) in sizes:
         for name, (hs, vs), bpp in (("420", (2, 2), 6.0), ("444", (1, 1), 9.0), ("422", (2, 1), 7.0)):
@@ -28,13 +29,14 @@ def main():
             for j in range(nb):
                 _, qts = synth.make_frame_t(w, h, hs, vs, 3, seed=1234, frame_index=j, device=dev,
                                             out=[pl[c][j * pe[c]:(j + 1) * pe[c]] for c in range(3)])
-            d = zj.FrameDesc.make(w, h, hs, vs, 3, zj.ColorSpace.RGB, qts)
-            o = torch.empty(nb * w * h * 3 + 64, dtype=torch.uint8, device=dev)
+            pitch = (3 * w + PITCH - 1) // PITCH * PITCH if PITCH else 0   # zj_frame_desc.out_pitch (0 = the tight rows)
+            d = zj.FrameDesc.make(w, h, hs, vs, 3, zj.ColorSpace.RGB, qts, out_pitch=pitch)
+            o = torch.empty(nb * (pitch or 3 * w) * h + 64, dtype=torch.uint8, device=dev)
             torch.cuda.synchronize()
             # frames packed back to back need out_len % 16 == 0 only for the aligned path; ragged frames take any byte
             ptr = [t.data_ptr() for t in pl] + [o.data_ptr()]
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-            for _ in range(20):
+            for _ in range(100):
                 ctx.decode_planes_device(d, nb, ptr[0], ptr[1], ptr[2], ptr[3], side.cuda_stream)
             ev[0].record(side)
             for _ in range(100):
@@ -44,7 +46,7 @@ def main():
             ms = ev[0].elapsed_time(ev[1]) / 100
             gbs = nb * w * h * bpp / (ms * 1e-3) / 1e9
             _, _, kname = ctx.time_decode_device(d, nb, ptr[0], ptr[1], ptr[2], ptr[3], 1, side.cuda_stream)
-            print(f"{w}x{h} {name}->RGB  {nb} frames/launch  {ms:.4f} ms  {nb * w * h / 1e6 / (ms * 1e-3):.0f} MP/s  "
+            print(f"{w}x{h}{'/' + str(pitch) if pitch else ''} {name}->RGB  {nb} frames/launch  {ms:.4f} ms  {nb * w * h / 1e6 / (ms * 1e-3):.0f} MP/s  "
                   f"{gbs:.0f} GB/s  frac {gbs / 8000:.4f}  {kname[18:60]}", flush=True)
             del pl, o
             torch.cuda.empty_cache()

@@ -253,7 +253,11 @@ size_t zj_plane_len(const zj_frame_desc* d, int comp)
 size_t zj_out_len(const zj_frame_desc* d)
 {
     if (!d) return 0;
-    return (size_t)d->width * d->height * (size_t)ncomp_of(d->out_colorspace);
+    // (make_plan's arithmetic without its checks: a length for any descriptor, as before)
+    const bool chw = d->out_layout == ZJ_LAYOUT_CHW && d->out_colorspace == ZJ_CS_RGB;
+    const size_t row = chw ? (size_t)d->width : (size_t)d->width * (size_t)ncomp_of(d->out_colorspace);
+    const size_t pitch = d->out_pitch > row ? (size_t)d->out_pitch : row;
+    return pitch * d->height * (chw ? 3 : 1);
 }
 
 /* ---- memory helpers ------------------------------------------------------------------------- */
@@ -377,7 +381,7 @@ static int decode_device_impl(zj_ctx* c, const zj_frame_desc* d, const Plan& pl,
             Params q = p;
             const long long yrow = (long long)pl.mcu_x * pl.hs * 64 * (pl.strip_rows / 8), crow = (long long)pl.mcu_x * 64 * (pl.strip_rows / (8 * pl.vs));
             q.y = p.y + s0 * yrow; q.cb = p.cb ? p.cb + s0 * crow : nullptr; q.cr = p.cr ? p.cr + s0 * crow : nullptr;
-            q.out = p.out + (size_t)s0 * pl.strip_rows * d->width * pl.ncomp_out;
+            q.out = p.out + (size_t)s0 * pl.strip_rows * pl.out_pitch;
             q.height = (int)d->height - s0 * pl.strip_rows;
             set_grid(q, 1, s1 - s0, pl.tiles_per_row);
             ZJ_HIP(c, hipStreamWaitEvent(in[r], fork, 0));
@@ -590,6 +594,9 @@ static int decode_planes_batch_impl(zj_ctx* c, const zj_frame_desc* d, const Pla
     //   Frames that are independent allocations (zj_decode_frames) differ only in the copies: one per frame and plane
     // where packed frames take one per unit and plane; on the device a unit is packed either way.
     int rc;
+    // a padded row pitch is a layout for outputs that stay on the device (the kernels never write the padding; the copies
+    // of this pipeline move whole strips): host outputs are tight, as the reference's are
+    if (pl.out_pitch != pl.row_bytes) return ZJ_ERR_UNSUPPORTED;
     ZJ_HIP(c, hipSetDevice(c->device));
     const bool chroma = pl.out != OUT_GRAY;
     const int mrps = pl.hs == 2 ? 2 : 1;                                     // MCU rows per strip

@@ -765,7 +765,9 @@ struct Params {
     int debug;                    // diagnostic build only (tools/ablate.py): 1 skip IDCT, 2 skip colour math, 4 no loads, 8 no stores
 #endif
     int plain;                    // OUT_RGB only: 1 = the last 16 samples of a row go to their own position (no Q5/Q6)
-    long long plane_stride;       // OUT_RGB_CHW: bytes between the R, G and B planes of a frame (width * height)
+    int out_pitch;                // bytes between the starts of consecutive output rows (zj_frame_desc.out_pitch; tight = width x
+                                  // components, CHW: width); what lies between a row's end and the next row is never written
+    long long plane_stride;       // OUT_RGB_CHW: bytes between the R, G and B planes of a frame (out_pitch * height)
     int clamp_dc;                 // extension: DC-only shortcut value clamped to 0..255 (Q1 corrected)
     int edge_rep;                 // extension: horizontal chroma filter per row with replicated edges (Q4 corrected)
     uint32_t tab[3 * TAB_DW];     // the three quantisation tables + guard constants (build_table), by value
@@ -1447,8 +1449,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
     const bool left_wrap = cb0 == 0, right_wrap = cb0 + C::TWC >= cbw;
     const bool edge_tile = HS == 2 && (left_wrap || right_wrap); // workgroup-uniform
     const int x0 = t.tile * C::TWY;
-    const int ncomp = OUT == OUT_GRAY ? 1 : (OUT == OUT_RGBA ? 4 : 3);
-    const long long row_bytes = OUT == OUT_RGB_CHW ? (long long)W : (long long)W * ncomp; // CHW: one plane's row
+    const long long row_bytes = p.out_pitch; // between rows (tight: W * ncomp; CHW: W, one plane's row); clip ends stay W-based
     uint8_t* const frame_out = t.out;
     const int elements = P / 16 - 1; // worker.rs:171 (P >= 32 on this path)
     if (TS) io->kind = 0;
@@ -1714,7 +1715,7 @@ ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid /* logi
     const int x0 = t.tile * C::TWY;
     const int left = P - x0 > 0 ? (P - x0) / 16 : 0;
     const int nvg = left < C::NGRP ? left : C::NGRP; // valid 16-pixel groups of this tile
-    const uint32_t row_bytes = (uint32_t)(PPI == 4 ? 4 : 3) * (uint32_t)p.width;
+    const uint32_t row_bytes = (uint32_t)p.out_pitch;
     // everything up to here is uniform: a scalar base address, 32-bit per-lane offsets below
     uint8_t* const tile_out = t.out + (long long)t.strip * C::SH * row_bytes + (long long)(PPI == 4 ? 4 : 3) * x0;
     const int w = uniform(tid >> 6), L = tid & 63;

@@ -86,11 +86,11 @@ __device__ __forceinline__ void stagger_start(const Params& p, const int bid)
 __device__ __forceinline__ void pin_head(const Params& p)
 {
     if (!ZJ_PIN_ARGS) return;
-    asm volatile("; kernel arguments 0x00-0x7f are resident"
+    asm volatile("; kernel arguments 0x00-0x87 are resident"
                  :: "s"(p.y), "s"(p.cb), "s"(p.cr), "s"(p.out), "s"(p.y_frame_stride), "s"(p.c_frame_stride), "s"(p.out_frame_stride),
                     "s"(p.width), "s"(p.height), "s"(p.mcu_x), "s"(p.n_strips), "s"(p.tiles_per_row), "s"(p.regular_px), "s"(p.zero_fill),
                     "s"(p.total_tiles), "s"(p.tpr_magic), "s"(p.tpr_shift), "s"(p.ns_magic), "s"(p.ns_shift), "s"(p.stagger_wgs),
-                    "s"(p.stagger_delay), "s"(p.stagger_magic), "s"(p.stagger_shift), "s"(p.plain));
+                    "s"(p.stagger_delay), "s"(p.stagger_magic), "s"(p.stagger_shift), "s"(p.plain), "s"(p.out_pitch));
 }
 
 // the body of both kernel families: zj_fused_kernel (RAG = false) and zj_fused_ragged_kernel (GEN_PACKED, FAST, RAG)

@@ -25,7 +25,9 @@ struct Plan {
     int tiles_per_row;
     int nt;              // threads per workgroup
     size_t y_len, c_len; // i16 elements per plane
-    size_t out_len;      // bytes per frame
+    size_t out_len;      // bytes per frame (out_pitch x height, CHW: x 3)
+    size_t row_bytes;    // bytes of one output row (CHW: of a plane's row): width x components
+    size_t out_pitch;    // bytes between rows: zj_frame_desc.out_pitch, or row_bytes when that is 0
     int ncomp_out;
     bool fast;           // aligned fast path (W % 16 == 0, W >= 32)
     int regular_px;      // !fast: pixels of a row made of ordinary 16-pixel groups; 0: the generic kernels (see make_plan)
@@ -91,7 +93,12 @@ inline int make_plan(const zj_frame_desc* d, Plan& pl)
     pl.mcu_y = (int)((d->height + 8 * d->v_max - 1) / (8 * d->v_max)); // headers.rs:319
     pl.y_len = (size_t)pl.mcu_x * 64 * d->v_max * d->h_max * pl.mcu_y; // mcu_prog.rs:76
     pl.c_len = d->in_components == 3 ? (size_t)pl.mcu_x * 64 * pl.mcu_y : 0;
-    pl.out_len = (size_t)d->width * d->height * nout;
+    // rows may be laid out wider than they are (a pitch that is a multiple of 128 bytes keeps every tile's row segment on
+    // whole cache lines: DESIGN.md 4.0 "row pitch"); the reference's own layout is the tight one
+    pl.row_bytes = pl.out == OUT_RGB_CHW ? (size_t)d->width : (size_t)d->width * nout;
+    pl.out_pitch = d->out_pitch ? (size_t)d->out_pitch : pl.row_bytes;
+    if (pl.out_pitch < pl.row_bytes || pl.out_pitch > (1u << 20)) return ZJ_ERR_ARG;
+    pl.out_len = pl.out_pitch * d->height * (pl.out == OUT_RGB_CHW ? 3 : 1);
     const bool chroma = pl.out != OUT_GRAY;
     if (pl.hs == 1 && pl.vs == 1) plan_geo<1, 1>(pl, chroma);
     else if (pl.hs == 2 && pl.vs == 1) plan_geo<2, 1>(pl, chroma);
@@ -107,6 +114,7 @@ inline int make_plan(const zj_frame_desc* d, Plan& pl)
     const size_t chunk = (size_t)d->width * nout * 8 * d->h_max * d->v_max;
     if (total / chunk < (size_t)pl.n_strips) pl.n_strips = (int)(total / chunk);
     pl.fast = (d->width % 16 == 0) && d->width >= 32;
+    if (pl.fast && (pl.out_pitch & 15)) return ZJ_ERR_ARG; // the aligned kernels store 16 bytes per lane at 16-byte-aligned addresses
     // A ragged width (the reference's own medium images are 2500 pixels wide, tests/medium_images.rs) is irregular only
     // at the END of its rows: the last two 8-pixel units are written early (Q5), what lies between them and the padded
     // width is never converted, the row is clipped at 3W (worker.rs:143-251).  The tail region starts at most 61 bytes
@@ -133,14 +141,15 @@ inline int make_plan(const zj_frame_desc* d, Plan& pl)
 // Q6: the reference leaves them 0).  HWC: one range; CHW: one per plane.  Returns the number of ranges.
 inline int uncovered_ranges(const zj_frame_desc* d, const Plan& pl, size_t off[3], size_t len[3])
 {
-    const size_t H = d->height, W = d->width;
+    // (whole rows of out_pitch bytes: with a padded pitch the padding of THESE rows is zeroed along with them)
+    const size_t H = d->height, Pb = pl.out_pitch;
     const size_t covered = (size_t)pl.rows_covered < H ? (size_t)pl.rows_covered : H;
     if (covered >= H) return 0;
     if (pl.out == OUT_RGB_CHW) {
-        for (int c = 0; c < 3; c++) { off[c] = (size_t)c * W * H + covered * W; len[c] = (H - covered) * W; }
+        for (int c = 0; c < 3; c++) { off[c] = (size_t)c * Pb * H + covered * Pb; len[c] = (H - covered) * Pb; }
         return 3;
     }
-    off[0] = covered * W * pl.ncomp_out;
+    off[0] = covered * Pb;
     len[0] = pl.out_len - off[0];
     return 1;
 }
@@ -174,7 +183,8 @@ inline void fill_params(const zj_frame_desc* d, const Plan& pl, size_t nframes, 
     p.plain = pl.plain;
     p.clamp_dc = pl.clamp_dc;
     p.edge_rep = pl.edge_rep;
-    p.plane_stride = (long long)d->width * d->height;
+    p.out_pitch = (int)pl.out_pitch;
+    p.plane_stride = (long long)pl.out_pitch * d->height;
     p.regular_px = pl.regular_px;
 }
 

@@ -68,14 +68,15 @@ LAYOUT_HWC, LAYOUT_CHW = 0, 1
 class FrameDesc(C.Structure):  # zj_frame_desc
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("h_max", C.c_uint32),
                 ("v_max", C.c_uint32), ("in_components", C.c_uint32), ("out_colorspace", C.c_int32),
-                ("qt", (C.c_int32 * 64) * 3), ("flags", C.c_uint32), ("out_layout", C.c_uint32)]
+                ("qt", (C.c_int32 * 64) * 3), ("flags", C.c_uint32), ("out_layout", C.c_uint32),
+                ("out_pitch", C.c_uint32)]
 
     @classmethod
-    def make(cls, width, height, h_max, v_max, in_components, out_colorspace, qts, flags=0, out_layout=0):
+    def make(cls, width, height, h_max, v_max, in_components, out_colorspace, qts, flags=0, out_layout=0, out_pitch=0):
         d = cls()
         d.width, d.height, d.h_max, d.v_max = width, height, h_max, v_max
         d.in_components, d.out_colorspace = in_components, int(out_colorspace)
-        d.flags, d.out_layout = int(flags), int(out_layout)
+        d.flags, d.out_layout, d.out_pitch = int(flags), int(out_layout), int(out_pitch)
         for c in range(3):
             q = np.asarray(qts[min(c, len(qts) - 1)], np.int32).reshape(64)
             C.memmove(d.qt[c], q.ctypes.data, 256)
