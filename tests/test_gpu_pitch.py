@@ -149,3 +149,34 @@ def test_padded_rows_batches_scattered_strided_and_multi(zj, synth):
         for b in bufs:
             ctx.device_free(b)
         ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["hwc", "chw", "gray", "rgba"])
+@pytest.mark.parametrize("padded", [False, True])
+def test_tensor_views_of_the_output(zj, synth, kind, padded):
+    """zune-jpeg_amd/tensors.py: the decoded bytes as [N, H, W, C] / [N, 3, H, W] / [N, H, W] uint8 tensors, tight or strided
+    over a padded pitch; .contiguous() of the padded view is the tight tensor"""
+    import torch
+    tz = importlib.import_module("zune-jpeg_amd.tensors")
+    ctx = zj.Context(zj.BACKEND_HIP, 0)
+    try:
+        w, h, n = 2500, 70, 3
+        dev = torch.device("cuda", 0)
+        out_cs, layout, flags = {"hwc": (oc.RGB, 0, 0), "chw": (oc.RGB, 1, 0), "gray": (oc.GRAYSCALE, 0, 0), "rgba": (oc.RGBA, 0, 0)}[kind]
+        frames = [synth.make_frame(w, h, 2, 2, 3, seed=21, frame_index=i) for i in range(n)]
+        qts = frames[0][1]
+        d = zj.FrameDesc.make(w, h, 2, 2, 3, out_cs, qts, out_layout=layout)
+        if padded:
+            d = tz.padded_desc(d)
+            assert d.out_pitch % 128 == 0 and 0 <= d.out_pitch - tz.row_bytes(d) < 128
+        planes = [torch.from_numpy(np.concatenate([fr[0][c] for fr in frames])).to(dev) for c in range(3)]
+        view = tz.decode_to_tensor(ctx, d, planes, n)
+        torch.cuda.synchronize()
+        got = view.contiguous().cpu().numpy()
+        for i, fr in enumerate(frames):
+            rc, exp = expected(synth, w, h, 2, 2, out_cs, flags, layout, qts, fr[0])
+            assert rc == 0
+            shape = {"hwc": (h, w, 3), "chw": (3, h, w), "gray": (h, w), "rgba": (h, w, 4)}[kind]
+            assert got[i].shape == shape and np.array_equal(got[i].reshape(exp.shape), exp), (kind, padded, i)
+    finally:
+        ctx.close()
