@@ -211,8 +211,11 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAV
 // Ragged widths (width % 16 != 0, width >= 64; the reference's medium images are 2500 wide): the packed generation's fast
 // path for every ordinary 16-pixel group of a row, the generic stores for the few groups at the row's end -- one launch,
 // one kernel (zj_device.h: phase_color, RAG).  A family of its own so that the aligned kernels above keep their code.
+#ifndef ZJ_WAVES_PER_SIMD_RAG
+#define ZJ_WAVES_PER_SIMD_RAG ZJ_WAVES_PER_SIMD_PACKED
+#endif
 template <int HS, int VS, int OUT, bool TS>
-__global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), ZJ_WAVES_PER_SIMD_PACKED) void zj_fused_ragged_kernel(const Params p)
+__global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), ZJ_WAVES_PER_SIMD_RAG) void zj_fused_ragged_kernel(const Params p)
 {
     using C = Cfg<HS, VS, OUT>;
     __shared__ __attribute__((aligned(16))) char lds[C::LDS_PACKED];
