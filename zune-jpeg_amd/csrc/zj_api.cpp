@@ -358,9 +358,15 @@ static int decode_device_impl(zj_ctx* c, const zj_frame_desc* d, const Plan& pl,
     if (zero_fill) {
         // rows below the last complete strip are never written by the reference (Q6): zeros
         size_t off[3], len[3];
-        const int nr = uncovered_ranges(d, pl, off, len);
-        for (size_t f = 0; f < nframes; f++)
-            for (int r = 0; r < nr; r++) ZJ_HIP(c, hipMemsetAsync(d_out + f * ostride + off[r], 0, len[r], s));
+        ZeroRows z;
+        z.nr = uncovered_ranges(d, pl, off, len);
+        for (int r = 0; r < z.nr; r++) { z.off[r] = off[r]; z.len[r] = len[r]; }
+        z.frame_stride = (long long)ostride;
+        for (size_t f0 = 0; z.nr && f0 < nframes; f0 += 16384) { // (grid.y <= 65535)
+            z.out = d_out + f0 * ostride;
+            z.nframes = (int)(nframes - f0 < 16384 ? nframes - f0 : 16384);
+            ZJ_HIP(c, launch_zero_rows(z, s));
+        }
     }
 #if defined(ZJ_ABLATION)
     // Experiment of round 4, diagnostic build only: ONE frame cut into ZJ_SPLIT strip ranges (strips
@@ -418,8 +424,13 @@ static int decode_frames_device_impl(zj_ctx* c, const zj_frame_desc* d, const Pl
         Params p;
         fill_params(d, pl, (size_t)n, nullptr, nullptr, nullptr, nullptr, zero_fill, p);
         set_scatter(p, y, chroma ? cb : nullptr, chroma ? cr : nullptr, out, f0, n);
-        for (int f = 0; f < n; f++)
-            for (int r = 0; r < nr; r++) ZJ_HIP(c, hipMemsetAsync(out[f0 + f] + off[r], 0, len[r], s));
+        if (nr) {
+            ZeroRows z;
+            z.out = nullptr; z.frame_stride = 0; z.nr = nr; z.nframes = n;
+            for (int r = 0; r < nr; r++) { z.off[r] = off[r]; z.len[r] = len[r]; }
+            for (int f = 0; f < n; f++) z.fptr[f] = (uint64_t)(uintptr_t)out[f0 + f];
+            ZJ_HIP(c, launch_zero_rows(z, s));
+        }
         const int rc = launch_params(c, pl, p, s);
         if (rc) return rc;
     }

@@ -222,6 +222,38 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), ZJ_WAVES_PER_SIMD_RAG) void
     fused_body<HS, VS, OUT, GEN_PACKED, true, TS, true>(p, lds);
 }
 
+// Zeros for the rows below a frame's last complete strip (zj_launch.h: ZeroRows).  blockIdx.y = frame * nr + range,
+// blockIdx.x = a 16 KB piece of the range; bytes up to the first 16-byte boundary and after the last one go out singly
+// (the rows of a ragged width start anywhere).
+__global__ __launch_bounds__(256) void zj_zero_rows_kernel(const ZeroRows z)
+{
+    const int fr = (int)blockIdx.y / z.nr, r = (int)blockIdx.y - fr * z.nr;
+    uint8_t* const base = (z.out ? z.out + (long long)fr * z.frame_stride : ZJ_GLOBAL_PTR(uint8_t, z.fptr[fr])) + z.off[r];
+    const unsigned long long len = z.len[r], begin = (unsigned long long)blockIdx.x * 16384ull;
+    if (begin >= len) return;
+    const unsigned n = (unsigned)(len - begin < 16384ull ? len - begin : 16384ull);
+    uint8_t* const p = base + begin;
+    unsigned head = (16u - ((unsigned)reinterpret_cast<uintptr_t>(p) & 15u)) & 15u;
+    if (head > n) head = n;
+    const unsigned nq = (n - head) >> 4, tail = head + (nq << 4);
+    const unsigned tid = threadIdx.x;
+    if (tid < head) p[tid] = 0;
+    const U4 zero = {0, 0, 0, 0};
+    for (unsigned i = tid; i < nq; i += 256) *reinterpret_cast<U4*>(p + head + 16u * i) = zero;
+    if (tail + tid < n) p[tail + tid] = 0;
+}
+
+hipError_t launch_zero_rows(const ZeroRows& z, hipStream_t s)
+{
+    if (z.nr <= 0 || z.nframes <= 0) return hipSuccess;
+    unsigned long long longest = 0;
+    for (int r = 0; r < z.nr; r++) longest = z.len[r] > longest ? z.len[r] : longest;
+    if (longest == 0) return hipSuccess;
+    const dim3 grid((unsigned)((longest + 16383ull) / 16384ull), (unsigned)(z.nframes * z.nr)), block(256);
+    hipLaunchKernelGGL(zj_zero_rows_kernel, grid, block, 0, s, z);
+    return hipGetLastError();
+}
+
 #if defined(ZJ_ABLATION)
 // occupancy probe of tools/occupancy.py (diagnostic build only): extra dynamic LDS per workgroup
 static int g_pad_lds = 0;
