@@ -4,7 +4,8 @@ Soak of the PIXEL path (GPU box): random geometries, sampling modes, output colo
 variants and coefficient statistics through the C ABI against the oracle (oracle/zj_oracle.c), byte for byte, for --seconds
 seconds.  Every case goes through one entry point picked at random: zj_decode_planes_batch (packed host frames),
 zj_decode_frames (host frames as independent allocations), zj_decode_frames_device (device frames at scattered addresses,
-shuffled table order), zj_decode_planes_device_strided (padded device frames), zj_multi_decode_frames (two device slots).  Where the reference panics, the ABI must report ZJ_ERR_PANIC.  Checker
+shuffled table order), zj_decode_planes_device_strided (padded device frames), zj_multi_decode_frames (two device slots); half of the device
+outputs with their rows at a padded pitch (zj_frame_desc.out_pitch).  Where the reference panics, the ABI must report ZJ_ERR_PANIC.  Checker
 infrastructure: the oracle is only the judge here.
 
     python tools/pixel_soak.py --seconds 600 > gpurun_out/pixel_soak.txt
@@ -47,6 +48,8 @@ def decode(zj, ctx, multi, path, d, frames, planes, nframes, rng):
             ptr[f][c] = p
             if c < 3:
                 ctx.h2d(p, per[f][c])
+            elif d.out_pitch:
+                zj.lib().zj_device_memset(ctx.handle, p, 0xAA, nb)   # the padding of a padded pitch must keep this
         order = [int(v) for v in rng.permutation(nframes)]
         try:
             ctx.decode_frames_device(d, [ptr[f][0] for f in order], [ptr[f][1] for f in order], [ptr[f][2] for f in order],
@@ -75,6 +78,8 @@ def decode(zj, ctx, multi, path, d, frames, planes, nframes, rng):
         ctx.h2d(bufs[0], hy)
         ctx.h2d(bufs[1], hc[0])
         ctx.h2d(bufs[2], hc[1])
+        if d.out_pitch:
+            zj.lib().zj_device_memset(ctx.handle, bufs[3], 0xAA, nframes * os_)
         ctx.decode_planes_device_strided(d, nframes, bufs[0], bufs[1], bufs[2], bufs[3], ys, cs, os_)
         ctx.sync()
         raw = np.empty(nframes * os_, np.uint8)
@@ -136,12 +141,29 @@ def main():
             if layout == 1 and rc == 0:
                 e = np.ascontiguousarray(e.reshape(h, w, 3).transpose(2, 0, 1)).reshape(-1)
             exp.append(e)
-        d = zj.FrameDesc.make(w, h, hs, vs, 3, out_cs, qts, flags=flags, out_layout=layout)
+        # device outputs: half of them with their rows at a pitch of the caller's choosing (zj_frame_desc.out_pitch)
+        ncomp = {oc.RGB: 3, oc.GRAYSCALE: 1, oc.YCBCR: 3, oc.RGBA: 4}[out_cs]
+        row = w if layout == 1 else w * ncomp
+        pitch = 0
+        if path in ("frames_device", "strided") and rng.random() < 0.5:
+            fast = w % 16 == 0 and w >= 32
+            pitch = [(row + 127) // 128 * 128, row + (16 * int(rng.integers(0, 12)) if fast else int(rng.integers(0, 200)))][int(rng.integers(0, 2))]
+        d = zj.FrameDesc.make(w, h, hs, vs, 3, out_cs, qts, flags=flags, out_layout=layout, out_pitch=pitch)
         ctx.set_variant(variant)
         planes = [np.concatenate([f[0][c] for f in frames]) for c in range(3)]
-        key = f"{path} {hs}x{vs} out={out_cs} flags={flags} layout={layout} variant={variant} adv={int(adversarial)}"
+        key = f"{path} {hs}x{vs} out={out_cs} flags={flags} layout={layout} variant={variant} adv={int(adversarial)} pitch={pitch}"
         try:
             got = decode(zj, ctx, multi, path, d, frames, planes, nframes, rng)
+            if pitch and not rc_all:   # rows of the padded layout -> the tight bytes; the padding keeps the 0xAA it was given,
+                rows = got.reshape(-1, pitch)   # except in rows the strips never reach (zeroed whole, Q6)
+                pad = rows[:, row:]
+                touched = (pad != 0xAA).any(axis=1)
+                if pad.size and ((pad[touched] != 0).any() or rows[touched][:, :row].any()):
+                    bad.append((key, w, h, "bytes between the rows were written"))
+                    stats["MISMATCH"] += 1
+                    continue
+                got = np.ascontiguousarray(rows[:, :row]).reshape(-1)
+                stats["equal with a padded pitch"] += 0
             if rc_all:
                 bad.append((key, w, h, "the oracle panics, the ABI did not"))
                 stats["MISMATCH"] += 1
@@ -155,6 +177,7 @@ def main():
                 stats["equal"] += 1
                 stats[f"equal {hs}x{vs}"] += 1
                 stats[f"equal via {path}"] += 1
+                stats["equal with a padded pitch"] += 1 if pitch else 0
         except zj.ZjError as e:
             if rc_all and e.status == -5:
                 stats["both panic"] += 1
