@@ -19,10 +19,13 @@ def main():
     ctx = zj.Context(zj.BACKEND_HIP, 0)
     side = torch.cuda.Stream(device=dev)
     B = int(os.environ.get("ZJ_RAGGED_B", "32"))
+    MODES = os.environ.get("ZJ_RAGGED_MODES", "420,444,422").split(",")
     PITCH = int(os.environ.get("ZJ_RAGGED_PITCH", "0"))  # e.g. 128: output rows at the next multiple of 128 bytes
     sizes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(2500, 1786), (2512, 1786), (4090, 4096), (4096, 4096)]
     for (w, h) in sizes:
         for name, (hs, vs), bpp in (("420", (2, 2), 6.0), ("444", (1, 1), 9.0), ("422", (2, 1), 7.0)):
+            if name not in MODES:
+                continue
             nb = B if w * h < 8e6 else (32 if w * h < 12e6 else 16)
             pe = [synth.plane_blocks(w, h, hs, vs, c)[0] * synth.plane_blocks(w, h, hs, vs, c)[1] * 64 for c in range(3)]
             pl = [torch.empty(nb * n, dtype=torch.int16, device=dev) for n in pe]
