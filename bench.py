@@ -177,7 +177,7 @@ def e2e_pinned(zj, ctx, desc, d_planes, plane_elems, frame_out, golden_sums=None
 
 def from_files(zj, ctx, size=4096, batch=16, reps=4):
     """Never `value`: whole 4096x4096 4:2:0 q90 JPEG FILES -> RGB left in HBM, Huffman decoding on the device too
-    (zj_decoder_prepare on one host thread, zj_decoder_finish_pixels_batch in batches of 16), and the same
+    (DESIGN_ENTROPY.md; zj_decoder_prepare on one host thread, zj_decoder_finish_pixels_batch in batches of 16), and the same
     files with the CPU walker in front of the pixel kernel.  None if anything is missing (Pillow writes the files)."""
     try:
         sys.path.insert(0, os.path.join(ROOT, "tools"))

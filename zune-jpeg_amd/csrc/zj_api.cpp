@@ -964,7 +964,7 @@ bool scan_check(ScanJob& j, int launched)
 } // namespace
 
 // The scans of up to ZJ_SCAN_BATCH_MAX files as ONE launch per phase (blockIdx.y = file): a file's entropy kernels are
-// latency-bound at under half a wave per SIMD, several at once cost hardly more than one.
+// latency-bound at under half a wave per SIMD (DESIGN_ENTROPY.md), several at once cost hardly more than one.
 //   Synchronisation rounds are launched ahead and turn into no-ops once one of them changed nothing; a look at the
 // counters costs a stream synchronisation, so it happens once, after the pixels.  A scan whose last planned round still
 // changed something gets more rounds on its own (looking after each group), has what its premature write pass
