@@ -26,6 +26,12 @@ for k, v in sorted(rows.items()):
         print(f"<{hs},{vs},{names[o]:5s},packed,rag ,{'staged' if t else 'direct'}>".ljust(40),
               f"{v.get('VGPRs', -1):4d} {v.get('ScratchSize', -1):7d} {v.get('LDS', -1):6d} {v.get('Occupancy', -1):4d}")
         continue
+    sm = re.search(r"zj_fused_seam_kernelILi(\d)ELi(\d)ELi(\d)E", k)
+    if sm:  # the seam family: aligned widths whose rows do not start on 128-byte boundaries (staged stores, shared lines written back)
+        hs, vs, o = map(int, sm.groups())
+        print(f"<{hs},{vs},{names[o]:5s},packed,seam,staged>".ljust(40),
+              f"{v.get('VGPRs', -1):4d} {v.get('ScratchSize', -1):7d} {v.get('LDS', -1):6d} {v.get('Occupancy', -1):4d}")
+        continue
     if not m:
         continue
     hs, vs, o, g, f, t = map(int, m.groups())

@@ -17,11 +17,26 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 //    write-back, everything else non-temporal (NT must be true)
 // XCD: workgroup -> tile as the product does it (zj_device.h: xcd_order): each XCD takes a contiguous run of tiles, so the
 //    tiles on both sides of a seam meet in ONE L2
-template <int MODE, bool NT, bool XCD>
-__global__ __launch_bounds__(256) void probe(unsigned char* out, int tiles_per_row, int strips, unsigned pitch, long long frame_bytes)
+// LD (second table): 0 no loads; 1 / 2: every workgroup first streams in as many bytes as it writes (24 KB, its tile's
+//    coefficients in the fused kernel) with ordinary / non-temporal loads, folds them into what it stores, and waits a
+//    pseudo-random 0 .. 8 us before its stores -- neighbouring tiles of the fused kernel do not reach their copy-out together
+template <int MODE, bool NT, bool XCD, int LD = 0>
+__global__ __launch_bounds__(256) void probe(unsigned char* out, int tiles_per_row, int strips, unsigned pitch, long long frame_bytes,
+                                             const u4* in = nullptr)
 {
     int bid = blockIdx.x;
     if (XCD && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    u4 acc = {0, 0, 0, 0};
+    if (LD) {
+        const u4* src = in + (size_t)bid * 1536 + threadIdx.x;   // 24 KB per tile
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const u4 x = LD == 2 ? __builtin_nontemporal_load(src + 256 * k) : src[256 * k];
+            acc.x ^= x.x; acc.y ^= x.y; acc.z ^= x.z; acc.w ^= x.w;
+        }
+        const unsigned hsh = ((unsigned)bid * 2654435761u) >> 16;
+        for (unsigned k = hsh % 38u; k > 0; k--) __builtin_amdgcn_s_sleep(8);   // 512 cycles a step
+    }
     const int per_frame = tiles_per_row * strips;
     const int frame = bid / per_frame, rem = bid % per_frame;
     const int strip = rem / tiles_per_row, tile = rem % tiles_per_row;
@@ -29,7 +44,7 @@ __global__ __launch_bounds__(256) void probe(unsigned char* out, int tiles_per_r
     const int w = threadIdx.x >> 6, L = threadIdx.x & 63;
     const unsigned a0 = (unsigned)((unsigned long long)tile_out >> 4);
     const unsigned rho = pitch >> 4;
-    const u4 v = {(unsigned)bid, (unsigned)threadIdx.x, 0x01020304u, 0x05060708u};
+    const u4 v = {(unsigned)bid ^ acc.x, (unsigned)threadIdx.x ^ acc.y, 0x01020304u ^ acc.z, 0x05060708u ^ acc.w};
 #pragma unroll
     for (int round = 0; round < 2; round++) {
 #pragma unroll
@@ -60,17 +75,17 @@ __global__ __launch_bounds__(256) void probe(unsigned char* out, int tiles_per_r
     }
 }
 
-template <int MODE, bool NT, bool XCD>
-static float run(unsigned char* buf, int W, int H, int frames, size_t offset)
+template <int MODE, bool NT, bool XCD, int LD = 0>
+static float run(unsigned char* buf, int W, int H, int frames, size_t offset, const u4* in = nullptr)
 {
     const int tiles = W / 256, strips = H / 32;
     const unsigned pitch = 3u * W;
     const long long fb = (long long)pitch * H;
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
-    for (int i = 0; i < 20; i++) probe<MODE, NT, XCD><<<tiles * strips * frames, 256>>>(buf + offset, tiles, strips, pitch, fb);
+    for (int i = 0; i < 20; i++) probe<MODE, NT, XCD, LD><<<tiles * strips * frames, 256>>>(buf + offset, tiles, strips, pitch, fb, in);
     CHECK(hipEventRecord(a));
     const int reps = 50;
-    for (int i = 0; i < reps; i++) probe<MODE, NT, XCD><<<tiles * strips * frames, 256>>>(buf + offset, tiles, strips, pitch, fb);
+    for (int i = 0; i < reps; i++) probe<MODE, NT, XCD, LD><<<tiles * strips * frames, 256>>>(buf + offset, tiles, strips, pitch, fb, in);
     CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
     float ms; CHECK(hipEventElapsedTime(&ms, a, b));
     CHECK(hipEventDestroy(a)); CHECK(hipEventDestroy(b));
@@ -99,6 +114,23 @@ int main(int argc, char** argv)
         for (int i = 0; i < 8; i++) printf(" %9.0f%s", bytes / (t[i] * 1e-3) / 1e9, i == 1 ? " |" : "");
         printf("\n");
     }
+    // the same with the fused kernel's other half: as many bytes read as written, stores not in step (LD)
+    u4* in; const size_t in_bytes = (size_t)frames * 16 * 128 * 24576;
+    CHECK(hipMalloc(&in, in_bytes)); CHECK(hipMemset(in, 1, in_bytes));
+    printf("\n%-30s %9s %9s %9s | %9s %9s %9s   (GB/s written, as much read; XCD order; loads ordinary | non-temporal; stores 0-8 us out of step)\n",
+           "pitch", "wb", "NT", "128B mix", "wb", "NT", "128B mix");
+    for (int W : widths) {
+        const int Wt = W / 256 * 256;
+        const double bytes = (double)frames * 4096 * 3 * Wt;
+        float t[6];
+        t[0] = run<0, false, true, 1>(buf, W, 4096, frames, 0, in); t[1] = run<0, true, true, 1>(buf, W, 4096, frames, 0, in); t[2] = run<5, true, true, 1>(buf, W, 4096, frames, 0, in);
+        t[3] = run<0, false, true, 2>(buf, W, 4096, frames, 0, in); t[4] = run<0, true, true, 2>(buf, W, 4096, frames, 0, in); t[5] = run<5, true, true, 2>(buf, W, 4096, frames, 0, in);
+        char name[64]; snprintf(name, sizeof name, "3 x %d = %u (%% 128 = %u)", W, 3u * W, 3u * W % 128u);
+        printf("%-30s", name);
+        for (int i = 0; i < 6; i++) printf(" %9.0f%s", bytes / (t[i] * 1e-3) / 1e9, i == 2 ? " |" : "");
+        printf("\n");
+    }
+    CHECK(hipFree(in));
     CHECK(hipFree(buf));
     return 0;
 }

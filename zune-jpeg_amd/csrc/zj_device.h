@@ -62,6 +62,15 @@ typedef uint32_t V4 __attribute__((vector_size(16)));    // the same 16 bytes fo
 #ifndef ZJ_NT
 #define ZJ_NT 4
 #endif
+// 1: aligned widths whose rows do not start on 128-byte boundaries (a pitch or a base that is not a multiple of 128) are
+//    decoded by the SEAM instantiation (4:2:0): the pieces of a 128-byte line that a tile's row segment shares with the
+//    neighbouring tile are stored write-back, so that the L2 puts the two halves together, and only the lines the tile
+//    owns stream out non-temporally (color_copyout; tools/store_probe).  0 (default): the family is not even compiled --
+//    over four boxes it measured between +8 % and -5 % on such frames (profiles/r05_store_probe.txt); the layout that
+//    repairs the seams for good is zj_frame_desc.out_pitch.
+#ifndef ZJ_SEAM_WB
+#define ZJ_SEAM_WB 0
+#endif
 // 1: a colour round that does not fill the workgroup is served by its last wave (Cfg::ROUND_ROT); 0: by its first (A/B knob)
 #ifndef ZJ_ROUND_ROT
 #define ZJ_ROUND_ROT 1
@@ -1255,6 +1264,21 @@ ZJ_DEV void store16(uint8_t* p, const U4& v, const bool staged = false)
 #endif
 }
 
+// A staged 16-byte store whose cache policy is chosen per lane: write-back for a piece of a line shared with another
+// tile, non-temporal otherwise.  Two instructions under complementary exec masks -- written as two C++ stores the compiler
+// merges the arms into ONE store without the nt bit.
+ZJ_DEV void store16_seam(uint8_t* p, const U4& v, const bool shared)
+{
+#if defined(ZJ_EMU)
+    (void)shared;
+    __builtin_memcpy(p, &v, 16);
+#else
+    const V4 t = {v.x, v.y, v.z, v.w};
+    if (shared) asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(t) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(t) : "memory");
+#endif
+}
+
 // 4 pixels -> 12 bytes from UNCLAMPED i16 pairs.  EO arrangement: (e) holds px 0,2  (o) px 1,3.
 ZJ_DEV void pack_rgb4_eo(const RGB2& e, const RGB2& o, uint32_t& d0, uint32_t& d1, uint32_t& d2)
 {
@@ -1706,7 +1730,7 @@ ZJ_DEV void phase_color(const Params& p, const TileId t, const int tid, char* ld
 // Second half of a staged-store round: lane L of a wave stores pieces 64*j + L (j = 0 .. PPI-1) of the 64*PPI pieces
 // its wave staged, i.e. every store instruction writes 1024 contiguous bytes of the tile's rows (row segments of
 // PIECES_PER_ROW pieces), instead of 64 pieces 48 (64) bytes apart.
-template <class C, int OUT, bool RAG = false>
+template <class C, int OUT, bool RAG = false, bool SEAM = false>
 ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid /* logical */, char* lds, const int round, const int hw_wave = -1)
 {
     using LL = typename C::template L<GEN_PACKED>;
@@ -1755,6 +1779,19 @@ ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid /* logi
     // next dword boundary, assembled from its own piece and the first dword of the next one with v_alignbyte_b32 -- every
     // 16-byte store is dword-aligned; the first d bytes of a row segment and the short last piece go out as bytes / dwords
     // from the two lanes at its ends.
+    // Rows whose pitch or start is not a multiple of 128 bytes: a tile's row segment shares its first and last cache line
+    // with the neighbouring tiles (tools/store_probe, profiles/r05_store_probe.txt).  x = byte offset of a piece from the
+    // 128-byte boundary below its row segment's start.
+    // (SEAM: an instantiation of its own, so that frames whose rows do start on line boundaries keep their code; rows of an
+    // aligned width start on 16-byte boundaries, so a piece never lies across two lines)
+    static_assert(!(SEAM && RAG), "the seam form serves aligned widths");
+    uint32_t la0 = 0, lrho = 0, segb = 0;
+    if (SEAM) { la0 = (uint32_t)reinterpret_cast<uintptr_t>(tile_out) & 127u; lrho = row_bytes & 127u; segb = 16u * (uint32_t)(PPI * nvg); }
+    const bool seams = SEAM && (la0 | lrho) != 0;          // workgroup-uniform; segb = bytes of this tile's row segment
+    auto shared_line = [&](const int j) {
+        const uint32_t A = (la0 + (uint32_t)mm[j] * lrho) & 127u, ls = (A + 16u * (uint32_t)cc[j]) & ~127u;
+        return ls < A || ls + 128u > A + segb;
+    };
     if (RAG) {
         const uint32_t a0 = (uint32_t)reinterpret_cast<uintptr_t>(tile_out) & 3u, rho = row_bytes & 3u;
         if ((a0 | rho) != 0) { // workgroup-uniform
@@ -1790,6 +1827,11 @@ ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid /* logi
         U4 v[PPI];
 #pragma unroll
         for (int j = 0; j < PPI; j++) v[j] = *reinterpret_cast<const U4*>(src[j]);
+        if (SEAM && seams) {
+#pragma unroll
+            for (int j = 0; j < PPI; j++) store16_seam(tile_out + off[j], v[j], shared_line(j));
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < PPI; j++) store16(tile_out + off[j], v[j], true);
         return;
@@ -1798,6 +1840,7 @@ ZJ_DEV void color_copyout(const Params& p, const TileId t, const int tid /* logi
 #pragma unroll
     for (int j = 0; j < PPI; j++) {
         const bool ok = PPI * item0 + 64 * j + L < PPI * C::NITEMS && cc[j] < PPI * nvg && mm[j] < rows_left && cc[j] != never;
+        if (SEAM && ok && seams) { store16_seam(tile_out + off[j], *reinterpret_cast<const U4*>(src[j]), shared_line(j)); continue; }
         if (ok) store16(tile_out + off[j], *reinterpret_cast<const U4*>(src[j]), true);
     }
 ragged_tail:
@@ -1839,6 +1882,19 @@ inline bool ts_eligible(const Params& p, const int out, const bool fast, const b
     for (int m = 0; m < C::SH; m++)
         if ((m * C::NGRP + nvg_last - 1) % 64 == 0) return false;
     return true;
+}
+
+// Does this launch take the SEAM instantiation (color_copyout)?  4:2:0 (256-pixel tiles: the seams are densest there; the
+// 512-pixel tiles of 4:4:4 and the 16-row tiles of 4:2:2 measured 0 .. -3 %), staged stores, and rows that do not start on
+// 128-byte boundaries: the pitch, the first frame, the distance between frames, or any frame of a scattered launch.
+template <class C>
+inline bool seam_launch(const Params& p)
+{
+    if (!ZJ_SEAM_WB || C::YBR != 4) return false;
+    if (p.out_pitch & 127) return true;
+    if (p.y != nullptr) return (((uintptr_t)p.out | (uintptr_t)p.out_frame_stride) & 127) != 0;
+    for (int f = 0; f < SCATTER_MAX; f++) if (p.fptr[f][3] & 127) return true;
+    return false;
 }
 
 } // namespace zj

@@ -94,7 +94,7 @@ __device__ __forceinline__ void pin_head(const Params& p)
 }
 
 // the body of both kernel families: zj_fused_kernel (RAG = false) and zj_fused_ragged_kernel (GEN_PACKED, FAST, RAG)
-template <int HS, int VS, int OUT, int GEN, bool FAST, bool TS, bool RAG>
+template <int HS, int VS, int OUT, int GEN, bool FAST, bool TS, bool RAG, bool SEAM = false>
 __device__ __forceinline__ void fused_body(const Params& p, char* lds)
 {
     using C = Cfg<HS, VS, OUT>;
@@ -188,7 +188,7 @@ __device__ __forceinline__ void fused_body(const Params& p, char* lds)
             if (round == 0 && ZJ_ABL(ZJ_PDBG(p), 128)) { ZJ_USE(io.s0.x ^ io.s0.y ^ io.s0.z ^ io.s0.w ^ io.s1.x ^ io.s1.y ^ io.s1.z ^ io.s1.w ^ io.s2.x ^ io.s2.y ^ io.s2.z ^ io.s2.w); return; } // ... after round 0's filters, colour math, packing
             stage_item<C>(io, ltid, lds, round, hw);
             ZJ_WAVE_FENCE();
-            color_copyout<C, OUT, RAG>(p, t, ltid, lds, round, hw);
+            color_copyout<C, OUT, RAG, SEAM>(p, t, ltid, lds, round, hw);
             ZJ_WAVE_FENCE();
             if (round == 0 && ZJ_ABL(ZJ_PDBG(p), 256)) return; // ... after round 0's staging and stores
         }
@@ -211,6 +211,17 @@ __global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), (GEN == GEN_PACKED ? ZJ_WAV
 // Ragged widths (width % 16 != 0, width >= 64; the reference's medium images are 2500 wide): the packed generation's fast
 // path for every ordinary 16-pixel group of a row, the generic stores for the few groups at the row's end -- one launch,
 // one kernel (zj_device.h: phase_color, RAG).  A family of its own so that the aligned kernels above keep their code.
+// Aligned widths whose rows do not start on 128-byte boundaries (zj_device.h: seam_launch, color_copyout SEAM): the packed
+// generation's fast path with staged stores, the lines shared between neighbouring tiles written back.  A family of its
+// own for the same reason as the ragged one.
+template <int HS, int VS, int OUT>
+__global__ __launch_bounds__((Cfg<HS, VS, OUT>::NT), ZJ_WAVES_PER_SIMD_PACKED) void zj_fused_seam_kernel(const Params p)
+{
+    using C = Cfg<HS, VS, OUT>;
+    __shared__ __attribute__((aligned(16))) char lds[C::LDS_PACKED];
+    fused_body<HS, VS, OUT, GEN_PACKED, true, C::TSCAP, false, C::TSCAP>(p, lds);
+}
+
 #ifndef ZJ_WAVES_PER_SIMD_RAG
 #define ZJ_WAVES_PER_SIMD_RAG ZJ_WAVES_PER_SIMD_PACKED
 #endif
@@ -297,7 +308,9 @@ static hipError_t launch_fused_t(const Params& p, int variant, int fast, hipStre
         if (fast) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, GEN_WIDE, true, false>), grid, block, dyn, s, p);
         else hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, GEN_WIDE, false, false>), grid, block, dyn, s, p);
     } else if (!fast) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, GEN_PACKED, false, false>), grid, block, dyn, s, p);
-    else if (ts && TSC) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, GEN_PACKED, true, TSC>), grid, block, dyn, s, p);
+    else if (ts && TSC && seam_launch<C>(p)) {
+        if constexpr (ZJ_SEAM_WB != 0 && C::YBR == 4 && TSC) hipLaunchKernelGGL((zj_fused_seam_kernel<HS, VS, OUT>), grid, block, dyn, s, p); // (the only shapes seam_launch admits)
+    } else if (ts && TSC) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, GEN_PACKED, true, TSC>), grid, block, dyn, s, p);
     else hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, GEN_PACKED, true, false>), grid, block, dyn, s, p);
     return hipGetLastError();
 }
@@ -348,6 +361,8 @@ int fused_slots_per_cu(int hs, int vs, int out, int variant, int fast, const Par
 
 template <int HS, int VS, int OUT>
 static bool ts_ok_t(const Params& p, int fast) { return ts_eligible<Cfg<HS, VS, OUT>>(p, OUT, fast != 0); }
+template <int HS, int VS, int OUT>
+static bool seam_t(const Params& p) { return seam_launch<Cfg<HS, VS, OUT>>(p); }
 
 const char* fused_kernel_name(int hs, int vs, int out, int variant, int fast, const Params& p)
 {
@@ -363,7 +378,10 @@ const char* fused_kernel_name(int hs, int vs, int out, int variant, int fast, co
 #undef ZJ_CASE
     int gen; bool ts;
     pick(variant, out, fast != 0, ok || (fast == 2 && (out == OUT_RGB || out == OUT_YCBCR || out == OUT_RGBA)), gen, ts);
-    if (fast == 2 && gen == GEN_PACKED) snprintf(b, 112, "void zj::zj_fused_ragged_kernel<%d, %d, %d, %s>(zj::Params)", hs, vs, out, ts ? "true" : "false");
+    bool seam = false;
+    if (fast == 1 && ts && hs == 2 && vs == 2) seam = out == OUT_RGB ? seam_t<2, 2, OUT_RGB>(p) : (out == OUT_YCBCR ? seam_t<2, 2, OUT_YCBCR>(p) : seam_t<2, 2, OUT_RGBA>(p));
+    if (seam) snprintf(b, 112, "void zj::zj_fused_seam_kernel<%d, %d, %d>(zj::Params)", hs, vs, out);
+    else if (fast == 2 && gen == GEN_PACKED) snprintf(b, 112, "void zj::zj_fused_ragged_kernel<%d, %d, %d, %s>(zj::Params)", hs, vs, out, ts ? "true" : "false");
     else snprintf(b, 112, "void zj::zj_fused_kernel<%d, %d, %d, %d, %s, %s>(zj::Params)", hs, vs, out, gen, (fast == 1) ? "true" : "false", ts ? "true" : "false");
     return b;
 }
