@@ -75,6 +75,47 @@ __global__ __launch_bounds__(256) void probe(unsigned char* out, int tiles_per_r
     }
 }
 
+// Third table: the SHAPE of what a workgroup writes, at equal bytes (24 KB read as whole lines, 24 KB written non-temporally,
+// XCD order, aligned rows): SEG bytes of each of 24576 / SEG consecutive rows -- 768 x 32 is the 4:2:0 tile, 1536 x 16 a
+// 512-pixel tile half as tall, 24576 x 1 a plain copy.
+template <int SEG>
+__global__ __launch_bounds__(256) void shape_probe(unsigned char* out, const u4* in, int tiles_per_row, unsigned pitch)
+{
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    constexpr int ROWS = 24576 / SEG, PPR = SEG / 16;
+    const int strip = bid / tiles_per_row, tile = bid % tiles_per_row;
+    unsigned char* const tile_out = out + (long long)strip * ROWS * pitch + (long long)SEG * tile;
+    const u4* src = in + (size_t)bid * 1536 + threadIdx.x;
+    u4 v[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) v[k] = src[256 * k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int Q = 256 * k + (int)threadIdx.x;          // piece of the tile, row-major
+        const int m = Q / PPR, cc = Q - PPR * m;
+        __builtin_nontemporal_store(v[k], reinterpret_cast<u4*>(tile_out + (long long)m * pitch + 16 * cc));
+    }
+}
+
+template <int SEG>
+static float run_shape(unsigned char* buf, const u4* in, long long total_bytes)
+{
+    // one "image" whose rows are 12288 bytes (4096 RGB pixels): tiles_per_row = 12288 / SEG (>= 1), rows = total / 12288
+    const unsigned pitch = SEG > 12288 ? SEG : 12288;
+    const int tiles = pitch / SEG;
+    const int nwg = (int)(total_bytes / 24576);
+    hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    for (int i = 0; i < 20; i++) shape_probe<SEG><<<nwg, 256>>>(buf, in, tiles, pitch);
+    CHECK(hipEventRecord(a));
+    const int reps = 50;
+    for (int i = 0; i < reps; i++) shape_probe<SEG><<<nwg, 256>>>(buf, in, tiles, pitch);
+    CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+    float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+    CHECK(hipEventDestroy(a)); CHECK(hipEventDestroy(b));
+    return ms / reps;
+}
+
 template <int MODE, bool NT, bool XCD, int LD = 0>
 static float run(unsigned char* buf, int W, int H, int frames, size_t offset, const u4* in = nullptr)
 {
@@ -129,6 +170,14 @@ int main(int argc, char** argv)
         printf("%-30s", name);
         for (int i = 0; i < 6; i++) printf(" %9.0f%s", bytes / (t[i] * 1e-3) / 1e9, i == 2 ? " |" : "");
         printf("\n");
+    }
+    {
+        const long long total = (long long)frames * 4096 * 12288;
+        const float t[6] = {run_shape<768>(buf, in, total), run_shape<1536>(buf, in, total), run_shape<3072>(buf, in, total),
+                            run_shape<6144>(buf, in, total), run_shape<12288>(buf, in, total), run_shape<24576>(buf, in, total)};
+        printf("\nshape of a workgroup's 24 KB of output (as much read; aligned rows; GB/s read + written):\n");
+        const char* nm[6] = {"768 B x 32 rows (the 4:2:0 tile)", "1536 B x 16 rows", "3072 B x 8 rows", "6144 B x 4 rows", "12288 B x 2 rows", "24576 B contiguous (a copy)"};
+        for (int i = 0; i < 6; i++) printf("  %-36s %9.0f\n", nm[i], 2.0 * total / (t[i] * 1e-3) / 1e9);
     }
     CHECK(hipFree(in));
     CHECK(hipFree(buf));
