@@ -716,6 +716,28 @@ def main():
         ev[3].synchronize()
         dense_ms = ev[2].elapsed_time(ev[3]) / 100
         del dpl
+    # A yardstick from the same box, same minute: a plain device-to-device copy of one launch's bytes (as many read as the
+    # kernel reads, as many written as it writes) by torch's Tensor.copy_, timed like the kernel.  8 TB/s is the pin rate; a
+    # hand-written streaming copy reaches ~6.3 TB/s on this part (MI355X_MICROARCH.md, tools/store_probe), torch's 5.1-5.2
+    # (the fused kernel decodes 1.10 x faster than torch copies the same bytes).  Never `value`, never `frac`'s denominator.
+    copy_gbs = None
+    if not args.child and not args.no_dense_control:
+        try:
+            half = int(B * W * H * bytes_per_px) // 2 // 16 * 16
+            src_t = torch.empty(half, dtype=torch.uint8, device=dev)
+            dst_t = torch.empty(half, dtype=torch.uint8, device=dev)
+            with torch.cuda.stream(side):
+                for _ in range(10):
+                    dst_t.copy_(src_t)
+                ev[2].record(side)
+                for _ in range(30):
+                    dst_t.copy_(src_t)
+                ev[3].record(side)
+            ev[3].synchronize()
+            copy_gbs = 2 * half / (ev[2].elapsed_time(ev[3]) / 30 * 1e-3) / 1e9
+            del src_t, dst_t
+        except Exception:  # noqa: BLE001 -- a yardstick, not the measurement
+            copy_gbs = None
     # configs[1] read literally is ONE 4096x4096 frame per launch: time that shape too, reported beside the batched figure
     one_ms = one_ms_each = one_ms_4s = None
     if not args.no_single_frame:
@@ -898,6 +920,12 @@ def main():
                              "what": "the same 16 frames with coefficient (row 1, column 7) of every block set to 1: no DC-only "
                                      "block, no empty column anywhere; the rate stays within 3 % of the shard's (vs_kernel_ms)"},
                          "valu_issue": valu,
+                         "same_box_copy": None if not copy_gbs else {
+                             "gbs": round(copy_gbs, 1), "kernel_vs_copy": round(achieved / copy_gbs, 4),
+                             "what": "torch's device-to-device copy (Tensor.copy_) of half a launch's algorithmic bytes -- as many read and "
+                                     "written as the kernel reads and writes --, HIP events around 30 copies on the launch stream, same "
+                                     "process: a yardstick from this box beside the 8 TB/s pin rate that `frac` is quoted against (a "
+                                     "hand-written copy, tools/store_probe, reaches 6.2-6.3 TB/s warm)"},
                          "single_frame_launch": None if one_ms is None else {
                              "kernel_ms": round(one_ms, 4), "kernel_ms_single_launch": round(one_ms_each, 4),
                              "megapixels_per_s": round(W * H / 1e6 / (one_ms * 1e-3), 1),

@@ -91,6 +91,8 @@ def test_single_rank_line_has_the_contract_fields():
     assert e["megapixels_per_s"] > 1000 and e["last_frame_matches_golden"] is True
     assert e["pcie_probe"]["duplex_gbs_per_direction"] > 5 and 0 < e["frac_of_duplex_ceiling"] < 1.25, e
     assert rf["scattered_batch"] is None                              # a 16-frame shard has no 16 non-adjacent frames
+    sbc = rf["same_box_copy"]                                         # the yardstick beside the pin rate: a plain copy on this box
+    assert sbc and 2000 < sbc["gbs"] < 8000 and abs(sbc["kernel_vs_copy"] - rf["achieved"] / sbc["gbs"]) < 2e-3
     # configs[2] / configs[3] in the driver's line
     ow = res["other_workloads"]
     for name, bpp in (("444-rgb", 9.0), ("444-gray", 3.0), ("422-rgb", 7.0), ("440-rgb", 7.0)):

@@ -19,7 +19,7 @@ if has test; then
 fi
 if has smoke; then
   echo "== smoke" | tee -a $O/summary.txt
-  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee -a $O/summary.txt
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -6 | tee -a $O/summary.txt
 fi
 if has ubench; then
   echo "== ubench" | tee -a $O/summary.txt
