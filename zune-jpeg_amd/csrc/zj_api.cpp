@@ -358,7 +358,7 @@ static int decode_device_impl(zj_ctx* c, const zj_frame_desc* d, const Plan& pl,
     if (zero_fill) {
         // rows below the last complete strip are never written by the reference (Q6): zeros
         size_t off[3], len[3];
-        ZeroRows z;
+        ZeroRows z{};
         z.nr = uncovered_ranges(d, pl, off, len);
         for (int r = 0; r < z.nr; r++) { z.off[r] = off[r]; z.len[r] = len[r]; }
         z.frame_stride = (long long)ostride;
@@ -425,7 +425,7 @@ static int decode_frames_device_impl(zj_ctx* c, const zj_frame_desc* d, const Pl
         fill_params(d, pl, (size_t)n, nullptr, nullptr, nullptr, nullptr, zero_fill, p);
         set_scatter(p, y, chroma ? cb : nullptr, chroma ? cr : nullptr, out, f0, n);
         if (nr) {
-            ZeroRows z;
+            ZeroRows z{};
             z.out = nullptr; z.frame_stride = 0; z.nr = nr; z.nframes = n;
             for (int r = 0; r < nr; r++) { z.off[r] = off[r]; z.len[r] = len[r]; }
             for (int f = 0; f < n; f++) z.fptr[f] = (uint64_t)(uintptr_t)out[f0 + f];
