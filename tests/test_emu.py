@@ -310,3 +310,59 @@ def test_emulated_out_pitch_rows_are_the_tight_rows(mode, w, synth):
     if w % 16 == 0:
         assert emu_c.decode_planes(f, planes, out_pitch=3 * w + 8)[0] == -1      # aligned kernels: 16-byte rows
     assert emu_c.decode_planes(f, planes, out_pitch=(1 << 20) + 16)[0] == -1
+
+
+def test_random_descriptors_are_decoded_or_refused_never_anything_else(synth):
+    """make_plan (csrc/zj_plan.h, shared by the product and the emulation) over random descriptors, legal and not: sampling
+    factors, colour spaces, flags, layouts, pitches.  Every call returns one of the documented verdicts, an illegal
+    descriptor is never accepted, and whatever is accepted decodes to the rows of the tight layout (which the other tests
+    pin to the oracle)."""
+    import ctypes as C
+    rng = np.random.default_rng(20260)
+    L = emu_c.lib()
+
+    def raw(w, h, hs, vs, out_cs, qts, planes, flags, layout, pitch):
+        d = emu_c.FrameDesc()
+        d.width, d.height, d.h_max, d.v_max, d.in_components, d.out_colorspace = w, h, hs, vs, 3, out_cs
+        for c in range(3):
+            q = np.ascontiguousarray(qts[c], np.int32)
+            C.memmove(d.qt[c], q.ctypes.data, 256)
+        d.flags, d.out_layout, d.out_pitch = flags, layout, pitch
+        cap = (max(pitch if pitch <= (1 << 20) else 0, 4 * w) * h * 3 + 64) if pitch <= (1 << 20) else 64
+        buf = np.full(cap, 0x5C, np.uint8)
+        rc = L.zje_decode_planes(C.byref(d), C.c_size_t(1), C.c_void_p(planes[0].ctypes.data), C.c_void_p(planes[1].ctypes.data),
+                                 C.c_void_p(planes[2].ctypes.data), C.c_void_p(buf.ctypes.data), C.c_int(0))
+        return rc, buf
+
+    seen = {0: 0, -1: 0, -2: 0, -5: 0}
+    for it in range(500):
+        w, h = int(rng.integers(1, 400)), int(rng.integers(1, 80))
+        hs, vs = int(rng.choice([1, 2, 1, 2, 3, 0])), int(rng.choice([1, 2, 1, 2, 4]))
+        out_cs = int(rng.choice([oc.RGB, oc.GRAYSCALE, oc.YCBCR, oc.RGBA, oc.CMYK, oc.YCCK, 9]))
+        flags = int(rng.choice([0, 0, 1, 2, 4, 7, 8, 1 << 20]))
+        layout = int(rng.choice([0, 0, 0, 1, 2]))
+        ncomp = {oc.RGB: 3, oc.GRAYSCALE: 1, oc.YCBCR: 3}.get(out_cs, 4)
+        planar = layout == 1 and out_cs == oc.RGB
+        row = w if planar else w * ncomp
+        pitch = int(rng.choice([0, 0, row, row + 16, (row + 127) // 128 * 128, max(row - 1, 1), row + int(rng.integers(1, 300)), (1 << 20) + 16]))
+        geo = hs in (1, 2) and vs in (1, 2)
+        planes, qts = synth.make_frame(w, h, hs if geo else 1, vs if geo else 1, 3, seed=it)
+        planes = [np.ascontiguousarray(p, np.int16) for p in planes]
+        rc, out = raw(w, h, hs, vs, out_cs, qts, planes, flags, layout, pitch)
+        assert rc in seen, (it, rc, w, h, hs, vs, out_cs, flags, layout, pitch)
+        seen[rc] += 1
+        fast = w % 16 == 0 and w >= 32
+        legal = (geo and out_cs in (oc.RGB, oc.GRAYSCALE, oc.YCBCR, oc.RGBA) and flags in (0, 1, 2, 4, 7) and layout in (0, 1)
+                 and not (layout == 1 and out_cs in (oc.YCBCR, oc.RGBA)) and (pitch == 0 or (row <= pitch <= (1 << 20) and not (fast and pitch % 16))))
+        if not legal:
+            assert rc != 0, (it, w, h, hs, vs, out_cs, flags, layout, pitch)
+            continue
+        if rc != 0:
+            assert rc == -5, (it, rc)      # the reference itself panics on this geometry
+            continue
+        rc0, tight = raw(w, h, hs, vs, out_cs, qts, planes, flags, layout, 0)
+        assert rc0 == 0
+        p_, nrows = pitch or row, h * (3 if planar else 1)
+        assert np.array_equal(out[:nrows * p_].reshape(nrows, p_)[:, :row], tight[:nrows * row].reshape(nrows, row)), (it, w, h, hs, vs, out_cs, flags, layout, pitch)
+        assert (out[:nrows * p_].reshape(nrows, p_)[:, row:] == 0x5C).all()
+    assert seen[0] > 40 and seen[-1] > 40 and seen[-2] > 5, seen
