@@ -180,3 +180,59 @@ def test_tensor_views_of_the_output(zj, synth, kind, padded):
             assert got[i].shape == shape and np.array_equal(got[i].reshape(exp.shape), exp), (kind, padded, i)
     finally:
         ctx.close()
+
+
+def test_random_descriptors_the_gpu_and_the_emulation_agree(zj, synth):
+    """Random descriptors, legal and not (sampling factors, colour spaces, flags, layouts, pitches), through
+    zj_decode_planes_device and through the CPU emulation of the same kernels (tests/emu): the same verdict, and where it is
+    ZJ_OK the same bytes -- padding included."""
+    import emu_c
+    rng = np.random.default_rng(777)
+    ctx = zj.Context(zj.BACKEND_HIP, 0)
+    L = emu_c.lib()
+    verdicts = {}
+    try:
+        for it in range(250):
+            w, h = int(rng.integers(1, 700)), int(rng.integers(1, 100))
+            hs, vs = int(rng.choice([1, 2, 1, 2, 3])), int(rng.choice([1, 2, 1, 2, 4]))
+            out_cs = int(rng.choice([oc.RGB, oc.GRAYSCALE, oc.YCBCR, oc.RGBA, oc.CMYK, 9]))
+            flags = int(rng.choice([0, 0, 1, 2, 4, 7, 8]))
+            layout = int(rng.choice([0, 0, 0, 1, 2]))
+            ncomp = {oc.RGB: 3, oc.GRAYSCALE: 1, oc.YCBCR: 3}.get(out_cs, 4)
+            row = w if (layout == 1 and out_cs == oc.RGB) else w * ncomp
+            pitch = int(rng.choice([0, 0, row, row + 16, (row + 127) // 128 * 128, max(row - 1, 1), row + int(rng.integers(1, 300))]))
+            geo = hs in (1, 2) and vs in (1, 2)
+            planes, qts = synth.make_frame(w, h, hs if geo else 1, vs if geo else 1, 3, seed=1000 + it)
+            planes = [np.ascontiguousarray(p, np.int16) for p in planes]
+            d = zj.FrameDesc.make(w, h, hs, vs, 3, out_cs, qts, flags=flags, out_layout=layout, out_pitch=pitch)
+            cap = max(pitch, 4 * w) * h * 3 + 64
+            # emulation
+            e = emu_c.FrameDesc()
+            C.memmove(C.byref(e), C.byref(d), C.sizeof(e))
+            want = np.full(cap, 0x5C, np.uint8)
+            rc_e = L.zje_decode_planes(C.byref(e), C.c_size_t(1), C.c_void_p(planes[0].ctypes.data), C.c_void_p(planes[1].ctypes.data),
+                                       C.c_void_p(planes[2].ctypes.data), C.c_void_p(want.ctypes.data), C.c_int(1))
+            # GPU
+            bufs = [ctx.device_alloc(max(p.nbytes, 16)) for p in planes] + [ctx.device_alloc(cap)]
+            try:
+                for b, p in zip(bufs, planes):
+                    ctx.h2d(b, p)
+                zj.lib().zj_device_memset(ctx.handle, bufs[3], 0x5C, cap)
+                try:
+                    ctx.decode_planes_device(d, 1, bufs[0], bufs[1], bufs[2], bufs[3])
+                    ctx.sync()
+                    rc_g = 0
+                except zj.ZjError as err:
+                    rc_g = err.status
+                got = np.empty(cap, np.uint8)
+                ctx.d2h(got, bufs[3])
+            finally:
+                for b in bufs:
+                    ctx.device_free(b)
+            assert rc_g == rc_e, (it, rc_g, rc_e, w, h, hs, vs, out_cs, flags, layout, pitch)
+            verdicts[rc_g] = verdicts.get(rc_g, 0) + 1
+            if rc_g == 0:
+                assert np.array_equal(got, want), (it, w, h, hs, vs, out_cs, flags, layout, pitch, np.nonzero(got != want)[0][:5])
+    finally:
+        ctx.close()
+    assert verdicts.get(0, 0) > 30 and verdicts.get(-1, 0) > 20, verdicts
