@@ -20,7 +20,10 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 // LD (second table): 0 no loads; 1 / 2: every workgroup first streams in as many bytes as it writes (24 KB, its tile's
 //    coefficients in the fused kernel) with ordinary / non-temporal loads, folds them into what it stores, and waits a
 //    pseudo-random 0 .. 8 us before its stores -- neighbouring tiles of the fused kernel do not reach their copy-out together
-template <int MODE, bool NT, bool XCD, int LD = 0>
+// PF (fourth table): after its own loads and its wait a workgroup touches one dword of each of the 192 lines that the
+//    workgroup PF launch positions behind it will read (the one that takes over its slot, give or take): a prefetch into
+//    the L2 by the only means gfx950 has, a load whose result nobody waits for
+template <int MODE, bool NT, bool XCD, int LD = 0, int PF = 0>
 __global__ __launch_bounds__(256) void probe(unsigned char* out, int tiles_per_row, int strips, unsigned pitch, long long frame_bytes,
                                              const u4* in = nullptr)
 {
@@ -36,6 +39,15 @@ __global__ __launch_bounds__(256) void probe(unsigned char* out, int tiles_per_r
         }
         const unsigned hsh = ((unsigned)bid * 2654435761u) >> 16;
         for (unsigned k = hsh % 38u; k > 0; k--) __builtin_amdgcn_s_sleep(8);   // 512 cycles a step
+        if (PF) {
+            int nb = (int)blockIdx.x + PF;
+            if (nb < (int)gridDim.x && threadIdx.x < 192) {
+                if (XCD && (gridDim.x & 7) == 0) nb = (nb & 7) * (gridDim.x >> 3) + (nb >> 3);
+                const unsigned* line = reinterpret_cast<const unsigned*>(in + (size_t)nb * 1536) + 32 * threadIdx.x;
+                unsigned dummy;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(dummy) : "v"(line) : "memory");
+            }
+        }
     }
     const int per_frame = tiles_per_row * strips;
     const int frame = bid / per_frame, rem = bid % per_frame;
@@ -116,17 +128,17 @@ static float run_shape(unsigned char* buf, const u4* in, long long total_bytes)
     return ms / reps;
 }
 
-template <int MODE, bool NT, bool XCD, int LD = 0>
+template <int MODE, bool NT, bool XCD, int LD = 0, int PF = 0>
 static float run(unsigned char* buf, int W, int H, int frames, size_t offset, const u4* in = nullptr)
 {
     const int tiles = W / 256, strips = H / 32;
     const unsigned pitch = 3u * W;
     const long long fb = (long long)pitch * H;
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
-    for (int i = 0; i < 20; i++) probe<MODE, NT, XCD, LD><<<tiles * strips * frames, 256>>>(buf + offset, tiles, strips, pitch, fb, in);
+    for (int i = 0; i < 20; i++) probe<MODE, NT, XCD, LD, PF><<<tiles * strips * frames, 256>>>(buf + offset, tiles, strips, pitch, fb, in);
     CHECK(hipEventRecord(a));
     const int reps = 50;
-    for (int i = 0; i < reps; i++) probe<MODE, NT, XCD, LD><<<tiles * strips * frames, 256>>>(buf + offset, tiles, strips, pitch, fb, in);
+    for (int i = 0; i < reps; i++) probe<MODE, NT, XCD, LD, PF><<<tiles * strips * frames, 256>>>(buf + offset, tiles, strips, pitch, fb, in);
     CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
     float ms; CHECK(hipEventElapsedTime(&ms, a, b));
     CHECK(hipEventDestroy(a)); CHECK(hipEventDestroy(b));
@@ -170,6 +182,18 @@ int main(int argc, char** argv)
         printf("%-30s", name);
         for (int i = 0; i < 6; i++) printf(" %9.0f%s", bytes / (t[i] * 1e-3) / 1e9, i == 2 ? " |" : "");
         printf("\n");
+    }
+    {
+        // fourth table: the desynchronised read + write pattern of the second table (aligned rows, ordinary loads, non-temporal
+        // stores) with a prefetch of the slot's next occupant
+        const int W = 4096;
+        const double bytes = (double)frames * 4096 * 3 * W;
+        const float t[5] = {run<0, true, true, 1, 0>(buf, W, 4096, frames, 0, in), run<0, true, true, 1, 1024>(buf, W, 4096, frames, 0, in),
+                            run<0, true, true, 1, 2048>(buf, W, 4096, frames, 0, in), run<0, true, true, 1, 3072>(buf, W, 4096, frames, 0, in),
+                            run<0, true, true, 1, 4096>(buf, W, 4096, frames, 0, in)};
+        printf("\nprefetch of the slot's next occupant (GB/s read + written; loads, then 0-8 us, then stores; 8 workgroups per CU = 2048 slots):\n");
+        const char* nm[5] = {"none", "1024 launch positions ahead", "2048", "3072", "4096"};
+        for (int i = 0; i < 5; i++) printf("  %-32s %9.0f\n", nm[i], 2.0 * bytes / (t[i] * 1e-3) / 1e9);
     }
     {
         const long long total = (long long)frames * 4096 * 12288;
