@@ -32,3 +32,24 @@ def test_shard_frames_example(tmp_path):
     r = subprocess.run([exe, "5", "528", "72"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert "5 frames of 528x72 decoded over" in r.stdout and "status 0" in r.stdout, r.stdout
+
+
+@pytest.mark.parametrize("entropy", ["cpu", "gpu"])
+def test_decode_file_example_writes_the_pixels_the_python_path_gives(tmp_path, entropy):
+    """examples/decode_file.c on the reference's own test image (a copy under tests/golden/): the PPM's payload equals
+    Decoder.decode_buffer of the same file, with the Huffman stage on the CPU and on the device"""
+    import importlib
+    import numpy as np
+    zj = importlib.import_module("zune-jpeg_amd")
+    exe = build("decode_file", tmp_path)
+    src = os.path.join(ROOT, "tests", "golden", "test-baseline.jpg")
+    ppm = str(tmp_path / "out.ppm")
+    r = subprocess.run([exe, src, ppm] + (["gpu"] if entropy == "gpu" else []), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    raw = open(ppm, "rb").read()
+    assert raw.startswith(b"P6\n")
+    header_end = 0
+    for _ in range(3):                      # "P6", "W H", "255"
+        header_end = raw.index(b"\n", header_end) + 1
+    want = zj.Decoder().decode_buffer(open(src, "rb").read())
+    assert np.array_equal(np.frombuffer(raw[header_end:], np.uint8), want)
