@@ -152,6 +152,63 @@ UB_KERNEL_BODY(ub_grp_mad2_add2, I_MAD24V(%0) I_MAD24V(%1) I_ADD(%2) I_ADD(%3) I
 UB_KERNEL_BODY(ub_grp_mad1_add1_indep, I_MAD24V(%0) I_ADD(%1) I_MAD24V(%2) I_ADD(%3) I_MAD24V(%4) I_ADD(%5) I_MAD24V(%6) I_ADD(%7) I_MAD24V(%1) I_ADD(%0) I_MAD24V(%3) I_ADD(%2) I_MAD24V(%5) I_ADD(%4) I_MAD24V(%7) I_ADD(%6))
 UB_KERNEL_BODY(ub_grp_mad1_add3, I_MAD24V(%0) I_ADD(%1) I_ADD(%2) I_ADD(%3) I_MAD24V(%4) I_ADD(%5) I_ADD(%6) I_ADD(%7) I_MAD24V(%1) I_ADD(%0) I_ADD(%2) I_ADD(%3) I_MAD24V(%5) I_ADD(%4) I_ADD(%6) I_ADD(%7))
 
+// round 5: what does a select cost?  (v_cndmask_b32_e32 on an untouched vcc measured 21 cycles in round 1 -- real, or the
+// benchmark's?)  The same 64-instruction loop with a 64-bit lane mask in an SGPR pair as operand %10, vcc written once
+// in front of the loop, and the idioms that could stand in for a select.
+#define UB_KERNEL_M(NAME, INSTR)                                                                       \
+    __global__ __launch_bounds__(256) void NAME(int* out, int iters, int seed)                         \
+    {                                                                                                  \
+        int a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, \
+            a6 = a0 * 17, a7 = a0 * 19;                                                                \
+        int k = __builtin_amdgcn_readfirstlane(seed | 3);                                              \
+        int b = a0 ^ 0x55aa;                                                                           \
+        const unsigned long long m = 0x5a5a33cc0ff0aa55ull ^ (unsigned long long)k;                    \
+        asm volatile("s_mov_b64 vcc, %0" : : "s"(m) : "vcc");                                          \
+        for (int it = 0; it < iters; it++) {                                                           \
+            R8(asm volatile(INSTR(%0) INSTR(%1) INSTR(%2) INSTR(%3) INSTR(%4) INSTR(%5) INSTR(%6) INSTR(%7) \
+                            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) \
+                            : "s"(k), "v"(b), "s"(m) : "vcc");)                                        \
+        }                                                                                              \
+        int acc = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;                                               \
+        if (acc == 0x7fffffff) out[blockIdx.x * blockDim.x + threadIdx.x] = acc;                       \
+    }
+#define I_CND_VCC(r) "v_cndmask_b32_e32 " #r ", " #r ", %9, vcc\n"
+#define I_CND_S64(r) "v_cndmask_b32_e64 " #r ", " #r ", %9, %10\n"
+#define I_CND_S64_K(r) "v_cndmask_b32_e64 " #r ", 0, 1, %10\n"
+#define I_BFI(r) "v_bfi_b32 " #r ", %9, " #r ", %9\n"
+#define I_CMP_CND(r) "v_cmp_gt_i32_e32 vcc, %9, " #r "\nv_cndmask_b32_e32 " #r ", " #r ", %9, vcc\n"
+#define I_CMP_S(r) "v_cmp_gt_i32_e64 s[20:21], %9, " #r "\n"
+UB_KERNEL_M(ub_cnd_vcc, I_CND_VCC)
+UB_KERNEL_M(ub_cnd_s64, I_CND_S64)
+UB_KERNEL_M(ub_cnd_s64k, I_CND_S64_K)
+UB_KERNEL_M(ub_bfi, I_BFI)
+UB_KERNEL_M(ub_cmp_cnd, I_CMP_CND)
+// which use of vcc is the slow one: a second select on the same compare?  a select with another instruction between it
+// and its compare?  a select on a vcc that the scalar unit wrote?
+#define I_CMP_CND2(r) "v_cmp_gt_i32_e32 vcc, %9, " #r "\nv_cndmask_b32_e32 " #r ", " #r ", %9, vcc\nv_cndmask_b32_e32 " #r ", %9, " #r ", vcc\n"
+#define I_CMP_X_CND(r) "v_cmp_gt_i32_e32 vcc, %9, " #r "\nv_add_u32_e32 " #r ", %9, " #r "\nv_cndmask_b32_e32 " #r ", " #r ", %9, vcc\n"
+#define I_CMP_X3_CND(r) "v_cmp_gt_i32_e32 vcc, %9, " #r "\nv_add_u32_e32 " #r ", %9, " #r "\nv_sub_u32_e32 " #r ", " #r ", %9\nv_or_b32_e32 " #r ", %9, " #r "\nv_cndmask_b32_e32 " #r ", " #r ", %9, vcc\n"
+#define I_SVCC_CND(r) "s_mov_b64 vcc, %10\nv_cndmask_b32_e32 " #r ", " #r ", %9, vcc\n"
+#define I_CMP64_CND2(r) "v_cmp_gt_i32_e64 s[20:21], %9, " #r "\nv_cndmask_b32_e64 " #r ", " #r ", %9, s[20:21]\nv_cndmask_b32_e64 " #r ", %9, " #r ", s[20:21]\n"
+UB_KERNEL_M(ub_cmp_cnd2, I_CMP_CND2)
+UB_KERNEL_M(ub_cmp_x_cnd, I_CMP_X_CND)
+UB_KERNEL_M(ub_cmp_x3_cnd, I_CMP_X3_CND)
+UB_KERNEL_M(ub_svcc_cnd, I_SVCC_CND)
+__global__ __launch_bounds__(256) void ub_cmp64_cnd2(int* out, int iters, int seed)
+{
+    int a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    int k = __builtin_amdgcn_readfirstlane(seed | 3);
+    int b = a0 ^ 0x55aa;
+    const unsigned long long m = 0x5a5a33cc0ff0aa55ull ^ (unsigned long long)k;
+    for (int it = 0; it < iters; it++) {
+        R8(asm volatile(I_CMP64_CND2(%0) I_CMP64_CND2(%1) I_CMP64_CND2(%2) I_CMP64_CND2(%3) I_CMP64_CND2(%4) I_CMP64_CND2(%5) I_CMP64_CND2(%6) I_CMP64_CND2(%7)
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                        : "s"(k), "v"(b), "s"(m) : "s20", "s21");)
+    }
+    int acc = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+    if (acc == 0x7fffffff) out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
 // shader-clock probe: cycles (s_memtime) spent by one wave in a fixed spin, to convert ms -> MHz
 __global__ void ub_clock(unsigned long long* out, int iters)
 {
@@ -189,6 +246,12 @@ static const struct { const char* name; ub_fn fn; } UB[] = {
     {"RUNS 2 mad | 2 add (indep)        (x2 instr)", ub_grp_mad2_add2},
     {"RUNS 1 mad | 1 add (indep)        (x2 instr)", ub_grp_mad1_add1_indep},
     {"RUNS 1 mad | 3 add (indep)        (x2 instr)", ub_grp_mad1_add3},
+    {"v_cndmask_b32_e32 v,v,v,vcc (vcc set once)", ub_cnd_vcc}, {"v_cndmask_b32_e64 v,v,v,s[n:n+1]", ub_cnd_s64},
+    {"v_cndmask_b32_e64 v,0,1,s[n:n+1]", ub_cnd_s64k}, {"v_bfi_b32 v,v,v,v", ub_bfi},
+    {"PAIR v_cmp_gt_i32 vcc ; v_cndmask vcc (2 instr)", ub_cmp_cnd},
+    {"v_cmp vcc ; cndmask vcc ; cndmask vcc (3 instr)", ub_cmp_cnd2}, {"v_cmp vcc ; v_add ; cndmask vcc (3 instr)", ub_cmp_x_cnd},
+    {"v_cmp vcc ; add ; sub ; or ; cndmask vcc (5 instr)", ub_cmp_x3_cnd}, {"s_mov vcc ; cndmask vcc (1 VALU)", ub_svcc_cnd},
+    {"v_cmp_e64 s[20:21] ; cndmask_e64 x2 s[20:21] (3 instr)", ub_cmp64_cnd2},
 };
 
 int ubench2_count() { return (int)(sizeof(UB) / sizeof(UB[0])); }
