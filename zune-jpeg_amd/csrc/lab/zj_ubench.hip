@@ -190,6 +190,13 @@ UB_KERNEL_M(ub_cmp_cnd, I_CMP_CND)
 #define I_CMP_X3_CND(r) "v_cmp_gt_i32_e32 vcc, %9, " #r "\nv_add_u32_e32 " #r ", %9, " #r "\nv_sub_u32_e32 " #r ", " #r ", %9\nv_or_b32_e32 " #r ", %9, " #r "\nv_cndmask_b32_e32 " #r ", " #r ", %9, vcc\n"
 #define I_SVCC_CND(r) "s_mov_b64 vcc, %10\nv_cndmask_b32_e32 " #r ", " #r ", %9, vcc\n"
 #define I_CMP64_CND2(r) "v_cmp_gt_i32_e64 s[20:21], %9, " #r "\nv_cndmask_b32_e64 " #r ", " #r ", %9, s[20:21]\nv_cndmask_b32_e64 " #r ", %9, " #r ", s[20:21]\n"
+#define I_DPP_SHR(r) "v_mov_b32_dpp " #r ", %9 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define I_DPP_SHL_SELF(r) "v_mov_b32_dpp " #r ", " #r " row_shl:1 row_mask:0xf bank_mask:0xf\n"
+#define I_DPP_ADD(r) "v_add_u32_dpp " #r ", %9, " #r " row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define I_DS_SWZ(r) "ds_swizzle_b32 " #r ", " #r " offset:swizzle(SWAP,1)\ns_waitcnt lgkmcnt(0)\n"
+UB_KERNEL_M(ub_dpp_shr, I_DPP_SHR)
+UB_KERNEL_M(ub_dpp_shl_self, I_DPP_SHL_SELF)
+UB_KERNEL_M(ub_dpp_add, I_DPP_ADD)
 UB_KERNEL_M(ub_cmp_cnd2, I_CMP_CND2)
 UB_KERNEL_M(ub_cmp_x_cnd, I_CMP_X_CND)
 UB_KERNEL_M(ub_cmp_x3_cnd, I_CMP_X3_CND)
@@ -252,6 +259,7 @@ static const struct { const char* name; ub_fn fn; } UB[] = {
     {"v_cmp vcc ; cndmask vcc ; cndmask vcc (3 instr)", ub_cmp_cnd2}, {"v_cmp vcc ; v_add ; cndmask vcc (3 instr)", ub_cmp_x_cnd},
     {"v_cmp vcc ; add ; sub ; or ; cndmask vcc (5 instr)", ub_cmp_x3_cnd}, {"s_mov vcc ; cndmask vcc (1 VALU)", ub_svcc_cnd},
     {"v_cmp_e64 s[20:21] ; cndmask_e64 x2 s[20:21] (3 instr)", ub_cmp64_cnd2},
+    {"v_mov_b32_dpp v,v row_shr:1", ub_dpp_shr}, {"v_mov_b32_dpp v,v(self) row_shl:1 (dependent)", ub_dpp_shl_self}, {"v_add_u32_dpp v,v,v row_shr:1", ub_dpp_add},
 };
 
 int ubench2_count() { return (int)(sizeof(UB) / sizeof(UB[0])); }
