@@ -239,8 +239,6 @@ def test_decode_planes_ragged_widths(ctx, zj, synth, mode, out_cs, wh):
     P % 16 == 8; where the reference panics the ABI reports ZJ_ERR_PANIC."""
     hs, vs = MODES[mode]
     w, h = wh
-    if w * h > 1_000_000 and (out_cs == oc.YCBCR or mode in ("h", "v")):
-        pytest.skip("large case covered for hv/none x rgb/gray")
     planes, qts = synth.make_frame(w, h, hs, vs, 3, seed=83)
     rc, exp = oc.decode_planes(oc.make_frame(w, h, hs, vs, 3, out_cs, qts), planes)
     d = zj.FrameDesc.make(w, h, hs, vs, 3, out_cs, qts)
@@ -731,3 +729,20 @@ def test_corrected_mode_flags(ctx, zj, synth, mode, flags, out_cs, layout, wh):
         if layout == 1:
             exp = np.ascontiguousarray(exp.reshape(h, w, 3).transpose(2, 0, 1)).reshape(-1)
         assert_same(ctx.decode_planes(d, planes), exp, (mode, flags, out_cs, layout, wh, adversarial))
+
+
+@pytest.mark.parametrize("out_cs", [oc.RGB, oc.GRAYSCALE, oc.YCBCR])
+def test_reference_medium_image_2500x1786_h_sampled(ctx, zj, out_cs):
+    """The reference's medium image (tests/medium_images.rs: 2500x1786, (2,1) sampling; a copy travels under tests/golden/ref):
+    the CPU walker's coefficient planes through the pixel kernels of every variant, every byte against the oracle over the
+    same planes -- a ragged width (2500 = 156 * 16 + 4) on real image content."""
+    data = open(os.path.join(HERE, "golden", "ref", "medium_horiz_samp_2500x1786.jpg"), "rb").read()
+    o = zj.ZuneJpegOptions()
+    o.num_threads = 1
+    desc, planes, info = zj.Decoder(o).decode_coefficients(data)
+    assert (info.width, info.height, info.h_max, info.v_max) == (2500, 1786, 2, 1)
+    qts = list(np.ctypeslib.as_array(desc.qt))
+    rc, exp = oc.decode_planes(oc.make_frame(2500, 1786, 2, 1, 3, out_cs, qts), planes)
+    assert rc == 0
+    d = zj.FrameDesc.make(2500, 1786, 2, 1, 3, out_cs, qts)
+    assert_same(ctx.decode_planes(d, planes), exp, ("medium_horiz_samp_2500x1786.jpg", out_cs))

@@ -261,11 +261,38 @@ size_t zj_out_len(const zj_frame_desc* d)
 }
 
 /* ---- memory helpers ------------------------------------------------------------------------- */
+// ZJ_PINNED_KIND chooses how zj_alloc_pinned gets its memory (an A/B switch: profiles/r06_feeder_ab.txt):
+//   0 hipHostMalloc, portable (the default: the planes of a zj_pool are filled by entropy threads and read by submitter
+//     threads' contexts, possibly on another device)
+//   1 hipHostMalloc, default flags      2 hipHostMalloc, portable | NumaUser (the pages follow the calling thread's policy)
+//   3 page-aligned heap memory, touched by the calling thread, then hipHostRegister'ed (portable)
+//   4 hipHostMalloc, portable | non-coherent
+// Registered blocks are remembered so that zj_free_pinned can undo them.
+namespace {
+std::mutex g_reg_mu;
+std::vector<void*> g_registered;
+}
 void* zj_alloc_pinned(size_t bytes)
 {
     void* p = nullptr;
-    // portable: the planes of a zj_pool are filled by entropy threads and read by submitter threads' contexts
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) return nullptr;
+    int kind = 0;
+    if (const char* e = getenv("ZJ_PINNED_KIND")) kind = atoi(e);
+    if (!bytes) bytes = 1;
+    if (kind == 3) {
+        const size_t len = (bytes + 4095) & ~(size_t)4095;
+        p = aligned_alloc(4096, len);
+        if (!p) return nullptr;
+        for (size_t o = 0; o < len; o += 4096) ((volatile char*)p)[o] = 0; // first touch: the pages land on this thread's node
+        if (hipHostRegister(p, len, hipHostRegisterPortable) != hipSuccess) { (void)hipGetLastError(); free(p); return nullptr; }
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        g_registered.push_back(p);
+        return p;
+    }
+    const unsigned flags = kind == 1 ? hipHostMallocDefault
+                         : kind == 2 ? (hipHostMallocPortable | hipHostMallocNumaUser)
+                         : kind == 4 ? (hipHostMallocPortable | hipHostMallocNonCoherent)
+                                     : hipHostMallocPortable;
+    if (hipHostMalloc(&p, bytes, flags) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return p;
 }
 int zj_set_thread_device(int device)
@@ -275,7 +302,21 @@ int zj_set_thread_device(int device)
     if (device < 0 || device >= n) return ZJ_ERR_ARG;
     return hipSetDevice(device) == hipSuccess ? ZJ_OK : ZJ_ERR_HIP;
 }
-void zj_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
+void zj_free_pinned(void* p)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        for (size_t i = 0; i < g_registered.size(); i++)
+            if (g_registered[i] == p) {
+                g_registered.erase(g_registered.begin() + (long)i);
+                (void)hipHostUnregister(p);
+                free(p);
+                return;
+            }
+    }
+    (void)hipHostFree(p);
+}
 int zj_pointer_device(const void* p)
 {
     if (!p) return ZJ_ERR_ARG;

@@ -15,7 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <emmintrin.h> // _mm_stream_si128: the coefficient planes are written once and read by DMA
+#include <immintrin.h> // _mm_stream_si128 and wider: the coefficient planes are written once and read by DMA
 
 #include <atomic>
 #include <chrono>
@@ -271,9 +271,9 @@ struct PlaneStore {
     {
         if (p && cap >= bytes && pinned == want_pinned) return (int16_t*)p;
         release();
-        const size_t c = bytes + bytes / 8 + 4096;
-        p = want_pinned ? zj_alloc_pinned(c) : malloc(c);
-        if (!p && want_pinned) { p = malloc(c); want_pinned = false; } // no device / no pinned memory left
+        const size_t c = (bytes + bytes / 8 + 4096 + 63) & ~(size_t)63;
+        p = want_pinned ? zj_alloc_pinned(c) : aligned_alloc(64, c); // whole cache lines: the walker's wide stores
+        if (!p && want_pinned) { p = aligned_alloc(64, c); want_pinned = false; } // no device / no pinned memory left
         if (!p) return nullptr;
         cap = c; pinned = want_pinned;
         return (int16_t*)p;
@@ -303,6 +303,7 @@ struct zj_decoder {
     int max_width = 16384, max_height = 16384, max_scans = 64;
     int threads = 4;       // options.rs:33 (default 4): here, restart segments / plane zeroing in parallel
     bool pinned = false;   // coefficient planes in pinned host memory
+    int plane_store = 0;   // how the baseline walker's blocks reach their plane (STORE_*; ZJ_PLANE_STORE)
     int entropy = 0;       // zj_options.entropy: 0 CPU walker, 1 GPU for baseline scans worth it, 2 GPU for every eligible scan
     int sub_bytes = 128;   // sub-sequence size of the GPU entropy stage (ZJ_HUFF_SUB: 16..128, multiple of 16)
     PlaneStore blob_store; // the scan as the GPU entropy stage wants it (zj_huff.h), pinned when the planes are
@@ -566,7 +567,29 @@ inline int16_t* block_at(Comp& cm, int bx, int by) { return cm.coef + ((size_t)b
 // HIST: also keep the history register of the reference's aligned_buffer (BitReader::rhist).  Off in the first decode of an
 // image; a short DC read that would need it returns ZJ_INT_NEED_HIST and decode_all starts over with it on.
 constexpr int ZJ_INT_NEED_HIST = 1000; // internal status, never leaves this file
-template <bool TRACK, bool HIST>
+// How a finished block leaves for its plane (zj_decoder::plane_store; ZJ_PLANE_STORE, profiles/r06_feeder_ab.txt):
+enum { STORE_NT16 = 0,   // assembled in a cached 128-byte buffer, written with eight 16-byte non-temporal stores
+       STORE_PLAIN = 1,  // the same buffer, ordinary stores (the lines are allocated in the cache, read for ownership first)
+       STORE_DIRECT = 2, // cleared and filled in place
+       STORE_NT32 = 3,   // four 32-byte non-temporal stores (AVX)
+       STORE_NT64 = 4 }; // two whole-line non-temporal stores (AVX-512F)
+__attribute__((target("avx"))) void flush_nt32(const int16_t* src, int16_t* dst)
+{
+    for (int i = 0; i < 4; i++) _mm256_stream_si256((__m256i*)dst + i, _mm256_load_si256((const __m256i*)src + i));
+}
+__attribute__((target("avx512f"))) void flush_nt64(const int16_t* src, int16_t* dst)
+{
+    for (int i = 0; i < 2; i++) _mm512_stream_si512((__m512i*)dst + i, _mm512_load_si512((const __m512i*)src + i));
+}
+template <int STORE> inline void flush_block(const int16_t* src, int16_t* dst)
+{
+    if (STORE == STORE_NT16) for (int i = 0; i < 8; i++) _mm_stream_si128((__m128i*)dst + i, _mm_load_si128((const __m128i*)src + i));
+    if (STORE == STORE_PLAIN) for (int i = 0; i < 8; i++) _mm_store_si128((__m128i*)dst + i, _mm_load_si128((const __m128i*)src + i));
+    if (STORE == STORE_NT32) flush_nt32(src, dst);
+    if (STORE == STORE_NT64) flush_nt64(src, dst);
+    // STORE_DIRECT: nothing to move
+}
+template <bool TRACK, bool HIST, int STORE>
 int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, int32_t& dc_pred, int16_t* out, const char** err)
 {
     const Huff& hd = d->dc[cm.td & 3];
@@ -574,11 +597,12 @@ int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, in
     // The block is assembled in a cached 128-byte buffer and leaves with non-temporal stores: the planes (50 MB for a
     // 4096x4096 4:2:0 frame) are written once and read by DMA, so allocating their lines in the cache only costs a
     // read-for-ownership per line.
-    alignas(16) int16_t blk[64];
+    alignas(64) int16_t stack_blk[64];
+    int16_t* const blk = STORE == STORE_DIRECT ? out : stack_blk;
     memset(blk, 0, 128);
     struct Flush {
         const int16_t* src; int16_t* dst;
-        ~Flush() { for (int i = 0; i < 8; i++) _mm_stream_si128((__m128i*)dst + i, _mm_load_si128((const __m128i*)src + i)); }
+        ~Flush() { flush_block<STORE>(src, dst); }
     } flush{blk, out};
     int rbl = br.rbl, rbl0 = HIST ? br.rbl0 : 0; // the reference's bits_left and (HIST) its history (BitReader::rbl, rbl0, rhist),
     uint64_t hist = HIST ? br.rhist : 0;         // in registers through the block
@@ -646,6 +670,26 @@ int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, in
         }
     }
     return ZJ_OK;
+}
+
+// the three instantiations a scan uses, for the decoder's store mode
+struct BlockFns {
+    using Fn = int (*)(const zj_decoder*, BitReader&, const Comp&, int32_t&, int16_t*, const char**);
+    Fn hot, track, hist;
+};
+template <int STORE> BlockFns block_fns_of()
+{
+    return {decode_block_baseline<false, false, STORE>, decode_block_baseline<true, false, STORE>, decode_block_baseline<true, true, STORE>};
+}
+BlockFns block_fns(int store)
+{
+    switch (store) {
+    case STORE_PLAIN: return block_fns_of<STORE_PLAIN>();
+    case STORE_DIRECT: return block_fns_of<STORE_DIRECT>();
+    case STORE_NT32: return block_fns_of<STORE_NT32>();
+    case STORE_NT64: return block_fns_of<STORE_NT64>();
+    default: return block_fns_of<STORE_NT16>();
+    }
 }
 
 // restart marker handling shared by all scan kinds (mcu.rs:386-419)
@@ -770,6 +814,7 @@ int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p,
 {
     BitReader br;
     br.p = p; br.end = end; br.istart = p;
+    const BlockFns fn = block_fns(d->plane_store);
     EoiCut cut;
     cut.eoi = eoi; cut.rowlen = eoi_rowlen(d);
     int32_t pred[3] = {0, 0, 0};
@@ -782,9 +827,7 @@ int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p,
             for (int v = 0; v < cm.v; v++)
                 for (int h = 0; h < cm.h; h++) {
                     int16_t* blk = block_at(cm, mx * cm.h + h, my * cm.v + v);
-                    int rc = d->track_hist ? decode_block_baseline<true, true>(d, br, cm, pred[d->order[ci]], blk, err)
-                           : near_end ? decode_block_baseline<true, false>(d, br, cm, pred[d->order[ci]], blk, err)
-                                      : decode_block_baseline<false, false>(d, br, cm, pred[d->order[ci]], blk, err);
+                    int rc = (d->track_hist ? fn.hist : near_end ? fn.track : fn.hot)(d, br, cm, pred[d->order[ci]], blk, err);
                     if (rc) return rc;
                 }
         }
@@ -827,6 +870,7 @@ int scan_baseline(zj_decoder* d, BitReader& br)
         }
     }
     d->dri_parallel_segments = 0;
+    const BlockFns fn = block_fns(d->plane_store);
     int todo = d->restart_interval ? d->restart_interval : 0x7fffffff;
     EoiCut cut;
     {
@@ -859,9 +903,7 @@ int scan_baseline(zj_decoder* d, BitReader& br)
                     for (int h = 0; h < cm.h; h++) {
                         const char* err = nullptr;
                         int16_t* blk = block_at(cm, mx * cm.h + h, my * cm.v + v);
-                        int rc = d->track_hist ? decode_block_baseline<true, true>(d, br, cm, cm.dc_pred, blk, &err)
-                               : near_end ? decode_block_baseline<true, false>(d, br, cm, cm.dc_pred, blk, &err)
-                                          : decode_block_baseline<false, false>(d, br, cm, cm.dc_pred, blk, &err);
+                        int rc = (d->track_hist ? fn.hist : near_end ? fn.track : fn.hot)(d, br, cm, cm.dc_pred, blk, &err);
                         if (rc) { clear_from(my, mx); return fail(d, rc, err); }
                     }
             }
@@ -1367,6 +1409,11 @@ zj_decoder* zj_decoder_new(const zj_options* opt)
     }
     if (d) {
         if (const char* e = getenv("ZJ_ENTROPY")) d->entropy = atoi(e); // A/B switch for whole applications
+        if (const char* e = getenv("ZJ_PLANE_STORE")) {
+            const int v = atoi(e);
+            const bool ok = v >= 0 && v <= 4 && (v != 3 || __builtin_cpu_supports("avx")) && (v != 4 || __builtin_cpu_supports("avx512f"));
+            if (ok) d->plane_store = v;
+        }
         if (const char* e = getenv("ZJ_HUFF_SUB")) { const int v = atoi(e); if (v >= 16 && v <= zj::HUFF_SUB_MAX && v % 16 == 0) d->sub_bytes = v; }
     }
     return d;
