@@ -303,7 +303,7 @@ struct zj_decoder {
     int max_width = 16384, max_height = 16384, max_scans = 64;
     int threads = 4;       // options.rs:33 (default 4): here, restart segments / plane zeroing in parallel
     bool pinned = false;   // coefficient planes in pinned host memory
-    int plane_store = 0;   // how the baseline walker's blocks reach their plane (STORE_*; ZJ_PLANE_STORE)
+    int plane_store = 2;   // how the baseline walker's blocks reach their plane (STORE_*; ZJ_PLANE_STORE): in place
     int entropy = 0;       // zj_options.entropy: 0 CPU walker, 1 GPU for baseline scans worth it, 2 GPU for every eligible scan
     int sub_bytes = 128;   // sub-sequence size of the GPU entropy stage (ZJ_HUFF_SUB: 16..128, multiple of 16)
     PlaneStore blob_store; // the scan as the GPU entropy stage wants it (zj_huff.h), pinned when the planes are
@@ -594,9 +594,12 @@ int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, in
 {
     const Huff& hd = d->dc[cm.td & 3];
     const Huff& ha = d->ac[cm.ta & 3];
-    // The block is assembled in a cached 128-byte buffer and leaves with non-temporal stores: the planes (50 MB for a
-    // 4096x4096 4:2:0 frame) are written once and read by DMA, so allocating their lines in the cache only costs a
-    // read-for-ownership per line.
+    // Where the block is assembled (STORE): in place in its plane with ordinary stores -- the default since round 6 -- or in a
+    // cached 128-byte buffer that leaves with ordinary or non-temporal stores.  Non-temporal stores were the default through
+    // round 5 (the planes, 50 MB for a 4096x4096 4:2:0 frame, are written once and read by DMA; no read-for-ownership) and
+    // are fine on the build container's Xeon, but on the GPU hosts' EPYC 9575F the pattern "fill a stack buffer, copy it out
+    // with NT stores" runs at 1.4 GB/s (0.7 GB/s from the other socket) against 92 GB/s for a plain NT fill: 9.5 ms instead
+    // of 1.3 ms for the reference's test-baseline.jpg, heap and pinned memory alike (profiles/r06_feeder_ab.txt).
     alignas(64) int16_t stack_blk[64];
     int16_t* const blk = STORE == STORE_DIRECT ? out : stack_blk;
     memset(blk, 0, 128);
