@@ -2,12 +2,12 @@
 //! names follow the reference crate (`Decoder`, `ZuneJpegOptions`, `ColorSpace`, the three fn-pointer types of
 //! `src/decoder.rs:47,56` and `src/components.rs:14`).
 //!
-//! The C side is `include/zjhip.h` (ABI version 7, checked at run time by `Decoder::new_with_options`).  Output bytes equal the reference's *scalar* arms.
+//! The C side is `include/zjhip.h` (ABI version 8, checked at run time by `Decoder::new_with_options`).  Output bytes equal the reference's *scalar* arms.
 #![allow(non_camel_case_types)]
 use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const ZJ_ABI_VERSION: c_int = 7;
+pub const ZJ_ABI_VERSION: c_int = 8;
 pub const ZJ_SCATTER_MAX: usize = 32;
 pub const ZJ_BACKEND_SCALAR: c_int = 0;
 pub const ZJ_BACKEND_AVX2: c_int = 1;
@@ -18,6 +18,8 @@ pub const ZJ_FLAG_PLAIN_TAIL: u32 = 1;
 pub const ZJ_FLAG_CLAMP_DC: u32 = 2;
 pub const ZJ_FLAG_EDGE_REPLICATE: u32 = 4;
 pub const ZJ_FLAG_CORRECTED: u32 = 7;
+/// zj_options.flags only: AC values as the file codes them (the reference cuts some fast-AC values to six bits)
+pub const ZJ_FLAG_FULL_AC_VALUES: u32 = 8;
 pub const ZJ_LAYOUT_HWC: u32 = 0;
 pub const ZJ_LAYOUT_CHW: u32 = 1;
 

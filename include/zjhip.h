@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ZJ_ABI_VERSION 7
+#define ZJ_ABI_VERSION 8
 
 /* libzjhip.so is built with -fvisibility=hidden: the functions declared here are its whole dynamic symbol table */
 #if defined(__GNUC__) || defined(__clang__)
@@ -138,6 +138,13 @@ typedef struct zj_frame_desc {
 #define ZJ_FLAG_CLAMP_DC 2u
 #define ZJ_FLAG_EDGE_REPLICATE 4u
 #define ZJ_FLAG_CORRECTED 7u
+/* zj_options.flags only (the CPU front-end; never passed on to a zj_frame_desc): AC values as the file codes them.  The
+ * reference packs a fast-AC value as `k << 10` into an i16 (src/huffman.rs:251) and reads it back with `>> 10`
+ * (src/bitstream.rs:343,466): a value of size 6..8 whose code and magnitude fit its 9-bit look-ahead (a code of 1..3 bits --
+ * optimised tables, progressive files) keeps six bits, sign-extended: +104 decodes as -24.  The default reproduces that
+ * (the reference's own test-images/test-progressive.jpg: 958 coefficients in 649 of 97 200 blocks); with this flag the
+ * front-end yields the coded values, which is what libjpeg decodes. */
+#define ZJ_FLAG_FULL_AC_VALUES 8u
 #define ZJ_LAYOUT_HWC 0u
 #define ZJ_LAYOUT_CHW 1u
 
@@ -267,7 +274,8 @@ typedef struct zj_options {      /* zero = reference default */
                                     the pixel path is one GPU launch, so they decode restart segments (DRI/RSTn,
                                     baseline) concurrently and clear the planes; 1 = strictly serial */
     int32_t pinned_planes;       /* non-zero: coefficient planes live in pinned host memory (DMA without staging) */
-    uint32_t flags;              /* ZJ_FLAG_* for the pixel path (0 = the reference's bytes), see zj_frame_desc */
+    uint32_t flags;              /* ZJ_FLAG_* for the pixel path (0 = the reference's bytes), see zj_frame_desc;
+                                    + ZJ_FLAG_FULL_AC_VALUES for the front-end itself */
     uint32_t out_layout;         /* ZJ_LAYOUT_HWC (0) or ZJ_LAYOUT_CHW */
     int32_t entropy;             /* where baseline Huffman scans are decoded: ZJ_ENTROPY_CPU (0), ZJ_ENTROPY_GPU (scans of
                                     32 KB and more and 16 bits per block and more on the device, the rest and everything

@@ -163,6 +163,10 @@ _UNZ = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 
         62, 63]
 
 
+def _sext6(v):
+    return ((v & 63) ^ 32) - 32
+
+
 def _extend(x, s):  # huff_extend, src/bitstream.rs:683-687
     return x - (1 << s) + 1 if x < (1 << (s - 1)) else x
 
@@ -180,8 +184,8 @@ def decode_baseline_planes(jpeg_bytes):
     c's whole-image plane [block row][block column][64] int16, natural order, zeros where the walk never went;
     short_reads counts the DC symbols the reference reads with fewer bits than they have (decode_dc refills only below
     16 bits, src/bitstream.rs:278: get_bits() then serves zeros for what is missing and the missing bits are parsed
-    again as the next symbol).  Written for well-formed streams: the fast-AC table (src/bitstream.rs:343-350) yields the
-    same values as the general path there, and runs never pass coefficient 63."""
+    again as the next symbol).  Damaged streams included (round 6): the fast-AC table's rules -- min(pos, 63) against pos & 63
+    once a run passes coefficient 63, size-0 symbols behind short codes, values cut to six bits -- are followed literally."""
     rows, planes, short = _walk(jpeg_bytes, True)
     return planes, short, rows
 
@@ -245,19 +249,36 @@ def _walk(jpeg_bytes, values):
                             r, size = rs >> 4, rs & 15
                             if size:
                                 pos += r
+                                fast = False
                                 if s.last_len + size <= 9:
-                                    # the fast-AC table (src/huffman.rs:186-243, src/bitstream.rs:339-347) holds every
-                                    # code + magnitude that fits the 9 look-ahead bits: ONE drop_bits for both, zeros
-                                    # enter aligned_buffer; only the general path (:350-362) rotates with get_bits
+                                    # the fast-AC table (src/huffman.rs:236-251, src/bitstream.rs:339-347) holds every code +
+                                    # magnitude that fits the 9 look-ahead bits AND whose value fits a byte
+                                    fast = -128 <= _extend(s.peek(size), size) <= 127
+                                if fast:
+                                    # ONE drop_bits for both, zeros enter aligned_buffer; only the general path (:350-362)
+                                    # rotates with get_bits
                                     bits = s.peek(size)
                                     s.drop(size)
                                 else:
                                     bits = s.get(size)
                                 if values:
-                                    blk[_UNZ[pos & 63]] = _extend(bits, size)
+                                    # a damaged stream can push pos past 63: the fast path writes at min(pos, 63) (:343),
+                                    # the general path at pos & 63 (:359)
+                                    # ... and the fast table keeps six bits of the value: `k << 10` into an i16
+                                    # (src/huffman.rs:248), read back with `>> 10` (src/bitstream.rs:343)
+                                    val = _extend(bits, size)
+                                    blk[_UNZ[min(pos, 63) if fast else pos & 63]] = _sext6(val) if fast else val
+                                pos += 1
+                            elif s.last_len <= 9:
+                                # size 0 with a code of up to 9 bits is in the fast table too (src/huffman.rs:217-233): run 0
+                                # (EOB) counts as 63, and ANY other run -- 15 (ZRL) and the 1..14 that are not baseline
+                                # symbols alike -- skips run + 1 coefficients after "writing" a zero
+                                pos += 63 if r == 0 else r
+                                if values:
+                                    blk[_UNZ[min(pos, 63)]] = 0
                                 pos += 1
                             elif r != 15:
-                                break
+                                break  # the general path (:365-367): anything but ZRL ends the block
                             else:
                                 pos += 16
                 n += 1

@@ -61,7 +61,7 @@ def test_no_oracle_in_product_library(zj):
 
 def test_host_only_entry_points(zj):
     L = zj.lib()
-    assert L.zj_abi_version() == 7
+    assert L.zj_abi_version() == 8
     assert L.zj_strerror(0) == b"ok"
     assert b"panic" in L.zj_strerror(-5)
     qts = [np.ones(64, np.int32)] * 3

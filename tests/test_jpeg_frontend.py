@@ -125,7 +125,15 @@ def test_reference_images_vs_pillow(zj, name, prog, scans):
     from PIL import Image
     path = os.path.join(ROOT, "tests", "golden", name)
     data = open(path, "rb").read()
-    desc, planes, info = zj.Decoder().decode_coefficients(data)
+    # libjpeg decodes the values the file codes: ZJ_FLAG_FULL_AC_VALUES.  Without it the front-end gives what the reference
+    # gives -- 958 AC coefficients of the progressive file (in 649 blocks) cut to six bits by its fast-AC table
+    # (src/huffman.rs:251, include/zjhip.h), none in the baseline file, whose standard tables have no short code for size 6
+    o = zj.ZuneJpegOptions()
+    o.flags = zj.FLAG_FULL_AC_VALUES
+    desc, planes, info = zj.Decoder(o).decode_coefficients(data)
+    _, planes_ref, _ = zj.Decoder().decode_coefficients(data)
+    cut = np.nonzero(np.concatenate(planes) != np.concatenate(planes_ref))[0]
+    assert (cut.size, np.unique(cut // 64).size) == ((958, 649) if prog else (0, 0))
     assert (info.width, info.height, info.components, info.progressive, info.scans) == (1920, 1080, 3, prog, scans)
     qts = list(np.ctypeslib.as_array(desc.qt))
     rc, ours = oc.decode_planes(oc.make_frame(1920, 1080, 1, 1, 3, oc.YCBCR, qts), planes)
@@ -432,6 +440,112 @@ def test_short_dc_read_picks_up_stale_rotated_bits(zj, synth):
         w_ = want[0].reshape(-1, 64)
         assert np.array_equal(g, w_), (diff, [int(x) for x in g[:, 0]], [int(x) for x in w_[:, 0]])
         assert int(g[1, 0]) == dc1 and dc1 != -2047   # -2047 = zeros for all eleven bits: what the mask gave at nhist == 64
+
+
+# ---- the reference's fast-AC table, followed to the letter (round 6; src/huffman.rs:204-251, src/bitstream.rs:339-347) ----
+def _hand_made_scan(tabs, blocks, synth, width_blocks=None):
+    """One-component baseline file from symbol lists: blocks = [(dc_diff, [(symbol, value or None), ...]), ...], emitted
+    verbatim (no EOB unless listed) -- streams no encoder writes: runs past coefficient 63, size-0 symbols with a run."""
+    nb = len(blocks) if width_blocks is None else width_blocks
+    out = jpeg_enc._headers(8 * nb, 8 * (len(blocks) // nb), 1, 1, 1, [synth.quant_tables(85)[0]], False, 0, tabs)
+    out += jpeg_enc._sos([0], 0, 63, 0, 0)
+    bw = jpeg_enc.BitWriter()
+    for diff, syms in blocks:
+        s = jpeg_enc._nbits(diff)
+        bw.put(*tabs["dc"]["codes"][s])
+        if s:
+            bw.put(diff if diff >= 0 else diff + (1 << s) - 1, s)
+        for sym, v in syms:
+            bw.put(*tabs["ac"]["codes"][sym])
+            if sym & 15:
+                bw.put(v if v >= 0 else v + (1 << (sym & 15)) - 1, sym & 15)
+    bw.flush()
+    return bytes(out) + bytes(bw.out) + b"\xff\xd9"
+
+
+_DC_LEN = {0: 2, 1: 3, 2: 3, 3: 3, 4: 3, 5: 3, 6: 4, 7: 5, 8: 6, 9: 7, 10: 8, 11: 9}
+
+
+def _model_and_front_end(zj, data, nblocks):
+    want, short, rows = ref_walk.decode_baseline_planes(data)
+    desc, got, info = zj.Decoder(_opts(zj, 1)).decode_coefficients(data)
+    g = np.array(got[0], np.int16).reshape(-1, 64)[:nblocks]
+    w = want[0].reshape(-1, 64)[:nblocks]
+    return g, w
+
+
+@pytest.mark.parametrize("reps", [1, 300])  # 300: tens of KB of scan, decode_mcus_v2 carries them (the last 4 KB go block by block)
+def test_fast_ac_values_keep_six_bits(zj, synth, reps):
+    """The reference packs a fast-AC value as `k << 10` into an i16: a size of 6..8 behind a code short enough for the fast
+    table (code + size <= 9) comes back as its low six bits, sign-extended -- +32 reads as -32, 64 as 0.  Standard tables
+    never get there (size 6 has a 7-bit code); hand-made ones do, and the front-end must give the reference's values."""
+    ac_len = {0x08: 1, 0x07: 2, 0x06: 3, 0x00: 4, 0x01: 5, 0x16: 6, 0x05: 7, 0xF0: 8}
+    tabs = jpeg_enc.canonical_tables(_DC_LEN, ac_len)
+    zz = jpeg_enc.ZIGZAG
+    vals = [32, -32, 33, 63, -63, 64, -64, 100, 127, -127, -128, 128, 255, -255, 31, -31, 17]
+    blocks = []
+    for i in range(0, len(vals), 3):
+        syms = []
+        for v in vals[i:i + 3]:
+            syms.append((jpeg_enc._nbits(v), v))        # run 0: sizes 6, 7, 8 behind 3-, 2-, 1-bit codes; size 5 behind 7 bits
+        syms.append((0x16, 45))                         # run 1, size 6 behind a 6-bit code: 12 bits, the general path
+        syms.append((0x00, None))
+        blocks.append((10 * (i + 1), syms))
+    npat = len(blocks)
+    data = _hand_made_scan(tabs, blocks * reps, synth, npat)
+    g, w = _model_and_front_end(zj, data, npat * reps)
+    assert np.array_equal(g, w), (g[:, :12], w[:, :12])
+    blocks = blocks[:npat]
+    flat = [int(g[b, zz[1 + j]]) for b in range(len(blocks)) for j in range(len(vals[3 * b:3 * b + 3]))]
+    expect = [((v & 63) ^ 32) - 32 if -128 <= v <= 127 and jpeg_enc._nbits(v) >= 6 else v for v in vals]
+    assert flat == expect, (flat, expect)
+    assert flat[0] == -32 and flat[5] == 0 and flat[11] == 128 and flat[14] == 31  # cut / cut / too wide for the table / small
+    assert all(int(g[b, zz[5]]) == 45 for b in range(len(blocks) - 1))            # the general path keeps its value
+
+
+@pytest.mark.parametrize("reps", [1, 300])
+def test_runs_past_coefficient_63(zj, synth, reps):
+    """A damaged stream can push the zig-zag position past 63.  The reference's general path then writes at pos & 63
+    (src/bitstream.rs:359) -- over a low coefficient -- and its fast path at min(pos, 63) (:343); both end the block."""
+    ac_len = {0x01: 2, 0xF1: 3, 0x00: 3, 0xFA: 4, 0x31: 4, 0xF0: 5, 0x0A: 6}
+    tabs = jpeg_enc.canonical_tables(_DC_LEN, ac_len)
+    zz = jpeg_enc.ZIGZAG
+    walk = [(0xF1, 1), (0xF1, -1), (0xF1, 1)]          # k = 1 -> 49 with coefficients at 16, 32, 48
+    fill = [(0x01, 1)] * 8                              # ... -> 57, coefficients at 49..56
+    blocks = [(5, walk + fill + [(0xF1, -1)]),          # fast path (3 + 1 bits): 57 + 15 = 72 -> written at 63
+              (7, walk + fill + [(0xFA, 700)]),         # general path (4 + 10 bits): 72 & 63 = 8 -> over zig-zag 8
+              (-3, walk + fill + [(0x31, 1)]),          # 57 + 3 = 60: nothing special, then an EOB
+              (2, [(0x01, -1), (0x00, None)])]
+    blocks[2][1].append((0x00, None))
+    blocks += [(1, [(0x01, 1)] * 20 + [(0x00, None)])] * 8  # (the reference stops decoding once EOI comes into its reader's view)
+    data = _hand_made_scan(tabs, blocks * reps, synth, len(blocks))
+    g, w = _model_and_front_end(zj, data, len(blocks) * reps)
+    assert np.array_equal(g, w), (g, w)
+    assert int(g[0, 63]) == -1 and int(g[0, zz[8]]) == 0
+    assert int(g[1, zz[8]]) == 700 and int(g[1, 63]) == 0
+    assert int(g[2, zz[60]]) == 1 and int(g[3, zz[1]]) == -1 and int(g[3, 0]) == 11
+
+
+@pytest.mark.parametrize("reps", [1, 300])
+def test_size_zero_symbols_with_a_run(zj, synth, reps):
+    """(run 1..14, size 0) is not a baseline symbol.  Behind a code of up to 9 bits the reference's fast table treats it like
+    ZRL -- it skips run + 1 coefficients (src/huffman.rs:217-233) -- and behind a longer code the general path ends the
+    block (src/bitstream.rs:365-367).  Both, in one file."""
+    ac_len = {0x01: 2, 0x30: 3, 0x00: 3, 0x02: 4, 0xF0: 5, 0x50: 10, 0x11: 6}
+    tabs = jpeg_enc.canonical_tables(_DC_LEN, ac_len)
+    zz = jpeg_enc.ZIGZAG
+    blocks = [(4, [(0x01, 1), (0x30, None), (0x02, -3), (0x00, None)]),      # 1 at k=1, skip 4 (k = 2..5), -3 at k = 6
+              (1, [(0x01, -1), (0x50, None)]),                               # the 10-bit code ends the block ...
+              (1, [(0x02, 2), (0xF0, None), (0x11, 1), (0x00, None)]),       # ... so this is the next block: 2 at 1, 1 at 19
+              (-6, [(0x30, None), (0x30, None), (0x01, 1), (0x00, None)])]   # k = 1 -> 5 -> 9
+    blocks += [(1, [(0x01, 1)] * 20 + [(0x00, None)])] * 8  # (the reference stops decoding once EOI comes into its reader's view)
+    data = _hand_made_scan(tabs, blocks * reps, synth, len(blocks))
+    g, w = _model_and_front_end(zj, data, len(blocks) * reps)
+    assert np.array_equal(g, w), (g, w)
+    assert int(g[0, zz[1]]) == 1 and int(g[0, zz[6]]) == -3 and np.count_nonzero(g[0]) == 3
+    assert int(g[1, zz[1]]) == -1 and np.count_nonzero(g[1]) == 2
+    assert int(g[2, zz[1]]) == 2 and int(g[2, zz[19]]) == 1 and int(g[2, 0]) == 6
+    assert int(g[3, zz[9]]) == 1 and np.count_nonzero(g[3]) == 1  # (the DC is 6 - 6 = 0)
 
 
 def _first_scan_only(data):

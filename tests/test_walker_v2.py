@@ -1,0 +1,92 @@
+"""CPU: the baseline walker's stretch decoder (zj_jpeg.cpp decode_mcus_v2, round 6) against the block-at-a-time decoder it
+replaced on the hot path (ZJ_WALKER_V1=1 keeps every block on decode_block_baseline): same planes, same status, same error
+text -- on intact files of every sampling mode (Pillow's tables and optimised ones, with and without restart intervals, one
+thread and restart segments on several) and on the same files with bits flipped inside the scan, where what comes out is
+the reference's garbage (runs past coefficient 63, bad codes, short DC reads) and must be the same garbage.  The files are
+large enough (tens of KB of scan) for the stretch decoder to carry them: it leaves the scan's last 4 KB to the old code."""
+import importlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def zj():
+    return importlib.import_module("zune-jpeg_amd")
+
+
+def _jpeg(seed, w, h, subsampling, quality, optimize, restart_rows):
+    from PIL import Image, ImageFile
+    ImageFile.MAXBLOCK = max(ImageFile.MAXBLOCK, 4 * w * h)  # (optimize=True needs the whole file in one encoder buffer)
+    rng = np.random.default_rng(seed)
+    small = rng.integers(0, 256, (max(2, h // 16), max(2, w // 16), 3), dtype=np.uint8)
+    img = Image.fromarray(small, "RGB").resize((w, h), Image.BICUBIC)
+    noise = rng.integers(-24, 25, (h, w, 3), dtype=np.int16) * (1 + seed % 3)
+    img = Image.fromarray(np.clip(np.asarray(img).astype(np.int16) + noise, 0, 255).astype(np.uint8), "RGB")
+    b = io.BytesIO()
+    kw = {"restart_marker_rows": restart_rows} if restart_rows else {}
+    img.save(b, "JPEG", quality=quality, subsampling=subsampling, optimize=optimize, **kw)
+    return b.getvalue()
+
+
+def _decode(zj, data, threads, v1):
+    if v1:
+        os.environ["ZJ_WALKER_V1"] = "1"
+    else:
+        os.environ.pop("ZJ_WALKER_V1", None)
+    try:
+        o = zj.ZuneJpegOptions()
+        o.num_threads = threads
+        dec = zj.Decoder(o)
+        try:
+            _, planes, info = dec.decode_coefficients(data)
+            return ("ok", [p.tobytes() for p in planes], (info.width, info.height, info.scans), dec.parallel_segments())
+        except zj.DecodeError as e:
+            return ("error", str(e))
+        finally:
+            dec.close()
+    finally:
+        os.environ.pop("ZJ_WALKER_V1", None)
+
+
+CASES = [(seed, w, h, sub, q, opt, rst)
+         for seed, (w, h) in enumerate([(448, 336), (512, 320), (333, 477), (1024, 160)])
+         for sub in (0, 1, 2)
+         for q, opt, rst in ((35, False, 0), (90, True, 0), (100, False, 2), (97, True, 1))]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"{c[1]}x{c[2]}-s{c[3]}-q{c[4]}{'-opt' if c[5] else ''}{'-rst' if c[6] else ''}" for c in CASES])
+def test_stretch_decoder_equals_block_decoder(zj, case):
+    seed, w, h, sub, q, opt, rst = case
+    data = _jpeg(seed, w, h, sub, q, opt, rst)
+    assert len(data) > 12000  # the stretch decoder gets most of the scan
+    for threads in (1, 4) if rst else (1,):
+        a = _decode(zj, data, threads, v1=False)
+        b = _decode(zj, data, threads, v1=True)
+        # (quality-100 noise can END in an error even undamaged: a long DC symbol read short desynchronises the reference's
+        # reader, tests/test_jpeg_frontend.py -- then both must report the same one)
+        assert a == b and (a[0] == "ok" or q == 100), (case, threads, a[0], b[0])
+    # the same file with damage inside the scan: flipped bits, a byte made 0xFF, a few bytes dropped
+    rng = np.random.default_rng(1000 + seed)
+    sos = data.index(b"\xff\xda")
+    start = sos + 2 + int.from_bytes(data[sos + 2:sos + 4], "big")
+    differing = 0
+    for trial in range(12):
+        d = bytearray(data)
+        at = int(rng.integers(start + 16, len(d) - 5000))
+        kind = trial % 3
+        if kind == 0:
+            d[at] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            d[at] = 0xFF
+            d[at + 1] = [0x00, 0xD9, 0xD3, 0x17][trial % 4]
+        else:
+            del d[at:at + int(rng.integers(1, 4))]
+        d = bytes(d)
+        a = _decode(zj, d, 1, v1=False)
+        b = _decode(zj, d, 1, v1=True)
+        assert a == b, (case, trial, kind, a[0], b[0], a[1] if a[0] == "error" else "", b[1] if b[0] == "error" else "")
+        differing += a[0] == "error" or a[1] != _decode(zj, data, 1, v1=False)[1]
+    assert differing >= 6  # the damage did reach the decoder

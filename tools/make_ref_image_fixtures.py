@@ -58,12 +58,25 @@ def main():
             rec.update(width=w, height=h, components=nc, h_max=int(info.h_max), v_max=int(info.v_max),
                        progressive=int(info.progressive), scans=int(info.scans), restart_interval=int(info.restart_interval),
                        sha256_planes=sha(np.concatenate(planes)))
+            # the same file with ZJ_FLAG_FULL_AC_VALUES: how many coefficients the reference's fast-AC table cuts to six bits
+            # (src/huffman.rs:251; include/zjhip.h) -- only files with 1..3-bit codes for sizes 6..8 have any
+            o2 = zj.ZuneJpegOptions()
+            o2.flags = zj.FLAG_FULL_AC_VALUES
+            dec2 = zj.Decoder(o2)
+            _, planes_full, _ = dec2.decode_coefficients(data)
+            dec2.close()
+            cut = np.nonzero(np.concatenate(planes) != np.concatenate(planes_full))[0]
+            rec["six_bit_cut_coefficients"] = int(cut.size)
+            rec["six_bit_cut_blocks"] = int(np.unique(cut // 64).size)
             for cs_name, cs in (("rgb", oc.RGB), ("gray", oc.GRAYSCALE), ("ycbcr", oc.YCBCR)):   # the three outputs tests/large_images.rs asks for
                 rc, px = oc.decode_planes(oc.make_frame(w, h, info.h_max, info.v_max, nc, cs if nc == 3 else oc.GRAYSCALE, qts), planes)
                 assert rc == 0, (name, rc)
                 rec[f"sha256_{cs_name}"] = sha(px)
                 if cs_name == "rgb" and nc == 3:
                     pil = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"), np.int32)
+                    if cut.size:  # libjpeg decodes the coded values: compare what the front-end gives with the flag
+                        rc, px = oc.decode_planes(oc.make_frame(w, h, info.h_max, info.v_max, nc, cs, qts), planes_full)
+                        assert rc == 0
                     dlt = np.abs(px.reshape(h, w, 3).astype(np.int32) - pil)[:, : max(w - 32, 16)]   # Q5/Q6 live in the last 16 samples
                     rec["pillow_mean_abs_diff"] = round(float(dlt.mean()), 3)
                     rec["pillow_p999_abs_diff"] = int(np.quantile(dlt, 0.999))
@@ -71,7 +84,7 @@ def main():
             dec.close()
             out["files"].append(rec)
             print(f"{rec['file']:60s} {w}x{h} {info.h_max}x{info.v_max} prog={info.progressive} scans={info.scans} dri={info.restart_interval} "
-                  f"pillow mean|d|={rec.get('pillow_mean_abs_diff')}")
+                  f"pillow mean|d|={rec.get('pillow_mean_abs_diff')} six-bit cuts {rec['six_bit_cut_coefficients']} in {rec['six_bit_cut_blocks']} blocks")
     gold = os.path.join(ROOT, "tests", "golden")
     os.makedirs(os.path.join(gold, "ref"), exist_ok=True)
     for f in COPY:

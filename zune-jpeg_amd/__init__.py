@@ -8,7 +8,7 @@ There is NO CPU fallback: if libzjhip.so is missing, or no HIP device is usable,
 Import with importlib.import_module("zune-jpeg_amd") (the directory name carries a hyphen).
 """
 from .host import (  # noqa: F401
-    BACKEND_AVX2, BACKEND_HIP, BACKEND_SCALAR, FLAG_CLAMP_DC, FLAG_CORRECTED, FLAG_EDGE_REPLICATE, FLAG_PLAIN_TAIL, LAYOUT_CHW, LAYOUT_HWC, ColorSpace, Component, Context, DecodeError, Decoder, FrameDesc,
+    BACKEND_AVX2, BACKEND_HIP, BACKEND_SCALAR, FLAG_CLAMP_DC, FLAG_CORRECTED, FLAG_EDGE_REPLICATE, FLAG_FULL_AC_VALUES, FLAG_PLAIN_TAIL, LAYOUT_CHW, LAYOUT_HWC, ColorSpace, Component, Context, DecodeError, Decoder, FrameDesc,
     ENTROPY_CPU, ENTROPY_GPU, ENTROPY_GPU_ALWAYS, HUFF_ST, RETRY_CPU, FileBatchDecoder, ImageInfo, Pool, ZjError,
     ZuneJpegOptions, abi_symbols, choose_idct_func, choose_upsample_func,
     choose_ycbcr_to_rgb_convert_func, device_count, finish_pixels_batch, lib, lib_path, num_components,

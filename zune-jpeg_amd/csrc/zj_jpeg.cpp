@@ -33,6 +33,8 @@ const uint8_t kUnZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 1
                                41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
+constexpr int AC_BITS = 10;
+inline int sext6(int v) { return (int)((unsigned)v << 26) >> 26; }
 struct Huff {
     bool present = false;
     // canonical decoding (T.81 F.2.2.3) with an 9-bit lookahead table
@@ -43,6 +45,18 @@ struct Huff {
     int32_t valoff[17];
     uint8_t vals[256];
     uint8_t nlen[17];      // codes per length, as the DHT segment gave them (for the GPU tables, gpu_table())
+    // The baseline walker's AC table (decode_mcus_v2): one entry per AC_BITS-bit window for every code of up to AC_BITS bits.
+    // Byte fields, each read by its own load (the loop is short of shift ports, not of load ports):
+    //   total   what the entry consumes: code length + magnitude bits (+ the EOB code behind it, see fold); 0 = a longer code,
+    //           see ac_escape()
+    //   idxoff  what to add to the zig-zag position k to index kZZ (which coefficient the value goes to)
+    //   kadv    what the entry adds to k
+    //   len, sz code length and magnitude bits of the (first) symbol
+    //   sx      26 where the reference's fast-AC table keeps only six bits of the value (see fast[] above), else 0
+    // The value itself is computed from the bits (the arithmetic is off the critical path).
+    struct AcEnt { uint8_t total, idxoff, kadv, len, sz, fold, sx, pad; };
+    AcEnt actab[1 << AC_BITS];
+    bool full_values = false; // ZJ_FLAG_FULL_AC_VALUES: fast-AC values are not cut to six bits
     int build(const uint8_t counts[17], const uint8_t* symbols, int nsym, std::string& err)
     {
         memcpy(nlen, counts, 17);
@@ -88,12 +102,95 @@ struct Huff {
             if (!sz || len + sz > 9) continue;
             const int bits = ((i << len) & 511) >> (9 - sz);
             const int v = bits < (1 << (sz - 1)) ? bits - (1 << sz) + 1 : bits; // T.81 F.2.2.1 EXTEND
-            if (v >= -128 && v <= 127) fast[i] = (int16_t)((v * 256) | (run << 4) | (len + sz));
+            // The reference packs the value as `k << 10` into an i16 (src/huffman.rs:248) and reads it back with `>> 10`
+            // (src/bitstream.rs:343): six bits of it survive, sign-extended.  Sizes up to 5 are unharmed; a size of 6..8 behind
+            // a code of 1..3 bits (hand-made or heavily optimised tables only) comes back as sext6(v): 32 -> -32, 64 -> 0.
+            // (ZJ_FLAG_FULL_AC_VALUES: the coded value)
+            if (v >= -128 && v <= 127) fast[i] = (int16_t)(((full_values ? v : sext6(v)) * 256) | (run << 4) | (len + sz));
+        }
+        memset(actab, 0, sizeof actab);
+        p = 0;
+        for (int l = 1; l <= AC_BITS; l++)
+            for (int i = 0; i < counts[l]; i++, p++) {
+                const int base = codes[p] << (AC_BITS - l);
+                for (int j = 0; j < (1 << (AC_BITS - l)); j++) {
+                    const int w = base + j;
+                    actab[w] = ac_entry(vals[p], l, l <= 9 && fast[w >> (AC_BITS - 9)] != 0);
+                    if (full_values) actab[w].sx = 0;
+                }
+            }
+        // A coefficient followed by the end-of-block symbol, both inside the window: one entry for the pair (fold) -- it
+        // consumes both codes and ends the loop (k += 64).  decode_mcus_v2 undoes the second half when the coefficient
+        // itself was the block's last (k reached 64: no EOB follows in the stream).
+        {
+            static_assert(sizeof(AcEnt) == 8, "AcEnt");
+            AcEnt folded[1 << AC_BITS];
+            for (int w = 0; w < (1 << AC_BITS); w++) {
+                const AcEnt e1 = actab[w];
+                folded[w] = e1;
+                if (!e1.total || !e1.sz || e1.total >= AC_BITS) continue;
+                const AcEnt e2 = actab[(w << e1.total) & ((1 << AC_BITS) - 1)];
+                if (!e2.total || e2.sz || e2.kadv != 64 || e2.len > AC_BITS - e1.total) continue;
+                folded[w].total = (uint8_t)(e1.total + e2.len);
+                folded[w].kadv = 64;
+                folded[w].fold = 1;
+            }
+            memcpy(actab, folded, sizeof actab);
         }
         present = true;
         return 0;
     }
+    // The entry of AC symbol `rs` with a code of `len` bits, as src/bitstream.rs:332-372 treats it; ref_fast: the reference
+    // takes it through its fast-AC table (code + magnitude within 9 bits and a value that fits a byte, src/huffman.rs:236-251).
+    //   * a coefficient (size > 0): k += run, the value goes to zig-zag position k, k += 1.  When a damaged stream pushes k
+    //     past 63 the general path writes at k & 63 (:359), the fast path at min(k, 63) (:343): kZZ[k + run] and
+    //     kZZ[128 + k + run] are those two rules.
+    //   * size 0 with a code of up to 9 bits: the reference's fast table has an entry for these too (src/huffman.rs:217-233):
+    //     k += run (63 for run 0: the end of the block), a zero is written at min(k, 63) -- a coefficient that is still zero --
+    //     and k += 1.  So a run of 1..14 with size 0 (not a baseline symbol) SKIPS run + 1 coefficients there.
+    //   * size 0 with a longer code (the general path, :365-371): run 15 skips 16, anything else ends the block.
+    // Zeros "written" for size 0 go to natural position 63, which is zero for as long as the loop runs.
+    static AcEnt ac_entry(int rs, int len, bool ref_fast)
+    {
+        const int run = rs >> 4, sz = rs & 15;
+        int idxoff, kadv;
+        if (sz) { idxoff = ref_fast ? 128 + run : run; kadv = run + 1; }
+        else {
+            idxoff = 192; // k + 192 >= 128 + 63: natural position 63
+            if (len <= 9) kadv = (run == 0 ? 63 : run) + 1;
+            else kadv = run == 15 ? 16 : 64;
+        }
+        AcEnt e;
+        memset(&e, 0, sizeof e);
+        e.total = (uint8_t)(len + sz); e.idxoff = (uint8_t)idxoff; e.kadv = (uint8_t)kadv; e.len = (uint8_t)len; e.sz = (uint8_t)sz;
+        e.sx = ref_fast && sz >= 6 ? 26 : 0;
+        return e;
+    }
+    // a code of more than AC_BITS bits at the top of acc: its entry, or 0 if there is no such code
+    __attribute__((noinline)) AcEnt ac_escape(uint64_t acc) const
+    {
+        const uint32_t code = (uint32_t)(acc >> 48);
+        for (int l = AC_BITS + 1; l <= 16; l++) {
+            const int32_t c = (int32_t)(code >> (16 - l));
+            if (c <= maxcode[l]) return ac_entry(vals[(c + valoff[l]) & 0xff], l, false);
+        }
+        AcEnt none;
+        memset(&none, 0, sizeof none);
+        return none;
+    }
 };
+
+// kZZ[k + entry's offset] -> natural index of the coefficient (Huff::ac_entry)
+struct ZigzagPad {
+    uint8_t t[256];
+    ZigzagPad()
+    {
+        for (int i = 0; i < 128; i++) t[i] = kUnZigzag[i & 63];                         // general path: k & 63
+        for (int i = 128; i < 256; i++) t[i] = kUnZigzag[i - 128 < 63 ? i - 128 : 63];  // fast path: min(k, 63)
+    }
+};
+const ZigzagPad kZZ;
+const uint32_t kSizeMask[16] = {0, 1, 3, 7, 15, 31, 63, 127, 255, 511, 1023, 2047, 4095, 8191, 16383, 32767};
 
 struct BitReader {
     const uint8_t* p;
@@ -395,6 +492,7 @@ int parse_dht(zj_decoder* d, Cursor& c)
         if (c.end - c.p < sum) return fail(d, ZJ_ERR_FORMAT, "Could not read symbols into the buffer");
         std::string e;
         Huff& h = cls == 0 ? d->dc[idx] : d->ac[idx];
+        h.full_values = (d->flags & ZJ_FLAG_FULL_AC_VALUES) != 0;
         if (h.build(counts, c.p, sum, e)) return fail(d, ZJ_ERR_HUFFMAN, e);
         c.p += sum;
         len -= sum;
@@ -630,59 +728,238 @@ int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, in
     for (int k = 1; k < 64;) {
         if (br.nbits < 32) br.fill(); // a code (<= 16 bits) and its magnitude bits (<= 15) without another refill
         if (rbl <= 32) { rbl += 32; if (HIST) rbl0 = rbl; } // the reference's refill before every AC symbol (bitstream.rs:334)
-        const uint32_t look9 = br.peek(9);
-        const int16_t fa = ha.fast[look9];
-        if (fa) { // short code + small value: run, magnitude and sign from one table entry -- in the reference too
-                  // (src/huffman.rs:186-243 fills its fast_ac by the same rule: code + magnitude <= 9 bits), ONE drop_bits
-            k += (fa >> 4) & 15;
-            br.drop(fa & 15);
-            rbl -= fa & 15;
-            if (HIST) hist <<= fa & 15;
-            if (TRACK) br.last_sym = fa & 15;
-            blk[kUnZigzag[k & 63]] = (int16_t)(fa >> 8);
-            k++;
-            continue;
+        // the same table as decode_mcus_v2 (Huff::ac_entry holds the reference's rules), ONE symbol at a time: an entry that
+        // folds a coefficient and the EOB behind it is taken apart again
+        Huff::AcEnt en = ha.actab[br.peek(AC_BITS)];
+        if (!en.total) {
+            en = ha.ac_escape(br.acc);
+            if (!en.total) { br.drop(16); *err = "Bad Huffman code in AC"; return ZJ_ERR_HUFFMAN; }
         }
-        int rs;
-        const uint16_t e = ha.look[look9];
-        if (e) { br.drop(e >> 8); rbl -= e >> 8; if (HIST) hist <<= e >> 8; if (TRACK) br.last_sym = e >> 8; rs = e & 0xff; }
-        else {
-            const int before = br.nbits; // >= 32 here: decode() does not refill, the difference is the code's length
-            rs = br.decode(ha);
-            if (rs < 0) { *err = "Bad Huffman code in AC"; return ZJ_ERR_HUFFMAN; }
-            rbl -= before - br.nbits;
-            if (HIST) hist <<= before - br.nbits;
-            if (TRACK) br.last_sym = before - br.nbits;
-        }
-        const int r = rs >> 4, sz = rs & 15;
+        const int len = en.len, sz = en.sz;
+        br.drop(len);
+        rbl -= len;
+        if (HIST) hist <<= len;
+        if (TRACK) br.last_sym = len;
         if (sz) {
-            k += r;
             const int32_t bits = (int32_t)br.peek(sz);
             br.drop(sz);
             rbl -= sz;
-            if (HIST) hist = (hist << sz) | (uint32_t)bits; // the general path reads the magnitude with get_bits: it rotates back in
+            // the reference's fast-AC path (src/bitstream.rs:339-347) is ONE drop_bits for code and magnitude: zeros enter its
+            // aligned_buffer; the general path reads the magnitude with get_bits, which rotates it back in
+            if (HIST) hist = en.idxoff >= 128 ? hist << sz : (hist << sz) | (uint32_t)bits;
             if (TRACK) br.last_sym += sz;
             // EXTEND (T.81 F.2.2.1) without a branch: values below 2^(sz-1) are negative
-            const int32_t v = bits + ((((bits - (1 << (sz - 1))) >> 31)) & (1 - (1 << sz)));
-            blk[kUnZigzag[k & 63]] = (int16_t)v;
-            k++;
-        } else if (r == 15) {
-            k += 16;
-        } else {
-            break; // EOB
-        }
+            const int32_t v0 = bits + ((((bits - (1 << (sz - 1))) >> 31)) & (1 - (1 << sz)));
+            const int32_t v = (int32_t)((uint32_t)v0 << en.sx) >> en.sx; // (sx: Huff::AcEnt)
+            blk[kZZ.t[k + en.idxoff]] = (int16_t)v;
+            k += (en.idxoff & 127) + 1;
+        } else k += en.kadv; // ZRL, EOB, and the reference's reading of the other size-0 symbols (Huff::ac_entry)
     }
     return ZJ_OK;
 }
 
+// ---- the hot instantiation (no TRACK, no HIST) rewritten in round 6: decode_block_v2 -------------------------------------
+// Same results as decode_block_baseline<false, false, STORE>, block for block and bit for bit (reader state, rbl, error
+// texts); what changed is the shape of the AC loop:
+//   * the reader's accumulator and bit count live in registers through the block;
+//   * ONE table lookup per symbol (Huff::actab: code length, magnitude bits, where the value goes, how far k moves), the
+//     value computed from the bits without a branch; ZRL and EOB are entries like any other, so the loop has one exit;
+//   * the reference's bits_left (rbl) is not followed symbol by symbol: refill-before-every-AC-symbol keeps it in (32, 64]
+//     and congruent to its start minus the bits consumed, so its value after the block follows from the bits the AC symbols
+//     consumed and the length of the last one.
+// 128 bytes of zeros at a 16-byte aligned address with vector stores (gcc turns memset(p, 0, 128) into `rep stos`)
+inline __attribute__((always_inline)) void zero_block(int16_t* p)
+{
+#ifdef __AVX__
+    const __m256i z = _mm256_setzero_si256();
+    for (int i = 0; i < 4; i++) _mm256_storeu_si256((__m256i*)p + i, z);
+#else
+    const __m128i z = _mm_setzero_si128();
+    for (int i = 0; i < 8; i++) _mm_store_si128((__m128i*)p + i, z);
+#endif
+}
+// x << (n & 63) -- the hardware masks the count by itself; written so that the shift can start from the table entry as loaded,
+// without waiting for an `and` (the shift is on the loop's critical path: accumulator -> index -> entry -> accumulator)
+template <bool BMI2> inline __attribute__((always_inline)) uint64_t shl_lo6(uint64_t x, uint32_t n)
+{
+#if defined(__x86_64__)
+    if (BMI2) __asm__("shlx %1, %0, %0" : "+r"(x) : "r"((uint64_t)n));
+    else __asm__("shlq %%cl, %0" : "+r"(x) : "c"(n) : "cc");
+    return x;
+#else
+    return x << (n & 63);
+#endif
+}
+// A stretch of `n` consecutive MCUs starting at MCU `m0` (row-major), the reader's state in registers from the first block to
+// the last.  Stops in front of the first MCU that starts at or behind `stop` (the scan's last 4 KB belong to the TRACK
+// instantiation, see near_end) -- *done tells how many it decoded.  On an error *done is the index (relative to m0) of the MCU
+// that failed.  pred[]: the DC predictors by component.
+template <int STORE, bool BMI2>
+inline __attribute__((always_inline)) int decode_mcus_v2_body(const zj_decoder* d, zj_decoder* dm, BitReader& br, int32_t* pred,
+                                                              long long m0, long long n, const uint8_t* stop, long long* done,
+                                                              const char** err)
+{
+    uint64_t acc = br.acc;
+    int nbits = br.nbits;
+    const uint8_t* p = br.p;
+    int rbl = br.rbl;
+    int rc = ZJ_OK;
+    auto put = [&]() __attribute__((always_inline)) { br.acc = acc; br.nbits = nbits; br.p = p; };
+    auto get = [&]() __attribute__((always_inline)) { acc = br.acc; nbits = br.nbits; p = br.p; };
+    auto refill = [&]() __attribute__((always_inline)) {
+        if (__builtin_expect(!br.marker && br.end - p >= 8, 1)) {
+            uint64_t x;
+            memcpy(&x, p, 8);
+            x = __builtin_bswap64(x);
+            const uint64_t y = ~x;
+            if (__builtin_expect(!((y - 0x0101010101010101ull) & ~y & 0x8080808080808080ull), 1)) { // no 0xFF among them
+                acc |= x >> nbits;
+                p += (63 - nbits) >> 3;
+                nbits |= 56;
+                return;
+            }
+        }
+        put(); br.fill(); get();
+    };
+    const int mcu_x = d->mcu_x;
+    int my = (int)(m0 / mcu_x), mx = (int)(m0 % mcu_x);
+    long long i = 0;
+    for (; i < n; i++) {
+        if (stop && p >= stop) break;
+        for (int ci = 0; ci < d->ns && !rc; ci++) {
+            const int c = d->order[ci];
+            Comp& cm = dm->comps[c];
+            const Huff& hd = d->dc[cm.td & 3];
+            const Huff::AcEnt* tab = d->ac[cm.ta & 3].actab;
+            __asm__("" : "+r"(tab)); // one register for the table: the lookup's address is base + index * 4, nothing to add first
+            for (int v = 0; v < cm.v && !rc; v++)
+                for (int h = 0; h < cm.h; h++) {
+                    int16_t* const out = cm.coef + ((size_t)(my * cm.v + v) * cm.bw + (size_t)(mx * cm.h + h)) * 64;
+                    alignas(64) int16_t stack_blk[64];
+                    int16_t* const blk = STORE == STORE_DIRECT ? out : stack_blk;
+                    zero_block(blk);
+                    if (nbits < 32) refill();
+                    // DC: src/bitstream.rs:264-296
+                    int s, dc_len;
+                    {
+                        const uint16_t e = hd.look[acc >> 55];
+                        if (__builtin_expect(e != 0, 1)) { dc_len = e >> 8; s = e & 0xff; acc <<= dc_len; nbits -= dc_len; }
+                        else {
+                            put();
+                            s = br.decode(hd); // nbits >= 32: no refill in there
+                            dc_len = nbits - br.nbits;
+                            get();
+                        }
+                    }
+                    if (s < 0 || s > 16) { *err = "Bad Huffman code in DC"; rc = ZJ_ERR_HUFFMAN; }
+                    else {
+                        if (rbl < 16) rbl += 32; // bitstream.rs:278
+                        if (__builtin_expect(dc_len + s > rbl, 0) && s) {
+                            put();
+                            bool need_hist = false;
+                            int32_t short_bits = 0;
+                            if (ref_dc_misread(br, rbl, 0, 0, dc_len, s, &short_bits, &need_hist)) {
+                                *err = "short DC read reaches the reader's history";
+                                rc = ZJ_INT_NEED_HIST;
+                            }
+                        }
+                    }
+                    if (!rc) {
+                        // magnitude and EXTEND without a branch (s == 0 gives 0)
+                        const int64_t sgn = (int64_t)acc >> 63;
+                        const uint32_t raw = (uint32_t)((acc >> 1) >> (63 - s));
+                        const int32_t diff = (int32_t)raw - (int32_t)(~(uint32_t)sgn & (uint32_t)((1ull << s) - 1));
+                        acc <<= s; nbits -= s; // s <= 16 <= nbits
+                        rbl -= dc_len + s;
+                        pred[c] = (int32_t)((uint32_t)pred[c] + (uint32_t)diff);
+                        blk[0] = (int16_t)pred[c]; // bitstream.rs:330
+                        // AC: src/bitstream.rs:332-372
+                        const int T = rbl <= 32 ? rbl + 32 : rbl; // bits_left after the refill in front of the first AC symbol
+                        const int nb0 = nbits;
+                        int filled = 0;
+                        unsigned total = 0;
+                        int k = 1;
+                        uint64_t acc0;
+                        const Huff::AcEnt* en;
+                        Huff::AcEnt esc;
+                        do {
+                            if (nbits < 32) { const int b = nbits; refill(); filled += nbits - b; } // code (<= 16) + magnitude (<= 15) fit
+                            acc0 = acc;
+                            en = tab + (acc >> (64 - AC_BITS));
+                            total = en->total;
+                            if (__builtin_expect(total == 0, 0)) {
+                                esc = d->ac[cm.ta & 3].ac_escape(acc);
+                                en = &esc;
+                                total = esc.total;
+                                if (!total) { acc <<= 16; nbits -= 16; *err = "Bad Huffman code in AC"; rc = ZJ_ERR_HUFFMAN; break; }
+                            }
+                            acc = shl_lo6<BMI2>(acc, total);
+                            nbits -= (int)total;
+                            const unsigned sz = en->sz;
+                            const uint64_t m = acc0 << en->len;              // the magnitude bits at the top
+                            const int64_t sg = (int64_t)m >> 63;            // all ones: a positive value (T.81 F.2.2.1)
+                            const uint32_t mask = kSizeMask[sz];
+                            const uint32_t rw = (uint32_t)(m >> ((0u - sz) & 63)) & mask; // (size 0: the mask clears it)
+                            const int32_t v0 = (int32_t)rw - (int32_t)(~(uint32_t)sg & mask);
+                            const int32_t val = (int32_t)((uint32_t)v0 << en->sx) >> en->sx; // (sx: Huff::AcEnt)
+                            blk[kZZ.t[k + en->idxoff]] = (int16_t)val;
+                            k += en->kadv;
+                        } while (k < 64);
+                        if (!rc) {
+                            int last = (int)total; // length of the block's last symbol
+                            if (en->fold) {
+                                const int t1 = en->len + en->sz, off = en->idxoff;
+                                if (k - 64 + (off & 127) + 1 >= 64) { // the coefficient ended the block by itself
+                                    acc = acc0 << t1;
+                                    nbits += (int)total - t1;
+                                    last = t1;
+                                } else last = (int)total - t1;
+                            }
+                            const int c_last = nb0 + filled - nbits - last; // bits the AC symbols in front of the last one consumed
+                            rbl = (c_last == 0 ? T : 33 + ((T - c_last - 33) & 31)) - last;
+                        }
+                    }
+                    if (STORE != STORE_DIRECT) flush_block<STORE>(blk, out);
+                    if (rc) break;
+                }
+        }
+        if (rc) break;
+        if (++mx == mcu_x) { mx = 0; my++; }
+    }
+    put();
+    br.rbl = rbl < 0 ? 0 : rbl;
+    *done = i;
+    return rc;
+}
+template <int STORE>
+int decode_mcus_v2(const zj_decoder* d, zj_decoder* dm, BitReader& br, int32_t* pred, long long m0, long long n,
+                   const uint8_t* stop, long long* done, const char** err)
+{
+    return decode_mcus_v2_body<STORE, false>(d, dm, br, pred, m0, n, stop, done, err);
+}
+// the same body compiled for BMI2 (three-operand shifts without the flags dependency) and AVX2
+template <int STORE>
+__attribute__((target("bmi2,avx2"))) int decode_mcus_v2_x3(const zj_decoder* d, zj_decoder* dm, BitReader& br, int32_t* pred, long long m0,
+                                                           long long n, const uint8_t* stop, long long* done, const char** err)
+{
+    return decode_mcus_v2_body<STORE, true>(d, dm, br, pred, m0, n, stop, done, err);
+}
 // the three instantiations a scan uses, for the decoder's store mode
 struct BlockFns {
     using Fn = int (*)(const zj_decoder*, BitReader&, const Comp&, int32_t&, int16_t*, const char**);
+    using McuFn = int (*)(const zj_decoder*, zj_decoder*, BitReader&, int32_t*, long long, long long, const uint8_t*, long long*, const char**);
     Fn hot, track, hist;
+    McuFn mcus; // null: ZJ_WALKER_V1
 };
 template <int STORE> BlockFns block_fns_of()
 {
-    return {decode_block_baseline<false, false, STORE>, decode_block_baseline<true, false, STORE>, decode_block_baseline<true, true, STORE>};
+    // (read per scan, not cached: tests switch them inside one process)
+    //   ZJ_WALKER_V1       every block through decode_block_baseline, as before round 6 (the A/B and the differential test)
+    //   ZJ_WALKER_GENERIC  decode_mcus_v2 without the BMI2 / AVX2 build of its body
+    const bool x3 = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("avx2") && !getenv("ZJ_WALKER_GENERIC");
+    const bool v1 = getenv("ZJ_WALKER_V1") != nullptr;
+    return {decode_block_baseline<false, false, STORE>, decode_block_baseline<true, false, STORE>, decode_block_baseline<true, true, STORE>,
+            v1 ? nullptr : x3 ? decode_mcus_v2_x3<STORE> : decode_mcus_v2<STORE>};
 }
 BlockFns block_fns(int store)
 {
@@ -821,7 +1098,15 @@ int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p,
     EoiCut cut;
     cut.eoi = eoi; cut.rowlen = eoi_rowlen(d);
     int32_t pred[3] = {0, 0, 0};
+    const uint8_t* const stop = cut.eoi ? cut.eoi - (cut.eoi - p > 4096 ? 4096 : cut.eoi - p) : nullptr;
     for (long long i = 0; i < nmcu; i++) {
+        if (fn.mcus && !d->track_hist && !cut.seen) { // as many MCUs as possible in one go (decode_mcus_v2)
+            long long done = 0;
+            const int rc = fn.mcus(d, dm, br, pred, mcu0 + i, nmcu - i, stop, &done, err);
+            if (rc) return rc;
+            i += done;
+            if (i == nmcu) break;
+        }
         const int my = (int)((mcu0 + i) / d->mcu_x), mx = (int)((mcu0 + i) % d->mcu_x);
         if (cut.seen && (mcu0 + i) / cut.rowlen == cut.cut_row) { clear_mcu(dm, mx, my); continue; }
         const bool near_end = cut.eoi && cut.eoi - br.p <= 4096; // an MCU is at most 6 blocks x 64 x 27 bits = 1.3 KB
@@ -894,30 +1179,50 @@ int scan_baseline(zj_decoder* d, BitReader& br)
                 }
     };
     // (2,1): the reference walks 2*mcu_x MCUs per strip (mcu.rs:145-152); MCU order is unchanged
-    for (int my = 0; my < d->mcu_y; my++)
-        for (int mx = 0; mx < d->mcu_x; mx++) {
-            const long long m = (long long)my * d->mcu_x + mx;
-            // the reference left this row's loop at an earlier MCU (see EoiCut): the block keeps its zeros
-            if (cut.seen && m / cut.rowlen == cut.cut_row) { clear_mcu(d, mx, my); continue; }
-            const bool near_end = cut.eoi && cut.eoi - br.p <= 4096; // an MCU is at most 6 blocks x 64 x 27 bits = 1.3 KB
-            for (int ci = 0; ci < d->ns; ci++) {
-                Comp& cm = d->comps[d->order[ci]];
-                for (int v = 0; v < cm.v; v++)
-                    for (int h = 0; h < cm.h; h++) {
-                        const char* err = nullptr;
-                        int16_t* blk = block_at(cm, mx * cm.h + h, my * cm.v + v);
-                        int rc = (d->track_hist ? fn.hist : near_end ? fn.track : fn.hot)(d, br, cm, cm.dc_pred, blk, &err);
-                        if (rc) { clear_from(my, mx); return fail(d, rc, err); }
-                    }
+    const uint8_t* const stop = cut.eoi ? cut.eoi - (cut.eoi - br.p > 4096 ? 4096 : cut.eoi - br.p) : nullptr;
+    for (long long m = 0; m < total;) {
+        if (fn.mcus && !d->track_hist && !cut.seen) {
+            // as many MCUs as possible in one go (decode_mcus_v2): up to the next restart boundary, short of the scan's last 4 KB.
+            // eoi_cut_after_mcu has nothing to do for them (it starts looking 64 bytes in front of the EOI marker).
+            int32_t pred[3] = {d->comps[0].dc_pred, d->comps[1].dc_pred, d->comps[2].dc_pred};
+            long long done = 0;
+            const char* err = nullptr;
+            const int rc = fn.mcus(d, d, br, pred, m, total - m < todo ? total - m : (long long)todo, stop, &done, &err);
+            for (int i = 0; i < 3; i++) d->comps[i].dc_pred = pred[i];
+            m += done;
+            if (rc) { clear_from((int)(m / d->mcu_x), (int)(m % d->mcu_x)); return fail(d, rc, err); }
+            if (done) {
+                todo -= (int)done;
+                if (todo == 0) {
+                    const int rc2 = handle_restart(d, br, todo);
+                    if (rc2) { clear_from((int)(m / d->mcu_x), (int)(m % d->mcu_x)); return rc2; }
+                }
+                continue;
             }
-            bool restarted = false;
-            if (--todo == 0) {
-                restarted = br.marker >= 0xD0 && br.marker <= 0xD7;
-                int rc = handle_restart(d, br, todo);
-                if (rc) { clear_from(my, mx + 1); return rc; }
-            }
-            if (!restarted) eoi_cut_after_mcu(cut, br, m); // (a restart clears the reference's pending marker, mcu.rs:400-408)
         }
+        const int my = (int)(m / d->mcu_x), mx = (int)(m % d->mcu_x);
+        // the reference left this row's loop at an earlier MCU (see EoiCut): the block keeps its zeros
+        if (cut.seen && m / cut.rowlen == cut.cut_row) { clear_mcu(d, mx, my); m++; continue; }
+        const bool near_end = cut.eoi && cut.eoi - br.p <= 4096; // an MCU is at most 6 blocks x 64 x 27 bits = 1.3 KB
+        for (int ci = 0; ci < d->ns; ci++) {
+            Comp& cm = d->comps[d->order[ci]];
+            for (int v = 0; v < cm.v; v++)
+                for (int h = 0; h < cm.h; h++) {
+                    const char* err = nullptr;
+                    int16_t* blk = block_at(cm, mx * cm.h + h, my * cm.v + v);
+                    int rc = (d->track_hist ? fn.hist : near_end ? fn.track : fn.hot)(d, br, cm, cm.dc_pred, blk, &err);
+                    if (rc) { clear_from(my, mx); return fail(d, rc, err); }
+                }
+        }
+        bool restarted = false;
+        if (--todo == 0) {
+            restarted = br.marker >= 0xD0 && br.marker <= 0xD7;
+            int rc = handle_restart(d, br, todo);
+            if (rc) { clear_from(my, mx + 1); return rc; }
+        }
+        if (!restarted) eoi_cut_after_mcu(cut, br, m); // (a restart clears the reference's pending marker, mcu.rs:400-408)
+        m++;
+    }
     _mm_sfence(); // the blocks left with streaming stores (decode_block_baseline)
     return ZJ_OK;
 }
@@ -954,7 +1259,7 @@ int ac_first(zj_decoder* d, BitReader& br, const Huff& ha, int16_t* blk)
         if (fa) { // short code + small value from one table entry (same shortcut as the baseline scan)
             k += (fa >> 4) & 15;
             br.drop(fa & 15);
-            blk[kUnZigzag[k & 63]] = (int16_t)((uint16_t)(int16_t)(fa >> 8) * (uint16_t)(1u << d->al));
+            blk[kUnZigzag[k < 63 ? k : 63]] = (int16_t)((uint16_t)(int16_t)(fa >> 8) * (uint16_t)(1u << d->al)); // min(k, 63): bitstream.rs:466
             k++;
             continue;
         }
@@ -1081,7 +1386,14 @@ int gpu_table(const Huff& h, bool ac, uint16_t* out, int room)
             // entry: bits consumed | zig-zag advance << 5 | magnitude bits << 11 (zj_huff.h)
             const int sym = h.vals[k], sz = ac ? (sym & 15) : sym, run = ac ? sym >> 4 : 0;
             const int zadv = !ac ? 1 : sz ? run + 1 : run == 15 ? 16 : 63;
-            const uint16_t e = (sz > 15 || l + sz > 31) ? NONE : (uint16_t)((l + sz) | (zadv << 5) | (sz << 11));
+            // AC symbols the device stage does not read the reference's way count as "no such code": if one OCCURS the write
+            // pass raises HUFF_ST_BAD_CODE and the CPU walker decodes the file.  The device computes every value from the bits
+            // and ends the block at any size-0 symbol but ZRL; the reference's fast-AC table skips run + 1 coefficients at a
+            // size-0 run of 1..14 behind a code of up to 9 bits, and keeps six bits of a value of size 6..8 that fits its
+            // 9-bit window (Huff::ac_entry, Huff::fast).  Tables often list such symbols (tools/jpeg_enc.py lists all 256);
+            // scans written by an encoder do not use the former and need a 1..3-bit code for the latter.
+            const bool walker_only = ac && ((!sz && run != 0 && run != 15 && l <= 9) || (sz >= 6 && l + sz <= 9 && !h.full_values));
+            const uint16_t e = (sz > 15 || l + sz > 31 || walker_only) ? NONE : (uint16_t)((l + sz) | (zadv << 5) | (sz << 11));
             if (l <= B) {
                 const uint32_t base = code << (B - l);
                 for (uint32_t q = 0; q < (1u << (B - l)); q++) out[base + q] = e;
@@ -1440,7 +1752,7 @@ static void fill_info(const zj_decoder* d, zj_image_info* info, zj_frame_desc* f
         fd->in_components = (uint32_t)d->ncomp;
         // single-component images are always decoded to GRAYSCALE (headers.rs:283-290)
         fd->out_colorspace = d->ncomp == 1 ? (int)ZJ_CS_GRAYSCALE : d->out_colorspace;
-        fd->flags = d->flags;
+        fd->flags = d->flags & ZJ_FLAG_CORRECTED; // (ZJ_FLAG_FULL_AC_VALUES is the front-end's own)
         fd->out_layout = d->out_layout;
         for (int c = 0; c < 3; c++) {
             const Comp& cm = d->comps[c < d->ncomp ? c : 0];

@@ -62,6 +62,7 @@ FLAG_PLAIN_TAIL = 1   # zj_frame_desc.flags: extension, every pixel at its own p
 FLAG_CLAMP_DC = 2     # extension: DC-only shortcut value clamped to 0..255 (Q1 corrected)
 FLAG_EDGE_REPLICATE = 4  # extension: horizontal chroma filter per row with replicated edges (Q4 corrected)
 FLAG_CORRECTED = 7
+FLAG_FULL_AC_VALUES = 8  # zj_options.flags only: the front-end yields AC values as coded (the reference cuts some to six bits)
 LAYOUT_HWC, LAYOUT_CHW = 0, 1
 
 
