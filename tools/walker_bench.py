@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""The CPU walker by itself (container parsing + Huffman -> coefficient planes; zj_decoder_decode_coefficients) on ONE host
-thread, beside Pillow's / libjpeg-turbo's FULL decode of the same file on the same core.  No GPU needed: the planes are
+"""The CPU walker by itself (container parsing + Huffman -> coefficient planes; zj_decoder_prepare with the CPU entropy
+setting, which leaves the planes where they are) on ONE host thread, beside Pillow's / libjpeg-turbo's FULL decode of the same file on the same core.  No GPU needed: the planes are
 pinned when a device is there (ZuneJpegOptions.pinned_planes) and malloc'd otherwise.
 
   python tools/walker_bench.py [files ...] [--reps 7] [--pinned] [--synthetic 4096]
@@ -38,7 +38,7 @@ def time_walker(data, reps, pinned, threads=1):
     info = None
     for _ in range(reps):
         t0 = time.perf_counter()
-        _, _, info = dec.decode_coefficients(data)
+        _, info = dec.prepare(data)  # (decode_coefficients would add a copy of the planes to every pass: 199 MB for speed_bench.jpg)
         ts.append(time.perf_counter() - t0)
     dec.close()
     return ts, info
