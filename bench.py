@@ -82,7 +82,11 @@ def cpu_baseline(frames, qts, budget_s=20.0):
     sc = run(scalar, budget_s * 0.15)
     best = max(res, key=lambda t: res[t][0])
     detail = "; ".join(f"{t} threads {res[t][0]:.0f} MP/s ({res[t][1]} frames, {res[t][2]:.1f} s)" for t in sorted(res))
-    return {"value": round(res[best][0], 1), "unit": "megapixels/s", "cores": best, "kind": "port",
+    # `cores` = the cores the fastest run could actually occupy: its threads, capped by the cgroup's CPU quota (32 threads on
+    # a 16-CPU quota are 16 cores' worth of work, time-sliced); the thread count, the quota and the host's size beside it
+    return {"value": round(res[best][0], 1), "unit": "megapixels/s", "cores": min(best, eff), "threads": best, "cpu_quota": eff,
+            "logical_cpus": ncpu, "kind": "port",
+            "by_threads": {str(t): round(res[t][0], 1) for t in sorted(res)},
             "distinct_frames": len(frames), "l3_resident": False,
             "sample": f"restated zune-jpeg AVX2 path (oracle/zj_avx2.c) on 4096x4096 4:2:0 frames, {len(frames)} distinct "
                       f"frames in rotation: {detail}; "
@@ -203,7 +207,8 @@ def from_files(zj, ctx, size=4096, batch=16, reps=4):
                 assert not any(rcs)
                 best_total, best_prep = min(best_total, (t2 - t0) / n), min(best_prep, (t1 - t0) / n)
             out[name] = {"megapixels_per_s": round(mp / best_total, 1), "ms_per_file": round(best_total * 1e3, 3),
-                         "host_ms_per_file": round(best_prep * 1e3, 3)}
+                         "host_ms_per_file": round(best_prep * 1e3, 3), "planes": "pinned", "host_threads": 1,
+                         "blocks": 6 * (size // 16) ** 2, "ns_per_block": round(best_prep * 1e9 / (6 * (size // 16) ** 2), 1)}
             ctx.device_free(base)
             for d in decs:
                 d.close()
@@ -385,7 +390,9 @@ def reference_files(zj, ctx, reps=5):
                 host, gpu = min(host, t1 - t0), min(gpu, t2 - t1)
             dec.close()
             mp = r["width"] * r["height"] / 1e6
+            blocks = 3 * ((r["width"] + 7) // 8) * ((r["height"] + 7) // 8)  # 4:4:4: three planes of (w/8) x (h/8) blocks
             out[name] = {"host_entropy_ms": round(host * 1e3, 3), "gpu_pixels_ms": round(gpu * 1e3, 3),
+                         "blocks": blocks, "ns_per_block": round(host * 1e9 / blocks, 1), "planes": "pinned", "host_threads": 1,
                          "megapixels_per_s": round(mp / (host + gpu), 1), "scans": r["scans"], "progressive": bool(r["progressive"]),
                          "width": r["width"], "height": r["height"],
                          "sha256_matches_golden": hashlib.sha256(np.ascontiguousarray(px).tobytes()).hexdigest() == r["sha256_rgb"]}
@@ -539,7 +546,7 @@ def main():
     ap.add_argument("--as-rank", default=None, metavar="R/N",
                     help="one process on one GPU playing rank R of an N-rank run: its shard [R*S, (R+1)*S), its golden offsets; "
                          "collectives at world size 1 (virtual ranks: everything about configs[4] one GPU can prove)")
-    ap.add_argument("--no-other-workloads", action="store_true", help="skip other_workloads / reference_files / scattered_batch")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip other_workloads / reference_files / from_files / scattered_batch")
     args = ap.parse_args()
     if args.child:
         args.no_cpu_baseline = args.no_single_frame = args.no_live_traffic = args.no_e2e = True
@@ -576,6 +583,10 @@ def main():
     same_gpu = os.environ.get("ZJ_BENCH_SAME_GPU") == "1"
     gpu_index = 0 if same_gpu else local_rank
     torch.cuda.set_device(gpu_index)
+    # this rank's host side next to its GPU (zj_numa.cpp): the main thread now, and with it every thread started from here on
+    # (RCCL's, the pinned-plane feeders of the side measurements).  ZJ_NUMA=off leaves the rank where the launcher put it.
+    numa_bound = zj.bind_thread_near_device(gpu_index)
+    numa_here = (zj.device_numa_node(gpu_index), zj.thread_numa_node(), numa_bound >= 0)
     dev = torch.device("cuda", gpu_index)
     backend = "gloo" if same_gpu else "nccl"
     port_file = os.environ.get("ZJ_BENCH_PORT_FILE")
@@ -696,6 +707,8 @@ def main():
     kernel_ms_each = sum(each) / len(each)
     # every rank's own figure: the roofline fraction below is the SLOWEST rank's, not rank 0's
     per_rank_kernel_ms = shard.gather_values(kernel_ms, world, coll_dev)
+    per_rank_numa = [{"device_node": int(a), "thread_node": int(b), "bound": bool(c)} for a, b, c in
+                     zip(*(shard.gather_values(float(v), world, coll_dev) for v in numa_here))]
     kernel_ms_rank0, kernel_ms = kernel_ms, max(per_rank_kernel_ms)
     # Control for data dependence: the kernel's only data-dependent shortcut is the reference's own DC-only one, and it is
     # taken lane by lane (a wave transforms as long as any of its 64 blocks needs it).  The same sub-batch with ONE coefficient
@@ -907,6 +920,7 @@ def main():
                                                                           ("--no-live-traffic" if args.no_live_traffic else None)),
                          "kernel": kname, "kernel_ms": round(kernel_ms, 4), "kernel_ms_rank0": round(kernel_ms_rank0, 4),
                          "per_rank_kernel_ms": [round(v, 4) for v in per_rank_kernel_ms],
+                         "per_rank_numa": per_rank_numa,
                          "kernel_ms_single_launch": round(kernel_ms_each, 4),
                          "kernel_launches_timed": kiters, "kernel_ms_timed_region": round(kernel_ms_region, 4),
                          "kernel_timing": f"HIP events on the launch stream; {kiters} launches walking the shard's {nsub} "
@@ -957,11 +971,10 @@ def main():
                           for j in range(nf)]
             res["cpu_baseline"] = cpu_baseline(cpu_frames, qts, budget_s=20.0 if world == 1 else 8.0)
             del cpu_frames
-            if world == 1 and not virt:
-                res["from_files"] = from_files(zj, ctx)
         if not args.no_other_workloads and args.workload == "420-rgb" and world == 1 and not virt:
             res["other_workloads"] = other_workloads(zj, synth, ctx, dev, side)
             res["reference_files"] = reference_files(zj, ctx)
+            res["from_files"] = from_files(zj, ctx)
         if not args.no_e2e and args.workload == "420-rgb" and world == 1 and not virt:
             gsums = [int(x, 16) for x in golden["rgb"][lo:lo + 8]] if golden else None
             res["e2e_pinned"] = e2e_pinned(zj, ctx, desc, d_planes, plane_elems, frame_out, gsums, nb=min(8, S), probe=pcie_probe(dev))

@@ -173,6 +173,15 @@ extern "C" {
                                    d_cb: *const *const i16, d_cr: *const *const i16, d_out: *const *mut u8,
                                    stream: *mut c_void) -> c_int;
     pub fn zj_pointer_device(p: *const c_void) -> c_int;
+    pub fn zj_device_pci_bus_id(device: c_int, buf: *mut c_char, cap: usize) -> c_int;
+    pub fn zj_device_numa_node(device: c_int) -> c_int;
+    pub fn zj_bind_thread_to_numa_node(node: c_int) -> c_int;
+    pub fn zj_bind_thread_near_device(device: c_int) -> c_int;
+    pub fn zj_thread_numa_node() -> c_int;
+    pub fn zj_pool_slot_numa(pool: *mut zj_pool, slot: c_int, device_node: *mut c_int, threads_bound: *mut c_int,
+                             threads: *mut c_int) -> c_int;
+    pub fn zj_multi_slot_numa(m: *mut zj_multi, slot: c_int, device_node: *mut c_int, thread_node: *mut c_int,
+                              bound: *mut c_int) -> c_int;
     pub fn zj_pool_create_multi(devices: *const c_int, ndev: c_int, threads_per_device: c_int, opt: *const zj_options,
                                 status: *mut c_int) -> *mut zj_pool;
     pub fn zj_pool_devices(pool: *const zj_pool) -> c_int;

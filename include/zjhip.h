@@ -346,6 +346,10 @@ ZJ_API zj_pool *zj_pool_create_multi(const int *devices, int ndev, int threads_p
 ZJ_API int zj_pool_devices(const zj_pool *pool);              /* device slots */
 /* of one slot, accumulated since creation: its HIP device, seconds inside its GPU stage, files it finished */
 ZJ_API int zj_pool_device_stats(zj_pool *pool, int slot, int *device, double *gpu_seconds, size_t *files);
+/* of one slot: NUMA node of its device (-1 unknown), how many of its threads (entropy workers + submitters) were bound to
+ * that node, how many it has.  Each slot has its own workers and plane sets; a file's planes are filled, pinned and DMA'd
+ * on the socket of the GPU that decodes it (a slot with nothing to do may take over a file of another slot). */
+ZJ_API int zj_pool_slot_numa(zj_pool *pool, int slot, int *device_node, int *threads_bound, int *threads);
 ZJ_API void zj_pool_destroy(zj_pool *pool);
 ZJ_API int zj_pool_threads(const zj_pool *pool);
 ZJ_API const char *zj_pool_error(const zj_pool *pool);
@@ -375,6 +379,9 @@ ZJ_API void zj_multi_destroy(zj_multi *m);
 ZJ_API int zj_multi_devices(const zj_multi *m);
 ZJ_API zj_ctx *zj_multi_ctx(zj_multi *m, int slot);            /* slot's context (owned by m), e.g. for zj_device_alloc */
 ZJ_API int zj_multi_slot_stats(zj_multi *m, int slot, int *device, size_t *frames); /* frames decoded since creation */
+/* where slot's device and its host thread live: NUMA node of the device (-1 unknown), node the thread runs on (-1 unknown),
+ * whether the thread was bound (0 with ZJ_NUMA=off, an unknown node, or an affinity that excludes the node) */
+ZJ_API int zj_multi_slot_numa(zj_multi *m, int slot, int *device_node, int *thread_node, int *bound);
 /* zj_decode_planes_batch / zj_decode_frames, sharded: host planes (pinned: zj_alloc_pinned) -> host pixels */
 ZJ_API int zj_multi_decode_planes_batch(zj_multi *m, const zj_frame_desc *d, size_t nframes, const int16_t *y,
                                  const int16_t *cb, const int16_t *cr, uint8_t *out, int *statuses /*[slots] or NULL*/);
@@ -391,6 +398,17 @@ ZJ_API void *zj_alloc_pinned(size_t bytes); /* hipHostMalloc, portable (usable a
 /* binds the CALLING thread to `device` (hipSetDevice): host threads that only allocate pinned memory or fill planes for a
  * context on device N call this first, so they neither initialise nor pin against device 0 */
 ZJ_API int zj_set_thread_device(int device);
+/* ---- NUMA placement of a device's host side (round 6).  On a two-socket node a GPU's feeder threads and the
+ * pinned planes they fill belong on the GPU's socket.  hipHostMalloc already puts pinned memory on the node of the thread's
+ * CURRENT device (so call zj_set_thread_device before zj_alloc_pinned); these bind the threads.  zj_pool and zj_multi bind
+ * their own slot threads; a process-per-GPU caller (bench.py's ranks) calls zj_bind_thread_near_device first thing, so every
+ * thread it starts later inherits the placement.  ZJ_NUMA=off turns all binding off.  A CPU affinity the process was
+ * started with (taskset, cpuset) is respected: threads are bound to its intersection with the node, or left alone. */
+ZJ_API int zj_device_pci_bus_id(int device, char *buf, size_t cap);  /* "0000:5a:00.0" */
+ZJ_API int zj_device_numa_node(int device);          /* >= 0, or -1: unknown / single node */
+ZJ_API int zj_bind_thread_to_numa_node(int node);    /* CPUs the calling thread may now run on, or -1: not bound */
+ZJ_API int zj_bind_thread_near_device(int device);   /* the node the calling thread is now bound to, or -1: not bound */
+ZJ_API int zj_thread_numa_node(void);                /* node of the CPU the calling thread is running on, or -1 */
 /* the HIP device that owns device pointer p (>= 0), ZJ_ERR_ARG for host memory or an unknown pointer */
 ZJ_API int zj_pointer_device(const void *p);
 ZJ_API void zj_free_pinned(void *p);

@@ -43,7 +43,13 @@ def test_two_ranks_carry_the_cpu_baseline_in_the_same_run():
                  "--no-live-traffic", "--no-single-frame", "--no-dense-control", env_extra={"ZJ_BENCH_SAME_GPU": "1"})
     cb = res["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 100 and cb["cores"] >= 1 and "4 threads" in cb["sample"]
+    # north_star "core count stated": the thread count, the cgroup's CPU quota and the host's size, cores = what the run could occupy
+    assert cb["threads"] >= cb["cores"] == min(cb["threads"], cb["cpu_quota"]) and cb["logical_cpus"] >= cb["cpu_quota"] >= 1
+    assert str(cb["threads"]) in cb["by_threads"] and "4" in cb["by_threads"]
     assert res["checksums_match_golden"] is True and res["n_gpus"] == 2
+    numa = res["roofline"]["per_rank_numa"]                                     # every rank says where its host side ran
+    assert len(numa) == 2 and all(set(n) == {"device_node", "thread_node", "bound"} for n in numa)
+    assert all(n["thread_node"] == n["device_node"] and n["bound"] for n in numa if n["device_node"] >= 0)
 
 
 @pytest.mark.gpu
@@ -109,6 +115,18 @@ def test_single_rank_line_has_the_contract_fields():
         assert "error" not in rfiles[name], rfiles[name]
         assert rfiles[name]["sha256_matches_golden"] is True and rfiles[name]["progressive"] is prog
         assert rfiles[name]["host_entropy_ms"] > 0 and rfiles[name]["gpu_pixels_ms"] > 0
+        assert rfiles[name]["blocks"] == 97200 and rfiles[name]["planes"] == "pinned" and rfiles[name]["host_threads"] == 1
+        assert abs(rfiles[name]["ns_per_block"] - rfiles[name]["host_entropy_ms"] * 1e6 / 97200) < 0.2
+    # round 6: the baseline walker no longer loses to the ten-scan progressive file on the same thread (it did, 17.8 vs 3.6 ms,
+    # while its blocks left through non-temporal stores: profiles/r06_feeder_ab.txt)
+    assert rfiles["test-baseline.jpg"]["host_entropy_ms"] <= rfiles["test-progressive.jpg"]["host_entropy_ms"]
+    ff = res["from_files"]
+    assert "error" not in ff, ff
+    for mode in ("cpu_entropy", "gpu_entropy"):
+        assert ff[mode]["planes"] == "pinned" and ff[mode]["host_threads"] == 1 and ff[mode]["blocks"] == 393216
+    assert ff["cpu_entropy"]["host_ms_per_file"] <= 35.0, ff["cpu_entropy"]
+    numa = rf["per_rank_numa"]
+    assert len(numa) == 1 and (numa[0]["device_node"] < 0 or (numa[0]["bound"] and numa[0]["thread_node"] == numa[0]["device_node"]))
 
 
 @pytest.mark.gpu

@@ -295,6 +295,15 @@ void* zj_alloc_pinned(size_t bytes)
     if (hipHostMalloc(&p, bytes, flags) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return p;
 }
+int zj_device_pci_bus_id(int device, char* buf, size_t cap)
+{
+    if (!buf || cap < 16) return ZJ_ERR_ARG;
+    const int n = zj_device_count();
+    if (n <= 0) return ZJ_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return ZJ_ERR_ARG;
+    if (hipDeviceGetPCIBusId(buf, (int)cap, device) != hipSuccess) { (void)hipGetLastError(); return ZJ_ERR_HIP; }
+    return ZJ_OK;
+}
 int zj_set_thread_device(int device)
 {
     const int n = zj_device_count();

@@ -35,6 +35,8 @@ struct zj_multi {
         std::thread th;
         int rc = 0;          // of the slot's last shard
         size_t frames = 0;   // decoded since creation
+        int node = -1, thread_node = -1, bound = 0; // NUMA: of the device, of the thread once it runs, whether it was bound (zj_numa.cpp)
+        bool settled = false; // the thread has placed itself
     };
     std::deque<Slot> slots;
     std::mutex mu, call_mu;
@@ -48,8 +50,13 @@ struct zj_multi {
     {
         Slot& me = slots[(size_t)k];
         (void)zj_set_thread_device(me.device);
+        // the slot's host thread next to its GPU: it stages, submits and waits for that device's transfers
+        const int node = zj_device_numa_node(me.device), bound = zj_bind_thread_near_device(me.device) >= 0 ? 1 : 0;
+        const int here = zj_thread_numa_node();
         unsigned long long seen = 0;
         std::unique_lock<std::mutex> lk(mu);
+        me.node = node; me.bound = bound; me.thread_node = here; me.settled = true;
+        cv_done.notify_all(); // (zj_multi_create waits for every slot to have settled)
         for (;;) {
             cv_go.wait(lk, [&] { return stop || epoch != seen; });
             if (stop) return;
@@ -141,6 +148,10 @@ zj_multi* zj_multi_create(const int* devices, int ndev, int* status)
     }
     if (*status != ZJ_OK) { zj_multi_destroy(m); return nullptr; }
     for (int k = 0; k < ndev; k++) m->slots[(size_t)k].th = std::thread([m, k] { m->loop(k); });
+    {
+        std::unique_lock<std::mutex> lk(m->mu);
+        m->cv_done.wait(lk, [&] { for (auto& sl : m->slots) if (!sl.settled) return false; return true; });
+    }
     return m;
 }
 
@@ -154,6 +165,17 @@ int zj_multi_slot_stats(zj_multi* m, int slot, int* device, size_t* frames)
     std::lock_guard<std::mutex> lk(m->mu);
     if (device) *device = m->slots[(size_t)slot].device;
     if (frames) *frames = m->slots[(size_t)slot].frames;
+    return ZJ_OK;
+}
+
+int zj_multi_slot_numa(zj_multi* m, int slot, int* device_node, int* thread_node, int* bound)
+{
+    if (!m || slot < 0 || slot >= (int)m->slots.size()) return ZJ_ERR_ARG;
+    std::lock_guard<std::mutex> lk(m->mu);
+    const zj_multi::Slot& sl = m->slots[(size_t)slot];
+    if (device_node) *device_node = sl.node;
+    if (thread_node) *thread_node = sl.thread_node;
+    if (bound) *bound = sl.bound;
     return ZJ_OK;
 }
 

@@ -12,11 +12,15 @@
 // pool lives across calls because streams, pinned planes and device buffers are worth keeping.
 //
 // Several devices (zj_pool_create_multi): image-level sharding inside the library (north_star: "independent frames across
-// the 8 GPUs of one node"; SURVEY.md 8e: one host thread per GPU).  Every device slot gets its own submitters and contexts;
-// the entropy workers and the plane sets (pinned, portable: any device can DMA them) are shared.  A file whose pixels
-// go to host memory is taken by whichever slot has a submitter free (dealt by readiness, not by index, so a slow GPU does
-// not hold up its share); a file whose pixels stay in HBM goes to the slot(s) of the device that owns its output
-// pointer.  Results land in the caller's order because every file carries its own output pointer.
+// the 8 GPUs of one node"; SURVEY.md 8e: one host thread per GPU).  Every device slot is a small pool of its own -- entropy
+// workers, plane sets, submitters, contexts -- whose threads are bound to the NUMA node of its GPU (zj_numa.cpp) and whose
+// plane sets are pinned from there, so a file's coefficients are written, pinned and DMA'd on one socket (round 6; before,
+// workers and plane sets were shared and landed wherever the creating thread ran).  A file whose pixels go to host memory
+// is decoded by whichever worker gets to it and submitted by that worker's slot; a slot whose queue is empty takes a
+// prepared file from a slot with a backlog (so a slow GPU does not hold up its share).  A file whose pixels stay in HBM is
+// decoded by a worker of the slot that owns its output pointer -- or, when that slot's workers have run dry, by another
+// slot's -- and always submitted on the owning device.  Results land in the caller's order because every file carries
+// its own output pointer.
 //
 // Only the C ABI of the library is used (include/zjhip.h, plus the zj_set_pipeline knob).
 #include <stdint.h>
@@ -60,11 +64,16 @@ struct zj_pool {
         size_t done = 0;     // files finished or failed       (under mu)
         int first_error = 0;
     };
-    struct Job { size_t index; zj_decoder* dec; };
+    struct Job { size_t index; zj_decoder* dec; int home; }; // home: the slot whose plane set dec is
     struct Slot {                        // one device of the pool (the same device may fill several slots)
         int device = 0;
-        std::deque<Job> ready;           // prepared files whose output lives on this slot's device
+        int node = -1, n_threads = 0, n_bound = 0; // NUMA node of the device; this slot's threads, and how many were bound there
+        std::deque<Job> ready;           // prepared files this slot's submitters should take
+        std::vector<zj_decoder*> free_dec; // this slot's plane sets (pinned by its workers: on its device's node)
+        std::deque<size_t> todo;         // device-output batch: files whose output pointer lives on this slot's device
         std::condition_variable cv;      // this slot's submitters
+        int idle = 0;                    // ... of which so many are waiting for a file
+        std::condition_variable cv_work; // this slot's entropy workers: files are left and one of its plane sets is free
         double gpu_s = 0;                // under mu
         size_t files = 0;
     };
@@ -74,13 +83,10 @@ struct zj_pool {
     std::vector<zj_ctx*> ctxs;           // one per submitter
     std::deque<Slot> slots;              // (a deque: condition variables do not move)
     std::mutex mu;
-    // one condition per kind of waiter, so that a finished file wakes one submitter or one worker and not all 20+
+    // one condition per kind of waiter and slot, so that a finished file wakes one submitter or one worker and not all 20+
     // threads of the pool (with the device entropy stage a file is ~1 ms of work: the wake-ups showed)
-    std::condition_variable cv_work;     // entropy workers: a batch has files left and a plane set is free
-                                         // (submitters wait on their slot's condition: a prepared file waits)
     std::condition_variable cv_done;     // the caller: the batch is complete
-    std::vector<zj_decoder*> free_dec;
-    std::deque<Job> ready;               // entropy-decoded, waiting for the GPU, output in host memory: any slot
+    int settled = 0, expected_threads = 0; // threads that have placed themselves (bind_here), threads there will be
     Batch* batch = nullptr;
     bool stop = false;
     std::mutex call_mu;                  // serialises zj_pool_decode_files callers
@@ -102,24 +108,51 @@ struct zj_pool {
         b.done++;
     }
 
-    void wake_submitters()
-    {   // a file any slot may take: one submitter of every slot looks (those that find nothing go back to sleep)
-        for (Slot& sl : slots) sl.cv.notify_one();
+    bool files_left(const Batch& b, int k) const
+    {   // under mu: is there a file a worker of slot k may decode?
+        if (!b.on_device) return b.next < b.n;
+        if (!slots[(size_t)k].todo.empty()) return true;
+        for (const Slot& sl : slots) if (!sl.todo.empty()) return true; // (its own have run dry: help another slot)
+        return false;
+    }
+    size_t take_file(Batch& b, int k)
+    {   // under mu, files_left(b, k)
+        if (!b.on_device) return b.next++;
+        Slot* from = &slots[(size_t)k];
+        if (from->todo.empty())
+            for (Slot& sl : slots) if (sl.todo.size() > from->todo.size()) from = &sl;
+        const size_t i = from->todo.front();
+        from->todo.pop_front();
+        b.next++;
+        return i;
+    }
+    void bind_here(Slot& me)
+    {   // the calling thread next to the slot's GPU (zj_numa.cpp); counts are read by zj_pool_slot_numa
+        const int node = zj_device_numa_node(me.device);
+        const bool bound = zj_bind_thread_near_device(me.device) >= 0;
+        std::lock_guard<std::mutex> lk(mu);
+        me.node = node;
+        me.n_threads++;
+        if (bound) me.n_bound++;
+        if (++settled == expected_threads) cv_done.notify_all();
     }
 
-    void entropy_loop(int device)
+    void entropy_loop(int slot_index)
     {
+        Slot& me = slots[(size_t)slot_index];
         // the planes this thread fills are pinned (zj_alloc_pinned) and DMA'd by the submitters' contexts:
-        // bind the thread to one of the pool's devices, so a pool on device N never touches device 0
-        (void)zj_set_thread_device(device);
+        // bind the thread to the slot's device, so a pool on device N never touches device 0 -- and hipHostMalloc places the
+        // planes on that device's NUMA node -- and to that node's CPUs
+        (void)zj_set_thread_device(me.device);
+        bind_here(me);
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
-            cv_work.wait(lk, [&] { return stop || (batch && batch->next < batch->n && !free_dec.empty()); });
+            me.cv_work.wait(lk, [&] { return stop || (batch && !me.free_dec.empty() && files_left(*batch, slot_index)); });
             if (stop) return;
             Batch& b = *batch;
-            const size_t i = b.next++;
-            zj_decoder* dec = free_dec.back();
-            free_dec.pop_back();
+            const size_t i = take_file(b, slot_index);
+            zj_decoder* dec = me.free_dec.back();
+            me.free_dec.pop_back();
             lk.unlock();
             zj_image_info info;
             memset(&info, 0, sizeof info);
@@ -131,13 +164,18 @@ struct zj_pool {
             entropy_s += dt;
             if (rc) {
                 finish(b, i, rc, zj_decoder_error(dec), 0, &info);
-                free_dec.push_back(dec);
+                me.free_dec.push_back(dec);
                 if (b.done == b.n) cv_done.notify_all();
-                cv_work.notify_one();
+                me.cv_work.notify_one();
             } else {
                 if (b.infos) b.infos[i] = info;
-                if (b.on_device) { Slot& sl = slots[(size_t)out_slot[i]]; sl.ready.push_back(Job{i, dec}); sl.cv.notify_one(); }
-                else { ready.push_back(Job{i, dec}); wake_submitters(); }
+                // device output: the slot that owns the pointer; host output: this slot (its planes are on this socket) --
+                // and once this slot has a backlog, one submitter of every other slot gets a look (gpu_loop steals)
+                Slot& to = b.on_device ? slots[(size_t)out_slot[i]] : me;
+                to.ready.push_back(Job{i, dec, slot_index});
+                to.cv.notify_one();
+                if (!b.on_device && to.ready.size() > (size_t)to.idle)
+                    for (Slot& sl : slots) if (&sl != &to) sl.cv.notify_one();
             }
         }
     }
@@ -146,9 +184,19 @@ struct zj_pool {
     {
         Slot& me = slots[(size_t)slot_index];
         (void)zj_set_thread_device(me.device);
+        bind_here(me);
         std::unique_lock<std::mutex> lk(mu);
+        auto backlog_elsewhere = [&]() -> Slot* { // host outputs only: the slot with the longest queue of prepared files
+            if (!batch || batch->on_device) return nullptr;
+            Slot* best = nullptr;
+            for (Slot& sl : slots) // (a file an idle submitter of its own slot is about to take is not a backlog)
+                if (&sl != &me && sl.ready.size() > (size_t)sl.idle && (!best || sl.ready.size() > best->ready.size())) best = &sl;
+            return best;
+        };
         for (;;) {
-            me.cv.wait(lk, [&] { return stop || !ready.empty() || !me.ready.empty(); });
+            me.idle++;
+            me.cv.wait(lk, [&] { return stop || !me.ready.empty() || backlog_elsewhere(); });
+            me.idle--;
             if (stop) return;
             Batch& b = *batch;
             // Pixels that stay on the device: take what is ready, up to a batch -- the device entropy stage runs the scans of
@@ -158,7 +206,8 @@ struct zj_pool {
             size_t nj = 0;
             const size_t want = b.on_device ? (size_t)device_batch : 1;
             while (nj < want && !me.ready.empty()) { jobs[nj++] = me.ready.front(); me.ready.pop_front(); }
-            while (nj < want && !ready.empty()) { jobs[nj++] = ready.front(); ready.pop_front(); }
+            if (!nj) { Slot* from = backlog_elsewhere(); if (from) { jobs[nj++] = from->ready.front(); from->ready.pop_front(); } }
+            if (!nj) continue;
             lk.unlock();
             zj_decoder* decs[ZJ_SCAN_BATCH_MAX];
             uint8_t* outs[ZJ_SCAN_BATCH_MAX];
@@ -180,10 +229,11 @@ struct zj_pool {
             me.files += nj;
             for (size_t q = 0; q < nj; q++) {
                 finish(b, jobs[q].index, rcs[q], rcs[q] ? zj_decoder_error(jobs[q].dec) : nullptr, olens[q], nullptr);
-                free_dec.push_back(jobs[q].dec);
+                Slot& home = slots[(size_t)jobs[q].home];
+                home.free_dec.push_back(jobs[q].dec); // the plane set goes back to the slot (the socket) it belongs to
+                home.cv_work.notify_one();
             }
             if (b.done == b.n) cv_done.notify_all();
-            if (nj > 1) cv_work.notify_all(); else cv_work.notify_one();
         }
     }
 };
@@ -197,8 +247,7 @@ void zj_pool_destroy(zj_pool* p)
         std::lock_guard<std::mutex> lk(p->mu);
         p->stop = true;
     }
-    p->cv_work.notify_all();
-    for (auto& sl : p->slots) sl.cv.notify_all();
+    for (auto& sl : p->slots) { sl.cv_work.notify_all(); sl.cv.notify_all(); }
     for (auto& th : p->threads) if (th.joinable()) th.join();
     for (zj_decoder* d : p->decoders) zj_decoder_free(d);
     for (zj_ctx* c : p->ctxs) zj_ctx_destroy(c);
@@ -238,19 +287,24 @@ zj_pool* zj_pool_create_multi(const int* devices, int ndev, int threads_per_devi
             p->ctxs.push_back(c);
             ctx_slot.push_back(k);
         }
-    // plane sets: one per entropy worker plus what the submitters hold plus one in the queue each
-    // (with the device entropy stage a plane set is a few MB of prepared scan, and a submitter may hold a batch of them)
-    const int all_submitters = submitters * ndev;
-    (void)zj_set_thread_device(devices[0]); // the pinned planes are allocated from here: not against device 0 unless it is the pool's
-    for (int k = 0; k < threads + (o.entropy ? all_submitters * p->device_batch : 2 * all_submitters) && *status == ZJ_OK; k++) {
-        zj_decoder* d = zj_decoder_new(&o);
-        if (!d) { *status = ZJ_ERR_NOMEM; break; }
-        p->decoders.push_back(d);
-        p->free_dec.push_back(d);
-    }
+    // plane sets, per slot: one per entropy worker plus what the submitters hold plus one in the queue each
+    // (with the device entropy stage a plane set is a few MB of prepared scan, and a submitter may hold a batch of them).
+    // They are empty shells here: the planes are pinned by the worker that first fills them, bound to the slot's device.
+    for (int k = 0; k < ndev && *status == ZJ_OK; k++)
+        for (int q = 0; q < threads_per_device + (o.entropy ? submitters * p->device_batch : 2 * submitters) && *status == ZJ_OK; q++) {
+            zj_decoder* d = zj_decoder_new(&o);
+            if (!d) { *status = ZJ_ERR_NOMEM; break; }
+            p->decoders.push_back(d);
+            p->slots[(size_t)k].free_dec.push_back(d);
+        }
     if (*status != ZJ_OK) { zj_pool_destroy(p); return nullptr; }
-    for (int t = 0; t < threads; t++) { const int dev = devices[t % ndev]; p->threads.emplace_back([p, dev] { p->entropy_loop(dev); }); }
+    p->expected_threads = threads + (int)p->ctxs.size();
+    for (int t = 0; t < threads; t++) { const int k = t % ndev; p->threads.emplace_back([p, k] { p->entropy_loop(k); }); }
     for (size_t g = 0; g < p->ctxs.size(); g++) { zj_ctx* c = p->ctxs[g]; const int k = ctx_slot[g]; p->threads.emplace_back([p, c, k] { p->gpu_loop(c, k); }); }
+    {   // every thread has placed itself before the first batch (and before zj_pool_slot_numa is asked)
+        std::unique_lock<std::mutex> lk(p->mu);
+        p->cv_done.wait(lk, [&] { return p->settled == p->expected_threads; });
+    }
     return p;
 }
 
@@ -269,6 +323,17 @@ int zj_pool_device_stats(zj_pool* p, int slot, int* device, double* gpu_seconds,
     if (device) *device = sl.device;
     if (gpu_seconds) *gpu_seconds = sl.gpu_s;
     if (files) *files = sl.files;
+    return ZJ_OK;
+}
+
+int zj_pool_slot_numa(zj_pool* p, int slot, int* device_node, int* threads_bound, int* threads)
+{
+    if (!p || slot < 0 || slot >= (int)p->slots.size()) return ZJ_ERR_ARG;
+    std::lock_guard<std::mutex> lk(p->mu);
+    const zj_pool::Slot& sl = p->slots[(size_t)slot];
+    if (device_node) *device_node = sl.node;
+    if (threads_bound) *threads_bound = sl.n_bound;
+    if (threads) *threads = sl.n_threads;
     return ZJ_OK;
 }
 
@@ -331,8 +396,11 @@ static int pool_decode(zj_pool* p, size_t nfiles, const uint8_t* const* bufs, co
     b.n = nfiles; b.bufs = bufs; b.lens = lens; b.outs = outs; b.caps = out_caps;
     b.out_lens = out_lens; b.infos = infos; b.statuses = statuses; b.on_device = on_device;
     std::unique_lock<std::mutex> lk(p->mu);
+    for (auto& sl : p->slots) sl.todo.clear();
+    if (on_device)
+        for (size_t i = 0; i < nfiles; i++) p->slots[(size_t)p->out_slot[i]].todo.push_back(i);
     p->batch = &b;
-    p->cv_work.notify_all();
+    for (auto& sl : p->slots) sl.cv_work.notify_all();
     p->cv_done.wait(lk, [&] { return b.done == b.n; });
     p->batch = nullptr;
     return b.first_error;

@@ -156,6 +156,8 @@ ABI = [  # every symbol include/zjhip.h declares
     "zj_decode_frames", "zj_decode_planes_device_strided", "zj_decode_frames_device", "zj_pointer_device",
     "zj_pool_create_multi", "zj_pool_devices", "zj_pool_device_stats",
     "zj_shard_range", "zj_multi_create", "zj_multi_destroy", "zj_multi_devices", "zj_multi_ctx", "zj_multi_slot_stats",
+    "zj_device_pci_bus_id", "zj_device_numa_node", "zj_bind_thread_to_numa_node", "zj_bind_thread_near_device",
+    "zj_thread_numa_node", "zj_pool_slot_numa", "zj_multi_slot_numa",
     "zj_multi_decode_planes_batch", "zj_multi_decode_frames", "zj_multi_decode_frames_device",
 ]
 SCATTER_MAX = 32  # ZJ_SCATTER_MAX: frames per launch of the scattered form
@@ -296,6 +298,14 @@ def lib():
     L.zj_multi_decode_planes_batch.argtypes = [vp, C.POINTER(FrameDesc), sz, i16p, i16p, i16p, u8p, C.POINTER(C.c_int)]
     L.zj_multi_decode_frames.argtypes = [vp, C.POINTER(FrameDesc), sz, vp, vp, vp, vp, C.POINTER(C.c_int)]
     L.zj_multi_decode_frames_device.argtypes = [vp, C.POINTER(FrameDesc), sz, vp, vp, vp, vp, C.POINTER(C.c_int)]
+    ip = C.POINTER(C.c_int)
+    L.zj_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, sz]
+    L.zj_device_numa_node.argtypes = [C.c_int]
+    L.zj_bind_thread_to_numa_node.argtypes = [C.c_int]
+    L.zj_bind_thread_near_device.argtypes = [C.c_int]
+    L.zj_thread_numa_node.argtypes = []
+    L.zj_pool_slot_numa.argtypes = [vp, C.c_int, ip, ip, ip]
+    L.zj_multi_slot_numa.argtypes = [vp, C.c_int, ip, ip, ip]
     if hasattr(L, "zj_set_ablation"):  # diagnostic build only (tools/build_variant.sh ablate "-DZJ_ABLATION")
         L.zj_set_ablation.argtypes = [vp, C.c_int]
     _LIB = L
@@ -766,6 +776,21 @@ class FileBatchDecoder:
         return t
 
 
+def device_numa_node(device=0):
+    """NUMA node of a HIP device (PCI bus id -> sysfs), -1 unknown"""
+    return lib().zj_device_numa_node(int(device))
+
+
+def bind_thread_near_device(device=0):
+    """Bind the calling thread (and the threads it starts from now on) to the CPUs of the device's NUMA node; returns the
+    node, or -1 if nothing was bound (unknown node, ZJ_NUMA=off, an affinity that excludes the node)."""
+    return lib().zj_bind_thread_near_device(int(device))
+
+
+def thread_numa_node():
+    return lib().zj_thread_numa_node()
+
+
 def pointer_device(p):
     """HIP device that owns device pointer p, or a negative zj_status (host memory, unknown pointer)."""
     return lib().zj_pointer_device(p)
@@ -807,6 +832,15 @@ class Multi:
             d, n = C.c_int(0), C.c_size_t(0)
             lib().zj_multi_slot_stats(self._m, k, C.byref(d), C.byref(n))
             res.append((d.value, n.value))
+        return res
+
+    def slot_numa(self):
+        """[(NUMA node of the slot's device, node its host thread runs on, bound?)] per slot; -1 = unknown"""
+        res = []
+        for k in range(self.nslots):
+            a, b, c = C.c_int(-1), C.c_int(-1), C.c_int(0)
+            lib().zj_multi_slot_numa(self._m, k, C.byref(a), C.byref(b), C.byref(c))
+            res.append((a.value, b.value, bool(c.value)))
         return res
 
     def decode_planes(self, desc, planes, nframes):
@@ -869,6 +903,15 @@ class Pool:
             d, s_, n = C.c_int(0), C.c_double(0), C.c_size_t(0)
             lib().zj_pool_device_stats(self._p, k, C.byref(d), C.byref(s_), C.byref(n))
             res.append((d.value, s_.value, n.value))
+        return res
+
+    def slot_numa(self):
+        """[(NUMA node of the slot's device, threads bound there, threads)] per device slot; node -1 = unknown"""
+        res = []
+        for k in range(lib().zj_pool_devices(self._p)):
+            a, b, c = C.c_int(-1), C.c_int(0), C.c_int(0)
+            lib().zj_pool_slot_numa(self._p, k, C.byref(a), C.byref(b), C.byref(c))
+            res.append((a.value, b.value, c.value))
         return res
 
     def close(self):
