@@ -300,7 +300,7 @@ def other_workloads(zj, synth, ctx, dev, side, names=("444-rgb", "444-gray", "42
     pixel; and the reference's medium image size, a ragged width (60 frames per launch: the same pixels per launch), in the
     reference's tight layout and with its rows laid out at a pitch that is a multiple of 128 bytes (zj_frame_desc.out_pitch:
     a layout for outputs that stay in HBM; its rows must equal the tight layout's).
-    The wide kernel generation decodes frame 0 once more and must give the same bytes."""
+    Another kernel variant decodes frame 0 once more and must give the same bytes."""
     import torch
     out = {}
     B16 = B
@@ -334,7 +334,10 @@ def other_workloads(zj, synth, ctx, dev, side, names=("444-rgb", "444-gray", "42
             ms = ev[0].elapsed_time(ev[1]) / iters
             _, _, kname = ctx.time_decode_device(desc, B, ptr[0], ptr[1], ptr[2], ptr[3], 1, side.cuda_stream)
             first = o[:fo].clone()
-            ctx.set_variant(1)
+            # the same frame through another kernel variant: the wide generation where the library carries it
+            # (make VARIANTS=all), else the packed generation with direct stores -- different store path, same bytes
+            other = 1 if 1 in zj.variants_available() else 2
+            ctx.set_variant(other)
             try:
                 ctx.decode_planes_device(desc, 1, ptr[0], ptr[1], ptr[2], ptr[3], side.cuda_stream)
                 side.synchronize()
@@ -350,7 +353,7 @@ def other_workloads(zj, synth, ctx, dev, side, names=("444-rgb", "444-gray", "42
             gbs = B * W * H * bpp / (ms * 1e-3) / 1e9
             out[name] = {"kernel_ms": round(ms, 4), "megapixels_per_s": round(B * W * H / 1e6 / (ms * 1e-3), 1),
                          "frames_per_launch": B, "width": W, "height": H, "bytes_per_px": bpp, "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "kernel": kname,
-                         "matches_wide_variant": bool(torch.equal(first, o[:fo])), "what": what}
+                         "matches_other_variant": bool(torch.equal(first, o[:fo])), "other_variant": {1: "wide", 2: "packed-direct"}[other], "what": what}
             if pitch:
                 out[name].update({"out_pitch": pitch, "rows_match_tight_layout": tight_ok})
             del pl, o, first

@@ -163,6 +163,7 @@ extern "C" {
     pub fn zj_device_memset(ctx: *mut zj_ctx, d_ptr: *mut c_void, value: c_int, bytes: usize) -> c_int;
     pub fn zj_sync(ctx: *mut zj_ctx) -> c_int;
     pub fn zj_set_variant(ctx: *mut zj_ctx, variant: c_int) -> c_int;
+    pub fn zj_variant_available(variant: c_int) -> c_int;
     pub fn zj_set_pipeline(ctx: *mut zj_ctx, on: c_int) -> c_int;
     pub fn zj_decode_frames(ctx: *mut zj_ctx, d: *const zj_frame_desc, nframes: usize, y: *const *const i16,
                             cb: *const *const i16, cr: *const *const i16, out: *const *mut u8) -> c_int;
@@ -245,6 +246,17 @@ pub fn ycbcr_to_rgb_hip_16(y: &[i16; 16], cb: &[i16; 16], cr: &[i16; 16], out: &
                                      out.len(), pos as *mut usize) }, "zj_ycbcr_to_rgb16");
 }
 
+/// The C side reads `zj_plane_len` elements behind every plane pointer it is given: a safe function must not hand it a
+/// shorter slice.  The chroma planes are read whenever the frame has three components (an empty slice is too short then).
+fn check_plane_lengths(d: &zj_frame_desc, frames: &[[&[i16]; 3]]) {
+    let (ylen, clen) = unsafe { (zj_plane_len(d, 0), if d.in_components == 3 { zj_plane_len(d, 1) } else { 0 }) };
+    assert!(ylen > 0, "not a decodable frame descriptor");
+    for f in frames {
+        assert!(f[0].len() >= ylen, "luma plane too short");
+        assert!(f[1].len() >= clen && f[2].len() >= clen, "chroma plane too short");
+    }
+}
+
 /// Frames the caller owns as independent `Vec`s -- the shape the reference's own callers have (a fresh `Vec` per strip,
 /// `src/mcu.rs:238-250`; one `Vec<u8>` per decode, `src/decoder.rs:178`) -- decoded together: one pipelined pass over the
 /// GPU instead of one launch per frame (`zj_decode_frames`).  `frames[f]` = `[y, cb, cr]` coefficient planes of frame `f`.
@@ -255,10 +267,7 @@ pub fn decode_frames(d: &zj_frame_desc, frames: &[[&[i16]; 3]]) -> Vec<Vec<u8>> 
     let cb: Vec<*const i16> = frames.iter().map(|f| f[1].as_ptr()).collect();
     let cr: Vec<*const i16> = frames.iter().map(|f| f[2].as_ptr()).collect();
     let o: Vec<*mut u8> = outs.iter_mut().map(|v| v.as_mut_ptr()).collect();
-    for f in frames {
-        assert!(f[0].len() >= unsafe { zj_plane_len(d, 0) }, "luma plane too short");
-        if d.in_components == 3 { assert!(f[1].len() >= unsafe { zj_plane_len(d, 1) } && f[2].len() >= unsafe { zj_plane_len(d, 2) }, "chroma plane too short"); }
-    }
+    check_plane_lengths(d, frames);
     check(unsafe { zj_decode_frames(zj_default_ctx(), d, frames.len(), y.as_ptr(), cb.as_ptr(), cr.as_ptr(), o.as_ptr()) },
           "zj_decode_frames");
     outs
@@ -295,6 +304,7 @@ impl Multi {
         let cb: Vec<*const i16> = frames.iter().map(|f| f[1].as_ptr()).collect();
         let cr: Vec<*const i16> = frames.iter().map(|f| f[2].as_ptr()).collect();
         let o: Vec<*mut u8> = outs.iter_mut().map(|v| v.as_mut_ptr()).collect();
+        check_plane_lengths(d, frames);
         let mut statuses = vec![0 as c_int; self.slots()];
         let rc = unsafe { zj_multi_decode_frames(self.m, d, frames.len(), y.as_ptr(), cb.as_ptr(), cr.as_ptr(), o.as_ptr(),
                                                  statuses.as_mut_ptr()) };

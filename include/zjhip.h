@@ -421,8 +421,12 @@ ZJ_API int zj_sync(zj_ctx *ctx);
 
 /* ---- tuning knobs (every setting produces the same bytes) ------------------------------------ */
 /* generation of the fused kernel: 0 = packed IDCT + staged stores (default), 1 = wide (24-bit multiplies, per-lane
- * stores), 2 = packed with direct stores.  Also settable per process with ZJ_VARIANT. */
+ * stores; only in a `make VARIANTS=all` build), 2 = packed with direct stores.  Also settable per process with ZJ_VARIANT. */
 ZJ_API int zj_set_variant(zj_ctx *ctx, int variant);
+/* 1 if this build of the library carries the variant.  The default build is the product: 0 and 2.  Variant 1 (round 1's
+ * generation, the A/B baseline and the parity suite's N-version cross-check) comes with `make VARIANTS=all`; without it
+ * zj_set_variant(ctx, 1) returns ZJ_ERR_UNSUPPORTED. */
+ZJ_API int zj_variant_available(int variant);
 /* 0 = zj_decode_planes_batch runs upload / kernel / download back to back instead of overlapped on three streams */
 ZJ_API int zj_set_pipeline(zj_ctx *ctx, int on);
 

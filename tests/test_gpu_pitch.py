@@ -5,6 +5,7 @@ there.  A pitch that is a multiple of 128 bytes is what the layout exists for (D
 legal too."""
 import ctypes as C
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -20,7 +21,15 @@ def zj():
     return importlib.import_module("zune-jpeg_amd")
 
 
-@pytest.fixture(scope="module", params=[0, 1, 2], ids=["packed", "wide", "packed-direct"])
+def _variants():
+    """the kernel variants the library under test carries: the product build has 0 (packed, staged stores) and 2 (packed,
+    direct stores); `make VARIANTS=all` adds 1 (round 1's wide generation), the N-version cross-check of earlier rounds"""
+    names = {0: "packed", 1: "wide", 2: "packed-direct"}
+    have = importlib.import_module("zune-jpeg_amd").variants_available()
+    return have, [names[v] for v in have]
+
+
+@pytest.fixture(scope="module", params=_variants()[0], ids=_variants()[1])
 def ctx(zj, request):
     c = zj.Context(zj.BACKEND_HIP, 0)
     c.set_variant(request.param)
@@ -236,3 +245,42 @@ def test_random_descriptors_the_gpu_and_the_emulation_agree(zj, synth):
     finally:
         ctx.close()
     assert verdicts.get(0, 0) > 30 and verdicts.get(-1, 0) > 20, verdicts
+
+
+def test_scan_entry_points_refuse_a_padded_pitch_for_host_outputs(zj, synth):
+    """ADVICE r5: zj_decode_scan / zj_decode_scans copy pitch x height bytes out of a reused staging arena for a host output;
+    the kernels never write the padding, so stale pixels of earlier decodes would travel.  A padded pitch is a device-only
+    layout (include/zjhip.h): refused for host outputs, served for device outputs."""
+    import ctypes as C
+    data = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "test-baseline.jpg"), "rb").read()
+    ctx = zj.Context(zj.BACKEND_HIP, 0)
+    o = zj.ZuneJpegOptions()
+    o.entropy = zj.ENTROPY_GPU_ALWAYS
+    dec = zj.Decoder(o, ctx)
+    try:
+        desc, info = dec.prepare(data)
+        blob = dec.scan_blob()
+        assert blob is not None
+        tight, rc, st = ctx.decode_scan(desc, blob)
+        assert rc == 0
+        padded = zj.FrameDesc.make(info.width, info.height, info.h_max, info.v_max, 3, zj.ColorSpace.RGB,
+                                   list(np.ctypeslib.as_array(desc.qt)), out_pitch=3 * info.width + 128)
+        with pytest.raises(zj.ZjError) as e:
+            ctx.decode_scan(padded, blob)
+        assert e.value.status == -2                                   # ZJ_ERR_UNSUPPORTED
+        out_len = zj.lib().zj_out_len(C.byref(padded))
+        buf = ctx.device_alloc(out_len)
+        try:
+            zj.lib().zj_device_memset(ctx.handle, buf, 0x5A, out_len)
+            _, rc, st = ctx.decode_scan(padded, blob, device_out=buf)
+            assert rc == 0
+            ctx.sync()
+            got = np.empty(out_len, np.uint8)
+            ctx.d2h(got, buf)
+            rows = got.reshape(info.height, 3 * info.width + 128)
+            assert np.array_equal(rows[:, :3 * info.width].reshape(-1), tight) and (rows[:, 3 * info.width:] == 0x5A).all()
+        finally:
+            ctx.device_free(buf)
+    finally:
+        dec.close()
+        ctx.close()

@@ -9,7 +9,7 @@ class Lab:
     def __init__(self, device=0):
         p = os.path.join(ROOT, "zune-jpeg_amd", "libzjlab.so")
         if not os.path.exists(p):
-            raise ImportError(f"{p} not found: make -C zune-jpeg_amd/csrc")
+            raise ImportError(f"{p} not found: make -C zune-jpeg_amd/csrc lab")
         L = self.L = C.CDLL(p)
         vp, f = C.c_void_p, C.POINTER(C.c_float)
         L.zjlab_create.restype = vp

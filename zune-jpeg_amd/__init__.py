@@ -12,5 +12,5 @@ from .host import (  # noqa: F401
     ENTROPY_CPU, ENTROPY_GPU, ENTROPY_GPU_ALWAYS, HUFF_ST, RETRY_CPU, FileBatchDecoder, ImageInfo, Pool, ZjError,
     ZuneJpegOptions, abi_symbols, choose_idct_func, choose_upsample_func,
     choose_ycbcr_to_rgb_convert_func, device_count, finish_pixels_batch, lib, lib_path, num_components,
-    SCATTER_MAX, Multi, pointer_device, shard_range, device_numa_node, bind_thread_near_device, thread_numa_node,
+    SCATTER_MAX, Multi, pointer_device, shard_range, device_numa_node, bind_thread_near_device, thread_numa_node, variants_available,
 )

@@ -164,12 +164,18 @@ zj_ctx* zj_ctx_create(int backend, int device, int* status)
     zj_ctx* c = new (std::nothrow) zj_ctx();
     if (!c) { *status = ZJ_ERR_NOMEM; return nullptr; }
     c->device = device;
-    if (const char* e = getenv("ZJ_VARIANT")) { int v = atoi(e); if (v >= 0 && v <= 2) c->variant = v; }
+    if (const char* e = getenv("ZJ_VARIANT")) { int v = atoi(e); if (v >= 0 && v <= 2 && (v != 1 || fused_has_wide())) c->variant = v; }
     {
         hipDeviceProp_t prop;
         c->cus = hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         c->stagger_delay = 16;                        // x 128 cycles per slot group; 0 = off (ZJ_STAGGER: the escape hatch)
-        if (const char* e = getenv("ZJ_STAGGER")) { const int v = atoi(e); if (v >= 0 && v < 256) c->stagger_delay = v; }
+        // ZJ_STAGGER = 0..255 (round 4's "delay + 256 * mode" encoding is gone: anything else is refused aloud, not ignored)
+        if (const char* e = getenv("ZJ_STAGGER")) {
+            char* end = nullptr;
+            const long v = strtol(e, &end, 10);
+            if (end != e && *end == 0 && v >= 0 && v < 256) c->stagger_delay = (int)v;
+            else fprintf(stderr, "libzjhip: ZJ_STAGGER=%s is out of range (0..255, 0 = off); keeping %d\n", e, c->stagger_delay);
+        }
     }
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
@@ -368,7 +374,7 @@ int zj_sync(zj_ctx* c)
 }
 
 // The launch itself, shared by the contiguous / strided form and the scattered form.
-static int launch_params(zj_ctx* c, const Plan& pl, Params& p, hipStream_t s)
+static int launch_params(zj_ctx* c, const Plan& pl, Params& p, hipStream_t s, bool may_stagger = true)
 {
 #if defined(ZJ_ABLATION)
     p.debug = c->debug;
@@ -378,7 +384,9 @@ static int launch_params(zj_ctx* c, const Plan& pl, Params& p, hipStream_t s)
     // frame (profiles/r04_single_frame.txt).  That is the only regime it was measured in, so it is the only one that gets
     // it: a grid smaller than one wave of workgroups, or longer than two, starts as the hardware dispatches it.  The slots
     // per CU are the occupancy of the instantiation that is launched, not a constant.
-    if (c->stagger_delay > 0 && pl.hs == 2 && pl.vs == 2 && pl.out != OUT_GRAY && c->variant != 1) {
+    // (may_stagger false: the units of the pipelined host path -- strip ranges of a frame that overlap with copies on two
+    // other streams; a unit can land in the 1..2-wave window, but nobody has measured the stagger there)
+    if (may_stagger && c->stagger_delay > 0 && pl.hs == 2 && pl.vs == 2 && pl.out != OUT_GRAY && c->variant != 1) {
         const int slots = pl.fast ? fused_slots_per_cu(pl.hs, pl.vs, pl.out, c->variant, 1, p) : 0;
         const int wgs = c->cus * slots;
         if (slots >= 2 && p.total_tiles > wgs && p.total_tiles <= 2 * wgs) {
@@ -738,7 +746,7 @@ static int decode_planes_batch_impl(zj_ctx* c, const zj_frame_desc* d, const Pla
                 p.height = (int)d->height - (int)s0 * pl.strip_rows;
                 set_grid(p, 1, (int)(s1 - s0), pl.tiles_per_row);
             }
-            if ((rc = launch_params(c, pl, p, c->s_run))) return rc;
+            if ((rc = launch_params(c, pl, p, c->s_run, whole))) return rc;
             ZJ_HIP(c, hipEventRecord(sl.run_done, c->s_run));
             // down
             ZJ_HIP(c, hipStreamWaitEvent(c->s_down, sl.run_done, 0));
@@ -927,6 +935,9 @@ int scan_setup(zj_ctx* c, ScanJob& j, int slot, const zj_frame_desc* d, const vo
     if (!scan_header_ok(h, blob_bytes)) return ZJ_ERR_ARG;
     int rc = make_plan(d, j.pl);
     if (rc) return rc;
+    // a padded pitch is a layout for outputs that stay in HBM (include/zjhip.h): the host copy moves pitch x height bytes out
+    // of a reused staging arena, and the kernels never write the padding -- stale pixels of earlier decodes would go along
+    if (!out_on_device && j.pl.out_pitch != j.pl.row_bytes) return ZJ_ERR_UNSUPPORTED;
     j.d = d; j.h = h; j.blob = blob; j.blob_bytes = blob_bytes; j.out = out; j.slot = slot;
     j.chroma = h->ncomp == 3;
     j.ylen = zj_plane_len(d, 0);
@@ -1369,7 +1380,14 @@ zj_color_convert16_fn zj_choose_ycbcr_to_rgb_convert_func(int backend, int out_c
 }
 
 /* kernel-variant switch for A/B measurements (both variants are bit-exact) */
-int zj_set_variant(zj_ctx* c, int variant) { if (!c || variant < 0 || variant > 2) return ZJ_ERR_ARG; c->variant = variant; return ZJ_OK; }
+int zj_variant_available(int variant) { return variant == 0 || variant == 2 || (variant == 1 && fused_has_wide()) ? 1 : 0; }
+int zj_set_variant(zj_ctx* c, int variant)
+{
+    if (!c || variant < 0 || variant > 2) return ZJ_ERR_ARG;
+    if (variant == 1 && !fused_has_wide()) return ZJ_ERR_UNSUPPORTED; // round 1's generation: `make VARIANTS=all` builds (tests, A/B)
+    c->variant = variant;
+    return ZJ_OK;
+}
 /* 0 = one unit per zj_decode_planes_batch call (no copy/compute overlap); A/B timing only */
 int zj_set_pipeline(zj_ctx* c, int on) { if (!c) return ZJ_ERR_ARG; c->pipeline = on ? 1 : 0; return ZJ_OK; }
 } // extern "C"

@@ -9,6 +9,7 @@
 //   zj_upsample_{h,v}_kernel    UpSampler-compatible flat-array filters (src/upsampler/scalar.rs)
 //   zj_rgb16_kernel             ColorConvert16Ptr (src/color_convert/scalar.rs:52)
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdio.h>
 
 #include "zj_device.h"
@@ -305,8 +306,12 @@ static hipError_t launch_fused_t(const Params& p, int variant, int fast, hipStre
     }
     if (fast == 2) fast = 0; // (the wide generation has no ragged form)
     if (gen == GEN_WIDE) {
+#if defined(ZJ_VARIANTS_ALL)
         if (fast) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, GEN_WIDE, true, false>), grid, block, dyn, s, p);
         else hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, GEN_WIDE, false, false>), grid, block, dyn, s, p);
+#else
+        return hipErrorNotSupported; // (the product build leaves round 1's generation out: make VARIANTS=all)
+#endif
     } else if (!fast) hipLaunchKernelGGL((zj_fused_kernel<HS, VS, OUT, GEN_PACKED, false, false>), grid, block, dyn, s, p);
     else if (ts && TSC && seam_launch<C>(p)) {
         if constexpr (ZJ_SEAM_WB != 0 && C::YBR == 4 && TSC) hipLaunchKernelGGL((zj_fused_seam_kernel<HS, VS, OUT>), grid, block, dyn, s, p); // (the only shapes seam_launch admits)
@@ -328,6 +333,16 @@ hipError_t launch_fused(int hs, int vs, int out, int variant, int fast, const Pa
     return hipErrorInvalidValue;
 }
 
+// does this build carry round 1's kernel generation (variant 1: the A/B and N-version cross-check)?  make VARIANTS=all
+bool fused_has_wide()
+{
+#if defined(ZJ_VARIANTS_ALL)
+    return true;
+#else
+    return false;
+#endif
+}
+
 // workgroups of the instantiation launch_fused() picks that fit one CU (occupancy query, once per instantiation)
 template <int HS, int VS, int OUT>
 static int slots_t(const Params& p, int variant, int fast)
@@ -336,19 +351,34 @@ static int slots_t(const Params& p, int variant, int fast)
     int gen; bool ts;
     pick(variant, OUT, fast != 0, ts_eligible<C>(p, OUT, fast != 0), gen, ts);
     constexpr bool TSC = C::TSCAP;
-    static int cache[6] = {0, 0, 0, 0, 0, 0}; // 0 = not asked yet, -1 = the query failed
+    // 0 = not asked yet, -1 = the query failed.  Per device (a node may mix parts) and atomic: launch_params asks on every
+    // 4:2:0 launch, from zj_multi's slot threads and the pool's submitters at once (two threads asking first both store the
+    // same answer)
+    constexpr int MAX_DEV = 64;
+    static std::atomic<int> cache_all[MAX_DEV][6];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) dev = 0;
+    std::atomic<int>* const cache = cache_all[dev];
     const int which = gen == GEN_WIDE ? (fast ? 0 : 1) : (!fast ? 2 : ((ts && TSC) ? 3 : 4));
-    if (cache[which] == 0) {
+    int have = cache[which].load(std::memory_order_relaxed);
+    if (have == 0) {
         int n = 0;
         hipError_t e;
+#if defined(ZJ_VARIANTS_ALL)
         if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zj_fused_kernel<HS, VS, OUT, GEN_WIDE, true, false>, C::NT, 0);
         else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zj_fused_kernel<HS, VS, OUT, GEN_WIDE, false, false>, C::NT, 0);
-        else if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zj_fused_kernel<HS, VS, OUT, GEN_PACKED, false, false>, C::NT, 0);
+        else
+#else
+        if (which < 2) e = hipErrorNotSupported;
+        else
+#endif
+        if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zj_fused_kernel<HS, VS, OUT, GEN_PACKED, false, false>, C::NT, 0);
         else if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zj_fused_kernel<HS, VS, OUT, GEN_PACKED, true, TSC>, C::NT, 0);
         else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zj_fused_kernel<HS, VS, OUT, GEN_PACKED, true, false>, C::NT, 0);
-        cache[which] = (e == hipSuccess && n > 0) ? n : -1;
+        have = (e == hipSuccess && n > 0) ? n : -1;
+        cache[which].store(have, std::memory_order_relaxed);
     }
-    return cache[which] > 0 ? cache[which] : 0;
+    return have > 0 ? have : 0;
 }
 
 int fused_slots_per_cu(int hs, int vs, int out, int variant, int fast, const Params& p)
@@ -367,8 +397,8 @@ static bool seam_t(const Params& p) { return seam_launch<Cfg<HS, VS, OUT>>(p); }
 const char* fused_kernel_name(int hs, int vs, int out, int variant, int fast, const Params& p)
 {
     // the demangled name rocprofv3 prints for the instantiation launch_fused() picks
-    static char buf[8][112];
-    static int slot = 0;
+    thread_local char buf[8][112];
+    thread_local int slot = 0;
     char* b = buf[slot++ & 7];
     bool ok = false;
 #define ZJ_CASE(H, V, O) if (hs == H && vs == V && out == O) ok = ts_ok_t<H, V, O>(p, fast);

@@ -7,6 +7,7 @@
 
 namespace zj {
 hipError_t launch_fused(int hs, int vs, int out, int variant, int fast, const Params& p, hipStream_t s);
+bool fused_has_wide(); // built with VARIANTS=all
 #if defined(ZJ_ABLATION)
 void set_pad_lds(int bytes);
 int fused_occupancy_420_rgb(int pad_lds);

@@ -152,7 +152,7 @@ ABI = [  # every symbol include/zjhip.h declares
     "zj_decoder_decode_coefficients", "zj_decoder_finish_pixels", "zj_decoder_decode_buffer",
     "zj_decoder_parallel_segments",
     "zj_pool_create", "zj_pool_destroy", "zj_pool_threads", "zj_pool_error", "zj_pool_stats",
-    "zj_pool_decode_files", "zj_set_variant", "zj_set_pipeline",
+    "zj_pool_decode_files", "zj_set_variant", "zj_variant_available", "zj_set_pipeline",
     "zj_decode_frames", "zj_decode_planes_device_strided", "zj_decode_frames_device", "zj_pointer_device",
     "zj_pool_create_multi", "zj_pool_devices", "zj_pool_device_stats",
     "zj_shard_range", "zj_multi_create", "zj_multi_destroy", "zj_multi_devices", "zj_multi_ctx", "zj_multi_slot_stats",
@@ -278,6 +278,7 @@ def lib():
     L.zj_pool_decode_files_device.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp]
     L.zj_set_pipeline.argtypes = [vp, C.c_int]
     L.zj_set_variant.argtypes = [vp, C.c_int]
+    L.zj_variant_available.argtypes = [C.c_int]
     L.zj_decode_frames.argtypes = [vp, C.POINTER(FrameDesc), sz, vp, vp, vp, vp]
     L.zj_decode_planes_device_strided.argtypes = [vp, C.POINTER(FrameDesc), sz, vp, vp, vp, vp, sz, sz, sz, vp]
     L.zj_decode_frames_device.argtypes = [vp, C.POINTER(FrameDesc), sz, vp, vp, vp, vp, vp]
@@ -789,6 +790,11 @@ def bind_thread_near_device(device=0):
 
 def thread_numa_node():
     return lib().zj_thread_numa_node()
+
+
+def variants_available():
+    """Kernel variants this build of libzjhip.so carries: [0, 2], plus 1 when it was built with `make VARIANTS=all`."""
+    return [v for v in (0, 1, 2) if lib().zj_variant_available(v)]
 
 
 def pointer_device(p):

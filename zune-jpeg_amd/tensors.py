@@ -61,7 +61,16 @@ def decode_to_tensor(ctx, desc, planes, nframes=1, stream=None):
     synchronises as with any other kernel on that stream."""
     import torch
     dev = planes[0].device
-    s = stream if stream is not None else torch.cuda.current_stream(dev)
-    storage, view = output_tensor(desc, nframes, dev)
+    cur = torch.cuda.current_stream(dev)
+    s = stream if stream is not None else cur
+    # The output is allocated (and, with a fill, written) under `s`, so that the caching allocator ties the block to the
+    # stream the kernel writes it on: allocated under another stream it could be handed out again while the launch is
+    # still pending.  The planes were produced on the caller's current stream: `s` waits for it before the launch.
+    with torch.cuda.stream(s):
+        storage, view = output_tensor(desc, nframes, dev)
+    if s != cur:
+        s.wait_stream(cur)
+        for p in planes:
+            p.record_stream(s)
     ctx.decode_planes_device(desc, nframes, planes[0].data_ptr(), planes[1].data_ptr(), planes[2].data_ptr(), storage.data_ptr(), s.cuda_stream)
     return view
