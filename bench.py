@@ -368,8 +368,12 @@ def reference_files(zj, ctx, reps=5):
     tests/golden/) through Decoder: entropy stage on ONE host thread (baseline: the MCU walk of src/mcu.rs:231-351;
     progressive: the 10-scan coefficient accumulation of src/mcu_prog.rs:49) into pinned planes, then the pixel path on the
     GPU (upload, fused kernel, download).  The output must hash to what tests/golden/ref_images.json records."""
+    import ctypes as C
     import hashlib
     import numpy as np
+    zj.lib().zj_alloc_pinned.restype = C.c_void_p
+    zj.lib().zj_alloc_pinned.argtypes = [C.c_size_t]
+    zj.lib().zj_free_pinned.argtypes = [C.c_void_p]
     out = {}
     try:
         rec = {r["file"]: r for r in json.load(open(os.path.join(ROOT, "tests", "golden", "ref_images.json")))["files"]}
@@ -391,6 +395,28 @@ def reference_files(zj, ctx, reps=5):
                 px = dec.finish_pixels(px)
                 t2 = time.perf_counter()
                 host, gpu = min(host, t1 - t0), min(gpu, t2 - t1)
+            # the whole call a drop-in caller makes -- Decoder::decode_buffer, src/decoder.rs:178 -- into pinned pixels: for a
+            # baseline file the strips go to the GPU while the walker is still in later rows (zj_frame_*; ZJ_STREAM=off: first
+            # all of the Huffman stage, then upload + kernel + download)
+            whole = {}
+            pin = zj.lib().zj_alloc_pinned(r["width"] * r["height"] * 3)
+            try:
+                pout = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint8)), shape=(r["width"] * r["height"] * 3,))
+                for key, env in (("decode_buffer_ms", None), ("decode_buffer_ms_stages_apart", "off")):
+                    if env:
+                        os.environ["ZJ_STREAM"] = env
+                    try:
+                        best = 1e9
+                        for _ in range(reps + 1):
+                            t0 = time.perf_counter()
+                            got = dec.decode_buffer(data, out=pout)
+                            best = min(best, time.perf_counter() - t0)
+                        whole[key] = round(best * 1e3, 3)
+                        whole[key.replace("_ms", "_matches")] = bool(np.array_equal(got, px))
+                    finally:
+                        os.environ.pop("ZJ_STREAM", None)
+            finally:
+                zj.lib().zj_free_pinned(pin)
             dec.close()
             mp = r["width"] * r["height"] / 1e6
             blocks = 3 * ((r["width"] + 7) // 8) * ((r["height"] + 7) // 8)  # 4:4:4: three planes of (w/8) x (h/8) blocks
@@ -399,6 +425,7 @@ def reference_files(zj, ctx, reps=5):
                          "megapixels_per_s": round(mp / (host + gpu), 1), "scans": r["scans"], "progressive": bool(r["progressive"]),
                          "width": r["width"], "height": r["height"],
                          "sha256_matches_golden": hashlib.sha256(np.ascontiguousarray(px).tobytes()).hexdigest() == r["sha256_rgb"]}
+            out[name].update(whole)
         except Exception as e:  # noqa: BLE001
             out[name] = {"error": repr(e)[:200]}
     out["what"] = ("the reference's test-images/*.jpg (1920x1080 4:4:4): Huffman / progressive accumulation on one host thread into "

@@ -144,6 +144,11 @@ extern "C" {
     pub fn zj_choose_idct_func(backend: c_int) -> Option<zj_idct_fn>;
     pub fn zj_choose_upsample_func(backend: c_int, h_max: c_int, v_max: c_int) -> Option<zj_upsample_fn>;
     pub fn zj_choose_ycbcr_to_rgb_convert_func(backend: c_int, out_cs: c_int) -> Option<zj_color_convert16_fn>;
+    pub fn zj_frame_begin(ctx: *mut zj_ctx, d: *const zj_frame_desc, y: *const i16, cb: *const i16, cr: *const i16,
+                          out: *mut u8, out_on_device: c_int) -> c_int;
+    pub fn zj_frame_rows_ready(ctx: *mut zj_ctx, mcu_rows: usize) -> c_int;
+    pub fn zj_frame_end(ctx: *mut zj_ctx) -> c_int;
+    pub fn zj_frame_abort(ctx: *mut zj_ctx) -> c_int;
     pub fn zj_decode_planes_to_device(ctx: *mut zj_ctx, d: *const zj_frame_desc, y: *const i16, cb: *const i16,
                                       cr: *const i16, d_out: *mut u8) -> c_int;
     pub fn zj_time_decode_device(ctx: *mut zj_ctx, d: *const zj_frame_desc, nframes: usize, d_y: *const i16,

@@ -236,6 +236,22 @@ ZJ_API int zj_time_decode_device(zj_ctx *ctx, const zj_frame_desc *d, size_t nfr
                           const int16_t *d_cb, const int16_t *d_cr, uint8_t *d_out, void *stream,
                           int iters, float *ms_total, float *ms_each, const char **kernel_name);
 
+/* ---- ONE frame whose planes are still being written (round 6): strips go to the GPU as they become final ----------------
+ * The reference runs post_process on strip N while its Huffman decoder is in strip N + 1 (src/mcu.rs:356-368: the strip is
+ * handed to a pool thread).  zj_frame_begin names the frame's planes and output; zj_frame_rows_ready(ctx, n) says that the
+ * coefficients of MCU rows [0, n) are final (n only grows; call it as often as convenient); the strips that became complete
+ * go through the three-stream pipeline in units of an eighth of the frame (at least 4 MB of coefficients, ZJ_STREAM_UNIT_MB)
+ * while the caller fills later rows; zj_frame_end submits what is left and waits for the pixels.  All calls but
+ * zj_frame_end return at once when the planes are pinned (zj_alloc_pinned).  Output: a device pointer (out_on_device), pinned
+ * host memory (downloads overlap as well), or pageable host memory (decoded into a device buffer, copied once at the end).
+ * One such frame at a time per context, and no other call on the context in between.  Same bytes as zj_decode_planes.
+ * ZJ_ERR_UNSUPPORTED: ZJ_LAYOUT_CHW, a padded out_pitch with a host output.  zj_decoder_decode_buffer uses this for baseline
+ * files when the decoder's planes are pinned (zj_options.pinned_planes); ZJ_STREAM=off keeps the two stages apart. */
+ZJ_API int zj_frame_begin(zj_ctx *ctx, const zj_frame_desc *d, const int16_t *y, const int16_t *cb, const int16_t *cr,
+                          uint8_t *out, int out_on_device);
+ZJ_API int zj_frame_rows_ready(zj_ctx *ctx, size_t mcu_rows);
+ZJ_API int zj_frame_end(zj_ctx *ctx);
+ZJ_API int zj_frame_abort(zj_ctx *ctx);   /* drains what is in flight; the output's content is undefined */
 /* Host planes -> pixels that stay in HBM (d_out: device pointer, 16-byte aligned). Synchronous. */
 ZJ_API int zj_decode_planes_to_device(zj_ctx *ctx, const zj_frame_desc *d, const int16_t *y, const int16_t *cb,
                                const int16_t *cr, uint8_t *d_out);

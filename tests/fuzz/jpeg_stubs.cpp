@@ -19,6 +19,10 @@ int zj_decode_planes_to_device(zj_ctx*, const zj_frame_desc*, const int16_t*, co
 int zj_decode_scan(zj_ctx*, const zj_frame_desc*, const void*, size_t, uint8_t*, int, unsigned*) { return ZJ_ERR_NO_DEVICE; }
 int zj_decode_scans(zj_ctx*, size_t, const zj_frame_desc*, const void* const*, const size_t*, uint8_t* const*, int, int*, unsigned*) { return ZJ_ERR_NO_DEVICE; }
 int zj_device_memset(zj_ctx*, void*, int, size_t) { return ZJ_ERR_NO_DEVICE; }
+int zj_frame_begin(zj_ctx*, const zj_frame_desc*, const int16_t*, const int16_t*, const int16_t*, uint8_t*, int) { return ZJ_ERR_NO_DEVICE; }
+int zj_frame_rows_ready(zj_ctx*, size_t) { return ZJ_ERR_NO_DEVICE; }
+int zj_frame_end(zj_ctx*) { return ZJ_ERR_NO_DEVICE; }
+int zj_frame_abort(zj_ctx*) { return ZJ_OK; }
 const char* zj_strerror(int) { return "stub"; }
 const char* zj_last_error(const zj_ctx*) { return ""; }
 }

@@ -116,6 +116,8 @@ def test_single_rank_line_has_the_contract_fields():
         assert rfiles[name]["sha256_matches_golden"] is True and rfiles[name]["progressive"] is prog
         assert rfiles[name]["host_entropy_ms"] > 0 and rfiles[name]["gpu_pixels_ms"] > 0
         assert rfiles[name]["blocks"] == 97200 and rfiles[name]["planes"] == "pinned" and rfiles[name]["host_threads"] == 1
+        assert rfiles[name]["decode_buffer_matches"] is True and rfiles[name]["decode_buffer_stages_apart_matches"] is True
+        assert rfiles[name]["decode_buffer_ms"] > 0 and rfiles[name]["decode_buffer_ms_stages_apart"] > 0
         assert abs(rfiles[name]["ns_per_block"] - rfiles[name]["host_entropy_ms"] * 1e6 / 97200) < 0.2
     # round 6: the baseline walker no longer loses to the ten-scan progressive file on the same thread (it did, 17.8 vs 3.6 ms,
     # while its blocks left through non-temporal stores: profiles/r06_feeder_ab.txt)

@@ -124,7 +124,7 @@ def main():
         layout = 1 if (out_cs == oc.RGB and rng.random() < 0.15) else 0
         if out_cs == oc.RGBA or layout == 1:
             flags |= 0  # (RGBA / CHW place every pixel at its own position whatever the flags say)
-        variant = int(rng.integers(0, 3))
+        variant = int(rng.choice(zj.variants_available()))  # (the product build: 0 and 2; make VARIANTS=all adds 1)
         adversarial = rng.random() < 0.3
         path = ["batch", "frames", "frames_device", "strided", "multi"][int(rng.integers(0, 5))]
         nframes = int(rng.integers(1, 4)) if w * h < 200_000 else 1

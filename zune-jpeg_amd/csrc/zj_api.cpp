@@ -46,6 +46,17 @@ struct zj_ctx {
     PipeSlot slots[N_SLOTS];
     hipStream_t s_up = nullptr, s_run = nullptr, s_down = nullptr;
     int pipeline = 1;             // 0: one unit per call (no overlap), for A/B timing only
+    // a frame whose planes are still being written (zj_frame_begin ... zj_frame_end)
+    struct FrameStream {
+        bool active = false;
+        zj_frame_desc d;
+        const int16_t* y = nullptr; const int16_t* cb = nullptr; const int16_t* cr = nullptr;
+        uint8_t* out = nullptr;
+        int on_device = 0;
+        bool staged = false;      // host output in pageable memory: decoded into a device buffer, ONE copy at the end (an
+                                  // asynchronous copy into pageable memory blocks its caller until the data has arrived)
+        size_t submitted = 0, unit = 1, units = 0; // strips handed to the GPU so far | strips per unit | units so far
+    } fs;
     std::string last_error;
 #if defined(ZJ_ABLATION)
     int debug = 0;                // ablation switches, diagnostic build only (results are WRONG when set)
@@ -653,6 +664,85 @@ int zj_decode_frames(zj_ctx* c, const zj_frame_desc* d, size_t nframes, const in
     return batch_guard(c, decode_planes_batch_impl(c, d, pl, nframes, hf));
 }
 
+// One unit of the three-stream host pipeline: strips [s0, s1) of frames [f0, f0 + nfr) -- whole frames (s0 == 0, s1 == n_strips)
+// or a strip range of ONE frame -- uploaded on s_up, decoded on s_run, and (d_out null) downloaded on s_down into the host
+// frames' pixels, or (d_out: the frame's device output) decoded straight into place with no copy back.  `u` numbers the units
+// of the call: unit u uses buffer set u % N_SLOTS.
+static int submit_unit(zj_ctx* c, const zj_frame_desc* d, const Plan& pl, const HostFrames& hf, size_t f0, size_t nfr, size_t s0, size_t s1,
+                       size_t u, size_t covered, uint8_t* d_out)
+{
+    int rc;
+    const bool chroma = pl.out != OUT_GRAY;
+    const int mrps = pl.hs == 2 ? 2 : 1;                                     // MCU rows per strip
+    const size_t ystrip = (size_t)pl.mcu_x * 64 * pl.hs * pl.vs * mrps;      // i16 per strip
+    const size_t cstrip = (size_t)pl.mcu_x * 64 * mrps;
+    const size_t ostrip = (size_t)d->width * pl.ncomp_out * pl.strip_rows;   // bytes per strip
+    const size_t covered_bytes = covered * d->width * pl.ncomp_out;
+    const bool planar = pl.out == OUT_RGB_CHW;
+    const bool whole = s0 == 0 && s1 == (size_t)pl.n_strips;
+    PipeSlot& sl = c->slots[u % N_SLOTS];
+    // unit extents: whole frames keep the frame strides; a strip range is one short "frame"
+    const size_t yel = whole ? nfr * pl.y_len : (s1 - s0) * ystrip;
+    const size_t cel = whole ? nfr * pl.c_len : (s1 - s0) * cstrip;
+    size_t obytes = whole ? nfr * pl.out_len : (s1 - s0) * ostrip;
+    if (!whole && s0 * ostrip + obytes > covered_bytes) obytes = covered_bytes - s0 * ostrip;
+    if ((rc = ensure_slot(c, sl, 0, yel * 2))) return rc;
+    if (chroma && ((rc = ensure_slot(c, sl, 1, cel * 2)) || (rc = ensure_slot(c, sl, 2, cel * 2)))) return rc;
+    if (!d_out && (rc = ensure_slot(c, sl, 3, whole ? nfr * pl.out_len : (s1 - s0) * ostrip))) return rc;
+    // up: the slot's planes are free once the kernel of its previous unit has run
+    if (sl.used) ZJ_HIP(c, hipStreamWaitEvent(c->s_up, sl.run_done, 0));
+    if (!whole || hf.packed()) {
+        const size_t yo = whole ? 0 : s0 * ystrip, co = whole ? 0 : s0 * cstrip;
+        ZJ_HIP(c, hipMemcpyAsync(sl.buf[0], hf.Y(f0) + yo, yel * 2, hipMemcpyHostToDevice, c->s_up));
+        if (chroma) {
+            ZJ_HIP(c, hipMemcpyAsync(sl.buf[1], hf.Cb(f0) + co, cel * 2, hipMemcpyHostToDevice, c->s_up));
+            ZJ_HIP(c, hipMemcpyAsync(sl.buf[2], hf.Cr(f0) + co, cel * 2, hipMemcpyHostToDevice, c->s_up));
+        }
+    } else {
+        for (size_t f = 0; f < nfr; f++) {
+            ZJ_HIP(c, hipMemcpyAsync((int16_t*)sl.buf[0] + f * pl.y_len, hf.Y(f0 + f), pl.y_len * 2, hipMemcpyHostToDevice, c->s_up));
+            if (chroma) {
+                ZJ_HIP(c, hipMemcpyAsync((int16_t*)sl.buf[1] + f * pl.c_len, hf.Cb(f0 + f), pl.c_len * 2, hipMemcpyHostToDevice, c->s_up));
+                ZJ_HIP(c, hipMemcpyAsync((int16_t*)sl.buf[2] + f * pl.c_len, hf.Cr(f0 + f), pl.c_len * 2, hipMemcpyHostToDevice, c->s_up));
+            }
+        }
+    }
+    ZJ_HIP(c, hipEventRecord(sl.up_done, c->s_up));
+    // run: after this unit's upload and after the slot's previous download has drained its pixels
+    ZJ_HIP(c, hipStreamWaitEvent(c->s_run, sl.up_done, 0));
+    if (sl.used && !d_out) ZJ_HIP(c, hipStreamWaitEvent(c->s_run, sl.down_done, 0));
+    Params p;
+    fill_params(d, pl, whole ? nfr : 1, (const int16_t*)sl.buf[0], (const int16_t*)sl.buf[1],
+                (const int16_t*)sl.buf[2], d_out ? d_out + (whole ? 0 : s0 * (size_t)pl.strip_rows * pl.out_pitch) : (uint8_t*)sl.buf[3], 1, p);
+    if (!whole) { // strips [s0, s1) of frame f0 as a frame of its own
+        p.height = (int)d->height - (int)s0 * pl.strip_rows;
+        set_grid(p, 1, (int)(s1 - s0), pl.tiles_per_row);
+    }
+    if ((rc = launch_params(c, pl, p, c->s_run, whole))) return rc;
+    ZJ_HIP(c, hipEventRecord(sl.run_done, c->s_run));
+    if (d_out) { sl.used = true; return ZJ_OK; } // the pixels are where they belong
+    // down
+    ZJ_HIP(c, hipStreamWaitEvent(c->s_down, sl.run_done, 0));
+    if (planar) { // the covered rows of every plane of every frame
+        for (size_t f = 0; f < nfr; f++)
+            for (size_t pc = 0; pc < 3; pc++) {
+                const size_t po = pc * (size_t)d->width * d->height;
+                ZJ_HIP(c, hipMemcpyAsync(hf.Out(f0 + f) + po, (uint8_t*)sl.buf[3] + f * pl.out_len + po, covered * d->width,
+                                         hipMemcpyDeviceToHost, c->s_down));
+            }
+    } else if (whole && (covered_bytes < pl.out_len || !hf.packed())) { // frame by frame, without the never-written rows
+        for (size_t f = 0; f < nfr; f++)
+            ZJ_HIP(c, hipMemcpyAsync(hf.Out(f0 + f), (uint8_t*)sl.buf[3] + f * pl.out_len, covered_bytes,
+                                     hipMemcpyDeviceToHost, c->s_down));
+    } else {
+        ZJ_HIP(c, hipMemcpyAsync(hf.Out(f0) + (whole ? 0 : s0 * ostrip), sl.buf[3], obytes,
+                                 hipMemcpyDeviceToHost, c->s_down));
+    }
+    ZJ_HIP(c, hipEventRecord(sl.down_done, c->s_down));
+    sl.used = true;
+    return ZJ_OK;
+}
+
 static int decode_planes_batch_impl(zj_ctx* c, const zj_frame_desc* d, const Plan& pl, size_t nframes, const HostFrames& hf)
 {
     // Host planes -> host pixels.  The batch is cut into units of about 16 MB of coefficients (ZJ_UNIT_MB) --
@@ -668,12 +758,7 @@ static int decode_planes_batch_impl(zj_ctx* c, const zj_frame_desc* d, const Pla
     if (pl.out_pitch != pl.row_bytes) return ZJ_ERR_UNSUPPORTED;
     ZJ_HIP(c, hipSetDevice(c->device));
     const bool chroma = pl.out != OUT_GRAY;
-    const int mrps = pl.hs == 2 ? 2 : 1;                                     // MCU rows per strip
-    const size_t ystrip = (size_t)pl.mcu_x * 64 * pl.hs * pl.vs * mrps;      // i16 per strip
-    const size_t cstrip = (size_t)pl.mcu_x * 64 * mrps;
-    const size_t ostrip = (size_t)d->width * pl.ncomp_out * pl.strip_rows;   // bytes per strip
     const size_t covered = (size_t)pl.rows_covered < d->height ? (size_t)pl.rows_covered : d->height;
-    const size_t covered_bytes = covered * d->width * pl.ncomp_out;
     // rows below the last complete strip are never written by the reference (Q6)
     {
         size_t off[3], len[3];
@@ -707,69 +792,128 @@ static int decode_planes_batch_impl(zj_ctx* c, const zj_frame_desc* d, const Pla
         const size_t nfr = f0 + group <= nframes ? group : nframes - f0;
         for (size_t s0 = 0; s0 < (size_t)pl.n_strips; s0 += strips_per_unit, u++) {
             const size_t s1 = s0 + strips_per_unit < (size_t)pl.n_strips ? s0 + strips_per_unit : (size_t)pl.n_strips;
-            const bool whole = s0 == 0 && s1 == (size_t)pl.n_strips;
-            PipeSlot& sl = c->slots[u % N_SLOTS];
-            // unit extents: whole frames keep the frame strides; a strip range is one short "frame"
-            const size_t yel = whole ? nfr * pl.y_len : (s1 - s0) * ystrip;
-            const size_t cel = whole ? nfr * pl.c_len : (s1 - s0) * cstrip;
-            size_t obytes = whole ? nfr * pl.out_len : (s1 - s0) * ostrip;
-            if (!whole && s0 * ostrip + obytes > covered_bytes) obytes = covered_bytes - s0 * ostrip;
-            if ((rc = ensure_slot(c, sl, 0, yel * 2))) return rc;
-            if (chroma && ((rc = ensure_slot(c, sl, 1, cel * 2)) || (rc = ensure_slot(c, sl, 2, cel * 2)))) return rc;
-            if ((rc = ensure_slot(c, sl, 3, whole ? nfr * pl.out_len : (s1 - s0) * ostrip))) return rc;
-            // up: the slot's planes are free once the kernel of its previous unit has run
-            if (sl.used) ZJ_HIP(c, hipStreamWaitEvent(c->s_up, sl.run_done, 0));
-            if (!whole || hf.packed()) {
-                const size_t yo = whole ? 0 : s0 * ystrip, co = whole ? 0 : s0 * cstrip;
-                ZJ_HIP(c, hipMemcpyAsync(sl.buf[0], hf.Y(f0) + yo, yel * 2, hipMemcpyHostToDevice, c->s_up));
-                if (chroma) {
-                    ZJ_HIP(c, hipMemcpyAsync(sl.buf[1], hf.Cb(f0) + co, cel * 2, hipMemcpyHostToDevice, c->s_up));
-                    ZJ_HIP(c, hipMemcpyAsync(sl.buf[2], hf.Cr(f0) + co, cel * 2, hipMemcpyHostToDevice, c->s_up));
-                }
-            } else {
-                for (size_t f = 0; f < nfr; f++) {
-                    ZJ_HIP(c, hipMemcpyAsync((int16_t*)sl.buf[0] + f * pl.y_len, hf.Y(f0 + f), pl.y_len * 2, hipMemcpyHostToDevice, c->s_up));
-                    if (chroma) {
-                        ZJ_HIP(c, hipMemcpyAsync((int16_t*)sl.buf[1] + f * pl.c_len, hf.Cb(f0 + f), pl.c_len * 2, hipMemcpyHostToDevice, c->s_up));
-                        ZJ_HIP(c, hipMemcpyAsync((int16_t*)sl.buf[2] + f * pl.c_len, hf.Cr(f0 + f), pl.c_len * 2, hipMemcpyHostToDevice, c->s_up));
-                    }
-                }
-            }
-            ZJ_HIP(c, hipEventRecord(sl.up_done, c->s_up));
-            // run: after this unit's upload and after the slot's previous download has drained its pixels
-            ZJ_HIP(c, hipStreamWaitEvent(c->s_run, sl.up_done, 0));
-            if (sl.used) ZJ_HIP(c, hipStreamWaitEvent(c->s_run, sl.down_done, 0));
-            Params p;
-            fill_params(d, pl, whole ? nfr : 1, (const int16_t*)sl.buf[0], (const int16_t*)sl.buf[1],
-                        (const int16_t*)sl.buf[2], (uint8_t*)sl.buf[3], 1, p);
-            if (!whole) { // strips [s0, s1) of frame f0 as a frame of its own
-                p.height = (int)d->height - (int)s0 * pl.strip_rows;
-                set_grid(p, 1, (int)(s1 - s0), pl.tiles_per_row);
-            }
-            if ((rc = launch_params(c, pl, p, c->s_run, whole))) return rc;
-            ZJ_HIP(c, hipEventRecord(sl.run_done, c->s_run));
-            // down
-            ZJ_HIP(c, hipStreamWaitEvent(c->s_down, sl.run_done, 0));
-            if (planar) { // the covered rows of every plane of every frame
-                for (size_t f = 0; f < nfr; f++)
-                    for (size_t pc = 0; pc < 3; pc++) {
-                        const size_t po = pc * (size_t)d->width * d->height;
-                        ZJ_HIP(c, hipMemcpyAsync(hf.Out(f0 + f) + po, (uint8_t*)sl.buf[3] + f * pl.out_len + po, covered * d->width,
-                                                 hipMemcpyDeviceToHost, c->s_down));
-                    }
-            } else if (whole && (covered_bytes < pl.out_len || !hf.packed())) { // frame by frame, without the never-written rows
-                for (size_t f = 0; f < nfr; f++)
-                    ZJ_HIP(c, hipMemcpyAsync(hf.Out(f0 + f), (uint8_t*)sl.buf[3] + f * pl.out_len, covered_bytes,
-                                             hipMemcpyDeviceToHost, c->s_down));
-            } else {
-                ZJ_HIP(c, hipMemcpyAsync(hf.Out(f0) + (whole ? 0 : s0 * ostrip), sl.buf[3], obytes,
-                                         hipMemcpyDeviceToHost, c->s_down));
-            }
-            ZJ_HIP(c, hipEventRecord(sl.down_done, c->s_down));
-            sl.used = true;
+            if ((rc = submit_unit(c, d, pl, hf, f0, nfr, s0, s1, u, covered, nullptr))) return rc;
         }
     }
     return pipe_sync(c);
+}
+
+/* ---- one frame whose planes are still being written: strips go to the GPU as they become final ----------------------
+ * The reference runs post_process on strip N while its Huffman decoder is in strip N + 1 (src/mcu.rs:356-368).  Here the
+ * caller names the frame (zj_frame_begin), says every now and then how many MCU rows are final (zj_frame_rows_ready),
+ * and the library pushes the strips that became complete through the three-stream pipeline in units of a few MB while
+ * the caller goes on filling the planes; zj_frame_end submits the rest and waits.  Every call returns at once (the copies
+ * are asynchronous when the planes are pinned). */
+static int frame_submit(zj_ctx* c, size_t upto, bool last)
+{
+    zj_ctx::FrameStream& f = c->fs;
+    Plan pl;
+    int rc = make_plan(&f.d, pl);
+    if (rc) return rc;
+    HostFrames hf;
+    uint8_t* const d_out = f.on_device ? f.out : (f.staged ? (uint8_t*)c->scratch[3] : nullptr);
+    hf.y = f.y; hf.cb = f.cb; hf.cr = f.cr; hf.out = d_out ? nullptr : f.out;
+    hf.y_len = pl.y_len; hf.c_len = pl.c_len; hf.out_len = pl.out_len;
+    const size_t covered = (size_t)pl.rows_covered < f.d.height ? (size_t)pl.rows_covered : f.d.height;
+    if (upto > (size_t)pl.n_strips) upto = (size_t)pl.n_strips;
+    while (f.submitted < upto && (last || upto - f.submitted >= f.unit)) {
+        size_t s1 = f.submitted + f.unit;
+        if (s1 > upto || (last && (size_t)pl.n_strips - s1 < f.unit / 2)) s1 = last ? (size_t)pl.n_strips : upto; // (no tiny last unit)
+        if (s1 > (size_t)pl.n_strips) s1 = (size_t)pl.n_strips;
+        if ((rc = submit_unit(c, &f.d, pl, hf, 0, 1, f.submitted, s1, f.units, covered, d_out))) return rc;
+        f.units++;
+        f.submitted = s1;
+    }
+    return ZJ_OK;
+}
+
+int zj_frame_begin(zj_ctx* c, const zj_frame_desc* d, const int16_t* y, const int16_t* cb, const int16_t* cr, uint8_t* out, int out_on_device)
+{
+    if (!c || c->fs.active) return ZJ_ERR_ARG;
+    Plan pl;
+    int rc = check_frame_args(c, d, 1, y, cb, cr, out, pl);
+    if (rc) return rc;
+    if (out_on_device && ((uintptr_t)out & 15)) return ZJ_ERR_ARG;
+    if (!out_on_device && pl.out_pitch != pl.row_bytes) return ZJ_ERR_UNSUPPORTED; // (host outputs are tight)
+    if (pl.out == OUT_RGB_CHW) return ZJ_ERR_UNSUPPORTED; // a strip range is not contiguous in a planar frame
+    ZJ_HIP(c, hipSetDevice(c->device));
+    if ((rc = pipe_init(c))) return rc;
+    zj_ctx::FrameStream& f = c->fs;
+    f.d = *d; f.y = y; f.cb = cb; f.cr = cr; f.out = out; f.on_device = out_on_device ? 1 : 0;
+    f.submitted = 0; f.units = 0;
+    f.staged = false;
+    if (!out_on_device) {
+        hipPointerAttribute_t a;
+        memset(&a, 0, sizeof a);
+        const bool pinned = hipPointerGetAttributes(&a, out) == hipSuccess && a.type == hipMemoryTypeHost;
+        if (!pinned) { (void)hipGetLastError(); f.staged = true; if ((rc = ensure_scratch(c, 3, pl.out_len))) return rc; }
+    }
+    const bool to_device = out_on_device || f.staged;
+    // units: an eighth of the frame, at least ZJ_STREAM_UNIT_MB (4) of coefficients -- every copy costs ~15 us of the calling
+    // thread and of the link, and the part that cannot overlap with the caller's work is the last unit
+    const bool chroma = pl.out != OUT_GRAY;
+    const size_t in_frame = (pl.y_len + (chroma ? 2 * pl.c_len : 0)) * 2;
+    size_t min_unit = (size_t)4 << 20;
+    if (const char* e = getenv("ZJ_STREAM_UNIT_MB")) { const long v = atol(e); if (v > 0 && v < 4096) min_unit = (size_t)v << 20; }
+    const size_t per_strip = pl.n_strips ? in_frame / (size_t)pl.n_strips : in_frame;
+    size_t unit = ((size_t)pl.n_strips + 7) / 8;
+    if (per_strip && unit * per_strip < min_unit) unit = (min_unit + per_strip - 1) / per_strip;
+    if (unit < 1) unit = 1;
+    f.unit = unit;
+    // the buffer sets at their final size now (growing one later would synchronise the pipeline in mid-frame)
+    const int mrps = pl.hs == 2 ? 2 : 1;
+    const size_t span = (unit + unit / 2 + 1 < (size_t)pl.n_strips ? unit + unit / 2 + 1 : (size_t)pl.n_strips);
+    for (PipeSlot& sl : c->slots) {
+        if ((rc = ensure_slot(c, sl, 0, span * (size_t)pl.mcu_x * 64 * pl.hs * pl.vs * mrps * 2))) return rc;
+        if (chroma && ((rc = ensure_slot(c, sl, 1, span * (size_t)pl.mcu_x * 64 * mrps * 2)) || (rc = ensure_slot(c, sl, 2, span * (size_t)pl.mcu_x * 64 * mrps * 2)))) return rc;
+        if (!to_device && (rc = ensure_slot(c, sl, 3, span * (size_t)d->width * pl.ncomp_out * pl.strip_rows))) return rc;
+    }
+    // rows below the last complete strip are never written by the reference (Q6)
+    {
+        size_t off[3], len[3];
+        const int nr = uncovered_ranges(d, pl, off, len);
+        if (!out_on_device) { for (int r = 0; r < nr; r++) memset(out + off[r], 0, len[r]); }
+        else if (nr) {
+            ZeroRows z{};
+            z.out = out; z.frame_stride = 0; z.nr = nr; z.nframes = 1;
+            for (int r = 0; r < nr; r++) { z.off[r] = off[r]; z.len[r] = len[r]; }
+            ZJ_HIP(c, launch_zero_rows(z, c->s_run));
+        }
+    }
+    f.active = true;
+    return ZJ_OK;
+}
+
+int zj_frame_rows_ready(zj_ctx* c, size_t mcu_rows)
+{
+    if (!c || !c->fs.active) return ZJ_ERR_ARG;
+    const size_t mrps = c->fs.d.h_max == 2 ? 2 : 1; // MCU rows per strip (zj_plan.h)
+    return batch_guard(c, frame_submit(c, mcu_rows / mrps, false));
+}
+
+int zj_frame_end(zj_ctx* c)
+{
+    if (!c || !c->fs.active) return ZJ_ERR_ARG;
+    int rc = frame_submit(c, (size_t)-1, true);
+    c->fs.active = false;
+    if (!rc) rc = pipe_sync(c);
+    if (!rc && c->fs.staged) { // the rows the strips cover (the rest was cleared in zj_frame_begin)
+        Plan pl;
+        if (!(rc = make_plan(&c->fs.d, pl))) {
+            const size_t covered = (size_t)pl.rows_covered < c->fs.d.height ? (size_t)pl.rows_covered : c->fs.d.height;
+            const hipError_t e = hipMemcpy(c->fs.out, c->scratch[3], covered * pl.out_pitch, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { c->last_error = std::string("hipMemcpy (zj_frame_end): ") + hipGetErrorString(e); rc = ZJ_ERR_HIP; }
+        }
+    }
+    return batch_guard(c, rc);
+}
+
+int zj_frame_abort(zj_ctx* c)
+{
+    if (!c) return ZJ_ERR_ARG;
+    if (!c->fs.active) return ZJ_OK;
+    c->fs.active = false;
+    return c->s_up ? pipe_sync(c) : ZJ_OK;
 }
 
 int zj_decode_planes(zj_ctx* c, const zj_frame_desc* d, const int16_t* y, const int16_t* cb,

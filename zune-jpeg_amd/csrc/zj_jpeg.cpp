@@ -429,6 +429,15 @@ struct zj_decoder {
     int ns = 0, order[3] = {0, 0, 0}, ss = 0, se = 63, ah = 0, al = 0;
     uint32_t eobrun = 0;
     int dri_parallel_segments = 0; // restart segments the last baseline scan decoded concurrently (0 = serial walk)
+    // zj_decoder_decode_buffer with pinned planes: the strips of a baseline scan go to the GPU while the walker is still in
+    // later rows (zj_frame_begin / _rows_ready / _end; the reference overlaps the same two things, src/mcu.rs:356-368)
+    struct Stream {
+        zj_ctx* ctx = nullptr;  // armed by zj_decoder_decode_buffer for the duration of its prepare step
+        uint8_t* out = nullptr;
+        size_t cap = 0;
+        bool active = false;    // zj_frame_begin succeeded for the scan being walked
+        int rows = 0;           // MCU rows reported so far
+    } stream;
 };
 
 namespace {
@@ -1125,6 +1134,32 @@ int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p,
     return ZJ_OK;
 }
 
+void fill_frame_desc(const zj_decoder* d, zj_frame_desc* fd);
+
+// the walker has finished MCU rows [0, rows): hand the strips they complete to the GPU (no-op unless a stream is active)
+inline void stream_rows(zj_decoder* d, long long mcus_done)
+{
+    if (!d->stream.active) return;
+    const int rows = (int)(mcus_done / d->mcu_x);
+    if (rows <= d->stream.rows) return;
+    d->stream.rows = rows;
+    if (zj_frame_rows_ready(d->stream.ctx, (size_t)rows) != ZJ_OK) { (void)zj_frame_abort(d->stream.ctx); d->stream.active = false; }
+}
+// before a baseline scan is walked on the CPU: start streaming if zj_decoder_decode_buffer armed it and everything fits
+void stream_begin(zj_decoder* d)
+{
+    d->stream.active = false;
+    d->stream.rows = 0;
+    if (!d->stream.ctx || !d->stream.out) return;
+    for (int i = 0; i < d->ncomp; i++) if (!d->store[i].pinned) return; // (copies out of pageable planes block the walker)
+    zj_frame_desc fd;
+    fill_frame_desc(d, &fd);
+    if (fd.in_components == 1 && fd.out_colorspace != ZJ_CS_GRAYSCALE) return; // all-zero output: nothing is decoded
+    if (zj_out_len(&fd) == 0 || d->stream.cap < zj_out_len(&fd)) return;       // (finish_impl reports it)
+    d->stream.active = zj_frame_begin(d->stream.ctx, &fd, d->comps[0].coef, d->ncomp == 3 ? d->comps[1].coef : nullptr,
+                                      d->ncomp == 3 ? d->comps[2].coef : nullptr, d->stream.out, 0) == ZJ_OK;
+}
+
 int scan_baseline(zj_decoder* d, BitReader& br)
 {
     for (int i = 0; i < d->ncomp; i++) {
@@ -1187,7 +1222,9 @@ int scan_baseline(zj_decoder* d, BitReader& br)
             int32_t pred[3] = {d->comps[0].dc_pred, d->comps[1].dc_pred, d->comps[2].dc_pred};
             long long done = 0;
             const char* err = nullptr;
-            const int rc = fn.mcus(d, d, br, pred, m, total - m < todo ? total - m : (long long)todo, stop, &done, &err);
+            long long n = total - m < todo ? total - m : (long long)todo;
+            if (d->stream.active && n > 4ll * d->mcu_x) n = 4ll * d->mcu_x; // come back every few rows: the GPU takes what is final
+            const int rc = fn.mcus(d, d, br, pred, m, n, stop, &done, &err);
             for (int i = 0; i < 3; i++) d->comps[i].dc_pred = pred[i];
             m += done;
             if (rc) { clear_from((int)(m / d->mcu_x), (int)(m % d->mcu_x)); return fail(d, rc, err); }
@@ -1197,6 +1234,7 @@ int scan_baseline(zj_decoder* d, BitReader& br)
                     const int rc2 = handle_restart(d, br, todo);
                     if (rc2) { clear_from((int)(m / d->mcu_x), (int)(m % d->mcu_x)); return rc2; }
                 }
+                stream_rows(d, m);
                 continue;
             }
         }
@@ -1222,6 +1260,7 @@ int scan_baseline(zj_decoder* d, BitReader& br)
         }
         if (!restarted) eoi_cut_after_mcu(cut, br, m); // (a restart clears the reference's pending marker, mcu.rs:400-408)
         m++;
+        if (m % d->mcu_x == 0) stream_rows(d, m);
     }
     _mm_sfence(); // the blocks left with streaming stores (decode_block_baseline)
     return ZJ_OK;
@@ -1650,6 +1689,7 @@ int decode_all(zj_decoder* d, const uint8_t* buf, size_t len, bool headers_only,
     d->track_hist = false;
     int rc = decode_all_once(d, buf, len, headers_only, for_device);
     if (rc == ZJ_INT_NEED_HIST) {
+        if (d->stream.active) { (void)zj_frame_abort(d->stream.ctx); d->stream.active = false; } // (the planes are written again)
         d->track_hist = true;
         d->hist_retries++;
         rc = decode_all_once(d, buf, len, headers_only, false);
@@ -1676,6 +1716,7 @@ int decode_all_once(zj_decoder* d, const uint8_t* buf, size_t len, bool headers_
             return ZJ_OK;
         }
         if ((rc = ensure_planes(d))) return rc;
+        stream_begin(d);
         rc = scan_baseline(d, br);
         d->scans = 1;
         d->coef_valid = rc == ZJ_OK;
@@ -1760,6 +1801,10 @@ static void fill_info(const zj_decoder* d, zj_image_info* info, zj_frame_desc* f
         }
     }
 }
+
+} // extern "C"
+namespace { void fill_frame_desc(const zj_decoder* d, zj_frame_desc* fd) { fill_info(d, nullptr, fd); } }
+extern "C" {
 
 int zj_decoder_read_headers(zj_decoder* d, const uint8_t* buf, size_t len, zj_image_info* info)
 {
@@ -1911,8 +1956,21 @@ int zj_decoder_decode_buffer(zj_decoder* d, zj_ctx* ctx, const uint8_t* buf, siz
                              size_t out_cap, size_t* out_len, zj_image_info* info)
 {
     if (!d || !ctx || !buf || !out) return ZJ_ERR_ARG;
+    // a baseline scan walked on the CPU into pinned planes: its strips go to the GPU while the walker is in later rows
+    // (stream_begin decides; ZJ_STREAM=off keeps the two stages apart)
+    const char* e = getenv("ZJ_STREAM");
+    if (!(e && (!strcmp(e, "off") || !strcmp(e, "0")))) { d->stream.ctx = ctx; d->stream.out = out; d->stream.cap = out_cap; }
     int rc = zj_decoder_prepare(d, buf, len, nullptr, info);
-    if (rc) return rc;
+    d->stream.ctx = nullptr; d->stream.out = nullptr; // (armed for this call only)
+    const bool streamed = d->stream.active;
+    d->stream.active = false;
+    if (rc) { if (streamed) (void)zj_frame_abort(ctx); return rc; }
+    if (streamed) {
+        rc = zj_frame_end(ctx);
+        if (rc) return fail(d, rc, std::string("pixel path: ") + zj_strerror(rc) + " " + zj_last_error(ctx));
+        if (out_len) { zj_frame_desc fd; fill_info(d, nullptr, &fd); *out_len = zj_out_len(&fd); }
+        return ZJ_OK;
+    }
     return zj_decoder_finish_pixels(d, ctx, out, out_cap, out_len);
 }
 

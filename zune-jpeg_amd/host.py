@@ -156,6 +156,7 @@ ABI = [  # every symbol include/zjhip.h declares
     "zj_decode_frames", "zj_decode_planes_device_strided", "zj_decode_frames_device", "zj_pointer_device",
     "zj_pool_create_multi", "zj_pool_devices", "zj_pool_device_stats",
     "zj_shard_range", "zj_multi_create", "zj_multi_destroy", "zj_multi_devices", "zj_multi_ctx", "zj_multi_slot_stats",
+    "zj_frame_begin", "zj_frame_rows_ready", "zj_frame_end", "zj_frame_abort",
     "zj_device_pci_bus_id", "zj_device_numa_node", "zj_bind_thread_to_numa_node", "zj_bind_thread_near_device",
     "zj_thread_numa_node", "zj_pool_slot_numa", "zj_multi_slot_numa",
     "zj_multi_decode_planes_batch", "zj_multi_decode_frames", "zj_multi_decode_frames_device",
@@ -299,6 +300,10 @@ def lib():
     L.zj_multi_decode_planes_batch.argtypes = [vp, C.POINTER(FrameDesc), sz, i16p, i16p, i16p, u8p, C.POINTER(C.c_int)]
     L.zj_multi_decode_frames.argtypes = [vp, C.POINTER(FrameDesc), sz, vp, vp, vp, vp, C.POINTER(C.c_int)]
     L.zj_multi_decode_frames_device.argtypes = [vp, C.POINTER(FrameDesc), sz, vp, vp, vp, vp, C.POINTER(C.c_int)]
+    L.zj_frame_begin.argtypes = [vp, C.POINTER(FrameDesc), i16p, i16p, i16p, vp, C.c_int]
+    L.zj_frame_rows_ready.argtypes = [vp, sz]
+    L.zj_frame_end.argtypes = [vp]
+    L.zj_frame_abort.argtypes = [vp]
     ip = C.POINTER(C.c_int)
     L.zj_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, sz]
     L.zj_device_numa_node.argtypes = [C.c_int]
@@ -488,6 +493,19 @@ class Context:
         self.decode_planes_device(desc, n, ptr(y), ptr(cb), ptr(cr), out.data_ptr(), torch.cuda.current_stream(y.device).cuda_stream)
         return out
 
+    # ---- one frame whose planes are still being written (zj_frame_*): pointers are raw addresses, the caller keeps them alive
+    def frame_begin(self, desc, y, cb, cr, out, out_on_device=False):
+        _check(lib().zj_frame_begin(self._h, C.byref(desc), y, cb, cr, out, 1 if out_on_device else 0), "zj_frame_begin", self._h)
+
+    def frame_rows_ready(self, mcu_rows):
+        _check(lib().zj_frame_rows_ready(self._h, int(mcu_rows)), "zj_frame_rows_ready", self._h)
+
+    def frame_end(self):
+        _check(lib().zj_frame_end(self._h), "zj_frame_end", self._h)
+
+    def frame_abort(self):
+        _check(lib().zj_frame_abort(self._h), "zj_frame_abort", self._h)
+
     def time_decode_device(self, desc, nframes, d_y, d_cb, d_cr, d_out, iters, stream=None):
         """HIP-event timing on the launch stream.  Returns (ms per launch from `iters` back-to-back
         launches, mean ms of individually bracketed launches, kernel name)."""
@@ -676,13 +694,16 @@ class Decoder:
             self._raise(rc)
         return n.value
 
-    def decode_buffer(self, buf):  # decoder.rs:178
+    def decode_buffer(self, buf, out=None):  # decoder.rs:178
+        """out: a uint8 array to decode into (e.g. a view of pinned memory, so that the downloads of a streamed baseline
+        decode overlap as well); allocated when None."""
         if self._ctx is None:
             self._ctx = Context()
         b = np.frombuffer(bytes(buf), np.uint8)
         info = self.read_headers(buf)
         ncomp = 1 if info.components == 1 else ColorSpace(self._out_cs).num_components()
-        out = np.zeros(int(info.width) * int(info.height) * ncomp, np.uint8)
+        if out is None:
+            out = np.zeros(int(info.width) * int(info.height) * ncomp, np.uint8)
         n = C.c_size_t(0)
         rc = lib().zj_decoder_decode_buffer(self._d, self._ctx.handle, _ptr(b), b.size, _ptr(out), out.size,
                                             C.byref(n), C.byref(info))
