@@ -261,10 +261,11 @@ def test_header_is_plain_c_and_cxx(cmd, tmp_path):
     assert "hip/hip_runtime" not in hdr and "torch" not in hdr.lower()
 
 
-@pytest.mark.parametrize("name", ["decode_file", "shard_frames", "padded_rows"])
+@pytest.mark.parametrize("name", ["decode_file", "shard_frames", "padded_rows", "stream_frame"])
 def test_c_example_builds_and_links(name):
     """examples/*.c: the C ABI used from plain C99, linked against libzjhip.so (decode_file: one JPEG file; shard_frames:
-    frames sharded over the node's GPUs with zj_multi_*; padded_rows: a device output at a pitch that is a multiple of 128 B)"""
+    frames sharded over the node's GPUs with zj_multi_*; padded_rows: a device output at a pitch that is a multiple of 128 B;
+    stream_frame: a frame whose strips go to the GPU while its planes are still being written, zj_frame_*)"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     importlib.import_module("zune-jpeg_amd").lib()  # make sure the library is built
     out = os.path.join(root, "examples", name)
@@ -272,7 +273,7 @@ def test_c_example_builds_and_links(name):
                            os.path.join(root, "examples", name + ".c"), "-L", os.path.join(root, "zune-jpeg_amd"), "-lzjhip",
                            "-Wl,-rpath," + os.path.join(root, "zune-jpeg_amd"), "-o", out])
     assert os.path.exists(out)
-    if name in ("shard_frames", "padded_rows"):  # without a GPU the example must refuse loudly, not compute anything
+    if name in ("shard_frames", "padded_rows", "stream_frame"):  # without a GPU the example must refuse loudly, not compute anything
         import torch
         if not torch.cuda.is_available():
             r = subprocess.run([out, "2", "64", "64"] if name == "shard_frames" else [out, "272", "64"], capture_output=True)

@@ -53,3 +53,13 @@ def test_decode_file_example_writes_the_pixels_the_python_path_gives(tmp_path, e
         header_end = raw.index(b"\n", header_end) + 1
     want = zj.Decoder().decode_buffer(open(src, "rb").read())
     assert np.array_equal(np.frombuffer(raw[header_end:], np.uint8), want)
+
+
+@pytest.mark.parametrize("wh", [(4096, 4096), (1920, 1080), (2500, 333)])
+def test_stream_frame_example(tmp_path, wh):
+    """zj_frame_begin / _rows_ready / _end from plain C: a frame streamed MCU row by MCU row out of pinned planes into pinned
+    pixels equals zj_decode_planes of the finished planes"""
+    exe = build("stream_frame", tmp_path)
+    r = subprocess.run([exe, str(wh[0]), str(wh[1])], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "0 bytes differ from zj_decode_planes" in r.stdout, r.stdout
