@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--threads", type=int, default=1)
     ap.add_argument("--synthetic", type=int, default=4096)
     ap.add_argument("--no-pillow", action="store_true")
+    ap.add_argument("--with-copy", action="store_true", help="also time Decoder.decode_coefficients, which copies the planes out (what a Python caller that wants the coefficients pays)")
     a = ap.parse_args()
     items = []
     if a.files:
@@ -88,9 +89,21 @@ def main():
         nb = blocks_of(info)
         best = min(ts)
         pl = None if a.no_pillow else time_pillow(data, max(3, a.reps // 2))
+        extra = ""
+        if a.with_copy:
+            o = zj.ZuneJpegOptions()
+            o.num_threads = a.threads
+            dec = zj.Decoder(o)
+            tc = []
+            for _ in range(max(3, a.reps // 2)):
+                t0 = time.perf_counter()
+                dec.decode_coefficients(data)
+                tc.append(time.perf_counter() - t0)
+            dec.close()
+            extra = f"   decode_coefficients (walker + a copy of the planes): {min(tc) * 1e3:.2f} ms"
         print(f"{name:<28}{len(data) / 1e6:>7.2f}{nb:>10}{best * 1e3:>9.2f} /{statistics.median(ts) * 1e3:>7.2f}"
               f"{best * 1e9 / nb:>10.1f}{info.width * info.height / 1e6 / best:>8.0f}"
-              + (f"{min(pl) * 1e3:>9.2f} /{statistics.median(pl) * 1e3:>7.2f}" if pl else f"{'n/a':>18}"))
+              + (f"{min(pl) * 1e3:>9.2f} /{statistics.median(pl) * 1e3:>7.2f}" if pl else f"{'n/a':>18}") + extra)
 
 
 if __name__ == "__main__":

@@ -634,8 +634,11 @@ class Decoder:
     def info(self):  # decoder.rs:210
         return self._info
 
-    def decode_coefficients(self, buf):
-        """CPU half only: (FrameDesc, [planes], ImageInfo); planes are copies."""
+    def decode_coefficients(self, buf, copy=True):
+        """CPU half only: (FrameDesc, [planes], ImageInfo).  The planes are copies (copy=False: views of the decoder's own
+        planes, valid until its next call or its end).  NOT for timing the walker: the copy of the planes -- 199 MB for a
+        7680 x 4320 4:4:4 file -- costs more than the Huffman stage; prepare() leaves the planes where they are
+        (tools/walker_bench.py)."""
         b = np.frombuffer(bytes(buf), np.uint8)
         desc, info = FrameDesc(), ImageInfo()
         ptrs = (C.c_void_p * 3)()
@@ -643,8 +646,9 @@ class Decoder:
         rc = lib().zj_decoder_decode_coefficients(self._d, _ptr(b), b.size, C.byref(desc), ptrs, lens, C.byref(info))
         if rc:
             self._raise(rc)
-        planes = [np.ctypeslib.as_array(C.cast(ptrs[c], C.POINTER(C.c_int16)), shape=(lens[c],)).copy()
-                  for c in range(info.components)]
+        planes = [np.ctypeslib.as_array(C.cast(ptrs[c], C.POINTER(C.c_int16)), shape=(lens[c],)) for c in range(info.components)]
+        if copy:
+            planes = [p.copy() for p in planes]
         self._info = info
         return desc, planes, info
 
