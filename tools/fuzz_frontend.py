@@ -77,6 +77,19 @@ def main():
     seeds.append(document_like(640, 480))
     seeds.append(document_like(512, 512, gray=True))
     seeds.append(document_like(400, 300, subsampling=0))
+    # scans of tens of KB: what decode_mcus_v2 carries (it leaves a scan's last 4 KB to the block-at-a-time decoder, so the
+    # small seeds above never reach it) -- standard and optimised tables, with and without restart intervals
+    import io
+    from PIL import Image, ImageFile
+    ImageFile.MAXBLOCK = max(ImageFile.MAXBLOCK, 1 << 22)
+    rs = np.random.default_rng(11)
+    for (w, h, sub, q, opt, rst) in [(512, 384, 2, 85, False, 0), (400, 300, 0, 95, True, 0), (640, 256, 1, 70, True, 2)]:
+        small = rs.integers(0, 256, (h // 16, w // 16, 3), dtype=np.uint8)
+        img = Image.fromarray(small, "RGB").resize((w, h), Image.BICUBIC)
+        img = Image.fromarray(np.clip(np.asarray(img).astype(np.int16) + rs.integers(-30, 31, (h, w, 3), dtype=np.int16), 0, 255).astype(np.uint8), "RGB")
+        bio = io.BytesIO()
+        img.save(bio, "JPEG", quality=q, subsampling=sub, optimize=opt, **({"restart_marker_rows": rst} if rst else {}))
+        seeds.append(bio.getvalue())
     rng = np.random.default_rng(7)
     decs = []
     for threads in (1, 3):
