@@ -188,6 +188,8 @@ zj_ctx* zj_ctx_create(int backend, int device, int* status)
             else fprintf(stderr, "libzjhip: ZJ_STAGGER=%s is out of range (0..255, 0 = off); keeping %d\n", e, c->stagger_delay);
         }
     }
+    // ZJ_BLOCKING_SYNC=1 (experiment, profiles/r06_pool_sync.txt): threads that wait for the device sleep instead of polling
+    if (const char* e = getenv("ZJ_BLOCKING_SYNC")) { if (atoi(e) == 1 && hipSetDevice(device) == hipSuccess) { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); } }
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
     if (!ok) { zj_ctx_destroy(c); *status = ZJ_ERR_NO_DEVICE; return nullptr; }
