@@ -402,20 +402,22 @@ def reference_files(zj, ctx, reps=5):
             pin = zj.lib().zj_alloc_pinned(r["width"] * r["height"] * 3)
             try:
                 pout = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint8)), shape=(r["width"] * r["height"] * 3,))
-                for key, mkey, env in (("decode_buffer_ms", "decode_buffer_matches", None),
-                                       ("decode_buffer_ms_stages_apart", "decode_buffer_stages_apart_matches", "off")):
-                    if env:
-                        os.environ["ZJ_STREAM"] = env
-                    try:
-                        best = 1e9
-                        for _ in range(reps + 1):
+                modes = (("decode_buffer_ms", "decode_buffer_matches", None),
+                         ("decode_buffer_ms_stages_apart", "decode_buffer_stages_apart_matches", "off"))
+                best = {m[0]: 1e9 for m in modes}
+                for _ in range(reps + 2):          # the two modes in turn, so that a slow phase of the host hits both
+                    for key, mkey, env in modes:
+                        if env:
+                            os.environ["ZJ_STREAM"] = env
+                        try:
                             t0 = time.perf_counter()
                             got = dec.decode_buffer(data, out=pout)
-                            best = min(best, time.perf_counter() - t0)
-                        whole[key] = round(best * 1e3, 3)
-                        whole[mkey] = bool(np.array_equal(got, px))
-                    finally:
-                        os.environ.pop("ZJ_STREAM", None)
+                            best[key] = min(best[key], time.perf_counter() - t0)
+                            whole[mkey] = whole.get(mkey, True) and bool(np.array_equal(got, px))
+                        finally:
+                            os.environ.pop("ZJ_STREAM", None)
+                for key, _, _ in modes:
+                    whole[key] = round(best[key] * 1e3, 3)
             finally:
                 zj.lib().zj_free_pinned(pin)
             dec.close()
