@@ -109,6 +109,16 @@ def test_fails_loudly_without_gpu(zj):
         zj.Context(backend=zj.BACKEND_SCALAR)
 
 
+def test_round6_entry_points_refuse_a_null_context(zj):
+    """zj_frame_* (a frame streamed while its planes are written) and the slot placement queries: argument errors, not
+    crashes, without a context / pool"""
+    L = zj.lib()
+    assert L.zj_frame_begin(None, None, None, None, None, None, 0) == -1      # ZJ_ERR_ARG
+    assert L.zj_frame_rows_ready(None, 3) == -1 and L.zj_frame_end(None) == -1 and L.zj_frame_abort(None) == -1
+    assert L.zj_pool_slot_numa(None, 0, None, None, None) == -1 and L.zj_multi_slot_numa(None, 0, None, None, None) == -1
+    assert L.zj_bind_thread_to_numa_node(-1) == -1 and L.zj_device_pci_bus_id(0, None, 0) == -1
+
+
 def test_rust_shim_declares_every_symbol():
     """bindings/rust/src/lib.rs cannot be compiled here (no rustc): at least keep its extern block in step with
     include/zjhip.h -- every function it declares exists in the header with the same number of parameters."""
