@@ -35,13 +35,6 @@ const uint8_t kUnZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 1
 
 constexpr int AC_BITS = 10;
 inline int sext6(int v) { return (int)((unsigned)v << 26) >> 26; }
-// zig-zag position of the coefficient at natural index i (the inverse of kUnZigzag)
-struct ZigzagOf {
-    uint8_t t[64];
-    ZigzagOf() { for (int k = 0; k < 64; k++) t[kUnZigzag[k]] = (uint8_t)k; }
-    uint8_t operator[](int i) const { return t[i]; }
-};
-const ZigzagOf kZigzagOf;
 struct Huff {
     bool present = false;
     // canonical decoding (T.81 F.2.2.3) with an 9-bit lookahead table
@@ -1366,23 +1359,6 @@ int ac_refine(zj_decoder* d, BitReader& br, const Huff& ha, int16_t* blk)
             __m128i any = _mm_and_si128(_mm_load_si128(q), _mm_set_epi16(-1, -1, -1, -1, -1, -1, -1, 0)); // not the DC
             for (int i = 1; i < 8; i++) any = _mm_or_si128(any, _mm_load_si128(q + i));
             if (_mm_movemask_epi8(_mm_cmpeq_epi8(any, _mm_setzero_si128())) == 0xFFFF) { d->eobrun--; return ZJ_OK; }
-            // ... and a block that has some: visit those only, in zig-zag order (a bit per non-zero coefficient, natural order,
-            // from eight compares; turned into zig-zag positions one set bit at a time)
-            uint64_t nat = 0;
-            for (int i = 0; i < 8; i++) {
-                const __m128i z = _mm_cmpeq_epi16(_mm_load_si128(q + i), _mm_setzero_si128());
-                nat |= (uint64_t)(~(unsigned)_mm_movemask_epi8(_mm_packs_epi16(z, z)) & 0xFFu) << (8 * i);
-            }
-            uint64_t zz = 0;
-            for (nat &= ~1ull; nat; nat &= nat - 1) zz |= 1ull << kZigzagOf[__builtin_ctzll(nat)];
-            zz &= ~0ull << k;
-            if (d->se < 63) zz &= (2ull << d->se) - 1;
-            for (; zz; zz &= zz - 1) {
-                int16_t* c = blk + kUnZigzag[__builtin_ctzll(zz)];
-                if (br.get(1) && (*c & p1) == 0) *c = (int16_t)(*c >= 0 ? *c + p1 : *c + m1);
-            }
-            d->eobrun--;
-            return ZJ_OK;
         }
         for (; k <= d->se; k++) {
             int16_t* c = blk + kUnZigzag[k];
