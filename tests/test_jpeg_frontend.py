@@ -240,6 +240,8 @@ def test_reference_eoi_cut_libjpeg_files(zj, subsampling, wh, restart_rows, thre
 
 def test_reference_eoi_cut_was_exercised():
     """the cases above must contain images where the reference drops MCUs (else they test nothing)"""
+    if os.environ.get("PYTEST_XDIST_WORKER"):
+        pytest.skip("counts what the cases above saw in THIS process: meaningful in a serial run only (python -m pytest tests -x -q)")
     assert sum(_CUTS.values()) >= 6, _CUTS
 
 
