@@ -90,3 +90,21 @@ def test_stretch_decoder_equals_block_decoder(zj, case):
         assert a == b, (case, trial, kind, a[0], b[0], a[1] if a[0] == "error" else "", b[1] if b[0] == "error" else "")
         differing += a[0] == "error" or a[1] != _decode(zj, data, 1, v1=False)[1]
     assert differing >= 6  # the damage did reach the decoder
+
+
+def test_grayscale_files_through_the_stretch_decoder(zj):
+    """one component: one block per MCU, no chroma tables"""
+    from PIL import Image
+    rng = np.random.default_rng(77)
+    for w, h, q, rst in ((640, 480, 85, 0), (1001, 333, 95, 3)):
+        small = rng.integers(0, 256, (h // 16, w // 16), dtype=np.uint8)
+        img = Image.fromarray(small, "L").resize((w, h), Image.BICUBIC)
+        img = Image.fromarray(np.clip(np.asarray(img).astype(np.int16) + rng.integers(-20, 21, (h, w), dtype=np.int16), 0, 255).astype(np.uint8), "L")
+        b = io.BytesIO()
+        img.save(b, "JPEG", quality=q, **({"restart_marker_rows": rst} if rst else {}))
+        data = b.getvalue()
+        assert len(data) > 12000
+        for threads in (1, 4):
+            a = _decode(zj, data, threads, v1=False)
+            c = _decode(zj, data, threads, v1=True)
+            assert a[0] == "ok" and a == c and len(a[1]) == 1, (w, h, threads)
