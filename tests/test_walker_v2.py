@@ -31,17 +31,26 @@ def _jpeg(seed, w, h, subsampling, quality, optimize, restart_rows):
     return b.getvalue()
 
 
-def _decode(zj, data, threads, v1):
+def _decode(zj, data, threads, v1, par=False):
+    """v1: every block through the block-at-a-time decoder.  par: scans without restart markers may be entered at one point per
+    thread (scan_baseline_parallel), even small ones; otherwise that path is off, so that `threads` only means restart segments."""
     if v1:
         os.environ["ZJ_WALKER_V1"] = "1"
     else:
         os.environ.pop("ZJ_WALKER_V1", None)
+    if par:
+        os.environ["ZJ_PAR_MIN_CHUNK"] = "1024"
+        os.environ.pop("ZJ_PAR_SCAN", None)
+    else:
+        os.environ["ZJ_PAR_SCAN"] = "off"
     try:
         o = zj.ZuneJpegOptions()
         o.num_threads = threads
         dec = zj.Decoder(o)
         try:
             _, planes, info = dec.decode_coefficients(data)
+            if par:
+                _PAR_MCUS.append(dec.parallel_mcus())
             return ("ok", [p.tobytes() for p in planes], (info.width, info.height, info.scans), dec.parallel_segments())
         except zj.DecodeError as e:
             return ("error", str(e))
@@ -49,6 +58,11 @@ def _decode(zj, data, threads, v1):
             dec.close()
     finally:
         os.environ.pop("ZJ_WALKER_V1", None)
+        os.environ.pop("ZJ_PAR_MIN_CHUNK", None)
+        os.environ.pop("ZJ_PAR_SCAN", None)
+
+
+_PAR_MCUS = []
 
 
 CASES = [(seed, w, h, sub, q, opt, rst)
@@ -108,3 +122,37 @@ def test_grayscale_files_through_the_stretch_decoder(zj):
             a = _decode(zj, data, threads, v1=False)
             c = _decode(zj, data, threads, v1=True)
             assert a[0] == "ok" and a == c and len(a[1]) == 1, (w, h, threads)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if not c[6]], ids=[f"{c[1]}x{c[2]}-s{c[3]}-q{c[4]}{'-opt' if c[5] else ''}" for c in CASES if not c[6]])
+def test_scans_without_restart_markers_on_several_threads(zj, case):
+    """scan_baseline_parallel: the scan entered at one point per thread, the threads falling into step with the true symbol
+    sequence -- same planes, same status, same error text as the serial walk, on intact files and on damaged ones (where it
+    must either drop the attempt or arrive at the same garbage)."""
+    seed, w, h, sub, q, opt, rst = case
+    data = _jpeg(seed, w, h, sub, q, opt, rst)
+    del _PAR_MCUS[:]
+    ref = _decode(zj, data, 1, v1=False)
+    for threads in (2, 3, 4, 7):
+        got = _decode(zj, data, threads, v1=False, par=True)
+        assert got[:3] == ref[:3] if got[0] == "ok" else got == ref, (case, threads)
+    if ref[0] == "ok":
+        assert sum(1 for m in _PAR_MCUS if m > 0) >= 3, _PAR_MCUS   # the path was taken, not just fallen back from
+    rng = np.random.default_rng(2000 + seed)
+    sos = data.index(b"\xff\xda")
+    start = sos + 2 + int.from_bytes(data[sos + 2:sos + 4], "big")
+    for trial in range(10):
+        d = bytearray(data)
+        at = int(rng.integers(start + 16, len(d) - 5000))
+        kind = trial % 3
+        if kind == 0:
+            d[at] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            d[at] = 0xFF
+            d[at + 1] = [0x00, 0xD9, 0xD3, 0x17][trial % 4]
+        else:
+            del d[at:at + int(rng.integers(1, 4))]
+        d = bytes(d)
+        a = _decode(zj, d, 1, v1=False)
+        b = _decode(zj, d, 4, v1=False, par=True)
+        assert (a[:3] == b[:3]) if a[0] == "ok" else a == b, (case, trial, kind, a[0], b[0])

@@ -429,6 +429,7 @@ struct zj_decoder {
     int ns = 0, order[3] = {0, 0, 0}, ss = 0, se = 63, ah = 0, al = 0;
     uint32_t eobrun = 0;
     int dri_parallel_segments = 0; // restart segments the last baseline scan decoded concurrently (0 = serial walk)
+    long long par_scan_mcus = 0;   // MCUs of the last baseline scan decoded by scan_baseline_parallel (no restart markers; 0: serial)
     // zj_decoder_decode_buffer with pinned planes: the strips of a baseline scan go to the GPU while the walker is still in
     // later rows (zj_frame_begin / _rows_ready / _end; the reference overlaps the same two things, src/mcu.rs:356-368)
     struct Stream {
@@ -1134,6 +1135,279 @@ int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p,
     return ZJ_OK;
 }
 
+
+// ---- a baseline scan WITHOUT restart markers on several threads (round 6) ------------------------------------------------
+// Restart markers cut a scan into independently decodable pieces (above); most files have none, and then `num_threads`
+// (reference default 4, src/options.rs:33) bought nothing.  A Huffman stream can still be entered in the middle: a decoder
+// that starts at an arbitrary byte with the wrong idea of where it is reads garbage for a while and then, with high
+// probability, falls into step with the true sequence of symbols -- from then on it is at MCU starts exactly where the true
+// decoder is.  So:
+//   A  (parallel)   the scan is cut into one chunk per thread; every thread decodes the STRUCTURE of its chunk only -- code
+//                   lengths and zig-zag advances, no values, no stores -- from its chunk's first byte, assuming an MCU starts
+//                   there, and notes the reader's state at every MCU start it believes in (ParSnap);
+//   stitch (serial) the true decoder's state at the end of chunk t-1 is looked up among chunk t's MCU starts; if it is not one
+//                   of them the true structure decode simply goes on into chunk t until it is (typically a few hundred bytes).
+//                   From that MCU on chunk t's notes are true, and how many MCUs precede it is known;
+//   B  (parallel)   every thread decodes its MCUs for real (decode_mcus_v2) from the noted state.  The DC predictors it starts
+//                   with come from pass A as well: the structure decode forms the DC differences (one per block) and keeps
+//                   their running sums, and differences of sums inside a chunk are true once the chunk is in step.
+// The scan's last 8 KB -- where the reference's early exit at EOI lives -- and everything the walker treats specially stay
+// with the serial walk: any DC symbol the reference might read short (ref_dc_misread: the structure decode follows bits_left
+// by the same rules), any code that does not exist, any marker, a chunk that never falls into step -> the attempt is dropped
+// and the serial walk decodes the scan as if nothing had happened (it clears every block before it fills it).
+// 4096 x 4096 4:2:0 q = 90, 3.5 MB, 4 threads: 18 -> 7.5 ms on the GPU host (profiles/r06_walker.txt).  ZJ_PAR_SCAN=off.
+struct ParSnap {
+    const uint8_t* p;   // the reader at an MCU start: next byte to load, accumulator, bits in it
+    uint64_t acc;
+    long long dbits;    // data bits (stuffing removed) consumed since the scan began: the same number for every reader that is
+                        // at this point of the stream, whatever its refill history
+    int nbits;
+    int rbl;            // the reference's bits_left here, if `exact`
+    bool exact;
+    bool hazard;        // the MCU that starts here holds a DC symbol the reference may read short
+    int32_t dc[3];      // the components' DC predictors here, counted from whatever the run was started with (wrapping)
+};
+
+// Structure-only decode from the state of `br` (br.istart marks the byte whose first bit is data bit `base_bits`): a ParSnap
+// at every MCU start, the first included, until an MCU starts at or behind `until` (recorded, not decoded) or `max_new` MCUs
+// have been decoded.  false: something undecodable (no such code, a marker or the end of the data in view).
+bool par_structure_run(const zj_decoder* d, BitReader& br, long long base_bits, int rbl, bool exact, const int32_t pred0[3], const uint8_t* until,
+                       size_t max_new, std::vector<ParSnap>& out)
+{
+    struct Blk { const Huff* hd; const Huff* ha; int comp; };
+    Blk pat[8];
+    int bpm = 0;
+    for (int ci = 0; ci < d->ns; ci++) {
+        const Comp& cm = d->comps[d->order[ci]];
+        for (int q = 0; q < cm.h * cm.v; q++) {
+            if (bpm == 8) return false;
+            pat[bpm++] = Blk{&d->dc[cm.td & 3], &d->ac[cm.ta & 3], d->order[ci]};
+        }
+    }
+    uint32_t pred[3] = {(uint32_t)pred0[0], (uint32_t)pred0[1], (uint32_t)pred0[2]};
+    uint64_t acc = br.acc;
+    int nbits = br.nbits;
+    const uint8_t* p = br.p;
+    auto put = [&]() { br.acc = acc; br.nbits = nbits; br.p = p; };
+    auto get = [&]() { acc = br.acc; nbits = br.nbits; p = br.p; };
+    auto refill = [&]() {
+        if (__builtin_expect(!br.marker && br.end - p >= 8, 1)) {
+            uint64_t x;
+            memcpy(&x, p, 8);
+            x = __builtin_bswap64(x);
+            const uint64_t y = ~x;
+            if (__builtin_expect(!((y - 0x0101010101010101ull) & ~y & 0x8080808080808080ull), 1)) {
+                acc |= x >> nbits;
+                p += (63 - nbits) >> 3;
+                nbits |= 56;
+                return;
+            }
+        }
+        put(); br.fill(); get();
+    };
+    for (size_t done = 0;; done++) {
+        put();
+        if (br.marker) return false;
+        const long long here = base_bits + br.consumed();
+        out.push_back(ParSnap{p, acc, here, nbits, rbl, exact, false, {(int32_t)pred[0], (int32_t)pred[1], (int32_t)pred[2]}});
+        if (p >= until || done == max_new) return true;
+        bool hazard = false;
+        long long bits = here; // data bits consumed, followed symbol by symbol through the MCU
+        for (int j = 0; j < bpm; j++) {
+            if (nbits < 32) refill();
+            // DC (src/bitstream.rs:264-296): the reference refills below 16 bits only, the symbol may be longer
+            int s, len;
+            {
+                const uint16_t e = pat[j].hd->look[acc >> 55];
+                if (__builtin_expect(e != 0, 1)) { len = e >> 8; s = e & 0xff; }
+                else {
+                    put();
+                    const int before = br.nbits;
+                    s = br.decode(*pat[j].hd);
+                    len = before - br.nbits;
+                    br.acc = acc; br.nbits = nbits; // (only the length was wanted)
+                }
+            }
+            if (s < 0 || s > 16) return false;
+            if (rbl < 16) rbl += 32;
+            if (s && len + s > (exact ? rbl : 16)) hazard = true;
+            rbl -= len + s;
+            if (rbl < 0) { rbl = 0; hazard = true; }
+            // the DC difference itself: the predictors are part of the state the ranges start from (values of the AC
+            // coefficients are not needed for that, and not formed)
+            if (s) pred[pat[j].comp] += (uint32_t)extend((int32_t)((acc << len) >> (64 - s)), s);
+            acc <<= len + s; nbits -= len + s; bits += len + s;
+            const int T = rbl <= 32 ? rbl + 32 : rbl;
+            // AC (src/bitstream.rs:332-372), one symbol per table entry (an entry that carries the EOB as well is read for its
+            // first symbol only)
+            const Huff::AcEnt* const tab = pat[j].ha->actab;
+            int k = 1, nac = 0, last = 0;
+            long long last_at = bits;
+            do {
+                if (nbits < 32) refill();
+                Huff::AcEnt en = tab[acc >> (64 - AC_BITS)];
+                if (__builtin_expect(en.total == 0, 0)) {
+                    en = pat[j].ha->ac_escape(acc);
+                    if (!en.total) return false;
+                }
+                last = en.len + en.sz;
+                last_at = bits;
+                k += en.sz ? (en.idxoff & 127) + 1 : en.kadv;
+                acc <<= last; nbits -= last; bits += last;
+                nac++;
+            } while (k < 64);
+            // bits_left behind the block: behind the refill in front of an AC symbol at data bit C it is 64 - (C mod 32)
+            // whatever came before -- except in front of a block's FIRST AC symbol, where it follows from the DC symbol
+            if (nac >= 2) { rbl = 64 - (int)(last_at & 31) - last; exact = true; }
+            else rbl = T - last;
+            if (nbits < 0) return false; // (padding ran out: the end of the data)
+        }
+        out.back().hazard = hazard;
+    }
+}
+
+// Returns the number of MCUs decoded from the start of the scan (0: not attempted or dropped; nothing but plane contents has
+// changed then) with `br` at the start of the next MCU and the components' predictors set.
+long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& fn, const uint8_t* scan_end)
+{
+    const uint8_t* const p0 = br.p;
+    const int T = d->threads < 16 ? d->threads : 16;
+    const long long usable = (long long)(scan_end - p0) - 8192; // the tail stays with the serial walk (EoiCut, near_end)
+    long long min_chunk = 32768;                                // below this per thread the threads cost more than they bring
+    if (const char* e = getenv("ZJ_PAR_MIN_CHUNK")) { const long v = atol(e); if (v >= 256) min_chunk = v; } // (tests: small files)
+    if (T < 2 || usable < (long long)T * min_chunk) return 0;
+    // chunk starts: never on the zero that follows a 0xFF; 0xFF00 pairs in front of every chunk (for data bit numbers)
+    std::vector<const uint8_t*> start((size_t)T + 1);
+    std::vector<long long> base((size_t)T);
+    for (int t = 0; t <= T; t++) {
+        const uint8_t* q = p0 + usable * t / T;
+        if (t && q[-1] == 0xFF && q[0] == 0x00) q++;
+        start[(size_t)t] = q;
+    }
+    {
+        long long stuffed = 0;
+        const uint8_t* q = p0;
+        for (int t = 0; t < T; t++) {
+            while (q < start[(size_t)t]) {
+                const uint8_t* f = (const uint8_t*)memchr(q, 0xFF, (size_t)(start[(size_t)t] - q));
+                if (!f) { q = start[(size_t)t]; break; }
+                if (f + 1 < scan_end && f[1] == 0x00) { stuffed++; q = f + 2; }
+                else if (f + 1 < scan_end && f[1] != 0xFF) return 0; // a marker inside the scan: not for this path
+                else q = f + 1;
+            }
+            if (q > start[(size_t)t]) { start[(size_t)t] = q; } // (a stuffed pair straddled the cut)
+            base[(size_t)t] = 8 * ((long long)(start[(size_t)t] - p0) - stuffed);
+        }
+    }
+    for (int t = 1; t <= T; t++) if (start[(size_t)t] <= start[(size_t)t - 1]) return 0;
+    // A: structure of every chunk, speculatively (chunk 0: truly)
+    std::vector<std::vector<ParSnap>> seen((size_t)T);
+    std::vector<char> ok((size_t)T, 0);
+    parallel_for(T, T, [&](int t) {
+        BitReader r;
+        r.p = start[(size_t)t]; r.end = br.end; r.istart = r.p;
+        seen[(size_t)t].reserve((size_t)((start[(size_t)t + 1] - start[(size_t)t]) / 24 + 64));
+        const int32_t zero[3] = {0, 0, 0}; // (the scan begins with predictors 0; a chunk's own count starts anywhere)
+        ok[(size_t)t] = par_structure_run(d, r, base[(size_t)t], t == 0 ? br.rbl : 0, t == 0, zero, start[(size_t)t + 1], (size_t)-1, seen[(size_t)t]);
+    });
+    if (!ok[0] || seen[0].size() < 2) return 0;
+    // stitch: lists of true MCU starts per range; `cur` = the true reader at the end of what has been assigned so far
+    std::vector<std::vector<ParSnap>> range((size_t)T);
+    range[0].assign(seen[0].begin(), seen[0].end() - 1);
+    ParSnap cur = seen[0].back(); // (cur.dc: the TRUE predictors at cur, kept so through the stitching)
+    int owner = 0; // the range that takes the MCUs decoded while looking for the next chunk's first true start
+    std::vector<ParSnap> more;
+    std::vector<int32_t> pred_at((size_t)T * 3, 0); // true predictors at the start of every range
+    for (int t = 1; t < T; t++) {
+        const std::vector<ParSnap>& cand = seen[(size_t)t];
+        size_t j = 0;
+        bool matched = false;
+        for (;;) {
+            while (j < cand.size() && cand[j].dbits < cur.dbits) j++;
+            if (ok[(size_t)t] && j + 1 < cand.size() && cand[j].dbits == cur.dbits) { matched = true; break; }
+            if (cur.p >= start[(size_t)t + 1]) break; // past this chunk without ever meeting it: the chunk is dropped
+            // one more true MCU (it belongs to the range in front), then look again
+            BitReader r;
+            r.p = cur.p; r.acc = cur.acc; r.nbits = cur.nbits; r.end = br.end; r.istart = cur.p;
+            more.clear();
+            if (!par_structure_run(d, r, cur.dbits + cur.nbits, cur.rbl, cur.exact, cur.dc, start[(size_t)T], 1, more) || more.size() != 2) return 0;
+            range[(size_t)owner].push_back(more[0]);
+            cur = more[1];
+        }
+        if (matched) {
+            range[(size_t)t].assign(cand.begin() + (long)j, cand.end() - 1);
+            // (the speculative reader did not know bits_left at its start; by its first true MCU it does, or the snapshot says so)
+            for (int c = 0; c < 3; c++) pred_at[(size_t)t * 3 + (size_t)c] = cur.dc[c];
+            const ParSnap from = cand[j];
+            int32_t truth[3];
+            for (int c = 0; c < 3; c++) truth[c] = (int32_t)((uint32_t)cur.dc[c] + ((uint32_t)cand.back().dc[c] - (uint32_t)from.dc[c]));
+            cur = cand.back();
+            for (int c = 0; c < 3; c++) cur.dc[c] = truth[c];
+            owner = t;
+        }
+    }
+    long long total_mcus = 0;
+    for (int t = 0; t < T; t++) {
+        for (const ParSnap& sn : range[(size_t)t]) if (sn.hazard) return 0; // the serial walk decides what the reference reads there
+        total_mcus += (long long)range[(size_t)t].size();
+    }
+    if (total_mcus <= 0 || total_mcus > (long long)d->mcu_x * d->mcu_y) return 0;
+    // B: the coefficients, every range from its own first MCU start with predictors 0
+    std::vector<long long> first((size_t)T + 1, 0);
+    for (int t = 0; t < T; t++) first[(size_t)t + 1] = first[(size_t)t] + (long long)range[(size_t)t].size();
+    struct Out { int32_t pred[3]; long long end_bits; int rc; int rbl; BitReader br; };
+    std::vector<Out> res((size_t)T);
+    parallel_for(T, T, [&](int t) {
+        Out& o = res[(size_t)t];
+        for (int c = 0; c < 3; c++) o.pred[c] = pred_at[(size_t)t * 3 + (size_t)c];
+        o.rc = 0; o.end_bits = -1;
+        const std::vector<ParSnap>& mine = range[(size_t)t];
+        if (mine.empty()) return;
+        BitReader& r = o.br;
+        r.p = mine[0].p; r.acc = mine[0].acc; r.nbits = mine[0].nbits; r.end = br.end; r.istart = mine[0].p;
+        r.rbl = mine[0].rbl;
+        long long done = 0;
+        const char* err = nullptr;
+        o.rc = fn.mcus(d, d, r, o.pred, first[(size_t)t], (long long)mine.size(), nullptr, &done, &err);
+        if (!o.rc && done != (long long)mine.size()) o.rc = ZJ_ERR_HUFFMAN;
+        if (!o.rc && r.marker) o.rc = ZJ_ERR_HUFFMAN;
+        if (!o.rc) o.end_bits = mine[0].dbits + mine[0].nbits + r.consumed();
+    });
+    // every range must have ended exactly where the next one began
+    {
+        int prev = -1;
+        for (int t = 0; t < T; t++) {
+            if (range[(size_t)t].empty()) continue;
+            if (res[(size_t)t].rc) return 0;
+            if (prev >= 0 && res[(size_t)prev].end_bits != range[(size_t)t][0].dbits) return 0;
+            prev = t;
+        }
+        if (prev < 0 || res[(size_t)prev].end_bits != cur.dbits) return 0;
+    }
+    // ... and with the predictors the next one was started with
+    {
+        int prev = -1;
+        for (int t = 0; t < T; t++) {
+            if (range[(size_t)t].empty()) continue;
+            if (prev >= 0 && memcmp(res[(size_t)prev].pred, &pred_at[(size_t)t * 3], sizeof res[0].pred) != 0) return 0;
+            prev = t;
+        }
+        if (memcmp(res[(size_t)prev].pred, cur.dc, sizeof cur.dc) != 0) return 0;
+        for (int c = 0; c < d->ncomp; c++) d->comps[c].dc_pred = res[(size_t)prev].pred[c];
+    }
+    // the serial walk goes on from the last range's end: the reader as that range left it
+    {
+        int last_t = T - 1;
+        while (range[(size_t)last_t].empty()) last_t--;
+        const BitReader& r = res[(size_t)last_t].br;
+        const long long stuffed_total = ((long long)(r.p - p0) * 8 - (cur.dbits + r.nbits)) / 8; // 0xFF00 pairs in front of r.p
+        br.p = r.p; br.acc = r.acc; br.nbits = r.nbits; br.rbl = r.rbl; br.marker = 0; br.mpos = nullptr; br.pad = 0;
+        br.istart = p0; br.stuffed = (uint32_t)stuffed_total;
+        br.rbl0 = 0; br.rhist = 0;
+    }
+    return total_mcus;
+}
+
 void fill_frame_desc(const zj_decoder* d, zj_frame_desc* fd);
 
 // the walker has finished MCU rows [0, rows): hand the strips they complete to the GPU (no-op unless a stream is active)
@@ -1215,7 +1489,18 @@ int scan_baseline(zj_decoder* d, BitReader& br)
     };
     // (2,1): the reference walks 2*mcu_x MCUs per strip (mcu.rs:145-152); MCU order is unchanged
     const uint8_t* const stop = cut.eoi ? cut.eoi - (cut.eoi - br.p > 4096 ? 4096 : cut.eoi - br.p) : nullptr;
-    for (long long m = 0; m < total;) {
+    long long m_first = 0;
+    d->par_scan_mcus = 0;
+    if (d->threads > 1 && !d->restart_interval && fn.mcus && !d->track_hist && d->plane_store == STORE_DIRECT && cut.eoi) {
+        const char* e = getenv("ZJ_PAR_SCAN");
+        if (!(e && (!strcmp(e, "off") || !strcmp(e, "0")))) {
+            m_first = scan_baseline_parallel(d, br, fn, cut.eoi);
+            d->par_scan_mcus = m_first;
+            if (!m_first) for (int i = 0; i < d->ncomp; i++) d->comps[i].dc_pred = 0;
+            stream_rows(d, m_first);
+        }
+    }
+    for (long long m = m_first; m < total;) {
         if (fn.mcus && !d->track_hist && !cut.seen) {
             // as many MCUs as possible in one go (decode_mcus_v2): up to the next restart boundary, short of the scan's last 4 KB.
             // eoi_cut_after_mcu has nothing to do for them (it starts looking 64 bytes in front of the EOI marker).
@@ -1786,6 +2071,7 @@ zj_decoder* zj_decoder_new(const zj_options* opt)
 void zj_decoder_free(zj_decoder* d) { delete d; }
 const char* zj_decoder_error(const zj_decoder* d) { return d ? d->err.c_str() : ""; }
 int zj_decoder_parallel_segments(const zj_decoder* d) { return d ? d->dri_parallel_segments : 0; }
+long long zj_decoder_parallel_mcus(const zj_decoder* d) { return d ? d->par_scan_mcus : 0; }
 
 static void fill_info(const zj_decoder* d, zj_image_info* info, zj_frame_desc* fd)
 {

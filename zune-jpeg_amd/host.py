@@ -150,7 +150,7 @@ ABI = [  # every symbol include/zjhip.h declares
     "zj_decoder_finish_pixels_device", "zj_decoder_scan_blob", "zj_decoder_gpu_status", "zj_pool_decode_files_device",
     "zj_decoder_new", "zj_decoder_free", "zj_decoder_error", "zj_decoder_read_headers",
     "zj_decoder_decode_coefficients", "zj_decoder_finish_pixels", "zj_decoder_decode_buffer",
-    "zj_decoder_parallel_segments",
+    "zj_decoder_parallel_segments", "zj_decoder_parallel_mcus",
     "zj_pool_create", "zj_pool_destroy", "zj_pool_threads", "zj_pool_error", "zj_pool_stats",
     "zj_pool_decode_files", "zj_set_variant", "zj_variant_available", "zj_set_pipeline",
     "zj_decode_frames", "zj_decode_planes_device_strided", "zj_decode_frames_device", "zj_pointer_device",
@@ -255,6 +255,8 @@ def lib():
     L.zj_decoder_decode_coefficients.argtypes = [vp, vp, sz, C.POINTER(FrameDesc), C.POINTER(C.c_void_p), C.POINTER(sz), C.POINTER(ImageInfo)]
     L.zj_decoder_decode_buffer.argtypes = [vp, vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(ImageInfo)]
     L.zj_decoder_parallel_segments.argtypes = [vp]
+    L.zj_decoder_parallel_mcus.restype = C.c_longlong
+    L.zj_decoder_parallel_mcus.argtypes = [vp]
     L.zj_decoder_prepare.argtypes = [vp, vp, sz, C.POINTER(FrameDesc), C.POINTER(ImageInfo)]
     L.zj_decoder_finish_pixels.argtypes = [vp, vp, vp, sz, C.POINTER(sz)]
     L.zj_decoder_finish_pixels_device.argtypes = [vp, vp, vp, sz, C.POINTER(sz)]
@@ -621,6 +623,10 @@ class Decoder:
     def parallel_segments(self):
         """Restart segments the last baseline scan decoded concurrently (0 = serial walk)."""
         return lib().zj_decoder_parallel_segments(self._d)
+
+    def parallel_mcus(self):
+        """MCUs of the last baseline scan without restart markers that several threads decoded (0 = serial walk)."""
+        return int(lib().zj_decoder_parallel_mcus(self._d))
 
     def read_headers(self, buf):  # decoder.rs:452
         b = np.frombuffer(bytes(buf), np.uint8)
