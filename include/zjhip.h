@@ -344,7 +344,7 @@ ZJ_API int zj_decoder_decode_buffer(zj_decoder *d, zj_ctx *ctx, const uint8_t *b
 ZJ_API int zj_decoder_parallel_segments(const zj_decoder *d);
 /* MCUs of the last baseline scan WITHOUT restart markers that several threads decoded (zj_options.num_threads > 1: the scan is
  * entered at one point per thread, the threads fall into step with the true symbol sequence; zj_jpeg.cpp); 0 = the serial walk */
-ZJ_API long long zj_decoder_parallel_mcus(const zj_decoder *d);
+ZJ_API int64_t zj_decoder_parallel_mcus(const zj_decoder *d);
 
 /* ---- batches of files: `threads` persistent host workers, each with its own entropy
  * decoder, pinned coefficient planes and GPU context on `device`; file i is decoded by whichever worker is

@@ -8,7 +8,7 @@ Canonical type = (base, chain) where chain lists, from the OUTERMOST pointer inw
 """
 import re
 
-C_BASE = {"int16_t": "i16", "int32_t": "i32", "uint8_t": "u8", "uint16_t": "u16", "uint32_t": "u32", "size_t": "usize",
+C_BASE = {"int16_t": "i16", "int32_t": "i32", "int64_t": "i64", "uint8_t": "u8", "uint16_t": "u16", "uint32_t": "u32", "size_t": "usize",
           "int": "c_int", "unsigned": "c_uint", "float": "f32", "double": "f64", "char": "c_char", "void": "c_void"}
 RUST_ALIAS = {"u32": "c_uint"}  # `unsigned` is declared as u32 in the shim: the same 32 bits on every target of the library
 

@@ -2071,7 +2071,7 @@ zj_decoder* zj_decoder_new(const zj_options* opt)
 void zj_decoder_free(zj_decoder* d) { delete d; }
 const char* zj_decoder_error(const zj_decoder* d) { return d ? d->err.c_str() : ""; }
 int zj_decoder_parallel_segments(const zj_decoder* d) { return d ? d->dri_parallel_segments : 0; }
-long long zj_decoder_parallel_mcus(const zj_decoder* d) { return d ? d->par_scan_mcus : 0; }
+int64_t zj_decoder_parallel_mcus(const zj_decoder* d) { return d ? (int64_t)d->par_scan_mcus : 0; }
 
 static void fill_info(const zj_decoder* d, zj_image_info* info, zj_frame_desc* fd)
 {
