@@ -1188,9 +1188,9 @@ bool par_structure_run(const zj_decoder* d, BitReader& br, long long base_bits, 
     uint64_t acc = br.acc;
     int nbits = br.nbits;
     const uint8_t* p = br.p;
-    auto put = [&]() { br.acc = acc; br.nbits = nbits; br.p = p; };
-    auto get = [&]() { acc = br.acc; nbits = br.nbits; p = br.p; };
-    auto refill = [&]() {
+    auto put = [&]() __attribute__((always_inline)) { br.acc = acc; br.nbits = nbits; br.p = p; };
+    auto get = [&]() __attribute__((always_inline)) { acc = br.acc; nbits = br.nbits; p = br.p; };
+    auto refill = [&]() __attribute__((always_inline)) {
         if (__builtin_expect(!br.marker && br.end - p >= 8, 1)) {
             uint64_t x;
             memcpy(&x, p, 8);
@@ -1205,14 +1205,13 @@ bool par_structure_run(const zj_decoder* d, BitReader& br, long long base_bits, 
         }
         put(); br.fill(); get();
     };
+    put();
+    long long bits = base_bits + br.consumed(); // data bits consumed, followed symbol by symbol (checked against the reader at the end)
     for (size_t done = 0;; done++) {
-        put();
         if (br.marker) return false;
-        const long long here = base_bits + br.consumed();
-        out.push_back(ParSnap{p, acc, here, nbits, rbl, exact, false, {(int32_t)pred[0], (int32_t)pred[1], (int32_t)pred[2]}});
-        if (p >= until || done == max_new) return true;
+        out.push_back(ParSnap{p, acc, bits, nbits, rbl, exact, false, {(int32_t)pred[0], (int32_t)pred[1], (int32_t)pred[2]}});
+        if (p >= until || done == max_new) { put(); return !br.marker && bits == base_bits + br.consumed(); }
         bool hazard = false;
-        long long bits = here; // data bits consumed, followed symbol by symbol through the MCU
         for (int j = 0; j < bpm; j++) {
             if (nbits < 32) refill();
             // DC (src/bitstream.rs:264-296): the reference refills below 16 bits only, the symbol may be longer
@@ -1300,6 +1299,9 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
         }
     }
     for (int t = 1; t <= T; t++) if (start[(size_t)t] <= start[(size_t)t - 1]) return 0;
+    const bool dbg = getenv("ZJ_PAR_DEBUG") != nullptr;
+    const auto clk = [] { return std::chrono::steady_clock::now(); };
+    const auto t_a = clk();
     // A: structure of every chunk, speculatively (chunk 0: truly)
     std::vector<std::vector<ParSnap>> seen((size_t)T);
     std::vector<char> ok((size_t)T, 0);
@@ -1310,10 +1312,14 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
         const int32_t zero[3] = {0, 0, 0}; // (the scan begins with predictors 0; a chunk's own count starts anywhere)
         ok[(size_t)t] = par_structure_run(d, r, base[(size_t)t], t == 0 ? br.rbl : 0, t == 0, zero, start[(size_t)t + 1], (size_t)-1, seen[(size_t)t]);
     });
+    const auto t_s = clk();
     if (!ok[0] || seen[0].size() < 2) return 0;
     // stitch: lists of true MCU starts per range; `cur` = the true reader at the end of what has been assigned so far
-    std::vector<std::vector<ParSnap>> range((size_t)T);
-    range[0].assign(seen[0].begin(), seen[0].end() - 1);
+    // A range = the MCUs one thread decodes for real: the true MCU starts its own structure run met, seen[t][from, to), and
+    // behind them the MCUs the stitching had to decode on the way to the next chunk's first true start (extra)
+    struct Range { size_t from = 0, to = 0; std::vector<ParSnap> extra; long long count() const { return (long long)(to - from + extra.size()); } };
+    std::vector<Range> range((size_t)T);
+    range[0].to = seen[0].size() - 1;
     ParSnap cur = seen[0].back(); // (cur.dc: the TRUE predictors at cur, kept so through the stitching)
     int owner = 0; // the range that takes the MCUs decoded while looking for the next chunk's first true start
     std::vector<ParSnap> more;
@@ -1331,74 +1337,70 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
             r.p = cur.p; r.acc = cur.acc; r.nbits = cur.nbits; r.end = br.end; r.istart = cur.p;
             more.clear();
             if (!par_structure_run(d, r, cur.dbits + cur.nbits, cur.rbl, cur.exact, cur.dc, start[(size_t)T], 1, more) || more.size() != 2) return 0;
-            range[(size_t)owner].push_back(more[0]);
+            range[(size_t)owner].extra.push_back(more[0]);
             cur = more[1];
         }
         if (matched) {
-            range[(size_t)t].assign(cand.begin() + (long)j, cand.end() - 1);
+            range[(size_t)t].from = j;
+            range[(size_t)t].to = cand.size() - 1;
             // (the speculative reader did not know bits_left at its start; by its first true MCU it does, or the snapshot says so)
             for (int c = 0; c < 3; c++) pred_at[(size_t)t * 3 + (size_t)c] = cur.dc[c];
-            const ParSnap from = cand[j];
             int32_t truth[3];
-            for (int c = 0; c < 3; c++) truth[c] = (int32_t)((uint32_t)cur.dc[c] + ((uint32_t)cand.back().dc[c] - (uint32_t)from.dc[c]));
+            for (int c = 0; c < 3; c++) truth[c] = (int32_t)((uint32_t)cur.dc[c] + ((uint32_t)cand.back().dc[c] - (uint32_t)cand[j].dc[c]));
             cur = cand.back();
             for (int c = 0; c < 3; c++) cur.dc[c] = truth[c];
             owner = t;
         }
     }
-    long long total_mcus = 0;
-    for (int t = 0; t < T; t++) {
-        for (const ParSnap& sn : range[(size_t)t]) if (sn.hazard) return 0; // the serial walk decides what the reference reads there
-        total_mcus += (long long)range[(size_t)t].size();
-    }
-    if (total_mcus <= 0 || total_mcus > (long long)d->mcu_x * d->mcu_y) return 0;
-    // B: the coefficients, every range from its own first MCU start with predictors 0
     std::vector<long long> first((size_t)T + 1, 0);
-    for (int t = 0; t < T; t++) first[(size_t)t + 1] = first[(size_t)t] + (long long)range[(size_t)t].size();
-    struct Out { int32_t pred[3]; long long end_bits; int rc; int rbl; BitReader br; };
+    for (int t = 0; t < T; t++) first[(size_t)t + 1] = first[(size_t)t] + range[(size_t)t].count();
+    const long long total_mcus = first[(size_t)T];
+    if (total_mcus <= 0 || total_mcus > (long long)d->mcu_x * d->mcu_y) return 0;
+    const auto t_b = clk();
+    // B: the coefficients, every range from its own first MCU start and the predictors that hold there
+    struct Out { int32_t pred[3]; long long begin_bits, end_bits; int rc; BitReader br; };
     std::vector<Out> res((size_t)T);
     parallel_for(T, T, [&](int t) {
         Out& o = res[(size_t)t];
         for (int c = 0; c < 3; c++) o.pred[c] = pred_at[(size_t)t * 3 + (size_t)c];
-        o.rc = 0; o.end_bits = -1;
-        const std::vector<ParSnap>& mine = range[(size_t)t];
-        if (mine.empty()) return;
+        o.rc = 0; o.begin_bits = o.end_bits = -1;
+        const Range& mine = range[(size_t)t];
+        if (!mine.count()) return;
+        // a DC symbol the reference may read short anywhere in the range: the serial walk decides what it reads there
+        for (size_t i = mine.from; i < mine.to; i++) if (seen[(size_t)t][i].hazard) { o.rc = ZJ_INT_NEED_HIST; return; }
+        for (const ParSnap& sn : mine.extra) if (sn.hazard) { o.rc = ZJ_INT_NEED_HIST; return; }
+        const ParSnap& s0 = mine.to > mine.from ? seen[(size_t)t][mine.from] : mine.extra[0];
         BitReader& r = o.br;
-        r.p = mine[0].p; r.acc = mine[0].acc; r.nbits = mine[0].nbits; r.end = br.end; r.istart = mine[0].p;
-        r.rbl = mine[0].rbl;
+        r.p = s0.p; r.acc = s0.acc; r.nbits = s0.nbits; r.end = br.end; r.istart = s0.p;
+        r.rbl = s0.rbl;
+        o.begin_bits = s0.dbits;
         long long done = 0;
         const char* err = nullptr;
-        o.rc = fn.mcus(d, d, r, o.pred, first[(size_t)t], (long long)mine.size(), nullptr, &done, &err);
-        if (!o.rc && done != (long long)mine.size()) o.rc = ZJ_ERR_HUFFMAN;
+        o.rc = fn.mcus(d, d, r, o.pred, first[(size_t)t], mine.count(), nullptr, &done, &err);
+        if (!o.rc && done != mine.count()) o.rc = ZJ_ERR_HUFFMAN;
         if (!o.rc && r.marker) o.rc = ZJ_ERR_HUFFMAN;
-        if (!o.rc) o.end_bits = mine[0].dbits + mine[0].nbits + r.consumed();
+        if (!o.rc) o.end_bits = s0.dbits + s0.nbits + r.consumed();
     });
-    // every range must have ended exactly where the next one began
-    {
-        int prev = -1;
-        for (int t = 0; t < T; t++) {
-            if (range[(size_t)t].empty()) continue;
-            if (res[(size_t)t].rc) return 0;
-            if (prev >= 0 && res[(size_t)prev].end_bits != range[(size_t)t][0].dbits) return 0;
-            prev = t;
-        }
-        if (prev < 0 || res[(size_t)prev].end_bits != cur.dbits) return 0;
+    if (dbg) {
+        const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        size_t extra = 0;
+        for (const Range& r : range) extra += r.extra.size();
+        fprintf(stderr, "scan_baseline_parallel: %d threads, %lld MCUs (%zu decoded while stitching); structure %.2f ms, stitch %.2f ms, decode %.2f ms\n",
+                T, total_mcus, extra, ms(t_a, t_s), ms(t_s, t_b), ms(t_b, clk()));
     }
-    // ... and with the predictors the next one was started with
-    {
-        int prev = -1;
-        for (int t = 0; t < T; t++) {
-            if (range[(size_t)t].empty()) continue;
-            if (prev >= 0 && memcmp(res[(size_t)prev].pred, &pred_at[(size_t)t * 3], sizeof res[0].pred) != 0) return 0;
-            prev = t;
-        }
-        if (memcmp(res[(size_t)prev].pred, cur.dc, sizeof cur.dc) != 0) return 0;
-        for (int c = 0; c < d->ncomp; c++) d->comps[c].dc_pred = res[(size_t)prev].pred[c];
+    // every range must have ended exactly where the next one began, with the predictors the next one was started with
+    int last_t = -1;
+    for (int t = 0; t < T; t++) {
+        if (!range[(size_t)t].count()) continue;
+        if (res[(size_t)t].rc) return 0;
+        if (last_t >= 0 && (res[(size_t)last_t].end_bits != res[(size_t)t].begin_bits ||
+                            memcmp(res[(size_t)last_t].pred, &pred_at[(size_t)t * 3], sizeof res[0].pred) != 0)) return 0;
+        last_t = t;
     }
+    if (last_t < 0 || res[(size_t)last_t].end_bits != cur.dbits || memcmp(res[(size_t)last_t].pred, cur.dc, sizeof cur.dc) != 0) return 0;
+    for (int c = 0; c < d->ncomp; c++) d->comps[c].dc_pred = res[(size_t)last_t].pred[c];
     // the serial walk goes on from the last range's end: the reader as that range left it
     {
-        int last_t = T - 1;
-        while (range[(size_t)last_t].empty()) last_t--;
         const BitReader& r = res[(size_t)last_t].br;
         const long long stuffed_total = ((long long)(r.p - p0) * 8 - (cur.dbits + r.nbits)) / 8; // 0xFF00 pairs in front of r.p
         br.p = r.p; br.acc = r.acc; br.nbits = r.nbits; br.rbl = r.rbl; br.marker = 0; br.mpos = nullptr; br.pad = 0;
