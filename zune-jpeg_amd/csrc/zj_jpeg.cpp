@@ -53,8 +53,10 @@ struct Huff {
     //   kadv    what the entry adds to k
     //   len, sz code length and magnitude bits of the (first) symbol
     //   sx      26 where the reference's fast-AC table keeps only six bits of the value (see fast[] above), else 0
+    //   t1, k1  what the (first) symbol alone consumes and adds to k: equal to total and kadv except in a folded entry, for the
+    //           decoders that take one symbol at a time (decode_block_baseline, par_structure_run)
     // The value itself is computed from the bits (the arithmetic is off the critical path).
-    struct AcEnt { uint8_t total, idxoff, kadv, len, sz, fold, sx, pad; };
+    struct AcEnt { uint8_t total, idxoff, kadv, len, sz, k1, sx, t1; };
     AcEnt actab[1 << AC_BITS];
     bool full_values = false; // ZJ_FLAG_FULL_AC_VALUES: fast-AC values are not cut to six bits
     int build(const uint8_t counts[17], const uint8_t* symbols, int nsym, std::string& err)
@@ -133,7 +135,7 @@ struct Huff {
                 if (!e2.total || e2.sz || e2.kadv != 64 || e2.len > AC_BITS - e1.total) continue;
                 folded[w].total = (uint8_t)(e1.total + e2.len);
                 folded[w].kadv = 64;
-                folded[w].fold = 1;
+                // (t1 and k1 stay the coefficient's own)
             }
             memcpy(actab, folded, sizeof actab);
         }
@@ -163,6 +165,7 @@ struct Huff {
         AcEnt e;
         memset(&e, 0, sizeof e);
         e.total = (uint8_t)(len + sz); e.idxoff = (uint8_t)idxoff; e.kadv = (uint8_t)kadv; e.len = (uint8_t)len; e.sz = (uint8_t)sz;
+        e.t1 = e.total; e.k1 = e.kadv;
         e.sx = ref_fast && sz >= 6 ? 26 : 0;
         return e;
     }
@@ -762,7 +765,7 @@ int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, in
             const int32_t v0 = bits + ((((bits - (1 << (sz - 1))) >> 31)) & (1 - (1 << sz)));
             const int32_t v = (int32_t)((uint32_t)v0 << en.sx) >> en.sx; // (sx: Huff::AcEnt)
             blk[kZZ.t[k + en.idxoff]] = (int16_t)v;
-            k += (en.idxoff & 127) + 1;
+            k += en.k1;
         } else k += en.kadv; // ZRL, EOB, and the reference's reading of the other size-0 symbols (Huff::ac_entry)
     }
     return ZJ_OK;
@@ -917,7 +920,7 @@ inline __attribute__((always_inline)) int decode_mcus_v2_body(const zj_decoder* 
                         } while (k < 64);
                         if (!rc) {
                             int last = (int)total; // length of the block's last symbol
-                            if (en->fold) {
+                            if (en->total != en->t1) { // a folded entry
                                 const int t1 = en->len + en->sz, off = en->idxoff;
                                 if (k - 64 + (off & 127) + 1 >= 64) { // the coefficient ended the block by itself
                                     acc = acc0 << t1;
@@ -1249,9 +1252,9 @@ bool par_structure_run(const zj_decoder* d, BitReader& br, long long base_bits, 
                     en = pat[j].ha->ac_escape(acc);
                     if (!en.total) return false;
                 }
-                last = en.len + en.sz;
+                last = en.t1;
                 last_at = bits;
-                k += en.sz ? (en.idxoff & 127) + 1 : en.kadv;
+                k += en.k1;
                 acc <<= last; nbits -= last; bits += last;
                 nac++;
             } while (k < 64);
