@@ -19,6 +19,9 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -381,18 +384,66 @@ struct PlaneStore {
 };
 
 // run fn(i) for i in [0, n) on up to `threads` std::threads (the calling thread is one of them)
-template <class F> void parallel_for(int n, int threads, F fn)
-{
-    if (threads > n) threads = n;
-    if (threads <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
-    std::atomic<int> next{0};
-    auto work = [&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
-    std::vector<std::thread> pool;
-    pool.reserve((size_t)threads - 1);
-    for (int t = 1; t < threads; t++) pool.emplace_back(work);
-    work();
-    for (auto& th : pool) th.join();
-}
+// The decoder's helper threads (round 6).  Rounds 4-5 started std::threads for every parallel region -- plane zeroing, restart
+// segments, and now the two passes of scan_baseline_parallel: three regions per file, and on the GPU hosts a clone() costs
+// 30-60 us, paid one after the other by the thread that should be working (16 threads: the last helper started 0.6 ms late,
+// twice, in a scan that takes 4 ms).  The crew is started once per decoder, at the first region that wants it, sleeps on a
+// condition variable between regions and is joined by zj_decoder_destroy.  Helpers inherit the creating thread's affinity
+// (zj_numa.cpp binds that one).
+class Crew {
+public:
+    Crew() = default;
+    Crew(const Crew&) = delete;
+    Crew& operator=(const Crew&) = delete;
+    ~Crew()
+    {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        wake_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    // fn(i) for every i in [0, n) on at most `threads` threads, the caller among them; items are claimed one at a time
+    template <class F> void each(int n, int threads, F fn)
+    {
+        if (threads > n) threads = n;
+        if (threads <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
+        std::atomic<int> next{0};
+        auto work = [&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
+        const std::function<void()> job = std::cref(work);
+        {
+            std::lock_guard<std::mutex> g(m_);
+            while ((int)th_.size() < threads - 1) th_.emplace_back([this] { helper(); });
+            job_ = &job; seats_ = threads - 1; gen_++;
+        }
+        wake_.notify_all();
+        work();
+        std::unique_lock<std::mutex> g(m_);
+        job_ = nullptr; // (a helper that has not woken up yet finds nothing to do: every item is claimed)
+        idle_.wait(g, [this] { return busy_ == 0; });
+    }
+private:
+    void helper()
+    {
+        unsigned long seen = 0;
+        std::unique_lock<std::mutex> g(m_);
+        for (;;) {
+            wake_.wait(g, [&] { return stop_ || (job_ && gen_ != seen && seats_ > 0); });
+            if (stop_) return;
+            seen = gen_; seats_--; busy_++;
+            const std::function<void()>* job = job_;
+            g.unlock();
+            (*job)();
+            g.lock();
+            if (--busy_ == 0) idle_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable wake_, idle_;
+    std::vector<std::thread> th_;
+    const std::function<void()>* job_ = nullptr;
+    unsigned long gen_ = 0;
+    int seats_ = 0, busy_ = 0;
+    bool stop_ = false;
+};
 
 } // namespace
 
@@ -401,6 +452,7 @@ struct zj_decoder {
     int out_colorspace = ZJ_CS_RGB;
     int strict_mode = 0;
     int max_width = 16384, max_height = 16384, max_scans = 64;
+    Crew crew;             // helper threads, started at the first parallel region
     int threads = 4;       // options.rs:33 (default 4): here, restart segments / plane zeroing in parallel
     bool pinned = false;   // coefficient planes in pinned host memory
     int plane_store = 2;   // how the baseline walker's blocks reach their plane (STORE_*; ZJ_PLANE_STORE): in place
@@ -579,7 +631,7 @@ int parse_sof(zj_decoder* d, Cursor& c, int progressive)
         const size_t bytes = cm.coef_len * 2, piece = (size_t)4 << 20;
         const int n = (int)((bytes + piece - 1) / piece);
         char* base = (char*)cm.coef;
-        parallel_for(n, d->threads, [&](int k) {
+        d->crew.each(n, d->threads, [&](int k) {
             const size_t o = (size_t)k * piece;
             memset(base + o, 0, o + piece <= bytes ? piece : bytes - o);
         });
@@ -1159,6 +1211,7 @@ int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p,
 // by the same rules), any code that does not exist, any marker, a chunk that never falls into step -> the attempt is dropped
 // and the serial walk decodes the scan as if nothing had happened (it clears every block before it fills it).
 // 4096 x 4096 4:2:0 q = 90, 3.5 MB, 4 threads: 18 -> 7.5 ms on the GPU host (profiles/r06_walker.txt).  ZJ_PAR_SCAN=off.
+constexpr size_t kParEvery = 16;
 struct ParSnap {
     const uint8_t* p;   // the reader at an MCU start: next byte to load, accumulator, bits in it
     uint64_t acc;
@@ -1169,13 +1222,17 @@ struct ParSnap {
     bool exact;
     bool hazard;        // the MCU that starts here holds a DC symbol the reference may read short
     int32_t dc[3];      // the components' DC predictors here, counted from whatever the run was started with (wrapping)
+    long long mcu;      // MCUs decoded by the run before this one
 };
 
 // Structure-only decode from the state of `br` (br.istart marks the byte whose first bit is data bit `base_bits`): a ParSnap
-// at every MCU start, the first included, until an MCU starts at or behind `until` (recorded, not decoded) or `max_new` MCUs
-// have been decoded.  false: something undecodable (no such code, a marker or the end of the data in view).
+// at every `every`-th MCU start, the first included, until an MCU starts at or behind `until` (recorded, not decoded) or
+// `max_new` MCUs have been decoded (recorded as well).  A snapshot's hazard flag covers the MCUs up to the next snapshot.
+// Every 16th is what the chunks keep: a chunk's notes then stay in the core's L2 (48 bytes x 16 K MCUs were 0.8 MB per
+// thread, fresh pages each time), and the stitching walks at most 15 MCUs further to meet one.
+// false: something undecodable (no such code, a marker or the end of the data in view).
 bool par_structure_run(const zj_decoder* d, BitReader& br, long long base_bits, int rbl, bool exact, const int32_t pred0[3], const uint8_t* until,
-                       size_t max_new, std::vector<ParSnap>& out)
+                       size_t max_new, size_t every, std::vector<ParSnap>& out)
 {
     struct Blk { const Huff* hd; const Huff* ha; int comp; };
     Blk pat[8];
@@ -1212,8 +1269,10 @@ bool par_structure_run(const zj_decoder* d, BitReader& br, long long base_bits, 
     long long bits = base_bits + br.consumed(); // data bits consumed, followed symbol by symbol (checked against the reader at the end)
     for (size_t done = 0;; done++) {
         if (br.marker) return false;
-        out.push_back(ParSnap{p, acc, bits, nbits, rbl, exact, false, {(int32_t)pred[0], (int32_t)pred[1], (int32_t)pred[2]}});
-        if (p >= until || done == max_new) { put(); return !br.marker && bits == base_bits + br.consumed(); }
+        const bool last_one = p >= until || done == max_new;
+        if (last_one || done % every == 0)
+            out.push_back(ParSnap{p, acc, bits, nbits, rbl, exact, false, {(int32_t)pred[0], (int32_t)pred[1], (int32_t)pred[2]}, (long long)done});
+        if (last_one) { put(); return !br.marker && bits == base_bits + br.consumed(); }
         bool hazard = false;
         for (int j = 0; j < bpm; j++) {
             if (nbits < 32) refill();
@@ -1264,7 +1323,7 @@ bool par_structure_run(const zj_decoder* d, BitReader& br, long long base_bits, 
             else rbl = T - last;
             if (nbits < 0) return false; // (padding ran out: the end of the data)
         }
-        out.back().hazard = hazard;
+        if (hazard) out.back().hazard = true;
     }
 }
 
@@ -1308,21 +1367,22 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
     // A: structure of every chunk, speculatively (chunk 0: truly)
     std::vector<std::vector<ParSnap>> seen((size_t)T);
     std::vector<char> ok((size_t)T, 0);
-    parallel_for(T, T, [&](int t) {
+    d->crew.each(T, T, [&](int t) {
         BitReader r;
         r.p = start[(size_t)t]; r.end = br.end; r.istart = r.p;
-        seen[(size_t)t].reserve((size_t)((start[(size_t)t + 1] - start[(size_t)t]) / 24 + 64));
+        seen[(size_t)t].reserve((size_t)((start[(size_t)t + 1] - start[(size_t)t]) / (24 * kParEvery) + 64));
         const int32_t zero[3] = {0, 0, 0}; // (the scan begins with predictors 0; a chunk's own count starts anywhere)
-        ok[(size_t)t] = par_structure_run(d, r, base[(size_t)t], t == 0 ? br.rbl : 0, t == 0, zero, start[(size_t)t + 1], (size_t)-1, seen[(size_t)t]);
+        ok[(size_t)t] = par_structure_run(d, r, base[(size_t)t], t == 0 ? br.rbl : 0, t == 0, zero, start[(size_t)t + 1], (size_t)-1, kParEvery, seen[(size_t)t]);
     });
     const auto t_s = clk();
     if (!ok[0] || seen[0].size() < 2) return 0;
     // stitch: lists of true MCU starts per range; `cur` = the true reader at the end of what has been assigned so far
     // A range = the MCUs one thread decodes for real: the true MCU starts its own structure run met, seen[t][from, to), and
     // behind them the MCUs the stitching had to decode on the way to the next chunk's first true start (extra)
-    struct Range { size_t from = 0, to = 0; std::vector<ParSnap> extra; long long count() const { return (long long)(to - from + extra.size()); } };
+    struct Range { size_t from = 0, to = 0; long long noted = 0; std::vector<ParSnap> extra; long long count() const { return noted + (long long)extra.size(); } };
     std::vector<Range> range((size_t)T);
     range[0].to = seen[0].size() - 1;
+    range[0].noted = seen[0].back().mcu;
     ParSnap cur = seen[0].back(); // (cur.dc: the TRUE predictors at cur, kept so through the stitching)
     int owner = 0; // the range that takes the MCUs decoded while looking for the next chunk's first true start
     std::vector<ParSnap> more;
@@ -1339,13 +1399,14 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
             BitReader r;
             r.p = cur.p; r.acc = cur.acc; r.nbits = cur.nbits; r.end = br.end; r.istart = cur.p;
             more.clear();
-            if (!par_structure_run(d, r, cur.dbits + cur.nbits, cur.rbl, cur.exact, cur.dc, start[(size_t)T], 1, more) || more.size() != 2) return 0;
+            if (!par_structure_run(d, r, cur.dbits + cur.nbits, cur.rbl, cur.exact, cur.dc, start[(size_t)T], 1, 1, more) || more.size() != 2) return 0;
             range[(size_t)owner].extra.push_back(more[0]);
             cur = more[1];
         }
         if (matched) {
             range[(size_t)t].from = j;
             range[(size_t)t].to = cand.size() - 1;
+            range[(size_t)t].noted = cand.back().mcu - cand[j].mcu;
             // (the speculative reader did not know bits_left at its start; by its first true MCU it does, or the snapshot says so)
             for (int c = 0; c < 3; c++) pred_at[(size_t)t * 3 + (size_t)c] = cur.dc[c];
             int32_t truth[3];
@@ -1363,7 +1424,7 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
     // B: the coefficients, every range from its own first MCU start and the predictors that hold there
     struct Out { int32_t pred[3]; long long begin_bits, end_bits; int rc; BitReader br; };
     std::vector<Out> res((size_t)T);
-    parallel_for(T, T, [&](int t) {
+    d->crew.each(T, T, [&](int t) {
         Out& o = res[(size_t)t];
         for (int c = 0; c < 3; c++) o.pred[c] = pred_at[(size_t)t * 3 + (size_t)c];
         o.rc = 0; o.begin_bits = o.end_bits = -1;
@@ -1456,7 +1517,7 @@ int scan_baseline(zj_decoder* d, BitReader& br)
         std::vector<const uint8_t*> seg;
         if (find_restart_segments(br.p, br.end, nseg, seg)) {
             std::atomic<int> bad{0};
-            parallel_for(nseg, d->threads, [&](int k) {
+            d->crew.each(nseg, d->threads, [&](int k) {
                 const char* err = nullptr;
                 const long long m0 = (long long)k * ri, n = m0 + ri <= total ? ri : total - m0;
                 // a segment ends where the next RSTn (or the closing marker) begins: the reader stops there
