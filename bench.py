@@ -423,6 +423,23 @@ def reference_files(zj, ctx, reps=5):
             finally:
                 zj.lib().zj_free_pinned(pin)
             dec.close()
+            # the same stage with the reference's default of four threads (src/options.rs:33).  Expect no gain on these two: a
+            # progressive file's scans stay serial, and the baseline one is all but flat (6 bits per block), which
+            # scan_baseline_parallel leaves to the serial walk (from_files.cpu_entropy_4_threads is the case it is for)
+            o4 = zj.ZuneJpegOptions()
+            o4.num_threads, o4.pinned_planes = 4, True
+            dec4 = zj.Decoder(o4, ctx)
+            host4, px4 = 1e9, None
+            for _ in range(reps + 2):
+                t0 = time.perf_counter()
+                dec4.prepare(data)
+                host4 = min(host4, time.perf_counter() - t0)
+                par4 = dec4.parallel_mcus()
+                px4 = dec4.finish_pixels(px4)
+            whole["host_entropy_ms_4_threads"] = round(host4 * 1e3, 3)
+            whole["mcus_decoded_in_parallel"] = int(par4)
+            whole["four_threads_match"] = bool(np.array_equal(px4, px))
+            dec4.close()
             mp = r["width"] * r["height"] / 1e6
             blocks = 3 * ((r["width"] + 7) // 8) * ((r["height"] + 7) // 8)  # 4:4:4: three planes of (w/8) x (h/8) blocks
             out[name] = {"host_entropy_ms": round(host * 1e3, 3), "gpu_pixels_ms": round(gpu * 1e3, 3),

@@ -40,6 +40,7 @@ def _decode(zj, data, threads, v1, par=False):
         os.environ.pop("ZJ_WALKER_V1", None)
     if par:
         os.environ["ZJ_PAR_MIN_CHUNK"] = "1024"
+        os.environ["ZJ_PAR_MIN_BITS"] = "0"   # flat pictures too (the product leaves them to the serial walk)
         os.environ.pop("ZJ_PAR_SCAN", None)
     else:
         os.environ["ZJ_PAR_SCAN"] = "off"
@@ -59,6 +60,7 @@ def _decode(zj, data, threads, v1, par=False):
     finally:
         os.environ.pop("ZJ_WALKER_V1", None)
         os.environ.pop("ZJ_PAR_MIN_CHUNK", None)
+        os.environ.pop("ZJ_PAR_MIN_BITS", None)
         os.environ.pop("ZJ_PAR_SCAN", None)
 
 

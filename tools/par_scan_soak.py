@@ -21,6 +21,7 @@ zj = importlib.import_module("zune-jpeg_amd")
 def decode(data, threads, par):
     if par:
         os.environ["ZJ_PAR_MIN_CHUNK"] = "600"
+        os.environ["ZJ_PAR_MIN_BITS"] = "0"   # flat pictures too (the product leaves them to the serial walk)
         os.environ.pop("ZJ_PAR_SCAN", None)
     else:
         os.environ["ZJ_PAR_SCAN"] = "off"

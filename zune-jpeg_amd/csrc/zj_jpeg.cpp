@@ -1332,11 +1332,25 @@ bool par_structure_run(const zj_decoder* d, BitReader& br, long long base_bits, 
 long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& fn, const uint8_t* scan_end)
 {
     const uint8_t* const p0 = br.p;
-    const int T = d->threads < 16 ? d->threads : 16;
+    int T = d->threads < 16 ? d->threads : 16;
     const long long usable = (long long)(scan_end - p0) - 8192; // the tail stays with the serial walk (EoiCut, near_end)
-    long long min_chunk = 32768;                                // below this per thread the threads cost more than they bring
+    long long min_chunk = 12288;                                // below this per thread the threads cost more than they bring
+                                                                // (two wake-ups of the crew, ~20 us each; 12 KB decode in ~0.15 ms)
     if (const char* e = getenv("ZJ_PAR_MIN_CHUNK")) { const long v = atol(e); if (v >= 256) min_chunk = v; } // (tests: small files)
-    if (T < 2 || usable < (long long)T * min_chunk) return 0;
+    if ((long long)T * min_chunk > usable) T = (int)(usable / min_chunk);
+    if (T < 2) return 0;
+    // Mostly flat pictures stay with the serial walk: a reader that enters a run of identical short MCUs out of step stays
+    // out of step until the picture changes, the true structure decode then has to walk through all of them one after the
+    // other, and a block of two symbols costs it what it costs the real decode (the reference's test-baseline.jpg: 6 bits
+    // per block, a third of its MCUs walked -- no faster than the serial walk, 10 % slower in the worst case).
+    {
+        long long blocks = 0;
+        for (int ci = 0; ci < d->ns; ci++) blocks += (long long)d->comps[d->order[ci]].h * d->comps[d->order[ci]].v;
+        blocks *= (long long)d->mcu_x * d->mcu_y;
+        long long min_bits = 16;
+        if (const char* e = getenv("ZJ_PAR_MIN_BITS")) min_bits = atol(e); // (tests)
+        if ((scan_end - p0) * 8 < blocks * min_bits) return 0;
+    }
     // chunk starts: never on the zero that follows a 0xFF; 0xFF00 pairs in front of every chunk (for data bit numbers)
     std::vector<const uint8_t*> start((size_t)T + 1);
     std::vector<long long> base((size_t)T);
@@ -1376,89 +1390,113 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
     });
     const auto t_s = clk();
     if (!ok[0] || seen[0].size() < 2) return 0;
-    // stitch: lists of true MCU starts per range; `cur` = the true reader at the end of what has been assigned so far
-    // A range = the MCUs one thread decodes for real: the true MCU starts its own structure run met, seen[t][from, to), and
-    // behind them the MCUs the stitching had to decode on the way to the next chunk's first true start (extra)
-    struct Range { size_t from = 0, to = 0; long long noted = 0; std::vector<ParSnap> extra; long long count() const { return noted + (long long)extra.size(); } };
-    std::vector<Range> range((size_t)T);
-    range[0].to = seen[0].size() - 1;
-    range[0].noted = seen[0].back().mcu;
-    ParSnap cur = seen[0].back(); // (cur.dc: the TRUE predictors at cur, kept so through the stitching)
-    int owner = 0; // the range that takes the MCUs decoded while looking for the next chunk's first true start
+    // stitch: one list of TRUE MCU starts (anchors) over the whole scan, each with the MCU's index and the predictors that hold
+    // there; `cur` = the true reader behind the last anchored MCU.  A chunk's notes join the list from the note the true
+    // reader lands on; the MCUs the true structure decode has to walk through to get there (a chunk that never falls into
+    // step -- long runs of identical short MCUs keep a shifted reader shifted -- is walked through entirely) are anchors too.
+    struct Anchor { ParSnap s; long long mcu; };
+    std::vector<Anchor> anchors;
+    {
+        size_t n = 1024;
+        for (const auto& v : seen) n += v.size();
+        anchors.reserve(n);
+    }
+    // v[from] is where the true reader `at` stands (MCU at_mcu): v[from, size - 1) become anchors, v.back() the new `cur`
+    ParSnap cur{};
+    long long cur_mcu = 0;
+    const auto join = [&](const std::vector<ParSnap>& v, size_t from, const ParSnap& at, long long at_mcu) {
+        const auto true_dc = [&](const ParSnap& x, int32_t* out) {
+            for (int c = 0; c < 3; c++) out[c] = (int32_t)((uint32_t)at.dc[c] + ((uint32_t)x.dc[c] - (uint32_t)v[from].dc[c]));
+        };
+        for (size_t i = from; i + 1 < v.size(); i++) {
+            Anchor a{v[i], at_mcu + (v[i].mcu - v[from].mcu)};
+            true_dc(v[i], a.s.dc);
+            if (i == from) { a.s.rbl = at.rbl; a.s.exact = at.exact; } // (a speculative run may not know bits_left yet; the true reader does)
+            anchors.push_back(a);
+        }
+        ParSnap e = v.back();
+        true_dc(v.back(), e.dc);
+        if (v.size() == from + 1) { e.rbl = at.rbl; e.exact = at.exact; }
+        cur_mcu = at_mcu + (v.back().mcu - v[from].mcu);
+        cur = e;
+    };
+    join(seen[0], 0, seen[0][0], 0);
     std::vector<ParSnap> more;
-    std::vector<int32_t> pred_at((size_t)T * 3, 0); // true predictors at the start of every range
+    size_t walked = 0;
     for (int t = 1; t < T; t++) {
         const std::vector<ParSnap>& cand = seen[(size_t)t];
         size_t j = 0;
-        bool matched = false;
+        const auto meets = [&](const ParSnap& x) {
+            while (j < cand.size() && cand[j].dbits < x.dbits) j++;
+            return ok[(size_t)t] && j + 1 < cand.size() && cand[j].dbits == x.dbits;
+        };
         for (;;) {
-            while (j < cand.size() && cand[j].dbits < cur.dbits) j++;
-            if (ok[(size_t)t] && j + 1 < cand.size() && cand[j].dbits == cur.dbits) { matched = true; break; }
+            if (meets(cur)) { join(cand, j, ParSnap(cur), cur_mcu); break; }
             if (cur.p >= start[(size_t)t + 1]) break; // past this chunk without ever meeting it: the chunk is dropped
-            // one more true MCU (it belongs to the range in front), then look again
+            // up to 64 more true MCUs, then look again
             BitReader r;
             r.p = cur.p; r.acc = cur.acc; r.nbits = cur.nbits; r.end = br.end; r.istart = cur.p;
             more.clear();
-            if (!par_structure_run(d, r, cur.dbits + cur.nbits, cur.rbl, cur.exact, cur.dc, start[(size_t)T], 1, 1, more) || more.size() != 2) return 0;
-            range[(size_t)owner].extra.push_back(more[0]);
-            cur = more[1];
-        }
-        if (matched) {
-            range[(size_t)t].from = j;
-            range[(size_t)t].to = cand.size() - 1;
-            range[(size_t)t].noted = cand.back().mcu - cand[j].mcu;
-            // (the speculative reader did not know bits_left at its start; by its first true MCU it does, or the snapshot says so)
-            for (int c = 0; c < 3; c++) pred_at[(size_t)t * 3 + (size_t)c] = cur.dc[c];
-            int32_t truth[3];
-            for (int c = 0; c < 3; c++) truth[c] = (int32_t)((uint32_t)cur.dc[c] + ((uint32_t)cand.back().dc[c] - (uint32_t)cand[j].dc[c]));
-            cur = cand.back();
-            for (int c = 0; c < 3; c++) cur.dc[c] = truth[c];
-            owner = t;
+            if (!par_structure_run(d, r, cur.dbits + cur.nbits, cur.rbl, cur.exact, cur.dc, start[(size_t)T], 64, 1, more) || more.size() < 2) return 0;
+            size_t i = 1;
+            for (;; i++) {
+                anchors.push_back(Anchor{more[i - 1], cur_mcu++});
+                walked++;
+                if (i + 1 == more.size() || meets(more[i]) || more[i].p >= start[(size_t)t + 1]) break;
+            }
+            cur = more[i]; // (what the run decoded behind it is decoded again: by the chunk's own notes or the next run)
         }
     }
-    std::vector<long long> first((size_t)T + 1, 0);
-    for (int t = 0; t < T; t++) first[(size_t)t + 1] = first[(size_t)t] + range[(size_t)t].count();
-    const long long total_mcus = first[(size_t)T];
-    if (total_mcus <= 0 || total_mcus > (long long)d->mcu_x * d->mcu_y) return 0;
+    const long long total_mcus = cur_mcu;
+    if (total_mcus <= 0 || total_mcus > (long long)d->mcu_x * d->mcu_y || anchors.empty() || !cur.exact) return 0;
+    // the MCUs in T equal parts, each beginning at an anchor whose bits_left is known
+    std::vector<size_t> cut((size_t)T + 1, anchors.size());
+    cut[0] = 0;
+    {
+        size_t a = 0;
+        for (int q = 1; q < T; q++) {
+            const long long want = total_mcus * q / T;
+            while (a < anchors.size() && (anchors[a].mcu < want || !anchors[a].s.exact)) a++;
+            cut[(size_t)q] = a;
+        }
+    }
     const auto t_b = clk();
-    // B: the coefficients, every range from its own first MCU start and the predictors that hold there
+    // B: the coefficients, every part from its own first MCU start and the predictors that hold there
     struct Out { int32_t pred[3]; long long begin_bits, end_bits; int rc; BitReader br; };
     std::vector<Out> res((size_t)T);
     d->crew.each(T, T, [&](int t) {
         Out& o = res[(size_t)t];
-        for (int c = 0; c < 3; c++) o.pred[c] = pred_at[(size_t)t * 3 + (size_t)c];
         o.rc = 0; o.begin_bits = o.end_bits = -1;
-        const Range& mine = range[(size_t)t];
-        if (!mine.count()) return;
-        // a DC symbol the reference may read short anywhere in the range: the serial walk decides what it reads there
-        for (size_t i = mine.from; i < mine.to; i++) if (seen[(size_t)t][i].hazard) { o.rc = ZJ_INT_NEED_HIST; return; }
-        for (const ParSnap& sn : mine.extra) if (sn.hazard) { o.rc = ZJ_INT_NEED_HIST; return; }
-        const ParSnap& s0 = mine.to > mine.from ? seen[(size_t)t][mine.from] : mine.extra[0];
+        const size_t a0 = cut[(size_t)t], a1 = cut[(size_t)t + 1];
+        if (a0 >= a1) return;
+        // a DC symbol the reference may read short anywhere in the part: the serial walk decides what it reads there
+        for (size_t i = a0; i < a1; i++) if (anchors[i].s.hazard) { o.rc = ZJ_INT_NEED_HIST; return; }
+        const ParSnap& s0 = anchors[a0].s;
+        const long long count = (a1 < anchors.size() ? anchors[a1].mcu : total_mcus) - anchors[a0].mcu;
+        for (int c = 0; c < 3; c++) o.pred[c] = s0.dc[c];
         BitReader& r = o.br;
         r.p = s0.p; r.acc = s0.acc; r.nbits = s0.nbits; r.end = br.end; r.istart = s0.p;
         r.rbl = s0.rbl;
         o.begin_bits = s0.dbits;
         long long done = 0;
         const char* err = nullptr;
-        o.rc = fn.mcus(d, d, r, o.pred, first[(size_t)t], mine.count(), nullptr, &done, &err);
-        if (!o.rc && done != mine.count()) o.rc = ZJ_ERR_HUFFMAN;
+        o.rc = fn.mcus(d, d, r, o.pred, anchors[a0].mcu, count, nullptr, &done, &err);
+        if (!o.rc && done != count) o.rc = ZJ_ERR_HUFFMAN;
         if (!o.rc && r.marker) o.rc = ZJ_ERR_HUFFMAN;
         if (!o.rc) o.end_bits = s0.dbits + s0.nbits + r.consumed();
     });
     if (dbg) {
         const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        size_t extra = 0;
-        for (const Range& r : range) extra += r.extra.size();
         fprintf(stderr, "scan_baseline_parallel: %d threads, %lld MCUs (%zu decoded while stitching); structure %.2f ms, stitch %.2f ms, decode %.2f ms\n",
-                T, total_mcus, extra, ms(t_a, t_s), ms(t_s, t_b), ms(t_b, clk()));
+                T, total_mcus, walked, ms(t_a, t_s), ms(t_s, t_b), ms(t_b, clk()));
     }
-    // every range must have ended exactly where the next one began, with the predictors the next one was started with
+    // every part must have ended exactly where the next one began, with the predictors the next one was started with
     int last_t = -1;
     for (int t = 0; t < T; t++) {
-        if (!range[(size_t)t].count()) continue;
+        if (cut[(size_t)t] >= cut[(size_t)t + 1]) continue;
         if (res[(size_t)t].rc) return 0;
         if (last_t >= 0 && (res[(size_t)last_t].end_bits != res[(size_t)t].begin_bits ||
-                            memcmp(res[(size_t)last_t].pred, &pred_at[(size_t)t * 3], sizeof res[0].pred) != 0)) return 0;
+                            memcmp(res[(size_t)last_t].pred, anchors[cut[(size_t)t]].s.dc, sizeof res[0].pred) != 0)) return 0;
         last_t = t;
     }
     if (last_t < 0 || res[(size_t)last_t].end_bits != cur.dbits || memcmp(res[(size_t)last_t].pred, cur.dc, sizeof cur.dc) != 0) return 0;
