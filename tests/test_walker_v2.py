@@ -40,7 +40,6 @@ def _decode(zj, data, threads, v1, par=False):
         os.environ.pop("ZJ_WALKER_V1", None)
     if par:
         os.environ["ZJ_PAR_MIN_CHUNK"] = "1024"
-        os.environ["ZJ_PAR_MIN_BITS"] = "0"   # flat pictures too (the product leaves them to the serial walk)
         os.environ.pop("ZJ_PAR_SCAN", None)
     else:
         os.environ["ZJ_PAR_SCAN"] = "off"
@@ -60,7 +59,6 @@ def _decode(zj, data, threads, v1, par=False):
     finally:
         os.environ.pop("ZJ_WALKER_V1", None)
         os.environ.pop("ZJ_PAR_MIN_CHUNK", None)
-        os.environ.pop("ZJ_PAR_MIN_BITS", None)
         os.environ.pop("ZJ_PAR_SCAN", None)
 
 
@@ -158,3 +156,36 @@ def test_scans_without_restart_markers_on_several_threads(zj, case):
         a = _decode(zj, d, 1, v1=False)
         b = _decode(zj, d, 4, v1=False, par=True)
         assert (a[:3] == b[:3]) if a[0] == "ok" else a == b, (case, trial, kind, a[0], b[0])
+
+
+@pytest.mark.parametrize("sub", [0, 2])
+def test_parallel_scan_gives_up_in_flat_areas_and_keeps_what_it_has(zj, sub):
+    """A band of one colour in the middle of the picture: runs of identical two-symbol MCUs, where a reader that enters out of
+    step stays out of step.  The stitching walks `patience` MCUs into it (ZJ_PAR_PATIENCE; the product: 512 or 1/64 of the
+    picture), then stops: the MCUs anchored so far are decoded in parallel, the serial walk takes the rest -- same planes."""
+    from PIL import Image, ImageFile
+    ImageFile.MAXBLOCK = max(ImageFile.MAXBLOCK, 1 << 24)
+    rng = np.random.default_rng(77 + sub)
+    w, h = 640, 960
+    arr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    arr[200:760] = (90, 140, 200)
+    b = io.BytesIO()
+    Image.fromarray(arr, "RGB").save(b, "JPEG", quality=80, subsampling=sub)
+    data = b.getvalue()
+    ref = _decode(zj, data, 1, v1=False)
+    assert ref[0] == "ok"
+    total = ((w + 15) // 16 if sub else (w + 7) // 8) * ((h + 15) // 16 if sub == 2 else (h + 7) // 8)
+    seen = set()
+    for patience in ("2", "40", None):
+        for threads in (3, 4, 6):
+            if patience:
+                os.environ["ZJ_PAR_PATIENCE"] = patience
+            try:
+                del _PAR_MCUS[:]
+                got = _decode(zj, data, threads, v1=False, par=True)
+            finally:
+                os.environ.pop("ZJ_PAR_PATIENCE", None)
+            assert got[:3] == ref[:3], (patience, threads)
+            assert 0 < _PAR_MCUS[0] <= total, (_PAR_MCUS, total)
+            seen.add(_PAR_MCUS[0])
+    assert len(seen) > 1, seen   # (the patience made a difference: some attempts stopped inside the band)

@@ -90,7 +90,6 @@ def main():
         bio = io.BytesIO()
         img.save(bio, "JPEG", quality=q, subsampling=sub, optimize=opt, **({"restart_marker_rows": rst} if rst else {}))
         seeds.append(bio.getvalue())
-    os.environ["ZJ_PAR_MIN_BITS"] = "0"
     os.environ["ZJ_PAR_MIN_CHUNK"] = "512"  # the three-thread decoder enters scans without restart markers at three points
                                             # (scan_baseline_parallel) whenever more than 8 KB + 1.5 KB of scan are there
     rng = np.random.default_rng(7)

@@ -18,10 +18,12 @@ sys.path.insert(0, ROOT)
 zj = importlib.import_module("zune-jpeg_amd")
 
 
-def decode(data, threads, par):
+def decode(data, threads, par, patience=None):
+    os.environ.pop("ZJ_PAR_PATIENCE", None)
     if par:
         os.environ["ZJ_PAR_MIN_CHUNK"] = "600"
-        os.environ["ZJ_PAR_MIN_BITS"] = "0"   # flat pictures too (the product leaves them to the serial walk)
+        if patience:  # how many MCUs the stitching may walk before it leaves the rest of the scan to the serial walk
+            os.environ["ZJ_PAR_PATIENCE"] = str(patience)
         os.environ.pop("ZJ_PAR_SCAN", None)
     else:
         os.environ["ZJ_PAR_SCAN"] = "off"
@@ -54,6 +56,9 @@ def main():
         img = Image.fromarray(small, "L" if gray else "RGB").resize((w, h), Image.BICUBIC)
         amp = int(rng.integers(0, 60))
         arr = np.asarray(img).astype(np.int16) + rng.integers(-amp, amp + 1, np.asarray(img).shape, dtype=np.int16)
+        if rng.integers(0, 2):  # a flat band: runs of identical two-symbol MCUs, where a reader out of step stays out of step
+            y0 = int(rng.integers(0, h - 16))
+            arr[y0:y0 + int(rng.integers(16, max(17, h // 2)))] = int(rng.integers(0, 256))
         img = Image.fromarray(np.clip(arr, 0, 255).astype(np.uint8), "L" if gray else "RGB")
         b = io.BytesIO()
         kw = {} if gray else {"subsampling": int(rng.integers(0, 3))}
@@ -64,7 +69,7 @@ def main():
         files += 1
         ref = decode(data, 1, False)
         for threads in (2, 4, int(rng.integers(3, 9))):
-            got = decode(data, threads, True)
+            got = decode(data, threads, True, int(rng.choice([0, 1, 8, 64])))
             assert got[:2] == ref[:2], ("intact", w, h, threads, got[0], ref[0])
             taken += got[2] > 0
         sos = data.index(b"\xff\xda")
@@ -83,7 +88,7 @@ def main():
                 d[at:at] = bytes(rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8))
             d = bytes(d)
             r1 = decode(d, 1, False)
-            r2 = decode(d, int(rng.integers(2, 9)), True)
+            r2 = decode(d, int(rng.integers(2, 9)), True, int(rng.choice([0, 1, 8, 64])))
             assert r1[:2] == r2[:2], ("damaged", w, h, kind, at, r1[0], r2[0], r1[1] if r1[0] == "error" else "", r2[1] if r2[0] == "error" else "")
             damaged += 1
             errors += r1[0] == "error"

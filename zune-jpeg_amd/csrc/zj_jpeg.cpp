@@ -17,6 +17,7 @@
 #include <string.h>
 #include <immintrin.h> // _mm_stream_si128 and wider: the coefficient planes are written once and read by DMA
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -413,6 +414,7 @@ public:
             std::lock_guard<std::mutex> g(m_);
             while ((int)th_.size() < threads - 1) th_.emplace_back([this] { helper(); });
             job_ = &job; seats_ = threads - 1; gen_++;
+            hint_.store(gen_, std::memory_order_relaxed);
         }
         wake_.notify_all();
         work();
@@ -434,6 +436,11 @@ private:
             (*job)();
             g.lock();
             if (--busy_ == 0) idle_.notify_all();
+            // regions come in quick succession (pass A, a few microseconds of stitching, pass B): stay awake for a moment
+            g.unlock();
+            const auto t0 = std::chrono::steady_clock::now();
+            while (hint_.load(std::memory_order_relaxed) == seen && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(80)) _mm_pause();
+            g.lock();
         }
     }
     std::mutex m_;
@@ -441,6 +448,7 @@ private:
     std::vector<std::thread> th_;
     const std::function<void()>* job_ = nullptr;
     unsigned long gen_ = 0;
+    std::atomic<unsigned long> hint_{0}; // gen_ again, for helpers that poll without the lock
     int seats_ = 0, busy_ = 0;
     bool stop_ = false;
 };
@@ -1339,18 +1347,6 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
     if (const char* e = getenv("ZJ_PAR_MIN_CHUNK")) { const long v = atol(e); if (v >= 256) min_chunk = v; } // (tests: small files)
     if ((long long)T * min_chunk > usable) T = (int)(usable / min_chunk);
     if (T < 2) return 0;
-    // Mostly flat pictures stay with the serial walk: a reader that enters a run of identical short MCUs out of step stays
-    // out of step until the picture changes, the true structure decode then has to walk through all of them one after the
-    // other, and a block of two symbols costs it what it costs the real decode (the reference's test-baseline.jpg: 6 bits
-    // per block, a third of its MCUs walked -- no faster than the serial walk, 10 % slower in the worst case).
-    {
-        long long blocks = 0;
-        for (int ci = 0; ci < d->ns; ci++) blocks += (long long)d->comps[d->order[ci]].h * d->comps[d->order[ci]].v;
-        blocks *= (long long)d->mcu_x * d->mcu_y;
-        long long min_bits = 16;
-        if (const char* e = getenv("ZJ_PAR_MIN_BITS")) min_bits = atol(e); // (tests)
-        if ((scan_end - p0) * 8 < blocks * min_bits) return 0;
-    }
     // chunk starts: never on the zero that follows a 0xFF; 0xFF00 pairs in front of every chunk (for data bit numbers)
     std::vector<const uint8_t*> start((size_t)T + 1);
     std::vector<long long> base((size_t)T);
@@ -1423,7 +1419,16 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
     join(seen[0], 0, seen[0][0], 0);
     std::vector<ParSnap> more;
     size_t walked = 0;
-    for (int t = 1; t < T; t++) {
+    // A reader that enters a run of identical short MCUs out of step (flat areas: two symbols per block) stays out of step
+    // until the picture changes, and the true structure decode would have to walk through all of them one after the other
+    // at what the real decode costs for such blocks.  Past `patience` MCUs the stitching stops instead: what is anchored so
+    // far is decoded in parallel, the serial walk takes the scan from there (the reference's test-baseline.jpg, 6 bits per
+    // block: its second quarter begins in the flat sky; speed_bench.jpg, 6.5 bits per block, is in step within 52 MCUs).
+    size_t patience = std::max<size_t>(512, (size_t)((long long)d->mcu_x * d->mcu_y / 64));
+    if (const char* e = getenv("ZJ_PAR_PATIENCE")) { const long v = atol(e); if (v >= 1) patience = (size_t)v; } // (tests)
+    bool gave_up = false;
+    for (int t = 1; t < T && !gave_up; t++) {
+        const size_t walked0 = walked;
         const std::vector<ParSnap>& cand = seen[(size_t)t];
         size_t j = 0;
         const auto meets = [&](const ParSnap& x) {
@@ -1445,6 +1450,7 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
                 if (i + 1 == more.size() || meets(more[i]) || more[i].p >= start[(size_t)t + 1]) break;
             }
             cur = more[i]; // (what the run decoded behind it is decoded again: by the chunk's own notes or the next run)
+            if (walked - walked0 > patience) { gave_up = true; break; }
         }
     }
     const long long total_mcus = cur_mcu;
@@ -1462,10 +1468,11 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
     }
     const auto t_b = clk();
     // B: the coefficients, every part from its own first MCU start and the predictors that hold there
-    struct Out { int32_t pred[3]; long long begin_bits, end_bits; int rc; BitReader br; };
+    struct Out { int32_t pred[3]; long long begin_bits, end_bits; int rc; BitReader br; double t0 = 0, t1 = 0; };
     std::vector<Out> res((size_t)T);
     d->crew.each(T, T, [&](int t) {
         Out& o = res[(size_t)t];
+        o.t0 = std::chrono::duration<double, std::milli>(clk() - t_b).count();
         o.rc = 0; o.begin_bits = o.end_bits = -1;
         const size_t a0 = cut[(size_t)t], a1 = cut[(size_t)t + 1];
         if (a0 >= a1) return;
@@ -1484,11 +1491,15 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
         if (!o.rc && done != count) o.rc = ZJ_ERR_HUFFMAN;
         if (!o.rc && r.marker) o.rc = ZJ_ERR_HUFFMAN;
         if (!o.rc) o.end_bits = s0.dbits + s0.nbits + r.consumed();
+        o.t1 = std::chrono::duration<double, std::milli>(clk() - t_b).count();
     });
     if (dbg) {
         const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "scan_baseline_parallel: %d threads, %lld MCUs (%zu decoded while stitching); structure %.2f ms, stitch %.2f ms, decode %.2f ms\n",
-                T, total_mcus, walked, ms(t_a, t_s), ms(t_s, t_b), ms(t_b, clk()));
+        fprintf(stderr, "scan_baseline_parallel: %d threads, %lld MCUs (%zu decoded while stitching%s); structure %.2f ms, stitch %.2f ms, decode %.2f ms\n",
+                T, total_mcus, walked, gave_up ? ", then left to the serial walk" : "", ms(t_a, t_s), ms(t_s, t_b), ms(t_b, clk()));
+        for (int t = 0; t < T; t++)
+            fprintf(stderr, "  part %d: anchors [%zu, %zu), MCUs from %lld, rc %d, %.3f .. %.3f ms\n", t, cut[(size_t)t], cut[(size_t)t + 1],
+                    cut[(size_t)t] < anchors.size() ? anchors[cut[(size_t)t]].mcu : total_mcus, res[(size_t)t].rc, res[(size_t)t].t0, res[(size_t)t].t1);
     }
     // every part must have ended exactly where the next one began, with the predictors the next one was started with
     int last_t = -1;
