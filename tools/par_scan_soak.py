@@ -89,6 +89,8 @@ def main():
             d = bytes(d)
             r1 = decode(d, 1, False)
             r2 = decode(d, int(rng.integers(2, 9)), True, int(rng.choice([0, 1, 8, 64])))
+            if r1[:2] != r2[:2]:
+                open("/tmp/par_scan_soak_failure.jpg", "wb").write(d)  # (kept for the post-mortem)
             assert r1[:2] == r2[:2], ("damaged", w, h, kind, at, r1[0], r2[0], r1[1] if r1[0] == "error" else "", r2[1] if r2[0] == "error" else "")
             damaged += 1
             errors += r1[0] == "error"

@@ -1350,8 +1350,13 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
     // chunk starts: never on the zero that follows a 0xFF; 0xFF00 pairs in front of every chunk (for data bit numbers)
     std::vector<const uint8_t*> start((size_t)T + 1);
     std::vector<long long> base((size_t)T);
+    // Chunk 0 is decoded for real straight away (its reader's state is known), the others structure first and coefficients
+    // later, with chunk 0's thread helping: chunk 0 is sized so that its decode takes what a structure pass over one of the
+    // others takes (0.85 of a decode per byte on the GPU hosts and in the build container)
+    const double c0 = 0.85 / ((double)(T - 1) + 0.85);
     for (int t = 0; t <= T; t++) {
-        const uint8_t* q = p0 + usable * t / T;
+        const uint8_t* q = p0 + (t == 0 ? 0 : (long long)((double)usable * (c0 + (1.0 - c0) * (double)(t - 1) / (double)(T - 1))));
+        if (t == T) q = p0 + usable;
         if (t && q[-1] == 0xFF && q[0] == 0x00) q++;
         start[(size_t)t] = q;
     }
@@ -1363,29 +1368,52 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
                 const uint8_t* f = (const uint8_t*)memchr(q, 0xFF, (size_t)(start[(size_t)t] - q));
                 if (!f) { q = start[(size_t)t]; break; }
                 if (f + 1 < scan_end && f[1] == 0x00) { stuffed++; q = f + 2; }
-                else if (f + 1 < scan_end && f[1] != 0xFF) return 0; // a marker inside the scan: not for this path
-                else q = f + 1;
+                else return 0; // a marker or 0xFF fill bytes inside the scan: not for this path
             }
             if (q > start[(size_t)t]) { start[(size_t)t] = q; } // (a stuffed pair straddled the cut)
             base[(size_t)t] = 8 * ((long long)(start[(size_t)t] - p0) - stuffed);
+        }
+        // (the last chunk as well: nothing but data and stuffed zeros up to where the serial walk takes over)
+        while (q < start[(size_t)T]) {
+            const uint8_t* f = (const uint8_t*)memchr(q, 0xFF, (size_t)(start[(size_t)T] - q));
+            if (!f) break;
+            if (f + 1 < scan_end && f[1] == 0x00) q = f + 2;
+            else return 0;
         }
     }
     for (int t = 1; t <= T; t++) if (start[(size_t)t] <= start[(size_t)t - 1]) return 0;
     const bool dbg = getenv("ZJ_PAR_DEBUG") != nullptr;
     const auto clk = [] { return std::chrono::steady_clock::now(); };
     const auto t_a = clk();
-    // A: structure of every chunk, speculatively (chunk 0: truly)
+    // A: chunk 0 for real; the structure of every other chunk, speculatively
+    if (br.nbits != 0 || br.marker) return 0; // (the scan's reader has not been used yet: chunk 0 starts a fresh one at p0)
     std::vector<std::vector<ParSnap>> seen((size_t)T);
     std::vector<char> ok((size_t)T, 0);
+    struct Out { int32_t pred[3]; long long begin_bits, end_bits; int rc; BitReader br; double t0 = 0, t1 = 0; };
+    Out head{};          // chunk 0
+    long long head_mcus = 0;
     d->crew.each(T, T, [&](int t) {
         BitReader r;
         r.p = start[(size_t)t]; r.end = br.end; r.istart = r.p;
+        if (t == 0) {
+            r.rbl = br.rbl;
+            for (int c = 0; c < 3; c++) head.pred[c] = 0; // (scan_baseline has just set the predictors to 0)
+            const char* err = nullptr;
+            head.begin_bits = 0;
+            head.rc = fn.mcus(d, d, r, head.pred, 0, (long long)d->mcu_x * d->mcu_y, start[1], &head_mcus, &err);
+            if (!head.rc && (r.marker || r.pad || r.mpos)) head.rc = ZJ_ERR_HUFFMAN; // (0xFF fill bytes count: FF FF 00 pads the reader)
+            head.end_bits = r.consumed();
+            head.br = r;
+            head.t1 = std::chrono::duration<double, std::milli>(clk() - t_a).count();
+            return;
+        }
         seen[(size_t)t].reserve((size_t)((start[(size_t)t + 1] - start[(size_t)t]) / (24 * kParEvery) + 64));
         const int32_t zero[3] = {0, 0, 0}; // (the scan begins with predictors 0; a chunk's own count starts anywhere)
-        ok[(size_t)t] = par_structure_run(d, r, base[(size_t)t], t == 0 ? br.rbl : 0, t == 0, zero, start[(size_t)t + 1], (size_t)-1, kParEvery, seen[(size_t)t]);
+        ok[(size_t)t] = par_structure_run(d, r, base[(size_t)t], 0, false, zero, start[(size_t)t + 1], (size_t)-1, kParEvery, seen[(size_t)t]);
     });
     const auto t_s = clk();
-    if (!ok[0] || seen[0].size() < 2) return 0;
+    // anything unusual in chunk 0 (a DC symbol the reference may read short, a bad code): the serial walk owns it
+    if (head.rc || head_mcus < 1) return 0;
     // stitch: one list of TRUE MCU starts (anchors) over the whole scan, each with the MCU's index and the predictors that hold
     // there; `cur` = the true reader behind the last anchored MCU.  A chunk's notes join the list from the note the true
     // reader lands on; the MCUs the true structure decode has to walk through to get there (a chunk that never falls into
@@ -1416,7 +1444,8 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
         cur_mcu = at_mcu + (v.back().mcu - v[from].mcu);
         cur = e;
     };
-    join(seen[0], 0, seen[0][0], 0);
+    cur = ParSnap{head.br.p, head.br.acc, head.end_bits, head.br.nbits, head.br.rbl, true, false, {head.pred[0], head.pred[1], head.pred[2]}, head_mcus};
+    cur_mcu = head_mcus;
     std::vector<ParSnap> more;
     size_t walked = 0;
     // A reader that enters a run of identical short MCUs out of step (flat areas: two symbols per block) stays out of step
@@ -1429,6 +1458,7 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
     bool gave_up = false;
     for (int t = 1; t < T && !gave_up; t++) {
         const size_t walked0 = walked;
+        size_t stride = 8;
         const std::vector<ParSnap>& cand = seen[(size_t)t];
         size_t j = 0;
         const auto meets = [&](const ParSnap& x) {
@@ -1438,11 +1468,12 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
         for (;;) {
             if (meets(cur)) { join(cand, j, ParSnap(cur), cur_mcu); break; }
             if (cur.p >= start[(size_t)t + 1]) break; // past this chunk without ever meeting it: the chunk is dropped
-            // up to 64 more true MCUs, then look again
+            // a few more true MCUs (8, then 16 ... 64 at a time: most chunks are met within twenty), then look again
             BitReader r;
             r.p = cur.p; r.acc = cur.acc; r.nbits = cur.nbits; r.end = br.end; r.istart = cur.p;
             more.clear();
-            if (!par_structure_run(d, r, cur.dbits + cur.nbits, cur.rbl, cur.exact, cur.dc, start[(size_t)T], 64, 1, more) || more.size() < 2) return 0;
+            if (!par_structure_run(d, r, cur.dbits + cur.nbits, cur.rbl, cur.exact, cur.dc, start[(size_t)T], stride, 1, more) || more.size() < 2) return 0;
+            if (stride < 64) stride *= 2;
             size_t i = 1;
             for (;; i++) {
                 anchors.push_back(Anchor{more[i - 1], cur_mcu++});
@@ -1454,21 +1485,20 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
         }
     }
     const long long total_mcus = cur_mcu;
-    if (total_mcus <= 0 || total_mcus > (long long)d->mcu_x * d->mcu_y || anchors.empty() || !cur.exact) return 0;
+    if (total_mcus <= 0 || total_mcus > (long long)d->mcu_x * d->mcu_y || !cur.exact) return 0;
     // the MCUs in T equal parts, each beginning at an anchor whose bits_left is known
     std::vector<size_t> cut((size_t)T + 1, anchors.size());
     cut[0] = 0;
     {
         size_t a = 0;
         for (int q = 1; q < T; q++) {
-            const long long want = total_mcus * q / T;
+            const long long want = head_mcus + (total_mcus - head_mcus) * q / T;
             while (a < anchors.size() && (anchors[a].mcu < want || !anchors[a].s.exact)) a++;
             cut[(size_t)q] = a;
         }
     }
     const auto t_b = clk();
     // B: the coefficients, every part from its own first MCU start and the predictors that hold there
-    struct Out { int32_t pred[3]; long long begin_bits, end_bits; int rc; BitReader br; double t0 = 0, t1 = 0; };
     std::vector<Out> res((size_t)T);
     d->crew.each(T, T, [&](int t) {
         Out& o = res[(size_t)t];
@@ -1489,7 +1519,7 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
         const char* err = nullptr;
         o.rc = fn.mcus(d, d, r, o.pred, anchors[a0].mcu, count, nullptr, &done, &err);
         if (!o.rc && done != count) o.rc = ZJ_ERR_HUFFMAN;
-        if (!o.rc && r.marker) o.rc = ZJ_ERR_HUFFMAN;
+        if (!o.rc && (r.marker || r.pad || r.mpos)) o.rc = ZJ_ERR_HUFFMAN;
         if (!o.rc) o.end_bits = s0.dbits + s0.nbits + r.consumed();
         o.t1 = std::chrono::duration<double, std::milli>(clk() - t_b).count();
     });
@@ -1497,24 +1527,24 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
         const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "scan_baseline_parallel: %d threads, %lld MCUs (%zu decoded while stitching%s); structure %.2f ms, stitch %.2f ms, decode %.2f ms\n",
                 T, total_mcus, walked, gave_up ? ", then left to the serial walk" : "", ms(t_a, t_s), ms(t_s, t_b), ms(t_b, clk()));
+        fprintf(stderr, "  chunk 0: %lld MCUs for real, .. %.3f ms after the start\n", head_mcus, head.t1);
         for (int t = 0; t < T; t++)
             fprintf(stderr, "  part %d: anchors [%zu, %zu), MCUs from %lld, rc %d, %.3f .. %.3f ms\n", t, cut[(size_t)t], cut[(size_t)t + 1],
                     cut[(size_t)t] < anchors.size() ? anchors[cut[(size_t)t]].mcu : total_mcus, res[(size_t)t].rc, res[(size_t)t].t0, res[(size_t)t].t1);
     }
     // every part must have ended exactly where the next one began, with the predictors the next one was started with
-    int last_t = -1;
+    const Out* last = &head;
     for (int t = 0; t < T; t++) {
         if (cut[(size_t)t] >= cut[(size_t)t + 1]) continue;
         if (res[(size_t)t].rc) return 0;
-        if (last_t >= 0 && (res[(size_t)last_t].end_bits != res[(size_t)t].begin_bits ||
-                            memcmp(res[(size_t)last_t].pred, anchors[cut[(size_t)t]].s.dc, sizeof res[0].pred) != 0)) return 0;
-        last_t = t;
+        if (last->end_bits != res[(size_t)t].begin_bits || memcmp(last->pred, anchors[cut[(size_t)t]].s.dc, sizeof last->pred) != 0) return 0;
+        last = &res[(size_t)t];
     }
-    if (last_t < 0 || res[(size_t)last_t].end_bits != cur.dbits || memcmp(res[(size_t)last_t].pred, cur.dc, sizeof cur.dc) != 0) return 0;
-    for (int c = 0; c < d->ncomp; c++) d->comps[c].dc_pred = res[(size_t)last_t].pred[c];
+    if (last->end_bits != cur.dbits || memcmp(last->pred, cur.dc, sizeof cur.dc) != 0) return 0;
+    for (int c = 0; c < d->ncomp; c++) d->comps[c].dc_pred = last->pred[c];
     // the serial walk goes on from the last range's end: the reader as that range left it
     {
-        const BitReader& r = res[(size_t)last_t].br;
+        const BitReader& r = last->br;
         const long long stuffed_total = ((long long)(r.p - p0) * 8 - (cur.dbits + r.nbits)) / 8; // 0xFF00 pairs in front of r.p
         br.p = r.p; br.acc = r.acc; br.nbits = r.nbits; br.rbl = r.rbl; br.marker = 0; br.mpos = nullptr; br.pad = 0;
         br.istart = p0; br.stuffed = (uint32_t)stuffed_total;
