@@ -1205,20 +1205,30 @@ int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p,
 // that starts at an arbitrary byte with the wrong idea of where it is reads garbage for a while and then, with high
 // probability, falls into step with the true sequence of symbols -- from then on it is at MCU starts exactly where the true
 // decoder is.  So:
-//   A  (parallel)   the scan is cut into one chunk per thread; every thread decodes the STRUCTURE of its chunk only -- code
-//                   lengths and zig-zag advances, no values, no stores -- from its chunk's first byte, assuming an MCU starts
-//                   there, and notes the reader's state at every MCU start it believes in (ParSnap);
-//   stitch (serial) the true decoder's state at the end of chunk t-1 is looked up among chunk t's MCU starts; if it is not one
-//                   of them the true structure decode simply goes on into chunk t until it is (typically a few hundred bytes).
-//                   From that MCU on chunk t's notes are true, and how many MCUs precede it is known;
-//   B  (parallel)   every thread decodes its MCUs for real (decode_mcus_v2) from the noted state.  The DC predictors it starts
-//                   with come from pass A as well: the structure decode forms the DC differences (one per block) and keeps
-//                   their running sums, and differences of sums inside a chunk are true once the chunk is in step.
+//   A  (parallel)   the scan is cut into one chunk per thread.  Chunk 0 begins where the scan begins: it is decoded for real
+//                   straight away.  Every other thread decodes the STRUCTURE of its chunk only -- code lengths and zig-zag
+//                   advances, no values, no stores -- from its chunk's first byte, assuming an MCU starts there, and notes
+//                   the reader's state at every 16th MCU start it believes in (ParSnap);
+//   stitch (serial) the true reader's state at the end of chunk t-1 is looked up among chunk t's notes; if it is not one of
+//                   them the true structure decode goes on into chunk t, a few MCUs at a time, until it is (typically within
+//                   twenty MCUs).  From that note on chunk t's notes are true, and how many MCUs precede each is known: they
+//                   join one list of ANCHORS over the whole scan (MCU index, reader, DC predictors);
+//   B  (parallel)   the MCUs behind chunk 0 are cut into one part per thread at anchors, equal in MCUs, and every thread
+//                   decodes its part for real (decode_mcus_v2).  The DC predictors a part starts with come from pass A as
+//                   well: the structure decode forms the DC differences (one per block) and keeps their running sums, and
+//                   differences of sums inside a chunk are true once the chunk is in step.
+//   check           every part must end at the bit the next one began at, with the predictors the next one was given.
+// Flat areas (two symbols per block, identical MCUs) are where it does not work: a reader that enters such a run out of step
+// stays out of step until the picture changes.  The stitching has `patience` for max(512, 1/64 of the picture) MCUs per
+// chunk; then it stops, what is anchored so far is decoded in parallel and the serial walk takes the scan from there.
 // The scan's last 8 KB -- where the reference's early exit at EOI lives -- and everything the walker treats specially stay
 // with the serial walk: any DC symbol the reference might read short (ref_dc_misread: the structure decode follows bits_left
-// by the same rules), any code that does not exist, any marker, a chunk that never falls into step -> the attempt is dropped
-// and the serial walk decodes the scan as if nothing had happened (it clears every block before it fills it).
-// 4096 x 4096 4:2:0 q = 90, 3.5 MB, 4 threads: 18 -> 7.5 ms on the GPU host (profiles/r06_walker.txt).  ZJ_PAR_SCAN=off.
+// by the same rules), any code that does not exist, any marker or 0xFF fill byte, a chunk that never falls into step -> the
+// attempt is dropped (or ends there) and the serial walk decodes the rest as if nothing had happened (it clears every block
+// before it fills it).
+// 4096 x 4096 4:2:0 q = 90, 3.5 MB, on the GPU host: 18.4 ms on one thread, 13.8 on 2, 8.4 on 4, 4.8 on 8, 2.9 on 16; the
+// reference's own test-baseline.jpg (73 KB, 6 bits per block, mostly sky) 0.90 -> 0.97 ms: its second chunk begins in the
+// flat part and the attempt ends there (profiles/r06_walker.txt).  ZJ_PAR_SCAN=off; tools/par_scan_soak.py.
 constexpr size_t kParEvery = 16;
 struct ParSnap {
     const uint8_t* p;   // the reader at an MCU start: next byte to load, accumulator, bits in it
