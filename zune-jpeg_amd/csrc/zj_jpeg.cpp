@@ -1217,7 +1217,9 @@ int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p,
 //                   decodes its part for real (decode_mcus_v2).  The DC predictors a part starts with come from pass A as
 //                   well: the structure decode forms the DC differences (one per block) and keeps their running sums, and
 //                   differences of sums inside a chunk are true once the chunk is in step.
-//   check           every part must end at the bit the next one began at, with the predictors the next one was given.
+//   check           every part must end at the bit the next one began at, with the predictors the next one was given; what
+//                   lies in front of the first link that does not hold is kept (chunk 0 always is: its decode is the serial
+//                   walk's own), the serial walk decodes the rest.
 // Flat areas (two symbols per block, identical MCUs) are where it does not work: a reader that enters such a run out of step
 // stays out of step until the picture changes.  The stitching has `patience` for max(512, 1/64 of the picture) MCUs per
 // chunk; then it stops, what is anchored so far is decoded in parallel and the serial walk takes the scan from there.
@@ -1345,8 +1347,10 @@ bool par_structure_run(const zj_decoder* d, BitReader& br, long long base_bits, 
     }
 }
 
-// Returns the number of MCUs decoded from the start of the scan (0: not attempted or dropped; nothing but plane contents has
-// changed then) with `br` at the start of the next MCU and the components' predictors set.
+// Returns the number of MCUs decoded from the start of the scan, with `br` at the start of the next MCU and the components'
+// predictors set: all of the region when every check held, chunk 0 plus the parts whose links held otherwise (0: not
+// attempted, or chunk 0 itself met something unusual; nothing but plane contents has changed then).
+inline void stream_rows(zj_decoder* d, long long mcus_done);
 long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& fn, const uint8_t* scan_end)
 {
     const uint8_t* const p0 = br.p;
@@ -1424,6 +1428,18 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
     const auto t_s = clk();
     // anything unusual in chunk 0 (a DC symbol the reference may read short, a bad code): the serial walk owns it
     if (head.rc || head_mcus < 1) return 0;
+    // From here on chunk 0 is decoded, and decoded truly -- it is the serial walk's own decode of those MCUs -- whatever
+    // becomes of the rest: the scan goes on behind `mcus` MCUs from the reader `o` ended with.
+    const auto keep = [&](const Out& o, long long mcus) {
+        for (int c = 0; c < d->ncomp; c++) d->comps[c].dc_pred = o.pred[c];
+        const BitReader& r = o.br;
+        const long long stuffed_total = ((long long)(r.p - p0) * 8 - (o.end_bits + r.nbits)) / 8; // 0xFF00 pairs in front of r.p
+        br.p = r.p; br.acc = r.acc; br.nbits = r.nbits; br.rbl = r.rbl; br.marker = 0; br.mpos = nullptr; br.pad = 0;
+        br.istart = p0; br.stuffed = (uint32_t)stuffed_total;
+        br.rbl0 = 0; br.rhist = 0;
+        return mcus;
+    };
+    stream_rows(d, head_mcus); // (zj_decoder_decode_buffer: those rows can go to the GPU while the rest is decoded)
     // stitch: one list of TRUE MCU starts (anchors) over the whole scan, each with the MCU's index and the predictors that hold
     // there; `cur` = the true reader behind the last anchored MCU.  A chunk's notes join the list from the note the true
     // reader lands on; the MCUs the true structure decode has to walk through to get there (a chunk that never falls into
@@ -1482,7 +1498,7 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
             BitReader r;
             r.p = cur.p; r.acc = cur.acc; r.nbits = cur.nbits; r.end = br.end; r.istart = cur.p;
             more.clear();
-            if (!par_structure_run(d, r, cur.dbits + cur.nbits, cur.rbl, cur.exact, cur.dc, start[(size_t)T], stride, 1, more) || more.size() < 2) return 0;
+            if (!par_structure_run(d, r, cur.dbits + cur.nbits, cur.rbl, cur.exact, cur.dc, start[(size_t)T], stride, 1, more) || more.size() < 2) return keep(head, head_mcus);
             if (stride < 64) stride *= 2;
             size_t i = 1;
             for (;; i++) {
@@ -1495,7 +1511,7 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
         }
     }
     const long long total_mcus = cur_mcu;
-    if (total_mcus <= 0 || total_mcus > (long long)d->mcu_x * d->mcu_y || !cur.exact) return 0;
+    if (total_mcus <= 0 || total_mcus > (long long)d->mcu_x * d->mcu_y || !cur.exact) return keep(head, head_mcus);
     // the MCUs in T equal parts, each beginning at an anchor whose bits_left is known
     std::vector<size_t> cut((size_t)T + 1, anchors.size());
     cut[0] = 0;
@@ -1542,25 +1558,21 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
             fprintf(stderr, "  part %d: anchors [%zu, %zu), MCUs from %lld, rc %d, %.3f .. %.3f ms\n", t, cut[(size_t)t], cut[(size_t)t + 1],
                     cut[(size_t)t] < anchors.size() ? anchors[cut[(size_t)t]].mcu : total_mcus, res[(size_t)t].rc, res[(size_t)t].t0, res[(size_t)t].t1);
     }
-    // every part must have ended exactly where the next one began, with the predictors the next one was started with
+    // A part that begins on the bit the one in front ended on, with the predictors it ended with, begins at a true MCU start
+    // (by induction from chunk 0, whose decode IS the serial decode) and at the MCU index it was given -- so its own end is
+    // true as well.  The first link that does not hold ends what is kept; the serial walk goes on from there.
     const Out* last = &head;
+    long long kept = head_mcus;
     for (int t = 0; t < T; t++) {
         if (cut[(size_t)t] >= cut[(size_t)t + 1]) continue;
-        if (res[(size_t)t].rc) return 0;
-        if (last->end_bits != res[(size_t)t].begin_bits || memcmp(last->pred, anchors[cut[(size_t)t]].s.dc, sizeof last->pred) != 0) return 0;
-        last = &res[(size_t)t];
+        const Out& o = res[(size_t)t];
+        if (o.rc || last->end_bits != o.begin_bits || memcmp(last->pred, anchors[cut[(size_t)t]].s.dc, sizeof last->pred) != 0) break;
+        last = &o;
+        kept = cut[(size_t)t + 1] < anchors.size() ? anchors[cut[(size_t)t + 1]].mcu : total_mcus;
     }
-    if (last->end_bits != cur.dbits || memcmp(last->pred, cur.dc, sizeof cur.dc) != 0) return 0;
-    for (int c = 0; c < d->ncomp; c++) d->comps[c].dc_pred = last->pred[c];
-    // the serial walk goes on from the last range's end: the reader as that range left it
-    {
-        const BitReader& r = last->br;
-        const long long stuffed_total = ((long long)(r.p - p0) * 8 - (cur.dbits + r.nbits)) / 8; // 0xFF00 pairs in front of r.p
-        br.p = r.p; br.acc = r.acc; br.nbits = r.nbits; br.rbl = r.rbl; br.marker = 0; br.mpos = nullptr; br.pad = 0;
-        br.istart = p0; br.stuffed = (uint32_t)stuffed_total;
-        br.rbl0 = 0; br.rhist = 0;
-    }
-    return total_mcus;
+    // (all links held: the last part ends where the stitching ended, or the notes are not to be trusted at all)
+    if (kept == total_mcus && (last->end_bits != cur.dbits || memcmp(last->pred, cur.dc, sizeof cur.dc) != 0)) return keep(head, head_mcus);
+    return keep(*last, kept);
 }
 
 void fill_frame_desc(const zj_decoder* d, zj_frame_desc* fd);
