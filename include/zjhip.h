@@ -288,7 +288,9 @@ typedef struct zj_options {      /* zero = reference default */
     int32_t max_scans;           /* options.rs:36, default 64 */
     int32_t num_threads;         /* options.rs:33, default 4.  The reference spends them on post_process strips; here
                                     the pixel path is one GPU launch, so they decode restart segments (DRI/RSTn,
-                                    baseline) concurrently and clear the planes; 1 = strictly serial */
+                                    baseline) concurrently, enter a baseline scan WITHOUT restart markers at one point
+                                    per thread (at most 16; zj_decoder_parallel_mcus) and clear the planes; the
+                                    decoder keeps its helper threads until zj_decoder_free; 1 = strictly serial */
     int32_t pinned_planes;       /* non-zero: coefficient planes live in pinned host memory (DMA without staging) */
     uint32_t flags;              /* ZJ_FLAG_* for the pixel path (0 = the reference's bytes), see zj_frame_desc;
                                     + ZJ_FLAG_FULL_AC_VALUES for the front-end itself */
