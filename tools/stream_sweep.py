@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """The whole zj_decoder_decode_buffer call (one host thread, planes and pixels pinned) with the strips streamed to the GPU
 behind the walker, for several unit sizes (ZJ_STREAM_UNIT_MB), and with the stages apart (ZJ_STREAM=off).
-  python tools/stream_sweep.py
+  python tools/stream_sweep.py [--threads 1]      (--threads 4: the reference's default; scans without restart markers are
+                                                  then entered at four points, zj_jpeg.cpp scan_baseline_parallel)
 """
+import argparse
 import ctypes as C
 import importlib
 import os
@@ -18,6 +20,9 @@ zj = importlib.import_module("zune-jpeg_amd")
 
 
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--threads", type=int, default=1)
+    a = ap.parse_args()
     import files_bench
     L = zj.lib()
     L.zj_alloc_pinned.restype = C.c_void_p
@@ -28,11 +33,11 @@ def main():
              ("q90 4096x4096 4:2:0", files_bench.make_jpeg(4096, 0, 0))]
     ctx = zj.Context()
     node = zj.bind_thread_near_device(0)
-    print(f"thread bound to NUMA node {node}; ms = best of 9 calls of Decoder.decode_buffer into pinned pixels")
+    print(f"thread bound to NUMA node {node}; num_threads {a.threads}; ms = best of 9 calls of Decoder.decode_buffer into pinned pixels")
     print(f"{'file':<36}{'stages apart':>14}" + "".join(f"{'unit ' + u + ' MB':>14}" for u in ("1", "2", "4", "8", "16")))
     for name, data in files:
         o = zj.ZuneJpegOptions()
-        o.num_threads, o.pinned_planes = 1, True
+        o.num_threads, o.pinned_planes = a.threads, True
         dec = zj.Decoder(o, ctx)
         info = dec.read_headers(data)
         n = int(info.width) * int(info.height) * 3
