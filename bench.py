@@ -424,8 +424,8 @@ def reference_files(zj, ctx, reps=5):
                 zj.lib().zj_free_pinned(pin)
             dec.close()
             # the same stage with the reference's default of four threads (src/options.rs:33).  Expect no gain on these two: a
-            # progressive file's scans stay serial, and the baseline one is all but flat (6 bits per block), which
-            # scan_baseline_parallel leaves to the serial walk (from_files.cpu_entropy_4_threads is the case it is for)
+            # progressive file's scans stay serial, and the baseline one is 73 KB -- scan_baseline_parallel starts at 96 KB of
+            # scan (from_files.cpu_entropy_4_threads is the case it is for)
             o4 = zj.ZuneJpegOptions()
             o4.num_threads, o4.pinned_planes = 4, True
             dec4 = zj.Decoder(o4, ctx)

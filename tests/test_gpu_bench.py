@@ -120,8 +120,8 @@ def test_single_rank_line_has_the_contract_fields():
         assert rfiles[name]["decode_buffer_ms"] > 0 and rfiles[name]["decode_buffer_ms_stages_apart"] > 0
         assert abs(rfiles[name]["ns_per_block"] - rfiles[name]["host_entropy_ms"] * 1e6 / 97200) < 0.2
         assert rfiles[name]["four_threads_match"] is True and rfiles[name]["host_entropy_ms_4_threads"] > 0
-        # neither file is entered at four points: progressive scans never are, and the baseline file is all but flat (6 bits per
-        # block; scan_baseline_parallel leaves pictures under 16 to the serial walk) -- from_files' 4096 x 4096 file is
+        # neither file is entered at four points: progressive scans never are, and the baseline file is 73 KB (the attempt
+        # starts at 96 KB of scan; it is all but flat besides -- from_files' 4096 x 4096 file is the case this is for)
         assert rfiles[name]["mcus_decoded_in_parallel"] == 0
     # round 6: the baseline walker no longer loses to the ten-scan progressive file on the same thread (it did, 17.8 vs 3.6 ms,
     # while its blocks left through non-temporal stores: profiles/r06_feeder_ab.txt)

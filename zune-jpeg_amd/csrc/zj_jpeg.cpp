@@ -1229,8 +1229,9 @@ int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p,
 // attempt is dropped (or ends there) and the serial walk decodes the rest as if nothing had happened (it clears every block
 // before it fills it).
 // 4096 x 4096 4:2:0 q = 90, 3.5 MB, on the GPU host: 18.4 ms on one thread, 13.8 on 2, 8.4 on 4, 4.8 on 8, 2.9 on 16; the
-// reference's own test-baseline.jpg (73 KB, 6 bits per block, mostly sky) 0.90 -> 0.97 ms: its second chunk begins in the
-// flat part and the attempt ends there (profiles/r06_walker.txt).  ZJ_PAR_SCAN=off; tools/par_scan_soak.py.
+// reference's own test-baseline.jpg (73 KB, 6 bits per block, mostly sky; tried before the 96 KB threshold existed) 0.90 ->
+// 0.97 ms: its second chunk begins in the flat part and the attempt ends there (profiles/r06_walker.txt).
+// ZJ_PAR_SCAN=off; tools/par_scan_soak.py.
 constexpr size_t kParEvery = 16;
 struct ParSnap {
     const uint8_t* p;   // the reader at an MCU start: next byte to load, accumulator, bits in it
@@ -1356,9 +1357,12 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
     const uint8_t* const p0 = br.p;
     int T = d->threads < 16 ? d->threads : 16;
     const long long usable = (long long)(scan_end - p0) - 8192; // the tail stays with the serial walk (EoiCut, near_end)
-    long long min_chunk = 12288;                                // below this per thread the threads cost more than they bring
-                                                                // (two wake-ups of the crew, ~20 us each; 12 KB decode in ~0.15 ms)
-    if (const char* e = getenv("ZJ_PAR_MIN_CHUNK")) { const long v = atol(e); if (v >= 256) min_chunk = v; } // (tests: small files)
+    // Below 16 KB per thread, or 96 KB in all, the attempt costs more than it can bring: two wake-ups of the crew (20-40 us
+    // each; for a decoder's first file, starting its threads: ~50 us apiece) and, where the picture is flat, the stitching's
+    // patience -- 0.08 ms on the reference's 73 KB test-baseline.jpg, which one thread decodes in 0.9 ms.
+    long long min_chunk = 16384, min_scan = 98304;
+    if (const char* e = getenv("ZJ_PAR_MIN_CHUNK")) { const long v = atol(e); if (v >= 256) { min_chunk = v; min_scan = 2 * v; } } // (tests: small files)
+    if (usable < min_scan) return 0;
     if ((long long)T * min_chunk > usable) T = (int)(usable / min_chunk);
     if (T < 2) return 0;
     // chunk starts: never on the zero that follows a 0xFF; 0xFF00 pairs in front of every chunk (for data bit numbers)
