@@ -157,6 +157,7 @@ extern "C" {
     pub fn zj_decoder_gpu_status(d: *const zj_decoder) -> u32;
     pub fn zj_decoder_parallel_segments(d: *const zj_decoder) -> c_int;
     pub fn zj_decoder_parallel_mcus(d: *const zj_decoder) -> i64;
+    pub fn zj_decoder_set_num_threads(d: *mut zj_decoder, threads: c_int) -> c_int;
     pub fn zj_decoder_scan_blob(d: *const zj_decoder, blob: *mut *const c_void, len: *mut usize) -> c_int;
     pub fn zj_scan_planes(ctx: *mut zj_ctx, y: *mut i16, cb: *mut i16, cr: *mut i16, len: *mut usize) -> c_int;
     pub fn zj_scan_stats(ctx: *const zj_ctx, rounds: *mut c_int, ms: *mut f32) -> c_int;

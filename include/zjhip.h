@@ -347,13 +347,20 @@ ZJ_API int zj_decoder_parallel_segments(const zj_decoder *d);
 /* MCUs of the last baseline scan WITHOUT restart markers that several threads decoded (zj_options.num_threads > 1: the scan is
  * entered at one point per thread, the threads fall into step with the true symbol sequence; zj_jpeg.cpp); 0 = the serial walk */
 ZJ_API int64_t zj_decoder_parallel_mcus(const zj_decoder *d);
+/* Decoder::set_num_threads (src/decoder.rs:591-603, deprecated there in favour of the options): the thread count from the next
+ * file on; 0 -> ZJ_ERR_FORMAT "Cannot set zero threads to decode image".  zj_pool uses it to lend the workers a short batch
+ * leaves idle to the files it has (below). */
+ZJ_API int zj_decoder_set_num_threads(zj_decoder *d, int threads);
 
 /* ---- batches of files: `threads` persistent host workers, each with its own entropy
  * decoder, pinned coefficient planes and GPU context on `device`; file i is decoded by whichever worker is
  * free, so the CPU Huffman stage of one file overlaps the PCIe copies and kernels of the others.  Replaces a
  * caller-side loop over Decoder::decode_buffer (src/decoder.rs:178; the reference's own pool is per decode,
  * src/mcu.rs:135).  outs[i] must hold out_caps[i] >= width*height*ncomp bytes; statuses[i] (optional) gets
- * the zj_status of file i; the return value is the first error seen (ZJ_OK if none), text via zj_pool_error. */
+ * the zj_status of file i; the return value is the first error seen (ZJ_OK if none), text via zj_pool_error.
+ * A batch of at most half as many files as workers gets the idle workers' share of the CPUs inside its files
+ * (threads / files threads per file, at most 16: zj_decoder_set_num_threads), so two large files on a pool of sixteen do
+ * not take what one file takes on one thread; opt->num_threads is the floor (default here: 1). */
 typedef struct zj_pool zj_pool;
 ZJ_API zj_pool *zj_pool_create(int device, int threads, const zj_options *opt, int *status);
 /* Image-level sharding across the GPUs of one node, inside the library (north_star): one pool over `ndev`

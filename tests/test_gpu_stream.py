@@ -156,11 +156,15 @@ def test_decode_buffer_streams_baseline_files_to_the_same_bytes(zj):
         files += [_jpeg(3, 2048, 1536, 2, 90), _jpeg(4, 1600, 1200, 1, 85, restart_rows=2), _jpeg(5, 333, 277, 0, 100),
                   _jpeg(6, 4096, 4096, 2, 90)]
         for i, data in enumerate(files):
-            for threads in (1, 4):
-                for cs in (zj.ColorSpace.RGB, zj.ColorSpace.GRAYSCALE):
-                    a = _decode_buffer(zj, ctx, data, True, threads, cs)
-                    b = _decode_buffer(zj, ctx, data, False, threads, cs)
-                    assert a[0] == b[0] == "ok" and np.array_equal(a[1], b[1]), (i, threads, cs)
+            for cs in (zj.ColorSpace.RGB, zj.ColorSpace.GRAYSCALE):
+                one = _decode_buffer(zj, ctx, data, False, 1, cs)
+                assert one[0] == "ok"
+                # (four threads: restart segments side by side, or -- the files without restart markers, from 96 KB of scan --
+                # the scan entered at four points, its first chunk's rows on their way to the GPU while the rest is decoded)
+                for threads in (1, 4, 7):
+                    for stream in (True, False):
+                        a = _decode_buffer(zj, ctx, data, stream, threads, cs)
+                        assert a[0] == "ok" and np.array_equal(a[1], one[1]), (i, threads, stream, cs)
         # into pinned memory: the downloads overlap as well
         data = files[4]
         ref = _decode_buffer(zj, ctx, data, False)[1]
@@ -183,7 +187,52 @@ def test_decode_buffer_streams_baseline_files_to_the_same_bytes(zj):
             a = _decode_buffer(zj, ctx, bytes(d), True)
             b = _decode_buffer(zj, ctx, bytes(d), False)
             assert a[0] == b[0] and (np.array_equal(a[1], b[1]) if a[0] == "ok" else a[1] == b[1]), (trial, a[0], b[0])
+            c = _decode_buffer(zj, ctx, bytes(d), True, threads=4)
+            assert c[0] == b[0] and (np.array_equal(c[1], b[1]) if c[0] == "ok" else c[1] == b[1]), (trial, "4 threads", c[0], b[0])
             seen_error += a[0] == "error"
             assert np.array_equal(_decode_buffer(zj, ctx, good, True)[1], ref)
+    finally:
+        ctx.close()
+
+
+def test_pool_lends_idle_workers_to_a_short_batch(zj):
+    """Fewer files than workers: the files get the idle workers' threads (zj_pool.cpp: zj_decoder_set_num_threads; a scan
+    without restart markers is then entered at several points) -- same bytes as one decoder on one thread, with the lending
+    and without (ZJ_POOL_LEND=off), for batches of 1, 2, 3 and more files than workers, host and device outputs."""
+    ctx = zj.Context(zj.BACKEND_HIP, 0)
+    try:
+        blobs = [_jpeg(11, 2048, 2048, 2, 90), _jpeg(12, 1920, 1080, 0, 92), _jpeg(13, 1600, 1200, 1, 85, restart_rows=2),
+                 open(os.path.join(HERE, "golden", "test-progressive.jpg"), "rb").read()]
+        refs = [_decode_buffer(zj, ctx, b, False, 1)[1] for b in blobs]
+        for lend in (None, "off"):
+            if lend:
+                os.environ["ZJ_POOL_LEND"] = lend
+            try:
+                with zj.Pool(threads=8) as pool:
+                    for n in (1, 2, 3, 4, 11):
+                        files = [blobs[i % len(blobs)] for i in range(n)]
+                        for _ in range(2):
+                            outs, _, sts = pool.decode_files(files)
+                            assert not any(sts)
+                            for i in range(n):
+                                assert np.array_equal(np.asarray(outs[i]).reshape(-1), refs[i % len(blobs)]), (lend, n, i)
+                    # pixels left in HBM
+                    n = 2
+                    sizes = [refs[i].size for i in range(n)]
+                    base = ctx.device_alloc(sum((s + 255) // 256 * 256 for s in sizes))
+                    try:
+                        ptrs, off = [], 0
+                        for s_ in sizes:
+                            ptrs.append(base + off)
+                            off += (s_ + 255) // 256 * 256
+                        pool.decode_files_device(blobs[:n], ptrs, sizes)
+                        for i in range(n):
+                            got = np.empty(sizes[i], np.uint8)
+                            ctx.d2h(got, ptrs[i])
+                            assert np.array_equal(got, refs[i]), (lend, "device", i)
+                    finally:
+                        ctx.device_free(base)
+            finally:
+                os.environ.pop("ZJ_POOL_LEND", None)
     finally:
         ctx.close()

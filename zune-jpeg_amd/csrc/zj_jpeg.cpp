@@ -2243,6 +2243,13 @@ void zj_decoder_free(zj_decoder* d) { delete d; }
 const char* zj_decoder_error(const zj_decoder* d) { return d ? d->err.c_str() : ""; }
 int zj_decoder_parallel_segments(const zj_decoder* d) { return d ? d->dri_parallel_segments : 0; }
 int64_t zj_decoder_parallel_mcus(const zj_decoder* d) { return d ? (int64_t)d->par_scan_mcus : 0; }
+int zj_decoder_set_num_threads(zj_decoder* d, int threads)
+{   // Decoder::set_num_threads (src/decoder.rs:591-603): "Cannot set zero threads to decode image"
+    if (!d) return ZJ_ERR_ARG;
+    if (threads <= 0) return fail(d, ZJ_ERR_FORMAT, "Cannot set zero threads to decode image");
+    d->threads = threads;
+    return ZJ_OK;
+}
 
 static void fill_info(const zj_decoder* d, zj_image_info* info, zj_frame_desc* fd)
 {

@@ -150,7 +150,7 @@ ABI = [  # every symbol include/zjhip.h declares
     "zj_decoder_finish_pixels_device", "zj_decoder_scan_blob", "zj_decoder_gpu_status", "zj_pool_decode_files_device",
     "zj_decoder_new", "zj_decoder_free", "zj_decoder_error", "zj_decoder_read_headers",
     "zj_decoder_decode_coefficients", "zj_decoder_finish_pixels", "zj_decoder_decode_buffer",
-    "zj_decoder_parallel_segments", "zj_decoder_parallel_mcus",
+    "zj_decoder_parallel_segments", "zj_decoder_parallel_mcus", "zj_decoder_set_num_threads",
     "zj_pool_create", "zj_pool_destroy", "zj_pool_threads", "zj_pool_error", "zj_pool_stats",
     "zj_pool_decode_files", "zj_set_variant", "zj_variant_available", "zj_set_pipeline",
     "zj_decode_frames", "zj_decode_planes_device_strided", "zj_decode_frames_device", "zj_pointer_device",
@@ -257,6 +257,7 @@ def lib():
     L.zj_decoder_parallel_segments.argtypes = [vp]
     L.zj_decoder_parallel_mcus.restype = C.c_longlong
     L.zj_decoder_parallel_mcus.argtypes = [vp]
+    L.zj_decoder_set_num_threads.argtypes = [vp, C.c_int]
     L.zj_decoder_prepare.argtypes = [vp, vp, sz, C.POINTER(FrameDesc), C.POINTER(ImageInfo)]
     L.zj_decoder_finish_pixels.argtypes = [vp, vp, vp, sz, C.POINTER(sz)]
     L.zj_decoder_finish_pixels_device.argtypes = [vp, vp, vp, sz, C.POINTER(sz)]
@@ -627,6 +628,11 @@ class Decoder:
     def parallel_mcus(self):
         """MCUs of the last baseline scan without restart markers that several threads decoded (0 = serial walk)."""
         return int(lib().zj_decoder_parallel_mcus(self._d))
+
+    def set_num_threads(self, threads):  # decoder.rs:591-603 (deprecated there: options are the way)
+        rc = lib().zj_decoder_set_num_threads(self._d, int(threads))
+        if rc:
+            self._raise(rc)
 
     def read_headers(self, buf):  # decoder.rs:452
         b = np.frombuffer(bytes(buf), np.uint8)
