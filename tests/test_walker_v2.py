@@ -189,3 +189,47 @@ def test_parallel_scan_gives_up_in_flat_areas_and_keeps_what_it_has(zj, sub):
             assert 0 < _PAR_MCUS[0] <= total, (_PAR_MCUS, total)
             seen.add(_PAR_MCUS[0])
     assert len(seen) > 1, seen   # (the patience made a difference: some attempts stopped inside the band)
+
+
+def test_a_decoder_with_helper_threads_survives_fork(zj):
+    """The decoder's helper threads (Crew) do not exist in the child of a fork(): the child's first parallel region starts its
+    own, and closing the decoder there -- with or without having used it -- does not wait for threads that are not there."""
+    data = _jpeg(3, 1024, 768, 2, 90, False, 0)
+    os.environ["ZJ_PAR_MIN_CHUNK"] = "1024"
+    try:
+        o = zj.ZuneJpegOptions()
+        o.num_threads = 4
+        decs = [zj.Decoder(o), zj.Decoder(o)]
+        ref = None
+        for d in decs:
+            _, planes, _ = d.decode_coefficients(data)
+            assert d.parallel_mcus() > 0
+            ref = [p.tobytes() for p in planes]
+        r, w = os.pipe()
+        pid = os.fork()
+        if pid == 0:   # the child: one decoder used again, one only closed
+            code = 1
+            try:
+                _, planes, _ = decs[0].decode_coefficients(data)
+                same = [p.tobytes() for p in planes] == ref and decs[0].parallel_mcus() > 0
+                decs[0].close()
+                decs[1].close()
+                os.write(w, b"ok" if same else b"different")
+                code = 0
+            finally:
+                os._exit(code)
+        os.close(w)
+        import select
+        ready, _, _ = select.select([r], [], [], 60)
+        msg = os.read(r, 64) if ready else b"timeout"
+        os.close(r)
+        if not ready:
+            os.kill(pid, 9)
+        os.waitpid(pid, 0)
+        assert msg == b"ok", msg
+        for d in decs:   # the parent's decoders are unaffected
+            _, planes, _ = d.decode_coefficients(data)
+            assert [p.tobytes() for p in planes] == ref
+            d.close()
+    finally:
+        os.environ.pop("ZJ_PAR_MIN_CHUNK", None)

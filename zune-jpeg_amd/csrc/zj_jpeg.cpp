@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <immintrin.h> // _mm_stream_si128 and wider: the coefficient planes are written once and read by DMA
 
 #include <algorithm>
@@ -398,6 +399,7 @@ public:
     Crew& operator=(const Crew&) = delete;
     ~Crew()
     {
+        orphaned();
         { std::lock_guard<std::mutex> g(m_); stop_ = true; }
         wake_.notify_all();
         for (auto& t : th_) t.join();
@@ -410,8 +412,10 @@ public:
         std::atomic<int> next{0};
         auto work = [&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
         const std::function<void()> job = std::cref(work);
+        orphaned();
         {
             std::lock_guard<std::mutex> g(m_);
+            if (th_.empty()) pid_ = getpid();
             while ((int)th_.size() < threads - 1) th_.emplace_back([this] { helper(); });
             job_ = &job; seats_ = threads - 1; gen_++;
             hint_.store(gen_, std::memory_order_relaxed);
@@ -423,6 +427,19 @@ public:
         idle_.wait(g, [this] { return busy_ == 0; });
     }
 private:
+    // in the child of a fork() the helpers do not exist (only the forking thread does): forget them, start new ones on demand
+    void orphaned()
+    {
+        if (th_.empty() || getpid() == pid_) return;
+        for (auto& t : th_) t.detach();
+        th_.clear();
+        job_ = nullptr; seats_ = 0; busy_ = 0;
+        // the condition variables still count the parent's sleeping helpers as waiters (destroying one would wait for them):
+        // fresh ones in their place, without running the old ones' destructors
+        new (&wake_) std::condition_variable();
+        new (&idle_) std::condition_variable();
+        new (&m_) std::mutex();
+    }
     void helper()
     {
         unsigned long seen = 0;
@@ -451,6 +468,7 @@ private:
     std::atomic<unsigned long> hint_{0}; // gen_ again, for helpers that poll without the lock
     int seats_ = 0, busy_ = 0;
     bool stop_ = false;
+    pid_t pid_ = 0; // the process the helpers belong to
 };
 
 } // namespace
