@@ -431,7 +431,9 @@ private:
     void orphaned()
     {
         if (th_.empty() || getpid() == pid_) return;
-        for (auto& t : th_) t.detach();
+        // (no pthread call on the stale handles -- the child's own new threads may already live in those stacks: the handles
+        // are moved to a vector that is never destroyed)
+        (void)new std::vector<std::thread>(std::move(th_));
         th_.clear();
         job_ = nullptr; seats_ = 0; busy_ = 0;
         // the condition variables still count the parent's sleeping helpers as waiters (destroying one would wait for them):
