@@ -1536,66 +1536,89 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
     }
     const long long total_mcus = cur_mcu;
     if (total_mcus <= 0 || total_mcus > (long long)d->mcu_x * d->mcu_y || !cur.exact) return keep(head, head_mcus);
-    // the MCUs in T equal parts, each beginning at an anchor whose bits_left is known
-    std::vector<size_t> cut((size_t)T + 1, anchors.size());
+    // the MCUs in P = 4 T parts of equal size, each beginning at an anchor whose bits_left is known.  The threads take them in
+    // order, one at a time: a helper that wakes up late costs a quarter of what it would with one part per thread, and the
+    // picture becomes final from the top -- the calling thread, between its own parts, checks the links of what is finished
+    // and hands those rows to the GPU (zj_decoder_decode_buffer's streamed frame).
+    const int P = 4 * T;
+    std::vector<size_t> cut((size_t)P + 1, anchors.size());
     cut[0] = 0;
     {
         size_t a = 0;
-        for (int q = 1; q < T; q++) {
-            const long long want = head_mcus + (total_mcus - head_mcus) * q / T;
+        for (int q = 1; q < P; q++) {
+            const long long want = head_mcus + (total_mcus - head_mcus) * q / P;
             while (a < anchors.size() && (anchors[a].mcu < want || !anchors[a].s.exact)) a++;
             cut[(size_t)q] = a;
         }
     }
     const auto t_b = clk();
     // B: the coefficients, every part from its own first MCU start and the predictors that hold there
-    std::vector<Out> res((size_t)T);
-    d->crew.each(T, T, [&](int t) {
+    std::vector<Out> res((size_t)P);
+    std::vector<std::atomic<int>> finished((size_t)P);
+    for (auto& f : finished) f.store(0, std::memory_order_relaxed);
+    // A part that begins on the bit the one in front ended on, with the predictors it ended with, begins at a true MCU start
+    // (by induction from chunk 0, whose decode IS the serial decode) and at the MCU index it was given -- so its own end is
+    // true as well.  The first link that does not hold ends what is kept; the serial walk goes on from there.
+    const Out* last = &head;
+    long long kept = head_mcus;
+    int checked = 0; // parts [0, checked) are behind `last`
+    const auto follow_links = [&](int upto) { // (one thread at a time: the caller)
+        for (; checked < upto; checked++) {
+            const int t = checked;
+            if (cut[(size_t)t] >= cut[(size_t)t + 1]) continue;
+            if (!finished[(size_t)t].load(std::memory_order_acquire)) return false;
+            const Out& o = res[(size_t)t];
+            if (o.rc || last->end_bits != o.begin_bits || memcmp(last->pred, anchors[cut[(size_t)t]].s.dc, sizeof last->pred) != 0) return false;
+            last = &o;
+            kept = cut[(size_t)t + 1] < anchors.size() ? anchors[cut[(size_t)t + 1]].mcu : total_mcus;
+        }
+        return true;
+    };
+    const std::thread::id caller = std::this_thread::get_id();
+    d->crew.each(P, T, [&](int t) {
         Out& o = res[(size_t)t];
         o.t0 = std::chrono::duration<double, std::milli>(clk() - t_b).count();
         o.rc = 0; o.begin_bits = o.end_bits = -1;
         const size_t a0 = cut[(size_t)t], a1 = cut[(size_t)t + 1];
         if (a0 >= a1) return;
-        // a DC symbol the reference may read short anywhere in the part: the serial walk decides what it reads there
-        for (size_t i = a0; i < a1; i++) if (anchors[i].s.hazard) { o.rc = ZJ_INT_NEED_HIST; return; }
-        const ParSnap& s0 = anchors[a0].s;
-        const long long count = (a1 < anchors.size() ? anchors[a1].mcu : total_mcus) - anchors[a0].mcu;
-        for (int c = 0; c < 3; c++) o.pred[c] = s0.dc[c];
-        BitReader& r = o.br;
-        r.p = s0.p; r.acc = s0.acc; r.nbits = s0.nbits; r.end = br.end; r.istart = s0.p;
-        r.rbl = s0.rbl;
-        o.begin_bits = s0.dbits;
-        long long done = 0;
-        const char* err = nullptr;
-        o.rc = fn.mcus(d, d, r, o.pred, anchors[a0].mcu, count, nullptr, &done, &err);
-        if (!o.rc && done != count) o.rc = ZJ_ERR_HUFFMAN;
-        if (!o.rc && (r.marker || r.pad || r.mpos)) o.rc = ZJ_ERR_HUFFMAN;
-        if (!o.rc) o.end_bits = s0.dbits + s0.nbits + r.consumed();
+        bool hazard = false; // a DC symbol the reference may read short anywhere in the part: the serial walk decides what it reads there
+        for (size_t i = a0; i < a1; i++) hazard |= anchors[i].s.hazard;
+        if (hazard) o.rc = ZJ_INT_NEED_HIST;
+        else {
+            const ParSnap& s0 = anchors[a0].s;
+            const long long count = (a1 < anchors.size() ? anchors[a1].mcu : total_mcus) - anchors[a0].mcu;
+            for (int c = 0; c < 3; c++) o.pred[c] = s0.dc[c];
+            BitReader& r = o.br;
+            r.p = s0.p; r.acc = s0.acc; r.nbits = s0.nbits; r.end = br.end; r.istart = s0.p;
+            r.rbl = s0.rbl;
+            o.begin_bits = s0.dbits;
+            long long done = 0;
+            const char* err = nullptr;
+            o.rc = fn.mcus(d, d, r, o.pred, anchors[a0].mcu, count, nullptr, &done, &err);
+            if (!o.rc && done != count) o.rc = ZJ_ERR_HUFFMAN;
+            if (!o.rc && (r.marker || r.pad || r.mpos)) o.rc = ZJ_ERR_HUFFMAN;
+            if (!o.rc) o.end_bits = s0.dbits + s0.nbits + r.consumed();
+        }
         o.t1 = std::chrono::duration<double, std::milli>(clk() - t_b).count();
+        finished[(size_t)t].store(1, std::memory_order_release);
+        // (never the last part from in here: its end is compared with the stitching's before anything of it leaves)
+        if (d->stream.active && std::this_thread::get_id() == caller) { (void)follow_links(P - 1); stream_rows(d, kept); }
     });
     if (dbg) {
         const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "scan_baseline_parallel: %d threads, %lld MCUs (%zu decoded while stitching%s); structure %.2f ms, stitch %.2f ms, decode %.2f ms\n",
                 T, total_mcus, walked, gave_up ? ", then left to the serial walk" : "", ms(t_a, t_s), ms(t_s, t_b), ms(t_b, clk()));
         fprintf(stderr, "  chunk 0: %lld MCUs for real, .. %.3f ms after the start\n", head_mcus, head.t1);
-        for (int t = 0; t < T; t++)
+        for (int t = 0; t < P; t++)
             fprintf(stderr, "  part %d: anchors [%zu, %zu), MCUs from %lld, rc %d, %.3f .. %.3f ms\n", t, cut[(size_t)t], cut[(size_t)t + 1],
                     cut[(size_t)t] < anchors.size() ? anchors[cut[(size_t)t]].mcu : total_mcus, res[(size_t)t].rc, res[(size_t)t].t0, res[(size_t)t].t1);
     }
-    // A part that begins on the bit the one in front ended on, with the predictors it ended with, begins at a true MCU start
-    // (by induction from chunk 0, whose decode IS the serial decode) and at the MCU index it was given -- so its own end is
-    // true as well.  The first link that does not hold ends what is kept; the serial walk goes on from there.
-    const Out* last = &head;
-    long long kept = head_mcus;
-    for (int t = 0; t < T; t++) {
-        if (cut[(size_t)t] >= cut[(size_t)t + 1]) continue;
-        const Out& o = res[(size_t)t];
-        if (o.rc || last->end_bits != o.begin_bits || memcmp(last->pred, anchors[cut[(size_t)t]].s.dc, sizeof last->pred) != 0) break;
-        last = &o;
-        kept = cut[(size_t)t + 1] < anchors.size() ? anchors[cut[(size_t)t + 1]].mcu : total_mcus;
+    if (follow_links(P - 1)) {
+        // all links so far held: the last part must also end where the stitching ended, or it is not kept
+        const Out* const l0 = last;
+        const long long k0 = kept;
+        if (follow_links(P) && (last->end_bits != cur.dbits || memcmp(last->pred, cur.dc, sizeof cur.dc) != 0)) { last = l0; kept = k0; }
     }
-    // (all links held: the last part ends where the stitching ended, or the notes are not to be trusted at all)
-    if (kept == total_mcus && (last->end_bits != cur.dbits || memcmp(last->pred, cur.dc, sizeof cur.dc) != 0)) return keep(head, head_mcus);
     return keep(*last, kept);
 }
 
