@@ -63,10 +63,43 @@ struct Huff {
     // The value itself is computed from the bits (the arithmetic is off the critical path).
     struct AcEnt { uint8_t total, idxoff, kadv, len, sz, k1, sx, t1; };
     AcEnt actab[1 << AC_BITS];
+    // The structure decode's table (par_structure_run: lengths and zig-zag advances only, round 6): what ALL the symbols
+    // whose CODES lie inside the window consume together -- their magnitude bits may lie outside, nothing reads them --
+    //   total, kadv  bits and zig-zag advance of the whole group (an EOB at its end: kadv reaches 64 from anywhere)
+    //   kpre         the advance of all but the last symbol: if that already ends the block the group does not apply
+    //   lastlen      bits of the group's last symbol (bits_left behind a block follows from where its last symbol began)
+    //   nsym         symbols in the group; 0 = take actab's entry (a longer code, or nothing to group)
+    // Built on demand (build_groups): 8 KB per table, wanted by scan_baseline_parallel only.
+    struct Group { uint8_t total, kadv, kpre, lastlen, nsym, pad[3]; };
+    Group groups[1 << AC_BITS];
+    bool have_groups = false;
+    void build_groups()
+    {
+        if (have_groups) return;
+        for (int w = 0; w < (1 << AC_BITS); w++) {
+            Group g{};
+            int pos = 0, kadv = 0, kpre = 0, nsym = 0, lastlen = 0;
+            for (;;) {
+                const AcEnt& e = actab[(w << pos) & ((1 << AC_BITS) - 1)];
+                if (!e.total || e.len > AC_BITS - pos) break;        // (the code must lie inside the bits the window knows)
+                if (pos + e.t1 > 250 || kadv + e.k1 > 250) break;
+                kpre = kadv;
+                kadv += e.k1;
+                lastlen = e.t1;
+                pos += e.t1;
+                nsym++;
+                if (e.k1 >= 64 || pos >= AC_BITS || nsym == 4) break; // (an EOB ends the group; the next code would begin outside)
+            }
+            if (nsym >= 2) { g.total = (uint8_t)pos; g.kadv = (uint8_t)kadv; g.kpre = (uint8_t)kpre; g.lastlen = (uint8_t)lastlen; g.nsym = (uint8_t)nsym; }
+            groups[w] = g;
+        }
+        have_groups = true;
+    }
     bool full_values = false; // ZJ_FLAG_FULL_AC_VALUES: fast-AC values are not cut to six bits
     int build(const uint8_t counts[17], const uint8_t* symbols, int nsym, std::string& err)
     {
         memcpy(nlen, counts, 17);
+        have_groups = false;
         uint16_t codes[257];
         uint8_t sizes[257];
         int k = 0;
@@ -1343,20 +1376,27 @@ bool par_structure_run(const zj_decoder* d, BitReader& br, long long base_bits, 
             // AC (src/bitstream.rs:332-372), one symbol per table entry (an entry that carries the EOB as well is read for its
             // first symbol only)
             const Huff::AcEnt* const tab = pat[j].ha->actab;
+            const Huff::Group* const grp = pat[j].ha->groups;
             int k = 1, nac = 0, last = 0;
             long long last_at = bits;
             do {
-                if (nbits < 32) refill();
-                Huff::AcEnt en = tab[acc >> (64 - AC_BITS)];
-                if (__builtin_expect(en.total == 0, 0)) {
-                    en = pat[j].ha->ac_escape(acc);
-                    if (!en.total) return false;
+                if (nbits < 32) refill(); // (a group is at most AC_BITS bits of codes and magnitudes + 15 of the last magnitude)
+                const unsigned w = (unsigned)(acc >> (64 - AC_BITS));
+                const Huff::Group g = grp[w];
+                int take, adv;
+                if (g.nsym && k + g.kpre < 64) { // every symbol of the group belongs to this block
+                    take = g.total; adv = g.kadv; last = g.lastlen; nac += g.nsym;
+                } else {
+                    Huff::AcEnt en = tab[w];
+                    if (__builtin_expect(en.total == 0, 0)) {
+                        en = pat[j].ha->ac_escape(acc);
+                        if (!en.total) return false;
+                    }
+                    take = en.t1; adv = en.k1; last = en.t1; nac++;
                 }
-                last = en.t1;
-                last_at = bits;
-                k += en.k1;
-                acc <<= last; nbits -= last; bits += last;
-                nac++;
+                last_at = bits + take - last;
+                k += adv;
+                acc <<= take; nbits -= take; bits += take;
             } while (k < 64);
             // bits_left behind the block: behind the refill in front of an AC symbol at data bit C it is 64 - (C mod 32)
             // whatever came before -- except in front of a block's FIRST AC symbol, where it follows from the DC symbol
@@ -1423,12 +1463,14 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
     const bool dbg = getenv("ZJ_PAR_DEBUG") != nullptr;
     const auto clk = [] { return std::chrono::steady_clock::now(); };
     const auto t_a = clk();
+    for (int ci = 0; ci < d->ns; ci++) d->ac[d->comps[d->order[ci]].ta & 3].build_groups();
     // A: chunk 0 for real; the structure of every other chunk, speculatively
     if (br.nbits != 0 || br.marker) return 0; // (the scan's reader has not been used yet: chunk 0 starts a fresh one at p0)
     std::vector<std::vector<ParSnap>> seen((size_t)T);
     std::vector<char> ok((size_t)T, 0);
     struct Out { int32_t pred[3]; long long begin_bits, end_bits; int rc; BitReader br; double t0 = 0, t1 = 0; };
     Out head{};          // chunk 0
+    std::vector<double> a_ms((size_t)T, 0.0); // (ZJ_PAR_DEBUG) when each chunk's pass A ended
     long long head_mcus = 0;
     d->crew.each(T, T, [&](int t) {
         BitReader r;
@@ -1448,6 +1490,7 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
         seen[(size_t)t].reserve((size_t)((start[(size_t)t + 1] - start[(size_t)t]) / (24 * kParEvery) + 64));
         const int32_t zero[3] = {0, 0, 0}; // (the scan begins with predictors 0; a chunk's own count starts anywhere)
         ok[(size_t)t] = par_structure_run(d, r, base[(size_t)t], 0, false, zero, start[(size_t)t + 1], (size_t)-1, kParEvery, seen[(size_t)t]);
+        a_ms[(size_t)t] = std::chrono::duration<double, std::milli>(clk() - t_a).count();
     });
     const auto t_s = clk();
     // anything unusual in chunk 0 (a DC symbol the reference may read short, a bad code): the serial walk owns it
@@ -1609,6 +1652,7 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
         fprintf(stderr, "scan_baseline_parallel: %d threads, %lld MCUs (%zu decoded while stitching%s); structure %.2f ms, stitch %.2f ms, decode %.2f ms\n",
                 T, total_mcus, walked, gave_up ? ", then left to the serial walk" : "", ms(t_a, t_s), ms(t_s, t_b), ms(t_b, clk()));
         fprintf(stderr, "  chunk 0: %lld MCUs for real, .. %.3f ms after the start\n", head_mcus, head.t1);
+        for (int t = 1; t < T; t++) fprintf(stderr, "  chunk %d: %lld bytes of structure, .. %.3f ms\n", t, (long long)(start[(size_t)t + 1] - start[(size_t)t]), a_ms[(size_t)t]);
         for (int t = 0; t < P; t++)
             fprintf(stderr, "  part %d: anchors [%zu, %zu), MCUs from %lld, rc %d, %.3f .. %.3f ms\n", t, cut[(size_t)t], cut[(size_t)t + 1],
                     cut[(size_t)t] < anchors.size() ? anchors[cut[(size_t)t]].mcu : total_mcus, res[(size_t)t].rc, res[(size_t)t].t0, res[(size_t)t].t1);
