@@ -1383,16 +1383,17 @@ bool par_structure_run(const zj_decoder* d, BitReader& br, long long base_bits, 
                 if (nbits < 32) refill(); // (a group is at most AC_BITS bits of codes and magnitudes + 15 of the last magnitude)
                 const unsigned w = (unsigned)(acc >> (64 - AC_BITS));
                 const Huff::Group g = grp[w];
-                int take, adv;
-                if (g.nsym && k + g.kpre < 64) { // every symbol of the group belongs to this block
-                    take = g.total; adv = g.kadv; last = g.lastlen; nac += g.nsym;
-                } else {
-                    Huff::AcEnt en = tab[w];
-                    if (__builtin_expect(en.total == 0, 0)) {
-                        en = pat[j].ha->ac_escape(acc);
-                        if (!en.total) return false;
-                    }
-                    take = en.t1; adv = en.k1; last = en.t1; nac++;
+                const Huff::AcEnt en1 = tab[w];
+                // the group if there is one and every symbol of it belongs to this block, else the first symbol alone -- chosen
+                // without a branch (it would be taken half of the time, in no order)
+                const bool whole = (g.nsym != 0) & (k + g.kpre < 64);
+                int take = whole ? g.total : en1.t1, adv = whole ? g.kadv : en1.k1;
+                last = whole ? g.lastlen : en1.t1;
+                nac += whole ? g.nsym : 1;
+                if (__builtin_expect(take == 0, 0)) { // a code longer than the window
+                    const Huff::AcEnt en = pat[j].ha->ac_escape(acc);
+                    if (!en.total) return false;
+                    take = en.t1; adv = en.k1; last = en.t1;
                 }
                 last_at = bits + take - last;
                 k += adv;
