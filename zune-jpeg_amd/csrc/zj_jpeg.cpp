@@ -68,7 +68,7 @@ struct Huff {
     //   total, kadv  bits and zig-zag advance of the whole group (an EOB at its end: kadv reaches 64 from anywhere)
     //   kpre         the advance of all but the last symbol: if that already ends the block the group does not apply
     //   lastlen      bits of the group's last symbol (bits_left behind a block follows from where its last symbol began)
-    //   nsym         symbols in the group; 0 = take actab's entry (a longer code, or nothing to group)
+    //   nsym         symbols in the group (1: the window's first symbol alone); 0 = a code longer than the window (ac_escape)
     // Built on demand (build_groups): 8 KB per table, wanted by scan_baseline_parallel only.
     struct Group { uint8_t total, kadv, kpre, lastlen, nsym, pad[3]; };
     Group groups[1 << AC_BITS];
@@ -90,7 +90,7 @@ struct Huff {
                 nsym++;
                 if (e.k1 >= 64 || pos >= AC_BITS || nsym == 4) break; // (an EOB ends the group; the next code would begin outside)
             }
-            if (nsym >= 2) { g.total = (uint8_t)pos; g.kadv = (uint8_t)kadv; g.kpre = (uint8_t)kpre; g.lastlen = (uint8_t)lastlen; g.nsym = (uint8_t)nsym; }
+            if (nsym >= 1) { g.total = (uint8_t)pos; g.kadv = (uint8_t)kadv; g.kpre = (uint8_t)kpre; g.lastlen = (uint8_t)lastlen; g.nsym = (uint8_t)nsym; }
             groups[w] = g;
         }
         have_groups = true;
@@ -1370,7 +1370,12 @@ bool par_structure_run(const zj_decoder* d, BitReader& br, long long base_bits, 
             if (rbl < 0) { rbl = 0; hazard = true; }
             // the DC difference itself: the predictors are part of the state the ranges start from (values of the AC
             // coefficients are not needed for that, and not formed)
-            if (s) pred[pat[j].comp] += (uint32_t)extend((int32_t)((acc << len) >> (64 - s)), s);
+            {   // magnitude and EXTEND without a branch (s == 0 gives 0), as in decode_mcus_v2
+                const uint64_t m = acc << len;
+                const int64_t sgn = (int64_t)m >> 63;
+                const uint32_t raw = (uint32_t)((m >> 1) >> (63 - s));
+                pred[pat[j].comp] += raw - (~(uint32_t)sgn & (uint32_t)((1ull << s) - 1));
+            }
             acc <<= len + s; nbits -= len + s; bits += len + s;
             const int T = rbl <= 32 ? rbl + 32 : rbl;
             // AC (src/bitstream.rs:332-372), one symbol per table entry (an entry that carries the EOB as well is read for its
@@ -1383,17 +1388,19 @@ bool par_structure_run(const zj_decoder* d, BitReader& br, long long base_bits, 
                 if (nbits < 32) refill(); // (a group is at most AC_BITS bits of codes and magnitudes + 15 of the last magnitude)
                 const unsigned w = (unsigned)(acc >> (64 - AC_BITS));
                 const Huff::Group g = grp[w];
-                const Huff::AcEnt en1 = tab[w];
-                // the group if there is one and every symbol of it belongs to this block, else the first symbol alone -- chosen
-                // without a branch (it would be taken half of the time, in no order)
-                const bool whole = (g.nsym != 0) & (k + g.kpre < 64);
-                int take = whole ? g.total : en1.t1, adv = whole ? g.kadv : en1.k1;
-                last = whole ? g.lastlen : en1.t1;
-                nac += whole ? g.nsym : 1;
-                if (__builtin_expect(take == 0, 0)) { // a code longer than the window
-                    const Huff::AcEnt en = pat[j].ha->ac_escape(acc);
-                    if (!en.total) return false;
+                int take = g.total, adv = g.kadv;
+                last = g.lastlen;
+                nac += g.nsym;
+                // rare: a code longer than the window; a block that ends inside the group (coefficient 63 is coded and another
+                // symbol's code follows in the window: that one belongs to the next block) -> the first symbol alone
+                if (__builtin_expect(g.nsym == 0 || k + g.kpre >= 64, 0)) {
+                    Huff::AcEnt en = tab[w];
+                    if (!en.total) {
+                        en = pat[j].ha->ac_escape(acc);
+                        if (!en.total) return false;
+                    }
                     take = en.t1; adv = en.k1; last = en.t1;
+                    nac += 1 - g.nsym;
                 }
                 last_at = bits + take - last;
                 k += adv;
