@@ -1438,8 +1438,8 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
     std::vector<long long> base((size_t)T);
     // Chunk 0 is decoded for real straight away (its reader's state is known), the others structure first and coefficients
     // later, with chunk 0's thread helping: chunk 0 is sized so that its decode takes what a structure pass over one of the
-    // others takes (0.85 of a decode per byte on the GPU hosts and in the build container)
-    const double c0 = 0.85 / ((double)(T - 1) + 0.85);
+    // others takes (0.65 of a decode per byte on the GPU hosts since the structure decode takes its symbols in groups)
+    const double c0 = 0.65 / ((double)(T - 1) + 0.65);
     for (int t = 0; t <= T; t++) {
         const uint8_t* q = p0 + (t == 0 ? 0 : (long long)((double)usable * (c0 + (1.0 - c0) * (double)(t - 1) / (double)(T - 1))));
         if (t == T) q = p0 + usable;
