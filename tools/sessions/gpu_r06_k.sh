@@ -2,7 +2,7 @@
 # round 6, session k: the closing build (parallel scan, crew) through the driver's own commands, the walker by thread count,
 # the streamed decode_buffer with four threads, and the soaks that touch the front-end
 set -u
-R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r06k; mkdir -p $O; cd $R
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/${ZJ_SESSION:-r06k}; mkdir -p $O; cd $R
 ls -la zune-jpeg_amd/*.so > $O/libs.txt
 ( time timeout 1500 python -m pytest tests/ -x -q -m gpu ) > $O/gputest.txt 2>&1; echo "pytest rc $?"; tail -6 $O/gputest.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke rc $?"; cat $O/smoke.txt
