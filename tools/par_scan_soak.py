@@ -70,6 +70,8 @@ def main():
         ref = decode(data, 1, False)
         for threads in (2, 4, int(rng.integers(3, 9))):
             got = decode(data, threads, True, int(rng.choice([0, 1, 8, 64])))
+            if got[:2] != ref[:2]:
+                open("/tmp/par_scan_soak_failure.jpg", "wb").write(data)
             assert got[:2] == ref[:2], ("intact", w, h, threads, got[0], ref[0])
             taken += got[2] > 0
         sos = data.index(b"\xff\xda")
