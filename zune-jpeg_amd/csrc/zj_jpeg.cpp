@@ -1281,7 +1281,7 @@ int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p,
 // by the same rules), any code that does not exist, any marker or 0xFF fill byte, a chunk that never falls into step -> the
 // attempt is dropped (or ends there) and the serial walk decodes the rest as if nothing had happened (it clears every block
 // before it fills it).
-// 4096 x 4096 4:2:0 q = 90, 3.5 MB, on the GPU host: 17.6 ms on one thread, 13.4 on 2, 7.7 on 4, 4.4 on 8, 2.8 on 16; the
+// 4096 x 4096 4:2:0 q = 90, 3.5 MB, on the GPU host: 17.7 ms on one thread, 13.1 on 2, 7.3 on 4, 4.2 on 8, 2.4 on 16; the
 // reference's own test-baseline.jpg (73 KB, 6 bits per block, mostly sky; tried before the 96 KB threshold existed) 0.90 ->
 // 0.97 ms: its second chunk begins in the flat part and the attempt ends there (profiles/r06_walker.txt).
 // ZJ_PAR_SCAN=off; tools/par_scan_soak.py.
