@@ -1258,16 +1258,18 @@ int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p,
 // that starts at an arbitrary byte with the wrong idea of where it is reads garbage for a while and then, with high
 // probability, falls into step with the true sequence of symbols -- from then on it is at MCU starts exactly where the true
 // decoder is.  So:
-//   A  (parallel)   the scan is cut into one chunk per thread.  Chunk 0 begins where the scan begins: it is decoded for real
-//                   straight away.  Every other thread decodes the STRUCTURE of its chunk only -- code lengths and zig-zag
-//                   advances, no values, no stores -- from its chunk's first byte, assuming an MCU starts there, and notes
-//                   the reader's state at every 16th MCU start it believes in (ParSnap);
+//   look (parallel) the scan is cut into one chunk per thread, and every thread looks through one chunk: nothing but data and
+//                   stuffed zeros may be there, and the stuffed zeros in front of a chunk give its first bit's number;
+//   A  (parallel)   chunk 0 begins where the scan begins: it is decoded for real straight away.  Every other thread decodes the
+//                   STRUCTURE of its chunk only -- code lengths and zig-zag advances (in groups of symbols, Huff::groups), no
+//                   values, no stores -- from its chunk's first byte, assuming an MCU starts there, and notes the reader's
+//                   state at every 16th MCU start it believes in (ParSnap);
 //   stitch (serial) the true reader's state at the end of chunk t-1 is looked up among chunk t's notes; if it is not one of
 //                   them the true structure decode goes on into chunk t, a few MCUs at a time, until it is (typically within
 //                   twenty MCUs).  From that note on chunk t's notes are true, and how many MCUs precede each is known: they
 //                   join one list of ANCHORS over the whole scan (MCU index, reader, DC predictors);
-//   B  (parallel)   the MCUs behind chunk 0 are cut into one part per thread at anchors, equal in MCUs, and every thread
-//                   decodes its part for real (decode_mcus_v2).  The DC predictors a part starts with come from pass A as
+//   B  (parallel)   the MCUs behind chunk 0 are cut at anchors into four parts per thread, equal in MCUs, which the threads
+//                   take in order and decode for real (decode_mcus_v2).  The DC predictors a part starts with come from pass A as
 //                   well: the structure decode forms the DC differences (one per block) and keeps their running sums, and
 //                   differences of sums inside a chunk are true once the chunk is in step.
 //   check           every part must end at the bit the next one began at, with the predictors the next one was given; what
