@@ -190,7 +190,8 @@ def from_files(zj, ctx, size=4096, batch=16, reps=4):
         mp = size * size / 1e6
         out = {}
         for name, mode, nthreads in (("gpu_entropy", zj.ENTROPY_GPU, 1), ("cpu_entropy", zj.ENTROPY_CPU, 1),
-                                     ("cpu_entropy_4_threads", zj.ENTROPY_CPU, 4)):  # 4: the reference's default (src/options.rs:33)
+                                     ("cpu_entropy_4_threads", zj.ENTROPY_CPU, 4),    # 4: the reference's default (src/options.rs:33)
+                                     ("cpu_entropy_16_threads", zj.ENTROPY_CPU, 16)):  # 16: the most one scan is cut into
             o = zj.ZuneJpegOptions()
             o.entropy, o.pinned_planes, o.num_threads = mode, True, nthreads
             decs = [zj.Decoder(o, ctx) for _ in range(batch)]
@@ -198,7 +199,7 @@ def from_files(zj, ctx, size=4096, batch=16, reps=4):
             ptrs = [(base + k * size * size * 3, size * size * 3) for k in range(batch)]
             n = batch if mode == zj.ENTROPY_GPU else 2
             best_total, best_prep = 1e9, 1e9
-            for _ in range(reps if mode == zj.ENTROPY_GPU else 2):  # (the first pass also allocates: best of the passes)
+            for _ in range(reps if mode == zj.ENTROPY_GPU else 3):  # (the first pass also allocates and starts the decoders' helper threads: best of the passes)
                 t0 = time.perf_counter()
                 for k in range(n):
                     decs[k].prepare(blobs[k % len(blobs)])
@@ -214,7 +215,7 @@ def from_files(zj, ctx, size=4096, batch=16, reps=4):
             ctx.device_free(base)
             for d in decs:
                 d.close()
-        out["what"] = f"{size}x{size} 4:2:0 q90 baseline JPEG files ({len(blobs[0]) / 1e6:.2f} MB) -> RGB in HBM, one host thread, batches of {batch}; host_ms_per_file = container parsing + Huffman (cpu_entropy; cpu_entropy_4_threads: the scan, which has no restart markers, entered at four points, zj_jpeg.cpp scan_baseline_parallel) or + scan preparation (gpu_entropy)"
+        out["what"] = f"{size}x{size} 4:2:0 q90 baseline JPEG files ({len(blobs[0]) / 1e6:.2f} MB) -> RGB in HBM, one host thread, batches of {batch}; host_ms_per_file = container parsing + Huffman (cpu_entropy; cpu_entropy_4_threads / _16_threads: the scan, which has no restart markers, entered at one point per thread, zj_jpeg.cpp scan_baseline_parallel) or + scan preparation (gpu_entropy)"
         return out
     except Exception as e:  # the headline must not depend on this
         return {"error": repr(e)[:200]}
