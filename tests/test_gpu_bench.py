@@ -129,7 +129,7 @@ def test_single_rank_line_has_the_contract_fields():
     ff = res["from_files"]
     assert "error" not in ff, ff
     for mode in ("cpu_entropy", "gpu_entropy", "cpu_entropy_4_threads", "cpu_entropy_16_threads"):
-        assert ff[mode]["planes"] == "pinned" and ff[mode]["host_threads"] == (4 if mode.endswith("threads") else 1) and ff[mode]["blocks"] == 393216
+        assert ff[mode]["planes"] == "pinned" and ff[mode]["host_threads"] == {"cpu_entropy_4_threads": 4, "cpu_entropy_16_threads": 16}.get(mode, 1) and ff[mode]["blocks"] == 393216
     assert ff["cpu_entropy_4_threads"]["mcus_decoded_in_parallel"] > 60000 and ff["cpu_entropy"]["mcus_decoded_in_parallel"] == 0
     assert ff["cpu_entropy_4_threads"]["host_ms_per_file"] < ff["cpu_entropy"]["host_ms_per_file"]
     assert ff["cpu_entropy_16_threads"]["mcus_decoded_in_parallel"] > 60000 and ff["cpu_entropy_16_threads"]["host_threads"] == 16
