@@ -1,4 +1,4 @@
-"""CPU: the front-end's threaded paths under ThreadSanitizer (round 6): the decoder's helper threads (zj_jpeg.cpp Crew), restart
+"""CPU: the front-end's threaded paths under ThreadSanitizer (round 6): the decoder's helper threads (zj_crew.h), restart
 segments on several threads, and a scan without restart markers entered at one point per thread (scan_baseline_parallel) --
 tests/tsan/par_scan_tsan.cpp, built from zj_jpeg.cpp + tests/fuzz/jpeg_stubs.cpp with g++ -fsanitize=thread.  The harness
 compares every threaded decode with the one-thread decode; a data race report ends it with a non-zero exit."""

@@ -1,4 +1,4 @@
-// ThreadSanitizer run of the front-end's threaded paths (round 6): the decoder's helper threads (Crew), restart segments on
+// ThreadSanitizer run of the front-end's threaded paths (round 6): the decoder's helper threads (zj_crew.h), restart segments on
 // several threads and scan_baseline_parallel.  Built by tests/test_tsan.py from zj_jpeg.cpp + tests/fuzz/jpeg_stubs.cpp with
 // -fsanitize=thread; decodes every file given on the command line with 1, 2, 3, 4 and 7 threads, several times per decoder
 // (the crew is reused) and with fresh decoders, and compares the planes with the one-thread decode.  Exit 0: equal and no
