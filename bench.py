@@ -456,6 +456,82 @@ def reference_files(zj, ctx, reps=5):
     return out
 
 
+def reference_bench(zj, ctx, reps=4):
+    """Never `value`: the reference's OWN benchmark (benches/decode.rs:9-14,44-131: `Decoder::new()` + `decode_buffer` of
+    benches/images/speed_bench*.jpg, 7680 x 4320; Benches.md quotes the whole-decode times -- Huffman included, four worker
+    threads, a Ryzen 5 4500U) on this host + GPU, the whole call, two ways:
+      as_the_reference_does  a NEW decoder per call with default options (4 threads, pageable planes), pixels into a fresh buffer
+      steady_state           one decoder kept, planes and pixels pinned (what a caller that decodes many files would do)
+    Bytes checked against the hashes the oracle recorded (tests/golden/ref_images.json).  Context, like BASELINE.md section 2: a
+    different CPU, and here a GPU does the pixel path -- `published_ms` is the reference's own figure for the same file."""
+    import ctypes as C
+    import hashlib
+    import numpy as np
+    out = {}
+    try:
+        rec = {r["file"]: r for r in json.load(open(os.path.join(ROOT, "tests", "golden", "ref_images.json")))["files"]}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:200]}
+    L = zj.lib()
+    L.zj_alloc_pinned.restype = C.c_void_p
+    L.zj_alloc_pinned.argtypes = [C.c_size_t]
+    L.zj_free_pinned.argtypes = [C.c_void_p]
+    cases = (("speed_bench.jpg", zj.ColorSpace.RGB, "sha256_rgb", 62.246, 98.343, "Benches.md:82-86"),
+             ("speed_bench.jpg", zj.ColorSpace.GRAYSCALE, "sha256_gray", 45.598, 46.648, "Benches.md:96-99"),
+             ("speed_bench_hv_subsampling.jpg", zj.ColorSpace.RGB, "sha256_rgb", 52.175, 78.343, "Benches.md:135-139"))
+    for name, cs, key, pub, turbo, where in cases:
+        label = name + (" -> GRAYSCALE" if cs == zj.ColorSpace.GRAYSCALE else " -> RGB")
+        try:
+            data = open(os.path.join(ROOT, "tests", "golden", "ref", name), "rb").read()
+            r = rec["benches/images/" + name]
+            n = r["width"] * r["height"] * cs.num_components()
+            fresh = 1e9
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                o = zj.ZuneJpegOptions()
+                o.out_colorspace = cs
+                dec = zj.Decoder(o, ctx)
+                px = dec.decode_buffer(data)
+                fresh = min(fresh, time.perf_counter() - t0)
+                dec.close()
+            ok = hashlib.sha256(np.ascontiguousarray(px).tobytes()).hexdigest() == r[key]
+            del px
+            o = zj.ZuneJpegOptions()
+            o.out_colorspace, o.pinned_planes = cs, True
+            dec = zj.Decoder(o, ctx)
+            pin = L.zj_alloc_pinned(n)
+            try:
+                pout = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint8)), shape=(n,))
+                steady, host4 = 1e9, 1e9
+                for _ in range(reps + 2):
+                    t0 = time.perf_counter()
+                    got = dec.decode_buffer(data, out=pout)
+                    steady = min(steady, time.perf_counter() - t0)
+                ok = ok and hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest() == r[key]
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    dec.prepare(data)
+                    host4 = min(host4, time.perf_counter() - t0)
+                par = dec.parallel_mcus()
+            finally:
+                dec.close()
+                L.zj_free_pinned(pin)
+            mp = r["width"] * r["height"] / 1e6
+            out[label] = {"as_the_reference_does_ms": round(fresh * 1e3, 2), "steady_state_ms": round(steady * 1e3, 2),
+                          "steady_state_megapixels_per_s": round(mp / steady, 1), "host_entropy_ms": round(host4 * 1e3, 2),
+                          "host_threads": 4, "mcus_decoded_in_parallel": int(par), "width": r["width"], "height": r["height"],
+                          "sampling": f"{r['h_max']}x{r['v_max']}", "file_bytes": len(data), "sha256_matches_golden": bool(ok),
+                          "published_ms": pub, "published_libjpeg_turbo_ms": turbo,
+                          "published_on": "AMD Ryzen 5 4500U, 4 worker threads, " + where}
+        except Exception as e:  # noqa: BLE001
+            out[label] = {"error": repr(e)[:200]}
+    out["what"] = ("the reference's benchmark images through the whole decode_buffer call (default options: four threads; a scan without "
+                   "restart markers is entered at four points): as_the_reference_does_ms = new decoder + pageable planes + a fresh pixel "
+                   "buffer per call, as benches/decode.rs does; steady_state_ms = one decoder, pinned planes and pixels; best of "
+                   f"{reps} / {reps + 2}")
+    return out
+
+
 def load_golden():
     try:
         g = json.load(open(os.path.join(ROOT, "tests", "golden", "checksums_seed1234.json")))
@@ -1028,6 +1104,7 @@ def main():
             res["other_workloads"] = other_workloads(zj, synth, ctx, dev, side)
             res["reference_files"] = reference_files(zj, ctx)
             res["from_files"] = from_files(zj, ctx)
+            res["reference_bench"] = reference_bench(zj, ctx)
         if not args.no_e2e and args.workload == "420-rgb" and world == 1 and not virt:
             gsums = [int(x, 16) for x in golden["rgb"][lo:lo + 8]] if golden else None
             res["e2e_pinned"] = e2e_pinned(zj, ctx, desc, d_planes, plane_elems, frame_out, gsums, nb=min(8, S), probe=pcie_probe(dev))

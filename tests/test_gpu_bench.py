@@ -126,6 +126,15 @@ def test_single_rank_line_has_the_contract_fields():
     # round 6: the baseline walker no longer loses to the ten-scan progressive file on the same thread (it did, 17.8 vs 3.6 ms,
     # while its blocks left through non-temporal stores: profiles/r06_feeder_ab.txt)
     assert rfiles["test-baseline.jpg"]["host_entropy_ms"] <= rfiles["test-progressive.jpg"]["host_entropy_ms"]
+    # the reference's own benchmark (benches/decode.rs on benches/images/speed_bench*.jpg), the whole decode_buffer call
+    rb = res["reference_bench"]
+    assert "error" not in rb, rb
+    for label, pub in (("speed_bench.jpg -> RGB", 62.246), ("speed_bench.jpg -> GRAYSCALE", 45.598), ("speed_bench_hv_subsampling.jpg -> RGB", 52.175)):
+        e = rb[label]
+        assert "error" not in e, e
+        assert e["sha256_matches_golden"] is True and e["published_ms"] == pub and (e["width"], e["height"]) == (7680, 4320)
+        assert 0 < e["steady_state_ms"] <= e["as_the_reference_does_ms"] and e["host_threads"] == 4
+        assert e["mcus_decoded_in_parallel"] > 100000      # (no restart markers: the scan is entered at four points)
     ff = res["from_files"]
     assert "error" not in ff, ff
     for mode in ("cpu_entropy", "gpu_entropy", "cpu_entropy_4_threads", "cpu_entropy_16_threads"):

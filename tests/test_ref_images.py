@@ -1,6 +1,6 @@
 """The reference's own integration inputs (tests/large_images.rs, tests/medium_images.rs, tests/random_images.rs,
 benches/decode.rs), pinned by tests/golden/ref_images.json (tools/make_ref_image_fixtures.py: product CPU front-end ->
-oracle pixel path, checked against libjpeg when recorded).  Three of the files travel as data under tests/golden/ref/;
+oracle pixel path, checked against libjpeg when recorded).  Five of the files travel as data under tests/golden/ref/;
 the rest are read from /root/reference when it exists (the build container), never on the GPU box."""
 import hashlib
 import importlib
@@ -18,6 +18,8 @@ REC = {r["file"]: r for r in json.load(open(os.path.join(GOLD, "ref_images.json"
 LOCAL = {"tests/inputs/huffman_third_index.jpg": "ref/huffman_third_index.jpg",
          "tests/inputs/single_qt.jpeg": "ref/single_qt.jpeg",
          "tests/inputs/medium_horiz_samp_2500x1786.jpg": "ref/medium_horiz_samp_2500x1786.jpg",
+         "benches/images/speed_bench.jpg": "ref/speed_bench.jpg",                                  # 7680 x 4320, 4:4:4
+         "benches/images/speed_bench_hv_subsampling.jpg": "ref/speed_bench_hv_subsampling.jpg",    # 7680 x 4320, 4:2:0
          "test-images/test-baseline.jpg": "test-baseline.jpg",
          "test-images/test-progressive.jpg": "test-progressive.jpg"}
 REF = "/root/reference"

@@ -27,7 +27,9 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
     sys.path.insert(0, p)
 REF = "/root/reference"
 DIRS = ["tests/inputs", "benches/images", "test-images"]
-COPY = ["tests/inputs/huffman_third_index.jpg", "tests/inputs/single_qt.jpeg", "tests/inputs/medium_horiz_samp_2500x1786.jpg"]
+COPY = ["tests/inputs/huffman_third_index.jpg", "tests/inputs/single_qt.jpeg", "tests/inputs/medium_horiz_samp_2500x1786.jpg",
+        # the reference's benchmark images (benches/decode.rs:44-131; Benches.md quotes their whole-decode times): bench.py times them
+        "benches/images/speed_bench.jpg", "benches/images/speed_bench_hv_subsampling.jpg"]
 
 
 def sha(a):

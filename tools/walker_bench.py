@@ -5,7 +5,7 @@ pinned when a device is there (ZuneJpegOptions.pinned_planes) and malloc'd other
 
   python tools/walker_bench.py [files ...] [--reps 7] [--pinned] [--synthetic 4096]
 
-Without file arguments: the reference's 7680x4320 speed_bench.jpg when /root/reference is there (build container only),
+Without file arguments: the reference's 7680x4320 speed_bench.jpg (4:4:4) and speed_bench_hv_subsampling.jpg (tests/golden/ref),
 tests/golden/test-baseline.jpg, test-progressive.jpg, and a 4096x4096 4:2:0 q90 file written by Pillow (tools/files_bench.py).
 """
 import argparse
@@ -73,9 +73,8 @@ def main():
     if a.files:
         items = [(os.path.basename(f), open(f, "rb").read()) for f in a.files]
     else:
-        ref = "/root/reference/benches/images/speed_bench.jpg"
-        if os.path.exists(ref):
-            items.append(("speed_bench.jpg", open(ref, "rb").read()))
+        for n in ("speed_bench.jpg", "speed_bench_hv_subsampling.jpg"):  # the reference's benchmark images (benches/decode.rs)
+            items.append((n, open(os.path.join(ROOT, "tests", "golden", "ref", n), "rb").read()))
         for n in ("test-baseline.jpg", "test-progressive.jpg"):
             items.append((n, open(os.path.join(ROOT, "tests", "golden", n), "rb").read()))
         if a.synthetic:
