@@ -461,6 +461,8 @@ def reference_bench(zj, ctx, reps=4):
     benches/images/speed_bench*.jpg, 7680 x 4320; Benches.md quotes the whole-decode times -- Huffman included, four worker
     threads, a Ryzen 5 4500U) on this host + GPU, the whole call, two ways:
       as_the_reference_does  a NEW decoder per call with default options (4 threads, pageable planes), pixels into a fresh buffer
+      new_decoder_pinned     a new decoder per call with zj_options.pinned_planes (the library hands freed pinned blocks to the
+                             next decoder), pixels into a fresh pageable buffer
       steady_state           one decoder kept, planes and pixels pinned (what a caller that decodes many files would do)
     Bytes checked against the hashes the oracle recorded (tests/golden/ref_images.json).  Context, like BASELINE.md section 2: a
     different CPU, and here a GPU does the pixel path -- `published_ms` is the reference's own figure for the same file."""
@@ -496,6 +498,18 @@ def reference_bench(zj, ctx, reps=4):
                 dec.close()
             ok = hashlib.sha256(np.ascontiguousarray(px).tobytes()).hexdigest() == r[key]
             del px
+            # the same with pinned planes: the library keeps freed pinned blocks for the next decoder (zj_alloc_pinned)
+            fresh_pinned = 1e9
+            for _ in range(reps + 1):
+                t0 = time.perf_counter()
+                o = zj.ZuneJpegOptions()
+                o.out_colorspace, o.pinned_planes = cs, True
+                dec = zj.Decoder(o, ctx)
+                px = dec.decode_buffer(data)
+                fresh_pinned = min(fresh_pinned, time.perf_counter() - t0)
+                dec.close()
+            ok = ok and hashlib.sha256(np.ascontiguousarray(px).tobytes()).hexdigest() == r[key]
+            del px
             o = zj.ZuneJpegOptions()
             o.out_colorspace, o.pinned_planes = cs, True
             dec = zj.Decoder(o, ctx)
@@ -517,7 +531,8 @@ def reference_bench(zj, ctx, reps=4):
                 dec.close()
                 L.zj_free_pinned(pin)
             mp = r["width"] * r["height"] / 1e6
-            out[label] = {"as_the_reference_does_ms": round(fresh * 1e3, 2), "steady_state_ms": round(steady * 1e3, 2),
+            out[label] = {"as_the_reference_does_ms": round(fresh * 1e3, 2), "new_decoder_pinned_planes_ms": round(fresh_pinned * 1e3, 2),
+                          "steady_state_ms": round(steady * 1e3, 2),
                           "steady_state_megapixels_per_s": round(mp / steady, 1), "host_entropy_ms": round(host4 * 1e3, 2),
                           "host_threads": 4, "mcus_decoded_in_parallel": int(par), "width": r["width"], "height": r["height"],
                           "sampling": f"{r['h_max']}x{r['v_max']}", "file_bytes": len(data), "sha256_matches_golden": bool(ok),
@@ -527,7 +542,7 @@ def reference_bench(zj, ctx, reps=4):
             out[label] = {"error": repr(e)[:200]}
     out["what"] = ("the reference's benchmark images through the whole decode_buffer call (default options: four threads; a scan without "
                    "restart markers is entered at four points): as_the_reference_does_ms = new decoder + pageable planes + a fresh pixel "
-                   "buffer per call, as benches/decode.rs does; steady_state_ms = one decoder, pinned planes and pixels; best of "
+                   "buffer per call, as benches/decode.rs does; new_decoder_pinned_planes_ms = the same with pinned planes (cached by the library between decoders); steady_state_ms = one decoder, pinned planes and pixels; best of "
                    f"{reps} / {reps + 2}")
     return out
 

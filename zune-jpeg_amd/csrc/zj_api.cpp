@@ -287,9 +287,25 @@ size_t zj_out_len(const zj_frame_desc* d)
 //   3 page-aligned heap memory, touched by the calling thread, then hipHostRegister'ed (portable)
 //   4 hipHostMalloc, portable | non-coherent
 // Registered blocks are remembered so that zj_free_pinned can undo them.
+// Freed hipHostMalloc blocks are kept for the next caller (round 6): pinning 200 MB of planes costs tens of milliseconds, and
+// a caller that makes a new decoder per file, as the reference's own benchmark does (benches/decode.rs:9-14), would pay it
+// per file.  A block is handed out again to a request of at least half its size with the same flags on the same device (its
+// pages live on that device's NUMA node); at most ZJ_PINNED_CACHE_MB (default 512, 0 = off) stay cached.
 namespace {
 std::mutex g_reg_mu;
 std::vector<void*> g_registered;
+struct PinnedBlock { void* p; size_t bytes; unsigned flags; int device; };
+std::vector<PinnedBlock> g_pin_live, g_pin_free;
+size_t g_pin_free_bytes = 0;
+size_t pinned_cache_limit()
+{
+    static const size_t lim = [] {
+        long mb = 512;
+        if (const char* e = getenv("ZJ_PINNED_CACHE_MB")) mb = atol(e);
+        return mb > 0 ? (size_t)mb << 20 : (size_t)0;
+    }();
+    return lim;
+}
 }
 void* zj_alloc_pinned(size_t bytes)
 {
@@ -311,7 +327,39 @@ void* zj_alloc_pinned(size_t bytes)
                          : kind == 2 ? (hipHostMallocPortable | hipHostMallocNumaUser)
                          : kind == 4 ? (hipHostMallocPortable | hipHostMallocNonCoherent)
                                      : hipHostMallocPortable;
-    if (hipHostMalloc(&p, bytes, flags) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); device = 0; }
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        size_t best = g_pin_free.size();
+        for (size_t i = 0; i < g_pin_free.size(); i++) {
+            const PinnedBlock& f = g_pin_free[i];
+            if (f.flags == flags && f.device == device && f.bytes >= bytes && f.bytes / 2 <= bytes &&
+                (best == g_pin_free.size() || f.bytes < g_pin_free[best].bytes)) best = i;
+        }
+        if (best != g_pin_free.size()) {
+            const PinnedBlock f = g_pin_free[best];
+            g_pin_free.erase(g_pin_free.begin() + (long)best);
+            g_pin_free_bytes -= f.bytes;
+            g_pin_live.push_back(f);
+            return f.p;
+        }
+    }
+    if (hipHostMalloc(&p, bytes, flags) != hipSuccess) {
+        (void)hipGetLastError();
+        // out of pinned memory with blocks lying idle: give them back and try once more
+        std::vector<PinnedBlock> idle;
+        {
+            std::lock_guard<std::mutex> lk(g_reg_mu);
+            idle.swap(g_pin_free);
+            g_pin_free_bytes = 0;
+        }
+        if (idle.empty()) return nullptr;
+        for (const PinnedBlock& f : idle) (void)hipHostFree(f.p);
+        if (hipHostMalloc(&p, bytes, flags) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    g_pin_live.push_back(PinnedBlock{p, bytes, flags, device});
     return p;
 }
 int zj_device_pci_bus_id(int device, char* buf, size_t cap)
@@ -341,6 +389,13 @@ void zj_free_pinned(void* p)
                 (void)hipHostUnregister(p);
                 free(p);
                 return;
+            }
+        for (size_t i = 0; i < g_pin_live.size(); i++)
+            if (g_pin_live[i].p == p) {
+                const PinnedBlock f = g_pin_live[i];
+                g_pin_live.erase(g_pin_live.begin() + (long)i);
+                if (g_pin_free_bytes + f.bytes <= pinned_cache_limit()) { g_pin_free.push_back(f); g_pin_free_bytes += f.bytes; return; }
+                break;
             }
     }
     (void)hipHostFree(p);
