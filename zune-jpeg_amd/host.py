@@ -14,7 +14,6 @@ Only the HIP arm exists here; asking for scalar/avx2 raises ZjError(ZJ_ERR_BACKE
 arms live in the host application (the Rust crate), not in this library.
 """
 import ctypes as C
-import mmap
 import enum
 import os
 import sys
@@ -720,7 +719,7 @@ class Decoder:
         info = self.read_headers(buf)
         ncomp = 1 if info.components == 1 else ColorSpace(self._out_cs).num_components()
         if out is None:
-            out = _pixel_buffer(int(info.width) * int(info.height) * ncomp)
+            out = np.zeros(int(info.width) * int(info.height) * ncomp, np.uint8)
         n = C.c_size_t(0)
         rc = lib().zj_decoder_decode_buffer(self._d, self._ctx.handle, _ptr(b), b.size, _ptr(out), out.size,
                                             C.byref(n), C.byref(info))
@@ -728,19 +727,6 @@ class Decoder:
             self._raise(rc)
         self._info = info
         return out[: n.value]
-
-
-def _pixel_buffer(n):
-    """A zeroed uint8 array of n bytes for decoded pixels (the reference returns a fresh Vec<u8>): large ones from an anonymous
-    mapping with huge pages asked for -- 100 MB of fresh 4 KB pages cost a 33 MP decode 24 000 page faults, a third of the call."""
-    if n >= (4 << 20) and hasattr(mmap, "MADV_HUGEPAGE"):
-        try:
-            m = mmap.mmap(-1, n)
-            m.madvise(mmap.MADV_HUGEPAGE)
-            return np.frombuffer(m, np.uint8)
-        except (OSError, ValueError):
-            pass
-    return np.zeros(n, np.uint8)
 
 
 def finish_pixels_batch(decoders, ctx, outs=None, device_ptrs=None):
