@@ -422,7 +422,10 @@ ZJ_API int zj_multi_decode_frames_device(zj_multi *m, const zj_frame_desc *d, si
                                   int *statuses);
 
 /* ---- memory helpers ------------------------------------------------------------------------- */
-ZJ_API void *zj_alloc_pinned(size_t bytes); /* hipHostMalloc, portable (usable as a DMA source/target from every device); NULL on failure */
+/* hipHostMalloc, portable (usable as a DMA source/target from every device); NULL on failure.  zj_free_pinned keeps up to
+ * ZJ_PINNED_CACHE_MB (default 512, 0 = none) of freed blocks for later requests of at least half their size from a thread on the
+ * same device: pinning costs milliseconds per 10 MB, and a decoder made per file (zj_options.pinned_planes) would pay it per file */
+ZJ_API void *zj_alloc_pinned(size_t bytes);
 /* binds the CALLING thread to `device` (hipSetDevice): host threads that only allocate pinned memory or fill planes for a
  * context on device N call this first, so they neither initialise nor pin against device 0 */
 ZJ_API int zj_set_thread_device(int device);
