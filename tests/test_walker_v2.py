@@ -159,10 +159,11 @@ def test_scans_without_restart_markers_on_several_threads(zj, case):
 
 
 @pytest.mark.parametrize("sub", [0, 2])
-def test_parallel_scan_gives_up_in_flat_areas_and_keeps_what_it_has(zj, sub):
+def test_parallel_scan_bridges_flat_areas(zj, sub):
     """A band of one colour in the middle of the picture: runs of identical two-symbol MCUs, where a reader that enters out of
     step stays out of step.  The stitching walks `patience` MCUs into it (ZJ_PAR_PATIENCE; the product: 512 or 1/64 of the
-    picture), then stops: the MCUs anchored so far are decoded in parallel, the serial walk takes the rest -- same planes."""
+    picture), then the calling thread decodes the rest of that chunk for real and the stitching goes on behind it: the chunks
+    below the band are in step again -- same planes, and the whole region is covered whatever the patience."""
     from PIL import Image, ImageFile
     ImageFile.MAXBLOCK = max(ImageFile.MAXBLOCK, 1 << 24)
     rng = np.random.default_rng(77 + sub)
@@ -175,7 +176,6 @@ def test_parallel_scan_gives_up_in_flat_areas_and_keeps_what_it_has(zj, sub):
     ref = _decode(zj, data, 1, v1=False)
     assert ref[0] == "ok"
     total = ((w + 15) // 16 if sub else (w + 7) // 8) * ((h + 15) // 16 if sub == 2 else (h + 7) // 8)
-    seen = set()
     for patience in ("2", "40", None):
         for threads in (3, 4, 6):
             if patience:
@@ -186,9 +186,8 @@ def test_parallel_scan_gives_up_in_flat_areas_and_keeps_what_it_has(zj, sub):
             finally:
                 os.environ.pop("ZJ_PAR_PATIENCE", None)
             assert got[:3] == ref[:3], (patience, threads)
-            assert 0 < _PAR_MCUS[0] <= total, (_PAR_MCUS, total)
-            seen.add(_PAR_MCUS[0])
-    assert len(seen) > 1, seen   # (the patience made a difference: some attempts stopped inside the band)
+            # everything but the scan's last 8 KB (which stay with the serial walk) went through the parallel path
+            assert 0.6 * total < _PAR_MCUS[0] <= total, (patience, threads, _PAR_MCUS, total)
 
 
 def test_a_decoder_with_helper_threads_survives_fork(zj):

@@ -1411,7 +1411,7 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
     if (br.nbits != 0 || br.marker) return 0; // (the scan's reader has not been used yet: chunk 0 starts a fresh one at p0)
     std::vector<std::vector<ParSnap>> seen((size_t)T);
     std::vector<char> ok((size_t)T, 0);
-    struct Out { int32_t pred[3]; long long begin_bits, end_bits; int rc; BitReader br; double t0 = 0, t1 = 0; };
+    struct Out { int32_t pred[3], pred0[3]; long long begin_bits, end_bits; int rc; BitReader br; double t0 = 0, t1 = 0; }; // pred0: at the start
     Out head{};          // chunk 0
     std::vector<double> a_ms((size_t)T, 0.0); // (ZJ_PAR_DEBUG) when each chunk's pass A ended
     long long head_mcus = 0;
@@ -1486,11 +1486,15 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
     size_t walked = 0;
     // A reader that enters a run of identical short MCUs out of step (flat areas: two symbols per block) stays out of step
     // until the picture changes, and the true structure decode would have to walk through all of them one after the other
-    // at what the real decode costs for such blocks.  Past `patience` MCUs the stitching stops instead: what is anchored so
-    // far is decoded in parallel, the serial walk takes the scan from there (the reference's test-baseline.jpg, 6 bits per
-    // block: its second quarter begins in the flat sky; speed_bench.jpg, 6.5 bits per block, is in step within 52 MCUs).
+    // at more than the real decode costs for such blocks (a note per MCU).  Past `patience` MCUs the stitching BRIDGES the
+    // rest of the chunk instead: the calling thread decodes it for real, here and now, up to the next chunk's first byte, and
+    // the stitching goes on from where that ends -- the next chunk may well be in step (the reference's speed_bench_hv: sky
+    // over a third of the picture, detail below).  A bridge is a part like any other when the links are checked.
     size_t patience = std::max<size_t>(512, (size_t)((long long)d->mcu_x * d->mcu_y / 64));
     if (const char* e = getenv("ZJ_PAR_PATIENCE")) { const long v = atol(e); if (v >= 1) patience = (size_t)v; } // (tests)
+    struct Bridge { size_t at; long long m0, m1; Out out; }; // in front of anchors[at]: MCUs [m0, m1) are decoded
+    std::vector<Bridge> bridges;
+    long long bridged = 0;
     bool gave_up = false;
     for (int t = 1; t < T && !gave_up; t++) {
         const size_t walked0 = walked;
@@ -1504,11 +1508,32 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
         for (;;) {
             if (meets(cur)) { join(cand, j, ParSnap(cur), cur_mcu); break; }
             if (cur.p >= start[(size_t)t + 1]) break; // past this chunk without ever meeting it: the chunk is dropped
+            if (walked - walked0 > patience) {
+                if (!cur.exact) { gave_up = true; break; }
+                Bridge g{anchors.size(), cur_mcu, cur_mcu, Out{}};
+                Out& o = g.out;
+                for (int c = 0; c < 3; c++) o.pred[c] = o.pred0[c] = cur.dc[c];
+                BitReader& r = o.br;
+                r.p = cur.p; r.acc = cur.acc; r.nbits = cur.nbits; r.end = br.end; r.istart = cur.p;
+                r.rbl = cur.rbl;
+                o.begin_bits = cur.dbits;
+                long long done = 0;
+                const char* err = nullptr;
+                o.rc = fn.mcus(d, d, r, o.pred, cur_mcu, (long long)d->mcu_x * d->mcu_y - cur_mcu, start[(size_t)t + 1], &done, &err);
+                if (o.rc || done < 1 || r.marker || r.pad || r.mpos) { gave_up = true; break; } // (the serial walk owns whatever that was)
+                o.end_bits = cur.dbits + cur.nbits + r.consumed();
+                g.m1 = cur_mcu + done;
+                cur = ParSnap{r.p, r.acc, o.end_bits, r.nbits, r.rbl, true, false, {o.pred[0], o.pred[1], o.pred[2]}, 0};
+                cur_mcu = g.m1;
+                bridged += done;
+                bridges.push_back(g);
+                continue; // (cur.p >= the next chunk's start now: on to the next junction)
+            }
             // a few more true MCUs (8, then 16 ... 64 at a time: most chunks are met within twenty), then look again
             BitReader r;
             r.p = cur.p; r.acc = cur.acc; r.nbits = cur.nbits; r.end = br.end; r.istart = cur.p;
             more.clear();
-            if (!par_structure_run(d, r, cur.dbits + cur.nbits, cur.rbl, cur.exact, cur.dc, start[(size_t)T], stride, 1, more) || more.size() < 2) return keep(head, head_mcus);
+            if (!par_structure_run(d, r, cur.dbits + cur.nbits, cur.rbl, cur.exact, cur.dc, start[(size_t)T], stride, 1, more) || more.size() < 2) { gave_up = true; break; }
             if (stride < 64) stride *= 2;
             size_t i = 1;
             for (;; i++) {
@@ -1517,95 +1542,119 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
                 if (i + 1 == more.size() || meets(more[i]) || more[i].p >= start[(size_t)t + 1]) break;
             }
             cur = more[i]; // (what the run decoded behind it is decoded again: by the chunk's own notes or the next run)
-            if (walked - walked0 > patience) { gave_up = true; break; }
         }
     }
     const long long total_mcus = cur_mcu;
     if (total_mcus <= 0 || total_mcus > (long long)d->mcu_x * d->mcu_y || !cur.exact) return keep(head, head_mcus);
-    // the MCUs in P = 4 T parts of equal size, each beginning at an anchor whose bits_left is known.  The threads take them in
-    // order, one at a time: a helper that wakes up late costs a quarter of what it would with one part per thread, and the
-    // picture becomes final from the top -- the calling thread, between its own parts, checks the links of what is finished
-    // and hands those rows to the GPU (zj_decoder_decode_buffer's streamed frame).
-    const int P = 4 * T;
-    std::vector<size_t> cut((size_t)P + 1, anchors.size());
-    cut[0] = 0;
+    // The MCUs that are left to decode, in about P = 4 T pieces of equal size, each beginning at an anchor whose bits_left is
+    // known.  The threads take them in order, one at a time: a helper that wakes up late costs a quarter of what it would with
+    // one piece per thread, and the picture becomes final from the top -- the calling thread, between its own pieces, checks
+    // the links of what is finished and hands those rows to the GPU (zj_decoder_decode_buffer's streamed frame).
+    struct Piece { size_t a0, a1; long long m0, m1; Out* out; bool bridge; };
+    std::vector<Piece> pieces;
     {
-        size_t a = 0;
-        for (int q = 1; q < P; q++) {
-            const long long want = head_mcus + (total_mcus - head_mcus) * q / P;
-            while (a < anchors.size() && (anchors[a].mcu < want || !anchors[a].s.exact)) a++;
-            cut[(size_t)q] = a;
+        const int P = 4 * T;
+        const long long to_do = total_mcus - head_mcus - bridged;
+        size_t lo = 0;
+        bool usable = true;
+        for (size_t k = 0; k <= bridges.size() && usable; k++) {
+            const size_t hi = k < bridges.size() ? bridges[k].at : anchors.size();
+            const long long run_end = k < bridges.size() ? bridges[k].m0 : total_mcus;
+            if (lo < hi) {
+                if (!anchors[lo].s.exact) { usable = false; break; } // (cannot happen: a run begins where the true reader stood)
+                const long long run_begin = anchors[lo].mcu, run = run_end - run_begin;
+                int pk = to_do > 0 ? (int)((run * P + to_do / 2) / to_do) : 1;
+                if (pk < 1) pk = 1;
+                size_t a = lo;
+                for (int q = 0; q < pk && a < hi; q++) {
+                    size_t b = hi;
+                    if (q + 1 < pk) {
+                        const long long want = run_begin + run * (q + 1) / pk;
+                        b = a + 1;
+                        while (b < hi && (anchors[b].mcu < want || !anchors[b].s.exact)) b++;
+                    }
+                    pieces.push_back(Piece{a, b, anchors[a].mcu, b < hi ? anchors[b].mcu : run_end, nullptr, false});
+                    a = b;
+                }
+            }
+            if (k < bridges.size()) pieces.push_back(Piece{hi, hi, bridges[k].m0, bridges[k].m1, &bridges[k].out, true});
+            lo = hi;
         }
+        if (!usable) return keep(head, head_mcus);
     }
+    const size_t NP = pieces.size();
     const auto t_b = clk();
-    // B: the coefficients, every part from its own first MCU start and the predictors that hold there
-    std::vector<Out> res((size_t)P);
-    std::vector<std::atomic<int>> finished((size_t)P);
-    for (auto& f : finished) f.store(0, std::memory_order_relaxed);
-    // A part that begins on the bit the one in front ended on, with the predictors it ended with, begins at a true MCU start
+    // B: the coefficients, every piece from its own first MCU start and the predictors that hold there
+    std::vector<Out> res(NP);
+    std::vector<std::atomic<int>> finished(NP);
+    std::vector<int> todo;
+    for (size_t q = 0; q < NP; q++) {
+        finished[q].store(pieces[q].bridge ? 1 : 0, std::memory_order_relaxed);
+        if (!pieces[q].bridge) { pieces[q].out = &res[q]; todo.push_back((int)q); }
+    }
+    // A piece that begins on the bit the one in front ended on, with the predictors it ended with, begins at a true MCU start
     // (by induction from chunk 0, whose decode IS the serial decode) and at the MCU index it was given -- so its own end is
     // true as well.  The first link that does not hold ends what is kept; the serial walk goes on from there.
     const Out* last = &head;
     long long kept = head_mcus;
-    int checked = 0; // parts [0, checked) are behind `last`
-    const auto follow_links = [&](int upto) { // (one thread at a time: the caller)
+    size_t checked = 0; // pieces [0, checked) are behind `last`
+    const auto follow_links = [&](size_t upto) { // (one thread at a time: the caller)
         for (; checked < upto; checked++) {
-            const int t = checked;
-            if (cut[(size_t)t] >= cut[(size_t)t + 1]) continue;
-            if (!finished[(size_t)t].load(std::memory_order_acquire)) return false;
-            const Out& o = res[(size_t)t];
-            if (o.rc || last->end_bits != o.begin_bits || memcmp(last->pred, anchors[cut[(size_t)t]].s.dc, sizeof last->pred) != 0) return false;
+            const Piece& pc = pieces[checked];
+            if (!finished[checked].load(std::memory_order_acquire)) return false;
+            const Out& o = *pc.out;
+            if (o.rc || last->end_bits != o.begin_bits || memcmp(last->pred, o.pred0, sizeof last->pred) != 0) return false;
             last = &o;
-            kept = cut[(size_t)t + 1] < anchors.size() ? anchors[cut[(size_t)t + 1]].mcu : total_mcus;
+            kept = pc.m1;
         }
         return true;
     };
     const std::thread::id caller = std::this_thread::get_id();
-    d->crew.each(P, T, [&](int t) {
-        Out& o = res[(size_t)t];
+    d->crew.each((int)todo.size(), T, [&](int ti) {
+        const size_t q = (size_t)todo[(size_t)ti];
+        const Piece& pc = pieces[q];
+        Out& o = res[q];
         o.t0 = std::chrono::duration<double, std::milli>(clk() - t_b).count();
         o.rc = 0; o.begin_bits = o.end_bits = -1;
-        const size_t a0 = cut[(size_t)t], a1 = cut[(size_t)t + 1];
-        if (a0 >= a1) return;
-        bool hazard = false; // a DC symbol the reference may read short anywhere in the part: the serial walk decides what it reads there
-        for (size_t i = a0; i < a1; i++) hazard |= anchors[i].s.hazard;
+        bool hazard = false; // a DC symbol the reference may read short anywhere in the piece: the serial walk decides what it reads there
+        for (size_t i = pc.a0; i < pc.a1; i++) hazard |= anchors[i].s.hazard;
+        const ParSnap& s0 = anchors[pc.a0].s;
+        for (int c = 0; c < 3; c++) o.pred[c] = o.pred0[c] = s0.dc[c];
+        o.begin_bits = s0.dbits;
         if (hazard) o.rc = ZJ_INT_NEED_HIST;
         else {
-            const ParSnap& s0 = anchors[a0].s;
-            const long long count = (a1 < anchors.size() ? anchors[a1].mcu : total_mcus) - anchors[a0].mcu;
-            for (int c = 0; c < 3; c++) o.pred[c] = s0.dc[c];
+            const long long count = pc.m1 - pc.m0;
             BitReader& r = o.br;
             r.p = s0.p; r.acc = s0.acc; r.nbits = s0.nbits; r.end = br.end; r.istart = s0.p;
             r.rbl = s0.rbl;
-            o.begin_bits = s0.dbits;
             long long done = 0;
             const char* err = nullptr;
-            o.rc = fn.mcus(d, d, r, o.pred, anchors[a0].mcu, count, nullptr, &done, &err);
+            o.rc = fn.mcus(d, d, r, o.pred, pc.m0, count, nullptr, &done, &err);
             if (!o.rc && done != count) o.rc = ZJ_ERR_HUFFMAN;
             if (!o.rc && (r.marker || r.pad || r.mpos)) o.rc = ZJ_ERR_HUFFMAN;
             if (!o.rc) o.end_bits = s0.dbits + s0.nbits + r.consumed();
         }
         o.t1 = std::chrono::duration<double, std::milli>(clk() - t_b).count();
-        finished[(size_t)t].store(1, std::memory_order_release);
-        // (never the last part from in here: its end is compared with the stitching's before anything of it leaves)
-        if (d->stream.active && std::this_thread::get_id() == caller) { (void)follow_links(P - 1); stream_rows(d, kept); }
+        finished[q].store(1, std::memory_order_release);
+        // (never the last piece from in here: its end is compared with the stitching's before anything of it leaves)
+        if (d->stream.active && std::this_thread::get_id() == caller && NP) { (void)follow_links(NP - 1); stream_rows(d, kept); }
     });
     if (dbg) {
         const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "scan_baseline_parallel: %d threads, %lld MCUs (%zu decoded while stitching%s); structure %.2f ms, stitch %.2f ms, decode %.2f ms\n",
-                T, total_mcus, walked, gave_up ? ", then left to the serial walk" : "", ms(t_a, t_s), ms(t_s, t_b), ms(t_b, clk()));
+        fprintf(stderr, "scan_baseline_parallel: %d threads, %lld MCUs (%zu decoded while stitching, %lld bridged in %zu bridges%s); structure %.2f ms, stitch %.2f ms, decode %.2f ms\n",
+                T, total_mcus, walked, bridged, bridges.size(), gave_up ? ", then left to the serial walk" : "", ms(t_a, t_s), ms(t_s, t_b), ms(t_b, clk()));
         fprintf(stderr, "  looking for markers and counting stuffed zeros in front of pass A: %.3f ms\n", ms(t_in, t_a));
         fprintf(stderr, "  chunk 0: %lld MCUs for real, .. %.3f ms after the start\n", head_mcus, head.t1);
         for (int t = 1; t < T; t++) fprintf(stderr, "  chunk %d: %lld bytes of structure, .. %.3f ms\n", t, (long long)(start[(size_t)t + 1] - start[(size_t)t]), a_ms[(size_t)t]);
-        for (int t = 0; t < P; t++)
-            fprintf(stderr, "  part %d: anchors [%zu, %zu), MCUs from %lld, rc %d, %.3f .. %.3f ms\n", t, cut[(size_t)t], cut[(size_t)t + 1],
-                    cut[(size_t)t] < anchors.size() ? anchors[cut[(size_t)t]].mcu : total_mcus, res[(size_t)t].rc, res[(size_t)t].t0, res[(size_t)t].t1);
+        for (size_t q = 0; q < NP; q++)
+            fprintf(stderr, "  piece %zu%s: MCUs [%lld, %lld), rc %d, %.3f .. %.3f ms\n", q, pieces[q].bridge ? " (bridge)" : "", pieces[q].m0, pieces[q].m1,
+                    pieces[q].out->rc, pieces[q].out->t0, pieces[q].out->t1);
     }
-    if (follow_links(P - 1)) {
-        // all links so far held: the last part must also end where the stitching ended, or it is not kept
+    if (NP && follow_links(NP - 1)) {
+        // all links so far held: the last piece must also end where the stitching ended, or it is not kept
         const Out* const l0 = last;
         const long long k0 = kept;
-        if (follow_links(P) && (last->end_bits != cur.dbits || memcmp(last->pred, cur.dc, sizeof cur.dc) != 0)) { last = l0; kept = k0; }
+        if (follow_links(NP) && (last->end_bits != cur.dbits || memcmp(last->pred, cur.dc, sizeof cur.dc) != 0)) { last = l0; kept = k0; }
     }
     return keep(*last, kept);
 }
