@@ -1202,7 +1202,8 @@ int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p,
 //                   walk's own), the serial walk decodes the rest.
 // Flat areas (two symbols per block, identical MCUs) are where it does not work: a reader that enters such a run out of step
 // stays out of step until the picture changes.  The stitching has `patience` for max(512, 1/64 of the picture) MCUs per
-// chunk; then it stops, what is anchored so far is decoded in parallel and the serial walk takes the scan from there.
+// chunk; then the calling thread decodes the rest of that chunk for real (a BRIDGE: a part like any other when the links
+// are checked, only decoded early and alone) and the stitching goes on with the next chunk from where the bridge ends.
 // The scan's last 8 KB -- where the reference's early exit at EOI lives -- and everything the walker treats specially stay
 // with the serial walk: any DC symbol the reference might read short (ref_dc_misread: the structure decode follows bits_left
 // by the same rules), any code that does not exist, any marker or 0xFF fill byte, a chunk that never falls into step -> the
