@@ -1453,8 +1453,8 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
     stream_rows(d, head_mcus); // (zj_decoder_decode_buffer: those rows can go to the GPU while the rest is decoded)
     // stitch: one list of TRUE MCU starts (anchors) over the whole scan, each with the MCU's index and the predictors that hold
     // there; `cur` = the true reader behind the last anchored MCU.  A chunk's notes join the list from the note the true
-    // reader lands on; the MCUs the true structure decode has to walk through to get there (a chunk that never falls into
-    // step -- long runs of identical short MCUs keep a shifted reader shifted -- is walked through entirely) are anchors too.
+    // reader lands on; the MCUs the true structure decode has to walk through to get there are anchors too (a chunk that never
+    // falls into step -- long runs of identical short MCUs keep a shifted reader shifted -- is bridged, see below).
     struct Anchor { ParSnap s; long long mcu; };
     std::vector<Anchor> anchors;
     {
