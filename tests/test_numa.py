@@ -129,3 +129,39 @@ def test_numa_off_binds_nothing_on_the_gpu_box():
             print(pool.slot_numa()[0][1])
         """, {"ZJ_NUMA": "off"})
     assert out[0] == "False -1 True" and out[1] == "0"
+
+
+@pytest.mark.gpu
+def test_freed_pinned_blocks_are_handed_out_again():
+    """zj_free_pinned keeps blocks for later requests of at least half their size (zj_api.cpp: a decoder made per file with
+    pinned planes would otherwise pin 0.17 ms per MB and unpin 0.09 per file); ZJ_PINNED_CACHE_MB=0 turns that off.  Each
+    setting in a fresh process: the limit is read once."""
+    code = r"""
+import ctypes as C, importlib, sys
+sys.path.insert(0, %r)
+zj = importlib.import_module("zune-jpeg_amd")
+L = zj.lib()
+L.zj_alloc_pinned.restype = C.c_void_p; L.zj_alloc_pinned.argtypes = [C.c_size_t]; L.zj_free_pinned.argtypes = [C.c_void_p]
+ctx = zj.Context()
+a = L.zj_alloc_pinned(48 << 20); C.memset(a, 7, 48 << 20); L.zj_free_pinned(a)
+b = L.zj_alloc_pinned(40 << 20)            # at least half of 48 MB: the same block
+c = L.zj_alloc_pinned(40 << 20)            # nothing cached any more: a new one
+L.zj_free_pinned(b)
+d = L.zj_alloc_pinned(8 << 20)             # less than half of 48 MB: not that block
+print(int(a == b), int(c != b and c is not None), int(d != b))
+for p in (c, d): L.zj_free_pinned(p)
+o = zj.ZuneJpegOptions(); o.pinned_planes = True
+data = open(%r, "rb").read()
+outs = []
+for _ in range(3):                          # decoders made per file share the planes' pinned blocks; the pixels do not change
+    dec = zj.Decoder(o, ctx); outs.append(dec.decode_buffer(data).tobytes()); dec.close()
+print(int(outs[0] == outs[1] == outs[2]))
+""" % (ROOT, os.path.join(ROOT, "tests", "golden", "test-baseline.jpg"))
+    for env, want in (({}, "1 1 1"), ({"ZJ_PINNED_CACHE_MB": "0"}, None)):
+        e = dict(os.environ, **env)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = r.stdout.strip().splitlines()
+        assert lines[-1] == "1", lines
+        if want:
+            assert lines[-2] == want, lines
