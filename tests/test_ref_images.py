@@ -68,10 +68,17 @@ def test_reference_tree_files_give_the_recorded_planes(zj, name):
             zj.Decoder().decode_coefficients(data)
         assert str(e.value) == r["error"]
         return
-    o = zj.ZuneJpegOptions()
-    o.num_threads = 1
-    desc, planes, info = zj.Decoder(o).decode_coefficients(data)
-    assert sha(np.concatenate(planes)) == r["sha256_planes"]
+    # one thread; the reference's default of four and seven (restart segments side by side, or -- every baseline file here but
+    # single_qt.jpeg and the 73 KB test-baseline.jpg -- the scan entered at one point per thread: scan_baseline_parallel)
+    for threads in (1, 4, 7):
+        o = zj.ZuneJpegOptions()
+        o.num_threads = threads
+        dec = zj.Decoder(o)
+        desc, planes, info = dec.decode_coefficients(data, copy=False)
+        assert sha(np.concatenate(planes)) == r["sha256_planes"], threads
+        if threads > 1 and not r["progressive"] and not r["restart_interval"] and r["bytes"] > 200000:
+            assert dec.parallel_mcus() > 0, (name, threads)
+        dec.close()
 
 
 @pytest.mark.gpu
