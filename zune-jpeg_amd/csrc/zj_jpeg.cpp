@@ -1139,9 +1139,13 @@ inline void clear_mcu(zj_decoder* dm, int mx, int my)
 
 long long eoi_rowlen(const zj_decoder* d) { return (d->ncomp == 3 && d->h_max == 2 && d->v_max == 1) ? 2ll * d->mcu_x : d->mcu_x; }
 
-// eoi: first 0xFF of the EOI marker when this segment is the one that ends with it, else null
+// eoi: first 0xFF of the EOI marker when this segment is the one that ends with it, else null.
+// must_end (every segment but the last): the reader must have come to the segment's end with its last MCU, as the serial walk
+// must see the RSTn marker in handle_restart() -- with bytes left over (a damaged file) the reference goes on decoding the NEXT
+// interval out of them, predictors and all, which only the serial walk reproduces (found by tools/stream_soak.py, round 6:
+// rounds 4-5 decoded such segments independently and returned other garbage than the reference's).
 int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p, const uint8_t* end, long long mcu0,
-                          long long nmcu, const char** err, const uint8_t* eoi = nullptr)
+                          long long nmcu, const char** err, const uint8_t* eoi = nullptr, bool must_end = false)
 {
     BitReader br;
     br.p = p; br.end = end; br.istart = p;
@@ -1173,6 +1177,15 @@ int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p,
         eoi_cut_after_mcu(cut, br, mcu0 + i);
     }
     _mm_sfence(); // the blocks left with streaming stores (decode_block_baseline)
+    // What the reader has met by now must be what the serial walk would have met (handle_restart: fill, then look at the
+    // marker).  A segment but the last ends right behind its RSTn: that marker, and nothing in front of it -- with bytes left
+    // over the reference goes on decoding the NEXT interval out of them, a marker in mid-segment resets it early or is "Marker
+    // found in bitstream".  The last segment ends in front of the scan's closing marker: no marker at all.
+    if (br.nbits < 64) br.fill();
+    if (must_end ? !(br.marker >= 0xD0 && br.marker <= 0xD7 && br.p == br.end) : (br.marker != 0 || br.mpos != nullptr)) {
+        *err = "a restart interval that does not end at its marker";
+        return ZJ_ERR_MCU;
+    }
     return ZJ_OK;
 }
 
@@ -1701,7 +1714,9 @@ int scan_baseline(zj_decoder* d, BitReader& br)
         const int ri = d->restart_interval;
         const int nseg = (int)((total + ri - 1) / ri);
         std::vector<const uint8_t*> seg;
-        if (find_restart_segments(br.p, br.end, nseg, seg)) {
+        // (the scan must close with EOI: behind a full last interval handle_restart() looks at whatever marker is there, and
+        // anything but RSTn / EOI is "Marker found in bitstream" -- the serial walk's to say)
+        if (find_restart_segments(br.p, br.end, nseg, seg) && seg[(size_t)nseg] + 1 < br.end && seg[(size_t)nseg][0] == 0xFF && seg[(size_t)nseg][1] == 0xD9) {
             std::atomic<int> bad{0};
             d->crew.each(nseg, d->threads, [&](int k) {
                 const char* err = nullptr;
@@ -1712,7 +1727,7 @@ int scan_baseline(zj_decoder* d, BitReader& br)
                     eoi = seg[(size_t)nseg];
                     while (eoi > seg[(size_t)k] && eoi[-1] == 0xFF) eoi--;
                 }
-                if (scan_baseline_segment(d, d, seg[(size_t)k], seg[(size_t)k + 1], m0, n, &err, eoi)) bad.store(1);
+                if (scan_baseline_segment(d, d, seg[(size_t)k], seg[(size_t)k + 1], m0, n, &err, eoi, k != nseg - 1)) bad.store(1);
             });
             if (!bad.load()) { br.p = seg[(size_t)nseg]; br.reset(); d->dri_parallel_segments = nseg; return ZJ_OK; }
             // (the serial walk below clears every block again before it writes into it)
