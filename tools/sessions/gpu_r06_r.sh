@@ -3,7 +3,7 @@
 # parity suites on the all-variants build, the pool soak on two slots with the CPU walker (short batches lend threads to their
 # files: the parallel scan inside the pool), the pixel soak, the reference's benchmark, the pool's short batches
 set -u
-R=${GRAFT_REPO_ROOT:-$(pwd)}; export ZJ_SESSION=r06r; O=$R/gpurun_out/r06r; mkdir -p $O; cd $R
+R=${GRAFT_REPO_ROOT:-$(pwd)}; export ZJ_SESSION=${ZJ_SESSION:-r06r}; O=$R/gpurun_out/$ZJ_SESSION; mkdir -p $O; cd $R
 bash tools/sessions/gpu_r06_k.sh
 ZJ_LIB=libzjhip_all.so timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_pitch.py tests/test_gpu_scatter.py -q -x -m gpu -n 4 > $O/gputest_all_variants.txt 2>&1; echo "pytest all-variants rc $?"; tail -3 $O/gputest_all_variants.txt
 timeout 400 python tools/pool_soak.py --seconds 120 --devices 0,0 --entropy cpu > $O/pool_soak_cpu.txt 2>&1; echo "pool soak cpu rc $?"; tail -2 $O/pool_soak_cpu.txt
