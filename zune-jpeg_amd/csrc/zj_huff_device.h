@@ -111,6 +111,7 @@ struct HuffWrite { // what only the write pass carries
     uint32_t mcu, mx, my;   // MCU in progress
     uint32_t seg_start_bits, eoi_d; // for the reference's early exit at EOI (zj_jpeg.cpp EoiCut): start of the segment,
     int eoi_seg;                    // data bytes in front of the marker; whether this is the segment that ends with EOI
+    uint32_t seg_end_bits;          // exact end of the segment's data; 0 for the scan's last segment (nothing follows it)
     uint32_t* ctl;
 };
 
@@ -187,7 +188,11 @@ ZJ_DEV HuffState huff_run(const HuffLds& L, uint32_t tid, uint32_t start_bits, H
     if (WRITE) dst = huff_block_ptr(h, *w, h.blk[j]);
     uint32_t prev_start = 0xffffffffu; // (write pass) first bit of the previous symbol; none yet in this sub-sequence
     for (;;) {
-        if (WRITE && w->blk >= w->blk_end) break;
+        if (WRITE && w->blk >= w->blk_end) {
+            // the interval's blocks are done: what is left in front of its marker must be padding (HUFF_ST_LEFT_OVER)
+            if (w->seg_end_bits && w->seg_end_bits >= pos + 8u) status |= HUFF_ST_LEFT_OVER;
+            break;
+        }
         if (pos >= limit) {
             if (WRITE && last_sub) status |= HUFF_ST_EXHAUSTED; // blocks are missing and the segment has no more bits
             break;
@@ -378,6 +383,7 @@ ZJ_DEV void huff_write_thread(const HuffArgs& a, const HuffLds& L, uint32_t tid,
     w.seg_start_bits = seg.start * 8u;
     w.eoi_d = seg.end - seg.start;
     w.eoi_seg = h.is_eoi && k + 1 == h.nseg;
+    w.seg_end_bits = k + 1 == h.nseg ? 0u : seg.end * 8u;
     w.ctl = a.ctl;
     HuffI4 aux;
     (void)huff_run<true>(L, tid, sub.start * 8u, s, huff_limit(a.blob, subs, i, sub), (sub.seg & HUFF_LAST) != 0, aux, &w);

@@ -2140,6 +2140,9 @@ int prepare_scan(zj_decoder* d, const uint8_t* p, const uint8_t* end)
             } else {
                 if (k + 1 != nseg) return why(3); // the scan ends early
                 is_eoi = m == 0xD9;
+                // (behind a full last restart interval handle_restart() looks at whatever marker is there: anything but RSTn /
+                // EOI is "Marker found in bitstream", src/mcu.rs:386-419 -- the CPU walker's to say)
+                if (!is_eoi && nseg > 1) return why(15);
                 at = mk;
             }
         } else {
