@@ -328,3 +328,45 @@ def test_long_dc_symbols_the_reference_reads_short_are_handed_back(zj):
         else:
             back += 1
     assert short_files >= 2 and kept >= 10, (short_files, kept, back)
+
+
+def test_intervals_with_bytes_left_over_are_handed_back(zj):
+    """Bytes inserted into a restart interval: its blocks are complete with data left in front of the marker, and the reference
+    decodes the NEXT interval out of what is left (handle_restart() sees no marker yet), predictors and all.  The device's
+    intervals are independent: it must say HUFF_ST_LEFT_OVER (128) -- until round 6 it kept such scans, with other
+    coefficients than the serial walk's (and than the reference's)."""
+    data = pil_jpeg(320, 240, 90, subsampling=2, seed=5, restart_marker_rows=1)
+    rst = [i for i in range(len(data) - 1) if data[i] == 0xFF and 0xD0 <= data[i + 1] <= 0xD7]
+    assert len(rst) == 14
+    rng = np.random.default_rng(8)
+    flagged = 0
+    for trial in range(40):
+        k = int(rng.integers(0, len(rst) - 1))
+        at = int(rng.integers(rst[k] + 30, rst[k + 1] - 30))
+        d = bytearray(data)
+        d[at:at] = bytes(rng.integers(1, 255, int(rng.integers(12, 60)), dtype=np.uint8))
+        d = bytes(d)
+        o = zj.ZuneJpegOptions()
+        o.entropy = zj.ENTROPY_GPU_ALWAYS
+        dec = zj.Decoder(o)
+        try:
+            dec.prepare(d)
+        except zj.DecodeError:
+            continue
+        blob = dec.scan_blob()
+        if blob is None:
+            continue
+        s1 = zj.ZuneJpegOptions()
+        s1.num_threads = 1
+        try:
+            _, want, _ = zj.Decoder(s1).decode_coefficients(d)
+        except zj.DecodeError:
+            want = None
+        lens = [20 * 15 * 4 * 64, 20 * 15 * 64, 20 * 15 * 64]
+        got, status, st = emu_c.huff_decode(blob, lens)
+        if status == 0:   # kept: then it must be what one thread makes of the file
+            assert want is not None
+            for g_, w_ in zip(got, want):
+                assert np.array_equal(g_[: w_.size], w_), (trial, "the device kept an interval with bytes left over")
+        flagged += bool(status & 128)
+    assert flagged >= 10, flagged
