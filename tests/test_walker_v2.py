@@ -237,8 +237,9 @@ def test_a_decoder_with_helper_threads_survives_fork(zj):
 def test_damaged_restart_intervals_go_to_the_serial_walk(zj):
     """Restart segments side by side (num_threads > 1) are only the reference's output where every interval ends at its marker.
     Bytes inserted into an interval: the reference decodes the NEXT interval out of what is left, predictors and all.  An
-    unknown marker in the last interval, the interval being full: handle_restart() says "Marker found in bitstream".  Both used
-    to be decoded segment by segment to other results (rounds 4-5; found by tools/stream_soak.py in round 6)."""
+    header's marker in the last interval, the interval being full: handle_restart() says "Marker found in bitstream"; a marker
+    the reference has no name for: its refill says "Unknown marker 0xFF17".  All used to be decoded segment by segment to other
+    results (rounds 4-5; found by tools/stream_soak.py in round 6)."""
     data = _jpeg(11, 448, 336, 2, 90, False, 1)     # 28 x 21 MCUs, an interval per MCU row: every interval is full
     ref = _decode(zj, data, 1, v1=False)
     par = _decode(zj, data, 4, v1=False)
@@ -253,9 +254,9 @@ def test_damaged_restart_intervals_go_to_the_serial_walk(zj):
             k = int(rng.integers(0, len(rst) - 1))
             at = int(rng.integers(rst[k] + 40, rst[k + 1] - 40))
             d[at:at] = bytes(rng.integers(1, 255, int(rng.integers(2, 40)), dtype=np.uint8))
-        elif trial % 3 == 1:    # an unknown marker in the last interval
+        elif trial % 3 == 1:    # a marker in the last interval: one the reference has no name for, or a header's
             at = int(rng.integers(rst[-1] + 40, len(d) - 40))
-            d[at:at + 2] = b"\xff\x17"
+            d[at:at + 2] = b"\xff\x17" if trial % 2 else b"\xff\xc4"
         else:                   # a restart marker that is not due, in mid-interval
             k = int(rng.integers(0, len(rst) - 1))
             at = int(rng.integers(rst[k] + 40, rst[k + 1] - 40))
@@ -265,4 +266,5 @@ def test_damaged_restart_intervals_go_to_the_serial_walk(zj):
         b = _decode(zj, d, 4, v1=False)
         assert (a[:3] == b[:3]) if a[0] == "ok" else a == b, (trial, a[0], b[0], a[1] if a[0] == "error" else "", b[1] if b[0] == "error" else "")
         seen.add(a[0] if a[0] == "ok" else a[1])
-    assert any("Marker found in bitstream" in s for s in seen), seen
+    assert any("Marker found in bitstream" in s for s in seen), seen     # (FF C4 at a restart boundary: src/mcu.rs:409-414)
+    assert any("Unknown marker 0xFF17" in s for s in seen), seen         # (src/bitstream.rs:199-206: the refill itself gives up)

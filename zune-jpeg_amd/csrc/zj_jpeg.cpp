@@ -1057,7 +1057,15 @@ struct EoiCut {
     long long rowlen = 0;         // MCUs the reference decodes per row loop (2 * mcu_x for (2,1) sampling, mcu.rs:145-152)
     bool seen = false;
     long long cut_row = -1;
+    int unknown = 0;              // the marker at `eoi` is not EOI but a byte the reference has no name for (see below): its code
 };
+// Marker::from_u8 (src/marker.rs:48-78): every other byte behind 0xFF ends the reference's refill -- and with it the decode --
+// in "Unknown marker 0xFF17" (src/bitstream.rs:199-206), at the moment its reader comes across it: the moment the EOI cut
+// follows for EOI.
+inline bool reference_knows_marker(int m)
+{
+    return m == 0xFE || m == 0xC0 || m == 0xC2 || m == 0xC4 || m == 0xCC || (m >= 0xD0 && m <= 0xDD) || m == 0xE0 || m == 0xE1 || m == 0xEE;
+}
 // data bytes of the current restart interval that precede the marker at `eoi`
 long long interval_data_bytes(const BitReader& br, const uint8_t* eoi)
 {
@@ -1741,6 +1749,12 @@ int scan_baseline(zj_decoder* d, BitReader& br)
         bool is_eoi = false;
         const uint8_t* e = find_scan_end(br.p, br.end, &is_eoi);
         cut.eoi = (e && is_eoi) ? e : nullptr;
+        if (e && !is_eoi) {
+            const uint8_t* t = e;
+            while (t + 1 < br.end && t[1] == 0xFF) t++;
+            const int m = t + 1 < br.end ? t[1] : 0xD9;
+            if (!reference_knows_marker(m)) { cut.eoi = e; cut.unknown = m; }
+        }
         cut.rowlen = eoi_rowlen(d);
     }
     // blocks of MCUs from (mx, my) on that the walk never reached stay zero, like the reference's fresh vectors
@@ -1811,6 +1825,12 @@ int scan_baseline(zj_decoder* d, BitReader& br)
             if (rc) { clear_from(my, mx + 1); return rc; }
         }
         if (!restarted) eoi_cut_after_mcu(cut, br, m); // (a restart clears the reference's pending marker, mcu.rs:400-408)
+        if (cut.seen && cut.unknown) {
+            char text[40];
+            snprintf(text, sizeof text, "Unknown marker 0xFF%X", cut.unknown);
+            clear_from(my, mx + 1);
+            return fail(d, ZJ_ERR_FORMAT, text);
+        }
         m++;
         if (m % d->mcu_x == 0) stream_rows(d, m);
     }
@@ -2143,6 +2163,9 @@ int prepare_scan(zj_decoder* d, const uint8_t* p, const uint8_t* end)
                 // (behind a full last restart interval handle_restart() looks at whatever marker is there: anything but RSTn /
                 // EOI is "Marker found in bitstream", src/mcu.rs:386-419 -- the CPU walker's to say)
                 if (!is_eoi && nseg > 1) return why(15);
+                // (a marker the reference has no name for ends its decode in "Unknown marker" once its reader comes across
+                // it -- scan_baseline's EoiCut decides when)
+                if (!is_eoi && !reference_knows_marker(m)) return why(16);
                 at = mk;
             }
         } else {
