@@ -601,3 +601,37 @@ def test_reference_short_dc_reads_in_progressive_dc_scans(zj):
         hit += short > 0
         clean += short == 0
     assert hit >= 3 and clean >= 10, (hit, clean)
+
+
+def test_fill_bytes_in_front_of_a_stuffed_zero_read_like_the_reference(zj):
+    """FF FF 00 inside a scan: the reference's refill appends the first 0xFF, skips the fill bytes, finds a zero -- no marker --
+    and goes on: the sequence reads like FF 00, one data byte 0xFF (src/bitstream.rs:183-211).  Until round 6 the front-end
+    appended a ZERO byte there.  The literal model of the reference's reader (oracle/ref_walk.py) decides."""
+    checked = 0
+    for seed in range(40):
+        sub = [0, 2, 1][seed % 3]
+        hs, vs = [(1, 1), (2, 2), (2, 1)][seed % 3]
+        data = bytearray(_noisy_jpeg(seed, sub))
+        sos = data.index(b"\xff\xda")
+        start = sos + 2 + int.from_bytes(data[sos + 2:sos + 4], "big")
+        pairs = [i for i in range(start, len(data) - 3) if data[i] == 0xFF and data[i + 1] == 0x00]
+        if not pairs:
+            continue
+        at = pairs[len(pairs) // 2]
+        data[at:at] = b"\xff" * (1 + seed % 3)        # one to three fill bytes in front of the stuffed pair
+        data = bytes(data)
+        planes, short, rows = ref_walk.decode_baseline_planes(data)
+        try:
+            desc, got, info = zj.Decoder(_opts(zj, 1)).decode_coefficients(data)
+        except zj.DecodeError:
+            assert short > 0, seed
+            continue
+        mcu_x = (64 + 8 * hs - 1) // (8 * hs)
+        assert _walked_blocks_equal(got, planes, rows, mcu_x, hs, vs), (seed, short)
+        # and it is the file without the fill bytes, coefficient for coefficient
+        clean = bytearray(data)
+        del clean[at:at + 1 + seed % 3]
+        _, want, _ = zj.Decoder(_opts(zj, 1)).decode_coefficients(bytes(clean))
+        assert all(np.array_equal(a, b) for a, b in zip(got, want)), seed
+        checked += 1
+    assert checked >= 10, checked

@@ -291,13 +291,24 @@ struct BitReader {
                 if (b == 0xFF) {
                     uint32_t n = p < end ? *p : 0xD9;
                     if (n == 0) { p++; stuffed++; }       // stuffed zero
-                    else {                                // marker: stop feeding, pad with zeros
-                        mpos = p - 1;
-                        while (n == 0xFF && p + 1 < end) { p++; n = *p; }
-                        marker = (int)n;
-                        if (p < end) p++;
-                        b = 0;
-                        pad += 8;
+                    else {
+                        const uint8_t* const first = p - 1;
+                        uint32_t fills = 0;
+                        while (n == 0xFF && p + 1 < end) { p++; n = *p; fills++; }
+                        if (n == 0 && fills) {
+                            // 0xFF fill bytes in front of a ZERO: the reference's refill skips them, finds no marker and keeps
+                            // the 0xFF it has already appended as a data byte (src/bitstream.rs:183-211) -- FF FF 00 reads like
+                            // FF 00.  (Until round 6 this appended a zero byte and counted it as padding; found while reading
+                            // the refill for the restart-segment findings of tools/stream_soak.py.)
+                            p++;
+                            stuffed += fills + 1;
+                        } else {                          // marker: stop feeding, pad with zeros
+                            mpos = first;
+                            marker = (int)n;
+                            if (p < end) p++;
+                            b = 0;
+                            pad += 8;
+                        }
                     }
                 }
             } else {
@@ -1446,7 +1457,7 @@ long long scan_baseline_parallel(zj_decoder* d, BitReader& br, const BlockFns& f
             const char* err = nullptr;
             head.begin_bits = 0;
             head.rc = fn.mcus(d, d, r, head.pred, 0, (long long)d->mcu_x * d->mcu_y, start[1], &head_mcus, &err);
-            if (!head.rc && (r.marker || r.pad || r.mpos)) head.rc = ZJ_ERR_HUFFMAN; // (0xFF fill bytes count: FF FF 00 pads the reader)
+            if (!head.rc && (r.marker || r.pad || r.mpos)) head.rc = ZJ_ERR_HUFFMAN; // (belt and braces: look_through lets nothing but data and stuffed zeros in)
             head.end_bits = r.consumed();
             head.br = r;
             head.t1 = std::chrono::duration<double, std::milli>(clk() - t_a).count();
