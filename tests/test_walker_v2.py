@@ -240,12 +240,14 @@ def test_damaged_restart_intervals_go_to_the_serial_walk(zj):
     header's marker in the last interval, the interval being full: handle_restart() says "Marker found in bitstream"; a marker
     the reference has no name for: its refill says "Unknown marker 0xFF17".  All used to be decoded segment by segment to other
     results (rounds 4-5; found by tools/stream_soak.py in round 6)."""
-    data = _jpeg(11, 448, 336, 2, 90, False, 1)     # 28 x 21 MCUs, an interval per MCU row: every interval is full
+    # 28 x 22 MCUs, an interval per MCU row: every interval is full.  (An EVEN number of MCU rows: with sub-sampled chroma the
+    # reference walks its rows in pairs and never reads an odd last one -- whatever is wrong in there is not an error.)
+    data = _jpeg(11, 448, 352, 2, 90, False, 1)
     ref = _decode(zj, data, 1, v1=False)
     par = _decode(zj, data, 4, v1=False)
-    assert ref[0] == "ok" and par[:3] == ref[:3] and par[3] == 21   # (intact: 21 segments decoded side by side)
+    assert ref[0] == "ok" and par[:3] == ref[:3] and par[3] == 22   # (intact: 22 segments decoded side by side)
     rst = [i for i in range(len(data) - 1) if data[i] == 0xFF and 0xD0 <= data[i + 1] <= 0xD7]
-    assert len(rst) == 20
+    assert len(rst) == 21
     rng = np.random.default_rng(5)
     seen = set()
     for trial in range(24):
@@ -268,3 +270,32 @@ def test_damaged_restart_intervals_go_to_the_serial_walk(zj):
         seen.add(a[0] if a[0] == "ok" else a[1])
     assert any("Marker found in bitstream" in s for s in seen), seen     # (FF C4 at a restart boundary: src/mcu.rs:409-414)
     assert any("Unknown marker 0xFF17" in s for s in seen), seen         # (src/bitstream.rs:199-206: the refill itself gives up)
+
+
+def test_an_odd_last_mcu_row_the_reference_never_reads_cannot_fail(zj):
+    """With horizontally sub-sampled chroma the reference walks its MCU rows in pairs (src/mcu.rs:145-152,225-231): the last row
+    of an odd number is never decoded -- its pixels stay zero -- so damage in its data is not an error (it was, until
+    tools/ref_walk_soak.py compared the serial walk with the literal model of the reference in round 6)."""
+    for sub, h in ((2, 336), (1, 168)):              # 4:2:0: 21 MCU rows of 16; 4:2:2: 21 MCU rows of 8
+        data = _jpeg(12, 448, h, sub, 90, False, 0)
+        ref = _decode(zj, data, 1, v1=False)
+        assert ref[0] == "ok"
+        tail = len(data) - (len(data) - data.index(b"\xff\xda")) // 42   # well inside the last of 21 rows
+        seen_ok = 0
+        rng = np.random.default_rng(3)
+        for trial in range(12):
+            d = bytearray(data)
+            at = int(rng.integers(tail, len(d) - 8))
+            if trial % 2:
+                d[at:at + 2] = b"\xff\x17"           # "Unknown marker 0xFF17" anywhere the reference reads
+            else:
+                d[at:at + 6] = bytes(rng.integers(1, 255, 6, dtype=np.uint8))
+            for threads in (1, 4):
+                got = _decode(zj, bytes(d), threads, v1=False)
+                assert got[0] == "ok", (sub, trial, threads, got)
+                seen_ok += 1
+                # the rows the reference walks are what they were
+                for a, b, rows in zip(got[1], ref[1], (20 * (2 if sub == 2 else 1), 20, 20)):
+                    bw = len(b) // 128 // (21 * (2 if (sub == 2 and rows == 40) else 1))
+                    assert a[: rows * bw * 128] == b[: rows * bw * 128], (sub, trial, threads)
+        assert seen_ok == 24

@@ -51,9 +51,10 @@ constexpr uint32_t HUFF_ST_BAD_CODE = 1, HUFF_ST_RUN_OVER = 2, HUFF_ST_EXHAUSTED
                    // a DC symbol of more than 16 bits: the reference may read it short (src/bitstream.rs:278; zj_jpeg.cpp
                    // ref_dc_misread) depending on its reader's state, which only the CPU walker follows
                    HUFF_ST_DC_LONG = 64,
-                   // a restart interval whose blocks are complete with a byte or more of data left in front of its marker: the
-                   // reference decodes the NEXT interval out of what is left (handle_restart sees no marker yet), predictors and
-                   // all -- only the CPU walker's serial walk reproduces that (round 6; tools/stream_soak.py)
+                   // a restart interval whose blocks are complete with a byte or more of data left in front of its marker, or
+                   // whose marker the reference's reader has not come across by then (a last symbol of 26 bits or more): the
+                   // reference resets nothing and decodes the NEXT interval out of what it holds, predictors and all -- only the
+                   // CPU walker's serial walk reproduces that (round 6; tools/stream_soak.py, tools/ref_walk_soak.py)
                    HUFF_ST_LEFT_OVER = 128;
 
 // table entry (u16): 16 (16 bits consumed, zig-zag advance 0) = no such code.  Bit 15 set: low byte = second-level table number, indexed by the 16 - L1 bits

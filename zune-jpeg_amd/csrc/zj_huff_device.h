@@ -189,8 +189,11 @@ ZJ_DEV HuffState huff_run(const HuffLds& L, uint32_t tid, uint32_t start_bits, H
     uint32_t prev_start = 0xffffffffu; // (write pass) first bit of the previous symbol; none yet in this sub-sequence
     for (;;) {
         if (WRITE && w->blk >= w->blk_end) {
-            // the interval's blocks are done: what is left in front of its marker must be padding (HUFF_ST_LEFT_OVER)
-            if (w->seg_end_bits && w->seg_end_bits >= pos + 8u) status |= HUFF_ST_LEFT_OVER;
+            // the interval's blocks are done: what is left in front of its marker must be padding, and the reference's reader
+            // must have come across the marker -- 4 * (C / 32 + 2) > D, C = bits consumed in front of the interval's last
+            // symbol (zj_jpeg.cpp handle_restart) -- or it resets nothing there (HUFF_ST_LEFT_OVER)
+            if (w->seg_end_bits && (w->seg_end_bits >= pos + 8u ||
+                                    (prev_start != 0xffffffffu && 4u * ((prev_start - w->seg_start_bits) / 32u + 2u) <= w->eoi_d))) status |= HUFF_ST_LEFT_OVER;
             break;
         }
         if (pos >= limit) {

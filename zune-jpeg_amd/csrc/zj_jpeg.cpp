@@ -801,7 +801,7 @@ int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, in
         br.drop(len);
         rbl -= len;
         if (HIST) hist <<= len;
-        if (TRACK) br.last_sym = len;
+        br.last_sym = len;
         if (sz) {
             const int32_t bits = (int32_t)br.peek(sz);
             br.drop(sz);
@@ -809,7 +809,7 @@ int decode_block_baseline(const zj_decoder* d, BitReader& br, const Comp& cm, in
             // the reference's fast-AC path (src/bitstream.rs:339-347) is ONE drop_bits for code and magnitude: zeros enter its
             // aligned_buffer; the general path reads the magnitude with get_bits, which rotates it back in
             if (HIST) hist = en.idxoff >= 128 ? hist << sz : (hist << sz) | (uint32_t)bits;
-            if (TRACK) br.last_sym += sz;
+            br.last_sym += sz;
             // EXTEND (T.81 F.2.2.1) without a branch: values below 2^(sz-1) are negative
             const int32_t v0 = bits + ((((bits - (1 << (sz - 1))) >> 31)) & (1 - (1 << sz)));
             const int32_t v = (int32_t)((uint32_t)v0 << en.sx) >> en.sx; // (sx: Huff::AcEnt)
@@ -885,6 +885,7 @@ inline __attribute__((always_inline)) int decode_mcus_v2_body(const zj_decoder* 
     };
     const int mcu_x = d->mcu_x;
     int my = (int)(m0 / mcu_x), mx = (int)(m0 % mcu_x);
+    int last_sym = br.last_sym; // bits of the last symbol decoded (handle_restart: has the reference come across the RSTn?)
     long long i = 0;
     for (; i < n; i++) {
         if (stop && p >= stop) break;
@@ -979,6 +980,7 @@ inline __attribute__((always_inline)) int decode_mcus_v2_body(const zj_decoder* 
                             }
                             const int c_last = nb0 + filled - nbits - last; // bits the AC symbols in front of the last one consumed
                             rbl = (c_last == 0 ? T : 33 + ((T - c_last - 33) & 31)) - last;
+                            last_sym = last;
                         }
                     }
                     if (STORE != STORE_DIRECT) flush_block<STORE>(blk, out);
@@ -990,6 +992,7 @@ inline __attribute__((always_inline)) int decode_mcus_v2_body(const zj_decoder* 
     }
     put();
     br.rbl = rbl < 0 ? 0 : rbl;
+    br.last_sym = last_sym;
     *done = i;
     return rc;
 }
@@ -1035,10 +1038,23 @@ BlockFns block_fns(int store)
 }
 
 // restart marker handling shared by all scan kinds (mcu.rs:386-419)
+long long interval_data_bytes(const BitReader& br, const uint8_t* eoi);
+// handle_rst looks at stream.marker as it stands (src/mcu.rs:391): the reference's reader has come across the RSTn only if one
+// of its four-byte refills reached it -- right after the refill in front of the interval's last symbol, C bits into the interval,
+// it has read min(D, 4 * (C / 32 + 2)) of the D data bytes in front of the marker (the closed form of the EOI cut, below).  If
+// it has not, nothing is reset: the reference decodes the next interval out of the bits it holds and then zeros (the marker
+// turns up at its next refill), with the old predictors, and resets one interval late.  Rare in intact files (the last
+// symbol would have to be 26 bits or longer); with bytes inserted into an interval, the usual case (tools/ref_walk_soak.py).
+inline bool reference_has_seen_restart_marker(const BitReader& br)
+{
+    const long long c_last = br.consumed() - br.last_sym;
+    return c_last >= 0 && 4 * (c_last / 32 + 2) > interval_data_bytes(br, br.mpos);
+}
 int handle_restart(zj_decoder* d, BitReader& br, int& todo)
 {
     todo = d->restart_interval;
-    if (br.nbits < 64) br.fill(); // make a pending marker visible
+    if (br.nbits < 64) br.fill(); // (this reader holds more than the reference's: whether THAT has the marker is decided below)
+    if (br.marker >= 0xD0 && br.marker <= 0xD7 && br.mpos && !reference_has_seen_restart_marker(br)) return ZJ_OK;
     if (br.marker >= 0xD0 && br.marker <= 0xD7) {
         br.reset();
         for (int i = 0; i < d->ncomp; i++) d->comps[i].dc_pred = 0;
@@ -1083,7 +1099,11 @@ long long interval_data_bytes(const BitReader& br, const uint8_t* eoi)
     const uint8_t* from = br.marker ? br.mpos : br.p; // stuffed zeros before this point are in br.stuffed already
     long long st = br.stuffed;
     for (const uint8_t* q = from; q + 1 < eoi; q++)
-        if (q[0] == 0xFF && q[1] == 0x00) { st++; q++; }
+        if (q[0] == 0xFF) { // FF 00, or FF FF .. 00 (fill bytes in front of the zero): one data byte, the rest is not
+            const uint8_t* z = q + 1;
+            while (z < eoi && *z == 0xFF) z++;
+            if (z < eoi && *z == 0x00) { st += (long long)(z - q); q = z; }
+        }
     return (long long)(eoi - br.istart) - st;
 }
 // call after an MCU has been decoded (and after the restart handling that may follow it)
@@ -1201,7 +1221,8 @@ int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p,
     // over the reference goes on decoding the NEXT interval out of them, a marker in mid-segment resets it early or is "Marker
     // found in bitstream".  The last segment ends in front of the scan's closing marker: no marker at all.
     if (br.nbits < 64) br.fill();
-    if (must_end ? !(br.marker >= 0xD0 && br.marker <= 0xD7 && br.p == br.end) : (br.marker != 0 || br.mpos != nullptr)) {
+    if (must_end ? !(br.marker >= 0xD0 && br.marker <= 0xD7 && br.p == br.end && reference_has_seen_restart_marker(br))
+                 : (br.marker != 0 || br.mpos != nullptr)) {
         *err = "a restart interval that does not end at its marker";
         return ZJ_ERR_MCU;
     }
@@ -1792,6 +1813,11 @@ int scan_baseline(zj_decoder* d, BitReader& br)
             stream_rows(d, m_first);
         }
     }
+    // With horizontally sub-sampled chroma the reference walks its MCU rows in pairs -- mcu_height / 2 passes over two rows
+    // (src/mcu.rs:145-152,225-231) -- so an odd last MCU row is never decoded (the pixel path leaves its rows zero: zj_plan.h).
+    // The walk below still fills that row's coefficients, but whatever is wrong with its data is nobody's business: the
+    // reference never reads it (found by tools/ref_walk_soak.py in round 6: a damaged last row made this an error).
+    const long long walked_total = (d->ncomp == 3 && d->h_max == 2) ? (long long)d->mcu_x * (d->mcu_y & ~1) : total;
     for (long long m = m_first; m < total;) {
         if (fn.mcus && !d->track_hist && !cut.seen) {
             // as many MCUs as possible in one go (decode_mcus_v2): up to the next restart boundary, short of the scan's last 4 KB.
@@ -1804,12 +1830,12 @@ int scan_baseline(zj_decoder* d, BitReader& br)
             const int rc = fn.mcus(d, d, br, pred, m, n, stop, &done, &err);
             for (int i = 0; i < 3; i++) d->comps[i].dc_pred = pred[i];
             m += done;
-            if (rc) { clear_from((int)(m / d->mcu_x), (int)(m % d->mcu_x)); return fail(d, rc, err); }
+            if (rc) { clear_from((int)(m / d->mcu_x), (int)(m % d->mcu_x)); if (m >= walked_total) break; return fail(d, rc, err); }
             if (done) {
                 todo -= (int)done;
                 if (todo == 0) {
                     const int rc2 = handle_restart(d, br, todo);
-                    if (rc2) { clear_from((int)(m / d->mcu_x), (int)(m % d->mcu_x)); return rc2; }
+                    if (rc2) { clear_from((int)(m / d->mcu_x), (int)(m % d->mcu_x)); if (m > walked_total) { d->err.clear(); d->err_code = 0; break; } return rc2; } // (m: one past the interval's last MCU)
                 }
                 stream_rows(d, m);
                 continue;
@@ -1826,25 +1852,27 @@ int scan_baseline(zj_decoder* d, BitReader& br)
                     const char* err = nullptr;
                     int16_t* blk = block_at(cm, mx * cm.h + h, my * cm.v + v);
                     int rc = (d->track_hist ? fn.hist : near_end ? fn.track : fn.hot)(d, br, cm, cm.dc_pred, blk, &err);
-                    if (rc) { clear_from(my, mx); return fail(d, rc, err); }
+                    if (rc) { clear_from(my, mx); if (m >= walked_total) goto walk_done; return fail(d, rc, err); }
                 }
         }
         bool restarted = false;
         if (--todo == 0) {
             restarted = br.marker >= 0xD0 && br.marker <= 0xD7;
             int rc = handle_restart(d, br, todo);
-            if (rc) { clear_from(my, mx + 1); return rc; }
+            if (rc) { clear_from(my, mx + 1); if (m >= walked_total) { d->err.clear(); d->err_code = 0; goto walk_done; } return rc; }
         }
         if (!restarted) eoi_cut_after_mcu(cut, br, m); // (a restart clears the reference's pending marker, mcu.rs:400-408)
         if (cut.seen && cut.unknown) {
             char text[40];
             snprintf(text, sizeof text, "Unknown marker 0xFF%X", cut.unknown);
             clear_from(my, mx + 1);
+            if (m >= walked_total) goto walk_done;
             return fail(d, ZJ_ERR_FORMAT, text);
         }
         m++;
         if (m % d->mcu_x == 0) stream_rows(d, m);
     }
+walk_done:
     _mm_sfence(); // the blocks left with streaming stores (decode_block_baseline)
     return ZJ_OK;
 }
