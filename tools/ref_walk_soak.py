@@ -128,7 +128,7 @@ def main():
             # read: its data lasts to the last block).  In a damaged file the decode may run past the data, and behind a marker the
             # reference serves what its rotating aligned_buffer holds -- zero gap, then its own history -- where the front-end
             # serves zeros.
-            fm = ref_walk.last_stats.get("first_marker_block") if (trial or short) else None   # (short: a DC symbol read short loses the place)
+            fm = ref_walk.last_stats.get("first_marker_block") if ((trial or short) and os.environ.get("ZJ_LITERAL") in ("off", "0")) else None
             limit = None if fm is None else fm // (hs * vs + 2)   # the first MCU the reference decoded with a marker pending
             behind_marker += fm is not None
             if not walked_equal(got, planes, rows, mcu_x, hs, vs, 3, limit):

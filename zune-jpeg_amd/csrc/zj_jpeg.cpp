@@ -472,6 +472,8 @@ struct zj_decoder {
     int seen_sof = 0, scans = 0;
     bool coef_valid = false; // the planes hold the coefficients of a complete, successful decode_all
     long long hist_retries = 0; // images decoded a second time for it (tests)
+    long long literal_retries = 0; // images whose baseline scan was decoded again by scan_baseline_literal
+    bool literal = false;    // third way of decode_all: the baseline scan through scan_baseline_literal (ZJ_INT_NEED_LITERAL)
     bool track_hist = false; // second pass of decode_all: the Huffman loop keeps the reference reader's bit history (BitReader::rhist)
     uint16_t qt[4][64];
     bool qt_present[4] = {false, false, false, false};
@@ -1103,6 +1105,7 @@ long long interval_data_bytes(const BitReader& br, const uint8_t* eoi)
             const uint8_t* z = q + 1;
             while (z < eoi && *z == 0xFF) z++;
             if (z < eoi && *z == 0x00) { st += (long long)(z - q); q = z; }
+            else if (z < eoi) return 1ll << 40; // another marker (an RSTn) lies in front of `eoi`: that one is met first
         }
     return (long long)(eoi - br.istart) - st;
 }
@@ -1111,6 +1114,7 @@ inline void eoi_cut_after_mcu(EoiCut& cut, const BitReader& br, long long mcu_in
 {
     if (!cut.eoi) return;
     if (!cut.seen) {
+        if (br.marker && br.mpos && br.mpos < cut.eoi) return; // (the reader stands at an earlier marker: an RSTn)
         const uint8_t* at = br.marker ? br.mpos : br.p;
         if (cut.eoi - at > 64) return; // the reader cannot have reached the marker's refill group yet
         const long long c_last = br.consumed() - br.last_sym;
@@ -1223,6 +1227,10 @@ int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p,
     if (br.nbits < 64) br.fill();
     if (must_end ? !(br.marker >= 0xD0 && br.marker <= 0xD7 && br.p == br.end && reference_has_seen_restart_marker(br))
                  : (br.marker != 0 || br.mpos != nullptr)) {
+        *err = "a restart interval that does not end at its marker";
+        return ZJ_ERR_MCU;
+    }
+    if (must_end && br.nbits < br.pad) { // (made-up bits consumed: the interval ran out of data -- the literal decode's case)
         *err = "a restart interval that does not end at its marker";
         return ZJ_ERR_MCU;
     }
@@ -1739,6 +1747,158 @@ void stream_begin(zj_decoder* d)
                                       d->ncomp == 3 ? d->comps[2].coef : nullptr, d->stream.out, 0) == ZJ_OK;
 }
 
+// ---- a baseline scan decoded the reference's way, LITERALLY (round 6) -------------------------------------------------------
+// The walk above models the reference's reader where intact files and the usual damage need it: the early exit at EOI, the
+// short DC reads with the bit history behind them, the restart boundaries.  One thing it does not follow bit by bit: a decode
+// that runs PAST its data behind a marker (an RSTn or EOI in mid-interval, a stream that has lost its place).  The reference's
+// refill then sets bits_left = 63 and serves what its rotating aligned_buffer happens to hold (src/bitstream.rs:254-258,
+// 394-402): the zero gap of the last real refill, then the magnitude bits it has handed out since -- again and again.  The
+// walk serves zeros; so the moment it consumes a bit it made up (BitReader::pad behind a marker) it gives up with
+// ZJ_INT_NEED_LITERAL and the scan is decoded once more by this: the reference's BitStream and MCU loop restated field by
+// field (buffer, aligned_buffer, bits_left, marker; src/bitstream.rs:158-258,264-402; src/mcu.rs:231-351,386-419), slow and
+// exact, as oracle/ref_walk.py restates them in Python for the tests (tools/ref_walk_soak.py compares the two).
+constexpr int ZJ_INT_NEED_LITERAL = 1001; // internal status, never leaves this file
+struct RefStream {
+    const uint8_t* buf; const uint8_t* end; const uint8_t* pos;
+    uint64_t buffer = 0, aligned = 0;
+    int bl = 0, marker = -1, last_len = 0, unknown = 0; // marker -1: none; unknown: a marker byte Marker::from_u8 has no name for
+    uint32_t byte() { const uint32_t v = pos < end ? *pos : 0u; pos++; return v; } // read_u8: zeros past the end (:689-703)
+    void realign() { aligned = bl ? buffer << (64 - bl) : buffer; }                // (x << 64 is x in release builds)
+    bool refill() // false: "Unknown marker" (:199-206)
+    {
+        if (bl <= 32 && marker < 0) {
+            if (pos + 4 < end && pos[0] != 0xFF && pos[1] != 0xFF && pos[2] != 0xFF && pos[3] != 0xFF) { // :220-236
+                buffer = (buffer << 32) | ((uint64_t)pos[0] << 24 | (uint64_t)pos[1] << 16 | (uint64_t)pos[2] << 8 | pos[3]);
+                pos += 4;
+                bl += 32;
+                realign();
+                return true;
+            }
+            for (int i = 0; i < 4; i++) { // the refill! macro, :168-213
+                const uint32_t b = byte();
+                buffer = (buffer << 8) | b;
+                bl += 8;
+                if (b == 0xFF) {
+                    uint32_t n = byte();
+                    if (n != 0) {
+                        while (n == 0xFF) n = byte();
+                        if (n != 0) {
+                            buffer >>= 8;
+                            bl -= 8;
+                            if (bl != 0) realign(); // :193-197
+                            if (!reference_knows_marker((int)n)) { unknown = (int)n; return false; }
+                            marker = (int)n;
+                            return true;
+                        }
+                    }
+                }
+            }
+            realign();
+        } else if (marker >= 0) bl = 63; // :254-258: aligned_buffer stays as it is
+        return true;
+    }
+    uint32_t peek(int n) const { return n ? (uint32_t)(aligned >> (64 - n)) : 0u; }                 // :378-382
+    void drop(int n) { bl = bl > n ? bl - n : 0; aligned = n < 64 ? aligned << n : 0; }              // :386-390
+    uint32_t get(int n)                                                                             // :394-402 (rotates)
+    {
+        if (!n) return 0;
+        aligned = (aligned << n) | (aligned >> (64 - n));
+        bl = bl > n ? bl - n : 0;
+        return (uint32_t)(aligned & ((1ull << n) - 1));
+    }
+    int symbol(const Huff& h) // decode_huff!, :49-86: the first (length, code) of the table found in the top bits
+    {
+        for (int l = 1; l <= 16; l++) {
+            const int32_t c = (int32_t)peek(l);
+            if (h.maxcode[l] >= 0 && c <= h.maxcode[l] && c + h.valoff[l] >= 0) { drop(l); last_len = l; return h.vals[(c + h.valoff[l]) & 0xff]; }
+        }
+        return -1;
+    }
+    void reset() { buffer = aligned = 0; bl = 0; marker = -1; } // :671-678
+};
+
+int scan_baseline_literal(zj_decoder* d, const uint8_t* p0, const uint8_t* end)
+{
+    for (int i = 0; i < d->ncomp; i++) {
+        Comp& cm = d->comps[i];
+        memset(cm.coef, 0, (size_t)cm.bw * cm.bh * 128); // blocks the reference never reaches keep the zeros of its fresh vectors
+    }
+    RefStream s{p0, end, p0};
+    const bool hsub = d->ncomp == 3 && d->h_max == 2;
+    const long long width = hsub && d->v_max == 1 ? 2ll * d->mcu_x : d->mcu_x;     // mcu.rs:145-152
+    const long long height = hsub ? d->mcu_y / 2 : d->mcu_y;
+    const int bias = hsub && d->v_max == 2 ? 2 : 1;
+    const bool full = (d->flags & ZJ_FLAG_FULL_AC_VALUES) != 0;
+    long long todo = d->restart_interval ? d->restart_interval : (1ll << 62);
+    uint32_t pred[4] = {0, 0, 0, 0};
+    char text[48];
+    long long mcu = 0;
+    for (long long row = 0; row < height; row++)
+        for (int pass = 0; pass < bias; pass++) {
+            const long long mcu_pass0 = mcu;
+            for (long long i = 0; i < width; i++) {
+                const int mx = (int)(mcu % d->mcu_x), my = (int)(mcu / d->mcu_x);
+                for (int ci = 0; ci < d->ns; ci++) {
+                    const int c = d->order[ci];
+                    Comp& cm = d->comps[c];
+                    const Huff& hd = d->dc[cm.td & 3];
+                    const Huff& ha = d->ac[cm.ta & 3];
+                    for (int b = 0; b < cm.h * cm.v; b++) {
+                        if (s.bl < 16 && !s.refill()) goto unknown_marker;                 // decode_dc, :264-296
+                        int size = s.symbol(hd);
+                        if (size < 0 || size > 16) return fail(d, ZJ_ERR_HUFFMAN, "Bad Huffman code in DC");
+                        if (size) {
+                            const uint32_t bits = s.get(size);
+                            pred[c] += (uint32_t)extend((int32_t)bits, size);
+                        }
+                        int16_t* blk = block_at(cm, mx * cm.h + b % cm.h, my * cm.v + b / cm.h);
+                        blk[0] = (int16_t)(uint16_t)pred[c];
+                        int pos = 1;
+                        while (pos < 64) {                                                  // :332-372
+                            if (!s.refill()) goto unknown_marker;
+                            const int rs = s.symbol(ha);
+                            if (rs < 0) return fail(d, ZJ_ERR_HUFFMAN, "Bad Huffman code in AC");
+                            const int r = rs >> 4;
+                            size = rs & 15;
+                            if (size) {
+                                pos += r;
+                                bool fast = false;
+                                if (s.last_len + size <= 9) { // the fast-AC table: code + magnitude inside 9 bits, value inside a byte
+                                    const int32_t v = extend((int32_t)s.peek(size), size);
+                                    fast = v >= -128 && v <= 127;
+                                }
+                                uint32_t bits;
+                                if (fast) { bits = s.peek(size); s.drop(size); } // ONE drop_bits for both (:339-347)
+                                else bits = s.get(size);
+                                const int32_t v = extend((int32_t)bits, size);
+                                blk[kUnZigzag[fast ? (pos < 63 ? pos : 63) : (pos & 63)]] = (int16_t)(fast && !full ? sext6(v) : v);
+                                pos += 1;
+                            } else if (s.last_len <= 9) { // size 0 in the fast table too (src/huffman.rs:217-233)
+                                pos += r == 0 ? 63 : r;
+                                blk[kUnZigzag[pos < 63 ? pos : 63]] = 0;
+                                pos += 1;
+                            } else if (r != 15) break;    // the general path (:365-367)
+                            else pos += 16;
+                        }
+                    }
+                }
+                mcu++;
+                if (--todo == 0) { // handle_rst, mcu.rs:386-419
+                    todo = d->restart_interval;
+                    if (s.marker >= 0xD0 && s.marker <= 0xD7) { s.reset(); pred[0] = pred[1] = pred[2] = pred[3] = 0; }
+                    else if (s.marker >= 0 && s.marker != 0xD9) return fail(d, ZJ_ERR_MCU, "Marker found in bitstream, possibly corrupt jpeg");
+                }
+                if (s.marker == 0xD9) break; // mcu.rs:337-343
+            }
+            mcu = mcu_pass0 + width; // the MCUs a cut pass never decoded keep their zeros; the next pass starts behind them
+        }
+    for (int i = 0; i < d->ncomp; i++) d->comps[i].dc_pred = (int32_t)pred[i];
+    return ZJ_OK;
+unknown_marker:
+    snprintf(text, sizeof text, "Unknown marker 0xFF%X", s.unknown);
+    return fail(d, ZJ_ERR_FORMAT, text);
+}
+
 int scan_baseline(zj_decoder* d, BitReader& br)
 {
     for (int i = 0; i < d->ncomp; i++) {
@@ -1818,6 +1978,7 @@ int scan_baseline(zj_decoder* d, BitReader& br)
     // The walk below still fills that row's coefficients, but whatever is wrong with its data is nobody's business: the
     // reference never reads it (found by tools/ref_walk_soak.py in round 6: a damaged last row made this an error).
     const long long walked_total = (d->ncomp == 3 && d->h_max == 2) ? (long long)d->mcu_x * (d->mcu_y & ~1) : total;
+    static const bool literal_allowed = [] { const char* e = getenv("ZJ_LITERAL"); return !(e && (!strcmp(e, "off") || !strcmp(e, "0"))); }();
     for (long long m = m_first; m < total;) {
         if (fn.mcus && !d->track_hist && !cut.seen) {
             // as many MCUs as possible in one go (decode_mcus_v2): up to the next restart boundary, short of the scan's last 4 KB.
@@ -1827,11 +1988,14 @@ int scan_baseline(zj_decoder* d, BitReader& br)
             const char* err = nullptr;
             long long n = total - m < todo ? total - m : (long long)todo;
             if (d->stream.active && n > 4ll * d->mcu_x) n = 4ll * d->mcu_x; // come back every few rows: the GPU takes what is final
+            if (m < walked_total && n > walked_total - m) n = walked_total - m;  // (the row the reference never reads: on its own)
             const int rc = fn.mcus(d, d, br, pred, m, n, stop, &done, &err);
             for (int i = 0; i < 3; i++) d->comps[i].dc_pred = pred[i];
             m += done;
             if (rc) { clear_from((int)(m / d->mcu_x), (int)(m % d->mcu_x)); if (m >= walked_total) break; return fail(d, rc, err); }
             if (done) {
+                // bits this reader made up behind a marker have been consumed: the reference serves its rotating buffer there
+                if (br.marker && br.nbits < br.pad && m <= walked_total && literal_allowed) return ZJ_INT_NEED_LITERAL;
                 todo -= (int)done;
                 if (todo == 0) {
                     const int rc2 = handle_restart(d, br, todo);
@@ -1855,6 +2019,7 @@ int scan_baseline(zj_decoder* d, BitReader& br)
                     if (rc) { clear_from(my, mx); if (m >= walked_total) goto walk_done; return fail(d, rc, err); }
                 }
         }
+        if (br.marker && br.nbits < br.pad && m < walked_total && literal_allowed) return ZJ_INT_NEED_LITERAL;
         bool restarted = false;
         if (--todo == 0) {
             restarted = br.marker >= 0xD0 && br.marker <= 0xD7;
@@ -2321,6 +2486,13 @@ int decode_all(zj_decoder* d, const uint8_t* buf, size_t len, bool headers_only,
         rc = decode_all_once(d, buf, len, headers_only, false);
         d->track_hist = false;
     }
+    if (rc == ZJ_INT_NEED_LITERAL) { // the walk consumed bits it made up behind a marker: the scan again, the reference's way
+        if (d->stream.active) { (void)zj_frame_abort(d->stream.ctx); d->stream.active = false; }
+        d->literal = true;
+        d->literal_retries++;
+        rc = decode_all_once(d, buf, len, headers_only, false);
+        d->literal = false;
+    }
     return rc;
 }
 
@@ -2342,6 +2514,14 @@ int decode_all_once(zj_decoder* d, const uint8_t* buf, size_t len, bool headers_
             return ZJ_OK;
         }
         if ((rc = ensure_planes(d))) return rc;
+        if (d->literal) {
+            if (d->ns != d->ncomp) return fail(d, ZJ_ERR_UNSUPPORTED, "baseline scans must carry every component (src/mcu.rs:253-321)");
+            rc = scan_baseline_literal(d, br.p, br.end);
+            d->scans = 1;
+            d->coef_valid = rc == ZJ_OK;
+            d->par_scan_mcus = 0; d->dri_parallel_segments = 0;
+            return rc;
+        }
         stream_begin(d);
         rc = scan_baseline(d, br);
         d->scans = 1;
