@@ -1230,7 +1230,8 @@ int scan_baseline_segment(const zj_decoder* d, zj_decoder* dm, const uint8_t* p,
         *err = "a restart interval that does not end at its marker";
         return ZJ_ERR_MCU;
     }
-    if (must_end && br.nbits < br.pad) { // (made-up bits consumed: the interval ran out of data -- the literal decode's case)
+    if (br.nbits < br.pad) { // (made-up bits consumed: the interval ran out of data -- the literal decode's case; the last segment too,
+                             // whose reader stops in front of the scan's closing marker and pads from there)
         *err = "a restart interval that does not end at its marker";
         return ZJ_ERR_MCU;
     }
